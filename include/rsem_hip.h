@@ -1,0 +1,135 @@
+/* rsem_hip.h -- C ABI of librsem_hip.so: RSEM's EM / Gibbs hot path on MI355X (gfx950).
+ *
+ * The reference (deweylab/RSEM) has no FFI: its hot path is reached through two executables,
+ * rsem-run-em (EM.cpp) and rsem-run-gibbs (Gibbs.cpp), whose in-process seams are the pthread
+ * entry points  E_STEP<>(Params{model,reader,hitv,ncpv,mhp,countv})  (EM.cpp:57-60,176-247) and
+ * Gibbs(Params{no,nsamples,fo,engine,pme_c,...})  (Gibbs.cpp:29-37,265-353): a CSR shard in,
+ * per-shard count vector / per-chain accumulators out.  Each entry point below replaces one of
+ * those seams (cited per function).  Conventions:
+ *   - plain C types; host pointers are caller-owned and only read/written during the call;
+ *   - an opaque ctx owns all device memory of one GPU; calls on one ctx are serialised by the caller;
+ *   - every function returns RSEM_OK (0) or a negative rsem_status; rsem_hip_strerror() explains,
+ *     rsem_hip_last_error() gives the HIP detail of the calling thread's last failure;
+ *   - no exceptions, no exit() across the boundary (the reference exits on error, my_assert.h:89-96;
+ *     the CLI wrappers in rsem_amd/csrc/host keep that behaviour on top of these codes);
+ *   - there is NO CPU fallback: without a usable gfx950 device every *_create fails with
+ *     RSEM_ERR_NODEVICE.
+ */
+#ifndef RSEM_HIP_H_
+#define RSEM_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RSEM_OK = 0,
+    RSEM_ERR_INVALID = -1,  /* bad argument (NULL, sid out of range, non-monotone row_ptr, ...) */
+    RSEM_ERR_HIP = -2,      /* a HIP runtime call failed; see rsem_hip_last_error() */
+    RSEM_ERR_NOMEM = -3,    /* device or host allocation failed */
+    RSEM_ERR_NODEVICE = -4, /* no such GPU / not a gfx950-class device */
+    RSEM_ERR_STATE = -5     /* call sequence error (e.g. values never set) */
+} rsem_status;
+
+const char* rsem_hip_strerror(int status);
+const char* rsem_hip_last_error(void);
+int rsem_hip_device_count(int* n);
+/* ABI version of this header: bumped on any signature change. */
+int rsem_hip_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * EM (rsem-run-em).  Replaces: HitContainer<HitType> (HitContainer.h:12-59, SingleHit.h:8-51),
+ * init<> sharding (EM.cpp:97-174), E_STEP<> (EM.cpp:176-247) and the count reduction / M step /
+ * convergence test of EM<> (EM.cpp:383-416).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rsem_em_ctx rsem_em_ctx;
+
+/* E-step kernel variants (rsem_em_set_option "kernel") */
+#define RSEM_EM_KERNEL_AUTO 0
+#define RSEM_EM_KERNEL_CSR 1   /* thread-per-read over the CSR as given (baseline / long rows / K5) */
+#define RSEM_EM_KERNEL_SELL 2  /* length-bucketed, class-sorted sliced layout, wave segmented reductions */
+#define RSEM_EM_KERNEL_SELLRUN 3 /* SELL + register accumulation across runs of identical rows */
+
+/* Upload one shard: N1 reads, nnz alignments.  row_ptr[N1+1] (row_ptr[0]==0, row_ptr[N1]==nnz),
+ * sid[nnz] in 1..M (strand already stripped: HitType::getSid, SingleHit.h:26),
+ * conprb[nnz] / ncp[N1] may be NULL when they will be supplied by rsem_em_set_values or computed
+ * on the device by the rsem_model_* entry points.  (HitContainer::read, HitContainer.h:63-79.) */
+int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64_t nnz,
+                   const uint64_t* row_ptr, const int32_t* sid, const double* conprb,
+                   const double* ncp);
+/* Replace the CSR values (hit.setConPrb / ncpv[i], EM.cpp:210,216) in the caller's (file) order. */
+int rsem_em_set_values(rsem_em_ctx* ctx, const double* conprb, const double* ncp);
+int rsem_em_set_option(rsem_em_ctx* ctx, const char* key, int64_t value);
+int rsem_em_destroy(rsem_em_ctx* ctx);
+
+/* One E step + M step.  theta[M+1] in; counts[M+1] out = fractional counts incl. +N0 in bin 0
+ * (EM.cpp:385-392), theta_new = counts / sum (EM.cpp:394-398), sum, and the convergence
+ * statistics bChange / totNum (EM.cpp:406-413).  Any output pointer may be NULL. */
+int rsem_em_step(rsem_em_ctx* ctx, const double* theta, double N0, double* counts,
+                 double* theta_new, double* sum, double* bChange, int32_t* totNum);
+
+/* Per-run measurements filled by rsem_em_run when non-NULL (HIP events on the ctx stream). */
+typedef struct {
+    double total_ms;        /* first E-step launch .. last M-step kernel of the run */
+    double estep_ms_sum;    /* sum of per-launch E-step kernel durations */
+    int32_t estep_launches; /* number of E-step launches timed */
+    int32_t rounds;         /* rounds executed */
+    uint64_t algorithmic_bytes_per_round; /* 12*nnz + 16*N1 + 16*(M+1), SURVEY.md section 8(d) */
+} rsem_em_profile;
+
+/* Device-resident EM loop for the rounds where the CSR values are frozen (ROUND >= 12 in the
+ * reference, EM.cpp:365-416 with needCalcConPrb == updateModel == false): rounds round0+1, ... until
+ * (ROUND >= min_round && totNum == 0) || ROUND == max_round.  theta_inout[M+1]; counts[M+1] (last
+ * round's counts, may be NULL); rounds_done = last ROUND; bChange/totNum of that round. */
+int rsem_em_run(rsem_em_ctx* ctx, double* theta_inout, double N0, int round0, int min_round,
+                int max_round, int* rounds_done, double* counts, double* bChange, int32_t* totNum,
+                rsem_em_profile* profile);
+
+/* Final pass with calcExpectedWeights = true (EM.cpp:460-478): counts incl. +N0, posterior weight
+ * of every alignment w[nnz] (file order) and of the noise transcript w_noise[N1]; rows whose
+ * normaliser is < 1e-300 get zeros (EM.cpp:237-243). */
+int rsem_em_expected_weights(rsem_em_ctx* ctx, const double* theta, double N0, double* counts,
+                             double* w, double* w_noise);
+
+/* Multi-GPU EM: rows sharded over ranks, theta replicated, one all-reduce of the
+ * counts per round issued by the caller between the two halves below.  d_counts / d_theta are
+ * device buffers of M+1 doubles owned by the CALLER (e.g. torch tensors) and stream is the HIP
+ * stream the caller's collective is ordered on. */
+int rsem_em_estep_device(rsem_em_ctx* ctx, const void* d_theta, void* d_counts, void* stream);
+int rsem_em_mstep_device(rsem_em_ctx* ctx, void* d_counts, double N0_global, const void* d_theta_old,
+                         void* d_theta_new, void* d_stats /* 3 doubles: sum,bChange,totNum */,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gibbs (rsem-run-gibbs).  Replaces: Item / s / hits (Gibbs.cpp:39-47,63-64), Gibbs()
+ * (Gibbs.cpp:265-353) incl. sample() (sampling.h:50-65), and the per-chain accumulators that
+ * release() sums (Gibbs.cpp:355-388).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rsem_gibbs_ctx rsem_gibbs_ctx;
+
+#define RSEM_GIBBS_EXACT 0    /* the reference's sequential collapsed chain, MT19937, bit-identical draws */
+#define RSEM_GIBBS_PARALLEL 1 /* data-augmentation sampler (theta | z, then z | theta in parallel), Philox */
+
+/* items CSR incl. the noise column (sid 0), as in .ofg (EM.cpp:435-457).  init_counts[M+1] is 0 or
+ * -1 (omitted transcripts, Gibbs.cpp:152-167); alpha[M+1] or NULL (scalar pseudoC); eel/mw[M+1];
+ * grp[m+1] gene start indices (GroupInfo.h:34-53). */
+int rsem_gibbs_create(rsem_gibbs_ctx** out, int device, int32_t M, uint64_t N1, uint64_t nitems,
+                      const uint64_t* row_ptr, const int32_t* sid, const double* conprb,
+                      const int32_t* init_counts, const double* alpha, double pseudoC, double totc,
+                      uint64_t N0, const double* eel, const double* mw, int32_t m, const int32_t* grp);
+/* Run one chain.  count_vectors: nsamples x (M+1) int32 or NULL.  The five accumulators receive
+ * this chain's SUMS (not divided; Gibbs.cpp:322-345), overwriting their previous contents. */
+int rsem_gibbs_run(rsem_gibbs_ctx* ctx, int mode, uint32_t seed, int burnin, int nsamples, int gap,
+                   int thin /* PARALLEL only: internal sweeps per counted round, >=1 */,
+                   int32_t* count_vectors, double* pme_c, double* pve_c, double* pme_tpm,
+                   double* pme_fpkm, double* pve_c_genes, double* sweep_ms /* may be NULL */);
+int rsem_gibbs_destroy(rsem_gibbs_ctx* ctx);
+/* sampling.h:19-44: seeds of the first nchains chains for --seed seed. */
+int rsem_gibbs_chain_seeds(uint32_t seed, int nchains, uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSEM_HIP_H_ */

@@ -1,0 +1,191 @@
+"""ctypes binding of librsem_hip.so (include/rsem_hip.h).  No fallbacks: a missing library raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librsem_hip.so")
+
+KERNEL_AUTO, KERNEL_CSR, KERNEL_SELL, KERNEL_SELLRUN = 0, 1, 2, 3
+GIBBS_EXACT, GIBBS_PARALLEL = 0, 1
+
+_u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+
+
+class RsemHipError(RuntimeError):
+    def __init__(self, status, detail):
+        super().__init__("librsem_hip: status %d (%s): %s" % (status, _strerror(status), detail))
+        self.status = status
+
+
+class EmProfile(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("estep_ms_sum", C.c_double), ("estep_launches", C.c_int32),
+                ("rounds", C.c_int32), ("algorithmic_bytes_per_round", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `python -m rsem_amd.build` (hipcc, gfx950). "
+                              "There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        vp, i32, u64, dbl, ci = C.c_void_p, C.c_int32, C.c_uint64, C.c_double, C.c_int
+        L.rsem_hip_strerror.restype = C.c_char_p
+        L.rsem_hip_strerror.argtypes = [ci]
+        L.rsem_hip_last_error.restype = C.c_char_p
+        L.rsem_hip_device_count.argtypes = [C.POINTER(ci)]
+        L.rsem_hip_abi_version.restype = ci
+        L.rsem_em_create.argtypes = [C.POINTER(vp), ci, i32, u64, u64, _u64p, vp, vp, vp]
+        L.rsem_em_set_values.argtypes = [vp, _f64p, _f64p]
+        L.rsem_em_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+        L.rsem_em_destroy.argtypes = [vp]
+        L.rsem_em_step.argtypes = [vp, _f64p, dbl, vp, vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(i32)]
+        L.rsem_em_run.argtypes = [vp, _f64p, dbl, ci, ci, ci, C.POINTER(ci), vp, C.POINTER(dbl), C.POINTER(i32), vp]
+        L.rsem_em_expected_weights.argtypes = [vp, _f64p, dbl, vp, vp, vp]
+        L.rsem_em_estep_device.argtypes = [vp, vp, vp, vp]
+        L.rsem_em_mstep_device.argtypes = [vp, vp, dbl, vp, vp, vp, vp]
+        L.rsem_gibbs_create.argtypes = [C.POINTER(vp), ci, i32, u64, u64, _u64p, _i32p, _f64p, _i32p, vp, dbl, dbl, u64,
+                                        _f64p, _f64p, i32, _i32p]
+        L.rsem_gibbs_run.argtypes = [vp, ci, C.c_uint32, ci, ci, ci, ci, vp, _f64p, _f64p, _f64p, _f64p, _f64p, vp]
+        L.rsem_gibbs_destroy.argtypes = [vp]
+        L.rsem_gibbs_chain_seeds.argtypes = [C.c_uint32, ci, _u32p]
+        _lib = L
+    return _lib
+
+
+def _strerror(status):
+    return lib().rsem_hip_strerror(status).decode()
+
+
+def _check(status):
+    if status != 0:
+        raise RsemHipError(status, lib().rsem_hip_last_error().decode())
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().rsem_hip_device_count(C.byref(n)))
+    return n.value
+
+
+class EmContext:
+    """One GPU's EM shard (rsem_em_ctx).  Mirrors E_STEP<> / EM<> of EM.cpp for frozen CSR values."""
+
+    def __init__(self, M, row_ptr, sid, conprb=None, ncp=None, device=0):
+        self.M = int(M)
+        self.N1 = len(row_ptr) - 1
+        self.nnz = len(sid)
+        row_ptr = np.ascontiguousarray(row_ptr, np.uint64)
+        sid = np.ascontiguousarray(sid, np.int32)
+        if conprb is not None:
+            conprb = np.ascontiguousarray(conprb, np.float64)
+            ncp = np.ascontiguousarray(ncp, np.float64)
+        self._h = C.c_void_p()
+        _check(lib().rsem_em_create(C.byref(self._h), device, self.M, self.N1, self.nnz, row_ptr, _ptr(sid), _ptr(conprb),
+                                    _ptr(ncp)))
+
+    def close(self):
+        if self._h:
+            lib().rsem_em_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_values(self, conprb, ncp):
+        _check(lib().rsem_em_set_values(self._h, np.ascontiguousarray(conprb, np.float64),
+                                        np.ascontiguousarray(ncp, np.float64)))
+
+    def set_option(self, key, value):
+        _check(lib().rsem_em_set_option(self._h, key.encode(), int(value)))
+
+    def step(self, theta, N0):
+        theta = np.ascontiguousarray(theta, np.float64)
+        counts, theta_new = np.zeros(self.M + 1), np.zeros(self.M + 1)
+        s, b, t = C.c_double(), C.c_double(), C.c_int32()
+        _check(lib().rsem_em_step(self._h, theta, float(N0), _ptr(counts), _ptr(theta_new), C.byref(s), C.byref(b),
+                                  C.byref(t)))
+        return counts, theta_new, s.value, b.value, t.value
+
+    def run(self, theta, N0, round0=0, min_round=20, max_round=10000, profile=False):
+        theta = np.array(theta, np.float64)
+        counts = np.zeros(self.M + 1)
+        r, b, t = C.c_int(), C.c_double(), C.c_int32()
+        prof = EmProfile() if profile else None
+        _check(lib().rsem_em_run(self._h, theta, float(N0), round0, min_round, max_round, C.byref(r), _ptr(counts),
+                                 C.byref(b), C.byref(t), C.cast(C.pointer(prof), C.c_void_p) if profile else None))
+        out = dict(theta=theta, rounds=r.value, counts=counts, bChange=b.value, totNum=t.value)
+        if profile:
+            out["profile"] = prof
+        return out
+
+    def expected_weights(self, theta, N0, want_weights=True):
+        theta = np.ascontiguousarray(theta, np.float64)
+        counts = np.zeros(self.M + 1)
+        w = np.zeros(self.nnz) if want_weights else None
+        wn = np.zeros(self.N1) if want_weights else None
+        _check(lib().rsem_em_expected_weights(self._h, theta, float(N0), _ptr(counts), _ptr(w), _ptr(wn)))
+        return counts, w, wn
+
+    # multi-GPU halves: raw device pointers + stream (ints)
+    def estep_device(self, d_theta, d_counts, stream):
+        _check(lib().rsem_em_estep_device(self._h, d_theta, d_counts, stream))
+
+    def mstep_device(self, d_counts, N0_global, d_theta_old, d_theta_new, d_stats, stream):
+        _check(lib().rsem_em_mstep_device(self._h, d_counts, float(N0_global), d_theta_old, d_theta_new, d_stats, stream))
+
+
+class GibbsContext:
+    """One GPU's Gibbs sampler state (rsem_gibbs_ctx).  Mirrors Gibbs() of Gibbs.cpp."""
+
+    def __init__(self, M, row_ptr, sid, conprb, init_counts, alpha, pseudoC, totc, N0, eel, mw, grp, device=0):
+        self.M = int(M)
+        self.m = len(grp) - 1
+        self._h = C.c_void_p()
+        alpha = None if alpha is None else np.ascontiguousarray(alpha, np.float64)
+        _check(lib().rsem_gibbs_create(C.byref(self._h), device, self.M, len(row_ptr) - 1, len(sid),
+                                       np.ascontiguousarray(row_ptr, np.uint64), np.ascontiguousarray(sid, np.int32),
+                                       np.ascontiguousarray(conprb, np.float64),
+                                       np.ascontiguousarray(init_counts, np.int32), _ptr(alpha), float(pseudoC),
+                                       float(totc), int(N0), np.ascontiguousarray(eel, np.float64),
+                                       np.ascontiguousarray(mw, np.float64), self.m, np.ascontiguousarray(grp, np.int32)))
+
+    def close(self):
+        if self._h:
+            lib().rsem_gibbs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, mode, seed, burnin, nsamples, gap, thin=1, want_vectors=True):
+        cv = np.zeros((nsamples, self.M + 1), np.int32) if want_vectors else None
+        acc = [np.zeros(self.M + 1) for _ in range(4)] + [np.zeros(self.m)]
+        ms = C.c_double()
+        _check(lib().rsem_gibbs_run(self._h, mode, int(seed), burnin, nsamples, gap, thin, _ptr(cv), *acc,
+                                    C.cast(C.pointer(ms), C.c_void_p)))
+        return cv, acc, ms.value
+
+
+def gibbs_chain_seeds(seed, n):
+    out = np.zeros(n, np.uint32)
+    _check(lib().rsem_gibbs_chain_seeds(int(seed), n, out))
+    return out

@@ -1,0 +1,778 @@
+// em.hip -- rsem-run-em's E step / M step on MI355X (gfx950).  C ABI: include/rsem_hip.h.
+//
+// What the reference does per round (EM.cpp:199-236, 385-413): for every read i, f_j =
+// theta[sid_j] * conprb_j over its alignments (plus the noise term theta[0] * ncp_i), each clamped
+// to 0 below 1e-300; if the row sum is >= 1e-300 the normalised fractions are added to
+// counts[sid_j]; then theta = counts / sum(counts) and two convergence statistics.
+//
+// Device design (this file is the product; the CPU restatement lives in oracle/ and is never
+// linked here):
+//   * the CSR is uploaded once, then re-laid-out ON THE DEVICE into a "sliced" layout: reads are
+//     radix-sorted by (shape, min sid, hash of the sid tuple) so that reads hitting the same
+//     transcript set become neighbours, and are packed 64/G to a 64-lane slice with G = 1..64 lanes
+//     per read and K <= 8 planes of 64 entries; lane l of plane k holds alignment k*G + (l % G) of
+//     read l / G.  Every global load of the hot loop is therefore a fully coalesced 256 B (sid) or
+//     512 B (conprb) wave access, whatever the row length (1..512 alignments per read).
+//   * per-read normaliser: xor-shuffle reduction over the G lanes of a read;
+//   * per-transcript counts: wave-level *segmented* shuffle reduction keyed by sid along the
+//     lanes (neighbouring reads share sids after the sort), only run tails issue an fp64 atomic;
+//     with RSEM_EM_KERNEL_SELLRUN, runs of consecutive slices whose reads all have the identical
+//     sid tuple keep their partial counts in registers across slices, skip the sid planes
+//     entirely (8 B/alignment of HBM traffic instead of 12) and flush once per run;
+//   * the noise bin (touched by every read) never sees an atomic: per-lane register, block
+//     reduction, one partial per workgroup summed deterministically by the M-step kernel;
+//   * M step + convergence statistics run on the device; a `done` word set by the last
+//     workgroup of the M step freezes theta at exactly the reference's stopping round while the
+//     host only polls it every few rounds (no per-round host sync).
+// MFMA is not used: ~2 flops per 12 bytes, the bound is HBM bandwidth.
+#include <climits>
+#include <cmath>
+
+#include "sell_layout.hpp"
+
+namespace {
+
+using rsem::kEpsilon;
+
+constexpr int kReduceBlocks = 64;   // partial sums of the M step
+constexpr int kMaxTimedRounds = 4096;
+
+struct Ctrl {  // device-resident loop control, one per ctx
+    int done;
+    int final_round;
+    int totNum;               // accumulating
+    unsigned int ticket;
+    unsigned long long bbits; // accumulating max |dtheta|/theta as ordered bits
+    double last_sum;
+    double last_bchange;
+    int last_totNum;
+    int last_round;
+};
+
+
+// ---- E step ----------------------------------------------------------------------------------
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__device__ inline void block_store_partial(double v, double* out) {
+    __shared__ double red[kBlock / 64];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < kBlock / 64; i++) t += red[i];
+        out[blockIdx.x] = t;
+    }
+}
+
+// Thread-per-read over the caller's CSR (EM.cpp:199-244 literally).  Used as the baseline
+// variant, for reads with > 512 alignments, and for the final expected-weights pass.
+template <bool kWriteW>
+__global__ __launch_bounds__(kBlock) void k_estep_csr(
+    uint64_t n_rows, const uint32_t* __restrict__ row_list, const uint64_t* __restrict__ row_ptr,
+    const int32_t* __restrict__ sid, const double* __restrict__ cp, const double* __restrict__ ncp,
+    const double* __restrict__ theta, double* counts, double* noise_partial, double* w,
+    double* w_noise, const Ctrl* ctrl) {
+    if (ctrl && ctrl->done) return;
+    double noise = 0.0;
+    const double th0 = theta[0];
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_rows;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t i = row_list ? row_list[t] : t;
+        uint64_t fr = row_ptr[i], to = row_ptr[i + 1];
+        double f0 = th0 * ncp[i];
+        if (f0 < kEpsilon) f0 = 0.0;
+        double sum = f0;
+        for (uint64_t j = fr; j < to; j++) {
+            double f = theta[sid[j]] * cp[j];
+            if (f < kEpsilon) f = 0.0;
+            sum += f;
+        }
+        if (sum >= kEpsilon) {
+            noise += f0 / sum;
+            if (kWriteW) w_noise[i] = f0 / sum;
+            for (uint64_t j = fr; j < to; j++) {
+                int s = sid[j];
+                double f = theta[s] * cp[j];
+                if (f < kEpsilon) f = 0.0;
+                f /= sum;
+                if (f != 0.0) unsafeAtomicAdd(&counts[s], f);
+                if (kWriteW) w[j] = f;
+            }
+        } else if (kWriteW) {
+            w_noise[i] = 0.0;
+            for (uint64_t j = fr; j < to; j++) w[j] = 0.0;
+        }
+    }
+    block_store_partial(noise, noise_partial);
+}
+
+// segmented sum of v over lanes {g, g+G, g+2G, ...} keyed by `key`; returns true on the tail lane
+// of each run, whose v then holds the run total.
+__device__ inline bool seg_reduce(int key, double& v, int lane, int lg) {
+    const int G = 1 << lg;
+    int kprev = __shfl_up(key, G);
+    int knext = __shfl_down(key, G);
+    int flag = (lane < G) || (kprev != key);
+    for (int d = G; d < 64; d <<= 1) {
+        double ov = __shfl_up(v, d);
+        int of = __shfl_up(flag, d);
+        if (lane >= d && !flag) { v += ov; flag = of; }
+    }
+    return (lane + G >= 64) || (knext != key);
+}
+
+// sum over lanes with equal (lane % G); result valid on lanes < G
+__device__ inline double strided_sum(double v, int lg) {
+    for (int d = 32; d >= (1 << lg); d >>= 1) v += __shfl_down(v, d);
+    return v;
+}
+
+template <bool kRuns>
+__global__ __launch_bounds__(kBlock) void k_estep_sell(
+    const Shape* __restrict__ shapes, int n_shapes, uint32_t n_slices, uint32_t chunk,
+    const double* __restrict__ theta, const double* __restrict__ scp, const int32_t* __restrict__ ssid,
+    const double* __restrict__ sncp, const uint8_t* __restrict__ flags, double* counts,
+    double* noise_partial, const Ctrl* ctrl) {
+    if (ctrl->done) return;
+    __shared__ Shape sh_shapes[kMaxShapes];
+    for (int i = threadIdx.x; i < n_shapes; i += blockDim.x) sh_shapes[i] = shapes[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (kBlock / 64);
+    const uint32_t n_chunks = (n_slices + chunk - 1) / chunk;
+    const double th0 = theta[0];
+    double noise = 0.0;
+
+    for (uint32_t ch = wave; ch < n_chunks; ch += n_waves) {
+        uint32_t s_begin = ch * chunk;
+        uint32_t s_end = min(n_slices, s_begin + chunk);
+        int sh = 0;
+        while (sh + 1 < n_shapes && s_begin >= sh_shapes[sh + 1].slice_base) ++sh;
+
+        // run state (kRuns): per-lane partial counts for the lane's fixed (plane, column) sids
+        double acc[kMaxK];
+        int rsid[kMaxK];
+        bool in_run = false;
+        int run_lg = 0, run_K = 0;
+#pragma unroll
+        for (int k = 0; k < kMaxK; k++) { acc[k] = 0.0; rsid[k] = 0; }
+
+        for (uint32_t s = s_begin; s < s_end; s++) {
+            while (sh + 1 < n_shapes && s >= sh_shapes[sh + 1].slice_base) ++sh;
+            const int K = sh_shapes[sh].K, lg = sh_shapes[sh].lg;
+            const uint32_t sl = s - sh_shapes[sh].slice_base;
+            const uint64_t pl0 = (sh_shapes[sh].plane_base + (uint64_t)sl * K) * 64 + lane;
+            const int g = lane & ((1 << lg) - 1);
+            const uint32_t rloc = sl * (64u >> lg) + (lane >> lg);
+            const bool row_ok = rloc < sh_shapes[sh].n_rows;
+
+            uint8_t fl = kRuns ? flags[s] : (uint8_t)2;
+            const bool uniform = fl & 1;
+            const bool starts = fl & 2;
+
+            if (kRuns && in_run && (starts || !uniform)) {
+                // flush the finished run: one atomic per distinct (plane, column)
+#pragma unroll
+                for (int k = 0; k < kMaxK; k++)
+                    if (k < run_K) {
+                        double t = strided_sum(acc[k], run_lg);
+                        if (lane < (1 << run_lg) && rsid[k] != 0 && t != 0.0) unsafeAtomicAdd(&counts[rsid[k]], t);
+                        acc[k] = 0.0;
+                    }
+                in_run = false;
+            }
+
+            double c[kMaxK];
+            int id[kMaxK];
+            const bool load_ids = !(kRuns && uniform && in_run);
+#pragma unroll
+            for (int k = 0; k < kMaxK; k++)
+                if (k < K) {
+                    c[k] = scp[pl0 + (uint64_t)k * 64];
+                    id[k] = load_ids ? ssid[pl0 + (uint64_t)k * 64] : rsid[k];
+                }
+            double f0 = 0.0;
+            if (g == 0 && row_ok) {
+                f0 = th0 * sncp[sh_shapes[sh].row_base + rloc];
+                if (f0 < kEpsilon) f0 = 0.0;
+            }
+            double f[kMaxK];
+            double part = f0;
+#pragma unroll
+            for (int k = 0; k < kMaxK; k++)
+                if (k < K) {
+                    double v = theta[id[k]] * c[k];
+                    if (v < kEpsilon) v = 0.0;
+                    f[k] = v;
+                    part += v;
+                }
+            for (int d = 1; d < (1 << lg); d <<= 1) part += __shfl_xor(part, d);
+            const double inv = (part >= kEpsilon) ? 1.0 / part : 0.0;
+            noise += f0 * inv;
+
+            if (kRuns && uniform) {
+                if (!in_run) {
+                    in_run = true;
+                    run_lg = lg;
+                    run_K = K;
+#pragma unroll
+                    for (int k = 0; k < kMaxK; k++)
+                        if (k < K) rsid[k] = id[k];
+                }
+#pragma unroll
+                for (int k = 0; k < kMaxK; k++)
+                    if (k < K) acc[k] += f[k] * inv;
+            } else {
+#pragma unroll
+                for (int k = 0; k < kMaxK; k++)
+                    if (k < K) {
+                        double v = f[k] * inv;
+                        bool tail = seg_reduce(id[k], v, lane, lg);
+                        if (tail && id[k] != 0 && v != 0.0) unsafeAtomicAdd(&counts[id[k]], v);
+                    }
+            }
+        }
+        if (kRuns && in_run) {
+#pragma unroll
+            for (int k = 0; k < kMaxK; k++)
+                if (k < run_K) {
+                    double t = strided_sum(acc[k], run_lg);
+                    if (lane < (1 << run_lg) && rsid[k] != 0 && t != 0.0) unsafeAtomicAdd(&counts[rsid[k]], t);
+                }
+        }
+    }
+    block_store_partial(noise, noise_partial);
+}
+
+// ---- M step ----------------------------------------------------------------------------------
+
+__device__ inline double block_sum_det(double v) {  // deterministic: fixed tree
+    __shared__ double red[kBlock / 64];
+    __syncthreads();
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < kBlock / 64; i++) t += red[i];
+    return t;
+}
+
+// counts[0] += sum(noise partials) + N0 (EM.cpp:392), then per-block partial sums of counts
+__global__ __launch_bounds__(kBlock) void k_mstep_reduce(int32_t M, double N0, double* counts,
+                                                          const double* __restrict__ noise_a, int n_a,
+                                                          const double* __restrict__ noise_b, int n_b,
+                                                          double* partials, const Ctrl* ctrl) {
+    if (ctrl && ctrl->done) return;
+    const int n = M + 1;
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    if (blockIdx.x == 0) {
+        double v = 0.0;
+        for (int i = threadIdx.x; i < n_a; i += blockDim.x) v += noise_a[i];
+        for (int i = threadIdx.x; i < n_b; i += blockDim.x) v += noise_b[i];
+        double t = block_sum_det(v);
+        if (threadIdx.x == 0) counts[0] = counts[0] + t + N0;
+        __syncthreads();
+    }
+    double v = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) v += counts[i];
+    double t = block_sum_det(v);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// theta = counts / sum (EM.cpp:394-398); convergence statistics (EM.cpp:406-413); stop rule
+// (EM.cpp:416) evaluated by the last workgroup to finish.
+__global__ __launch_bounds__(kBlock) void k_mstep_apply(int32_t M, const double* __restrict__ partials,
+                                                         int n_partials, double* counts,
+                                                         const double* __restrict__ theta_old,
+                                                         double* theta_new, double* counts_last, Ctrl* ctrl,
+                                                         int round, int min_round, int max_round) {
+    if (ctrl->done) return;
+    double sum = 0.0;
+    for (int i = 0; i < n_partials; i++) sum += partials[i];
+    int tot = 0;
+    double bmax = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= M; i += gridDim.x * blockDim.x) {
+        double c = counts[i];
+        double th = c / sum;
+        theta_new[i] = th;
+        counts_last[i] = c;
+        counts[i] = 0.0;
+        double old = theta_old[i];
+        if (old >= 1e-7) {
+            double change = fabs(th - old) / old;
+            if (change >= 0.001) ++tot;
+            bmax = fmax(bmax, change);
+        }
+    }
+    // block reduce
+    __shared__ int s_tot[kBlock / 64];
+    __shared__ double s_b[kBlock / 64];
+    for (int d = 32; d >= 1; d >>= 1) {
+        tot += __shfl_xor(tot, d);
+        bmax = fmax(bmax, __shfl_xor(bmax, d));
+    }
+    if ((threadIdx.x & 63) == 0) { s_tot[threadIdx.x >> 6] = tot; s_b[threadIdx.x >> 6] = bmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kBlock / 64; i++) { tot += s_tot[i]; bmax = fmax(bmax, s_b[i]); }
+        if (tot) atomicAdd(&ctrl->totNum, tot);
+        atomicMax(&ctrl->bbits, (unsigned long long)__double_as_longlong(bmax));
+        __threadfence();
+        unsigned int t = atomicAdd(&ctrl->ticket, 1u);
+        if (t == gridDim.x - 1) {
+            int totNum = atomicAdd(&ctrl->totNum, 0);
+            unsigned long long bb = atomicMax(&ctrl->bbits, 0ull);
+            ctrl->last_sum = sum;
+            ctrl->last_bchange = __longlong_as_double((long long)bb);
+            ctrl->last_totNum = totNum;
+            ctrl->last_round = round;
+            if (!(round < min_round || (totNum > 0 && round < max_round))) {
+                ctrl->done = 1;
+                ctrl->final_round = round;
+            }
+            atomicExch(&ctrl->totNum, 0);
+            atomicExch(&ctrl->bbits, 0ull);
+            atomicExch(&ctrl->ticket, 0u);
+        }
+    }
+}
+
+}  // namespace
+
+// ---- ctx -------------------------------------------------------------------------------------
+
+struct rsem_em_ctx {
+    int device = 0;
+    int32_t M = 0;
+    uint64_t N1 = 0, nnz = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    // caller-order CSR
+    uint64_t* d_row_ptr = nullptr;
+    int32_t* d_sid = nullptr;
+    double* d_cp = nullptr;
+    double* d_ncp = nullptr;
+    bool have_values = false;
+    // sliced layout
+    SellLayout L;
+    double* d_scp = nullptr;
+    double* d_sncp = nullptr;
+    // EM state
+    double* d_theta[2] = {nullptr, nullptr};
+    double* d_counts = nullptr;
+    double* d_counts_last = nullptr;
+    double* d_noise_a = nullptr;  // per-workgroup noise partials of the main E-step launch
+    double* d_noise_b = nullptr;  // ... of the long-row launch
+    double* d_partials = nullptr;
+    double* d_w = nullptr;        // expected-weights scratch (nnz), lazily allocated
+    double* d_wn = nullptr;
+    Ctrl* d_ctrl = nullptr;
+    int grid_main = 0, grid_long = 0, grid_apply = 0;
+    int kernel = RSEM_EM_KERNEL_AUTO;
+    uint32_t chunk = 8;
+    int check_every = 16;
+    int n_cus = 256;
+    std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStream_t st, bool use_ctrl) {
+    const Ctrl* ctrl = c->d_ctrl;
+    int kern = c->kernel == RSEM_EM_KERNEL_AUTO ? RSEM_EM_KERNEL_SELLRUN : c->kernel;
+    (void)use_ctrl;
+    if (kern == RSEM_EM_KERNEL_CSR) {
+        hipLaunchKernelGGL(k_estep_csr<false>, dim3(c->grid_main), dim3(kBlock), 0, st, c->N1, (const uint32_t*)nullptr,
+                           c->d_row_ptr, c->d_sid, c->d_cp, c->d_ncp, d_theta, d_counts, c->d_noise_a,
+                           (double*)nullptr, (double*)nullptr, ctrl);
+        RSEM_HIP_TRY(hipGetLastError());
+        return RSEM_OK;
+    }
+    if (kern == RSEM_EM_KERNEL_SELL)
+        hipLaunchKernelGGL(k_estep_sell<false>, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
+                           c->L.n_slices, c->chunk, d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_flags, d_counts,
+                           c->d_noise_a, ctrl);
+    else
+        hipLaunchKernelGGL(k_estep_sell<true>, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
+                           c->L.n_slices, c->chunk, d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_flags, d_counts,
+                           c->d_noise_a, ctrl);
+    RSEM_HIP_TRY(hipGetLastError());
+    if (c->L.n_long_rows) {
+        hipLaunchKernelGGL(k_estep_csr<false>, dim3(c->grid_long), dim3(kBlock), 0, st, (uint64_t)c->L.n_long_rows,
+                           c->L.d_order + c->L.n_sell_rows, c->d_row_ptr, c->d_sid, c->d_cp, c->d_ncp, d_theta, d_counts,
+                           c->d_noise_b, (double*)nullptr, (double*)nullptr, ctrl);
+        RSEM_HIP_TRY(hipGetLastError());
+    }
+    return RSEM_OK;
+}
+
+int n_noise_b(const rsem_em_ctx* c) {
+    int kern = c->kernel == RSEM_EM_KERNEL_AUTO ? RSEM_EM_KERNEL_SELLRUN : c->kernel;
+    return (kern != RSEM_EM_KERNEL_CSR && c->L.n_long_rows) ? c->grid_long : 0;
+}
+
+int launch_mstep(rsem_em_ctx* c, double N0, double* d_counts, const double* d_theta_old, double* d_theta_new,
+                 int round, int min_round, int max_round, hipStream_t st) {
+    hipLaunchKernelGGL(k_mstep_reduce, dim3(kReduceBlocks), dim3(kBlock), 0, st, c->M, N0, d_counts, c->d_noise_a,
+                       c->grid_main, c->d_noise_b, n_noise_b(c), c->d_partials, (const Ctrl*)c->d_ctrl);
+    RSEM_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_mstep_apply, dim3(c->grid_apply), dim3(kBlock), 0, st, c->M, c->d_partials, kReduceBlocks,
+                       d_counts, d_theta_old, d_theta_new, c->d_counts_last, c->d_ctrl, round, min_round, max_round);
+    RSEM_HIP_TRY(hipGetLastError());
+    return RSEM_OK;
+}
+
+int fill_values(rsem_em_ctx* c) {
+    return sell_fill_values(c->L, c->stream, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_scp, c->d_sncp);
+}
+
+int build_layout(rsem_em_ctx* c) {
+    int rc = sell_build(c->L, c->stream, c->N1, c->M, c->d_row_ptr, c->d_sid);
+    if (rc != RSEM_OK) return rc;
+    RSEM_HIP_TRY(dmalloc(&c->d_scp, c->L.n_planes * 64));
+    RSEM_HIP_TRY(dmalloc(&c->d_sncp, (size_t)c->L.n_sell_rows));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_scp, 0, sizeof(double) * c->L.n_planes * 64, c->stream));
+    if (c->have_values) {
+        rc = fill_values(c);
+        if (rc != RSEM_OK) return rc;
+    }
+    RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+    // launch geometry: persistent-ish grid, a few chunks per wave
+    int waves = c->n_cus * 8 * (kBlock / 64);
+    uint32_t ch = c->L.n_slices / (uint32_t)(waves * 4);
+    c->chunk = std::min<uint32_t>(64, std::max<uint32_t>(4, ch));
+    c->grid_long = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_long_rows, kBlock)));
+    return RSEM_OK;
+}
+
+void set_grid_for_kernel(rsem_em_ctx* c) {
+    int kern = c->kernel == RSEM_EM_KERNEL_AUTO ? RSEM_EM_KERNEL_SELLRUN : c->kernel;
+    if (kern == RSEM_EM_KERNEL_CSR) {
+        c->grid_main = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->N1, kBlock)));
+    } else {
+        uint32_t n_chunks = (c->L.n_slices + c->chunk - 1) / c->chunk;
+        c->grid_main = std::max(1, std::min<int>(c->n_cus * 8, (int)((n_chunks + 3) / 4)));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64_t nnz, const uint64_t* row_ptr,
+                   const int32_t* sid, const double* conprb, const double* ncp) {
+    RSEM_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    RSEM_REQUIRE(M >= 1, "M must be >= 1");
+    RSEM_REQUIRE(row_ptr != nullptr && (sid != nullptr || nnz == 0), "row_ptr / sid is NULL");
+    RSEM_REQUIRE(N1 < 0xfffffff0ull, "N1 too large for one shard (max 2^32-16 reads)");
+    RSEM_REQUIRE(row_ptr[0] == 0 && row_ptr[N1] == nnz, "row_ptr[0] != 0 or row_ptr[N1] != nnz");
+    RSEM_REQUIRE((conprb == nullptr) == (ncp == nullptr), "conprb and ncp must be given together");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        (void)hipGetLastError();
+        rsem::set_last_error("no HIP device %d (have %d)", device, ndev);
+        return RSEM_ERR_NODEVICE;
+    }
+    RSEM_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RSEM_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    rsem_em_ctx* c = new (std::nothrow) rsem_em_ctx();
+    if (!c) return RSEM_ERR_NOMEM;
+    c->device = device;
+    c->M = M;
+    c->N1 = N1;
+    c->nnz = nnz;
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int rc = RSEM_OK;
+    auto fail = [&](int code) { rsem_em_destroy(c); return code; };
+#define TRY_OR_FAIL(expr)                                                                               \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            rsem::set_last_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));  \
+            return fail(_e == hipErrorOutOfMemory ? RSEM_ERR_NOMEM : RSEM_ERR_HIP);                     \
+        }                                                                                               \
+    } while (0)
+    TRY_OR_FAIL(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    TRY_OR_FAIL(dmalloc(&c->d_row_ptr, N1 + 1));
+    TRY_OR_FAIL(dmalloc(&c->d_sid, nnz));
+    TRY_OR_FAIL(dmalloc(&c->d_cp, nnz));
+    TRY_OR_FAIL(dmalloc(&c->d_ncp, N1));
+    TRY_OR_FAIL(hipMemcpyAsync(c->d_row_ptr, row_ptr, sizeof(uint64_t) * (N1 + 1), hipMemcpyHostToDevice, c->stream));
+    if (nnz) TRY_OR_FAIL(hipMemcpyAsync(c->d_sid, sid, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, c->stream));
+    if (conprb) {
+        if (nnz) TRY_OR_FAIL(hipMemcpyAsync(c->d_cp, conprb, sizeof(double) * nnz, hipMemcpyHostToDevice, c->stream));
+        if (N1) TRY_OR_FAIL(hipMemcpyAsync(c->d_ncp, ncp, sizeof(double) * N1, hipMemcpyHostToDevice, c->stream));
+        c->have_values = true;
+    }
+    for (int i = 0; i < 2; i++) TRY_OR_FAIL(dmalloc(&c->d_theta[i], (size_t)M + 1));
+    TRY_OR_FAIL(dmalloc(&c->d_counts, (size_t)M + 1));
+    TRY_OR_FAIL(dmalloc(&c->d_counts_last, (size_t)M + 1));
+    TRY_OR_FAIL(dmalloc(&c->d_noise_a, (size_t)c->n_cus * 8));
+    TRY_OR_FAIL(dmalloc(&c->d_noise_b, (size_t)c->n_cus * 8));
+    TRY_OR_FAIL(dmalloc(&c->d_partials, kReduceBlocks));
+    TRY_OR_FAIL(dmalloc(&c->d_ctrl, 1));
+    TRY_OR_FAIL(hipMemsetAsync(c->d_counts, 0, sizeof(double) * ((size_t)M + 1), c->stream));
+    TRY_OR_FAIL(hipMemsetAsync(c->d_noise_a, 0, sizeof(double) * c->n_cus * 8, c->stream));
+    TRY_OR_FAIL(hipMemsetAsync(c->d_noise_b, 0, sizeof(double) * c->n_cus * 8, c->stream));
+    TRY_OR_FAIL(hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), c->stream));
+    c->grid_apply = std::max(1, std::min(c->n_cus * 2, rsem::ceil_div((uint64_t)M + 1, kBlock)));
+    rc = build_layout(c);
+    if (rc != RSEM_OK) return fail(rc);
+    set_grid_for_kernel(c);
+#undef TRY_OR_FAIL
+    *out = c;
+    return RSEM_OK;
+}
+
+int rsem_em_set_values(rsem_em_ctx* c, const double* conprb, const double* ncp) {
+    RSEM_REQUIRE(c && conprb && ncp, "NULL argument");
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    if (c->nnz) RSEM_HIP_TRY(hipMemcpyAsync(c->d_cp, conprb, sizeof(double) * c->nnz, hipMemcpyHostToDevice, c->stream));
+    if (c->N1) RSEM_HIP_TRY(hipMemcpyAsync(c->d_ncp, ncp, sizeof(double) * c->N1, hipMemcpyHostToDevice, c->stream));
+    c->have_values = true;
+    int rc = fill_values(c);
+    if (rc != RSEM_OK) return rc;
+    RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSEM_OK;
+}
+
+int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
+    RSEM_REQUIRE(c && key, "NULL argument");
+    if (!strcmp(key, "kernel")) {
+        RSEM_REQUIRE(value >= RSEM_EM_KERNEL_AUTO && value <= RSEM_EM_KERNEL_SELLRUN, "unknown kernel variant");
+        c->kernel = (int)value;
+        set_grid_for_kernel(c);
+        return RSEM_OK;
+    }
+    if (!strcmp(key, "chunk")) {
+        RSEM_REQUIRE(value >= 1 && value <= 4096, "chunk out of range");
+        c->chunk = (uint32_t)value;
+        set_grid_for_kernel(c);
+        return RSEM_OK;
+    }
+    if (!strcmp(key, "check_every")) {
+        RSEM_REQUIRE(value >= 1 && value <= 1024, "check_every out of range");
+        c->check_every = (int)value;
+        return RSEM_OK;
+    }
+    if (!strcmp(key, "grid")) {
+        RSEM_REQUIRE(value >= 1 && value <= c->n_cus * 8, "grid out of range");
+        c->grid_main = (int)value;
+        return RSEM_OK;
+    }
+    rsem::set_last_error("unknown option '%s'", key);
+    return RSEM_ERR_INVALID;
+}
+
+int rsem_em_destroy(rsem_em_ctx* c) {
+    if (!c) return RSEM_OK;
+    (void)hipSetDevice(c->device);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    hipFree(c->d_row_ptr); hipFree(c->d_sid); hipFree(c->d_cp); hipFree(c->d_ncp);
+    sell_free(c->L); hipFree(c->d_scp); hipFree(c->d_sncp);
+    hipFree(c->d_theta[0]); hipFree(c->d_theta[1]); hipFree(c->d_counts);
+    hipFree(c->d_counts_last); hipFree(c->d_noise_a); hipFree(c->d_noise_b); hipFree(c->d_partials);
+    hipFree(c->d_w); hipFree(c->d_wn); hipFree(c->d_ctrl);
+    if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RSEM_OK;
+}
+
+int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_round, int max_round, int* rounds_done,
+                double* counts, double* bChange, int32_t* totNum, rsem_em_profile* prof) {
+    RSEM_REQUIRE(c && theta, "NULL argument");
+    RSEM_REQUIRE(max_round > round0, "max_round must exceed round0");
+    if (!c->have_values) { rsem::set_last_error("CSR values were never set"); return RSEM_ERR_STATE; }
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t nb = sizeof(double) * ((size_t)c->M + 1);
+    RSEM_HIP_TRY(hipMemcpyAsync(c->d_theta[round0 & 1], theta, nb, hipMemcpyHostToDevice, st));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), st));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_counts, 0, nb, st));
+    const int timed = prof ? std::min(max_round - round0, kMaxTimedRounds) : 0;
+    if (prof) {
+        while ((int)c->events.size() < 2 * timed + 2) {
+            hipEvent_t e;
+            RSEM_HIP_TRY(hipEventCreate(&e));
+            c->events.push_back(e);
+        }
+        RSEM_HIP_TRY(hipEventRecord(c->events[0], st));
+    }
+    Ctrl h;
+    memset(&h, 0, sizeof(h));
+    int r = round0;
+    while (r < max_round) {
+        ++r;
+        const double* th_old = c->d_theta[(r - 1) & 1];
+        double* th_new = c->d_theta[r & 1];
+        const int ti = r - round0 - 1;
+        if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[2 + 2 * ti], st));
+        int rc = launch_estep(c, th_old, c->d_counts, st, true);
+        if (rc != RSEM_OK) return rc;
+        if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));
+        rc = launch_mstep(c, N0, c->d_counts, th_old, th_new, r, min_round, max_round, st);
+        if (rc != RSEM_OK) return rc;
+        if (r >= min_round && ((r - round0) % c->check_every == 0 || r == max_round)) {
+            RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
+            RSEM_HIP_TRY(hipStreamSynchronize(st));
+            if (h.done) break;
+        }
+    }
+    if (prof) RSEM_HIP_TRY(hipEventRecord(c->events[1], st));
+    RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipStreamSynchronize(st));
+    if (!h.done) { rsem::set_last_error("EM loop ended without the device stop flag"); return RSEM_ERR_STATE; }
+    const int fr = h.final_round;
+    RSEM_HIP_TRY(hipMemcpyAsync(theta, c->d_theta[fr & 1], nb, hipMemcpyDeviceToHost, st));
+    if (counts) RSEM_HIP_TRY(hipMemcpyAsync(counts, c->d_counts_last, nb, hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipStreamSynchronize(st));
+    if (rounds_done) *rounds_done = fr;
+    if (bChange) *bChange = h.last_bchange;
+    if (totNum) *totNum = h.last_totNum;
+    if (prof) {
+        float ms = 0.f;
+        RSEM_HIP_TRY(hipEventElapsedTime(&ms, c->events[0], c->events[1]));
+        prof->total_ms = ms;
+        prof->estep_ms_sum = 0.0;
+        prof->estep_launches = 0;
+        const int executed = fr - round0;
+        for (int i = 0; i < std::min(executed, timed); i++) {
+            RSEM_HIP_TRY(hipEventElapsedTime(&ms, c->events[2 + 2 * i], c->events[3 + 2 * i]));
+            prof->estep_ms_sum += ms;
+            prof->estep_launches++;
+        }
+        prof->rounds = executed;
+        prof->algorithmic_bytes_per_round = 12ull * c->nnz + 16ull * c->N1 + 16ull * ((uint64_t)c->M + 1);
+    }
+    return RSEM_OK;
+}
+
+int rsem_em_step(rsem_em_ctx* c, const double* theta, double N0, double* counts, double* theta_new, double* sum,
+                 double* bChange, int32_t* totNum) {
+    RSEM_REQUIRE(c && theta, "NULL argument");
+    if (!c->have_values) { rsem::set_last_error("CSR values were never set"); return RSEM_ERR_STATE; }
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t nb = sizeof(double) * ((size_t)c->M + 1);
+    RSEM_HIP_TRY(hipMemcpyAsync(c->d_theta[0], theta, nb, hipMemcpyHostToDevice, st));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), st));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_counts, 0, nb, st));
+    int rc = launch_estep(c, c->d_theta[0], c->d_counts, st, true);
+    if (rc != RSEM_OK) return rc;
+    rc = launch_mstep(c, N0, c->d_counts, c->d_theta[0], c->d_theta[1], 1, 1, 1, st);
+    if (rc != RSEM_OK) return rc;
+    Ctrl h;
+    RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
+    if (counts) RSEM_HIP_TRY(hipMemcpyAsync(counts, c->d_counts_last, nb, hipMemcpyDeviceToHost, st));
+    if (theta_new) RSEM_HIP_TRY(hipMemcpyAsync(theta_new, c->d_theta[1], nb, hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipStreamSynchronize(st));
+    if (sum) *sum = h.last_sum;
+    if (bChange) *bChange = h.last_bchange;
+    if (totNum) *totNum = h.last_totNum;
+    return RSEM_OK;
+}
+
+int rsem_em_expected_weights(rsem_em_ctx* c, const double* theta, double N0, double* counts, double* w, double* w_noise) {
+    RSEM_REQUIRE(c && theta, "NULL argument");
+    if (!c->have_values) { rsem::set_last_error("CSR values were never set"); return RSEM_ERR_STATE; }
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t nb = sizeof(double) * ((size_t)c->M + 1);
+    if (!c->d_w) RSEM_HIP_TRY(dmalloc(&c->d_w, c->nnz));
+    if (!c->d_wn) RSEM_HIP_TRY(dmalloc(&c->d_wn, c->N1));
+    RSEM_HIP_TRY(hipMemcpyAsync(c->d_theta[0], theta, nb, hipMemcpyHostToDevice, st));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), st));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_counts, 0, nb, st));
+    int grid = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->N1, kBlock)));
+    hipLaunchKernelGGL(k_estep_csr<true>, dim3(grid), dim3(kBlock), 0, st, c->N1, (const uint32_t*)nullptr, c->d_row_ptr,
+                       c->d_sid, c->d_cp, c->d_ncp, c->d_theta[0], c->d_counts, c->d_noise_a, c->d_w, c->d_wn,
+                       (const Ctrl*)c->d_ctrl);
+    RSEM_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_mstep_reduce, dim3(kReduceBlocks), dim3(kBlock), 0, st, c->M, N0, c->d_counts, c->d_noise_a, grid,
+                       c->d_noise_b, 0, c->d_partials, (const Ctrl*)c->d_ctrl);
+    RSEM_HIP_TRY(hipGetLastError());
+    if (counts) RSEM_HIP_TRY(hipMemcpyAsync(counts, c->d_counts, nb, hipMemcpyDeviceToHost, st));
+    if (w && c->nnz) RSEM_HIP_TRY(hipMemcpyAsync(w, c->d_w, sizeof(double) * c->nnz, hipMemcpyDeviceToHost, st));
+    if (w_noise && c->N1) RSEM_HIP_TRY(hipMemcpyAsync(w_noise, c->d_wn, sizeof(double) * c->N1, hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_counts, 0, nb, st));
+    RSEM_HIP_TRY(hipStreamSynchronize(st));
+    return RSEM_OK;
+}
+
+int rsem_em_estep_device(rsem_em_ctx* c, const void* d_theta, void* d_counts, void* stream) {
+    RSEM_REQUIRE(c && d_theta && d_counts, "NULL argument");
+    if (!c->have_values) { rsem::set_last_error("CSR values were never set"); return RSEM_ERR_STATE; }
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    // counts is an accumulator: the caller zeroes it (or mstep_device did after the previous round)
+    int rc = launch_estep(c, (const double*)d_theta, (double*)d_counts, st, false);
+    if (rc != RSEM_OK) return rc;
+    // fold this rank's noise partials into counts[0] now, so that the caller's all-reduce sees them
+    hipLaunchKernelGGL(k_mstep_reduce, dim3(1), dim3(kBlock), 0, st, 0, 0.0, (double*)d_counts, c->d_noise_a, c->grid_main,
+                       c->d_noise_b, n_noise_b(c), c->d_partials, (const Ctrl*)c->d_ctrl);
+    RSEM_HIP_TRY(hipGetLastError());
+    return RSEM_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// stats[0..2] = sum, bChange, totNum of this round (written by block 0 after a grid-wide ticket)
+__global__ __launch_bounds__(kBlock) void k_mstep_device(int32_t M, double N0, double* counts,
+                                                          const double* __restrict__ theta_old, double* theta_new,
+                                                          double* stats, Ctrl* ctrl) {
+    // single workgroup: M+1 <= a few 1e5 doubles, once per round after the all-reduce
+    double v = 0.0;
+    if (threadIdx.x == 0) counts[0] += N0;
+    __syncthreads();
+    for (int i = threadIdx.x; i <= M; i += blockDim.x) v += counts[i];
+    double sum = block_sum_det(v);
+    int tot = 0;
+    double bmax = 0.0;
+    for (int i = threadIdx.x; i <= M; i += blockDim.x) {
+        double th = counts[i] / sum;
+        theta_new[i] = th;
+        counts[i] = 0.0;
+        double old = theta_old[i];
+        if (old >= 1e-7) {
+            double change = fabs(th - old) / old;
+            if (change >= 0.001) ++tot;
+            bmax = fmax(bmax, change);
+        }
+    }
+    double t = block_sum_det((double)tot);
+    __shared__ double s_b[kBlock / 64];
+    for (int d = 32; d >= 1; d >>= 1) bmax = fmax(bmax, __shfl_xor(bmax, d));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6] = bmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kBlock / 64; i++) bmax = fmax(bmax, s_b[i]);
+        stats[0] = sum;
+        stats[1] = bmax;
+        stats[2] = t;
+    }
+    (void)ctrl;
+}
+}  // namespace
+
+extern "C" int rsem_em_mstep_device(rsem_em_ctx* c, void* d_counts, double N0_global, const void* d_theta_old,
+                                    void* d_theta_new, void* d_stats, void* stream) {
+    RSEM_REQUIRE(c && d_counts && d_theta_old && d_theta_new && d_stats, "NULL argument");
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_mstep_device, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, c->M, N0_global, (double*)d_counts,
+                       (const double*)d_theta_old, (double*)d_theta_new, (double*)d_stats, c->d_ctrl);
+    RSEM_HIP_TRY(hipGetLastError());
+    return RSEM_OK;
+}

@@ -1,0 +1,254 @@
+// sell_layout.hpp -- the "sliced" device layout shared by the EM and Gibbs kernels.
+//
+// Reads (CSR rows) are radix-sorted on the device by (shape, min sid, hash of the sid tuple) and
+// packed into 64-lane slices: G = 2^lg lanes per read (G = 1 for reads with <= 8 alignments, up to
+// 64 for <= 512), K <= 8 planes of 64 entries per slice; lane l of plane k holds alignment
+// k*G + (l % G) of read l / G of the slice.  Reads with > 512 alignments stay in the caller's CSR
+// ("long rows").  Included by em.hip and gibbs.hip (each TU gets its own copy of the kernels).
+#pragma once
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMaxShapes = 56;
+constexpr int kLongShape = 63;      // rows with more than 512 alignments: CSR kernel
+constexpr int kMaxK = 8;
+constexpr int kBlock = 256;         // 4 waves
+
+struct Shape {
+    uint64_t plane_base;  // first plane of this shape (one plane = 64 entries)
+    uint32_t slice_base;  // first slice
+    uint32_t n_slices;
+    uint32_t row_base;    // first sorted row
+    uint32_t n_rows;
+    int32_t K;            // planes per slice
+    int32_t lg;           // log2(lanes per read)
+};
+
+__host__ __device__ inline int shape_id_of(uint64_t L) {
+    if (L <= 8) return (int)(L == 0 ? 0 : L - 1);  // lg = 0, K = L
+    int lg = 1;
+    uint64_t cap = 16;
+    while (L > cap) { cap <<= 1; ++lg; }
+    if (lg > 6) return kLongShape;
+    int K = (int)((L + (1u << lg) - 1) >> lg);
+    return lg * 8 + (K - 1);
+}
+
+__device__ inline uint32_t mix32(uint32_t h, uint32_t v) {
+    h ^= v + 0x9e3779b9u + (h << 6) + (h >> 2);
+    return h;
+}
+
+// ---- layout construction ---------------------------------------------------------------------
+
+__global__ void k_row_keys(uint64_t N1, int32_t M, const uint64_t* __restrict__ row_ptr,
+                           const int32_t* __restrict__ sid, uint64_t* keys, uint32_t* vals, int* err) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N1) return;
+    uint64_t fr = row_ptr[i], to = row_ptr[i + 1];
+    if (to < fr) { *err = 1; return; }
+    uint32_t h = 0x811c9dc5u, mn = 0xffffffffu;
+    for (uint64_t j = fr; j < to; j++) {
+        int32_t s = sid[j];
+        if (s < 1 || s > M) { *err = 2; s = 1; }
+        h = mix32(h, (uint32_t)s);
+        mn = min(mn, (uint32_t)s);
+    }
+    if (mn > 0x3ffffffu) mn = 0x3ffffffu;
+    keys[i] = ((uint64_t)shape_id_of(to - fr) << 58) | ((uint64_t)mn << 32) | h;
+    vals[i] = (uint32_t)i;
+}
+
+__global__ void k_shape_bounds(uint64_t N1, const uint64_t* __restrict__ keys, uint32_t* first) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N1) return;
+    int sh = (int)(keys[p] >> 58);
+    if (p == 0 || sh != (int)(keys[p - 1] >> 58)) first[sh] = (uint32_t)p;
+}
+
+__device__ inline int find_shape_by_row(const Shape* shapes, int n, uint32_t p) {
+    int sh = 0;
+    while (sh + 1 < n && p >= shapes[sh + 1].row_base) ++sh;
+    return sh;
+}
+
+// one thread per sorted row: scatter its alignments into the planes (values optional)
+template <bool kIds>
+__global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint32_t n_sell_rows,
+                            const uint32_t* __restrict__ order, const uint64_t* __restrict__ row_ptr,
+                            const int32_t* __restrict__ sid, const double* __restrict__ cp,
+                            const double* __restrict__ ncp, int32_t* ssid, double* scp, double* sncp) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_sell_rows) return;
+    int sh = find_shape_by_row(shapes, n_shapes, p);
+    const Shape S = shapes[sh];
+    int G = 1 << S.lg, rps = 64 >> S.lg;
+    uint32_t q = p - S.row_base;
+    uint64_t slice_local = q / rps;
+    int r = q % rps;
+    uint32_t orig = order[p];
+    uint64_t fr = row_ptr[orig];
+    int L = (int)(row_ptr[orig + 1] - fr);
+    uint64_t pl0 = (S.plane_base + slice_local * S.K) * 64;
+    for (int c = 0; c < L; c++) {
+        uint64_t idx = pl0 + (uint64_t)(c >> S.lg) * 64 + r * G + (c & (G - 1));
+        if (kIds) ssid[idx] = sid[fr + c];
+        if (cp) scp[idx] = cp[fr + c];
+    }
+    if (ncp) sncp[p] = ncp[orig];
+}
+
+// bit0: every read of the slice has the same sid tuple; bit1: the slice starts a new run
+__global__ void k_slice_flags(const Shape* __restrict__ shapes, int n_shapes, uint32_t n_slices,
+                              const int32_t* __restrict__ ssid, uint8_t* flags) {
+    __shared__ Shape sh_shapes[kMaxShapes];
+    for (int i = threadIdx.x; i < n_shapes; i += blockDim.x) sh_shapes[i] = shapes[i];
+    __syncthreads();
+    int lane = threadIdx.x & 63;
+    uint32_t s = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    int sh = 0;
+    while (sh + 1 < n_shapes && s >= sh_shapes[sh + 1].slice_base) ++sh;
+    const Shape S = sh_shapes[sh];
+    int G = 1 << S.lg;
+    uint64_t pl0 = (S.plane_base + (uint64_t)(s - S.slice_base) * S.K) * 64;
+    bool uni = true, same_prev = (s > S.slice_base);
+    for (int k = 0; k < S.K; k++) {
+        int v = ssid[pl0 + (uint64_t)k * 64 + lane];
+        int v0 = __shfl(v, lane & (G - 1));
+        uni = uni && (v == v0);
+        if (same_prev) {
+            int pv = ssid[pl0 - (uint64_t)S.K * 64 + (uint64_t)k * 64 + lane];
+            same_prev = (pv == v);
+        }
+    }
+    bool all_uni = __all(uni);
+    bool all_same = __all(same_prev);
+    if (lane == 0) flags[s] = (uint8_t)((all_uni ? 1 : 0) | ((all_uni && all_same) ? 0 : 2));
+}
+
+
+template <typename T>
+hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)); }
+
+struct SellLayout {
+    uint64_t N1 = 0;
+    uint32_t* d_order = nullptr;  // sorted row -> caller row
+    uint32_t n_sell_rows = 0;     // sorted rows that live in the sliced layout
+    uint32_t n_long_rows = 0;     // rows > 512 alignments (tail of d_order)
+    Shape h_shapes[kMaxShapes];
+    int n_shapes = 0;
+    Shape* d_shapes = nullptr;
+    uint32_t n_slices = 0;
+    uint64_t n_planes = 0;
+    int32_t* d_ssid = nullptr;
+    uint8_t* d_flags = nullptr;
+};
+
+inline void sell_free(SellLayout& L) {
+    hipFree(L.d_order); hipFree(L.d_shapes); hipFree(L.d_ssid); hipFree(L.d_flags);
+    L = SellLayout();
+}
+
+// (re)write the value planes / per-row noise values from the caller-order arrays
+inline int sell_fill_values(const SellLayout& L, hipStream_t st, const uint64_t* d_row_ptr, const double* d_cp,
+                            const double* d_ncp, double* d_scp, double* d_sncp) {
+    RSEM_HIP_TRY(hipMemsetAsync(d_scp, 0, sizeof(double) * L.n_planes * 64, st));
+    if (L.n_sell_rows) {
+        hipLaunchKernelGGL(k_fill_sell<false>, dim3(rsem::ceil_div(L.n_sell_rows, kBlock)), dim3(kBlock), 0, st,
+                           L.d_shapes, L.n_shapes, L.n_sell_rows, L.d_order, d_row_ptr, (const int32_t*)nullptr, d_cp,
+                           d_ncp, (int32_t*)nullptr, d_scp, d_sncp);
+        RSEM_HIP_TRY(hipGetLastError());
+    }
+    return RSEM_OK;
+}
+
+// sort the rows, derive the shape table, scatter the sid planes and classify the slices
+inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, const uint64_t* d_row_ptr,
+                      const int32_t* d_sid) {
+    L.N1 = N1;
+    uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
+    uint32_t *d_vals = nullptr, *d_first = nullptr;
+    int* d_err = nullptr;
+    void* d_tmp = nullptr;
+    auto cleanup = [&]() {
+        hipFree(d_keys); hipFree(d_keys2); hipFree(d_vals); hipFree(d_first); hipFree(d_err); hipFree(d_tmp);
+    };
+    RSEM_HIP_TRY(dmalloc(&d_keys, N1));
+    RSEM_HIP_TRY(dmalloc(&d_keys2, N1));
+    RSEM_HIP_TRY(dmalloc(&d_vals, N1));
+    RSEM_HIP_TRY(dmalloc(&L.d_order, N1));
+    RSEM_HIP_TRY(dmalloc(&d_first, 64));
+    RSEM_HIP_TRY(dmalloc(&d_err, 1));
+    RSEM_HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), st));
+    RSEM_HIP_TRY(hipMemsetAsync(d_first, 0xff, 64 * sizeof(uint32_t), st));
+    if (N1) {
+        hipLaunchKernelGGL(k_row_keys, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, M, d_row_ptr, d_sid,
+                           d_keys, d_vals, d_err);
+        RSEM_HIP_TRY(hipGetLastError());
+        size_t tb = 0;
+        RSEM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_keys, d_keys2, d_vals, L.d_order, N1, 0, 64, st));
+        RSEM_HIP_TRY(hipMalloc(&d_tmp, tb ? tb : 1));
+        RSEM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, L.d_order, N1, 0, 64, st));
+        hipLaunchKernelGGL(k_shape_bounds, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, d_keys2, d_first);
+        RSEM_HIP_TRY(hipGetLastError());
+    }
+    uint32_t h_first[64];
+    int h_err = 0;
+    RSEM_HIP_TRY(hipMemcpyAsync(h_first, d_first, sizeof(h_first), hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipStreamSynchronize(st));
+    if (h_err) {
+        cleanup();
+        rsem::set_last_error(h_err == 1 ? "row_ptr is not monotone" : "sid outside 1..M");
+        return RSEM_ERR_INVALID;
+    }
+    L.n_shapes = 0;
+    L.n_slices = 0;
+    L.n_planes = 0;
+    uint32_t long_first = (h_first[kLongShape] == 0xffffffffu) ? (uint32_t)N1 : h_first[kLongShape];
+    L.n_sell_rows = long_first;
+    L.n_long_rows = (uint32_t)N1 - long_first;
+    for (int id = 0; id < kMaxShapes; id++) {
+        if (h_first[id] == 0xffffffffu) continue;
+        uint32_t next = long_first;
+        for (int j = id + 1; j < kMaxShapes; j++)
+            if (h_first[j] != 0xffffffffu) { next = h_first[j]; break; }
+        Shape& S = L.h_shapes[L.n_shapes++];
+        S.lg = id / 8;
+        S.K = id % 8 + 1;
+        S.row_base = h_first[id];
+        S.n_rows = next - h_first[id];
+        uint32_t rps = 64u >> S.lg;
+        S.n_slices = (S.n_rows + rps - 1) / rps;
+        S.slice_base = L.n_slices;
+        S.plane_base = L.n_planes;
+        L.n_slices += S.n_slices;
+        L.n_planes += (uint64_t)S.n_slices * S.K;
+    }
+    RSEM_HIP_TRY(dmalloc(&L.d_shapes, kMaxShapes));
+    RSEM_HIP_TRY(hipMemcpyAsync(L.d_shapes, L.h_shapes, sizeof(Shape) * kMaxShapes, hipMemcpyHostToDevice, st));
+    RSEM_HIP_TRY(dmalloc(&L.d_ssid, L.n_planes * 64));
+    RSEM_HIP_TRY(dmalloc(&L.d_flags, (size_t)L.n_slices));
+    RSEM_HIP_TRY(hipMemsetAsync(L.d_ssid, 0, sizeof(int32_t) * L.n_planes * 64, st));
+    if (L.n_sell_rows) {
+        hipLaunchKernelGGL(k_fill_sell<true>, dim3(rsem::ceil_div(L.n_sell_rows, kBlock)), dim3(kBlock), 0, st,
+                           L.d_shapes, L.n_shapes, L.n_sell_rows, L.d_order, d_row_ptr, d_sid, (const double*)nullptr,
+                           (const double*)nullptr, L.d_ssid, (double*)nullptr, (double*)nullptr);
+        RSEM_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_slice_flags, dim3(rsem::ceil_div(L.n_slices, kBlock / 64)), dim3(kBlock), 0, st,
+                           L.d_shapes, L.n_shapes, L.n_slices, L.d_ssid, L.d_flags);
+        RSEM_HIP_TRY(hipGetLastError());
+    }
+    RSEM_HIP_TRY(hipStreamSynchronize(st));
+    cleanup();
+    return RSEM_OK;
+}
+
+}  // namespace

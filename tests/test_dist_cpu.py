@@ -1,0 +1,90 @@
+"""world_size-2 gloo tests of the multi-GPU host logic (sharding + collectives), CPU only.
+The per-shard compute is stood in for by the oracle (tests may use it); the product's GPU kernels
+are exercised by the -m gpu tests."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import rsem_files as rf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _em_worker(rank, world, port, fxname, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import pyoracle as orc
+    from rsem_amd import dist as rd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fx = rf.fixture(fxname)
+    M, N0, rpi, sidi, vali = rf.read_ofg(os.path.join(fx, "temp", "s.ofg"))
+    rp, sid, cp, ncp = rf.split_noise(rpi, sidi, vali)
+    raw, _ = rf.read_theta(os.path.join(fx, "stat", "s.theta"))
+    b = rd.shard_rows(rp, world)
+    srp, ssid, scp, sncp = rd.take_shard(rp, sid, cp, ncp, b[rank], b[rank + 1])
+    theta = raw.copy()
+    for _ in range(3):
+        counts = orc.em_estep(M, srp, np.ascontiguousarray(ssid), np.ascontiguousarray(scp), np.ascontiguousarray(sncp), theta)
+        t = torch.from_numpy(counts)
+        dist.all_reduce(t)  # EM.cpp:385-389
+        _, theta, s, bc, tn = orc.em_mstep(M, N0, t.numpy(), theta)
+    if rank == 0:
+        q.put((theta, s))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_em_row_sharding_gloo():
+    from oracle import pyoracle as orc
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_em_worker, args=(r, world, port, "pe_q", q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    theta_d, s_d = q.get(timeout=120)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    fx = rf.fixture("pe_q")
+    M, N0, rpi, sidi, vali = rf.read_ofg(os.path.join(fx, "temp", "s.ofg"))
+    rp, sid, cp, ncp = rf.split_noise(rpi, sidi, vali)
+    theta, _ = rf.read_theta(os.path.join(fx, "stat", "s.theta"))
+    for _ in range(3):
+        counts = orc.em_estep(M, rp, sid, cp, ncp, theta)
+        _, theta, s, bc, tn = orc.em_mstep(M, N0, counts, theta)
+    assert np.allclose(theta_d, theta, rtol=1e-12, atol=0)
+    assert abs(s - s_d) < 1e-9
+
+
+def test_shard_rows_matches_reference_rule():
+    from rsem_amd import dist as rd
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 9, 1000)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    for T in (1, 2, 3, 8):
+        b = rd.shard_rows(rp, T)
+        assert b[0] == 0 and b[-1] == 1000 and all(x <= y for x, y in zip(b, b[1:]))
+        # literal restatement of the while loop in EM.cpp:139-153
+        nhT, left, cur, exp = int(rp[-1]) // T, 1000, 0, [0]
+        for i in range(T):
+            ntLeft, hits = T - i - 1, 0
+            while left > ntLeft and (i == T - 1 or hits < nhT):
+                hits += int(lens[cur]); cur += 1; left -= 1
+            exp.append(cur)
+        assert b == exp
+
+
+def test_gibbs_chain_plan():
+    from rsem_amd import dist as rd
+    assert rd.gibbs_chain_plan(1000, 8) == [125] * 8
+    assert rd.gibbs_chain_plan(10, 4) == [3, 3, 2, 2]
+    assert sum(rd.gibbs_chain_plan(1001, 8)) == 1001

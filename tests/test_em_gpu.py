@@ -1,0 +1,186 @@
+"""Parity of the HIP EM path (through the C ABI) against the oracle and the reference's golden outputs.
+
+Tolerances: the E step sums each read's fractions in a different order than the reference and uses
+f * (1/sum) instead of f / sum, so counts/theta agree to ~1e-15 relative per operation; the
+north-star bar is 1e-6 relative on theta.  Tests use 1e-9 for single steps and 1e-6 for whole runs.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import rsem_files as rf
+from oracle import pyoracle as orc
+from tools.synth_data import make_em_workload
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [1, 2, 3]  # CSR, SELL, SELLRUN
+
+
+def capi():
+    from rsem_amd import capi as c
+    return c
+
+
+def _fixture_csr(name):
+    fx = rf.fixture(name)
+    M, N0ofg, rpi, sidi, vali = rf.read_ofg(os.path.join(fx, "temp", "s.ofg"))
+    rp, sid, cp, ncp = rf.split_noise(rpi, sidi, vali)
+    raw, pol = rf.read_theta(os.path.join(fx, "stat", "s.theta"))
+    N0, N1, N2, Ntot = rf.read_cnt(os.path.join(fx, "stat", "s.cnt"))
+    return dict(fx=fx, M=M, N0=N0, Ntot=Ntot, N2=N2, rp=rp, sid=sid, cp=cp, ncp=ncp, raw=raw)
+
+
+def _rel(a, b, floor=1e-300):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))
+
+
+@pytest.mark.parametrize("name", rf.FIXTURES)
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_step_matches_oracle_and_golden(name, variant):
+    d = _fixture_csr(name)
+    ctx = capi().EmContext(d["M"], d["rp"], d["sid"], d["cp"], d["ncp"])
+    ctx.set_option("kernel", variant)
+    counts, theta_new, s, b, t = ctx.step(d["raw"], d["N0"])
+    oc = orc.em_estep(d["M"], d["rp"], d["sid"], d["cp"], d["ncp"], d["raw"])
+    oc, oth, os_, ob, ot = orc.em_mstep(d["M"], d["N0"], oc, d["raw"])
+    assert np.allclose(counts, oc, rtol=1e-9, atol=1e-12)
+    assert np.allclose(theta_new, oth, rtol=1e-9, atol=1e-15)
+    assert abs(s - os_) < 1e-9 * os_
+    assert t == ot and abs(b - ob) <= 1e-9 * max(ob, 1e-12)
+    # golden: expected_count row of the reference's iso_res (printed %.2f)
+    gold = np.array(rf.read_res(os.path.join(d["fx"], "temp", "s.iso_res.em"))[4], float)
+    assert np.allclose(counts[1:], gold, atol=0.00501)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", rf.FIXTURES)
+def test_expected_weights(name):
+    d = _fixture_csr(name)
+    ctx = capi().EmContext(d["M"], d["rp"], d["sid"], d["cp"], d["ncp"])
+    counts, w, wn = ctx.expected_weights(d["raw"], d["N0"])
+    oc, ow, own = orc.em_estep(d["M"], d["rp"], d["sid"], d["cp"], d["ncp"], d["raw"], want_weights=True)
+    oc[0] += d["N0"]
+    assert np.allclose(w, ow, rtol=1e-12, atol=0)
+    assert np.allclose(wn, own, rtol=1e-12, atol=0)
+    assert np.allclose(counts, oc, rtol=1e-9, atol=1e-12)
+    # every read with a non-zero normaliser distributes exactly one unit of mass
+    rows = np.repeat(np.arange(len(d["rp"]) - 1), np.diff(d["rp"].astype(np.int64)))
+    tot = np.bincount(rows, weights=w, minlength=len(wn)) + wn
+    assert np.all((np.abs(tot - 1.0) < 1e-12) | (tot == 0.0))
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", rf.FIXTURES)
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_full_run_same_rounds_and_theta(name, variant):
+    """Device-resident loop with the reference's stop rule: same ROUND count and theta as the oracle."""
+    d = _fixture_csr(name)
+    M = d["M"]
+    th0 = max(d["N0"] * 1.0 / (d["Ntot"] - d["N2"]), 1e-8)  # EM.cpp:343-346
+    theta0 = np.full(M + 1, (1.0 - th0) / M)
+    theta0[0] = th0
+    ctx = capi().EmContext(M, d["rp"], d["sid"], d["cp"], d["ncp"])
+    ctx.set_option("kernel", variant)
+    ctx.set_option("check_every", 7)
+    out = ctx.run(theta0, d["N0"])
+    oth, orounds, ob, ot = orc.em_run(M, d["rp"], d["sid"], d["cp"], d["ncp"], d["N0"], theta0)
+    assert out["rounds"] == orounds
+    assert out["totNum"] == ot
+    big = oth >= 1e-7
+    assert _rel(out["theta"][big], oth[big]) < 1e-6
+    assert np.allclose(out["theta"], oth, rtol=1e-6, atol=1e-12)
+    assert abs(out["theta"].sum() - 1.0) < 1e-12
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_synthetic_with_long_rows(variant):
+    wl = make_em_workload("tiny", seed=3, long_row_every=2500)
+    assert np.diff(wl["row_ptr"].astype(np.int64)).max() > 512
+    ctx = capi().EmContext(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
+    ctx.set_option("kernel", variant)
+    counts, theta_new, s, b, t = ctx.step(wl["theta0"], wl["N0"])
+    oc = orc.em_estep(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["theta0"])
+    oc, oth, os_, ob, ot = orc.em_mstep(wl["M"], wl["N0"], oc, wl["theta0"])
+    assert np.allclose(counts, oc, rtol=1e-9, atol=1e-9)
+    assert np.allclose(theta_new, oth, rtol=1e-9, atol=1e-15)
+    assert t == ot
+    out = ctx.run(wl["theta0"], wl["N0"], max_round=60)
+    oth, orounds, ob, ot = orc.em_run(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["N0"], wl["theta0"],
+                                      max_round=60)
+    assert out["rounds"] == orounds
+    assert np.allclose(out["theta"], oth, rtol=1e-6, atol=1e-12)
+    ctx.close()
+
+
+def test_variants_agree_medium():
+    wl = make_em_workload("small", seed=5)
+    res = []
+    for v in VARIANTS:
+        ctx = capi().EmContext(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
+        ctx.set_option("kernel", v)
+        res.append(ctx.step(wl["theta0"], wl["N0"]))
+        ctx.close()
+    oc = orc.em_estep(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["theta0"])
+    oc[0] += wl["N0"]
+    for r in res:
+        assert np.allclose(r[0], oc, rtol=1e-9, atol=1e-9)
+        assert r[4] == res[0][4]
+
+
+def test_edge_cases():
+    c = capi()
+    # rows whose every term underflows the 1e-300 clamp contribute nothing (EM.cpp:212,219,223)
+    M = 3
+    rp = np.array([0, 2, 3, 5], np.uint64)
+    sid = np.array([1, 2, 3, 1, 3], np.int32)
+    cp = np.array([1e-5, 2e-5, 1e-299, 1e-200, 1e-200], np.float64)
+    ncp = np.array([1e-9, 0.0, 1e-250], np.float64)
+    theta = np.array([0.1, 0.3, 0.3, 0.3])
+    for v in VARIANTS:
+        ctx = c.EmContext(M, rp, sid, cp, ncp)
+        ctx.set_option("kernel", v)
+        counts, th, s, b, t = ctx.step(theta, 2.0)
+        oc = orc.em_estep(M, rp, sid, cp, ncp, theta)
+        oc[0] += 2.0
+        assert np.allclose(counts, oc, rtol=1e-12, atol=0)
+        assert abs(s - 4.0) < 1e-12  # row 2 (0.3e-299 < 1e-300) is dropped entirely
+        ctx.close()
+    # empty shard
+    ctx = c.EmContext(2, np.array([0], np.uint64), np.zeros(0, np.int32), np.zeros(0), np.zeros(0))
+    counts, th, s, b, t = ctx.step(np.array([0.2, 0.4, 0.4]), 5.0)
+    assert counts[0] == 5.0 and counts[1:].sum() == 0.0 and s == 5.0
+    ctx.close()
+    # values supplied later, in file order
+    ctx = c.EmContext(M, rp, sid)
+    with pytest.raises(c.RsemHipError):
+        ctx.step(theta, 0.0)
+    ctx.set_values(cp, ncp)
+    counts2, *_ = ctx.step(theta, 2.0)
+    assert np.allclose(counts2, oc, rtol=1e-12)
+    ctx.close()
+    # bad sid is rejected
+    with pytest.raises(c.RsemHipError) as e:
+        c.EmContext(2, np.array([0, 1], np.uint64), np.array([3], np.int32), np.array([1.0]), np.array([0.0]))
+    assert e.value.status == -1
+
+
+def test_full_size_c2_properties():
+    """BASELINE configs[1] at full size: one step against the oracle + size-independent invariants."""
+    wl = make_em_workload("C2")
+    N1 = len(wl["row_ptr"]) - 1
+    ctx = capi().EmContext(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
+    counts, theta_new, s, b, t = ctx.step(wl["theta0"], wl["N0"])
+    assert abs(s - (wl["N0"] + N1)) < 1e-6 * N1     # every read carries mass 1 (SUM line, EM.cpp:415)
+    assert abs(theta_new.sum() - 1.0) < 1e-12 and counts.min() >= 0.0
+    oc = orc.em_estep(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["theta0"])
+    oc[0] += wl["N0"]
+    assert np.allclose(counts, oc, rtol=1e-9, atol=1e-7)
+    out = ctx.run(wl["theta0"], wl["N0"], min_round=30, max_round=30)
+    assert out["rounds"] == 30 and abs(out["theta"].sum() - 1.0) < 1e-12
+    ctx.set_option("kernel", 1)
+    out2 = ctx.run(wl["theta0"], wl["N0"], min_round=30, max_round=30)
+    assert np.allclose(out["theta"], out2["theta"], rtol=1e-9, atol=1e-18)
+    ctx.close()
