@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librsem_hip.so")
 
-KERNEL_AUTO, KERNEL_CSR, KERNEL_SELL, KERNEL_SELLRUN = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_CSR, KERNEL_SELL, KERNEL_LANE = 0, 1, 2, 3
 GIBBS_EXACT, GIBBS_PARALLEL = 0, 1
 
 _u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")

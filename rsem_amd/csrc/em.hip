@@ -10,9 +10,9 @@
 //   * the CSR is uploaded once, then re-laid-out ON THE DEVICE into a "sliced" layout: reads are
 //     radix-sorted by (shape, min sid, hash of the sid tuple) so that reads hitting the same
 //     transcript set become neighbours, and are packed 64/G to a 64-lane slice with G = 1..64 lanes
-//     per read and K <= 8 planes of 64 entries; lane l of plane k holds alignment k*G + (l % G) of
+//     per read and K <= 4 planes of 64 entries; lane l of plane k holds alignment k*G + (l % G) of
 //     read l / G.  Every global load of the hot loop is therefore a fully coalesced 256 B (sid) or
-//     512 B (conprb) wave access, whatever the row length (1..512 alignments per read).
+//     512 B (conprb) wave access, whatever the row length (1..256 alignments per read).
 //   * per-read normaliser: xor-shuffle reduction over the G lanes of a read;
 //   * per-transcript counts: wave-level *segmented* shuffle reduction keyed by sid along the
 //     lanes (neighbouring reads share sids after the sort), only run tails issue an fp64 atomic;
@@ -26,6 +26,7 @@
 //     host only polls it every few rounds (no per-round host sync).
 // MFMA is not used: ~2 flops per 12 bytes, the bound is HBM bandwidth.
 #include <climits>
+#include <cstdlib>
 #include <cmath>
 
 #include "sell_layout.hpp"
@@ -36,6 +37,7 @@ using rsem::kEpsilon;
 
 constexpr int kReduceBlocks = 64;   // partial sums of the M step
 constexpr int kMaxTimedRounds = 4096;
+constexpr int kWindow = 2048;        // doubles of LDS count window per workgroup (16 KB)
 
 struct Ctrl {  // device-resident loop control, one per ctx
     int done;
@@ -71,7 +73,7 @@ __device__ inline void block_store_partial(double v, double* out) {
 }
 
 // Thread-per-read over the caller's CSR (EM.cpp:199-244 literally).  Used as the baseline
-// variant, for reads with > 512 alignments, and for the final expected-weights pass.
+// variant, for reads with > 256 alignments, and for the final expected-weights pass.
 template <bool kWriteW>
 __global__ __launch_bounds__(kBlock) void k_estep_csr(
     uint64_t n_rows, const uint32_t* __restrict__ row_list, const uint64_t* __restrict__ row_ptr,
@@ -127,127 +129,219 @@ __device__ inline bool seg_reduce(int key, double& v, int lane, int lg) {
     return (lane + G >= 64) || (knext != key);
 }
 
-// sum over lanes with equal (lane % G); result valid on lanes < G
-__device__ inline double strided_sum(double v, int lg) {
-    for (int d = 32; d >= (1 << lg); d >>= 1) v += __shfl_down(v, d);
-    return v;
-}
-
-template <bool kRuns>
+// Variant SELL (cross-check / fallback): every slice on its own, per-plane segmented shuffle
+// reduction keyed by sid, run tails issue device atomics.  Makes no use of the lane-major order.
 __global__ __launch_bounds__(kBlock) void k_estep_sell(
-    const Shape* __restrict__ shapes, int n_shapes, uint32_t n_slices, uint32_t chunk,
-    const double* __restrict__ theta, const double* __restrict__ scp, const int32_t* __restrict__ ssid,
-    const double* __restrict__ sncp, const uint8_t* __restrict__ flags, double* counts,
-    double* noise_partial, const Ctrl* ctrl) {
+    const Shape* __restrict__ shapes, int n_shapes, uint32_t n_slices, const double* __restrict__ theta,
+    const double* __restrict__ scp, const int32_t* __restrict__ ssid, const double* __restrict__ sncp,
+    double* counts, double* noise_partial, const Ctrl* ctrl) {
     if (ctrl->done) return;
     __shared__ Shape sh_shapes[kMaxShapes];
     for (int i = threadIdx.x; i < n_shapes; i += blockDim.x) sh_shapes[i] = shapes[i];
     __syncthreads();
-
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
-    const uint32_t n_chunks = (n_slices + chunk - 1) / chunk;
     const double th0 = theta[0];
     double noise = 0.0;
-
-    for (uint32_t ch = wave; ch < n_chunks; ch += n_waves) {
-        uint32_t s_begin = ch * chunk;
-        uint32_t s_end = min(n_slices, s_begin + chunk);
+    for (uint32_t s = wave; s < n_slices; s += n_waves) {
         int sh = 0;
-        while (sh + 1 < n_shapes && s_begin >= sh_shapes[sh + 1].slice_base) ++sh;
-
-        // run state (kRuns): per-lane partial counts for the lane's fixed (plane, column) sids
-        double acc[kMaxK];
-        int rsid[kMaxK];
-        bool in_run = false;
-        int run_lg = 0, run_K = 0;
+        while (sh + 1 < n_shapes && s >= sh_shapes[sh + 1].slice_base) ++sh;
+        const int K = sh_shapes[sh].K, lg = sh_shapes[sh].lg;
+        const uint32_t sl = s - sh_shapes[sh].slice_base;
+        const uint64_t pl0 = (sh_shapes[sh].plane_base + (uint64_t)sl * K) * 64 + lane;
+        const int g = lane & ((1 << lg) - 1);
+        double f0 = 0.0;
+        if (g == 0) {
+            f0 = th0 * sncp[sh_shapes[sh].slot_base + sl * (64u >> lg) + (lane >> lg)];
+            if (f0 < kEpsilon) f0 = 0.0;
+        }
+        double f[kMaxK];
+        int id[kMaxK];
+        double part = f0;
 #pragma unroll
-        for (int k = 0; k < kMaxK; k++) { acc[k] = 0.0; rsid[k] = 0; }
-
-        for (uint32_t s = s_begin; s < s_end; s++) {
-            while (sh + 1 < n_shapes && s >= sh_shapes[sh + 1].slice_base) ++sh;
-            const int K = sh_shapes[sh].K, lg = sh_shapes[sh].lg;
-            const uint32_t sl = s - sh_shapes[sh].slice_base;
-            const uint64_t pl0 = (sh_shapes[sh].plane_base + (uint64_t)sl * K) * 64 + lane;
-            const int g = lane & ((1 << lg) - 1);
-            const uint32_t rloc = sl * (64u >> lg) + (lane >> lg);
-            const bool row_ok = rloc < sh_shapes[sh].n_rows;
-
-            uint8_t fl = kRuns ? flags[s] : (uint8_t)2;
-            const bool uniform = fl & 1;
-            const bool starts = fl & 2;
-
-            if (kRuns && in_run && (starts || !uniform)) {
-                // flush the finished run: one atomic per distinct (plane, column)
-#pragma unroll
-                for (int k = 0; k < kMaxK; k++)
-                    if (k < run_K) {
-                        double t = strided_sum(acc[k], run_lg);
-                        if (lane < (1 << run_lg) && rsid[k] != 0 && t != 0.0) unsafeAtomicAdd(&counts[rsid[k]], t);
-                        acc[k] = 0.0;
-                    }
-                in_run = false;
+        for (int k = 0; k < kMaxK; k++)
+            if (k < K) {
+                id[k] = ssid[pl0 + (uint64_t)k * 64];
+                double v = theta[id[k]] * scp[pl0 + (uint64_t)k * 64];
+                if (v < kEpsilon) v = 0.0;
+                f[k] = v;
+                part += v;
             }
-
-            double c[kMaxK];
-            int id[kMaxK];
-            const bool load_ids = !(kRuns && uniform && in_run);
+        for (int d = 1; d < (1 << lg); d <<= 1) part += __shfl_xor(part, d);
+        const double inv = (part >= kEpsilon) ? 1.0 / part : 0.0;
+        noise += f0 * inv;
 #pragma unroll
-            for (int k = 0; k < kMaxK; k++)
-                if (k < K) {
-                    c[k] = scp[pl0 + (uint64_t)k * 64];
-                    id[k] = load_ids ? ssid[pl0 + (uint64_t)k * 64] : rsid[k];
-                }
-            double f0 = 0.0;
-            if (g == 0 && row_ok) {
-                f0 = th0 * sncp[sh_shapes[sh].row_base + rloc];
-                if (f0 < kEpsilon) f0 = 0.0;
+        for (int k = 0; k < kMaxK; k++)
+            if (k < K) {
+                double v = f[k] * inv;
+                bool tail = seg_reduce(id[k], v, lane, lg);
+                if (tail && id[k] != 0 && v != 0.0) unsafeAtomicAdd(&counts[id[k]], v);
             }
-            double f[kMaxK];
-            double part = f0;
-#pragma unroll
-            for (int k = 0; k < kMaxK; k++)
-                if (k < K) {
-                    double v = theta[id[k]] * c[k];
-                    if (v < kEpsilon) v = 0.0;
-                    f[k] = v;
-                    part += v;
-                }
-            for (int d = 1; d < (1 << lg); d <<= 1) part += __shfl_xor(part, d);
-            const double inv = (part >= kEpsilon) ? 1.0 / part : 0.0;
-            noise += f0 * inv;
+    }
+    block_store_partial(noise, noise_partial);
+}
 
-            if (kRuns && uniform) {
-                if (!in_run) {
-                    in_run = true;
-                    run_lg = lg;
-                    run_K = K;
+// Variant LANE (default).  One workgroup = one Unit (sell_layout.hpp): each of its 4 waves walks one
+// block of T slices.  theta[base .. base+kWindow) is staged in LDS once, counts for the same sid
+// window accumulate in LDS (ds_add_f64) and leave the workgroup as ONE device atomic per touched
+// sid.  Inside a block every lane follows consecutive sorted reads: while the sid tuple does not
+// change (slice mask bit clear) the lane multiplies cached theta values with the streamed conprb
+// and adds the normalised fractions into registers; on a change it spills its registers to the
+// LDS window and reloads sid / theta for the new tuple.  The loads of slice s+1 are issued before
+// slice s is reduced (software pipeline, static instruction stream per K).
+template <int K>
+struct SliceRegs {
+    int id[K];
+    double c[K];
+    double nc;
+};
+
+template <int K>
+__device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, int lane, int base, int M,
+                                   const double* __restrict__ theta, double th0, const double* th_win, double* cnt_win,
+                                   const double* __restrict__ scp, const int32_t* __restrict__ ssid,
+                                   const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
+                                   double* counts, double& noise) {
+    const int lg = S.lg;
+    const int g = lane & ((1 << lg) - 1);
+    const bool g0 = (g == 0);
+    const uint32_t R = 64u >> lg;
+    // 64 slices' masks at a time, one per lane
+    uint32_t m_base = s_begin;
+    unsigned long long mv = (s_begin + lane < s_end) ? masks[s_begin + lane] : ~0ull;
+    auto mask_of = [&](uint32_t t) -> unsigned long long {
+        if (t - m_base >= 64u) {
+            m_base = t;
+            mv = (t + lane < s_end) ? masks[t + lane] : ~0ull;
+        }
+        const int src = (int)(t - m_base);
+        const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)mv, src);
+        const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), src);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    auto issue = [&](uint32_t t, unsigned long long m, SliceRegs<K>& b) {
+        const uint32_t sl = t - S.slice_base;
+        const uint64_t pl = (S.plane_base + (uint64_t)sl * K) * 64 + lane;
+        const bool want = (m >> lane) & 1ull;
 #pragma unroll
-                    for (int k = 0; k < kMaxK; k++)
-                        if (k < K) rsid[k] = id[k];
+        for (int k = 0; k < K; k++) b.id[k] = ssid[want ? pl + (uint64_t)k * 64 : 0];
+#pragma unroll
+        for (int k = 0; k < K; k++) b.c[k] = scp[pl + (uint64_t)k * 64];
+        b.nc = g0 ? sncp[S.slot_base + sl * R + (lane >> lg)] : 0.0;
+    };
+    auto spill = [&](const int* rsid, double* acc) {  // lane-private partial counts -> LDS window
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (acc[k] != 0.0) {
+                const unsigned off = (unsigned)(rsid[k] - base);
+                if (off < (unsigned)kWindow) unsafeAtomicAdd(&cnt_win[off], acc[k]);
+                else unsafeAtomicAdd(&counts[rsid[k]], acc[k]);
+            }
+            acc[k] = 0.0;
+        }
+    };
+
+    int rsid[K];
+    double rth[K], acc[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { rsid[k] = 0; rth[k] = 0.0; acc[k] = 0.0; }
+    auto reduce = [&](const SliceRegs<K>& cur, unsigned long long cur_m) {
+        if (cur_m != 0ull) {                 // wave-uniform
+            if ((cur_m >> lane) & 1ull) {    // lanes whose read starts a new sid tuple
+                spill(rsid, acc);
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const int sidv = cur.id[k];
+                    rsid[k] = sidv;
+                    const unsigned off = (unsigned)(sidv - base);
+                    rth[k] = (off < (unsigned)kWindow) ? th_win[off] : theta[sidv];
                 }
-#pragma unroll
-                for (int k = 0; k < kMaxK; k++)
-                    if (k < K) acc[k] += f[k] * inv;
-            } else {
-#pragma unroll
-                for (int k = 0; k < kMaxK; k++)
-                    if (k < K) {
-                        double v = f[k] * inv;
-                        bool tail = seg_reduce(id[k], v, lane, lg);
-                        if (tail && id[k] != 0 && v != 0.0) unsafeAtomicAdd(&counts[id[k]], v);
-                    }
             }
         }
-        if (kRuns && in_run) {
+        double f0 = th0 * cur.nc;
+        if (f0 < kEpsilon) f0 = 0.0;
+        double f[K];
+        double part = f0;
 #pragma unroll
-            for (int k = 0; k < kMaxK; k++)
-                if (k < run_K) {
-                    double t = strided_sum(acc[k], run_lg);
-                    if (lane < (1 << run_lg) && rsid[k] != 0 && t != 0.0) unsafeAtomicAdd(&counts[rsid[k]], t);
-                }
+        for (int k = 0; k < K; k++) {
+            double v = rth[k] * cur.c[k];
+            if (v < kEpsilon) v = 0.0;
+            f[k] = v;
+            part += v;
         }
+        for (int d = 1; d < (1 << lg); d <<= 1) part += __shfl_xor(part, d);
+        const double inv = (part >= kEpsilon) ? 1.0 / part : 0.0;
+        noise += f0 * inv;
+#pragma unroll
+        for (int k = 0; k < K; k++) acc[k] += f[k] * inv;
+    };
+    // ping-pong register sets A / B: the loads of the next slice are in flight while this one is reduced
+    SliceRegs<K> A, B;
+    unsigned long long mA = ~0ull, mB = 0;  // a block always starts fresh
+    issue(s_begin, mA, A);
+    for (uint32_t s = s_begin; s < s_end; s += 2) {
+        if (s + 1 < s_end) {
+            mB = mask_of(s + 1);
+            issue(s + 1, mB, B);
+        }
+        reduce(A, mA);
+        if (s + 1 >= s_end) break;
+        if (s + 2 < s_end) {
+            mA = mask_of(s + 2);
+            issue(s + 2, mA, A);
+        }
+        reduce(B, mB);
+    }
+    spill(rsid, acc);
+    (void)M;
+}
+
+__global__ __launch_bounds__(kBlock) void k_estep_lane(
+    const Shape* __restrict__ shapes, const Unit* __restrict__ units, uint32_t T, int M,
+    const double* __restrict__ theta, const double* __restrict__ scp, const int32_t* __restrict__ ssid,
+    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks, double* counts,
+    double* noise_partial, const Ctrl* ctrl) {
+    if (ctrl->done) return;
+    __shared__ double th_win[kWindow];
+    __shared__ double cnt_win[kWindow];
+    __shared__ Shape sS;
+    const Unit U = units[blockIdx.x];
+    if (threadIdx.x == 0) sS = shapes[U.shape];
+    for (int i = threadIdx.x; i < kWindow; i += blockDim.x) {
+        const int sidv = U.base + i;
+        th_win[i] = (sidv >= 0 && sidv <= M) ? theta[sidv] : 0.0;
+        cnt_win[i] = 0.0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double noise = 0.0;
+    if (w < U.n_blocks) {
+        Shape S;  // wave-uniform copy in SGPRs
+        S.plane_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sS.plane_base >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sS.plane_base);
+        S.slice_base = __builtin_amdgcn_readfirstlane(sS.slice_base);
+        S.n_slices = __builtin_amdgcn_readfirstlane(sS.n_slices);
+        S.row_base = 0;
+        S.n_rows = 0;
+        S.slot_base = __builtin_amdgcn_readfirstlane(sS.slot_base);
+        S.K = __builtin_amdgcn_readfirstlane(sS.K);
+        S.lg = __builtin_amdgcn_readfirstlane(sS.lg);
+        const uint32_t blk = U.block_begin + w;
+        const uint32_t s_begin = S.slice_base + blk * T;
+        const uint32_t s_end = min(S.slice_base + S.n_slices, s_begin + T);
+        const double th0 = theta[0];
+        switch (S.K) {
+            case 1: estep_block<1>(S, s_begin, s_end, lane, U.base, M, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
+            case 2: estep_block<2>(S, s_begin, s_end, lane, U.base, M, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
+            case 3: estep_block<3>(S, s_begin, s_end, lane, U.base, M, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
+            default: estep_block<4>(S, s_begin, s_end, lane, U.base, M, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kWindow; i += blockDim.x) {
+        const double v = cnt_win[i];
+        if (v != 0.0) unsafeAtomicAdd(&counts[U.base + i], v);
     }
     block_store_partial(noise, noise_partial);
 }
@@ -366,6 +460,11 @@ struct rsem_em_ctx {
     SellLayout L;
     double* d_scp = nullptr;
     double* d_sncp = nullptr;
+    // LANE variant work list
+    Unit* d_units = nullptr;
+    uint32_t n_units = 0;
+    int noise_n = 0;  // workgroups of the last main E-step launch (= valid entries of d_noise_a)
+    size_t noise_cap = 0;
     // EM state
     double* d_theta[2] = {nullptr, nullptr};
     double* d_counts = nullptr;
@@ -378,7 +477,7 @@ struct rsem_em_ctx {
     Ctrl* d_ctrl = nullptr;
     int grid_main = 0, grid_long = 0, grid_apply = 0;
     int kernel = RSEM_EM_KERNEL_AUTO;
-    uint32_t chunk = 8;
+    uint32_t forced_T = 0;
     int check_every = 16;
     int n_cus = 256;
     std::vector<hipEvent_t> events;
@@ -386,10 +485,15 @@ struct rsem_em_ctx {
 
 namespace {
 
+int resolved_kernel(const rsem_em_ctx* c) {
+    return c->kernel == RSEM_EM_KERNEL_AUTO ? RSEM_EM_KERNEL_LANE : c->kernel;
+}
+
 int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStream_t st, bool use_ctrl) {
     const Ctrl* ctrl = c->d_ctrl;
-    int kern = c->kernel == RSEM_EM_KERNEL_AUTO ? RSEM_EM_KERNEL_SELLRUN : c->kernel;
+    const int kern = resolved_kernel(c);
     (void)use_ctrl;
+    c->noise_n = (kern == RSEM_EM_KERNEL_LANE) ? (int)c->n_units : c->grid_main;
     if (kern == RSEM_EM_KERNEL_CSR) {
         hipLaunchKernelGGL(k_estep_csr<false>, dim3(c->grid_main), dim3(kBlock), 0, st, c->N1, (const uint32_t*)nullptr,
                            c->d_row_ptr, c->d_sid, c->d_cp, c->d_ncp, d_theta, d_counts, c->d_noise_a,
@@ -397,14 +501,14 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
         RSEM_HIP_TRY(hipGetLastError());
         return RSEM_OK;
     }
-    if (kern == RSEM_EM_KERNEL_SELL)
-        hipLaunchKernelGGL(k_estep_sell<false>, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
-                           c->L.n_slices, c->chunk, d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_flags, d_counts,
-                           c->d_noise_a, ctrl);
-    else
-        hipLaunchKernelGGL(k_estep_sell<true>, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
-                           c->L.n_slices, c->chunk, d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_flags, d_counts,
-                           c->d_noise_a, ctrl);
+    if (kern == RSEM_EM_KERNEL_LANE) {
+        if (c->n_units)
+            hipLaunchKernelGGL(k_estep_lane, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
+                               d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, ctrl);
+    } else {
+        hipLaunchKernelGGL(k_estep_sell, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
+                           c->L.n_slices, d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, d_counts, c->d_noise_a, ctrl);
+    }
     RSEM_HIP_TRY(hipGetLastError());
     if (c->L.n_long_rows) {
         hipLaunchKernelGGL(k_estep_csr<false>, dim3(c->grid_long), dim3(kBlock), 0, st, (uint64_t)c->L.n_long_rows,
@@ -416,14 +520,14 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
 }
 
 int n_noise_b(const rsem_em_ctx* c) {
-    int kern = c->kernel == RSEM_EM_KERNEL_AUTO ? RSEM_EM_KERNEL_SELLRUN : c->kernel;
+    const int kern = resolved_kernel(c);
     return (kern != RSEM_EM_KERNEL_CSR && c->L.n_long_rows) ? c->grid_long : 0;
 }
 
 int launch_mstep(rsem_em_ctx* c, double N0, double* d_counts, const double* d_theta_old, double* d_theta_new,
                  int round, int min_round, int max_round, hipStream_t st) {
     hipLaunchKernelGGL(k_mstep_reduce, dim3(kReduceBlocks), dim3(kBlock), 0, st, c->M, N0, d_counts, c->d_noise_a,
-                       c->grid_main, c->d_noise_b, n_noise_b(c), c->d_partials, (const Ctrl*)c->d_ctrl);
+                       c->noise_n, c->d_noise_b, n_noise_b(c), c->d_partials, (const Ctrl*)c->d_ctrl);
     RSEM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_mstep_apply, dim3(c->grid_apply), dim3(kBlock), 0, st, c->M, c->d_partials, kReduceBlocks,
                        d_counts, d_theta_old, d_theta_new, c->d_counts_last, c->d_ctrl, round, min_round, max_round);
@@ -436,32 +540,40 @@ int fill_values(rsem_em_ctx* c) {
 }
 
 int build_layout(rsem_em_ctx* c) {
-    int rc = sell_build(c->L, c->stream, c->N1, c->M, c->d_row_ptr, c->d_sid);
+    // one block per wave, ~2.5 blocks per wave slot (6 waves/SIMD) for load balance
+    const uint32_t target_waves = (uint32_t)c->n_cus * 4 * 6 * 5 / 2;
+    int rc = sell_build(c->L, c->stream, c->N1, c->M, c->d_row_ptr, c->d_sid, target_waves, c->forced_T);
     if (rc != RSEM_OK) return rc;
     RSEM_HIP_TRY(dmalloc(&c->d_scp, c->L.n_planes * 64));
-    RSEM_HIP_TRY(dmalloc(&c->d_sncp, (size_t)c->L.n_sell_rows));
+    RSEM_HIP_TRY(dmalloc(&c->d_sncp, (size_t)c->L.n_slots));
     RSEM_HIP_TRY(hipMemsetAsync(c->d_scp, 0, sizeof(double) * c->L.n_planes * 64, c->stream));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_sncp, 0, sizeof(double) * c->L.n_slots, c->stream));
     if (c->have_values) {
         rc = fill_values(c);
         if (rc != RSEM_OK) return rc;
     }
     RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
-    // launch geometry: persistent-ish grid, a few chunks per wave
-    int waves = c->n_cus * 8 * (kBlock / 64);
-    uint32_t ch = c->L.n_slices / (uint32_t)(waves * 4);
-    c->chunk = std::min<uint32_t>(64, std::max<uint32_t>(4, ch));
+    std::vector<Unit> units;
+    rc = sell_build_units(c->L, units);
+    if (rc != RSEM_OK) return rc;
+    c->n_units = (uint32_t)units.size();
+    RSEM_HIP_TRY(dmalloc(&c->d_units, units.size()));
+    if (!units.empty())
+        RSEM_HIP_TRY(hipMemcpy(c->d_units, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice));
+    // per-workgroup noise partials: enough for any variant's grid
+    c->noise_cap = std::max<size_t>((size_t)c->n_cus * 8, c->n_units);
+    RSEM_HIP_TRY(dmalloc(&c->d_noise_a, c->noise_cap));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_noise_a, 0, sizeof(double) * c->noise_cap, c->stream));
     c->grid_long = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_long_rows, kBlock)));
     return RSEM_OK;
 }
 
 void set_grid_for_kernel(rsem_em_ctx* c) {
-    int kern = c->kernel == RSEM_EM_KERNEL_AUTO ? RSEM_EM_KERNEL_SELLRUN : c->kernel;
-    if (kern == RSEM_EM_KERNEL_CSR) {
+    const int kern = resolved_kernel(c);
+    if (kern == RSEM_EM_KERNEL_CSR)
         c->grid_main = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->N1, kBlock)));
-    } else {
-        uint32_t n_chunks = (c->L.n_slices + c->chunk - 1) / c->chunk;
-        c->grid_main = std::max(1, std::min<int>(c->n_cus * 8, (int)((n_chunks + 3) / 4)));
-    }
+    else
+        c->grid_main = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_slices, kBlock / 64)));
 }
 
 }  // namespace
@@ -518,15 +630,14 @@ int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64
     for (int i = 0; i < 2; i++) TRY_OR_FAIL(dmalloc(&c->d_theta[i], (size_t)M + 1));
     TRY_OR_FAIL(dmalloc(&c->d_counts, (size_t)M + 1));
     TRY_OR_FAIL(dmalloc(&c->d_counts_last, (size_t)M + 1));
-    TRY_OR_FAIL(dmalloc(&c->d_noise_a, (size_t)c->n_cus * 8));
     TRY_OR_FAIL(dmalloc(&c->d_noise_b, (size_t)c->n_cus * 8));
     TRY_OR_FAIL(dmalloc(&c->d_partials, kReduceBlocks));
     TRY_OR_FAIL(dmalloc(&c->d_ctrl, 1));
     TRY_OR_FAIL(hipMemsetAsync(c->d_counts, 0, sizeof(double) * ((size_t)M + 1), c->stream));
-    TRY_OR_FAIL(hipMemsetAsync(c->d_noise_a, 0, sizeof(double) * c->n_cus * 8, c->stream));
     TRY_OR_FAIL(hipMemsetAsync(c->d_noise_b, 0, sizeof(double) * c->n_cus * 8, c->stream));
     TRY_OR_FAIL(hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), c->stream));
     c->grid_apply = std::max(1, std::min(c->n_cus * 2, rsem::ceil_div((uint64_t)M + 1, kBlock)));
+    if (const char* e = getenv("RSEM_HIP_T")) c->forced_T = (uint32_t)atoi(e);  // tuning knob: slices per block
     rc = build_layout(c);
     if (rc != RSEM_OK) return fail(rc);
     set_grid_for_kernel(c);
@@ -550,25 +661,14 @@ int rsem_em_set_values(rsem_em_ctx* c, const double* conprb, const double* ncp) 
 int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
     RSEM_REQUIRE(c && key, "NULL argument");
     if (!strcmp(key, "kernel")) {
-        RSEM_REQUIRE(value >= RSEM_EM_KERNEL_AUTO && value <= RSEM_EM_KERNEL_SELLRUN, "unknown kernel variant");
+        RSEM_REQUIRE(value >= RSEM_EM_KERNEL_AUTO && value <= RSEM_EM_KERNEL_LANE, "unknown kernel variant");
         c->kernel = (int)value;
-        set_grid_for_kernel(c);
-        return RSEM_OK;
-    }
-    if (!strcmp(key, "chunk")) {
-        RSEM_REQUIRE(value >= 1 && value <= 4096, "chunk out of range");
-        c->chunk = (uint32_t)value;
         set_grid_for_kernel(c);
         return RSEM_OK;
     }
     if (!strcmp(key, "check_every")) {
         RSEM_REQUIRE(value >= 1 && value <= 1024, "check_every out of range");
         c->check_every = (int)value;
-        return RSEM_OK;
-    }
-    if (!strcmp(key, "grid")) {
-        RSEM_REQUIRE(value >= 1 && value <= c->n_cus * 8, "grid out of range");
-        c->grid_main = (int)value;
         return RSEM_OK;
     }
     rsem::set_last_error("unknown option '%s'", key);
@@ -583,7 +683,7 @@ int rsem_em_destroy(rsem_em_ctx* c) {
     sell_free(c->L); hipFree(c->d_scp); hipFree(c->d_sncp);
     hipFree(c->d_theta[0]); hipFree(c->d_theta[1]); hipFree(c->d_counts);
     hipFree(c->d_counts_last); hipFree(c->d_noise_a); hipFree(c->d_noise_b); hipFree(c->d_partials);
-    hipFree(c->d_w); hipFree(c->d_wn); hipFree(c->d_ctrl);
+    hipFree(c->d_w); hipFree(c->d_wn); hipFree(c->d_ctrl); hipFree(c->d_units);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RSEM_OK;
@@ -719,7 +819,7 @@ int rsem_em_estep_device(rsem_em_ctx* c, const void* d_theta, void* d_counts, vo
     int rc = launch_estep(c, (const double*)d_theta, (double*)d_counts, st, false);
     if (rc != RSEM_OK) return rc;
     // fold this rank's noise partials into counts[0] now, so that the caller's all-reduce sees them
-    hipLaunchKernelGGL(k_mstep_reduce, dim3(1), dim3(kBlock), 0, st, 0, 0.0, (double*)d_counts, c->d_noise_a, c->grid_main,
+    hipLaunchKernelGGL(k_mstep_reduce, dim3(1), dim3(kBlock), 0, st, 0, 0.0, (double*)d_counts, c->d_noise_a, c->noise_n,
                        c->d_noise_b, n_noise_b(c), c->d_partials, (const Ctrl*)c->d_ctrl);
     RSEM_HIP_TRY(hipGetLastError());
     return RSEM_OK;

@@ -107,145 +107,193 @@ __global__ void k_reset_counts(int32_t M, const int32_t* __restrict__ init_count
     if (i <= M) counts[i] = init_counts[i] + (i == 0 ? n0 : 0);
 }
 
-__device__ inline int strided_sum_i(int v, int lg) {
-    for (int d = 32; d >= (1 << lg); d >>= 1) v += __shfl_down(v, d);
-    return v;
-}
+constexpr int kGWindow = 2048;  // sids per workgroup window (g values: 16 KB, int counts: 8 KB of LDS)
 
-// z_i | g for every read of the sliced layout; histogram into counts (int atomics, aggregated
-// per run of identical reads).  Weight order inside a read: noise, then the lanes of the read in
-// order, each lane's planes in order.
-__global__ __launch_bounds__(kBlock) void k_sample_z_sell(
-    const Shape* __restrict__ shapes, int n_shapes, uint32_t n_slices, uint32_t chunk,
-    const double* __restrict__ g, const double* __restrict__ scp, const int32_t* __restrict__ ssid,
-    const double* __restrict__ sncp, const uint8_t* __restrict__ flags, Philox ph, uint32_t sweep,
-    int32_t* counts) {
-    __shared__ Shape sh_shapes[kMaxShapes];
-    __shared__ int s_noise;
-    for (int i = threadIdx.x; i < n_shapes; i += blockDim.x) sh_shapes[i] = shapes[i];
-    if (threadIdx.x == 0) s_noise = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (kBlock / 64);
-    const uint32_t n_chunks = (n_slices + chunk - 1) / chunk;
-    const double g0 = g[0];
-    int noise = 0;
+template <int K>
+struct SliceRegs {
+    int id[K];
+    double c[K];
+    double nc;
+};
 
-    for (uint32_t ch = wave; ch < n_chunks; ch += n_waves) {
-        uint32_t s_begin = ch * chunk, s_end = min(n_slices, s_begin + chunk);
-        int sh = 0;
-        while (sh + 1 < n_shapes && s_begin >= sh_shapes[sh + 1].slice_base) ++sh;
-        int acc[kMaxK], rsid[kMaxK];
-        bool in_run = false;
-        int run_lg = 0, run_K = 0;
+// z_i | g for the reads of one block (T slices, one wave), lane-major runs as in the E step: a lane
+// keeps the g values and integer pick counters of its current sid tuple in registers and spills
+// them to the workgroup's LDS window when the tuple changes.  Weight order inside a read: noise,
+// then the G lanes of the read in order, each lane's K planes in order.
+template <int K>
+__device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32_t s_end, int lane, int base,
+                                   const double* __restrict__ g, double g0, const double* g_win, int* cnt_win,
+                                   const double* __restrict__ scp, const int32_t* __restrict__ ssid,
+                                   const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
+                                   const Philox& ph, uint32_t sweep, int32_t* counts, int& noise) {
+    const int lg = S.lg, G = 1 << lg;
+    const int gl = lane & (G - 1);
+    const bool g0lane = (gl == 0);
+    const uint32_t R = 64u >> lg;
+    const int gbase = lane & ~(G - 1);
+    uint32_t m_base = s_begin;
+    unsigned long long mv = (s_begin + lane < s_end) ? masks[s_begin + lane] : ~0ull;
+    auto mask_of = [&](uint32_t t) -> unsigned long long {
+        if (t - m_base >= 64u) {
+            m_base = t;
+            mv = (t + lane < s_end) ? masks[t + lane] : ~0ull;
+        }
+        const int src = (int)(t - m_base);
+        const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)mv, src);
+        const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), src);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    auto issue = [&](uint32_t t, unsigned long long m, SliceRegs<K>& b) {
+        const uint32_t sl = t - S.slice_base;
+        const uint64_t pl = (S.plane_base + (uint64_t)sl * K) * 64 + lane;
+        const bool want = (m >> lane) & 1ull;
 #pragma unroll
-        for (int k = 0; k < kMaxK; k++) { acc[k] = 0; rsid[k] = 0; }
-
-        for (uint32_t s = s_begin; s < s_end; s++) {
-            while (sh + 1 < n_shapes && s >= sh_shapes[sh + 1].slice_base) ++sh;
-            const int K = sh_shapes[sh].K, lg = sh_shapes[sh].lg, G = 1 << lg;
-            const uint32_t sl = s - sh_shapes[sh].slice_base;
-            const uint64_t pl0 = (sh_shapes[sh].plane_base + (uint64_t)sl * K) * 64 + lane;
-            const int gl = lane & (G - 1);
-            const uint32_t rloc = sl * (64u >> lg) + (lane >> lg);
-            const bool row_ok = rloc < sh_shapes[sh].n_rows;
-            const uint8_t fl = flags[s];
-            const bool uniform = fl & 1, starts = fl & 2;
-
-            if (in_run && (starts || !uniform)) {
+        for (int k = 0; k < K; k++) b.id[k] = ssid[want ? pl + (uint64_t)k * 64 : 0];
 #pragma unroll
-                for (int k = 0; k < kMaxK; k++)
-                    if (k < run_K) {
-                        int t = strided_sum_i(acc[k], run_lg);
-                        if (lane < (1 << run_lg) && t != 0) atomicAdd(&counts[rsid[k]], t);
-                        acc[k] = 0;
-                    }
-                in_run = false;
+        for (int k = 0; k < K; k++) b.c[k] = scp[pl + (uint64_t)k * 64];
+        b.nc = g0lane ? sncp[S.slot_base + sl * R + (lane >> lg)] : 0.0;
+    };
+    int rsid[K], acc[K];
+    double rg[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { rsid[k] = 0; acc[k] = 0; rg[k] = 0.0; }
+    auto spill = [&]() {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (acc[k] != 0) {
+                const unsigned off = (unsigned)(rsid[k] - base);
+                if (off < (unsigned)kGWindow) atomicAdd(&cnt_win[off], acc[k]);
+                else atomicAdd(&counts[rsid[k]], acc[k]);
             }
-            double c[kMaxK];
-            int id[kMaxK];
-            const bool load_ids = !(uniform && in_run);
+            acc[k] = 0;
+        }
+    };
+    auto sample = [&](const SliceRegs<K>& cur, unsigned long long cur_m, uint32_t s) {
+        if (cur_m != 0ull) {
+            if ((cur_m >> lane) & 1ull) {
+                spill();
 #pragma unroll
-            for (int k = 0; k < kMaxK; k++)
-                if (k < K) {
-                    c[k] = scp[pl0 + (uint64_t)k * 64];
-                    id[k] = load_ids ? ssid[pl0 + (uint64_t)k * 64] : rsid[k];
+                for (int k = 0; k < K; k++) {
+                    const int sidv = cur.id[k];
+                    rsid[k] = sidv;
+                    const unsigned off = (unsigned)(sidv - base);
+                    rg[k] = (off < (unsigned)kGWindow) ? g_win[off] : g[sidv];
                 }
-            double f0 = 0.0;
-            if (gl == 0 && row_ok) f0 = g0 * sncp[sh_shapes[sh].row_base + rloc];
-            double f[kMaxK];
-            double part = f0;
-#pragma unroll
-            for (int k = 0; k < kMaxK; k++)
-                if (k < K) {
-                    f[k] = g[id[k]] * c[k];
-                    part += f[k];
-                }
-            // inclusive scan of `part` over the G lanes of the read
-            double incl = part;
-            for (int d = 1; d < G; d <<= 1) {
-                double o = __shfl_up(incl, d);
-                if (gl >= d) incl += o;
-            }
-            double excl = __shfl_up(incl, 1);
-            if (gl == 0) excl = 0.0;
-            const int base = lane & ~(G - 1);
-            const double total = __shfl(incl, base + G - 1);
-            // one uniform per read, drawn by its first lane
-            uint32_t r[4] = {0, 0, 0, 0};
-            if (gl == 0) ph.gen(sh_shapes[sh].row_base + rloc, sweep, 0x5a5a5a5au, 0u, r);
-            double u = __shfl(u53(r[0], r[1]), base);
-            double target = u * total;
-            if (target >= total) target = total * (1.0 - 1.1102230246251565e-16);
-            int pick = -2;  // -2: not mine, -1: noise, k >= 0: my plane k
-            if (row_ok && total > 0.0 && target >= excl && target < incl) {
-                double run = excl;
-                if (gl == 0) { run += f0; if (target < run) pick = -1; }
-                if (pick == -2) {
-                    int last = -2;
-#pragma unroll
-                    for (int k = 0; k < kMaxK; k++)
-                        if (k < K && pick == -2) {
-                            run += f[k];
-                            if (f[k] > 0.0) last = k;
-                            if (target < run) pick = k;
-                        }
-                    if (pick == -2) pick = (last >= 0) ? last : ((gl == 0 && f0 > 0.0) ? -1 : -2);
-                }
-            }
-            if (pick == -1) ++noise;
-            if (uniform) {
-                if (!in_run) {
-                    in_run = true; run_lg = lg; run_K = K;
-#pragma unroll
-                    for (int k = 0; k < kMaxK; k++) if (k < K) rsid[k] = id[k];
-                }
-#pragma unroll
-                for (int k = 0; k < kMaxK; k++) if (k < K) acc[k] += (pick == k);
-            } else if (pick >= 0) {
-                int sidp = 0;
-#pragma unroll
-                for (int k = 0; k < kMaxK; k++) if (k == pick) sidp = id[k];
-                atomicAdd(&counts[sidp], 1);
             }
         }
-        if (in_run) {
+        const double f0 = g0 * cur.nc;
+        double f[K];
+        double part = f0;
 #pragma unroll
-            for (int k = 0; k < kMaxK; k++)
-                if (k < run_K) {
-                    int t = strided_sum_i(acc[k], run_lg);
-                    if (lane < (1 << run_lg) && t != 0) atomicAdd(&counts[rsid[k]], t);
-                }
+        for (int k = 0; k < K; k++) {
+            f[k] = rg[k] * cur.c[k];
+            part += f[k];
+        }
+        double incl = part;  // inclusive scan over the G lanes of the read
+        for (int d = 1; d < G; d <<= 1) {
+            double o = __shfl_up(incl, d);
+            if (gl >= d) incl += o;
+        }
+        double excl = __shfl_up(incl, 1);
+        if (gl == 0) excl = 0.0;
+        const double total = __shfl(incl, gbase + G - 1);
+        // one uniform per read, keyed by the read's position in the sorted order (layout independent)
+        const uint32_t sl = s - S.slice_base;
+        const uint32_t b = sl / T, t = sl % T, r = (uint32_t)lane >> lg;
+        const uint32_t left = S.n_rows - b * R * T;
+        const uint32_t nb = left < R * T ? left : R * T;
+        const uint32_t Tb = (nb + R - 1) / R;
+        const uint32_t p = S.row_base + b * R * T + r * Tb + t;
+        uint32_t rnd[4] = {0, 0, 0, 0};
+        if (g0lane) ph.gen(p, sweep, 0x5a5a5a5au, 0u, rnd);
+        const double u = __shfl(u53(rnd[0], rnd[1]), gbase);
+        double target = u * total;
+        if (target >= total) target = total * (1.0 - 1.1102230246251565e-16);
+        int pick = -2;  // -2: not mine, -1: noise, k >= 0: my plane k
+        if (total > 0.0 && target >= excl && target < incl) {
+            double run = excl;
+            if (g0lane) { run += f0; if (target < run) pick = -1; }
+            if (pick == -2) {
+                int last = -2;
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    if (pick == -2) {
+                        run += f[k];
+                        if (f[k] > 0.0) last = k;
+                        if (target < run) pick = k;
+                    }
+                if (pick == -2) pick = (last >= 0) ? last : ((g0lane && f0 > 0.0) ? -1 : -2);
+            }
+        }
+        noise += (pick == -1);
+#pragma unroll
+        for (int k = 0; k < K; k++) acc[k] += (pick == k);
+    };
+    SliceRegs<K> A, B;
+    unsigned long long mA = ~0ull, mB = 0;
+    issue(s_begin, mA, A);
+    for (uint32_t s = s_begin; s < s_end; s += 2) {
+        if (s + 1 < s_end) { mB = mask_of(s + 1); issue(s + 1, mB, B); }
+        sample(A, mA, s);
+        if (s + 1 >= s_end) break;
+        if (s + 2 < s_end) { mA = mask_of(s + 2); issue(s + 2, mA, A); }
+        sample(B, mB, s + 1);
+    }
+    spill();
+}
+
+__global__ __launch_bounds__(kBlock) void k_sample_z_lane(
+    const Shape* __restrict__ shapes, const Unit* __restrict__ units, uint32_t T, int M,
+    const double* __restrict__ g, const double* __restrict__ scp, const int32_t* __restrict__ ssid,
+    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks, Philox ph, uint32_t sweep,
+    int32_t* counts) {
+    __shared__ double g_win[kGWindow];
+    __shared__ int cnt_win[kGWindow];
+    __shared__ Shape sS;
+    __shared__ int s_noise;
+    const Unit U = units[blockIdx.x];
+    if (threadIdx.x == 0) { sS = shapes[U.shape]; s_noise = 0; }
+    for (int i = threadIdx.x; i < kGWindow; i += blockDim.x) {
+        const int sidv = U.base + i;
+        g_win[i] = (sidv >= 0 && sidv <= M) ? g[sidv] : 0.0;
+        cnt_win[i] = 0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int noise = 0;
+    if (w < U.n_blocks) {
+        Shape S;
+        S.plane_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sS.plane_base >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sS.plane_base);
+        S.slice_base = __builtin_amdgcn_readfirstlane(sS.slice_base);
+        S.n_slices = __builtin_amdgcn_readfirstlane(sS.n_slices);
+        S.row_base = __builtin_amdgcn_readfirstlane(sS.row_base);
+        S.n_rows = __builtin_amdgcn_readfirstlane(sS.n_rows);
+        S.slot_base = __builtin_amdgcn_readfirstlane(sS.slot_base);
+        S.K = __builtin_amdgcn_readfirstlane(sS.K);
+        S.lg = __builtin_amdgcn_readfirstlane(sS.lg);
+        const uint32_t blk = U.block_begin + w;
+        const uint32_t s_begin = S.slice_base + blk * T;
+        const uint32_t s_end = min(S.slice_base + S.n_slices, s_begin + T);
+        const double g0 = g[0];
+        switch (S.K) {
+            case 1: gibbs_block<1>(S, T, s_begin, s_end, lane, U.base, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
+            case 2: gibbs_block<2>(S, T, s_begin, s_end, lane, U.base, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
+            case 3: gibbs_block<3>(S, T, s_begin, s_end, lane, U.base, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
+            default: gibbs_block<4>(S, T, s_begin, s_end, lane, U.base, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
         }
     }
     for (int d = 32; d >= 1; d >>= 1) noise += __shfl_xor(noise, d);
     if (lane == 0 && noise) atomicAdd(&s_noise, noise);
     __syncthreads();
+    for (int i = threadIdx.x; i < kGWindow; i += blockDim.x) {
+        const int v = cnt_win[i];
+        if (v != 0) atomicAdd(&counts[U.base + i], v);
+    }
     if (threadIdx.x == 0 && s_noise) atomicAdd(&counts[0], s_noise);
 }
 
-// reads with > 512 alignments: thread per read over the caller's CSR
+// reads with > 256 alignments: thread per read over the caller's CSR
 __global__ void k_sample_z_long(uint32_t n_rows, const uint32_t* __restrict__ row_list, uint32_t row_id_base,
                                 const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
                                 const double* __restrict__ cp, const double* __restrict__ ncp,
@@ -499,8 +547,8 @@ struct rsem_gibbs_ctx {
     SellLayout L;
     double* d_scp = nullptr;
     double* d_sncp = nullptr;
-    uint32_t chunk = 8;
-    int grid_main = 1;
+    Unit* d_units = nullptr;
+    uint32_t n_units = 0;
     // state
     int32_t* d_init_counts = nullptr;
     int32_t* d_counts = nullptr;
@@ -540,7 +588,7 @@ int rsem_gibbs_destroy(rsem_gibbs_ctx* c) {
     hipFree(c->d_init_counts); hipFree(c->d_counts); hipFree(c->d_z); hipFree(c->d_g); hipFree(c->d_alpha);
     hipFree(c->d_eel); hipFree(c->d_mw); hipFree(c->d_grp); hipFree(c->d_tmp);
     for (int i = 0; i < 4; i++) hipFree(c->d_acc[i]);
-    hipFree(c->d_acc_genes); hipFree(c->d_mt);
+    hipFree(c->d_acc_genes); hipFree(c->d_mt); hipFree(c->d_units);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RSEM_OK;
@@ -626,19 +674,24 @@ int rsem_gibbs_create(rsem_gibbs_ctx** out, int device, int32_t M, uint64_t N1, 
     }
     G_TRY(hipStreamSynchronize(st));
 #undef G_TRY
-    int rc = sell_build(c->L, st, N1, M, c->d_row_ptr, c->d_sid);
+    // a fixed block length keeps the layout (and with it nothing but performance) device independent
+    int rc = sell_build(c->L, st, N1, M, c->d_row_ptr, c->d_sid, (uint32_t)c->n_cus * 4 * 6 * 5 / 2);
     if (rc == RSEM_OK) {
-        hipError_t e1 = dmalloc(&c->d_scp, c->L.n_planes * 64), e2 = dmalloc(&c->d_sncp, (size_t)c->L.n_sell_rows);
+        hipError_t e1 = dmalloc(&c->d_scp, c->L.n_planes * 64), e2 = dmalloc(&c->d_sncp, (size_t)c->L.n_slots);
         if (e1 != hipSuccess || e2 != hipSuccess) rc = RSEM_ERR_NOMEM;
     }
     if (rc == RSEM_OK) rc = sell_fill_values(c->L, st, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_scp, c->d_sncp);
     if (rc == RSEM_OK && hipStreamSynchronize(st) != hipSuccess) rc = RSEM_ERR_HIP;
+    std::vector<Unit> units;
+    if (rc == RSEM_OK) rc = sell_build_units(c->L, units);
+    if (rc == RSEM_OK) {
+        c->n_units = (uint32_t)units.size();
+        if (dmalloc(&c->d_units, units.size()) != hipSuccess) rc = RSEM_ERR_NOMEM;
+        else if (!units.empty() &&
+                 hipMemcpy(c->d_units, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice) != hipSuccess)
+            rc = RSEM_ERR_HIP;
+    }
     if (rc != RSEM_OK) { rsem_gibbs_destroy(c); return rc; }
-    int waves = c->n_cus * 8 * (kBlock / 64);
-    uint32_t ch = c->L.n_slices / (uint32_t)(waves * 4);
-    c->chunk = std::min<uint32_t>(64, std::max<uint32_t>(4, ch));
-    uint32_t n_chunks = (c->L.n_slices + c->chunk - 1) / c->chunk;
-    c->grid_main = std::max(1, std::min<int>(c->n_cus * 8, (int)((n_chunks + 3) / 4)));
     *out = c;
     return RSEM_OK;
 }
@@ -667,10 +720,9 @@ int rsem_gibbs_run(rsem_gibbs_ctx* c, int mode, uint32_t seed, int burnin, int n
     auto parallel_z = [&](uint32_t sw) -> int {
         hipLaunchKernelGGL(k_reset_counts, dim3(gM), dim3(kBlock), 0, st, c->M, c->d_init_counts, (int32_t)c->N0,
                            c->d_counts);
-        if (c->L.n_slices)
-            hipLaunchKernelGGL(k_sample_z_sell, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
-                               c->L.n_slices, c->chunk, c->d_g, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_flags, ph, sw,
-                               c->d_counts);
+        if (c->n_units)
+            hipLaunchKernelGGL(k_sample_z_lane, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
+                               c->d_g, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, ph, sw, c->d_counts);
         if (c->L.n_long_rows)
             hipLaunchKernelGGL(k_sample_z_long, dim3(rsem::ceil_div(c->L.n_long_rows, kBlock)), dim3(kBlock), 0, st,
                                c->L.n_long_rows, c->L.d_order + c->L.n_sell_rows, c->L.n_sell_rows, c->d_row_ptr, c->d_sid,

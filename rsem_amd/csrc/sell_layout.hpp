@@ -1,10 +1,16 @@
 // sell_layout.hpp -- the "sliced" device layout shared by the EM and Gibbs kernels.
 //
-// Reads (CSR rows) are radix-sorted on the device by (shape, min sid, hash of the sid tuple) and
-// packed into 64-lane slices: G = 2^lg lanes per read (G = 1 for reads with <= 8 alignments, up to
-// 64 for <= 512), K <= 8 planes of 64 entries per slice; lane l of plane k holds alignment
-// k*G + (l % G) of read l / G of the slice.  Reads with > 512 alignments stay in the caller's CSR
-// ("long rows").  Included by em.hip and gibbs.hip (each TU gets its own copy of the kernels).
+// Reads (CSR rows) are radix-sorted on the device by (shape, min sid, hash of the sid tuple), so
+// reads hitting the same transcript set become neighbours, and packed into 64-lane slices:
+// G = 2^lg lanes per read (G = 1 for reads with <= 4 alignments, up to 64 for <= 256), K <= 4 planes
+// of 64 entries per slice; lane l of plane k holds alignment k*G + (l % G) of the read in row slot
+// l / G of the slice.  Slices are grouped in BLOCKS of T consecutive slices = one wave's work; inside
+// a block the sorted reads are laid out LANE-MAJOR: row slot r walks T consecutive sorted reads over
+// the block's T slices.  A lane therefore sees long runs of reads with the identical sid tuple and
+// can keep their partial counts in registers, while every global load stays a fully coalesced
+// 256 B (sid) / 512 B (conprb) wave access.  A 64-bit mask per slice tells which lanes start a new
+// tuple there.  Reads with > 256 alignments stay in the caller's CSR ("long rows").
+// Included by em.hip and gibbs.hip (each TU gets its own copy of the kernels).
 #pragma once
 #include <hipcub/hipcub.hpp>
 
@@ -15,9 +21,9 @@
 
 namespace {
 
-constexpr int kMaxShapes = 56;
-constexpr int kLongShape = 63;      // rows with more than 512 alignments: CSR kernel
-constexpr int kMaxK = 8;
+constexpr int kMaxShapes = 28;
+constexpr int kLongShape = 63;      // rows with more than 256 alignments: CSR kernel
+constexpr int kMaxK = 4;
 constexpr int kBlock = 256;         // 4 waves
 
 struct Shape {
@@ -26,18 +32,31 @@ struct Shape {
     uint32_t n_slices;
     uint32_t row_base;    // first sorted row
     uint32_t n_rows;
+    uint32_t slot_base;   // first row slot (slot = slice * rows_per_slice + r)
     int32_t K;            // planes per slice
     int32_t lg;           // log2(lanes per read)
+    int32_t pad;
 };
 
 __host__ __device__ inline int shape_id_of(uint64_t L) {
-    if (L <= 8) return (int)(L == 0 ? 0 : L - 1);  // lg = 0, K = L
+    if (L <= 4) return (int)(L == 0 ? 0 : L - 1);  // lg = 0, K = L
     int lg = 1;
-    uint64_t cap = 16;
+    uint64_t cap = 8;
     while (L > cap) { cap <<= 1; ++lg; }
     if (lg > 6) return kLongShape;
-    int K = (int)((L + (1u << lg) - 1) >> lg);
-    return lg * 8 + (K - 1);
+    int K = (int)((L + (1u << lg) - 1) >> lg);  // 3 or 4
+    return lg * 4 + (K - 1);
+}
+
+// sorted read q of a shape  ->  (slice within the shape, row slot within the slice)
+__host__ __device__ inline void row_to_slot(const Shape& S, uint32_t T, uint32_t q, uint32_t& slice_local, uint32_t& r) {
+    const uint32_t R = 64u >> S.lg, rpb = R * T;
+    const uint32_t b = q / rpb, qb = q % rpb;
+    const uint32_t left = S.n_rows - b * rpb;
+    const uint32_t nb = left < rpb ? left : rpb;
+    const uint32_t Tb = (nb + R - 1) / R;
+    r = qb / Tb;
+    slice_local = b * T + qb % Tb;
 }
 
 __device__ inline uint32_t mix32(uint32_t h, uint32_t v) {
@@ -80,7 +99,7 @@ __device__ inline int find_shape_by_row(const Shape* shapes, int n, uint32_t p) 
 
 // one thread per sorted row: scatter its alignments into the planes (values optional)
 template <bool kIds>
-__global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint32_t n_sell_rows,
+__global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_sell_rows,
                             const uint32_t* __restrict__ order, const uint64_t* __restrict__ row_ptr,
                             const int32_t* __restrict__ sid, const double* __restrict__ cp,
                             const double* __restrict__ ncp, int32_t* ssid, double* scp, double* sncp) {
@@ -88,25 +107,25 @@ __global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint
     if (p >= n_sell_rows) return;
     int sh = find_shape_by_row(shapes, n_shapes, p);
     const Shape S = shapes[sh];
-    int G = 1 << S.lg, rps = 64 >> S.lg;
-    uint32_t q = p - S.row_base;
-    uint64_t slice_local = q / rps;
-    int r = q % rps;
+    const int G = 1 << S.lg;
+    uint32_t slice_local, r;
+    row_to_slot(S, T, p - S.row_base, slice_local, r);
     uint32_t orig = order[p];
     uint64_t fr = row_ptr[orig];
     int L = (int)(row_ptr[orig + 1] - fr);
-    uint64_t pl0 = (S.plane_base + slice_local * S.K) * 64;
+    uint64_t pl0 = (S.plane_base + (uint64_t)slice_local * S.K) * 64;
     for (int c = 0; c < L; c++) {
         uint64_t idx = pl0 + (uint64_t)(c >> S.lg) * 64 + r * G + (c & (G - 1));
         if (kIds) ssid[idx] = sid[fr + c];
         if (cp) scp[idx] = cp[fr + c];
     }
-    if (ncp) sncp[p] = ncp[orig];
+    if (ncp) sncp[S.slot_base + slice_local * (64u >> S.lg) + r] = ncp[orig];
 }
 
-// bit0: every read of the slice has the same sid tuple; bit1: the slice starts a new run
-__global__ void k_slice_flags(const Shape* __restrict__ shapes, int n_shapes, uint32_t n_slices,
-                              const int32_t* __restrict__ ssid, uint8_t* flags) {
+// per slice: bit l set when lane l's read has a different sid tuple than the same lane's read in
+// the previous slice of its block (= the previous read in sorted order), or starts a block
+__global__ void k_slice_masks(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_slices,
+                              const int32_t* __restrict__ ssid, unsigned long long* masks) {
     __shared__ Shape sh_shapes[kMaxShapes];
     for (int i = threadIdx.x; i < n_shapes; i += blockDim.x) sh_shapes[i] = shapes[i];
     __syncthreads();
@@ -116,62 +135,80 @@ __global__ void k_slice_flags(const Shape* __restrict__ shapes, int n_shapes, ui
     int sh = 0;
     while (sh + 1 < n_shapes && s >= sh_shapes[sh + 1].slice_base) ++sh;
     const Shape S = sh_shapes[sh];
-    int G = 1 << S.lg;
-    uint64_t pl0 = (S.plane_base + (uint64_t)(s - S.slice_base) * S.K) * 64;
-    bool uni = true, same_prev = (s > S.slice_base);
-    for (int k = 0; k < S.K; k++) {
-        int v = ssid[pl0 + (uint64_t)k * 64 + lane];
-        int v0 = __shfl(v, lane & (G - 1));
-        uni = uni && (v == v0);
-        if (same_prev) {
+    const uint32_t sl = s - S.slice_base;
+    uint64_t pl0 = (S.plane_base + (uint64_t)sl * S.K) * 64;
+    bool changed = (sl % T == 0);
+    if (!changed)
+        for (int k = 0; k < S.K; k++) {
+            int v = ssid[pl0 + (uint64_t)k * 64 + lane];
             int pv = ssid[pl0 - (uint64_t)S.K * 64 + (uint64_t)k * 64 + lane];
-            same_prev = (pv == v);
+            changed = changed || (pv != v);
         }
-    }
-    bool all_uni = __all(uni);
-    bool all_same = __all(same_prev);
-    if (lane == 0) flags[s] = (uint8_t)((all_uni ? 1 : 0) | ((all_uni && all_same) ? 0 : 2));
+    // a read occupies G lanes: all of them restart together
+    const int G = 1 << S.lg;
+    unsigned long long m = __ballot(changed);
+    const int gb = lane & ~(G - 1);
+    const unsigned long long grp = (G == 64) ? ~0ull : (((1ull << G) - 1) << gb);
+    m = __ballot((m & grp) != 0);
+    if (lane == 0) masks[s] = m;
 }
 
+// min sid of the read in row slot 0 of every slice (non-decreasing along the blocks of a shape)
+__global__ void k_slice_minsid(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_slices,
+                               const uint64_t* __restrict__ keys_sorted, uint32_t* slice_minsid) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slices) return;
+    int sh = 0;
+    while (sh + 1 < n_shapes && s >= shapes[sh + 1].slice_base) ++sh;
+    const Shape S = shapes[sh];
+    const uint32_t sl = s - S.slice_base, R = 64u >> S.lg;
+    uint32_t q = (sl / T) * R * T + sl % T;  // row slot 0 of this slice
+    slice_minsid[s] = (uint32_t)((keys_sorted[S.row_base + q] >> 32) & 0x3ffffffu);
+}
 
 template <typename T>
 hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)); }
 
 struct SellLayout {
     uint64_t N1 = 0;
+    uint32_t T = 16;              // slices per block (one wave's unit of work)
     uint32_t* d_order = nullptr;  // sorted row -> caller row
     uint32_t n_sell_rows = 0;     // sorted rows that live in the sliced layout
-    uint32_t n_long_rows = 0;     // rows > 512 alignments (tail of d_order)
+    uint32_t n_long_rows = 0;     // rows > 256 alignments (tail of d_order)
     Shape h_shapes[kMaxShapes];
     int n_shapes = 0;
     Shape* d_shapes = nullptr;
     uint32_t n_slices = 0;
+    uint32_t n_slots = 0;
     uint64_t n_planes = 0;
     int32_t* d_ssid = nullptr;
-    uint8_t* d_flags = nullptr;
+    unsigned long long* d_masks = nullptr;
+    uint32_t* d_slice_minsid = nullptr;
 };
 
 inline void sell_free(SellLayout& L) {
-    hipFree(L.d_order); hipFree(L.d_shapes); hipFree(L.d_ssid); hipFree(L.d_flags);
+    hipFree(L.d_order); hipFree(L.d_shapes); hipFree(L.d_ssid); hipFree(L.d_masks); hipFree(L.d_slice_minsid);
     L = SellLayout();
 }
 
-// (re)write the value planes / per-row noise values from the caller-order arrays
+// (re)write the value planes / per-slot noise values from the caller-order arrays
 inline int sell_fill_values(const SellLayout& L, hipStream_t st, const uint64_t* d_row_ptr, const double* d_cp,
                             const double* d_ncp, double* d_scp, double* d_sncp) {
     RSEM_HIP_TRY(hipMemsetAsync(d_scp, 0, sizeof(double) * L.n_planes * 64, st));
+    RSEM_HIP_TRY(hipMemsetAsync(d_sncp, 0, sizeof(double) * L.n_slots, st));
     if (L.n_sell_rows) {
         hipLaunchKernelGGL(k_fill_sell<false>, dim3(rsem::ceil_div(L.n_sell_rows, kBlock)), dim3(kBlock), 0, st,
-                           L.d_shapes, L.n_shapes, L.n_sell_rows, L.d_order, d_row_ptr, (const int32_t*)nullptr, d_cp,
-                           d_ncp, (int32_t*)nullptr, d_scp, d_sncp);
+                           L.d_shapes, L.n_shapes, L.T, L.n_sell_rows, L.d_order, d_row_ptr, (const int32_t*)nullptr,
+                           d_cp, d_ncp, (int32_t*)nullptr, d_scp, d_sncp);
         RSEM_HIP_TRY(hipGetLastError());
     }
     return RSEM_OK;
 }
 
-// sort the rows, derive the shape table, scatter the sid planes and classify the slices
+// sort the rows, derive the shape table, scatter the sid planes and compute the per-slice masks.
+// target_waves: how many wave-sized blocks the caller wants (sets T).
 inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, const uint64_t* d_row_ptr,
-                      const int32_t* d_sid) {
+                      const int32_t* d_sid, uint32_t target_waves, uint32_t forced_T = 0) {
     L.N1 = N1;
     uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
     uint32_t *d_vals = nullptr, *d_first = nullptr;
@@ -212,6 +249,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     L.n_shapes = 0;
     L.n_slices = 0;
     L.n_planes = 0;
+    L.n_slots = 0;
     uint32_t long_first = (h_first[kLongShape] == 0xffffffffu) ? (uint32_t)N1 : h_first[kLongShape];
     L.n_sell_rows = long_first;
     L.n_long_rows = (uint32_t)N1 - long_first;
@@ -221,33 +259,76 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
         for (int j = id + 1; j < kMaxShapes; j++)
             if (h_first[j] != 0xffffffffu) { next = h_first[j]; break; }
         Shape& S = L.h_shapes[L.n_shapes++];
-        S.lg = id / 8;
-        S.K = id % 8 + 1;
+        S.lg = id / 4;
+        S.K = id % 4 + 1;
+        S.pad = 0;
         S.row_base = h_first[id];
         S.n_rows = next - h_first[id];
         uint32_t rps = 64u >> S.lg;
         S.n_slices = (S.n_rows + rps - 1) / rps;
         S.slice_base = L.n_slices;
         S.plane_base = L.n_planes;
+        S.slot_base = L.n_slots;
         L.n_slices += S.n_slices;
         L.n_planes += (uint64_t)S.n_slices * S.K;
+        L.n_slots += S.n_slices * rps;
     }
+    // slices per block: enough blocks to fill the chip a few times over, long enough lane runs
+    uint32_t T = forced_T ? forced_T : L.n_slices / std::max(1u, target_waves);
+    L.T = std::min<uint32_t>(256, std::max<uint32_t>(forced_T ? 1 : 8, T));
     RSEM_HIP_TRY(dmalloc(&L.d_shapes, kMaxShapes));
     RSEM_HIP_TRY(hipMemcpyAsync(L.d_shapes, L.h_shapes, sizeof(Shape) * kMaxShapes, hipMemcpyHostToDevice, st));
     RSEM_HIP_TRY(dmalloc(&L.d_ssid, L.n_planes * 64));
-    RSEM_HIP_TRY(dmalloc(&L.d_flags, (size_t)L.n_slices));
+    RSEM_HIP_TRY(dmalloc(&L.d_masks, (size_t)L.n_slices));
+    RSEM_HIP_TRY(dmalloc(&L.d_slice_minsid, (size_t)L.n_slices));
     RSEM_HIP_TRY(hipMemsetAsync(L.d_ssid, 0, sizeof(int32_t) * L.n_planes * 64, st));
     if (L.n_sell_rows) {
         hipLaunchKernelGGL(k_fill_sell<true>, dim3(rsem::ceil_div(L.n_sell_rows, kBlock)), dim3(kBlock), 0, st,
-                           L.d_shapes, L.n_shapes, L.n_sell_rows, L.d_order, d_row_ptr, d_sid, (const double*)nullptr,
+                           L.d_shapes, L.n_shapes, L.T, L.n_sell_rows, L.d_order, d_row_ptr, d_sid, (const double*)nullptr,
                            (const double*)nullptr, L.d_ssid, (double*)nullptr, (double*)nullptr);
         RSEM_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_slice_flags, dim3(rsem::ceil_div(L.n_slices, kBlock / 64)), dim3(kBlock), 0, st,
-                           L.d_shapes, L.n_shapes, L.n_slices, L.d_ssid, L.d_flags);
+        hipLaunchKernelGGL(k_slice_minsid, dim3(rsem::ceil_div(L.n_slices, kBlock)), dim3(kBlock), 0, st, L.d_shapes,
+                           L.n_shapes, L.T, L.n_slices, d_keys2, L.d_slice_minsid);
+        RSEM_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_slice_masks, dim3(rsem::ceil_div(L.n_slices, kBlock / 64)), dim3(kBlock), 0, st,
+                           L.d_shapes, L.n_shapes, L.T, L.n_slices, L.d_ssid, L.d_masks);
         RSEM_HIP_TRY(hipGetLastError());
     }
     RSEM_HIP_TRY(hipStreamSynchronize(st));
     cleanup();
+    return RSEM_OK;
+}
+
+// One workgroup's work: up to 4 consecutive blocks (one per wave) of one shape, plus the base of its
+// LDS windows = the smallest sid any of its reads can touch.
+struct Unit {
+    int32_t shape;
+    uint32_t block_begin;  // block index within the shape
+    int32_t n_blocks;      // 1..4
+    int32_t base;
+};
+
+inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units) {
+    std::vector<uint32_t> ms(L.n_slices);
+    if (L.n_slices)
+        RSEM_HIP_TRY(hipMemcpy(ms.data(), L.d_slice_minsid, sizeof(uint32_t) * L.n_slices, hipMemcpyDeviceToHost));
+    units.clear();
+    for (int sh = 0; sh < L.n_shapes; sh++) {
+        const Shape& S = L.h_shapes[sh];
+        const uint32_t nb = (S.n_slices + L.T - 1) / L.T;
+        for (uint32_t b = 0; b < nb; b += kBlock / 64) {
+            Unit U;
+            U.shape = sh;
+            U.block_begin = b;
+            U.n_blocks = (int32_t)std::min<uint32_t>(kBlock / 64, nb - b);
+            U.base = (int32_t)ms[S.slice_base + b * L.T];
+            units.push_back(U);
+        }
+    }
+    // longest-processing-time-first: the hardware hands workgroups out in order
+    std::stable_sort(units.begin(), units.end(), [&](const Unit& a, const Unit& b) {
+        return L.h_shapes[a.shape].K * a.n_blocks > L.h_shapes[b.shape].K * b.n_blocks;
+    });
     return RSEM_OK;
 }
 

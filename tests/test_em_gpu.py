@@ -15,7 +15,7 @@ from tools.synth_data import make_em_workload
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [1, 2, 3]  # CSR, SELL, SELLRUN
+VARIANTS = [1, 2, 3]  # CSR, SELL, LANE
 
 
 def capi():
@@ -136,7 +136,7 @@ def test_edge_cases():
     M = 3
     rp = np.array([0, 2, 3, 5], np.uint64)
     sid = np.array([1, 2, 3, 1, 3], np.int32)
-    cp = np.array([1e-5, 2e-5, 1e-299, 1e-200, 1e-200], np.float64)
+    cp = np.array([1e-5, 2e-5, 1e-300, 1e-200, 1e-200], np.float64)
     ncp = np.array([1e-9, 0.0, 1e-250], np.float64)
     theta = np.array([0.1, 0.3, 0.3, 0.3])
     for v in VARIANTS:

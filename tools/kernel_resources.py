@@ -23,7 +23,8 @@ for k, v in rows.items():
     if "rocprim" in k or "hipcub" in k:
         continue
     name = subprocess.run(["c++filt", k], stdout=subprocess.PIPE, text=True).stdout.strip()
-    name = re.sub(r"\(.*", "", name).replace("(anonymous namespace)::", "")
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    name = re.sub(r"\(.*", "", name)
     print("%-40s VGPR %3d AGPR %3d SGPR %3d scratch %4d LDS %6d occ %d" % (
         name[:40], v.get("VGPRs", -1), v.get("AGPRs", -1), v.get("TotalSGPRs", -1), v.get("ScratchSize [bytes/lane]", -1),
         v.get("LDS Size [bytes/block]", -1), v.get("Occupancy [waves/SIMD]", -1)))
