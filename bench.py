@@ -191,7 +191,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else "read-sharded x%d + RCCL all-reduce(M+1 f64)/round" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "k_estep_sell (E step)", "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": "k_estep_lane (E step)", "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": estep_ms},
             "checks": {"theta_sum": theta_sum},
             "gibbs": gibbs,

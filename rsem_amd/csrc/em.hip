@@ -44,6 +44,7 @@ struct Ctrl {  // device-resident loop control, one per ctx
     int final_round;
     int totNum;               // accumulating
     unsigned int ticket;
+    unsigned int bar;         // grid barrier of the fused M-step kernel
     unsigned long long bbits; // accumulating max |dtheta|/theta as ordered bits
     double last_sum;
     double last_bchange;
@@ -440,6 +441,107 @@ __global__ __launch_bounds__(kBlock) void k_mstep_apply(int32_t M, const double*
     }
 }
 
+
+constexpr int kMstepBlocks = 32;
+
+// Fused M step: one launch, <= 32 co-resident workgroups, one grid barrier.
+//   phase 1: counts[0] += noise partials + N0 (EM.cpp:392); per-workgroup partial sums of counts
+//   phase 2: theta = counts / sum (EM.cpp:394-398), convergence statistics (EM.cpp:406-413), counts
+//            zeroed for the next round; the last workgroup evaluates the stop rule (EM.cpp:416).
+__global__ __launch_bounds__(kBlock) void k_mstep_fused(int32_t M, double N0, double* counts,
+                                                         const double* __restrict__ noise_a, int n_a,
+                                                         const double* __restrict__ noise_b, int n_b,
+                                                         double* partials, const double* __restrict__ theta_old,
+                                                         double* theta_new, double* counts_last, Ctrl* ctrl, int round,
+                                                         int min_round, int max_round) {
+    if (ctrl->done) return;
+    const int n = M + 1;
+    const int nb = gridDim.x;
+    const int per = (n + nb - 1) / nb;
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    // phase 1: this workgroup's share of sum(counts) and of the noise partials
+    double v = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) v += counts[i];
+    const double t_counts = block_sum_det(v);
+    const int n_noise = n_a + n_b;
+    const int nper = (n_noise + nb - 1) / nb;
+    const int nlo = blockIdx.x * nper, nhi = min(n_noise, nlo + nper);
+    v = 0.0;
+    for (int i = nlo + threadIdx.x; i < nhi; i += blockDim.x) v += (i < n_a) ? noise_a[i] : noise_b[i - n_a];
+    const double t_noise = block_sum_det(v);
+    // grid barrier (all workgroups are resident: gridDim <= 32)
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partials[blockIdx.x], t_counts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partials[kMstepBlocks + blockIdx.x], t_noise, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&ctrl->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(&ctrl->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nb) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    // lanes 0..31 of wave 0 load the count partials, lanes 32..63 the noise partials; fixed summation order
+    __shared__ double s_sum[2];
+    if (threadIdx.x < 64) {
+        const int li = threadIdx.x & 31;
+        double pv = (li < nb) ? __hip_atomic_load(&partials[(threadIdx.x < 32 ? 0 : kMstepBlocks) + li], __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT)
+                              : 0.0;
+        for (int d = 1; d < 32; d <<= 1) pv += __shfl_xor(pv, d);
+        if (threadIdx.x == 0) s_sum[0] = pv;
+        if (threadIdx.x == 32) s_sum[1] = pv;
+    }
+    __syncthreads();
+    const double extra0 = s_sum[1] + N0;      // counts[0] += noise + N0 (EM.cpp:392)
+    const double sum = s_sum[0] + extra0;
+    int tot = 0;
+    double bmax = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        double c = counts[i] + (i == 0 ? extra0 : 0.0);
+        double th = c / sum;
+        theta_new[i] = th;
+        counts_last[i] = c;
+        counts[i] = 0.0;
+        double old = theta_old[i];
+        if (old >= 1e-7) {
+            double change = fabs(th - old) / old;
+            if (change >= 0.001) ++tot;
+            bmax = fmax(bmax, change);
+        }
+    }
+    __shared__ int s_tot[kBlock / 64];
+    __shared__ double s_b[kBlock / 64];
+    for (int d = 32; d >= 1; d >>= 1) {
+        tot += __shfl_xor(tot, d);
+        bmax = fmax(bmax, __shfl_xor(bmax, d));
+    }
+    if ((threadIdx.x & 63) == 0) { s_tot[threadIdx.x >> 6] = tot; s_b[threadIdx.x >> 6] = bmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kBlock / 64; i++) { tot += s_tot[i]; bmax = fmax(bmax, s_b[i]); }
+        if (tot) atomicAdd(&ctrl->totNum, tot);
+        atomicMax(&ctrl->bbits, (unsigned long long)__double_as_longlong(bmax));
+        __threadfence();
+        unsigned int tk = atomicAdd(&ctrl->ticket, 1u);
+        if (tk == gridDim.x - 1) {
+            int totNum = atomicAdd(&ctrl->totNum, 0);
+            unsigned long long bb = atomicMax(&ctrl->bbits, 0ull);
+            ctrl->last_sum = sum;
+            ctrl->last_bchange = __longlong_as_double((long long)bb);
+            ctrl->last_totNum = totNum;
+            ctrl->last_round = round;
+            if (!(round < min_round || (totNum > 0 && round < max_round))) {
+                ctrl->done = 1;
+                ctrl->final_round = round;
+            }
+            atomicExch(&ctrl->totNum, 0);
+            atomicExch(&ctrl->bbits, 0ull);
+            atomicExch(&ctrl->ticket, 0u);
+            atomicExch(&ctrl->bar, 0u);
+        }
+    }
+}
+
 }  // namespace
 
 // ---- ctx -------------------------------------------------------------------------------------
@@ -526,11 +628,10 @@ int n_noise_b(const rsem_em_ctx* c) {
 
 int launch_mstep(rsem_em_ctx* c, double N0, double* d_counts, const double* d_theta_old, double* d_theta_new,
                  int round, int min_round, int max_round, hipStream_t st) {
-    hipLaunchKernelGGL(k_mstep_reduce, dim3(kReduceBlocks), dim3(kBlock), 0, st, c->M, N0, d_counts, c->d_noise_a,
-                       c->noise_n, c->d_noise_b, n_noise_b(c), c->d_partials, (const Ctrl*)c->d_ctrl);
-    RSEM_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_mstep_apply, dim3(c->grid_apply), dim3(kBlock), 0, st, c->M, c->d_partials, kReduceBlocks,
-                       d_counts, d_theta_old, d_theta_new, c->d_counts_last, c->d_ctrl, round, min_round, max_round);
+    const int grid = std::max(1, std::min(kMstepBlocks, rsem::ceil_div((uint64_t)c->M + 1, kBlock * 4)));
+    hipLaunchKernelGGL(k_mstep_fused, dim3(grid), dim3(kBlock), 0, st, c->M, N0, d_counts, c->d_noise_a, c->noise_n,
+                       c->d_noise_b, n_noise_b(c), c->d_partials, d_theta_old, d_theta_new, c->d_counts_last, c->d_ctrl,
+                       round, min_round, max_round);
     RSEM_HIP_TRY(hipGetLastError());
     return RSEM_OK;
 }
@@ -631,7 +732,7 @@ int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64
     TRY_OR_FAIL(dmalloc(&c->d_counts, (size_t)M + 1));
     TRY_OR_FAIL(dmalloc(&c->d_counts_last, (size_t)M + 1));
     TRY_OR_FAIL(dmalloc(&c->d_noise_b, (size_t)c->n_cus * 8));
-    TRY_OR_FAIL(dmalloc(&c->d_partials, kReduceBlocks));
+    TRY_OR_FAIL(dmalloc(&c->d_partials, 2 * kReduceBlocks));
     TRY_OR_FAIL(dmalloc(&c->d_ctrl, 1));
     TRY_OR_FAIL(hipMemsetAsync(c->d_counts, 0, sizeof(double) * ((size_t)M + 1), c->stream));
     TRY_OR_FAIL(hipMemsetAsync(c->d_noise_b, 0, sizeof(double) * c->n_cus * 8, c->stream));
