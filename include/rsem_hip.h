@@ -103,6 +103,83 @@ int rsem_em_mstep_device(rsem_em_ctx* ctx, void* d_counts, double N0_global, con
                          void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Read models (rounds 1-11 of rsem-run-em).  Replaces the per-read / per-alignment work of
+ * SingleModel / SingleQModel / PairedEndModel / PairedEndQModel: getConPrb + getNoiseConPrb
+ * (SingleQModel.h:101-162, PairedEndQModel.h:94-155 and the no-quality twins) as used by
+ * E_STEP<> when needCalcConPrb (EM.cpp:210,216) and calcConProbs (EM.cpp:249-278), and
+ * update + updateNoise (SingleQModel.h:168-221, PairedEndQModel.h:161-188) when updateModel
+ * (EM.cpp:226,233).  The O(table) work between rounds (init / collect / finish / calcMW) stays
+ * with the caller (rsem_amd/csrc/host/model_host.hpp).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rsem_model_ctx rsem_model_ctx;
+
+/* Immutable inputs, all in the order of imd.dat / imd_alignable*.f[aq] (host pointers, copied). */
+typedef struct {
+    int32_t model_type;          /* 0 Single, 1 SingleQ, 2 PairedEnd, 3 PairedEndQ */
+    int32_t M;
+    uint64_t N1, nnz;
+    const uint64_t* row_ptr;     /* [N1+1] */
+    const int32_t* sid_signed;   /* [nnz] as in .dat: negative = reverse strand (SingleHit.h:24-26) */
+    const int32_t* pos;          /* [nnz] */
+    const int32_t* insertL;      /* [nnz], paired-end only (PairedEndHit.h:8-34), else NULL */
+    /* reads: base ids 0..4 = A C G T N (utils.h:36-50), quality = ASCII - 33 (QProfile.h:44); mate 2 NULL for SE */
+    const uint64_t* read_off[2]; /* [N1+1] offsets into read_seq / read_qual */
+    const uint8_t* read_seq[2];
+    const uint8_t* read_qual[2]; /* NULL for the no-quality models */
+    const uint8_t* low_quality;  /* [N1] Read::isLowQuality() after calc_lq (SingleReadQ.h:63-95, PairedEndReadQ.h:55-62) */
+    /* references (RefSeq.h): forward-strand base ids incl. poly(A) tail, concatenated */
+    const uint64_t* ref_off;     /* [M+2], ref_off[0] = ref_off[1] = 0 */
+    const uint8_t* ref_seq;
+    const int32_t* fullLen;      /* [M+1] */
+    const int32_t* totLen;       /* [M+1] */
+    const uint64_t* mask_off;    /* [M+2] offsets (in 32-bit words) into mask_words */
+    const uint32_t* mask_words;  /* RefSeq::fmasks */
+} rsem_model_data;
+
+/* The current model parameters (one EM round's view of the master model). */
+typedef struct {
+    double probF;                /* Orientation */
+    int32_t seedLen;
+    int32_t estRSPD, B;          /* RSPD: pdf/cdf [B+2] */
+    const double* rspd_pdf;
+    const double* rspd_cdf;
+    int32_t gld_lb, gld_ub;      /* LenDist gld: pdf/cdf [ub-lb+1] */
+    const double* gld_pdf;
+    const double* gld_cdf;
+    int32_t has_mld, mld_lb, mld_ub;
+    const double* mld_pdf;
+    const double* mld_cdf;
+    int32_t prof_rows;           /* 100 (QProfile) or proLen (Profile) */
+    const double* prof;          /* [prof_rows*25]  p[q or i][ref][read] */
+    const double* noise;         /* [100*5] NoiseQProfile p, or [5] NoiseProfile p */
+    const double* mw;            /* [M+1] */
+} rsem_model_tables;
+
+/* Sums accumulated by one rsem_model_estep_update (the merged helper models of EM.cpp:400-404). */
+typedef struct {
+    double* prof;                /* [prof_rows*25] */
+    double* noise;               /* [100*5] or [5] */
+    double* rspd;                /* [B+2] (estRSPD only, else may be NULL) */
+    double* gld;                 /* [gld0_ub-gld0_lb+1] over the ORIGINAL support (paired-end only, else NULL) */
+    int32_t gld0_lb, gld0_ub;    /* in: support of the helper models' gld (mparams minL-1, maxL) */
+} rsem_model_accum;
+
+/* `em` must have been created with the same CSR (|sid_signed|); the model ctx writes the CSR values of
+ * `em` on the device and drives its E step. */
+int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_data* data);
+int rsem_model_set_tables(rsem_model_ctx* ctx, const rsem_model_tables* t);
+/* conprb of every alignment and the noise conprb of every read with the current tables -> em values */
+int rsem_model_calc_conprb(rsem_model_ctx* ctx);
+/* One round with updateModel = true (EM.cpp:199-236): E step, counts/theta_new/statistics as
+ * rsem_em_step, plus the model sufficient statistics weighted by the posterior fractions. */
+int rsem_model_estep_update(rsem_model_ctx* ctx, const double* theta, double N0, double* counts,
+                            double* theta_new, double* sum, double* bChange, int32_t* totNum,
+                            rsem_model_accum* acc);
+/* current CSR values back to the host in file order (for imd.ofg, EM.cpp:421-457) */
+int rsem_model_get_values(rsem_model_ctx* ctx, double* conprb, double* ncp);
+int rsem_model_destroy(rsem_model_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------
  * Gibbs (rsem-run-gibbs).  Replaces: Item / s / hits (Gibbs.cpp:39-47,63-64), Gibbs()
  * (Gibbs.cpp:265-353) incl. sample() (sampling.h:50-65), and the per-chain accumulators that
  * release() sums (Gibbs.cpp:355-388).

@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cmath>
 
+#include "em_internal.hpp"
 #include "sell_layout.hpp"
 
 namespace {
@@ -977,3 +978,69 @@ extern "C" int rsem_em_mstep_device(rsem_em_ctx* c, void* d_counts, double N0_gl
     RSEM_HIP_TRY(hipGetLastError());
     return RSEM_OK;
 }
+
+
+// ---- internal hooks for model.hip (em_internal.hpp) ------------------------------------------------
+namespace rsem {
+
+int em_device_view(rsem_em_ctx* c, EmDeviceView* v) {
+    RSEM_REQUIRE(c && v, "NULL argument");
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_w) RSEM_HIP_TRY(dmalloc(&c->d_w, c->nnz));
+    if (!c->d_wn) RSEM_HIP_TRY(dmalloc(&c->d_wn, c->N1));
+    v->device = c->device;
+    v->stream = c->stream;
+    v->M = c->M;
+    v->N1 = c->N1;
+    v->nnz = c->nnz;
+    v->d_row_ptr = c->d_row_ptr;
+    v->d_sid = c->d_sid;
+    v->d_cp = c->d_cp;
+    v->d_ncp = c->d_ncp;
+    v->d_w = c->d_w;
+    v->d_wn = c->d_wn;
+    return RSEM_OK;
+}
+
+int em_values_changed(rsem_em_ctx* c) {
+    RSEM_REQUIRE(c, "NULL argument");
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    c->have_values = true;
+    return fill_values(c);
+}
+
+int em_step_with_weights(rsem_em_ctx* c, const double* theta, double N0, double* counts, double* theta_new, double* sum,
+                         double* bChange, int32_t* totNum) {
+    RSEM_REQUIRE(c && theta, "NULL argument");
+    if (!c->have_values) { set_last_error("CSR values were never set"); return RSEM_ERR_STATE; }
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t nb = sizeof(double) * ((size_t)c->M + 1);
+    if (!c->d_w) RSEM_HIP_TRY(dmalloc(&c->d_w, c->nnz));
+    if (!c->d_wn) RSEM_HIP_TRY(dmalloc(&c->d_wn, c->N1));
+    RSEM_HIP_TRY(hipMemcpyAsync(c->d_theta[0], theta, nb, hipMemcpyHostToDevice, st));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), st));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_counts, 0, nb, st));
+    const int grid = std::max(1, std::min<int>(c->n_cus * 8, ceil_div(c->N1, kBlock)));
+    hipLaunchKernelGGL(k_estep_csr<true>, dim3(grid), dim3(kBlock), 0, st, c->N1, (const uint32_t*)nullptr, c->d_row_ptr,
+                       c->d_sid, c->d_cp, c->d_ncp, c->d_theta[0], c->d_counts, c->d_noise_a, c->d_w, c->d_wn,
+                       (const Ctrl*)c->d_ctrl);
+    RSEM_HIP_TRY(hipGetLastError());
+    c->noise_n = grid;
+    const int save_kernel = c->kernel;
+    c->kernel = RSEM_EM_KERNEL_CSR;  // n_noise_b(): the CSR launch covered the long rows too
+    int rc = launch_mstep(c, N0, c->d_counts, c->d_theta[0], c->d_theta[1], 1, 1, 1, st);
+    c->kernel = save_kernel;
+    if (rc != RSEM_OK) return rc;
+    Ctrl h;
+    RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
+    if (counts) RSEM_HIP_TRY(hipMemcpyAsync(counts, c->d_counts_last, nb, hipMemcpyDeviceToHost, st));
+    if (theta_new) RSEM_HIP_TRY(hipMemcpyAsync(theta_new, c->d_theta[1], nb, hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipStreamSynchronize(st));
+    if (sum) *sum = h.last_sum;
+    if (bChange) *bChange = h.last_bchange;
+    if (totNum) *totNum = h.last_totNum;
+    return RSEM_OK;
+}
+
+}  // namespace rsem

@@ -1,0 +1,382 @@
+// files.hpp -- readers / writers for the files rsem-run-em and rsem-run-gibbs exchange with the
+// rest of the RSEM pipeline (formats: SURVEY.md Appendix A; each function cites the reference
+// code that defines the format).  Host side of the product; plain C++17, no GPU code here.
+#pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace rsemh {
+
+constexpr double kEpsilon = 1e-300;  // utils.h:19
+constexpr double kMinEel = 1.0;      // utils.h:20
+constexpr int kOLen = 25;            // utils.h:23
+
+// the reference's error convention: message on stderr, exit(-1)  (my_assert.h:89-96)
+[[noreturn]] inline void die(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+    exit(-1);
+}
+
+// read-only memory map of a whole file
+struct MappedFile {
+    const char* data = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    bool open(const std::string& path) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) { ::close(fd); fd = -1; return false; }
+        size = (size_t)st.st_size;
+        if (size == 0) { data = ""; return true; }
+        void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (p == MAP_FAILED) { ::close(fd); fd = -1; return false; }
+        madvise(p, size, MADV_SEQUENTIAL);
+        data = (const char*)p;
+        return true;
+    }
+    ~MappedFile() {
+        if (data && size) munmap((void*)data, size);
+        if (fd >= 0) ::close(fd);
+    }
+};
+
+inline int hardware_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(std::max<unsigned>(n, 1), 32);
+}
+
+// split [begin, end) into ~n chunks that end right after a '\n'
+inline std::vector<size_t> line_chunks(const char* buf, size_t begin, size_t end, int n) {
+    std::vector<size_t> cut{begin};
+    for (int i = 1; i < n; i++) {
+        size_t p = begin + (end - begin) / n * i;
+        if (p <= cut.back()) continue;
+        const char* nl = (const char*)memchr(buf + p, '\n', end - p);
+        if (!nl) break;
+        size_t q = (size_t)(nl - buf) + 1;
+        if (q > cut.back() && q < end) cut.push_back(q);
+    }
+    cut.push_back(end);
+    return cut;
+}
+
+inline void parallel_for(int n, const std::function<void(int)>& fn) {
+    if (n <= 1) { if (n == 1) fn(0); return; }
+    std::vector<std::thread> th;
+    for (int i = 0; i < n; i++) th.emplace_back(fn, i);
+    for (auto& t : th) t.join();
+}
+
+// fast decimal integer (optionally signed); advances p; skips leading blanks (not newlines)
+inline bool parse_long(const char*& p, const char* end, long long& v) {
+    while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) ++p;
+    if (p >= end) return false;
+    bool neg = false;
+    if (*p == '-') { neg = true; ++p; } else if (*p == '+') ++p;
+    if (p >= end || *p < '0' || *p > '9') return false;
+    long long x = 0;
+    while (p < end && *p >= '0' && *p <= '9') { x = x * 10 + (*p - '0'); ++p; }
+    v = neg ? -x : x;
+    return true;
+}
+
+// ---- reference files -------------------------------------------------------------------------
+
+struct RefInfo {  // ref.seq (RefSeq.h:108-138, Refs.h:118-145)
+    int M = 0;
+    bool has_polyA = false;
+    std::vector<int32_t> fullLen, totLen;        // [M+1], index 0 unused
+    std::vector<std::string> seq;                // forward strand incl. poly(A) tail (empty when not loaded)
+    std::vector<std::vector<uint32_t>> masks;    // fmasks words
+    bool mask_at(int sid, int pos) const { return masks[sid][pos / 32] & (1u << (pos % 32)); }
+};
+
+inline RefInfo load_refs(const std::string& path, bool with_seq) {
+    MappedFile f;
+    if (!f.open(path)) die("Cannot open %s! It may not exist.", path.c_str());
+    RefInfo R;
+    R.fullLen.push_back(0); R.totLen.push_back(0); R.seq.emplace_back(); R.masks.emplace_back();
+    const char* p = f.data;
+    const char* end = f.data + f.size;
+    auto next_line = [&](const char*& b, const char*& e) -> bool {
+        if (p >= end) return false;
+        b = p;
+        const char* nl = (const char*)memchr(p, '\n', end - p);
+        e = nl ? nl : end;
+        p = nl ? nl + 1 : end;
+        return true;
+    };
+    const char *b, *e;
+    while (next_line(b, e)) {
+        if (b == e) continue;
+        long long fl, tl;
+        const char* q = b;
+        if (!parse_long(q, e, fl) || !parse_long(q, e, tl)) break;
+        if (!next_line(b, e)) break;  // name
+        if (!next_line(b, e)) break;  // sequence
+        if (with_seq) R.seq.emplace_back(b, e - b); else R.seq.emplace_back();
+        if (!next_line(b, e)) break;  // mask words
+        std::vector<uint32_t> m;
+        q = b;
+        long long w;
+        while (parse_long(q, e, w)) m.push_back((uint32_t)w);
+        R.fullLen.push_back((int32_t)fl);
+        R.totLen.push_back((int32_t)tl);
+        R.masks.push_back(std::move(m));
+        R.has_polyA = R.has_polyA || fl < tl;
+        ++R.M;
+    }
+    return R;
+}
+
+struct TranscriptInfo {  // ref.ti (Transcripts.h:81-94, Transcript.h:119-148)
+    std::string transcript_id, transcript_name, gene_id, gene_name, seqname;
+    int length = 0;
+};
+
+struct Transcripts {
+    int M = 0, type = 0;
+    std::vector<TranscriptInfo> t;  // [M+1]
+};
+
+inline Transcripts load_transcripts(const std::string& path) {
+    FILE* fi = fopen(path.c_str(), "r");
+    if (!fi) die("Cannot open %s! It may not exist.", path.c_str());
+    Transcripts T;
+    if (fscanf(fi, "%d %d", &T.M, &T.type) != 2) die("%s: bad header", path.c_str());
+    char* line = nullptr;
+    size_t cap = 0;
+    auto getl = [&](std::string& s) {
+        ssize_t n = getline(&line, &cap, fi);
+        if (n < 0) die("%s: truncated", path.c_str());
+        while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) --n;
+        s.assign(line, n);
+    };
+    std::string s;
+    getl(s);  // rest of the header line
+    T.t.resize(T.M + 1);
+    for (int i = 1; i <= T.M; i++) {
+        TranscriptInfo& x = T.t[i];
+        getl(s);
+        size_t tab = s.find('\t');
+        x.transcript_id = s.substr(0, tab);
+        x.transcript_name = tab == std::string::npos ? "" : s.substr(tab + 1);
+        getl(s);
+        tab = s.find('\t');
+        x.gene_id = s.substr(0, tab);
+        x.gene_name = tab == std::string::npos ? "" : s.substr(tab + 1);
+        getl(x.seqname);
+        getl(s);  // strand length
+        char strand;
+        if (sscanf(s.c_str(), " %c %d", &strand, &x.length) != 2) die("%s: bad transcript record %d", path.c_str(), i);
+        getl(s);  // structure
+        getl(s);  // left
+    }
+    free(line);
+    fclose(fi);
+    return T;
+}
+
+struct GroupInfo {  // ref.grp / .gt / .ta  (GroupInfo.h:34-53)
+    int m = 0;
+    std::vector<int32_t> starts;  // [m+1]
+    bool load(const std::string& path) {
+        FILE* fi = fopen(path.c_str(), "r");
+        if (!fi) return false;
+        int v;
+        starts.clear();
+        while (fscanf(fi, "%d", &v) == 1) starts.push_back(v);
+        fclose(fi);
+        m = (int)starts.size() - 1;
+        return m >= 0;
+    }
+};
+
+inline bool file_exists(const std::string& p) {
+    struct stat st;
+    return stat(p.c_str(), &st) == 0;
+}
+
+// ---- length distribution (shared by the model file reader and the result math) --------------------
+
+struct LenDist {  // LenDist.h: support (lb, ub], pdf/cdf indexed 1..span
+    int lb = 0, ub = 1, span = 1;
+    std::vector<double> pdf, cdf;
+    LenDist() { reset(1, 1000); }
+    void reset(int minL, int maxL) {  // LenDist.h:20-34 (uniform initial parameters)
+        lb = minL - 1; ub = maxL; span = ub - lb;
+        pdf.assign(span + 1, 0.0); cdf.assign(span + 1, 0.0);
+        for (int i = 1; i <= span; i++) { pdf[i] = 1.0 / span; cdf[i] = i * 1.0 / span; }
+    }
+    int minL() const { return lb + 1; }
+    int maxL() const { return ub; }
+    void trim() {  // LenDist.h:265-294
+        int newlb, newub;
+        for (newlb = 1; newlb <= span && pdf[newlb] < kEpsilon; newlb++) {}
+        newlb--;
+        for (newub = span; newub > newlb && pdf[newub] < kEpsilon; newub--) {}
+        if (!(newlb < newub)) die("LenDist::trim: empty distribution");
+        if (newlb == 0 && newub == span) return;
+        int nspan = newub - newlb;
+        std::vector<double> np(nspan + 1, 0.0), nc(nspan + 1, 0.0);
+        for (int i = 1; i <= nspan; i++) { np[i] = pdf[i + newlb]; nc[i] = cdf[i + newlb]; }
+        pdf.swap(np); cdf.swap(nc);
+        span = nspan; lb += newlb; ub = lb + span;
+    }
+    void finish() {  // LenDist.h:186-199
+        double sum = 0.0;
+        for (int i = 1; i <= span; i++) sum += pdf[i];
+        if (sum <= kEpsilon) die("No valid read to estimate the length distribution!");
+        for (int i = 1; i <= span; i++) { pdf[i] = pdf[i] / sum; cdf[i] = cdf[i - 1] + pdf[i]; }
+        trim();
+    }
+    void read(FILE* fi) {  // LenDist.h:218-233
+        if (fscanf(fi, "%d %d %d", &lb, &ub, &span) != 3) die("model file: bad length distribution");
+        pdf.assign(span + 1, 0.0); cdf.assign(span + 1, 0.0);
+        for (int i = 1; i <= span; i++) {
+            if (fscanf(fi, "%lf", &pdf[i]) != 1) die("model file: bad length distribution");
+            cdf[i] = cdf[i - 1] + pdf[i];
+        }
+        trim();
+    }
+    void write(FILE* fo) const {  // LenDist.h:235-241
+        fprintf(fo, "%d %d %d\n", lb, ub, span);
+        for (int i = 1; i < span; i++) fprintf(fo, "%.10g ", pdf[i]);
+        fprintf(fo, "%.10g\n", pdf[span]);
+    }
+};
+
+// ---- result arithmetic (WriteResults.h:24-104) ---------------------------------------------------
+
+inline std::vector<double> calc_eel(int M, const RefInfo& R, const LenDist& gld) {
+    std::vector<double> clen(gld.span + 1, 0.0), eel(M + 1, 0.0);
+    for (int i = 1; i <= gld.span; i++) clen[i] = clen[i - 1] + gld.pdf[i] * (gld.lb + i);
+    for (int i = 1; i <= M; i++) {
+        int totLen = R.totLen[i], fullLen = R.fullLen[i];
+        int pos1 = std::max(std::min(totLen - fullLen + 1, gld.ub) - gld.lb, 0);
+        int pos2 = std::max(std::min(totLen, gld.ub) - gld.lb, 0);
+        if (pos2 == 0) { eel[i] = 0.0; continue; }
+        eel[i] = fullLen * gld.cdf[pos1] + ((gld.cdf[pos2] - gld.cdf[pos1]) * (totLen + 1) - (clen[pos2] - clen[pos1]));
+        if (eel[i] < kMinEel) eel[i] = 0.0;
+    }
+    return eel;
+}
+
+inline void polish_theta(int M, std::vector<double>& theta, const std::vector<double>& eel, const double* mw) {
+    double sum = 0.0;
+    for (int i = 0; i <= M; i++) {
+        if (i > 0 && (mw[i] < kEpsilon || eel[i] < kEpsilon)) { theta[i] = 0.0; continue; }
+        theta[i] = theta[i] / mw[i];
+        sum += theta[i];
+    }
+    if (!(sum >= kEpsilon)) die("No effective length is no less than %.6f !", kMinEel);
+    for (int i = 0; i <= M; i++) theta[i] /= sum;
+}
+
+inline void calc_expression(int M, const std::vector<double>& theta, const std::vector<double>& eel,
+                            std::vector<double>& tpm, std::vector<double>& fpkm) {
+    double denom = 0.0;
+    std::vector<double> frac(M + 1, 0.0);
+    for (int i = 1; i <= M; i++)
+        if (eel[i] >= kEpsilon) { frac[i] = theta[i]; denom += frac[i]; }
+    if (denom < kEpsilon) denom = 1.0;
+    for (int i = 1; i <= M; i++) frac[i] /= denom;
+    fpkm.assign(M + 1, 0.0);
+    for (int i = 1; i <= M; i++)
+        if (eel[i] >= kEpsilon) fpkm[i] = frac[i] * 1e9 / eel[i];
+    tpm.assign(M + 1, 0.0);
+    denom = 0.0;
+    for (int i = 1; i <= M; i++) denom += fpkm[i];
+    if (denom < kEpsilon) denom = 1.0;
+    for (int i = 1; i <= M; i++) tpm[i] = fpkm[i] / denom * 1e6;
+}
+
+// ---- Gibbs inputs -------------------------------------------------------------------------------
+
+struct OfgData {  // imd.ofg (EM.cpp:435-457): items CSR incl. the noise column
+    int M = 0;
+    uint64_t N0 = 0;
+    std::vector<uint64_t> row_ptr;
+    std::vector<int32_t> sid;
+    std::vector<double> conprb;
+};
+
+inline OfgData load_ofg(const std::string& path) {
+    MappedFile f;
+    if (!f.open(path)) die("Cannot open %s!", path.c_str());
+    OfgData D;
+    const char* p = f.data;
+    const char* end = f.data + f.size;
+    long long M, N0;
+    if (!parse_long(p, end, M) || !parse_long(p, end, N0)) die("%s: bad header", path.c_str());
+    D.M = (int)M; D.N0 = (uint64_t)N0;
+    const char* nl = (const char*)memchr(p, '\n', end - p);
+    size_t body = nl ? (size_t)(nl - f.data) + 1 : f.size;
+    int nt = f.size > (64u << 20) ? hardware_threads() : 1;
+    std::vector<size_t> cut = line_chunks(f.data, body, f.size, nt);
+    int nc = (int)cut.size() - 1;
+    struct Part { std::vector<uint32_t> lens; std::vector<int32_t> sid; std::vector<double> val; };
+    std::vector<Part> parts(nc);
+    parallel_for(nc, [&](int c) {
+        const char* q = f.data + cut[c];
+        const char* e = f.data + cut[c + 1];
+        Part& P = parts[c];
+        while (q < e) {
+            const char* le = (const char*)memchr(q, '\n', e - q);
+            if (!le) le = e;
+            uint32_t n = 0;
+            while (q < le) {
+                long long s;
+                if (!parse_long(q, le, s)) break;
+                char* ep;
+                double v = strtod(q, &ep);  // the line ends in '\n' (or the buffer in a mapped page): strtod stops there
+                if (ep == q) break;
+                q = ep;
+                P.sid.push_back((int32_t)s);
+                P.val.push_back(v);
+                ++n;
+            }
+            // Gibbs.cpp:121-132: every line of the file is a read, even an empty one
+            P.lens.push_back(n);
+            q = le + 1;
+        }
+    });
+    D.row_ptr.push_back(0);
+    for (auto& P : parts) {
+        for (uint32_t n : P.lens) D.row_ptr.push_back(D.row_ptr.back() + n);
+        D.sid.insert(D.sid.end(), P.sid.begin(), P.sid.end());
+        D.conprb.insert(D.conprb.end(), P.val.begin(), P.val.end());
+    }
+    return D;
+}
+
+// first number of each of the 4 entries of stat.cnt line 1 (EM.cpp:607-613)
+inline void load_cnt(const std::string& path, uint64_t& N0, uint64_t& N1, uint64_t& N2, uint64_t& Ntot) {
+    FILE* fi = fopen(path.c_str(), "r");
+    if (!fi) die("Cannot open %s! It may not exist.", path.c_str());
+    unsigned long long a, b, c, d;
+    if (fscanf(fi, "%llu %llu %llu %llu", &a, &b, &c, &d) != 4) die("%s: bad first line", path.c_str());
+    fclose(fi);
+    N0 = a; N1 = b; N2 = c; Ntot = d;
+}
+
+}  // namespace rsemh

@@ -1,0 +1,210 @@
+// reads.hpp -- imd.dat and imd_{un,alignable,max}[_1|_2].f[aq] into packed arrays, once.
+// The reference streams these text files again in every one of rounds 1-11 (EM.cpp:195-202,
+// ReadReader.h); here they are parsed a single time (multi-threaded, mmap) into the byte arrays the
+// device kernels use.  Formats: SURVEY.md Appendix A.
+#pragma once
+#include "files.hpp"
+
+namespace rsemh {
+
+// get_base_id (utils.h:36-50): A C G T N (either case) -> 0..4
+inline const int8_t* base_table() {
+    static int8_t tbl[256];
+    static bool init = false;
+    if (!init) {
+        memset(tbl, -1, sizeof(tbl));
+        tbl['a'] = tbl['A'] = 0; tbl['c'] = tbl['C'] = 1; tbl['g'] = tbl['G'] = 2; tbl['t'] = tbl['T'] = 3; tbl['n'] = tbl['N'] = 4;
+        init = true;
+    }
+    return tbl;
+}
+
+struct ReadFile {
+    uint64_t n = 0;
+    std::vector<uint64_t> off;  // [n+1]
+    std::vector<uint8_t> seq;   // base ids
+    std::vector<uint8_t> qual;  // quality - 33 (FASTQ only)
+    std::vector<uint8_t> lq1;   // Single*Read::calc_lq of this mate alone
+    int len(uint64_t i) const { return (int)(off[i + 1] - off[i]); }
+};
+
+// SingleRead::calc_lq / SingleReadQ::calc_lq (SingleRead.h:57-88, SingleReadQ.h:63-95), on the raw characters
+inline bool calc_lq_single(const char* s, int len, bool hasPolyA, int seedLen) {
+    if (len < seedLen) return true;
+    if (!hasPolyA) return false;
+    int numA = 0, numT = 0, numAO = 0, numTO = 0;
+    const int threshold_1 = int(0.9 * len - 1.5 * sqrt(len * 1.0) + 0.5);
+    const int threshold_2 = (kOLen - 1) / 2 + 1;
+    for (int i = 0; i < len; i++) {
+        if (s[i] == 'A') { ++numA; if (i < kOLen) ++numAO; }
+        if (s[i] == 'T') { ++numT; if (i >= len - kOLen) ++numTO; }
+    }
+    if (numA >= threshold_1) return numAO >= threshold_2;
+    if (numT >= threshold_1) return numTO >= threshold_2;
+    return false;
+}
+
+// FASTA: 2 lines per read; FASTQ: 4 lines per read (SingleRead.h:38-50, SingleReadQ.h:38-56)
+inline ReadFile parse_read_file(const std::string& path, bool fastq, bool hasPolyA, int seedLen) {
+    MappedFile f;
+    if (!f.open(path)) die("Cannot open %s! It may not exist.", path.c_str());
+    const int L = fastq ? 4 : 2;
+    const int nt = f.size > (32u << 20) ? hardware_threads() : 1;
+    std::vector<size_t> cut = line_chunks(f.data, 0, f.size, nt);
+    const int nc = (int)cut.size() - 1;
+    // phase of every chunk = (#lines before it) mod L
+    std::vector<uint64_t> nl(nc, 0);
+    parallel_for(nc, [&](int c) {
+        uint64_t k = 0;
+        const char* p = f.data + cut[c];
+        const char* e = f.data + cut[c + 1];
+        while (p < e) {
+            const char* q = (const char*)memchr(p, '\n', e - p);
+            if (!q) { ++k; break; }  // last line without a newline
+            ++k;
+            p = q + 1;
+        }
+        nl[c] = k;
+    });
+    std::vector<uint64_t> first_line(nc + 1, 0);
+    for (int c = 0; c < nc; c++) first_line[c + 1] = first_line[c] + nl[c];
+    struct Part { std::vector<uint32_t> lens; std::vector<uint8_t> seq, qual, lq; };
+    std::vector<Part> parts(nc);
+    const int8_t* tbl = base_table();
+    const char* fend = f.data + f.size;
+    parallel_for(nc, [&](int c) {
+        Part& P = parts[c];
+        const char* p = f.data + cut[c];
+        const char* e = f.data + cut[c + 1];
+        uint64_t line = first_line[c];
+        auto next = [&](const char*& b, const char*& le) -> bool {  // may run past e to finish a record
+            if (p >= fend) return false;
+            b = p;
+            const char* q = (const char*)memchr(p, '\n', fend - p);
+            le = q ? q : fend;
+            p = q ? q + 1 : fend;
+            ++line;
+            if (le > b && le[-1] == '\r') --le;
+            return true;
+        };
+        const char *b, *le;
+        while (line % L != 0 && p < e) next(b, le);  // skip the tail of a record owned by the previous chunk
+        while (p < e) {
+            if (!next(b, le)) break;
+            if (b == le) continue;  // stray empty line at the end
+            if (*b != (fastq ? '@' : '>')) die("Read file %s does not look like a %s file!", path.c_str(), fastq ? "FASTQ" : "FASTA");
+            if (!next(b, le)) die("%s: truncated record", path.c_str());
+            const int len = (int)(le - b);
+            const size_t o = P.seq.size();
+            P.seq.resize(o + len);
+            for (int i = 0; i < len; i++) {
+                int8_t id = tbl[(unsigned char)b[i]];
+                if (id < 0) die("Found unknown sequence letter %c at function get_base_id!", b[i]);
+                P.seq[o + i] = (uint8_t)id;
+            }
+            P.lq.push_back(calc_lq_single(b, len, hasPolyA, seedLen) ? 1 : 0);
+            P.lens.push_back((uint32_t)len);
+            if (fastq) {
+                if (!next(b, le) || b == le || *b != '+') die("Read file %s does not look like a FASTQ file!", path.c_str());
+                if (!next(b, le)) die("%s: truncated record", path.c_str());
+                if ((int)(le - b) != len) die("%s: quality string and sequence differ in length", path.c_str());
+                P.qual.resize(o + len);
+                for (int i = 0; i < len; i++) {
+                    int qv = (unsigned char)b[i] - 33;  // c2q (QProfile.h:44)
+                    if (qv < 0 || qv > 93) die("%s: quality character out of range", path.c_str());
+                    P.qual[o + i] = (uint8_t)qv;
+                }
+            }
+        }
+    });
+    ReadFile R;
+    R.off.push_back(0);
+    size_t tot = 0;
+    for (auto& P : parts) tot += P.seq.size();
+    R.seq.reserve(tot);
+    if (fastq) R.qual.reserve(tot);
+    for (auto& P : parts) {
+        for (uint32_t l : P.lens) R.off.push_back(R.off.back() + l);
+        R.seq.insert(R.seq.end(), P.seq.begin(), P.seq.end());
+        if (fastq) R.qual.insert(R.qual.end(), P.qual.begin(), P.qual.end());
+        R.lq1.insert(R.lq1.end(), P.lq.begin(), P.lq.end());
+        P = Part();
+    }
+    R.n = R.off.size() - 1;
+    return R;
+}
+
+// genReadFileNames (utils.h:129-149)
+inline std::vector<std::string> read_file_names(const std::string& imdName, int tagType, int read_type) {
+    static const char* tags[3] = {"un", "alignable", "max"};
+    const char* suf = (read_type == 0 || read_type == 2) ? "fa" : "fq";
+    std::vector<std::string> v;
+    if (read_type < 2) v.push_back(imdName + "_" + tags[tagType] + "." + suf);
+    else {
+        v.push_back(imdName + "_" + tags[tagType] + "_1." + suf);
+        v.push_back(imdName + "_" + tags[tagType] + "_2." + suf);
+    }
+    return v;
+}
+
+struct DatData {  // imd.dat (HitContainer.h:63-91, SingleHit.h:44-51, PairedEndHit.h:27-34)
+    uint64_t N1 = 0, nHits = 0;
+    int read_type = 0;
+    std::vector<uint64_t> row_ptr;
+    std::vector<int32_t> sid_signed, pos, insertL;
+};
+
+inline DatData load_dat(const std::string& path, int expect_read_type) {
+    MappedFile f;
+    if (!f.open(path)) die("Cannot open %s! It may not exist.", path.c_str());
+    DatData D;
+    const char* p = f.data;
+    const char* end = f.data + f.size;
+    long long a, b, c;
+    if (!parse_long(p, end, a) || !parse_long(p, end, b) || !parse_long(p, end, c)) die("%s: bad header", path.c_str());
+    D.N1 = (uint64_t)a; D.nHits = (uint64_t)b; D.read_type = (int)c;
+    if (D.read_type != expect_read_type) die("Data file (.dat) does not have the right read type!");
+    const bool pe = D.read_type >= 2;
+    const char* nl = (const char*)memchr(p, '\n', end - p);
+    size_t body = nl ? (size_t)(nl - f.data) + 1 : f.size;
+    const int nt = f.size > (32u << 20) ? hardware_threads() : 1;
+    std::vector<size_t> cut = line_chunks(f.data, body, f.size, nt);
+    const int nc = (int)cut.size() - 1;
+    struct Part { std::vector<uint32_t> lens; std::vector<int32_t> sid, pos, ins; };
+    std::vector<Part> parts(nc);
+    parallel_for(nc, [&](int ci) {
+        Part& P = parts[ci];
+        const char* q = f.data + cut[ci];
+        const char* e = f.data + cut[ci + 1];
+        while (q < e) {
+            const char* le = (const char*)memchr(q, '\n', e - q);
+            if (!le) le = e;
+            long long k;
+            if (parse_long(q, le, k)) {
+                if (k <= 0) die("%s: a read without alignments", path.c_str());
+                for (long long t = 0; t < k; t++) {
+                    long long s, ps, il = 0;
+                    if (!parse_long(q, le, s) || !parse_long(q, le, ps) || (pe && !parse_long(q, le, il)))
+                        die("Cannot read alignments from .dat file!");
+                    P.sid.push_back((int32_t)s);
+                    P.pos.push_back((int32_t)ps);
+                    if (pe) P.ins.push_back((int32_t)il);
+                }
+                P.lens.push_back((uint32_t)k);
+            }
+            q = le + 1;
+        }
+    });
+    D.row_ptr.push_back(0);
+    for (auto& P : parts) {
+        for (uint32_t l : P.lens) D.row_ptr.push_back(D.row_ptr.back() + l);
+        D.sid_signed.insert(D.sid_signed.end(), P.sid.begin(), P.sid.end());
+        D.pos.insert(D.pos.end(), P.pos.begin(), P.pos.end());
+        if (pe) D.insertL.insert(D.insertL.end(), P.ins.begin(), P.ins.end());
+        P = Part();
+    }
+    if (D.row_ptr.size() - 1 != D.N1) die("Number of alignable reads does not match!");
+    return D;
+}
+
+}  // namespace rsemh

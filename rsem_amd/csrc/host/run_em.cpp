@@ -1,0 +1,357 @@
+// rsem-run-em on MI355X: same argv, same files as the reference program (EM.cpp:541-675).
+//
+//   rsem-run-em refName read_type sampleName imdName statName [-p N] [-b samInpF has_fai [fai]] [-q]
+//               [--gibbs-out] [--sampling] [--seed u32] [--append-names]     + ignored-by-the-reference: [--device d]
+//
+// Structure (EM<>() of EM.cpp:313-539): text inputs are parsed ONCE into packed arrays and uploaded;
+// rounds 1-11 recompute the alignment probabilities with the current read model on the GPU
+// (rsem_model_calc_conprb) and, in rounds 1-10, accumulate the model's sufficient statistics
+// (rsem_model_estep_update); the O(table) renormalisation between rounds runs here on the host
+// (model_host.hpp); from round 12 the device-resident loop rsem_em_run takes over.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/rsem_hip.h"
+#include "files.hpp"
+#include "model_host.hpp"
+#include "reads.hpp"
+#include "results.hpp"
+
+using namespace rsemh;
+
+static const int MAX_ROUND = 10000, MIN_ROUND = 20;  // EM.cpp:53-55
+
+static void hip_check(int rc, const char* what) {
+    if (rc != RSEM_OK) die("rsem-run-em: %s failed: %s (%s)", what, rsem_hip_strerror(rc), rsem_hip_last_error());
+}
+
+// boost::math::cdf(normal(mean, sd), x)
+static double normal_cdf(double mean, double sd, double x) { return 0.5 * erfc(-(x - mean) / (sd * sqrt(2.0))); }
+
+// LenDist::setAsNormal (LenDist.h:113-179)
+static void set_as_normal(LenDist& d, double mean, double sd, int minL, int maxL) {
+    const int meanL = int(mean + .5);
+    if (sd < kEpsilon) {
+        if (meanL < minL || meanL > maxL) die("Length distribution's probability mass is not within the possible range! MeanL = %d, MinL = %d, MaxL = %d", meanL, minL, maxL);
+        d.span = 1; d.lb = meanL - 1; d.ub = meanL;
+        d.pdf.assign(2, 0.0); d.cdf.assign(2, 0.0);
+        d.pdf[1] = d.cdf[1] = 1.0;
+        return;
+    }
+    if (maxL - minL + 1 > kRange) {
+        if (meanL <= minL) maxL = minL + kRange - 1;
+        else if (meanL >= maxL) minL = maxL - kRange + 1;
+        else {
+            double lg = mean - (minL - 0.5), rg = (maxL + 0.5) - mean, half = kRange / 2.0;
+            if (lg < half) maxL = minL + kRange - 1;
+            else if (rg < half) minL = maxL - kRange + 1;
+            else { minL = int(mean - half + 1.0); maxL = int(mean + half); }
+        }
+    }
+    d.lb = minL - 1; d.ub = maxL; d.span = d.ub - d.lb;
+    d.pdf.assign(d.span + 1, 0.0); d.cdf.assign(d.span + 1, 0.0);
+    double sum = 0.0, old_val = normal_cdf(mean, sd, minL - 0.5);
+    for (int i = 1; i <= d.span; i++) {
+        double val = normal_cdf(mean, sd, d.lb + i + 0.5);
+        d.pdf[i] = val - old_val;
+        sum += d.pdf[i];
+        old_val = val;
+    }
+    for (int i = 1; i <= d.span; i++) { d.pdf[i] /= sum; d.cdf[i] = d.cdf[i - 1] + d.pdf[i]; }
+    d.trim();
+}
+
+struct ReadSetFiles {  // the three categories of reads (utils.h:129-149): un, alignable, max
+    ReadFile mate[3][2];
+    bool present[3] = {false, false, false};
+};
+
+// *Model::estimateFromReads (SingleQModel.h:283-327, PairedEndQModel.h:241-290 and the no-Q twins)
+static void estimate_from_reads(Model& model, const ReadSetFiles& rs, const RefInfo& refs, std::vector<uint8_t>& lq_alignable) {
+    const bool pe = model.paired(), q = model.hasQ();
+    LenDist& ld = (pe || model.has_mld) ? model.mld : model.gld;
+    std::fill(ld.pdf.begin(), ld.pdf.end(), 0.0);
+    std::fill(ld.cdf.begin(), ld.cdf.end(), 0.0);
+    long n_warns = 0;
+    for (int tag = 0; tag < 3; tag++) {
+        if (!rs.present[tag]) continue;
+        const ReadFile& a = rs.mate[tag][0];
+        const ReadFile& b = rs.mate[tag][1];
+        if (pe && a.n != b.n) die("Mate files of the %d-th read category have different numbers of reads!", tag);
+        if (tag == 1) lq_alignable.assign(a.n, 0);
+        for (uint64_t i = 0; i < a.n; i++) {
+            bool lq;
+            if (!pe) lq = a.lq1[i];
+            else if (a.len(i) < model.P.seedLen || b.len(i) < model.P.seedLen) lq = true;  // PairedEndReadQ.h:55-62
+            else lq = a.lq1[i] && b.lq1[i];
+            if (tag == 1) lq_alignable[i] = lq ? 1 : 0;
+            if (lq) {
+                if (a.len(i) < model.P.seedLen || (pe && b.len(i) < model.P.seedLen)) ++n_warns;
+                continue;
+            }
+            for (int m = 0; m < (pe ? 2 : 1); m++) {
+                const ReadFile& f = m ? b : a;
+                const int len = f.len(i);
+                if (!(len > ld.lb && len <= ld.ub)) die("A read of length %d is outside the length range (%d, %d] given to RSEM!", len, ld.lb, ld.ub);
+                ld.pdf[len - ld.lb] += 1.0;
+                const uint8_t* sq = f.seq.data() + f.off[i];
+                if (q) {
+                    const uint8_t* ql = f.qual.data() + f.off[i];
+                    model.qd_init[ql[0]] += 1.0;  // QualDist::update (QualDist.h:55-65)
+                    for (int k = 1; k < len; k++) model.qd_tran[ql[k - 1] * kQSize + ql[k]] += 1.0;
+                    if (tag == 0)
+                        for (int k = 0; k < len; k++) model.nq_c[ql[k] * 5 + sq[k]] += 1.0;  // NoiseQProfile::updateC
+                } else if (tag == 0) {
+                    for (int k = 0; k < len; k++) model.np_c[sq[k]] += 1.0;  // NoiseProfile::updateC
+                }
+            }
+        }
+    }
+    if (n_warns > 0) fprintf(stderr, "Warning: There are %ld reads ignored in total.\n", n_warns);
+    ld.finish();
+    if (!pe && model.P.mean >= kEpsilon)
+        set_as_normal(model.gld, model.P.mean, model.P.sd, std::max(model.mld.minL(), model.gld.minL()), model.gld.maxL());
+    if (q) {
+        double sum = 0.0;  // QualDist::finish (QualDist.h:67-82)
+        for (int i = 0; i < kQSize; i++) sum += model.qd_init[i];
+        for (int i = 0; i < kQSize; i++) model.qd_init[i] /= sum;
+        for (int i = 0; i < kQSize; i++) {
+            sum = 0.0;
+            for (int j = 0; j < kQSize; j++) sum += model.qd_tran[i * kQSize + j];
+            if (sum <= 0.0) continue;
+            for (int j = 0; j < kQSize; j++) model.qd_tran[i * kQSize + j] /= sum;
+        }
+        for (int i = 0; i < kQSize; i++) {  // NoiseQProfile::calcInitParams (NoiseQProfile.h:100-112)
+            sum = 0.0;
+            for (int j = 0; j < kNCodes; j++) sum += (1.0 + model.nq_c[i * 5 + j]);
+            for (int j = 0; j < kNCodes; j++) model.nq_p[i * 5 + j] = (model.nq_c[i * 5 + j] + 1.0) / sum;
+        }
+    } else {
+        double sum = 0.0;  // NoiseProfile::calcInitParams (NoiseProfile.h:84-95)
+        for (int i = 0; i < kNCodes; i++) sum += (1.0 + model.np_c[i]);
+        for (int i = 0; i < kNCodes; i++) model.np_p[i] = (1.0 + model.np_c[i]) / sum;
+    }
+    model.calc_mw(refs);
+}
+
+static rsem_model_tables tables_of(const Model& m) {
+    rsem_model_tables t;
+    memset(&t, 0, sizeof(t));
+    t.probF = m.probF;
+    t.seedLen = m.P.seedLen;
+    t.estRSPD = m.rspd.est ? 1 : 0;
+    t.B = m.rspd.B;
+    t.rspd_pdf = m.rspd.pdf.data();
+    t.rspd_cdf = m.rspd.cdf.data();
+    t.gld_lb = m.gld.lb; t.gld_ub = m.gld.ub; t.gld_pdf = m.gld.pdf.data(); t.gld_cdf = m.gld.cdf.data();
+    t.has_mld = m.has_mld ? 1 : 0;
+    if (m.has_mld) { t.mld_lb = m.mld.lb; t.mld_ub = m.mld.ub; t.mld_pdf = m.mld.pdf.data(); t.mld_cdf = m.mld.cdf.data(); }
+    if (m.hasQ()) { t.prof_rows = kQSize; t.prof = m.qpro.data(); t.noise = m.nq_p.data(); }
+    else { t.prof_rows = m.proLen; t.prof = m.pro.data(); t.noise = m.np_p; }
+    t.mw = m.mw.data();
+    return t;
+}
+
+int main(int argc, char* argv[]) {
+    if (argc < 6) {
+        printf("Usage : rsem-run-em refName read_type sampleName imdName statName [-p #Threads] [-b samInpF has_fai? [fai_file]] [-q] "
+               "[--gibbs-out] [--sampling] [--seed seed] [--append-names] [--device d]\n\n");
+        printf("// model parameters should be in imdName.mparams.\n");
+        exit(-1);
+    }
+    const auto t_start = std::chrono::steady_clock::now();
+    const std::string refName = argv[1];
+    const int read_type = atoi(argv[2]);
+    const std::string outName = argv[3], imdName = argv[4], statName = argv[5];
+    bool verbose = true, genBamF = false, genGibbsOut = false, appendNames = false;
+    int device = 0;
+    for (int i = 6; i < argc; i++) {  // EM.cpp:578-595; -p is accepted and irrelevant (the GPU is the parallelism)
+        if (!strcmp(argv[i], "-b")) genBamF = true;
+        if (!strcmp(argv[i], "-q")) verbose = false;
+        if (!strcmp(argv[i], "--gibbs-out")) genGibbsOut = true;
+        if (!strcmp(argv[i], "--append-names")) appendNames = true;
+        if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[i + 1]);
+    }
+    if (read_type < 0 || read_type > 3) die("Unknown Read Type!");
+
+    RefInfo refs = load_refs(refName + ".seq", true);
+    const int M = refs.M;
+    if (verbose) printf("Refs.loadRefs finished!\n");
+    Transcripts T = load_transcripts(refName + ".ti");
+    if (T.M != M) die("%s.ti and %s.seq disagree on the number of transcripts!", refName.c_str(), refName.c_str());
+    uint64_t N0, N1, N2, N_tot;
+    load_cnt(statName + ".cnt", N0, N1, N2, N_tot);
+
+    if (N1 == 0) {  // EM.cpp:615-638
+        printf("Warning: There are no alignable reads!\n");
+        fclose(fopen((statName + ".theta").c_str(), "w"));
+        fclose(fopen((statName + ".model").c_str(), "w"));
+        std::vector<double> theta(M + 1, 0.0), eel(M + 1, 0.0), countv(M + 1, 0.0);
+        for (int i = 1; i <= M; ++i) eel[i] = T.t[i].length;
+        write_results_em(M, refName, imdName, T, theta, eel, countv.data(), appendNames);
+        return 0;
+    }
+    if (genBamF) fprintf(stderr, "Warning: this build of rsem-run-em does not write %s.transcript.bam (run rsem-calculate-expression with --no-bam-output).\n", outName.c_str());
+
+    ModelParams P = load_mparams(imdName + ".mparams");
+    const bool pe = read_type >= 2, hasQ = (read_type == 1 || read_type == 3);
+
+    // ---- inputs, parsed once --------------------------------------------------------------------------
+    DatData dat = load_dat(imdName + ".dat", read_type);
+    if (dat.N1 != N1) die("Number of alignable reads does not match!");
+    ReadSetFiles rs;
+    const uint64_t Ncat[3] = {N0, N1, N2};
+    for (int tag = 0; tag < 3; tag++) {
+        if (Ncat[tag] == 0) continue;
+        std::vector<std::string> names = read_file_names(imdName, tag, read_type);
+        for (size_t m = 0; m < names.size(); m++) rs.mate[tag][m] = parse_read_file(names[m], hasQ, refs.has_polyA, P.seedLen);
+        rs.present[tag] = true;
+        if (rs.mate[tag][0].n != Ncat[tag]) die("%s holds %llu reads, %s.cnt says %llu!", names[0].c_str(),
+                                                (unsigned long long)rs.mate[tag][0].n, statName.c_str(), (unsigned long long)Ncat[tag]);
+        if (verbose) printf("estimateFromReads, N%d finished.\n", tag);
+    }
+    Model model;
+    model.init_master(read_type, M, P);
+    std::vector<uint8_t> lq;
+    estimate_from_reads(model, rs, refs, lq);
+    rs.mate[0][0] = ReadFile(); rs.mate[0][1] = ReadFile(); rs.mate[2][0] = ReadFile(); rs.mate[2][1] = ReadFile();
+
+    // ---- device contexts -----------------------------------------------------------------------------
+    int ndev = 0;
+    rsem_hip_device_count(&ndev);
+    if (ndev < 1) die("rsem-run-em: no usable GPU (this program has no CPU path)");
+    const uint64_t nnz = dat.sid_signed.size();
+    std::vector<int32_t> sid_abs(nnz);
+    for (uint64_t j = 0; j < nnz; j++) {
+        int32_t s = dat.sid_signed[j];
+        sid_abs[j] = s < 0 ? -s : s;
+        if (sid_abs[j] < 1 || sid_abs[j] > M) die("%s.dat: transcript id %d out of range", imdName.c_str(), s);
+    }
+    rsem_em_ctx* em = nullptr;
+    hip_check(rsem_em_create(&em, device, M, N1, nnz, dat.row_ptr.data(), sid_abs.data(), nullptr, nullptr), "rsem_em_create");
+    // packed references
+    std::vector<uint64_t> ref_off(M + 2, 0), mask_off(M + 2, 0);
+    for (int i = 1; i <= M; i++) {
+        ref_off[i + 1] = ref_off[i] + refs.seq[i].size();
+        mask_off[i + 1] = mask_off[i] + refs.masks[i].size();
+        if ((int)refs.seq[i].size() != refs.totLen[i]) die("%s.seq: sequence %d has length %zu, header says %d", refName.c_str(), i, refs.seq[i].size(), refs.totLen[i]);
+    }
+    std::vector<uint8_t> ref_seq(ref_off[M + 1]);
+    std::vector<uint32_t> mask_words(mask_off[M + 1]);
+    const int8_t* tbl = base_table();
+    for (int i = 1; i <= M; i++) {
+        for (size_t k = 0; k < refs.seq[i].size(); k++) {
+            int8_t id = tbl[(unsigned char)refs.seq[i][k]];
+            if (id < 0) die("Found unknown sequence letter %c at function get_base_id!", refs.seq[i][k]);
+            ref_seq[ref_off[i] + k] = (uint8_t)id;
+        }
+        std::copy(refs.masks[i].begin(), refs.masks[i].end(), mask_words.begin() + mask_off[i]);
+    }
+    rsem_model_data md;
+    memset(&md, 0, sizeof(md));
+    md.model_type = read_type; md.M = M; md.N1 = N1; md.nnz = nnz;
+    md.row_ptr = dat.row_ptr.data(); md.sid_signed = dat.sid_signed.data(); md.pos = dat.pos.data();
+    md.insertL = pe ? dat.insertL.data() : nullptr;
+    for (int m = 0; m < (pe ? 2 : 1); m++) {
+        md.read_off[m] = rs.mate[1][m].off.data();
+        md.read_seq[m] = rs.mate[1][m].seq.data();
+        md.read_qual[m] = hasQ ? rs.mate[1][m].qual.data() : nullptr;
+    }
+    md.low_quality = lq.data();
+    md.ref_off = ref_off.data(); md.ref_seq = ref_seq.data(); md.fullLen = refs.fullLen.data(); md.totLen = refs.totLen.data();
+    md.mask_off = mask_off.data(); md.mask_words = mask_words.data();
+    rsem_model_ctx* mc = nullptr;
+    hip_check(rsem_model_create(&mc, em, &md), "rsem_model_create");
+    if (verbose) printf("EM_init finished!\n");
+
+    // ---- EM (EM.cpp:343-416) ---------------------------------------------------------------------------
+    std::vector<double> theta(M + 1, 0.0), theta_new(M + 1, 0.0), counts(M + 1, 0.0);
+    theta[0] = std::max(N0 * 1.0 / (N_tot - N2), 1e-8);
+    for (int i = 1; i <= M; i++) theta[i] = (1.0 - theta[0]) / M;
+    Model::Accum acc;
+    acc.prof.assign(hasQ ? (size_t)kQSize * 25 : (size_t)model.proLen * 25, 0.0);
+    acc.noise.assign(hasQ ? (size_t)kQSize * 5 : 5, 0.0);
+    acc.rspd.assign((size_t)model.rspd.B + 2, 0.0);
+    acc.gld.assign((size_t)(P.maxL - (P.minL - 1)) + 1, 0.0);
+    int ROUND = 0, totNum = 0;
+    double sum = 0.0, bChange = 0.0;
+    do {
+        ++ROUND;
+        const bool updateModel = ROUND <= 10;  // doesUpdateModel (EM.cpp:307-310)
+        if (model.needCalcConPrb) {
+            rsem_model_tables t = tables_of(model);
+            hip_check(rsem_model_set_tables(mc, &t), "rsem_model_set_tables");
+            hip_check(rsem_model_calc_conprb(mc), "rsem_model_calc_conprb");
+            model.needCalcConPrb = false;  // EM.cpp:383
+        }
+        if (updateModel) {
+            rsem_model_accum a;
+            a.prof = acc.prof.data(); a.noise = acc.noise.data(); a.rspd = acc.rspd.data(); a.gld = acc.gld.data();
+            a.gld0_lb = P.minL - 1; a.gld0_ub = P.maxL;
+            hip_check(rsem_model_estep_update(mc, theta.data(), (double)N0, counts.data(), theta_new.data(), &sum, &bChange, &totNum, &a),
+                      "rsem_model_estep_update");
+            model.finish_round(acc, refs);  // model.init(); collect; finish  (EM.cpp:400-404)
+        } else {
+            hip_check(rsem_em_step(em, theta.data(), (double)N0, counts.data(), theta_new.data(), &sum, &bChange, &totNum), "rsem_em_step");
+        }
+        theta.swap(theta_new);
+        if (verbose) printf("ROUND = %d, SUM = %.15g, bChange = %g, totNum = %d\n", ROUND, sum, bChange, totNum);
+        if (ROUND >= 11 && !model.needCalcConPrb) break;  // the CSR values are frozen from here on
+    } while (ROUND < MIN_ROUND || (totNum > 0 && ROUND < MAX_ROUND));
+    if (ROUND < MIN_ROUND || (totNum > 0 && ROUND < MAX_ROUND)) {
+        int rounds = ROUND;
+        int32_t tn = 0;
+        hip_check(rsem_em_run(em, theta.data(), (double)N0, ROUND, MIN_ROUND, MAX_ROUND, &rounds, counts.data(), &bChange, &tn, nullptr),
+                  "rsem_em_run");
+        ROUND = rounds;
+        totNum = tn;
+        if (verbose) printf("ROUND = %d, bChange = %g, totNum = %d\n", ROUND, bChange, totNum);
+    }
+    if (totNum > 0) fprintf(stderr, "Warning: RSEM reaches %d iterations before meeting the convergence criteria.\n", MAX_ROUND);
+
+    // ---- imd.ofg for the Gibbs sampler (EM.cpp:421-458) ---------------------------------------------------
+    if (genGibbsOut) {
+        std::vector<double> cp(nnz), ncp(N1);
+        hip_check(rsem_model_get_values(mc, cp.data(), ncp.data()), "rsem_model_get_values");
+        FILE* fo = fopen((imdName + ".ofg").c_str(), "w");
+        if (!fo) die("Cannot open %s.ofg for writing!", imdName.c_str());
+        fprintf(fo, "%d %llu\n", M, (unsigned long long)N0);
+        for (uint64_t i = 0; i < N1; i++) {
+            int n = 0;
+            if (ncp[i] >= kEpsilon) { ++n; fprintf(fo, "0 %.15g ", ncp[i]); }
+            for (uint64_t k = dat.row_ptr[i]; k < dat.row_ptr[i + 1]; k++)
+                if (cp[k] >= kEpsilon) { ++n; fprintf(fo, "%d %.15g ", sid_abs[k], cp[k]); }
+            if (n > 0) fputc('\n', fo);
+        }
+        fclose(fo);
+    }
+
+    // ---- expected counts with the learned theta (EM.cpp:460-478) -------------------------------------------
+    hip_check(rsem_em_expected_weights(em, theta.data(), (double)N0, counts.data(), nullptr, nullptr), "rsem_em_expected_weights");
+
+    // ---- stat.theta (EM.cpp:484-500) ------------------------------------------------------------------------
+    FILE* fo = fopen((statName + ".theta").c_str(), "w");
+    if (!fo) die("Cannot open %s.theta for writing!", statName.c_str());
+    fprintf(fo, "%d\n", M + 1);
+    for (int i = 0; i < M; i++) fprintf(fo, "%.15g ", theta[i]);
+    fprintf(fo, "%.15g\n", theta[M]);
+    std::vector<double> eel = calc_eel(M, refs, model.gld);
+    polish_theta(M, theta, eel, model.mw.data());
+    for (int i = 0; i < M; i++) fprintf(fo, "%.15g ", theta[i]);
+    fprintf(fo, "%.15g\n", theta[M]);
+    fclose(fo);
+
+    model.write(statName + ".model");
+    write_results_em(M, refName, imdName, T, theta, eel, counts.data(), appendNames);
+    if (verbose) printf("Expression Results are written!\n");
+
+    rsem_model_destroy(mc);
+    rsem_em_destroy(em);
+    const auto secs = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t_start).count();
+    printf("Time Used for EM.cpp : %d h %02d m %02d s\n", (int)(secs / 3600), (int)(secs % 3600 / 60), (int)(secs % 60));
+    return 0;
+}

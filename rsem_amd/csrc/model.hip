@@ -1,0 +1,553 @@
+// model.hip -- RSEM's read models on MI355X: P(read, alignment | transcript) for every alignment
+// (rounds 1-11 of rsem-run-em) and the posterior-weighted sufficient statistics that re-estimate
+// the model in rounds 1-10.  C ABI: include/rsem_hip.h (rsem_model_*).
+//
+// Reference semantics restated here (file:line under /root/reference):
+//   getConPrb       SingleModel.h:95-146, SingleQModel.h:101-151, PairedEndModel.h:90-134, PairedEndQModel.h:94-138
+//   getNoiseConPrb  SingleQModel.h:153-162, PairedEndQModel.h:140-155 (and twins)
+//   update          SingleQModel.h:168-215, PairedEndQModel.h:161-180;  updateNoise :217-221 / :182-188
+//   parts           LenDist.h:56-77, RSPD.h:43-75, QProfile.h:88-120, Profile.h:91-120,
+//                   NoiseQProfile.h:74-114, NoiseProfile.h:64-101, RefSeq.h:84-92
+// The reference re-reads every read from FASTA/FASTQ text each round (EM.cpp:200-202); here reads and
+// transcript sequences are uploaded once as byte codes and stay in HBM.
+//   k_conprb : one thread per alignment (product over the read's bases of table entries).
+//   k_noise  : one thread per read.
+//   k_update : one thread per alignment; weighted histograms accumulate in per-workgroup LDS tables
+//              (ds_add_f64) and are merged with one device atomic per touched entry.
+#include <cmath>
+#include <vector>
+
+#include "em_internal.hpp"
+
+namespace {
+
+using rsem::kEpsilon;
+constexpr int kBlk = 256;
+constexpr int kProfLds = 5120;  // doubles of the profile table kept in LDS by k_update (Q: 2500; no-Q: 204 positions)
+constexpr int kGldLds = 1024;
+constexpr int kRspdLds = 128;
+constexpr int kNoiseLds = 512;
+
+struct DevTables {  // device copies of rsem_model_tables
+    double probF;
+    int seedLen, estRSPD, B;
+    const double *rspd_pdf, *rspd_cdf;
+    int gld_lb, gld_ub;
+    const double *gld_pdf, *gld_cdf;
+    int has_mld, mld_lb, mld_ub;
+    const double *mld_pdf, *mld_cdf;
+    int prof_rows;
+    const double* prof;
+    const double* noise;
+    const double* mw;
+};
+
+struct DevData {
+    int model_type, M;
+    uint64_t N1, nnz;
+    const uint64_t* row_ptr;
+    const uint32_t* hit_row;
+    const int32_t* sid_signed;
+    const int32_t* pos;
+    const int32_t* insertL;
+    const uint64_t* read_off[2];
+    const uint8_t* read_seq[2];
+    const uint8_t* read_qual[2];
+    const uint8_t* lq;
+    const uint64_t* ref_off;
+    const uint8_t* ref_seq;
+    const int32_t* fullLen;
+    const int32_t* totLen;
+    const uint64_t* mask_off;
+    const uint32_t* mask_words;
+};
+
+// LenDist::getAdjustedProb (LenDist.h:63-68)
+__device__ inline double ld_adj(const double* pdf, const double* cdf, int lb, int ub, int len, int refL) {
+    if (len <= lb || len > ub || refL <= lb) return 0.0;
+    return pdf[len - lb] / cdf[min(ub, refL) - lb];
+}
+// RSPD::evalCDF / getAdjustedProb (RSPD.h:63-75)
+__device__ inline double rspd_cdf_at(const DevTables& T, int fpos, int fullLen) {
+    int i = (int)(((long long)fpos) * T.B / fullLen);
+    double val = fpos * 1.0 / fullLen * T.B;
+    return T.rspd_cdf[i] + (val - i) * T.rspd_pdf[i + 1];
+}
+__device__ inline double rspd_adj(const DevTables& T, int fpos, int effL, int fullLen) {
+    if (!T.estRSPD) return 1.0 / effL;
+    double denom = rspd_cdf_at(T, effL, fullLen);
+    return denom >= kEpsilon ? (rspd_cdf_at(T, fpos + 1, fullLen) - rspd_cdf_at(T, fpos, fullLen)) / denom : 0.0;
+}
+// RefSeq::get_id (RefSeq.h:84-87): base id on strand dir at strand position p
+__device__ inline int ref_id(const uint8_t* seq, int totLen, int p, int dir) {
+    if (dir == 0) return seq[p];
+    int b = seq[totLen - p - 1];
+    return b == 4 ? 4 : 3 - b;
+}
+__device__ inline bool ref_mask(const DevData& D, int sid, int p) {  // RefSeq.h:89-92
+    return (D.mask_words[D.mask_off[sid] + (p >> 5)] >> (p & 31)) & 1u;
+}
+
+// (Q)Profile::getProb (QProfile.h:111-120, Profile.h:114-120): product over the read
+template <bool kQ>
+__device__ inline double profile_prob(const DevTables& T, const uint8_t* rseq, const uint8_t* rqual, int len,
+                                      const uint8_t* ref, int totLen, int pos, int dir) {
+    double prob = 1.0;
+    for (int i = 0; i < len; i++) {
+        const int row = kQ ? rqual[i] : i;
+        prob *= T.prof[(row * 5 + ref_id(ref, totLen, i + pos, dir)) * 5 + rseq[i]];
+    }
+    return prob;
+}
+
+template <bool kQ, bool kPE>
+__global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double* cp) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D.nnz) return;
+    const uint32_t row = D.hit_row[j];
+    double prob = 0.0;
+    if (!D.lq[row]) {
+        const int s = D.sid_signed[j];
+        const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
+        const int pos = D.pos[j];
+        const int fullLen = D.fullLen[sid], totLen = D.totLen[sid];
+        const uint8_t* ref = D.ref_seq + D.ref_off[sid];
+        const uint64_t r0 = D.read_off[0][row];
+        const int len1 = (int)(D.read_off[0][row + 1] - r0);
+        if (!kPE) {
+            const int fpos = dir == 0 ? pos : totLen - pos - len1;
+            const int seedPos = dir == 0 ? pos : totLen - pos - T.seedLen;
+            if (!(seedPos >= fullLen || ref_mask(D, sid, seedPos))) {
+                double value;
+                if (T.has_mld) {  // SingleQModel.h:127-136
+                    const int minL = max(len1, T.gld_lb + 1), maxL = min(totLen - pos, T.gld_ub);
+                    value = 0.0;
+                    for (int fragLen = minL; fragLen <= maxL; fragLen++) {
+                        const int pfpos = dir == 0 ? pos : totLen - pos - fragLen;
+                        const int effL = min(fullLen, totLen - fragLen + 1);
+                        value += ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, fragLen, totLen) * rspd_adj(T, pfpos, effL, fullLen) *
+                                 ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len1, fragLen);
+                    }
+                } else {
+                    const int effL = min(fullLen, totLen - len1 + 1);
+                    value = ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, len1, totLen) * rspd_adj(T, fpos, effL, fullLen);
+                }
+                const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
+                prob = ori * value * profile_prob<kQ>(T, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1, ref, totLen, pos, dir);
+                if (prob < kEpsilon) prob = 0.0;
+                prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
+            }
+        } else {  // PairedEndQModel.h:94-138
+            const int insertLen = D.insertL[j];
+            const int fpos = dir == 0 ? pos : totLen - pos - insertLen;
+            const int effL = min(fullLen, totLen - insertLen + 1);
+            if (!(fpos >= fullLen || ref_mask(D, sid, fpos))) {
+                const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
+                prob = ori * ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, insertLen, totLen) * rspd_adj(T, fpos, effL, fullLen);
+                prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len1, insertLen) *
+                        profile_prob<kQ>(T, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1, ref, totLen, pos, dir);
+                const uint64_t q0 = D.read_off[1][row];
+                const int len2 = (int)(D.read_off[1][row + 1] - q0);
+                const int m2pos = totLen - pos - insertLen, m2dir = !dir;
+                prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len2, insertLen) *
+                        profile_prob<kQ>(T, D.read_seq[1] + q0, kQ ? D.read_qual[1] + q0 : nullptr, len2, ref, totLen, m2pos, m2dir);
+                if (prob < kEpsilon) prob = 0.0;
+                prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
+            }
+        }
+    }
+    cp[j] = prob;
+}
+
+// Noise(Q)Profile::getProb
+template <bool kQ>
+__device__ inline double noise_prob(const DevTables& T, const uint8_t* rseq, const uint8_t* rqual, int len) {
+    double prob = 1.0;
+    for (int i = 0; i < len; i++) prob *= kQ ? T.noise[rqual[i] * 5 + rseq[i]] : T.noise[rseq[i]];
+    return prob;
+}
+
+template <bool kQ, bool kPE>
+__global__ __launch_bounds__(kBlk) void k_noise(DevData D, DevTables T, double* ncp) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.N1) return;
+    double prob = 0.0;
+    if (!D.lq[i]) {
+        const uint64_t r0 = D.read_off[0][i];
+        const int len1 = (int)(D.read_off[0][i + 1] - r0);
+        const double* lpdf = (kPE || T.has_mld) ? T.mld_pdf : T.gld_pdf;
+        const int llb = (kPE || T.has_mld) ? T.mld_lb : T.gld_lb;
+        prob = lpdf[len1 - llb] * noise_prob<kQ>(T, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1);
+        if (kPE) {
+            const uint64_t q0 = D.read_off[1][i];
+            const int len2 = (int)(D.read_off[1][i + 1] - q0);
+            prob *= lpdf[len2 - llb] * noise_prob<kQ>(T, D.read_seq[1] + q0, kQ ? D.read_qual[1] + q0 : nullptr, len2);
+        }
+        if (prob < kEpsilon) prob = 0.0;
+        prob = (T.mw[0] < kEpsilon) ? 0.0 : prob / T.mw[0];
+    }
+    ncp[i] = prob;
+}
+
+// ---- sufficient statistics (updateModel rounds) ----------------------------------------------------
+
+struct AccumPtrs {
+    double* prof;   // [prof_rows*25]
+    double* noise;  // [100*5] or [5]
+    double* rspd;   // [B+2]
+    double* gld;    // [span0+1]
+    int gld0_lb, gld0_ub;
+};
+
+__device__ inline void add_tbl(double* lds, int cap, double* glob, int idx, double v) {
+    if (idx < cap) unsafeAtomicAdd(&lds[idx], v);
+    else unsafeAtomicAdd(&glob[idx], v);
+}
+
+// RSPD::update (RSPD.h:43-59)
+__device__ inline void rspd_update(double* lds, double* glob, int B, int fpos, int fullLen, double frac) {
+    if (fpos >= fullLen) return;
+    int i;
+    double a = fpos * 1.0 / fullLen, b;
+    for (i = (int)(((long long)fpos) * B / fullLen + 1); i < (int)((((long long)fpos + 1) * B - 1) / fullLen + 1); i++) {
+        b = i * 1.0 / B;
+        add_tbl(lds, kRspdLds, glob, i, (b - a) * fullLen * frac);
+        a = b;
+    }
+    b = (fpos + 1.0) / fullLen;
+    add_tbl(lds, kRspdLds, glob, i, (b - a) * fullLen * frac);
+}
+
+template <bool kQ>
+__device__ inline void profile_update(double* lds, double* glob, const uint8_t* rseq, const uint8_t* rqual, int len,
+                                      const uint8_t* ref, int totLen, int pos, int dir, double frac) {
+    for (int i = 0; i < len; i++) {
+        const int row = kQ ? rqual[i] : i;
+        add_tbl(lds, kProfLds, glob, (row * 5 + ref_id(ref, totLen, i + pos, dir)) * 5 + rseq[i], frac);
+    }
+}
+
+template <bool kQ, bool kPE>
+__global__ __launch_bounds__(kBlk) void k_update(DevData D, DevTables T, const double* __restrict__ w,
+                                                  const double* __restrict__ wn, AccumPtrs A) {
+    __shared__ double s_prof[kProfLds];
+    __shared__ double s_noise[kNoiseLds];
+    __shared__ double s_rspd[kRspdLds];
+    __shared__ double s_gld[kGldLds];
+    for (int i = threadIdx.x; i < kProfLds; i += blockDim.x) s_prof[i] = 0.0;
+    for (int i = threadIdx.x; i < kNoiseLds; i += blockDim.x) s_noise[i] = 0.0;
+    for (int i = threadIdx.x; i < kRspdLds; i += blockDim.x) s_rspd[i] = 0.0;
+    for (int i = threadIdx.x; i < kGldLds; i += blockDim.x) s_gld[i] = 0.0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    // alignments: (Q)Profile / RSPD / gld   (SingleQModel.h:168-215, PairedEndQModel.h:161-180)
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < D.nnz; j += stride) {
+        const double frac = w[j];
+        const uint32_t row = D.hit_row[j];
+        if (D.lq[row] || frac < kEpsilon) continue;
+        const int s = D.sid_signed[j];
+        const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
+        const int pos = D.pos[j];
+        const int fullLen = D.fullLen[sid], totLen = D.totLen[sid];
+        const uint8_t* ref = D.ref_seq + D.ref_off[sid];
+        const uint64_t r0 = D.read_off[0][row];
+        const int len1 = (int)(D.read_off[0][row + 1] - r0);
+        if (!kPE) {
+            if (T.estRSPD) {  // only one strand estimates the RSPD; helper models have no mld (SingleQModel.h:176-213)
+                if (T.probF >= 0.1 && dir == 0) rspd_update(s_rspd, A.rspd, T.B, pos, fullLen, frac);
+                if (T.probF < 0.1 && dir == 1) rspd_update(s_rspd, A.rspd, T.B, totLen - pos - len1, fullLen, frac);
+            }
+            profile_update<kQ>(s_prof, A.prof, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1, ref, totLen, pos, dir, frac);
+        } else {
+            const int insertL = D.insertL[j];
+            add_tbl(s_gld, kGldLds, A.gld, insertL - A.gld0_lb, frac);  // LenDist::update (LenDist.h:46-49)
+            if (T.estRSPD) {
+                const int fpos = dir == 0 ? pos : totLen - pos - insertL;
+                rspd_update(s_rspd, A.rspd, T.B, fpos, fullLen, frac);
+            }
+            profile_update<kQ>(s_prof, A.prof, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1, ref, totLen, pos, dir, frac);
+            const uint64_t q0 = D.read_off[1][row];
+            const int len2 = (int)(D.read_off[1][row + 1] - q0);
+            profile_update<kQ>(s_prof, A.prof, D.read_seq[1] + q0, kQ ? D.read_qual[1] + q0 : nullptr, len2, ref, totLen,
+                               totLen - pos - insertL, !dir, frac);
+        }
+    }
+    // reads: noise profile (SingleQModel.h:217-221, PairedEndQModel.h:182-188)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D.N1; i += stride) {
+        const double frac = wn[i];
+        if (D.lq[i] || frac < kEpsilon) continue;
+        for (int m = 0; m < (kPE ? 2 : 1); m++) {
+            const uint64_t r0 = D.read_off[m][i];
+            const int len = (int)(D.read_off[m][i + 1] - r0);
+            const uint8_t* sq = D.read_seq[m] + r0;
+            const uint8_t* ql = kQ ? D.read_qual[m] + r0 : nullptr;
+            for (int k = 0; k < len; k++) unsafeAtomicAdd(&s_noise[kQ ? ql[k] * 5 + sq[k] : sq[k]], frac);
+        }
+    }
+    __syncthreads();
+    const int nprof = min(kProfLds, T.prof_rows * 25);
+    for (int i = threadIdx.x; i < nprof; i += blockDim.x)
+        if (s_prof[i] != 0.0) unsafeAtomicAdd(&A.prof[i], s_prof[i]);
+    const int nnoise = kQ ? 500 : 5;
+    for (int i = threadIdx.x; i < nnoise; i += blockDim.x)
+        if (s_noise[i] != 0.0) unsafeAtomicAdd(&A.noise[i], s_noise[i]);
+    if (A.rspd)
+        for (int i = threadIdx.x; i < min(kRspdLds, T.B + 2); i += blockDim.x)
+            if (s_rspd[i] != 0.0) unsafeAtomicAdd(&A.rspd[i], s_rspd[i]);
+    if (A.gld)
+        for (int i = threadIdx.x; i < min(kGldLds, A.gld0_ub - A.gld0_lb + 1); i += blockDim.x)
+            if (s_gld[i] != 0.0) unsafeAtomicAdd(&A.gld[i], s_gld[i]);
+}
+
+__global__ void k_hit_rows(uint64_t N1, const uint64_t* __restrict__ row_ptr, uint32_t* hit_row) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N1) return;
+    for (uint64_t j = row_ptr[i]; j < row_ptr[i + 1]; j++) hit_row[j] = (uint32_t)i;
+}
+
+template <typename T>
+hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, (n ? n : 1) * sizeof(T)); }
+
+template <typename T>
+int upload(T** d, const T* h, size_t n, hipStream_t st) {
+    RSEM_HIP_TRY(dmalloc(d, n));
+    if (n) RSEM_HIP_TRY(hipMemcpyAsync(*d, h, sizeof(T) * n, hipMemcpyHostToDevice, st));
+    return RSEM_OK;
+}
+
+}  // namespace
+
+struct rsem_model_ctx {
+    rsem_em_ctx* em = nullptr;
+    rsem::EmDeviceView v;
+    DevData D;
+    DevTables T;
+    bool have_tables = false;
+    int B_alloc = 0, gld_n = 0, mld_n = 0, prof_n = 0, noise_n = 0;
+    std::vector<void*> owned;       // device allocations of the immutable data
+    // table buffers (re-uploaded every round)
+    double *t_rspd_pdf = nullptr, *t_rspd_cdf = nullptr, *t_gld_pdf = nullptr, *t_gld_cdf = nullptr, *t_mld_pdf = nullptr,
+           *t_mld_cdf = nullptr, *t_prof = nullptr, *t_noise = nullptr, *t_mw = nullptr;
+    // accumulators
+    double *a_prof = nullptr, *a_noise = nullptr, *a_rspd = nullptr, *a_gld = nullptr;
+    size_t a_prof_n = 0, a_gld_n = 0;
+};
+
+namespace {
+
+template <typename T>
+int up_field(rsem_model_ctx* c, const T*& field, const T* src, size_t n, hipStream_t st) {
+    T* p = nullptr;
+    int rc = upload(&p, src, n, st);
+    if (rc != RSEM_OK) return rc;
+    c->owned.push_back(p);
+    field = p;
+    return RSEM_OK;
+}
+
+template <bool kQ, bool kPE>
+int launch_conprb(rsem_model_ctx* c) {
+    hipStream_t st = c->v.stream;
+    if (c->D.nnz)
+        hipLaunchKernelGGL((k_conprb<kQ, kPE>), dim3(rsem::ceil_div(c->D.nnz, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_cp);
+    if (c->D.N1)
+        hipLaunchKernelGGL((k_noise<kQ, kPE>), dim3(rsem::ceil_div(c->D.N1, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_ncp);
+    RSEM_HIP_TRY(hipGetLastError());
+    return RSEM_OK;
+}
+
+template <bool kQ, bool kPE>
+int launch_update(rsem_model_ctx* c, const AccumPtrs& A) {
+    int grid = std::max(1, std::min(1024, rsem::ceil_div(std::max<uint64_t>(c->D.nnz, c->D.N1), kBlk * 4)));
+    hipLaunchKernelGGL((k_update<kQ, kPE>), dim3(grid), dim3(kBlk), 0, c->v.stream, c->D, c->T, (const double*)c->v.d_w,
+                       (const double*)c->v.d_wn, A);
+    RSEM_HIP_TRY(hipGetLastError());
+    return RSEM_OK;
+}
+
+int resize_buf(double** p, int* cur, int n) {
+    if (*p && *cur >= n) return RSEM_OK;
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    RSEM_HIP_TRY(dmalloc(p, (size_t)n));
+    *cur = n;
+    return RSEM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsem_model_destroy(rsem_model_ctx* c) {
+    if (!c) return RSEM_OK;
+    (void)hipSetDevice(c->v.device);
+    for (void* p : c->owned) hipFree(p);
+    hipFree(c->t_rspd_pdf); hipFree(c->t_rspd_cdf); hipFree(c->t_gld_pdf); hipFree(c->t_gld_cdf); hipFree(c->t_mld_pdf);
+    hipFree(c->t_mld_cdf); hipFree(c->t_prof); hipFree(c->t_noise); hipFree(c->t_mw);
+    hipFree(c->a_prof); hipFree(c->a_noise); hipFree(c->a_rspd); hipFree(c->a_gld);
+    delete c;
+    return RSEM_OK;
+}
+
+int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_data* d) {
+    RSEM_REQUIRE(out && em && d, "NULL argument");
+    *out = nullptr;
+    RSEM_REQUIRE(d->model_type >= 0 && d->model_type <= 3, "model_type must be 0..3");
+    const bool q = d->model_type == 1 || d->model_type == 3, pe = d->model_type >= 2;
+    RSEM_REQUIRE(d->row_ptr && d->sid_signed && d->pos && d->read_off[0] && d->read_seq[0] && d->low_quality && d->ref_off &&
+                     d->ref_seq && d->fullLen && d->totLen && d->mask_off && d->mask_words,
+                 "NULL array in rsem_model_data");
+    RSEM_REQUIRE(!pe || (d->insertL && d->read_off[1] && d->read_seq[1]), "paired-end data needs insertL and mate 2");
+    RSEM_REQUIRE(!q || (d->read_qual[0] && (!pe || d->read_qual[1])), "quality models need read_qual");
+    rsem_model_ctx* c = new (std::nothrow) rsem_model_ctx();
+    if (!c) return RSEM_ERR_NOMEM;
+    c->em = em;
+    int rc = rsem::em_device_view(em, &c->v);
+    if (rc != RSEM_OK) { delete c; return rc; }
+    if (c->v.N1 != d->N1 || c->v.nnz != d->nnz || c->v.M != d->M) {
+        delete c;
+        rsem::set_last_error("model data does not match the EM context (N1/nnz/M)");
+        return RSEM_ERR_INVALID;
+    }
+    hipStream_t st = c->v.stream;
+    DevData& D = c->D;
+    memset(&D, 0, sizeof(D));
+    D.model_type = d->model_type; D.M = d->M; D.N1 = d->N1; D.nnz = d->nnz;
+    D.row_ptr = c->v.d_row_ptr;
+#define UP(field, src, n)                                           \
+    do {                                                            \
+        rc = up_field(c, D.field, src, (size_t)(n), st);            \
+        if (rc != RSEM_OK) { rsem_model_destroy(c); return rc; }    \
+    } while (0)
+    UP(sid_signed, d->sid_signed, d->nnz);
+    UP(pos, d->pos, d->nnz);
+    if (pe) UP(insertL, d->insertL, d->nnz);
+    for (int m = 0; m < (pe ? 2 : 1); m++) {
+        const uint64_t nb = d->read_off[m][d->N1];
+        UP(read_off[m], d->read_off[m], d->N1 + 1);
+        UP(read_seq[m], d->read_seq[m], nb);
+        if (q) UP(read_qual[m], d->read_qual[m], nb);
+    }
+    UP(lq, d->low_quality, d->N1);
+    UP(ref_off, d->ref_off, (size_t)d->M + 2);
+    UP(ref_seq, d->ref_seq, d->ref_off[d->M + 1]);
+    UP(fullLen, d->fullLen, (size_t)d->M + 1);
+    UP(totLen, d->totLen, (size_t)d->M + 1);
+    UP(mask_off, d->mask_off, (size_t)d->M + 2);
+    UP(mask_words, d->mask_words, d->mask_off[d->M + 1]);
+#undef UP
+    uint32_t* hr = nullptr;
+    if (dmalloc(&hr, d->nnz) != hipSuccess) { rsem_model_destroy(c); return RSEM_ERR_NOMEM; }
+    c->owned.push_back(hr);
+    D.hit_row = hr;
+    if (d->N1) hipLaunchKernelGGL(k_hit_rows, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, d->N1, D.row_ptr, hr);
+    if (hipStreamSynchronize(st) != hipSuccess) { rsem_model_destroy(c); return RSEM_ERR_HIP; }
+    *out = c;
+    return RSEM_OK;
+}
+
+int rsem_model_set_tables(rsem_model_ctx* c, const rsem_model_tables* t) {
+    RSEM_REQUIRE(c && t && t->gld_pdf && t->gld_cdf && t->prof && t->noise && t->mw && t->rspd_pdf && t->rspd_cdf, "NULL table");
+    RSEM_REQUIRE(!t->has_mld || (t->mld_pdf && t->mld_cdf), "mld tables missing");
+    RSEM_REQUIRE(c->D.model_type < 2 || t->has_mld, "paired-end models need the mate length distribution");
+    RSEM_HIP_TRY(hipSetDevice(c->v.device));
+    hipStream_t st = c->v.stream;
+    const bool q = c->D.model_type == 1 || c->D.model_type == 3;
+    const int nr = t->B + 2, ng = t->gld_ub - t->gld_lb + 1, nm = t->has_mld ? t->mld_ub - t->mld_lb + 1 : 1;
+    const int np = t->prof_rows * 25, nn = q ? 500 : 5;
+    int rc;
+    int cur;
+    cur = c->B_alloc; if ((rc = resize_buf(&c->t_rspd_pdf, &cur, nr)) != RSEM_OK) return rc;
+    if ((rc = resize_buf(&c->t_rspd_cdf, &c->B_alloc, nr)) != RSEM_OK) return rc;
+    cur = c->gld_n; if ((rc = resize_buf(&c->t_gld_pdf, &cur, ng)) != RSEM_OK) return rc;
+    if ((rc = resize_buf(&c->t_gld_cdf, &c->gld_n, ng)) != RSEM_OK) return rc;
+    cur = c->mld_n; if ((rc = resize_buf(&c->t_mld_pdf, &cur, nm)) != RSEM_OK) return rc;
+    if ((rc = resize_buf(&c->t_mld_cdf, &c->mld_n, nm)) != RSEM_OK) return rc;
+    if ((rc = resize_buf(&c->t_prof, &c->prof_n, np)) != RSEM_OK) return rc;
+    if ((rc = resize_buf(&c->t_noise, &c->noise_n, nn)) != RSEM_OK) return rc;
+    if (!c->t_mw) RSEM_HIP_TRY(dmalloc(&c->t_mw, (size_t)c->D.M + 1));
+    auto cp = [&](double* dst, const double* src, int n) { return hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyHostToDevice, st); };
+    RSEM_HIP_TRY(cp(c->t_rspd_pdf, t->rspd_pdf, nr));
+    RSEM_HIP_TRY(cp(c->t_rspd_cdf, t->rspd_cdf, nr));
+    RSEM_HIP_TRY(cp(c->t_gld_pdf, t->gld_pdf, ng));
+    RSEM_HIP_TRY(cp(c->t_gld_cdf, t->gld_cdf, ng));
+    if (t->has_mld) {
+        RSEM_HIP_TRY(cp(c->t_mld_pdf, t->mld_pdf, nm));
+        RSEM_HIP_TRY(cp(c->t_mld_cdf, t->mld_cdf, nm));
+    }
+    RSEM_HIP_TRY(cp(c->t_prof, t->prof, np));
+    RSEM_HIP_TRY(cp(c->t_noise, t->noise, nn));
+    RSEM_HIP_TRY(cp(c->t_mw, t->mw, c->D.M + 1));
+    RSEM_HIP_TRY(hipStreamSynchronize(st));
+    DevTables& T = c->T;
+    T.probF = t->probF; T.seedLen = t->seedLen; T.estRSPD = t->estRSPD; T.B = t->B;
+    T.rspd_pdf = c->t_rspd_pdf; T.rspd_cdf = c->t_rspd_cdf;
+    T.gld_lb = t->gld_lb; T.gld_ub = t->gld_ub; T.gld_pdf = c->t_gld_pdf; T.gld_cdf = c->t_gld_cdf;
+    T.has_mld = t->has_mld; T.mld_lb = t->mld_lb; T.mld_ub = t->mld_ub; T.mld_pdf = c->t_mld_pdf; T.mld_cdf = c->t_mld_cdf;
+    T.prof_rows = t->prof_rows; T.prof = c->t_prof; T.noise = c->t_noise; T.mw = c->t_mw;
+    c->have_tables = true;
+    return RSEM_OK;
+}
+
+int rsem_model_calc_conprb(rsem_model_ctx* c) {
+    RSEM_REQUIRE(c, "NULL argument");
+    if (!c->have_tables) { rsem::set_last_error("model tables were never set"); return RSEM_ERR_STATE; }
+    RSEM_HIP_TRY(hipSetDevice(c->v.device));
+    int rc;
+    switch (c->D.model_type) {
+        case 0: rc = launch_conprb<false, false>(c); break;
+        case 1: rc = launch_conprb<true, false>(c); break;
+        case 2: rc = launch_conprb<false, true>(c); break;
+        default: rc = launch_conprb<true, true>(c); break;
+    }
+    if (rc != RSEM_OK) return rc;
+    return rsem::em_values_changed(c->em);
+}
+
+int rsem_model_estep_update(rsem_model_ctx* c, const double* theta, double N0, double* counts, double* theta_new, double* sum,
+                            double* bChange, int32_t* totNum, rsem_model_accum* acc) {
+    RSEM_REQUIRE(c && theta && acc && acc->prof && acc->noise, "NULL argument");
+    if (!c->have_tables) { rsem::set_last_error("model tables were never set"); return RSEM_ERR_STATE; }
+    const bool q = c->D.model_type == 1 || c->D.model_type == 3, pe = c->D.model_type >= 2;
+    RSEM_REQUIRE(!pe || acc->gld, "paired-end models accumulate the fragment length distribution");
+    RSEM_REQUIRE(!c->T.estRSPD || acc->rspd, "estRSPD needs the rspd accumulator");
+    int rc = rsem::em_step_with_weights(c->em, theta, N0, counts, theta_new, sum, bChange, totNum);
+    if (rc != RSEM_OK) return rc;
+    RSEM_HIP_TRY(hipSetDevice(c->v.device));
+    hipStream_t st = c->v.stream;
+    const size_t np = (size_t)c->T.prof_rows * 25, nn = q ? 500 : 5, nr = (size_t)c->T.B + 2;
+    const size_t ng = pe ? (size_t)(acc->gld0_ub - acc->gld0_lb + 1) : 1;
+    if (c->a_prof_n < np) { hipFree(c->a_prof); c->a_prof = nullptr; RSEM_HIP_TRY(dmalloc(&c->a_prof, np)); c->a_prof_n = np; }
+    if (!c->a_noise) RSEM_HIP_TRY(dmalloc(&c->a_noise, (size_t)500));
+    if (!c->a_rspd) RSEM_HIP_TRY(dmalloc(&c->a_rspd, std::max<size_t>(nr, 1024)));
+    if (c->a_gld_n < ng) { hipFree(c->a_gld); c->a_gld = nullptr; RSEM_HIP_TRY(dmalloc(&c->a_gld, ng)); c->a_gld_n = ng; }
+    RSEM_HIP_TRY(hipMemsetAsync(c->a_prof, 0, sizeof(double) * np, st));
+    RSEM_HIP_TRY(hipMemsetAsync(c->a_noise, 0, sizeof(double) * 500, st));
+    RSEM_HIP_TRY(hipMemsetAsync(c->a_rspd, 0, sizeof(double) * nr, st));
+    RSEM_HIP_TRY(hipMemsetAsync(c->a_gld, 0, sizeof(double) * ng, st));
+    AccumPtrs A{c->a_prof, c->a_noise, c->T.estRSPD ? c->a_rspd : nullptr, pe ? c->a_gld : nullptr, acc->gld0_lb, acc->gld0_ub};
+    switch (c->D.model_type) {
+        case 0: rc = launch_update<false, false>(c, A); break;
+        case 1: rc = launch_update<true, false>(c, A); break;
+        case 2: rc = launch_update<false, true>(c, A); break;
+        default: rc = launch_update<true, true>(c, A); break;
+    }
+    if (rc != RSEM_OK) return rc;
+    RSEM_HIP_TRY(hipMemcpyAsync(acc->prof, c->a_prof, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipMemcpyAsync(acc->noise, c->a_noise, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
+    if (c->T.estRSPD) RSEM_HIP_TRY(hipMemcpyAsync(acc->rspd, c->a_rspd, sizeof(double) * nr, hipMemcpyDeviceToHost, st));
+    if (pe) RSEM_HIP_TRY(hipMemcpyAsync(acc->gld, c->a_gld, sizeof(double) * ng, hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipStreamSynchronize(st));
+    return RSEM_OK;
+}
+
+int rsem_model_get_values(rsem_model_ctx* c, double* conprb, double* ncp) {
+    RSEM_REQUIRE(c && conprb && ncp, "NULL argument");
+    RSEM_HIP_TRY(hipSetDevice(c->v.device));
+    if (c->v.nnz) RSEM_HIP_TRY(hipMemcpyAsync(conprb, c->v.d_cp, sizeof(double) * c->v.nnz, hipMemcpyDeviceToHost, c->v.stream));
+    if (c->v.N1) RSEM_HIP_TRY(hipMemcpyAsync(ncp, c->v.d_ncp, sizeof(double) * c->v.N1, hipMemcpyDeviceToHost, c->v.stream));
+    RSEM_HIP_TRY(hipStreamSynchronize(c->v.stream));
+    return RSEM_OK;
+}
+
+}  // extern "C"

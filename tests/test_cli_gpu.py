@@ -1,0 +1,128 @@
+"""End-to-end parity of the drop-in programs rsem_amd/bin/rsem-run-em and rsem-run-gibbs against the
+reference's outputs on the golden fixtures (same argv, same input files, compared output files).
+
+EM is deterministic: theta (both lines of .theta) must agree to 1e-6 relative with the same ROUND count;
+the .model tables to 1e-6; iso_res/gene_res values are printed with %.2f.  Gibbs in exact mode must
+write byte-identical count vectors.
+"""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import rsem_files as rf
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "rsem_amd", "bin")
+
+
+def _stage(name, tmp_path):
+    fx = rf.fixture(name)
+    dst = os.path.join(str(tmp_path), name)
+    shutil.copytree(fx, dst)
+    return fx, dst
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    return r.stdout
+
+
+def _rel(a, b, floor):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    m = np.abs(b) >= floor
+    return float(np.max(np.abs(a[m] - b[m]) / np.abs(b[m]))) if m.any() else 0.0
+
+
+def _res_close(path_a, path_b, atol=0.011):
+    A, B = rf.read_res(path_a), rf.read_res(path_b)
+    assert len(A) == len(B)
+    for ra, rb in zip(A, B):
+        try:
+            va, vb = np.array(ra, float), np.array(rb, float)
+        except ValueError:
+            assert ra == rb
+            continue
+        assert np.allclose(va, vb, atol=atol, rtol=1e-6), (ra[:5], rb[:5])
+
+
+@pytest.mark.parametrize("name", rf.FIXTURES)
+def test_rsem_run_em_matches_reference(name, tmp_path):
+    fx, dst = _stage(name, tmp_path)
+    meta = rf.read_meta(fx)
+    for f in ("stat/s.theta", "stat/s.model", "temp/s.ofg", "temp/s.iso_res", "temp/s.gene_res"):
+        os.remove(os.path.join(dst, f))
+    out = _run([os.path.join(BIN, "rsem-run-em"), os.path.join(dst, "ref"), str(meta["model_type"]), os.path.join(dst, "s"),
+                os.path.join(dst, "temp", "s"), os.path.join(dst, "stat", "s"), "-p", "1", "--gibbs-out"])
+    # same number of rounds as the reference run
+    ref_rounds = int(open(os.path.join(fx, "em.log")).read().strip().split("\n")[-1].split(",")[0].split("=")[1])
+    my_rounds = int([l for l in out.split("\n") if l.startswith("ROUND")][-1].split(",")[0].split("=")[1])
+    assert my_rounds == ref_rounds
+    # the first 11 rounds print the same SUM / totNum lines as the reference
+    ref_lines = open(os.path.join(fx, "em.log")).read().strip().split("\n")[:11]
+    my_lines = [l for l in out.split("\n") if l.startswith("ROUND")][:11]
+    for a, b in zip(my_lines, ref_lines):
+        fa, fb = a.replace(",", "").split(), b.replace(",", "").split()
+        assert fa[2] == fb[2] and abs(float(fa[5]) - float(fb[5])) < 1e-6 * float(fb[5]) and fa[-1] == fb[-1], (a, b)
+    raw, pol = rf.read_theta(os.path.join(dst, "stat", "s.theta"))
+    graw, gpol = rf.read_theta(os.path.join(fx, "stat", "s.theta"))
+    assert _rel(raw, graw, 1e-7) < 1e-6 and np.allclose(raw, graw, rtol=1e-6, atol=1e-10)
+    assert _rel(pol, gpol, 1e-7) < 1e-6 and np.allclose(pol, gpol, rtol=1e-6, atol=1e-10)
+    # model file: every table
+    a, b = rf.read_model(os.path.join(dst, "stat", "s.model")), rf.read_model(os.path.join(fx, "stat", "s.model"))
+    assert a["type"] == b["type"] and a["gld"][:3] == b["gld"][:3]
+    for key in ("qd_init", "qd_tran", "qpro", "nqpro", "pro", "npro", "rspd", "mw"):
+        if key in b and b[key] is not None:
+            assert np.allclose(a[key], b[key], rtol=1e-6, atol=1e-9), key
+    assert np.allclose(a["gld"][3], b["gld"][3], rtol=1e-6, atol=1e-9)
+    if b["mld"] is not None:
+        assert a["mld"][:3] == b["mld"][:3] and np.allclose(a["mld"][3], b["mld"][3], rtol=1e-6, atol=1e-12)
+    # results and the Gibbs input
+    _res_close(os.path.join(dst, "temp", "s.iso_res"), os.path.join(fx, "temp", "s.iso_res.em"))
+    _res_close(os.path.join(dst, "temp", "s.gene_res"), os.path.join(fx, "temp", "s.gene_res.em"))
+    M, N0, rp, sid, val = rf.read_ofg(os.path.join(dst, "temp", "s.ofg"))
+    gM, gN0, grp, gsid, gval = rf.read_ofg(os.path.join(fx, "temp", "s.ofg"))
+    assert (M, N0) == (gM, gN0) and np.array_equal(rp, grp) and np.array_equal(sid, gsid)
+    assert np.allclose(val, gval, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("name", rf.FIXTURES)
+def test_rsem_run_gibbs_exact_matches_reference(name, tmp_path):
+    fx, dst = _stage(name, tmp_path)
+    meta = rf.read_meta(fx)
+    b, n, g = meta["gibbs"]
+    imd = os.path.join(dst, "temp", "s")
+    shutil.copy(imd + ".iso_res.em", imd + ".iso_res")
+    shutil.copy(imd + ".gene_res.em", imd + ".gene_res")
+    for k in range(meta["gibbs_threads"]):
+        os.remove(imd + ".countvectors%d" % k)
+    _run([os.path.join(BIN, "rsem-run-gibbs"), os.path.join(dst, "ref"), imd, os.path.join(dst, "stat", "s"), str(b), str(n), str(g),
+          "-p", str(meta["gibbs_threads"]), "--seed", str(meta["gibbs_seed"]), "-q", "--gibbs-mode", "exact"])
+    for k in range(meta["gibbs_threads"]):
+        with open(imd + ".countvectors%d" % k, "rb") as f1, open(os.path.join(fx, "temp", "s.countvectors%d" % k), "rb") as f2:
+            assert f1.read() == f2.read()
+    _res_close(imd + ".iso_res", os.path.join(fx, "temp", "s.iso_res"))
+    _res_close(imd + ".gene_res", os.path.join(fx, "temp", "s.gene_res"))
+
+
+def test_rsem_run_gibbs_parallel_runs_and_is_close(tmp_path):
+    fx, dst = _stage("pe_q", tmp_path)
+    imd = os.path.join(dst, "temp", "s")
+    shutil.copy(imd + ".iso_res.em", imd + ".iso_res")
+    shutil.copy(imd + ".gene_res.em", imd + ".gene_res")
+    _run([os.path.join(BIN, "rsem-run-gibbs"), os.path.join(dst, "ref"), imd, os.path.join(dst, "stat", "s"), "200", "1000", "1",
+          "-p", "2", "--seed", "5", "-q", "--gibbs-mode", "parallel", "--gibbs-thin", "4"])
+    res = rf.read_res(imd + ".iso_res")
+    assert len(res) == 13
+    em_counts = np.array(res[4], float)
+    pme = np.array(res[8], float)
+    cv = np.vstack([rf.read_countvectors(imd + ".countvectors%d" % k) for k in range(2)])
+    assert cv.shape[0] == 1000 and np.all(cv.sum(1) == cv[0].sum())
+    # posterior means track the ML counts (+1 pseudo count each) on well-determined transcripts
+    big = em_counts > 30
+    assert np.all(np.abs(pme[big] - em_counts[big]) < 0.25 * em_counts[big] + 3)
