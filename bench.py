@@ -30,7 +30,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(wl, budget_s=15.0):
+def cpu_baseline_port(wl, budget_s=12.0):
     """The CPU restatement (oracle/, single thread) timed on a bounded row-subsample of the same workload."""
     from oracle import pyoracle as orc
     N1 = len(wl["row_ptr"]) - 1
@@ -51,8 +51,63 @@ def cpu_baseline(wl, budget_s=15.0):
             break
     return {"value": nnz * rounds / el, "unit": "read-alignments/s", "cores": 1, "kind": "port",
             "sample": "first %d reads (%d alignments) of the same workload, %d EM rounds, oracle/rsem_oracle.c"
-                      % (sub, nnz, rounds),
-            "host_cores_available": os.cpu_count()}
+                      % (sub, nnz, rounds)}
+
+
+def cpu_baseline_reference(n_reads=1_000_000, M=20_000, limit_s=150.0):
+    """The UNMODIFIED reference binary (oracle/_ref/rsem-run-em, built from /root/reference) on this host's
+    cores, on a bounded SingleQModel sample written by tools/gen_temp.cpp; per-round time of the rounds
+    with frozen alignment probabilities (ROUND >= 12) from the arrival times of its 'ROUND =' lines
+    (EM.cpp:415).  The drop-in rsem_amd/bin/rsem-run-em is run on the same files for the wall-clock ratio."""
+    import shutil
+    import subprocess
+    import tempfile
+    gen = os.path.join(ROOT, "tools", "bin", "gen_temp")
+    ref_em = os.path.join(ROOT, "oracle", "_ref", "rsem-run-em")
+    ref_idx = os.path.join(ROOT, "oracle", "_ref", "rsem-build-read-index")
+    new_em = os.path.join(ROOT, "rsem_amd", "bin", "rsem-run-em")
+    if not all(os.path.exists(p) for p in (gen, ref_em, ref_idx, new_em)):
+        return None
+    d = tempfile.mkdtemp(prefix="rsem_bench_")
+    try:
+        out = subprocess.run([gen, d, str(n_reads), str(M), "1"], stdout=subprocess.PIPE, text=True, check=True).stdout
+        nhits = int(out.split("nHits=")[1].split()[0])
+        subprocess.run([ref_idx, "32", "1", "1", os.path.join(d, "temp", "s_alignable.fq")], stdout=subprocess.DEVNULL, check=True)
+        args = [os.path.join(d, "ref"), "1", os.path.join(d, "s"), os.path.join(d, "temp", "s"), os.path.join(d, "stat", "s")]
+        cores = min(os.cpu_count() or 1, 64)
+        t0 = time.perf_counter()
+        p = subprocess.Popen([ref_em] + args + ["-p", str(cores)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        stamps = []
+        finished = True
+        for line in p.stdout:
+            if line.startswith("ROUND ="):
+                stamps.append((int(line.split(",")[0].split("=")[1]), time.perf_counter()))
+            if time.perf_counter() - t0 > limit_s:
+                p.kill()
+                finished = False
+                break
+        p.wait()
+        ref_wall = time.perf_counter() - t0
+        late = [(r, t) for r, t in stamps if r >= 12]
+        if len(late) < 3:
+            return None
+        per_round = (late[-1][1] - late[0][1]) / (late[-1][0] - late[0][0])
+        res = {"value": nhits / per_round, "unit": "read-alignments/s", "cores": cores, "kind": "reference",
+               "sample": "oracle/_ref/rsem-run-em -p %d on a generated SingleQModel sample: %d reads, %d alignments, %d "
+                         "transcripts; %d rounds >= 12 timed (%.3f ms/round)" % (cores, n_reads, nhits, M, len(late) - 1, per_round * 1e3),
+               "reference_rounds": stamps[-1][0], "reference_finished": finished, "reference_wall_s": ref_wall,
+               "host_cores_available": os.cpu_count()}
+        t0 = time.perf_counter()
+        r = subprocess.run([new_em] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        res["dropin_wall_s"] = time.perf_counter() - t0
+        res["dropin_ok"] = r.returncode == 0
+        rl = [l for l in r.stdout.split("\n") if l.startswith("ROUND")]
+        res["dropin_rounds"] = int(rl[-1].split(",")[0].split("=")[1]) if rl else None
+        if finished and res["dropin_ok"]:
+            res["wall_clock_speedup_same_files"] = ref_wall / res["dropin_wall_s"]
+        return res
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -205,8 +260,13 @@ def main():
             "gibbs": gibbs,
         }
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(wl)
-            line["speedup_vs_cpu_port_1core"] = line["value"] / line["cpu_baseline"]["value"]
+            cb = cpu_baseline_reference()
+            if cb is None:
+                cb = cpu_baseline_port(wl)
+            else:
+                line["cpu_baseline_port_1core"] = cpu_baseline_port(wl, budget_s=6.0)
+            line["cpu_baseline"] = cb
+            line["speedup_vs_cpu_baseline_rounds"] = line["value"] / cb["value"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

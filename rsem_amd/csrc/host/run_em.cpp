@@ -164,6 +164,12 @@ int main(int argc, char* argv[]) {
         exit(-1);
     }
     const auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {  // phase timing (stdout is not parsed by the pipeline driver)
+        static auto last = std::chrono::steady_clock::now();
+        auto now = std::chrono::steady_clock::now();
+        if (getenv("RSEM_HIP_TIMING")) printf("[timing] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - last).count());
+        last = now;
+    };
     const std::string refName = argv[1];
     const int read_type = atoi(argv[2]);
     const std::string outName = argv[3], imdName = argv[4], statName = argv[5];
@@ -197,12 +203,14 @@ int main(int argc, char* argv[]) {
     }
     if (genBamF) fprintf(stderr, "Warning: this build of rsem-run-em does not write %s.transcript.bam (run rsem-calculate-expression with --no-bam-output).\n", outName.c_str());
 
+    lap("refs + transcripts");
     ModelParams P = load_mparams(imdName + ".mparams");
     const bool pe = read_type >= 2, hasQ = (read_type == 1 || read_type == 3);
 
     // ---- inputs, parsed once --------------------------------------------------------------------------
     DatData dat = load_dat(imdName + ".dat", read_type);
     if (dat.N1 != N1) die("Number of alignable reads does not match!");
+    lap("parse .dat");
     ReadSetFiles rs;
     const uint64_t Ncat[3] = {N0, N1, N2};
     for (int tag = 0; tag < 3; tag++) {
@@ -214,10 +222,12 @@ int main(int argc, char* argv[]) {
                                                 (unsigned long long)rs.mate[tag][0].n, statName.c_str(), (unsigned long long)Ncat[tag]);
         if (verbose) printf("estimateFromReads, N%d finished.\n", tag);
     }
+    lap("parse read files");
     Model model;
     model.init_master(read_type, M, P);
     std::vector<uint8_t> lq;
     estimate_from_reads(model, rs, refs, lq);
+    lap("estimateFromReads");
     rs.mate[0][0] = ReadFile(); rs.mate[0][1] = ReadFile(); rs.mate[2][0] = ReadFile(); rs.mate[2][1] = ReadFile();
 
     // ---- device contexts -----------------------------------------------------------------------------
@@ -266,6 +276,7 @@ int main(int argc, char* argv[]) {
     md.mask_off = mask_off.data(); md.mask_words = mask_words.data();
     rsem_model_ctx* mc = nullptr;
     hip_check(rsem_model_create(&mc, em, &md), "rsem_model_create");
+    lap("device contexts + upload");
     if (verbose) printf("EM_init finished!\n");
 
     // ---- EM (EM.cpp:343-416) ---------------------------------------------------------------------------
@@ -302,6 +313,7 @@ int main(int argc, char* argv[]) {
         if (verbose) printf("ROUND = %d, SUM = %.15g, bChange = %g, totNum = %d\n", ROUND, sum, bChange, totNum);
         if (ROUND >= 11 && !model.needCalcConPrb) break;  // the CSR values are frozen from here on
     } while (ROUND < MIN_ROUND || (totNum > 0 && ROUND < MAX_ROUND));
+    lap("rounds 1-11 (model rounds)");
     if (ROUND < MIN_ROUND || (totNum > 0 && ROUND < MAX_ROUND)) {
         int rounds = ROUND;
         int32_t tn = 0;
@@ -311,6 +323,7 @@ int main(int argc, char* argv[]) {
         totNum = tn;
         if (verbose) printf("ROUND = %d, bChange = %g, totNum = %d\n", ROUND, bChange, totNum);
     }
+    lap("rounds >= 12 (device loop)");
     if (totNum > 0) fprintf(stderr, "Warning: RSEM reaches %d iterations before meeting the convergence criteria.\n", MAX_ROUND);
 
     // ---- imd.ofg for the Gibbs sampler (EM.cpp:421-458) ---------------------------------------------------
@@ -330,6 +343,7 @@ int main(int argc, char* argv[]) {
         fclose(fo);
     }
 
+    lap("write .ofg");
     // ---- expected counts with the learned theta (EM.cpp:460-478) -------------------------------------------
     hip_check(rsem_em_expected_weights(em, theta.data(), (double)N0, counts.data(), nullptr, nullptr), "rsem_em_expected_weights");
 
@@ -349,6 +363,7 @@ int main(int argc, char* argv[]) {
     write_results_em(M, refName, imdName, T, theta, eel, counts.data(), appendNames);
     if (verbose) printf("Expression Results are written!\n");
 
+    lap("expected counts + results");
     rsem_model_destroy(mc);
     rsem_em_destroy(em);
     const auto secs = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t_start).count();

@@ -126,3 +126,31 @@ def test_rsem_run_gibbs_parallel_runs_and_is_close(tmp_path):
     # posterior means track the ML counts (+1 pseudo count each) on well-determined transcripts
     big = em_counts > 30
     assert np.all(np.abs(pme[big] - em_counts[big]) < 0.25 * em_counts[big] + 3)
+
+
+@pytest.mark.parametrize("read_type,n_reads", [(1, 40000), (3, 30000)])
+def test_generated_dataset_vs_reference_binary(read_type, n_reads, tmp_path):
+    """A fresh, larger synthetic .temp directory (tools/gen_temp.cpp): run the reference binary (oracle/_ref, shipped
+    to the GPU box) and the drop-in on the same files; same ROUND count, theta within 1e-6 relative."""
+    gen = os.path.join(ROOT, "tools", "bin", "gen_temp")
+    ref_em = os.path.join(ROOT, "oracle", "_ref", "rsem-run-em")
+    ref_idx = os.path.join(ROOT, "oracle", "_ref", "rsem-build-read-index")
+    if not (os.path.exists(gen) and os.path.exists(ref_em) and os.path.exists(ref_idx)):
+        pytest.skip("generator or reference binaries not built")
+    d = str(tmp_path)
+    _run([gen, d, str(n_reads), "2000", str(read_type), "7", "75"])
+    reads = ["s_alignable.fq"] if read_type == 1 else ["s_alignable_1.fq", "s_alignable_2.fq"]
+    _run([ref_idx, "32", "1", "1"] + [os.path.join(d, "temp", r) for r in reads])
+    args = [os.path.join(d, "ref"), str(read_type), os.path.join(d, "s"), os.path.join(d, "temp", "s"), os.path.join(d, "stat", "s")]
+    out_ref = _run([ref_em] + args + ["-p", "4"])
+    graw, gpol = rf.read_theta(os.path.join(d, "stat", "s.theta"))
+    gres = rf.read_res(os.path.join(d, "temp", "s.iso_res"))
+    os.rename(os.path.join(d, "stat", "s.theta"), os.path.join(d, "stat", "ref.theta"))
+    out_new = _run([os.path.join(BIN, "rsem-run-em")] + args)
+    raw, pol = rf.read_theta(os.path.join(d, "stat", "s.theta"))
+    r_ref = int([l for l in out_ref.split("\n") if l.startswith("ROUND")][-1].split(",")[0].split("=")[1])
+    r_new = int([l for l in out_new.split("\n") if l.startswith("ROUND")][-1].split(",")[0].split("=")[1])
+    assert r_new == r_ref
+    assert _rel(raw, graw, 1e-7) < 1e-6 and _rel(pol, gpol, 1e-7) < 1e-6
+    res = rf.read_res(os.path.join(d, "temp", "s.iso_res"))
+    assert np.allclose(np.array(res[5], float), np.array(gres[5], float), atol=0.011, rtol=1e-6)  # TPM

@@ -1,0 +1,177 @@
+// gen_temp.cpp -- seeded generator of a complete rsem-run-em input directory at benchmark scale
+// (".temp generator without SAM").  TEST / BENCH INFRASTRUCTURE, not product.
+//
+//   gen_temp <outdir> <n_reads> <M> <read_type 1|3> [seed] [read_len]
+//
+// writes  <outdir>/ref.{seq,ti,grp}, <outdir>/temp/s.{dat,mparams,omit}, s_alignable*.fq, s_un*.fq,
+// <outdir>/stat/s.cnt   in the formats of SURVEY.md Appendix A, so that BOTH the reference binary
+// (oracle/_ref/rsem-run-em, after rsem-build-read-index) and rsem_amd/bin/rsem-run-em can run on it.
+//
+// Model of the data: genes own 2..9 isoforms; every isoform is a contiguous sub-interval of its gene's
+// sequence (heavy overlap), so a read drawn from one isoform aligns, at shifted offsets, to every
+// sibling that contains it; true theta ~ lognormal(0,2) with 30% zeros; 5% noise reads; phred qualities
+// from a small Markov chain, base errors at the phred rate.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+#include <vector>
+
+static const char BASES[4] = {'A', 'C', 'G', 'T'};
+static char comp(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
+
+struct Tx { int gene; int a, b; };  // interval of the gene sequence
+
+int main(int argc, char** argv) {
+    if (argc < 5) { fprintf(stderr, "usage: gen_temp outdir n_reads M read_type(1|3) [seed] [read_len]\n"); return 1; }
+    const std::string out = argv[1];
+    const long long N = atoll(argv[2]);
+    const int M = atoi(argv[3]), read_type = atoi(argv[4]);
+    const unsigned seed = argc > 5 ? (unsigned)atoll(argv[5]) : 20250925u;
+    const int L = argc > 6 ? atoi(argv[6]) : 100;
+    const bool pe = read_type == 3;
+    if (read_type != 1 && read_type != 3) { fprintf(stderr, "read_type must be 1 or 3\n"); return 1; }
+    std::mt19937_64 rng(seed);
+    auto uni = [&](double a, double b) { return std::uniform_real_distribution<double>(a, b)(rng); };
+    auto irand = [&](int a, int b) { return std::uniform_int_distribution<int>(a, b)(rng); };
+
+    // genes / transcripts
+    std::vector<std::string> gseq;
+    std::vector<Tx> tx(1);
+    std::vector<int> gstart;  // first transcript id of each gene
+    while ((int)tx.size() - 1 < M) {
+        int k = std::min(irand(2, 9), M - ((int)tx.size() - 1));
+        int Lg = irand(1500, 4000);
+        std::string s(Lg, 'A');
+        for (int i = 0; i < Lg; i++) s[i] = BASES[rng() & 3];
+        gstart.push_back((int)tx.size());
+        for (int j = 0; j < k; j++) tx.push_back(Tx{(int)gseq.size(), irand(0, 300), Lg - irand(0, 300)});
+        gseq.push_back(std::move(s));
+    }
+    gstart.push_back(M + 1);
+    const int m = (int)gseq.size();
+    auto tlen = [&](int t) { return tx[t].b - tx[t].a; };
+
+    std::string cmd = "mkdir -p " + out + "/temp " + out + "/stat";
+    if (system(cmd.c_str()) != 0) return 1;
+    {   // ref.seq (RefSeq.h:108-138), ref.ti (Transcript.h:119-148), ref.grp (GroupInfo.h:34-53)
+        FILE* fs = fopen((out + "/ref.seq").c_str(), "w");
+        FILE* ft = fopen((out + "/ref.ti").c_str(), "w");
+        FILE* fg = fopen((out + "/ref.grp").c_str(), "w");
+        fprintf(ft, "%d 1\n", M);
+        for (int t = 1; t <= M; t++) {
+            const int len = tlen(t);
+            fprintf(fs, "%d %d\nt%d\n", len, len, t);
+            fwrite(gseq[tx[t].gene].data() + tx[t].a, 1, len, fs);
+            fputc('\n', fs);
+            const int words = (len - 1) / 32 + 1;
+            for (int w = 0; w < words; w++) fprintf(fs, w + 1 < words ? "0 " : "0\n");
+            fprintf(ft, "t%d\ng%d\nt%d\n+ %d\n1 1 %d\n\n", t, tx[t].gene, t, len, len);
+        }
+        for (int g = 0; g <= m; g++) fprintf(fg, "%d\n", gstart[g]);
+        fclose(fs); fclose(ft); fclose(fg);
+    }
+    // expression
+    std::vector<double> cdf(M + 1, 0.0);
+    {
+        std::normal_distribution<double> nd(0.0, 2.0);
+        for (int t = 1; t <= M; t++) {
+            double th = exp(nd(rng));
+            if (uni(0, 1) < 0.3) th = 0.0;
+            cdf[t] = cdf[t - 1] + th * tlen(t);
+        }
+    }
+    // quality Markov chain: states 2..40, drift to high quality
+    auto next_q = [&](int q) { int d = irand(-5, 3); int v = q + d; if (v > 40) v = 40 - irand(0, 3); if (v < 2) v = 2 + irand(0, 3); return v; };
+
+    const long long N0 = N / 20;
+    const long long N1 = N - N0;
+    FILE* fdat = fopen((out + "/temp/s.dat").c_str(), "w");
+    FILE* fq1 = fopen((out + (pe ? "/temp/s_alignable_1.fq" : "/temp/s_alignable.fq")).c_str(), "w");
+    FILE* fq2 = pe ? fopen((out + "/temp/s_alignable_2.fq").c_str(), "w") : nullptr;
+    static char buf1[1 << 16], buf2[1 << 16], buf3[1 << 16];
+    setvbuf(fdat, nullptr, _IOFBF, 1 << 22); setvbuf(fq1, nullptr, _IOFBF, 1 << 22); if (fq2) setvbuf(fq2, nullptr, _IOFBF, 1 << 22);
+    (void)buf1; (void)buf2; (void)buf3;
+    fprintf(fdat, "%-99s\n", "");  // header is patched at the end (parseIt.cpp:195-199)
+    long long nHits = 0;
+    std::string seq(L, 'A'), qual(L, 'I'), seq2(L, 'A'), qual2(L, 'I'), line;
+    auto emit_read = [&](FILE* f, long long id, const std::string& s, const std::string& q) {
+        fprintf(f, "@r%lld\n", id);
+        fwrite(s.data(), 1, s.size(), f); fputs("\n+\n", f);
+        fwrite(q.data(), 1, q.size(), f); fputc('\n', f);
+    };
+    // read sequence of `len` bases starting at strand position spos of transcript t on strand dir, with errors
+    auto make_read = [&](int t, int dir, int spos, std::string& s, std::string& q) {
+        const std::string& g = gseq[tx[t].gene];
+        const int tl = tlen(t);
+        int qv = irand(25, 40);
+        for (int i = 0; i < L; i++) {
+            char c = dir == 0 ? g[tx[t].a + spos + i] : comp(g[tx[t].a + (tl - 1 - (spos + i))]);
+            if (uni(0, 1) < pow(10.0, -qv / 10.0)) c = BASES[rng() & 3];
+            s[i] = c;
+            q[i] = (char)(qv + 33);
+            qv = next_q(qv);
+        }
+    };
+    for (long long r = 0; r < N1; r++) {
+        double u = uni(0, cdf[M]);
+        int t = (int)(std::upper_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
+        t = std::min(std::max(t, 1), M);
+        const int tl = tlen(t);
+        const int dir = (rng() & 1);
+        int frag = L;
+        if (pe) { frag = (int)std::lround(std::normal_distribution<double>(200, 30)(rng)); frag = std::min(std::max(frag, L), std::min(tl, 400)); }
+        const int fpos = irand(0, tl - frag);              // forward coordinate of the fragment in t
+        const int gpos = tx[t].a + fpos;                   // gene coordinate
+        const int spos = dir == 0 ? fpos : tl - fpos - frag;  // position on the strand of alignment
+        make_read(t, dir, spos, seq, qual);
+        if (pe) make_read(t, !dir, tl - spos - frag, seq2, qual2);
+        emit_read(fq1, r, seq, qual);
+        if (pe) emit_read(fq2, r, seq2, qual2);
+        // alignments: every isoform of the gene that contains [gpos, gpos+frag)
+        line.clear();
+        int k = 0;
+        const int g = tx[t].gene;
+        for (int s = gstart[g]; s < gstart[g + 1]; s++) {
+            if (tx[s].a <= gpos && gpos + frag <= tx[s].b) {
+                const int sl = tlen(s), f2 = gpos - tx[s].a;
+                const int p = dir == 0 ? f2 : sl - f2 - frag;
+                char tmp[64];
+                if (pe) snprintf(tmp, sizeof(tmp), " %d %d %d", dir == 0 ? s : -s, p, frag);
+                else snprintf(tmp, sizeof(tmp), " %d %d", dir == 0 ? s : -s, p);
+                line += tmp;
+                ++k;
+            }
+        }
+        fprintf(fdat, "%d%s\n", k, line.c_str());
+        nHits += k;
+    }
+    fseek(fdat, 0, SEEK_SET);
+    fprintf(fdat, "%lld %lld %d", N1, nHits, read_type);
+    fclose(fdat); fclose(fq1); if (fq2) fclose(fq2);
+    {   // unalignable reads
+        FILE* fu1 = fopen((out + (pe ? "/temp/s_un_1.fq" : "/temp/s_un.fq")).c_str(), "w");
+        FILE* fu2 = pe ? fopen((out + "/temp/s_un_2.fq").c_str(), "w") : nullptr;
+        for (long long r = 0; r < N0; r++) {
+            for (int mth = 0; mth < (pe ? 2 : 1); mth++) {
+                int qv = irand(10, 40);
+                for (int i = 0; i < L; i++) { seq[i] = BASES[rng() & 3]; qual[i] = (char)(qv + 33); qv = next_q(qv); }
+                emit_read(mth ? fu2 : fu1, N1 + r, seq, qual);
+            }
+        }
+        fclose(fu1); if (fu2) fclose(fu2);
+    }
+    FILE* f = fopen((out + "/stat/s.cnt").c_str(), "w");
+    fprintf(f, "%lld %lld 0 %lld\n%lld 0 %lld\n%lld %d\n0\t%lld\nInf\t0\n", N0, N1, N, N1, N1, nHits, read_type, N0);
+    fclose(f);
+    f = fopen((out + "/temp/s.mparams").c_str(), "w");
+    fprintf(f, "1 1000\n0.5\n0\n20\n1 1000\n-1 0\n25\n");
+    fclose(f);
+    f = fopen((out + "/temp/s.omit").c_str(), "w");
+    fclose(f);
+    printf("gen_temp: N0=%lld N1=%lld nHits=%lld (%.2f per read) M=%d genes=%d\n", N0, N1, nHits, (double)nHits / N1, M, m);
+    return 0;
+}
