@@ -61,7 +61,7 @@ struct MappedFile {
 
 inline int hardware_threads() {
     unsigned n = std::thread::hardware_concurrency();
-    return (int)std::min<unsigned>(std::max<unsigned>(n, 1), 32);
+    return (int)std::min<unsigned>(std::max<unsigned>(n, 1), 64);
 }
 
 // split [begin, end) into ~n chunks that end right after a '\n'

@@ -8,6 +8,7 @@
 // (rsem_model_calc_conprb) and, in rounds 1-10, accumulate the model's sufficient statistics
 // (rsem_model_estep_update); the O(table) renormalisation between rounds runs here on the host
 // (model_host.hpp); from round 12 the device-resident loop rsem_em_run takes over.
+#include <charconv>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -83,32 +84,58 @@ static void estimate_from_reads(Model& model, const ReadSetFiles& rs, const RefI
         const ReadFile& b = rs.mate[tag][1];
         if (pe && a.n != b.n) die("Mate files of the %d-th read category have different numbers of reads!", tag);
         if (tag == 1) lq_alignable.assign(a.n, 0);
-        for (uint64_t i = 0; i < a.n; i++) {
-            bool lq;
-            if (!pe) lq = a.lq1[i];
-            else if (a.len(i) < model.P.seedLen || b.len(i) < model.P.seedLen) lq = true;  // PairedEndReadQ.h:55-62
-            else lq = a.lq1[i] && b.lq1[i];
-            if (tag == 1) lq_alignable[i] = lq ? 1 : 0;
-            if (lq) {
-                if (a.len(i) < model.P.seedLen || (pe && b.len(i) < model.P.seedLen)) ++n_warns;
-                continue;
-            }
-            for (int m = 0; m < (pe ? 2 : 1); m++) {
-                const ReadFile& f = m ? b : a;
-                const int len = f.len(i);
-                if (!(len > ld.lb && len <= ld.ub)) die("A read of length %d is outside the length range (%d, %d] given to RSEM!", len, ld.lb, ld.ub);
-                ld.pdf[len - ld.lb] += 1.0;
-                const uint8_t* sq = f.seq.data() + f.off[i];
-                if (q) {
-                    const uint8_t* ql = f.qual.data() + f.off[i];
-                    model.qd_init[ql[0]] += 1.0;  // QualDist::update (QualDist.h:55-65)
-                    for (int k = 1; k < len; k++) model.qd_tran[ql[k - 1] * kQSize + ql[k]] += 1.0;
-                    if (tag == 0)
-                        for (int k = 0; k < len; k++) model.nq_c[ql[k] * 5 + sq[k]] += 1.0;  // NoiseQProfile::updateC
-                } else if (tag == 0) {
-                    for (int k = 0; k < len; k++) model.np_c[sq[k]] += 1.0;  // NoiseProfile::updateC
+        // all statistics are integer counts: per-thread tables, merged afterwards (exact in any order)
+        const int nt = a.n > 200000 ? hardware_threads() : 1;
+        struct Local { std::vector<double> len, qi, qt, nc; double npc[5] = {0, 0, 0, 0, 0}; long warns = 0; std::string err; };
+        std::vector<Local> loc(nt);
+        parallel_for(nt, [&](int t) {
+            Local& Lc = loc[t];
+            Lc.len.assign(ld.pdf.size(), 0.0);
+            if (q) { Lc.qi.assign(kQSize, 0.0); Lc.qt.assign((size_t)kQSize * kQSize, 0.0); Lc.nc.assign((size_t)kQSize * 5, 0.0); }
+            const uint64_t lo = a.n * t / nt, hi = a.n * (t + 1) / nt;
+            for (uint64_t i = lo; i < hi; i++) {
+                bool lq;
+                if (!pe) lq = a.lq1[i];
+                else if (a.len(i) < model.P.seedLen || b.len(i) < model.P.seedLen) lq = true;  // PairedEndReadQ.h:55-62
+                else lq = a.lq1[i] && b.lq1[i];
+                if (tag == 1) lq_alignable[i] = lq ? 1 : 0;
+                if (lq) {
+                    if (a.len(i) < model.P.seedLen || (pe && b.len(i) < model.P.seedLen)) ++Lc.warns;
+                    continue;
+                }
+                for (int m = 0; m < (pe ? 2 : 1); m++) {
+                    const ReadFile& f = m ? b : a;
+                    const int len = f.len(i);
+                    if (!(len > ld.lb && len <= ld.ub)) {
+                        char msg[200];
+                        snprintf(msg, sizeof(msg), "A read of length %d is outside the length range (%d, %d] given to RSEM!", len, ld.lb, ld.ub);
+                        Lc.err = msg;
+                        return;
+                    }
+                    Lc.len[len - ld.lb] += 1.0;
+                    const uint8_t* sq = f.seq.data() + f.off[i];
+                    if (q) {
+                        const uint8_t* ql = f.qual.data() + f.off[i];
+                        Lc.qi[ql[0]] += 1.0;  // QualDist::update (QualDist.h:55-65)
+                        for (int k = 1; k < len; k++) Lc.qt[ql[k - 1] * kQSize + ql[k]] += 1.0;
+                        if (tag == 0)
+                            for (int k = 0; k < len; k++) Lc.nc[ql[k] * 5 + sq[k]] += 1.0;  // NoiseQProfile::updateC
+                    } else if (tag == 0) {
+                        for (int k = 0; k < len; k++) Lc.npc[sq[k]] += 1.0;  // NoiseProfile::updateC
+                    }
                 }
             }
+        });
+        for (Local& Lc : loc) {
+            if (!Lc.err.empty()) die("%s", Lc.err.c_str());
+            n_warns += Lc.warns;
+            for (size_t k = 0; k < Lc.len.size(); k++) ld.pdf[k] += Lc.len[k];
+            if (q) {
+                for (int k = 0; k < kQSize; k++) model.qd_init[k] += Lc.qi[k];
+                for (size_t k = 0; k < Lc.qt.size(); k++) model.qd_tran[k] += Lc.qt[k];
+                for (size_t k = 0; k < Lc.nc.size(); k++) model.nq_c[k] += Lc.nc[k];
+            } else
+                for (int k = 0; k < 5; k++) model.np_c[k] += Lc.npc[k];
         }
     }
     if (n_warns > 0) fprintf(stderr, "Warning: There are %ld reads ignored in total.\n", n_warns);
@@ -333,16 +360,32 @@ int main(int argc, char* argv[]) {
         FILE* fo = fopen((imdName + ".ofg").c_str(), "w");
         if (!fo) die("Cannot open %s.ofg for writing!", imdName.c_str());
         fprintf(fo, "%d %llu\n", M, (unsigned long long)N0);
-        for (uint64_t i = 0; i < N1; i++) {
-            int n = 0;
-            if (ncp[i] >= kEpsilon) { ++n; fprintf(fo, "0 %.15g ", ncp[i]); }
-            for (uint64_t k = dat.row_ptr[i]; k < dat.row_ptr[i + 1]; k++)
-                if (cp[k] >= kEpsilon) { ++n; fprintf(fo, "%d %.15g ", sid_abs[k], cp[k]); }
-            if (n > 0) fputc('\n', fo);
-        }
+        // rows are formatted by all host threads into per-chunk buffers, then written in order
+        const int nt = N1 > 100000 ? hardware_threads() : 1;
+        std::vector<std::string> bufs(nt);
+        parallel_for(nt, [&](int t) {
+            const uint64_t lo = N1 * t / nt, hi = N1 * (t + 1) / nt;
+            std::string& b = bufs[t];
+            b.reserve((size_t)((dat.row_ptr[hi] - dat.row_ptr[lo]) * 30 + (hi - lo) * 28));
+            char tmp[64];
+            auto put = [&](int sidv, double v) {  // "<sid> <%.15g> "  (ostream << setprecision(15), EM.cpp:445-452)
+                auto r1 = std::to_chars(tmp, tmp + 16, sidv);
+                *r1.ptr++ = ' ';
+                auto r2 = std::to_chars(r1.ptr, tmp + 60, v, std::chars_format::general, 15);
+                *r2.ptr++ = ' ';
+                b.append(tmp, r2.ptr - tmp);
+            };
+            for (uint64_t i = lo; i < hi; i++) {
+                int n = 0;
+                if (ncp[i] >= kEpsilon) { ++n; put(0, ncp[i]); }
+                for (uint64_t k = dat.row_ptr[i]; k < dat.row_ptr[i + 1]; k++)
+                    if (cp[k] >= kEpsilon) { ++n; put(sid_abs[k], cp[k]); }
+                if (n > 0) b.push_back('\n');
+            }
+        });
+        for (auto& b : bufs) fwrite(b.data(), 1, b.size(), fo);
         fclose(fo);
     }
-
     lap("write .ofg");
     // ---- expected counts with the learned theta (EM.cpp:460-478) -------------------------------------------
     hip_check(rsem_em_expected_weights(em, theta.data(), (double)N0, counts.data(), nullptr, nullptr), "rsem_em_expected_weights");
