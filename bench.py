@@ -134,10 +134,16 @@ def main():
         log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: librsem_hip has no CPU path")
+    if os.environ.get("BENCH_SINGLE_DEVICE"):  # debugging aid: several ranks share GPU 0 (use with BENCH_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if rank == 0:
         build.build()
     if world > 1:

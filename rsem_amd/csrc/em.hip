@@ -200,7 +200,7 @@ struct SliceRegs {
 };
 
 template <int K>
-__device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, int lane, int base, int M,
+__device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
                                    const double* __restrict__ theta, double th0, const double* th_win, double* cnt_win,
                                    const double* __restrict__ scp, const int32_t* __restrict__ ssid,
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
@@ -237,7 +237,7 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
         for (int k = 0; k < K; k++) {
             if (acc[k] != 0.0) {
                 const unsigned off = (unsigned)(rsid[k] - base);
-                if (off < (unsigned)kWindow) unsafeAtomicAdd(&cnt_win[off], acc[k]);
+                if (off < (unsigned)span) unsafeAtomicAdd(&cnt_win[off], acc[k]);
                 else unsafeAtomicAdd(&counts[rsid[k]], acc[k]);
             }
             acc[k] = 0.0;
@@ -257,7 +257,7 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
                     const int sidv = cur.id[k];
                     rsid[k] = sidv;
                     const unsigned off = (unsigned)(sidv - base);
-                    rth[k] = (off < (unsigned)kWindow) ? th_win[off] : theta[sidv];
+                    rth[k] = (off < (unsigned)span) ? th_win[off] : theta[sidv];
                 }
             }
         }
@@ -296,7 +296,6 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
         reduce(B, mB);
     }
     spill(rsid, acc);
-    (void)M;
 }
 
 __global__ __launch_bounds__(kBlock) void k_estep_lane(
@@ -310,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
     __shared__ Shape sS;
     const Unit U = units[blockIdx.x];
     if (threadIdx.x == 0) sS = shapes[U.shape];
-    for (int i = threadIdx.x; i < kWindow; i += blockDim.x) {
+    for (int i = threadIdx.x; i < U.span; i += blockDim.x) {
         const int sidv = U.base + i;
         th_win[i] = (sidv >= 0 && sidv <= M) ? theta[sidv] : 0.0;
         cnt_win[i] = 0.0;
@@ -334,14 +333,14 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
         const uint32_t s_end = min(S.slice_base + S.n_slices, s_begin + T);
         const double th0 = theta[0];
         switch (S.K) {
-            case 1: estep_block<1>(S, s_begin, s_end, lane, U.base, M, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
-            case 2: estep_block<2>(S, s_begin, s_end, lane, U.base, M, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
-            case 3: estep_block<3>(S, s_begin, s_end, lane, U.base, M, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
-            default: estep_block<4>(S, s_begin, s_end, lane, U.base, M, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
+            case 1: estep_block<1>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
+            case 2: estep_block<2>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
+            case 3: estep_block<3>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
+            default: estep_block<4>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kWindow; i += blockDim.x) {
+    for (int i = threadIdx.x; i < U.span; i += blockDim.x) {
         const double v = cnt_win[i];
         if (v != 0.0) unsafeAtomicAdd(&counts[U.base + i], v);
     }
@@ -656,7 +655,7 @@ int build_layout(rsem_em_ctx* c) {
     }
     RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<Unit> units;
-    rc = sell_build_units(c->L, units);
+    rc = sell_build_units(c->L, units, kWindow);
     if (rc != RSEM_OK) return rc;
     c->n_units = (uint32_t)units.size();
     RSEM_HIP_TRY(dmalloc(&c->d_units, units.size()));

@@ -121,7 +121,7 @@ struct SliceRegs {
 // them to the workgroup's LDS window when the tuple changes.  Weight order inside a read: noise,
 // then the G lanes of the read in order, each lane's K planes in order.
 template <int K>
-__device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32_t s_end, int lane, int base,
+__device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
                                    const double* __restrict__ g, double g0, const double* g_win, int* cnt_win,
                                    const double* __restrict__ scp, const int32_t* __restrict__ ssid,
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
@@ -162,7 +162,7 @@ __device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin,
         for (int k = 0; k < K; k++) {
             if (acc[k] != 0) {
                 const unsigned off = (unsigned)(rsid[k] - base);
-                if (off < (unsigned)kGWindow) atomicAdd(&cnt_win[off], acc[k]);
+                if (off < (unsigned)span) atomicAdd(&cnt_win[off], acc[k]);
                 else atomicAdd(&counts[rsid[k]], acc[k]);
             }
             acc[k] = 0;
@@ -177,7 +177,7 @@ __device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin,
                     const int sidv = cur.id[k];
                     rsid[k] = sidv;
                     const unsigned off = (unsigned)(sidv - base);
-                    rg[k] = (off < (unsigned)kGWindow) ? g_win[off] : g[sidv];
+                    rg[k] = (off < (unsigned)span) ? g_win[off] : g[sidv];
                 }
             }
         }
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void k_sample_z_lane(
     __shared__ int s_noise;
     const Unit U = units[blockIdx.x];
     if (threadIdx.x == 0) { sS = shapes[U.shape]; s_noise = 0; }
-    for (int i = threadIdx.x; i < kGWindow; i += blockDim.x) {
+    for (int i = threadIdx.x; i < U.span; i += blockDim.x) {
         const int sidv = U.base + i;
         g_win[i] = (sidv >= 0 && sidv <= M) ? g[sidv] : 0.0;
         cnt_win[i] = 0;
@@ -277,16 +277,16 @@ __global__ __launch_bounds__(kBlock) void k_sample_z_lane(
         const uint32_t s_end = min(S.slice_base + S.n_slices, s_begin + T);
         const double g0 = g[0];
         switch (S.K) {
-            case 1: gibbs_block<1>(S, T, s_begin, s_end, lane, U.base, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
-            case 2: gibbs_block<2>(S, T, s_begin, s_end, lane, U.base, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
-            case 3: gibbs_block<3>(S, T, s_begin, s_end, lane, U.base, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
-            default: gibbs_block<4>(S, T, s_begin, s_end, lane, U.base, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
+            case 1: gibbs_block<1>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
+            case 2: gibbs_block<2>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
+            case 3: gibbs_block<3>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
+            default: gibbs_block<4>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
         }
     }
     for (int d = 32; d >= 1; d >>= 1) noise += __shfl_xor(noise, d);
     if (lane == 0 && noise) atomicAdd(&s_noise, noise);
     __syncthreads();
-    for (int i = threadIdx.x; i < kGWindow; i += blockDim.x) {
+    for (int i = threadIdx.x; i < U.span; i += blockDim.x) {
         const int v = cnt_win[i];
         if (v != 0) atomicAdd(&counts[U.base + i], v);
     }
@@ -683,7 +683,7 @@ int rsem_gibbs_create(rsem_gibbs_ctx** out, int device, int32_t M, uint64_t N1, 
     if (rc == RSEM_OK) rc = sell_fill_values(c->L, st, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_scp, c->d_sncp);
     if (rc == RSEM_OK && hipStreamSynchronize(st) != hipSuccess) rc = RSEM_ERR_HIP;
     std::vector<Unit> units;
-    if (rc == RSEM_OK) rc = sell_build_units(c->L, units);
+    if (rc == RSEM_OK) rc = sell_build_units(c->L, units, kGWindow);
     if (rc == RSEM_OK) {
         c->n_units = (uint32_t)units.size();
         if (dmalloc(&c->d_units, units.size()) != hipSuccess) rc = RSEM_ERR_NOMEM;

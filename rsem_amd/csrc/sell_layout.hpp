@@ -166,6 +166,25 @@ __global__ void k_slice_minsid(const Shape* __restrict__ shapes, int n_shapes, u
     slice_minsid[s] = (uint32_t)((keys_sorted[S.row_base + q] >> 32) & 0x3ffffffu);
 }
 
+// largest sid of every slice (for the extent of a unit's LDS windows)
+__global__ void k_slice_maxsid(const Shape* __restrict__ shapes, int n_shapes, uint32_t n_slices,
+                               const int32_t* __restrict__ ssid, uint32_t* slice_maxsid) {
+    __shared__ Shape sh_shapes[kMaxShapes];
+    for (int i = threadIdx.x; i < n_shapes; i += blockDim.x) sh_shapes[i] = shapes[i];
+    __syncthreads();
+    int lane = threadIdx.x & 63;
+    uint32_t s = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    int sh = 0;
+    while (sh + 1 < n_shapes && s >= sh_shapes[sh + 1].slice_base) ++sh;
+    const Shape S = sh_shapes[sh];
+    uint64_t pl0 = (S.plane_base + (uint64_t)(s - S.slice_base) * S.K) * 64;
+    int mx = 0;
+    for (int k = 0; k < S.K; k++) mx = max(mx, ssid[pl0 + (uint64_t)k * 64 + lane]);
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+    if (lane == 0) slice_maxsid[s] = (uint32_t)mx;
+}
+
 template <typename T>
 hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)); }
 
@@ -184,10 +203,11 @@ struct SellLayout {
     int32_t* d_ssid = nullptr;
     unsigned long long* d_masks = nullptr;
     uint32_t* d_slice_minsid = nullptr;
+    uint32_t* d_slice_maxsid = nullptr;
 };
 
 inline void sell_free(SellLayout& L) {
-    hipFree(L.d_order); hipFree(L.d_shapes); hipFree(L.d_ssid); hipFree(L.d_masks); hipFree(L.d_slice_minsid);
+    hipFree(L.d_order); hipFree(L.d_shapes); hipFree(L.d_ssid); hipFree(L.d_masks); hipFree(L.d_slice_minsid); hipFree(L.d_slice_maxsid);
     L = SellLayout();
 }
 
@@ -281,6 +301,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     RSEM_HIP_TRY(dmalloc(&L.d_ssid, L.n_planes * 64));
     RSEM_HIP_TRY(dmalloc(&L.d_masks, (size_t)L.n_slices));
     RSEM_HIP_TRY(dmalloc(&L.d_slice_minsid, (size_t)L.n_slices));
+    RSEM_HIP_TRY(dmalloc(&L.d_slice_maxsid, (size_t)L.n_slices));
     RSEM_HIP_TRY(hipMemsetAsync(L.d_ssid, 0, sizeof(int32_t) * L.n_planes * 64, st));
     if (L.n_sell_rows) {
         hipLaunchKernelGGL(k_fill_sell<true>, dim3(rsem::ceil_div(L.n_sell_rows, kBlock)), dim3(kBlock), 0, st,
@@ -289,6 +310,9 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
         RSEM_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_slice_minsid, dim3(rsem::ceil_div(L.n_slices, kBlock)), dim3(kBlock), 0, st, L.d_shapes,
                            L.n_shapes, L.T, L.n_slices, d_keys2, L.d_slice_minsid);
+        RSEM_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_slice_maxsid, dim3(rsem::ceil_div(L.n_slices, kBlock / 64)), dim3(kBlock), 0, st, L.d_shapes,
+                           L.n_shapes, L.n_slices, L.d_ssid, L.d_slice_maxsid);
         RSEM_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_slice_masks, dim3(rsem::ceil_div(L.n_slices, kBlock / 64)), dim3(kBlock), 0, st,
                            L.d_shapes, L.n_shapes, L.T, L.n_slices, L.d_ssid, L.d_masks);
@@ -306,12 +330,16 @@ struct Unit {
     uint32_t block_begin;  // block index within the shape
     int32_t n_blocks;      // 1..4
     int32_t base;
+    int32_t span;          // sids [base, base + span) are staged in LDS (<= the window capacity)
+    int32_t pad[3];
 };
 
-inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units) {
-    std::vector<uint32_t> ms(L.n_slices);
-    if (L.n_slices)
+inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units, int window_cap) {
+    std::vector<uint32_t> ms(L.n_slices), mx(L.n_slices);
+    if (L.n_slices) {
         RSEM_HIP_TRY(hipMemcpy(ms.data(), L.d_slice_minsid, sizeof(uint32_t) * L.n_slices, hipMemcpyDeviceToHost));
+        RSEM_HIP_TRY(hipMemcpy(mx.data(), L.d_slice_maxsid, sizeof(uint32_t) * L.n_slices, hipMemcpyDeviceToHost));
+    }
     units.clear();
     for (int sh = 0; sh < L.n_shapes; sh++) {
         const Shape& S = L.h_shapes[sh];
@@ -322,6 +350,13 @@ inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units) {
             U.block_begin = b;
             U.n_blocks = (int32_t)std::min<uint32_t>(kBlock / 64, nb - b);
             U.base = (int32_t)ms[S.slice_base + b * L.T];
+            const uint32_t s0 = S.slice_base + b * L.T;
+            const uint32_t s1 = std::min(S.slice_base + S.n_slices, s0 + (uint32_t)U.n_blocks * L.T);
+            uint32_t top = 0;
+            for (uint32_t t = s0; t < s1; t++) top = std::max(top, mx[t]);
+            long long span = (long long)top - U.base + 1;
+            U.span = (int32_t)std::min<long long>(std::max<long long>(span, 1), window_cap);
+            U.pad[0] = U.pad[1] = U.pad[2] = 0;
             units.push_back(U);
         }
     }
