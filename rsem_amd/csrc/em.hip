@@ -473,11 +473,11 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fused(int32_t M, double N0, do
     if (threadIdx.x == 0) {
         __hip_atomic_store(&partials[blockIdx.x], t_counts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&partials[kMstepBlocks + blockIdx.x], t_noise, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // the only data handed to the other workgroups are these two write-through (agent-scope) stores, and they
+        // are read back with agent-scope loads: draining them before the arrival is all the ordering needed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(&ctrl->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (__hip_atomic_load(&ctrl->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nb) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     // lanes 0..31 of wave 0 load the count partials, lanes 32..63 the noise partials; fixed summation order

@@ -90,18 +90,38 @@ __device__ inline bool ref_mask(const DevData& D, int sid, int p) {  // RefSeq.h
 
 // (Q)Profile::getProb (QProfile.h:111-120, Profile.h:114-120): product over the read
 template <bool kQ>
-__device__ inline double profile_prob(const DevTables& T, const uint8_t* rseq, const uint8_t* rqual, int len,
-                                      const uint8_t* ref, int totLen, int pos, int dir) {
+__device__ inline double profile_prob(const double* __restrict__ prof, const uint8_t* __restrict__ rseq,
+                                      const uint8_t* __restrict__ rqual, int len, const uint8_t* __restrict__ ref,
+                                      int totLen, int pos, int dir) {
     double prob = 1.0;
-    for (int i = 0; i < len; i++) {
+    // the table look-ups of 8 consecutive bases are independent: fetch them together, multiply in read order
+    int i = 0;
+    for (; i + 8 <= len; i += 8) {
+        double p[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int row = kQ ? rqual[i + u] : i + u;
+            p[u] = prof[(row * 5 + ref_id(ref, totLen, i + u + pos, dir)) * 5 + rseq[i + u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) prob *= p[u];
+    }
+    for (; i < len; i++) {
         const int row = kQ ? rqual[i] : i;
-        prob *= T.prof[(row * 5 + ref_id(ref, totLen, i + pos, dir)) * 5 + rseq[i]];
+        prob *= prof[(row * 5 + ref_id(ref, totLen, i + pos, dir)) * 5 + rseq[i]];
     }
     return prob;
 }
 
 template <bool kQ, bool kPE>
 __global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double* cp) {
+    // QProfile (100 x 5 x 5 doubles = 20 KB) is staged in LDS; the position-indexed Profile stays in global memory
+    __shared__ double s_prof[kQ ? 2500 : 1];
+    if (kQ) {
+        for (int i = threadIdx.x; i < 2500; i += blockDim.x) s_prof[i] = T.prof[i];
+        __syncthreads();
+    }
+    const double* prof = kQ ? s_prof : T.prof;
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= D.nnz) return;
     const uint32_t row = D.hit_row[j];
@@ -133,7 +153,7 @@ __global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double*
                     value = ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, len1, totLen) * rspd_adj(T, fpos, effL, fullLen);
                 }
                 const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
-                prob = ori * value * profile_prob<kQ>(T, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1, ref, totLen, pos, dir);
+                prob = ori * value * profile_prob<kQ>(prof, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1, ref, totLen, pos, dir);
                 if (prob < kEpsilon) prob = 0.0;
                 prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
             }
@@ -145,12 +165,12 @@ __global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double*
                 const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
                 prob = ori * ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, insertLen, totLen) * rspd_adj(T, fpos, effL, fullLen);
                 prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len1, insertLen) *
-                        profile_prob<kQ>(T, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1, ref, totLen, pos, dir);
+                        profile_prob<kQ>(prof, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1, ref, totLen, pos, dir);
                 const uint64_t q0 = D.read_off[1][row];
                 const int len2 = (int)(D.read_off[1][row + 1] - q0);
                 const int m2pos = totLen - pos - insertLen, m2dir = !dir;
                 prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len2, insertLen) *
-                        profile_prob<kQ>(T, D.read_seq[1] + q0, kQ ? D.read_qual[1] + q0 : nullptr, len2, ref, totLen, m2pos, m2dir);
+                        profile_prob<kQ>(prof, D.read_seq[1] + q0, kQ ? D.read_qual[1] + q0 : nullptr, len2, ref, totLen, m2pos, m2dir);
                 if (prob < kEpsilon) prob = 0.0;
                 prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
             }
@@ -161,14 +181,26 @@ __global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double*
 
 // Noise(Q)Profile::getProb
 template <bool kQ>
-__device__ inline double noise_prob(const DevTables& T, const uint8_t* rseq, const uint8_t* rqual, int len) {
+__device__ inline double noise_prob(const double* __restrict__ noise, const uint8_t* __restrict__ rseq,
+                                    const uint8_t* __restrict__ rqual, int len) {
     double prob = 1.0;
-    for (int i = 0; i < len; i++) prob *= kQ ? T.noise[rqual[i] * 5 + rseq[i]] : T.noise[rseq[i]];
+    int i = 0;
+    for (; i + 8 <= len; i += 8) {
+        double p[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) p[u] = kQ ? noise[rqual[i + u] * 5 + rseq[i + u]] : noise[rseq[i + u]];
+#pragma unroll
+        for (int u = 0; u < 8; u++) prob *= p[u];
+    }
+    for (; i < len; i++) prob *= kQ ? noise[rqual[i] * 5 + rseq[i]] : noise[rseq[i]];
     return prob;
 }
 
 template <bool kQ, bool kPE>
 __global__ __launch_bounds__(kBlk) void k_noise(DevData D, DevTables T, double* ncp) {
+    __shared__ double s_noise[kQ ? 500 : 5];
+    for (int i = threadIdx.x; i < (kQ ? 500 : 5); i += blockDim.x) s_noise[i] = T.noise[i];
+    __syncthreads();
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D.N1) return;
     double prob = 0.0;
@@ -177,11 +209,11 @@ __global__ __launch_bounds__(kBlk) void k_noise(DevData D, DevTables T, double* 
         const int len1 = (int)(D.read_off[0][i + 1] - r0);
         const double* lpdf = (kPE || T.has_mld) ? T.mld_pdf : T.gld_pdf;
         const int llb = (kPE || T.has_mld) ? T.mld_lb : T.gld_lb;
-        prob = lpdf[len1 - llb] * noise_prob<kQ>(T, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1);
+        prob = lpdf[len1 - llb] * noise_prob<kQ>(s_noise, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1);
         if (kPE) {
             const uint64_t q0 = D.read_off[1][i];
             const int len2 = (int)(D.read_off[1][i + 1] - q0);
-            prob *= lpdf[len2 - llb] * noise_prob<kQ>(T, D.read_seq[1] + q0, kQ ? D.read_qual[1] + q0 : nullptr, len2);
+            prob *= lpdf[len2 - llb] * noise_prob<kQ>(s_noise, D.read_seq[1] + q0, kQ ? D.read_qual[1] + q0 : nullptr, len2);
         }
         if (prob < kEpsilon) prob = 0.0;
         prob = (T.mw[0] < kEpsilon) ? 0.0 : prob / T.mw[0];
