@@ -165,8 +165,10 @@ def find_all(hay, needle):
     return res
 
 
-def make_sam(path, model_type, txs, sim_prefix):
-    """txs: list of (name, gene, fullseq_incl_polyA) in reference (internal id) order."""
+def make_sam(path, model_type, txs, sim_prefix, omit_last=0):
+    """txs: list of (name, gene, fullseq_incl_polyA) in reference (internal id) order.
+    omit_last: leave the last transcripts out of the @SQ header (-> imd.omit, Transcripts.h:135-142); alignments to them are dropped."""
+    n_keep = len(txs) - omit_last
     fastq = model_type in (1, 3)
     paired = model_type >= 2
     ext = "fq" if fastq else "fa"
@@ -175,7 +177,7 @@ def make_sam(path, model_type, txs, sim_prefix):
         genes.setdefault(g, []).append(i)
     with open(path, "w") as sam:
         sam.write("@HD\tVN:1.0\tSO:unsorted\n")
-        for name, _, seq in txs:
+        for name, _, seq in txs[:n_keep]:
             sam.write("@SQ\tSN:%s\tLN:%d\n" % (name, len(seq)))
         if not paired:
             reads = read_fasta_or_fastq("%s.%s" % (sim_prefix, ext), fastq)
@@ -194,6 +196,9 @@ def make_sam(path, model_type, txs, sim_prefix):
                     for p in find_all(txs[j][2], sub):
                         hits.append((j, p))
                 assert (sid - 1, fpos) in hits
+                hits = [(j, p) for j, p in hits if j < n_keep]
+                if not hits:
+                    sam.write("%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (name, seq, q))
                 for j, p in hits:
                     if d == 0:
                         sam.write("%s\t0\t%s\t%d\t255\t%dM\t*\t0\t0\t%s\t%s\n" % (name, txs[j][0], p + 1, L, seq, q))
@@ -246,7 +251,8 @@ def load_ref_seq(path):
 
 
 def build_fixture(name, model_type, n_reads, seed, n_genes=14, max_iso=4, polyA=False, estRSPD=0,
-                  read_len=(36, 50), gibbs=(20, 40, 1), gibbs_threads=2, theta0=0.06):
+                  read_len=(36, 50), gibbs=(20, 40, 1), gibbs_threads=2, theta0=0.06, probF=0.5, frag_mean=None,
+                  omit_last=0, pseudo_count=None):
     rng = np.random.default_rng(seed)
     out = os.path.join(HERE, name)
     work = os.path.join("/tmp", "rsem_fixture_" + name)
@@ -276,7 +282,7 @@ def build_fixture(name, model_type, n_reads, seed, n_genes=14, max_iso=4, polyA=
     ordered = [(n, t2g[n], s) for n, s in refseqs]
 
     sim_model = os.path.join(work, "sim.model")
-    write_sim_model(sim_model, model_type, rng, read_len[0], read_len[1])
+    write_sim_model(sim_model, model_type, rng, read_len[0], read_len[1], probF=probF)
     tpm = np.exp(rng.normal(0, 2, M))
     tpm[rng.random(M) < 0.3] = 0.0
     tpm = tpm / tpm.sum() * 1e6
@@ -288,7 +294,7 @@ def build_fixture(name, model_type, n_reads, seed, n_genes=14, max_iso=4, polyA=
     run([os.path.join(REFBIN, "rsem-simulate-reads"), ref, sim_model, os.path.join(work, "sim.isoforms.results"),
          str(theta0), str(n_reads), sim, "--seed", str(seed), "-q"])
     samf = os.path.join(work, "x.sam")
-    make_sam(samf, model_type, ordered, sim)
+    make_sam(samf, model_type, ordered, sim, omit_last=omit_last)
 
     imd = os.path.join(out, "temp", "s")
     stat = os.path.join(out, "stat", "s")
@@ -304,7 +310,7 @@ def build_fixture(name, model_type, n_reads, seed, n_genes=14, max_iso=4, polyA=
         idx = [imd + "_alignable_1." + ext, imd + "_alignable_2." + ext]
     run([os.path.join(REFBIN, "rsem-build-read-index"), "32", fastq, "1"] + idx)
     with open(imd + ".mparams", "w") as f:
-        f.write("1 1000\n0.5\n%d\n20\n1 1000\n-1 0\n25\n" % estRSPD)
+        f.write("1 1000\n%g\n%d\n20\n1 1000\n%s\n25\n" % (probF, estRSPD, "%g %g" % frag_mean if frag_mean else "-1 0"))
 
     log = run([os.path.join(REFBIN, "rsem-run-em"), oref, str(model_type), os.path.join(out, "s"), imd, stat,
                "-p", "1", "--gibbs-out"])
@@ -315,13 +321,14 @@ def build_fixture(name, model_type, n_reads, seed, n_genes=14, max_iso=4, polyA=
     shutil.copy(imd + ".gene_res", imd + ".gene_res.em")
     b, n, g = gibbs
     run([os.path.join(REFBIN, "rsem-run-gibbs"), oref, imd, stat, str(b), str(n), str(g),
-         "-p", str(gibbs_threads), "--seed", "12345", "-q"])
+         "-p", str(gibbs_threads), "--seed", "12345", "-q"] + (["--pseudo-count", str(pseudo_count)] if pseudo_count else []))
     # the read index is only needed by the reference binary; regenerated on demand by tests
     for p in idx:
         os.remove(p + ".ridx")
     with open(os.path.join(out, "META"), "w") as f:
         f.write("model_type %d\nM %d\nn_reads %d\nseed %d\npolyA %d\nestRSPD %d\ngibbs %d %d %d\ngibbs_threads %d\ngibbs_seed 12345\n"
                 % (model_type, M, n_reads, seed, polyA, estRSPD, b, n, g, gibbs_threads))
+        f.write("pseudo_count_x1000 %d\n" % int(round((pseudo_count or 1.0) * 1000)))
     shutil.rmtree(work, ignore_errors=True)
     sz = sum(os.path.getsize(os.path.join(dp, fn)) for dp, _, fns in os.walk(out) for fn in fns)
     print("fixture %-10s type %d M=%d size=%.1f KB" % (name, model_type, M, sz / 1024))
@@ -336,6 +343,11 @@ if __name__ == "__main__":
         dict(name="pe_noq", model_type=2, n_reads=1200, seed=13),
         dict(name="pe_q", model_type=3, n_reads=1200, seed=14),
         dict(name="pe_q_polya_rspd", model_type=3, n_reads=1200, seed=16, polyA=True, estRSPD=1),
+        # --fragment-length-mean/sd with single-end reads (mld != NULL paths, LenDist::setAsNormal)
+        dict(name="se_q_fragmean", model_type=1, n_reads=1200, seed=17, frag_mean=(140, 25)),
+        # reverse-stranded protocol + RSPD (the probF < 0.1 && dir == 1 branch of update), transcripts missing from
+        # the alignment header (imd.omit -> counts = -1 in Gibbs), single-cell pseudo count
+        dict(name="se_noq_rev_rspd_omit", model_type=0, n_reads=1200, seed=18, probF=0.0, estRSPD=1, omit_last=3, pseudo_count=0.1),
     ]
     for sp in specs:
         if not only or sp["name"] in only:

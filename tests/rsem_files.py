@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FIXTURES = ["se_noq", "se_q", "se_q_polya_rspd", "pe_noq", "pe_q", "pe_q_polya_rspd"]
+FIXTURES = ["se_noq", "se_q", "se_q_polya_rspd", "pe_noq", "pe_q", "pe_q_polya_rspd", "se_q_fragmean", "se_noq_rev_rspd_omit"]
 
 
 def fixture(name):
@@ -145,3 +145,16 @@ def read_res(path):
 
 def read_countvectors(path):
     return np.loadtxt(path, dtype=np.int32, ndmin=2)
+
+
+def gibbs_setup(fx, M, N0, N1):
+    """init_counts (0 / -1 for omitted transcripts), pseudo count and totc as rsem-run-gibbs derives them
+    (Gibbs.cpp:152-167)."""
+    meta = read_meta(fx)
+    pseudoC = meta.get("pseudo_count_x1000", 1000) / 1000.0
+    init = np.zeros(M + 1, np.int32)
+    with open(os.path.join(fx, "temp", "s.omit")) as f:
+        for tok in f.read().split():
+            init[int(tok)] = -1
+    totc = (M + 1 - int((init < 0).sum())) * pseudoC + N0 + N1
+    return init, pseudoC, totc

@@ -101,8 +101,11 @@ def test_rsem_run_gibbs_exact_matches_reference(name, tmp_path):
     shutil.copy(imd + ".gene_res.em", imd + ".gene_res")
     for k in range(meta["gibbs_threads"]):
         os.remove(imd + ".countvectors%d" % k)
+    extra = []
+    if meta.get("pseudo_count_x1000", 1000) != 1000:
+        extra = ["--pseudo-count", str(meta["pseudo_count_x1000"] / 1000.0)]
     _run([os.path.join(BIN, "rsem-run-gibbs"), os.path.join(dst, "ref"), imd, os.path.join(dst, "stat", "s"), str(b), str(n), str(g),
-          "-p", str(meta["gibbs_threads"]), "--seed", str(meta["gibbs_seed"]), "-q", "--gibbs-mode", "exact"])
+          "-p", str(meta["gibbs_threads"]), "--seed", str(meta["gibbs_seed"]), "-q", "--gibbs-mode", "exact"] + extra)
     for k in range(meta["gibbs_threads"]):
         with open(imd + ".countvectors%d" % k, "rb") as f1, open(os.path.join(fx, "temp", "s.countvectors%d" % k), "rb") as f2:
             assert f1.read() == f2.read()

@@ -48,7 +48,7 @@ def test_step_matches_oracle_and_golden(name, variant):
     assert np.allclose(counts, oc, rtol=1e-9, atol=1e-12)
     assert np.allclose(theta_new, oth, rtol=1e-9, atol=1e-15)
     assert abs(s - os_) < 1e-9 * os_
-    assert t == ot and abs(b - ob) <= 1e-9 * max(ob, 1e-12)
+    assert t == ot and abs(b - ob) <= 1e-9 * max(ob, 1e-12) + 1e-12  # bChange is a difference quotient of nearly equal numbers
     # golden: expected_count row of the reference's iso_res (printed %.2f)
     gold = np.array(rf.read_res(os.path.join(d["fx"], "temp", "s.iso_res.em"))[4], float)
     assert np.allclose(counts[1:], gold, atol=0.00501)

@@ -28,12 +28,13 @@ def _load(name):
     grp = rf.read_grp(os.path.join(fx, "ref.grp"))
     eel = orc.calc_eel(M, full, tot, model["gld"])
     N1 = len(rp) - 1
+    init, pseudoC, totc = rf.gibbs_setup(fx, M, N0, N1)
     return dict(fx=fx, M=M, N0=N0, N1=N1, rp=rp, sid=sid, val=val, eel=eel, mw=model["mw"], grp=grp,
-                meta=rf.read_meta(fx), totc=(M + 1) * 1.0 + N0 + N1)
+                meta=rf.read_meta(fx), totc=totc, init=init, pseudoC=pseudoC)
 
 
-def _ctx(d, pseudoC=1.0):
-    return capi().GibbsContext(d["M"], d["rp"], d["sid"], d["val"], np.zeros(d["M"] + 1, np.int32), None, pseudoC,
+def _ctx(d, alpha=None):
+    return capi().GibbsContext(d["M"], d["rp"], d["sid"], d["val"], d["init"], alpha, d["pseudoC"],
                                d["totc"], d["N0"], d["eel"], d["mw"], d["grp"])
 
 
@@ -50,7 +51,7 @@ def test_exact_chain_bit_identical_to_reference(name):
         cv, acc, _ = ctx.run(capi().GIBBS_EXACT, seeds[k], burnin, ns, gap)
         gold = rf.read_countvectors(os.path.join(d["fx"], "temp", "s.countvectors%d" % k))
         assert np.array_equal(cv, gold)
-        ocv, oacc = orc.gibbs_chain(d["M"], d["rp"], d["sid"], d["val"], np.zeros(d["M"] + 1, np.int32), None, 1.0,
+        ocv, oacc = orc.gibbs_chain(d["M"], d["rp"], d["sid"], d["val"], d["init"], None, d["pseudoC"],
                                     d["totc"], d["N0"], d["eel"], d["mw"], d["grp"], seeds[k], burnin, ns, gap)
         for a, b in zip(acc, oacc):
             assert np.allclose(a, b, rtol=1e-10, atol=1e-9)
@@ -75,13 +76,13 @@ def test_parallel_sampler_invariants_and_determinism():
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["se_q", "pe_q", "se_q_polya_rspd"])
+@pytest.mark.parametrize("name", ["se_q", "pe_q", "se_q_polya_rspd", "se_noq_rev_rspd_omit"])
 def test_parallel_posterior_means_within_sampling_tolerance(name):
     """z-test of PARALLEL posterior mean counts against a long oracle (reference-equivalent) chain."""
     d = _load(name)
     M = d["M"]
     n_o = 4000
-    ocv, oacc = orc.gibbs_chain(M, d["rp"], d["sid"], d["val"], np.zeros(M + 1, np.int32), None, 1.0, d["totc"], d["N0"],
+    ocv, oacc = orc.gibbs_chain(M, d["rp"], d["sid"], d["val"], d["init"], None, d["pseudoC"], d["totc"], d["N0"],
                                 d["eel"], d["mw"], d["grp"], 99, 200, n_o, 1)
     ctx = _ctx(d)
     n_g = 4000
@@ -100,4 +101,21 @@ def test_parallel_posterior_means_within_sampling_tolerance(name):
     # TPM means
     to, tg = oacc[2] / n_o, acc[2] / n_g
     assert np.corrcoef(to[1:], tg[1:])[0, 1] > 0.9995
+    ctx.close()
+
+
+def test_exact_chain_with_prior_file_semantics():
+    """--prior: per-transcript pseudo counts (Gibbs.cpp:171-194, 300-303): same integer draws as the oracle."""
+    d = _load("pe_q")
+    M = d["M"]
+    rng = np.random.default_rng(3)
+    alpha = np.concatenate([[0.0], rng.uniform(0.05, 3.0, M)])
+    totc = 1 + alpha[1:].sum() + d["N0"] + d["N1"]
+    ctx = capi().GibbsContext(M, d["rp"], d["sid"], d["val"], d["init"], alpha, 1.0, totc, d["N0"], d["eel"], d["mw"], d["grp"])
+    cv, acc, _ = ctx.run(capi().GIBBS_EXACT, 777, 5, 6, 2)
+    ocv, oacc = orc.gibbs_chain(M, d["rp"], d["sid"], d["val"], d["init"], alpha, 1.0, totc, d["N0"], d["eel"], d["mw"],
+                                d["grp"], 777, 5, 6, 2)
+    assert np.array_equal(cv, ocv)
+    for a, b in zip(acc, oacc):
+        assert np.allclose(a, b, rtol=1e-10, atol=1e-9)
     ctx.close()

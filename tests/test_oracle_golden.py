@@ -65,13 +65,12 @@ def test_gibbs_chain_bit_exact(name):
     seeds = orc.chain_seeds(d["meta"]["gibbs_seed"], T)
     eel = orc.calc_eel(M, d["full"], d["tot"], d["model"]["gld"])
     mw = d["model"]["mw"]
-    init_counts = np.zeros(M + 1, np.int32)
-    totc = (M + 1) * 1.0 + N0 + N1
+    init_counts, pseudoC, totc = rf.gibbs_setup(d["fx"], M, N0, N1)
     m = len(d["grp"]) - 1
     tot = [np.zeros(M + 1) for _ in range(4)] + [np.zeros(m)]
     for k in range(T):
         ns = nsamples // T + (1 if k < nsamples % T else 0)
-        cv, acc = orc.gibbs_chain(M, rp, sid, val, init_counts, None, 1.0, totc, N0, eel, mw, d["grp"], seeds[k],
+        cv, acc = orc.gibbs_chain(M, rp, sid, val, init_counts, None, pseudoC, totc, N0, eel, mw, d["grp"], seeds[k],
                                   burnin, ns, gap)
         gold = rf.read_countvectors(os.path.join(d["fx"], "temp", "s.countvectors%d" % k))
         assert np.array_equal(cv, gold)
