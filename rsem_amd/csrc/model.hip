@@ -15,6 +15,7 @@
 //   k_update : one thread per alignment; weighted histograms accumulate in per-workgroup LDS tables
 //              (ds_add_f64) and are merged with one device atomic per touched entry.
 #include <cmath>
+#include <thread>
 #include <vector>
 
 #include "em_internal.hpp"
@@ -50,12 +51,15 @@ struct DevData {
     const int32_t* sid_signed;
     const int32_t* pos;
     const int32_t* insertL;
-    const uint64_t* read_off[2];
-    const uint8_t* read_seq[2];
-    const uint8_t* read_qual[2];
+    // reads, packed 8 base ids (or qualities) per 64-bit word, every read starting on a word boundary
+    const uint64_t* roff8[2];   // [N1+1] first word of read i
+    const int32_t* rlen[2];     // [N1]
+    const uint64_t* rseq_w[2];
+    const uint64_t* rqual_w[2];
     const uint8_t* lq;
-    const uint64_t* ref_off;
-    const uint8_t* ref_seq;
+    // both strands of every transcript as base ids (strand 1 = reverse complement), word-aligned starts
+    const uint64_t* soff;       // [2*(M+1)] byte offset of strand dir of transcript sid: soff[2*sid + dir]
+    const uint64_t* refw;
     const int32_t* fullLen;
     const int32_t* totLen;
     const uint64_t* mask_off;
@@ -78,37 +82,39 @@ __device__ inline double rspd_adj(const DevTables& T, int fpos, int effL, int fu
     double denom = rspd_cdf_at(T, effL, fullLen);
     return denom >= kEpsilon ? (rspd_cdf_at(T, fpos + 1, fullLen) - rspd_cdf_at(T, fpos, fullLen)) / denom : 0.0;
 }
-// RefSeq::get_id (RefSeq.h:84-87): base id on strand dir at strand position p
-__device__ inline int ref_id(const uint8_t* seq, int totLen, int p, int dir) {
-    if (dir == 0) return seq[p];
-    int b = seq[totLen - p - 1];
-    return b == 4 ? 4 : 3 - b;
-}
+// RefSeq::get_id (RefSeq.h:84-87) is a table look-up here: both strands are stored, so the base ids of strand
+// positions p..p+7 are eight consecutive bytes.  load8() fetches them from the word-aligned array.
+__device__ inline uint64_t funnel8(uint64_t w0, uint64_t w1, int sh) { return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0; }
 __device__ inline bool ref_mask(const DevData& D, int sid, int p) {  // RefSeq.h:89-92
     return (D.mask_words[D.mask_off[sid] + (p >> 5)] >> (p & 31)) & 1u;
 }
 
-// (Q)Profile::getProb (QProfile.h:111-120, Profile.h:114-120): product over the read
+// (Q)Profile::getProb (QProfile.h:111-120, Profile.h:114-120): product over the read, 8 bases per step
+// (three 8-byte loads instead of 24 byte loads; the factors are multiplied in read order, padding multiplies by 1).
 template <bool kQ>
-__device__ inline double profile_prob(const double* __restrict__ prof, const uint8_t* __restrict__ rseq,
-                                      const uint8_t* __restrict__ rqual, int len, const uint8_t* __restrict__ ref,
-                                      int totLen, int pos, int dir) {
+__device__ inline double profile_prob(const double* __restrict__ prof, const uint64_t* __restrict__ rs,
+                                      const uint64_t* __restrict__ rq, int len, const uint64_t* __restrict__ refw,
+                                      uint64_t a /* byte address of the first strand position */) {
     double prob = 1.0;
-    // the table look-ups of 8 consecutive bases are independent: fetch them together, multiply in read order
-    int i = 0;
-    for (; i + 8 <= len; i += 8) {
+    const uint64_t* rw = refw + (a >> 3);
+    const int sh = (int)(a & 7) * 8;
+    uint64_t w0 = rw[0];
+    for (int i = 0; i < len; i += 8) {
+        const uint64_t w1 = rw[(i >> 3) + 1];
+        const uint64_t rf = funnel8(w0, w1, sh);
+        w0 = w1;
+        const uint64_t sb = rs[i >> 3];
+        const uint64_t qb = kQ ? rq[i >> 3] : 0;
+        const int n = len - i;
         double p[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int row = kQ ? rqual[i + u] : i + u;
-            p[u] = prof[(row * 5 + ref_id(ref, totLen, i + u + pos, dir)) * 5 + rseq[i + u]];
+            const int row = kQ ? (int)((qb >> (8 * u)) & 0xff) : i + u;
+            const int idx = (row * 5 + (int)((rf >> (8 * u)) & 0xff)) * 5 + (int)((sb >> (8 * u)) & 0xff);
+            p[u] = (u < n) ? prof[idx] : 1.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) prob *= p[u];
-    }
-    for (; i < len; i++) {
-        const int row = kQ ? rqual[i] : i;
-        prob *= prof[(row * 5 + ref_id(ref, totLen, i + pos, dir)) * 5 + rseq[i]];
     }
     return prob;
 }
@@ -131,9 +137,8 @@ __global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double*
         const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
         const int pos = D.pos[j];
         const int fullLen = D.fullLen[sid], totLen = D.totLen[sid];
-        const uint8_t* ref = D.ref_seq + D.ref_off[sid];
-        const uint64_t r0 = D.read_off[0][row];
-        const int len1 = (int)(D.read_off[0][row + 1] - r0);
+        const uint64_t r0 = D.roff8[0][row];
+        const int len1 = D.rlen[0][row];
         if (!kPE) {
             const int fpos = dir == 0 ? pos : totLen - pos - len1;
             const int seedPos = dir == 0 ? pos : totLen - pos - T.seedLen;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double*
                     value = ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, len1, totLen) * rspd_adj(T, fpos, effL, fullLen);
                 }
                 const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
-                prob = ori * value * profile_prob<kQ>(prof, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1, ref, totLen, pos, dir);
+                prob = ori * value * profile_prob<kQ>(prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, D.soff[2 * sid + dir] + pos);
                 if (prob < kEpsilon) prob = 0.0;
                 prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
             }
@@ -165,12 +170,12 @@ __global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double*
                 const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
                 prob = ori * ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, insertLen, totLen) * rspd_adj(T, fpos, effL, fullLen);
                 prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len1, insertLen) *
-                        profile_prob<kQ>(prof, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1, ref, totLen, pos, dir);
-                const uint64_t q0 = D.read_off[1][row];
-                const int len2 = (int)(D.read_off[1][row + 1] - q0);
+                        profile_prob<kQ>(prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, D.soff[2 * sid + dir] + pos);
+                const uint64_t q0 = D.roff8[1][row];
+                const int len2 = D.rlen[1][row];
                 const int m2pos = totLen - pos - insertLen, m2dir = !dir;
                 prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len2, insertLen) *
-                        profile_prob<kQ>(prof, D.read_seq[1] + q0, kQ ? D.read_qual[1] + q0 : nullptr, len2, ref, totLen, m2pos, m2dir);
+                        profile_prob<kQ>(prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2, D.refw, D.soff[2 * sid + m2dir] + m2pos);
                 if (prob < kEpsilon) prob = 0.0;
                 prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
             }
@@ -181,18 +186,22 @@ __global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double*
 
 // Noise(Q)Profile::getProb
 template <bool kQ>
-__device__ inline double noise_prob(const double* __restrict__ noise, const uint8_t* __restrict__ rseq,
-                                    const uint8_t* __restrict__ rqual, int len) {
+__device__ inline double noise_prob(const double* __restrict__ noise, const uint64_t* __restrict__ rs,
+                                    const uint64_t* __restrict__ rq, int len) {
     double prob = 1.0;
-    int i = 0;
-    for (; i + 8 <= len; i += 8) {
+    for (int i = 0; i < len; i += 8) {
+        const uint64_t sb = rs[i >> 3];
+        const uint64_t qb = kQ ? rq[i >> 3] : 0;
+        const int n = len - i;
         double p[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) p[u] = kQ ? noise[rqual[i + u] * 5 + rseq[i + u]] : noise[rseq[i + u]];
+        for (int u = 0; u < 8; u++) {
+            const int b = (int)((sb >> (8 * u)) & 0xff);
+            p[u] = (u < n) ? (kQ ? noise[(int)((qb >> (8 * u)) & 0xff) * 5 + b] : noise[b]) : 1.0;
+        }
 #pragma unroll
         for (int u = 0; u < 8; u++) prob *= p[u];
     }
-    for (; i < len; i++) prob *= kQ ? noise[rqual[i] * 5 + rseq[i]] : noise[rseq[i]];
     return prob;
 }
 
@@ -205,15 +214,15 @@ __global__ __launch_bounds__(kBlk) void k_noise(DevData D, DevTables T, double* 
     if (i >= D.N1) return;
     double prob = 0.0;
     if (!D.lq[i]) {
-        const uint64_t r0 = D.read_off[0][i];
-        const int len1 = (int)(D.read_off[0][i + 1] - r0);
+        const uint64_t r0 = D.roff8[0][i];
+        const int len1 = D.rlen[0][i];
         const double* lpdf = (kPE || T.has_mld) ? T.mld_pdf : T.gld_pdf;
         const int llb = (kPE || T.has_mld) ? T.mld_lb : T.gld_lb;
-        prob = lpdf[len1 - llb] * noise_prob<kQ>(s_noise, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1);
+        prob = lpdf[len1 - llb] * noise_prob<kQ>(s_noise, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1);
         if (kPE) {
-            const uint64_t q0 = D.read_off[1][i];
-            const int len2 = (int)(D.read_off[1][i + 1] - q0);
-            prob *= lpdf[len2 - llb] * noise_prob<kQ>(s_noise, D.read_seq[1] + q0, kQ ? D.read_qual[1] + q0 : nullptr, len2);
+            const uint64_t q0 = D.roff8[1][i];
+            const int len2 = D.rlen[1][i];
+            prob *= lpdf[len2 - llb] * noise_prob<kQ>(s_noise, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2);
         }
         if (prob < kEpsilon) prob = 0.0;
         prob = (T.mw[0] < kEpsilon) ? 0.0 : prob / T.mw[0];
@@ -251,11 +260,23 @@ __device__ inline void rspd_update(double* lds, double* glob, int B, int fpos, i
 }
 
 template <bool kQ>
-__device__ inline void profile_update(double* lds, double* glob, const uint8_t* rseq, const uint8_t* rqual, int len,
-                                      const uint8_t* ref, int totLen, int pos, int dir, double frac) {
-    for (int i = 0; i < len; i++) {
-        const int row = kQ ? rqual[i] : i;
-        add_tbl(lds, kProfLds, glob, (row * 5 + ref_id(ref, totLen, i + pos, dir)) * 5 + rseq[i], frac);
+__device__ inline void profile_update(double* lds, double* glob, const uint64_t* __restrict__ rs,
+                                      const uint64_t* __restrict__ rq, int len, const uint64_t* __restrict__ refw, uint64_t a,
+                                      double frac) {
+    const uint64_t* rw = refw + (a >> 3);
+    const int sh = (int)(a & 7) * 8;
+    uint64_t w0 = rw[0];
+    for (int i = 0; i < len; i += 8) {
+        const uint64_t w1 = rw[(i >> 3) + 1];
+        const uint64_t rf = funnel8(w0, w1, sh);
+        w0 = w1;
+        const uint64_t sb = rs[i >> 3];
+        const uint64_t qb = kQ ? rq[i >> 3] : 0;
+        const int n = min(8, len - i);
+        for (int u = 0; u < n; u++) {
+            const int row = kQ ? (int)((qb >> (8 * u)) & 0xff) : i + u;
+            add_tbl(lds, kProfLds, glob, (row * 5 + (int)((rf >> (8 * u)) & 0xff)) * 5 + (int)((sb >> (8 * u)) & 0xff), frac);
+        }
     }
 }
 
@@ -281,15 +302,14 @@ __global__ __launch_bounds__(kBlk) void k_update(DevData D, DevTables T, const d
         const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
         const int pos = D.pos[j];
         const int fullLen = D.fullLen[sid], totLen = D.totLen[sid];
-        const uint8_t* ref = D.ref_seq + D.ref_off[sid];
-        const uint64_t r0 = D.read_off[0][row];
-        const int len1 = (int)(D.read_off[0][row + 1] - r0);
+        const uint64_t r0 = D.roff8[0][row];
+        const int len1 = D.rlen[0][row];
         if (!kPE) {
             if (T.estRSPD) {  // only one strand estimates the RSPD; helper models have no mld (SingleQModel.h:176-213)
                 if (T.probF >= 0.1 && dir == 0) rspd_update(s_rspd, A.rspd, T.B, pos, fullLen, frac);
                 if (T.probF < 0.1 && dir == 1) rspd_update(s_rspd, A.rspd, T.B, totLen - pos - len1, fullLen, frac);
             }
-            profile_update<kQ>(s_prof, A.prof, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1, ref, totLen, pos, dir, frac);
+            profile_update<kQ>(s_prof, A.prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, D.soff[2 * sid + dir] + pos, frac);
         } else {
             const int insertL = D.insertL[j];
             add_tbl(s_gld, kGldLds, A.gld, insertL - A.gld0_lb, frac);  // LenDist::update (LenDist.h:46-49)
@@ -297,11 +317,11 @@ __global__ __launch_bounds__(kBlk) void k_update(DevData D, DevTables T, const d
                 const int fpos = dir == 0 ? pos : totLen - pos - insertL;
                 rspd_update(s_rspd, A.rspd, T.B, fpos, fullLen, frac);
             }
-            profile_update<kQ>(s_prof, A.prof, D.read_seq[0] + r0, kQ ? D.read_qual[0] + r0 : nullptr, len1, ref, totLen, pos, dir, frac);
-            const uint64_t q0 = D.read_off[1][row];
-            const int len2 = (int)(D.read_off[1][row + 1] - q0);
-            profile_update<kQ>(s_prof, A.prof, D.read_seq[1] + q0, kQ ? D.read_qual[1] + q0 : nullptr, len2, ref, totLen,
-                               totLen - pos - insertL, !dir, frac);
+            profile_update<kQ>(s_prof, A.prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, D.soff[2 * sid + dir] + pos, frac);
+            const uint64_t q0 = D.roff8[1][row];
+            const int len2 = D.rlen[1][row];
+            profile_update<kQ>(s_prof, A.prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2, D.refw,
+                               D.soff[2 * sid + (!dir)] + (totLen - pos - insertL), frac);
         }
     }
     // reads: noise profile (SingleQModel.h:217-221, PairedEndQModel.h:182-188)
@@ -309,11 +329,17 @@ __global__ __launch_bounds__(kBlk) void k_update(DevData D, DevTables T, const d
         const double frac = wn[i];
         if (D.lq[i] || frac < kEpsilon) continue;
         for (int m = 0; m < (kPE ? 2 : 1); m++) {
-            const uint64_t r0 = D.read_off[m][i];
-            const int len = (int)(D.read_off[m][i + 1] - r0);
-            const uint8_t* sq = D.read_seq[m] + r0;
-            const uint8_t* ql = kQ ? D.read_qual[m] + r0 : nullptr;
-            for (int k = 0; k < len; k++) unsafeAtomicAdd(&s_noise[kQ ? ql[k] * 5 + sq[k] : sq[k]], frac);
+            const uint64_t* sq = D.rseq_w[m] + D.roff8[m][i];
+            const uint64_t* ql = kQ ? D.rqual_w[m] + D.roff8[m][i] : nullptr;
+            const int len = D.rlen[m][i];
+            for (int k = 0; k < len; k += 8) {
+                const uint64_t sb = sq[k >> 3], qb = kQ ? ql[k >> 3] : 0;
+                const int n = min(8, len - k);
+                for (int u = 0; u < n; u++) {
+                    const int b = (int)((sb >> (8 * u)) & 0xff);
+                    unsafeAtomicAdd(&s_noise[kQ ? (int)((qb >> (8 * u)) & 0xff) * 5 + b : b], frac);
+                }
+            }
         }
     }
     __syncthreads();
@@ -454,15 +480,70 @@ int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_da
     UP(sid_signed, d->sid_signed, d->nnz);
     UP(pos, d->pos, d->nnz);
     if (pe) UP(insertL, d->insertL, d->nnz);
+    // reads: 8 codes per 64-bit word, every read on a word boundary (the kernels fetch 8 bases per load)
     for (int m = 0; m < (pe ? 2 : 1); m++) {
-        const uint64_t nb = d->read_off[m][d->N1];
-        UP(read_off[m], d->read_off[m], d->N1 + 1);
-        UP(read_seq[m], d->read_seq[m], nb);
-        if (q) UP(read_qual[m], d->read_qual[m], nb);
+        std::vector<uint64_t> off8(d->N1 + 1, 0);
+        std::vector<int32_t> len(d->N1);
+        for (uint64_t i = 0; i < d->N1; i++) {
+            const uint64_t l = d->read_off[m][i + 1] - d->read_off[m][i];
+            len[i] = (int32_t)l;
+            off8[i + 1] = off8[i] + (l + 7) / 8;
+        }
+        const uint64_t nw = off8[d->N1] + 1;
+        std::vector<uint64_t> ws(nw, 0), wq(q ? nw : 0, 0);
+        const int nt = d->N1 > 100000 ? 32 : 1;
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                const uint64_t lo = d->N1 * t / nt, hi = d->N1 * (t + 1) / nt;
+                for (uint64_t i = lo; i < hi; i++) {  // little-endian: packing 8 byte codes into a word is a memcpy
+                    memcpy(ws.data() + off8[i], d->read_seq[m] + d->read_off[m][i], (size_t)len[i]);
+                    if (q) memcpy(wq.data() + off8[i], d->read_qual[m] + d->read_off[m][i], (size_t)len[i]);
+                }
+            });
+        for (auto& x : th) x.join();
+        UP(roff8[m], off8.data(), d->N1 + 1);
+        UP(rlen[m], len.data(), d->N1);
+        UP(rseq_w[m], ws.data(), nw);
+        if (q) UP(rqual_w[m], wq.data(), nw);
+        if (hipStreamSynchronize(st) != hipSuccess) { rsem_model_destroy(c); return RSEM_ERR_HIP; }  // the vectors die here
     }
     UP(lq, d->low_quality, d->N1);
-    UP(ref_off, d->ref_off, (size_t)d->M + 2);
-    UP(ref_seq, d->ref_seq, d->ref_off[d->M + 1]);
+    {   // both strands of every transcript (RefSeq::get_id, RefSeq.h:84-87), word-aligned starts, one spare word at the end
+        std::vector<uint64_t> soff(2 * ((size_t)d->M + 1), 0);
+        uint64_t tot = 0;
+        for (int sid = 1; sid <= d->M; sid++)
+            for (int dir = 0; dir < 2; dir++) {
+                soff[2 * sid + dir] = tot;
+                tot += ((uint64_t)d->totLen[sid] + 7) / 8 * 8;
+            }
+        std::vector<uint8_t> strands(tot + 16, 0);
+        {
+            const int nt = d->M > 2000 ? 16 : 1;
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++)
+                th.emplace_back([&, t]() {
+                    for (int sid = 1 + t; sid <= d->M; sid += nt) {
+                        const uint8_t* f = d->ref_seq + d->ref_off[sid];
+                        const int tl = d->totLen[sid];
+                        uint8_t* o0 = strands.data() + soff[2 * sid];
+                        uint8_t* o1 = strands.data() + soff[2 * sid + 1];
+                        memcpy(o0, f, (size_t)tl);
+                        for (int p = 0; p < tl; p++) {
+                            const uint8_t b = f[tl - p - 1];
+                            o1[p] = b == 4 ? 4 : 3 - b;  // get_rbase_id (utils.h:52-66)
+                        }
+                    }
+                });
+            for (auto& x : th) x.join();
+        }
+        UP(soff, soff.data(), soff.size());
+        const uint64_t* wptr = nullptr;
+        rc = up_field(c, wptr, reinterpret_cast<const uint64_t*>(strands.data()), (tot + 16) / 8, st);
+        if (rc != RSEM_OK) { rsem_model_destroy(c); return rc; }
+        D.refw = wptr;
+        if (hipStreamSynchronize(st) != hipSuccess) { rsem_model_destroy(c); return RSEM_ERR_HIP; }
+    }
     UP(fullLen, d->fullLen, (size_t)d->M + 1);
     UP(totLen, d->totLen, (size_t)d->M + 1);
     UP(mask_off, d->mask_off, (size_t)d->M + 2);
