@@ -221,6 +221,11 @@ struct Model {
         for (int i = 1; i <= M; i++) {
             const int totLen = R.totLen[i], fullLen = R.fullLen[i];
             double value = 0.0;
+            // nothing to integrate for a transcript without masked positions and without a poly(A) tail: every loop
+            // below is either guarded by getMask() or runs over [fullLen, totLen) -- mw = 1 exactly as in the reference
+            bool any_mask = totLen != fullLen;
+            for (size_t w = 0; !any_mask && w < R.masks[i].size(); w++) any_mask = R.masks[i][w] != 0;
+            if (!any_mask) { mw[i] = 1.0; continue; }
             if (paired()) {
                 const int end = std::min(fullLen, totLen - gld.minL() + 1);
                 for (int seedPos = 0; seedPos < end; seedPos++)
