@@ -202,6 +202,11 @@ int rsem_gibbs_run(rsem_gibbs_ctx* ctx, int mode, uint32_t seed, int burnin, int
                    int thin /* PARALLEL only: internal sweeps per counted round, >=1 */,
                    int32_t* count_vectors, double* pme_c, double* pve_c, double* pme_tpm,
                    double* pme_fpkm, double* pve_c_genes, double* sweep_ms /* may be NULL */);
+/* Allele-specific references (ref.ta, GroupInfo.h): ta[m_trans+1] = first allele of every transcript.  After this
+ * call every rsem_gibbs_run also accumulates, per kept sample, the squared per-transcript count sums
+ * (pve_c_trans, Gibbs.cpp:339-345); rsem_gibbs_get_pve_c_trans returns the last run's sums [m_trans]. */
+int rsem_gibbs_set_allele_groups(rsem_gibbs_ctx* ctx, int32_t m_trans, const int32_t* ta);
+int rsem_gibbs_get_pve_c_trans(rsem_gibbs_ctx* ctx, double* pve_c_trans);
 int rsem_gibbs_destroy(rsem_gibbs_ctx* ctx);
 /* sampling.h:19-44: seeds of the first nchains chains for --seed seed. */
 int rsem_gibbs_chain_seeds(uint32_t seed, int nchains, uint32_t* out);

@@ -562,6 +562,10 @@ struct rsem_gibbs_ctx {
     double* d_acc[4] = {nullptr, nullptr, nullptr, nullptr};
     double* d_acc_genes = nullptr;
     MtState* d_mt = nullptr;
+    // allele-specific: transcript groups over alleles
+    int32_t m_trans = 0;
+    int32_t* d_ta = nullptr;
+    double* d_acc_trans = nullptr;
 };
 
 extern "C" {
@@ -588,9 +592,30 @@ int rsem_gibbs_destroy(rsem_gibbs_ctx* c) {
     hipFree(c->d_init_counts); hipFree(c->d_counts); hipFree(c->d_z); hipFree(c->d_g); hipFree(c->d_alpha);
     hipFree(c->d_eel); hipFree(c->d_mw); hipFree(c->d_grp); hipFree(c->d_tmp);
     for (int i = 0; i < 4; i++) hipFree(c->d_acc[i]);
-    hipFree(c->d_acc_genes); hipFree(c->d_mt); hipFree(c->d_units);
+    hipFree(c->d_acc_genes); hipFree(c->d_mt); hipFree(c->d_units); hipFree(c->d_ta); hipFree(c->d_acc_trans);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return RSEM_OK;
+}
+
+int rsem_gibbs_set_allele_groups(rsem_gibbs_ctx* c, int32_t m_trans, const int32_t* ta) {
+    RSEM_REQUIRE(c && ta && m_trans >= 1, "bad argument");
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    hipFree(c->d_ta); hipFree(c->d_acc_trans);
+    c->d_ta = nullptr; c->d_acc_trans = nullptr;
+    RSEM_HIP_TRY(dmalloc(&c->d_ta, (size_t)m_trans + 1));
+    RSEM_HIP_TRY(dmalloc(&c->d_acc_trans, (size_t)m_trans));
+    RSEM_HIP_TRY(hipMemcpy(c->d_ta, ta, sizeof(int32_t) * ((size_t)m_trans + 1), hipMemcpyHostToDevice));
+    RSEM_HIP_TRY(hipMemset(c->d_acc_trans, 0, sizeof(double) * m_trans));
+    c->m_trans = m_trans;
+    return RSEM_OK;
+}
+
+int rsem_gibbs_get_pve_c_trans(rsem_gibbs_ctx* c, double* out) {
+    RSEM_REQUIRE(c && out, "NULL argument");
+    if (!c->m_trans) { rsem::set_last_error("allele groups were never set"); return RSEM_ERR_STATE; }
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    RSEM_HIP_TRY(hipMemcpy(out, c->d_acc_trans, sizeof(double) * c->m_trans, hipMemcpyDeviceToHost));
     return RSEM_OK;
 }
 
@@ -709,6 +734,7 @@ int rsem_gibbs_run(rsem_gibbs_ctx* c, int mode, uint32_t seed, int burnin, int n
     const int gM = rsem::ceil_div(nM, kBlock);
     for (int i = 0; i < 4; i++) RSEM_HIP_TRY(hipMemsetAsync(c->d_acc[i], 0, sizeof(double) * nM, st));
     RSEM_HIP_TRY(hipMemsetAsync(c->d_acc_genes, 0, sizeof(double) * c->m, st));
+    if (c->m_trans) RSEM_HIP_TRY(hipMemsetAsync(c->d_acc_trans, 0, sizeof(double) * c->m_trans, st));
     int32_t* d_cv = nullptr;
     if (count_vectors) RSEM_HIP_TRY(dmalloc(&d_cv, (size_t)nsamples * nM));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -771,6 +797,9 @@ int rsem_gibbs_run(rsem_gibbs_ctx* c, int mode, uint32_t seed, int burnin, int n
                                c->totc, c->d_eel, c->d_mw, c->d_tmp, c->d_acc[0], c->d_acc[1], c->d_acc[2], c->d_acc[3]);
             hipLaunchKernelGGL(k_gibbs_gene_stats, dim3(rsem::ceil_div(c->m, kBlock)), dim3(kBlock), 0, st, c->m, c->d_grp,
                                c->d_counts, c->d_acc_genes);
+            if (c->m_trans)
+                hipLaunchKernelGGL(k_gibbs_gene_stats, dim3(rsem::ceil_div(c->m_trans, kBlock)), dim3(kBlock), 0, st, c->m_trans,
+                                   c->d_ta, c->d_counts, c->d_acc_trans);
             RSEM_HIP_TRY(hipGetLastError());
         }
     }

@@ -64,7 +64,10 @@ int main(int argc, char* argv[]) {
     if (verbose) printf("Loading data is finished!\n");
     GroupInfo gi;
     if (!gi.load(refName + ".grp")) die("Cannot open %s.grp! It may not exist.", refName.c_str());
-    if (is_allele_specific(refName)) die("Allele-specific references (%s.ta/.gt) are not supported by this build yet.", refName.c_str());
+    const bool alleleS = is_allele_specific(refName);  // Gibbs.cpp:145-146
+    GroupInfo gt, ta;
+    if (alleleS && (!gt.load(refName + ".gt") || !ta.load(refName + ".ta"))) die("Cannot load %s.gt / %s.ta!", refName.c_str(), refName.c_str());
+    const int m_trans = alleleS ? ta.m : 0;
     if (verbose) printf("Loading group information is finished!\n");
     // load_omit_info (Gibbs.cpp:152-167)
     std::vector<int32_t> init_counts(M + 1, 0);
@@ -127,6 +130,7 @@ int main(int argc, char* argv[]) {
     const int quotient = NSAMPLES / nThreads, left = NSAMPLES % nThreads;  // Gibbs.cpp:215-223
     std::vector<std::vector<double>> acc(nThreads * 4, std::vector<double>(M + 1, 0.0));
     std::vector<std::vector<double>> acc_g(nThreads, std::vector<double>(gi.m, 0.0));
+    std::vector<std::vector<double>> acc_t(nThreads, std::vector<double>(m_trans, 0.0));
     std::vector<std::string> errors(nThreads);
     const int nworkers = device >= 0 ? 1 : std::min(ndev, nThreads);
     std::vector<std::thread> workers;
@@ -137,12 +141,14 @@ int main(int argc, char* argv[]) {
             int rc = rsem_gibbs_create(&g, dev, M, N1, ofg.sid.size(), ofg.row_ptr.data(), ofg.sid.data(), ofg.conprb.data(),
                                        init_counts.data(), has_prior ? pseudo_counts.data() : nullptr, pseudoC, totc, N0,
                                        eel.data(), model.mw.data(), gi.m, gi.starts.data());
+            if (rc == RSEM_OK && alleleS) rc = rsem_gibbs_set_allele_groups(g, m_trans, ta.starts.data());
             if (rc != RSEM_OK) { errors[w] = std::string(rsem_hip_strerror(rc)) + ": " + rsem_hip_last_error(); return; }
             for (int k = w; k < nThreads; k += nworkers) {
                 const int ns = quotient + (k < left ? 1 : 0);
                 std::vector<int32_t> cv((size_t)ns * (M + 1));
                 rc = rsem_gibbs_run(g, mode, seeds[k], BURNIN, ns, GAP, thin, cv.data(), acc[k * 4 + 0].data(), acc[k * 4 + 1].data(),
                                     acc[k * 4 + 2].data(), acc[k * 4 + 3].data(), acc_g[k].data(), nullptr);
+                if (rc == RSEM_OK && alleleS) rc = rsem_gibbs_get_pve_c_trans(g, acc_t[k].data());
                 if (rc != RSEM_OK) { errors[w] = std::string(rsem_hip_strerror(rc)) + ": " + rsem_hip_last_error(); break; }
                 // writeCountVector (Gibbs.cpp:257-262): one file per chain
                 FILE* fo = fopen((imdName + ".countvectors" + std::to_string(k)).c_str(), "w");
@@ -186,8 +192,19 @@ int main(int argc, char* argv[]) {
         pve_c_genes[i] = (pve_c_genes[i] - double(NSAMPLES) * pme_c_gene * pme_c_gene) / double(NSAMPLES - 1);
         if (pve_c_genes[i] < 0.0) pve_c_genes[i] = 0.0;
     }
+    std::vector<double> pve_c_trans(m_trans, 0.0);
+    if (alleleS) {
+        for (int k = 0; k < nThreads; k++)
+            for (int j = 0; j < m_trans; j++) pve_c_trans[j] += acc_t[k][j];
+        for (int i = 0; i < m_trans; i++) {
+            double pme_c_tran = 0.0;
+            for (int j = ta.starts[i]; j < ta.starts[i + 1]; j++) pme_c_tran += pme_c[j];
+            pve_c_trans[i] = (pve_c_trans[i] - double(NSAMPLES) * pme_c_tran * pme_c_tran) / double(NSAMPLES - 1);
+            if (pve_c_trans[i] < 0.0) pve_c_trans[i] = 0.0;
+        }
+    }
     if (verbose) printf("Gibbs finished!\n");
-    write_results_gibbs(M, gi, imdName, pme_c, pme_fpkm, pme_tpm, pve_c, pve_c_genes);
+    write_results_gibbs(M, gi, imdName, pme_c, pme_fpkm, pme_tpm, pve_c, pve_c_genes, alleleS, &gt, &ta, &pve_c_trans);
     if (verbose) printf("Gibbs based expression values are written!\n");
     return 0;
 }

@@ -252,7 +252,7 @@ def load_ref_seq(path):
 
 def build_fixture(name, model_type, n_reads, seed, n_genes=14, max_iso=4, polyA=False, estRSPD=0,
                   read_len=(36, 50), gibbs=(20, 40, 1), gibbs_threads=2, theta0=0.06, probF=0.5, frag_mean=None,
-                  omit_last=0, pseudo_count=None):
+                  omit_last=0, pseudo_count=None, allele=False):
     rng = np.random.default_rng(seed)
     out = os.path.join(HERE, name)
     work = os.path.join("/tmp", "rsem_fixture_" + name)
@@ -263,6 +263,18 @@ def build_fixture(name, model_type, n_reads, seed, n_genes=14, max_iso=4, polyA=
     os.makedirs(os.path.join(out, "stat"))
 
     txs = make_transcriptome(rng, n_genes, max_iso)
+    if allele:  # two alleles per isoform differing by a few SNPs (allele-specific reference: ref.ta / ref.gt)
+        al = []
+        for t, g, s in txs:
+            b = list(s)
+            for p in rng.choice(len(b), size=max(2, len(b) // 150), replace=False):
+                b[p] = "ACGT"[("ACGT".index(b[p]) + 1 + int(rng.integers(0, 3))) % 4]
+            al.append((t + "_a", g, s, t))
+            al.append((t + "_b", g, "".join(b), t))
+        with open(os.path.join(work, "amap.txt"), "w") as f:
+            for an, g, s, t in al:
+                f.write("%s\t%s\t%s\n" % (g, t, an))
+        txs = [(an, g, s) for an, g, s, t in al]
     with open(os.path.join(work, "tx.fa"), "w") as f:
         for t, g, s in txs:
             f.write(">%s\n%s\n" % (t, s))
@@ -270,8 +282,12 @@ def build_fixture(name, model_type, n_reads, seed, n_genes=14, max_iso=4, polyA=
         for t, g, s in txs:
             f.write("%s\t%s\n" % (g, t))
     ref = os.path.join(work, "ref")
-    run([os.path.join(REFBIN, "rsem-synthesis-reference-transcripts"), ref, "1", "1",
-         os.path.join(work, "t2g.txt"), os.path.join(work, "tx.fa")])
+    if allele:
+        run([os.path.join(REFBIN, "rsem-synthesis-reference-transcripts"), ref, "1", "2",
+             os.path.join(work, "amap.txt"), os.path.join(work, "tx.fa")])
+    else:
+        run([os.path.join(REFBIN, "rsem-synthesis-reference-transcripts"), ref, "1", "1",
+             os.path.join(work, "t2g.txt"), os.path.join(work, "tx.fa")])
     cmd = [os.path.join(REFBIN, "rsem-preref"), ref + ".transcripts.fa", "0" if polyA else "1", ref, "-q"]
     if polyA:
         cmd += ["-l", "125"]
@@ -287,9 +303,14 @@ def build_fixture(name, model_type, n_reads, seed, n_genes=14, max_iso=4, polyA=
     tpm[rng.random(M) < 0.3] = 0.0
     tpm = tpm / tpm.sum() * 1e6
     with open(os.path.join(work, "sim.isoforms.results"), "w") as f:
-        f.write("transcript_id\tgene_id\tlength\teffective_length\texpected_count\tTPM\tFPKM\tIsoPct\n")
-        for (n, g, s), v in zip(ordered, tpm):
-            f.write("%s\t%s\t%d\t0\t0\t%.4f\t0\t0\n" % (n, g, len(s), v))
+        if allele:  # alleles.results layout: TPM is the 7th column (simulation.cpp:189 OFFSITE = 6)
+            f.write("allele_id\ttranscript_id\tgene_id\tlength\teffective_length\texpected_count\tTPM\tFPKM\tAlleleIsoPct\tAlleleGenePct\n")
+            for (n, g, s), v in zip(ordered, tpm):
+                f.write("%s\t%s\t%s\t%d\t0\t0\t%.4f\t0\t0\t0\n" % (n, n[:-2], g, len(s), v))
+        else:
+            f.write("transcript_id\tgene_id\tlength\teffective_length\texpected_count\tTPM\tFPKM\tIsoPct\n")
+            for (n, g, s), v in zip(ordered, tpm):
+                f.write("%s\t%s\t%d\t0\t0\t%.4f\t0\t0\n" % (n, g, len(s), v))
     sim = os.path.join(work, "sim")
     run([os.path.join(REFBIN, "rsem-simulate-reads"), ref, sim_model, os.path.join(work, "sim.isoforms.results"),
          str(theta0), str(n_reads), sim, "--seed", str(seed), "-q"])
@@ -298,7 +319,7 @@ def build_fixture(name, model_type, n_reads, seed, n_genes=14, max_iso=4, polyA=
 
     imd = os.path.join(out, "temp", "s")
     stat = os.path.join(out, "stat", "s")
-    for ext in ("seq", "ti", "grp"):
+    for ext in ("seq", "ti", "grp") + (("ta", "gt") if allele else ()):
         shutil.copy(ref + "." + ext, os.path.join(out, "ref." + ext))
     oref = os.path.join(out, "ref")
     run([os.path.join(REFBIN, "rsem-parse-alignments"), oref, imd, stat, samf, str(model_type), "-q"])
@@ -319,6 +340,8 @@ def build_fixture(name, model_type, n_reads, seed, n_genes=14, max_iso=4, polyA=
     # keep pre-Gibbs result files
     shutil.copy(imd + ".iso_res", imd + ".iso_res.em")
     shutil.copy(imd + ".gene_res", imd + ".gene_res.em")
+    if allele:
+        shutil.copy(imd + ".allele_res", imd + ".allele_res.em")
     b, n, g = gibbs
     run([os.path.join(REFBIN, "rsem-run-gibbs"), oref, imd, stat, str(b), str(n), str(g),
          "-p", str(gibbs_threads), "--seed", "12345", "-q"] + (["--pseudo-count", str(pseudo_count)] if pseudo_count else []))
@@ -347,6 +370,7 @@ if __name__ == "__main__":
         dict(name="se_q_fragmean", model_type=1, n_reads=1200, seed=17, frag_mean=(140, 25)),
         # reverse-stranded protocol + RSPD (the probF < 0.1 && dir == 1 branch of update), transcripts missing from
         # the alignment header (imd.omit -> counts = -1 in Gibbs), single-cell pseudo count
+        dict(name="se_q_allele", model_type=1, n_reads=1500, seed=19, allele=True, n_genes=8, max_iso=3),
         dict(name="se_noq_rev_rspd_omit", model_type=0, n_reads=1200, seed=18, probF=0.0, estRSPD=1, omit_last=3, pseudo_count=0.1),
     ]
     for sp in specs:

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FIXTURES = ["se_noq", "se_q", "se_q_polya_rspd", "pe_noq", "pe_q", "pe_q_polya_rspd", "se_q_fragmean", "se_noq_rev_rspd_omit"]
+FIXTURES = ["se_noq", "se_q", "se_q_polya_rspd", "pe_noq", "pe_q", "pe_q_polya_rspd", "se_q_fragmean", "se_noq_rev_rspd_omit", "se_q_allele"]
 
 
 def fixture(name):
@@ -158,3 +158,19 @@ def gibbs_setup(fx, M, N0, N1):
             init[int(tok)] = -1
     totc = (M + 1 - int((init < 0).sum())) * pseudoC + N0 + N1
     return init, pseudoC, totc
+
+
+def per_target_rows(fx, em_only=False):
+    """Per-reference-sequence rows (one entry per internal sid 1..M) of the reference's result file: iso_res, or
+    allele_res for allele-specific references (WriteResults.h:262-290 vs 223-260)."""
+    allele = os.path.exists(os.path.join(fx, "ref.ta"))
+    name = "s.allele_res" if allele else "s.iso_res"
+    res = read_res(os.path.join(fx, "temp", name + (".em" if em_only else "")))
+    o = 1 if allele else 0       # allele_res has one more leading id row
+    g = 2 if allele else 0       # ... and one more percentage row before the Gibbs rows
+    out = dict(eel=np.array(res[3 + o], float), count=np.array(res[4 + o], float), tpm=np.array(res[5 + o], float),
+               fpkm=np.array(res[6 + o], float))
+    if len(res) > 8 + g:
+        out.update(pme_c=np.array(res[8 + g], float), sd=np.array(res[9 + g], float), pme_tpm=np.array(res[10 + g], float),
+                   pme_fpkm=np.array(res[11 + g], float))
+    return out

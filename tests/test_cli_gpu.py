@@ -55,7 +55,8 @@ def _res_close(path_a, path_b, atol=0.011):
 def test_rsem_run_em_matches_reference(name, tmp_path):
     fx, dst = _stage(name, tmp_path)
     meta = rf.read_meta(fx)
-    for f in ("stat/s.theta", "stat/s.model", "temp/s.ofg", "temp/s.iso_res", "temp/s.gene_res"):
+    allele = os.path.exists(os.path.join(fx, "ref.ta"))
+    for f in ("stat/s.theta", "stat/s.model", "temp/s.ofg", "temp/s.iso_res", "temp/s.gene_res") + (("temp/s.allele_res",) if allele else ()):
         os.remove(os.path.join(dst, f))
     out = _run([os.path.join(BIN, "rsem-run-em"), os.path.join(dst, "ref"), str(meta["model_type"]), os.path.join(dst, "s"),
                 os.path.join(dst, "temp", "s"), os.path.join(dst, "stat", "s"), "-p", "1", "--gibbs-out"])
@@ -85,6 +86,8 @@ def test_rsem_run_em_matches_reference(name, tmp_path):
     # results and the Gibbs input
     _res_close(os.path.join(dst, "temp", "s.iso_res"), os.path.join(fx, "temp", "s.iso_res.em"))
     _res_close(os.path.join(dst, "temp", "s.gene_res"), os.path.join(fx, "temp", "s.gene_res.em"))
+    if allele:
+        _res_close(os.path.join(dst, "temp", "s.allele_res"), os.path.join(fx, "temp", "s.allele_res.em"))
     M, N0, rp, sid, val = rf.read_ofg(os.path.join(dst, "temp", "s.ofg"))
     gM, gN0, grp, gsid, gval = rf.read_ofg(os.path.join(fx, "temp", "s.ofg"))
     assert (M, N0) == (gM, gN0) and np.array_equal(rp, grp) and np.array_equal(sid, gsid)
@@ -99,6 +102,9 @@ def test_rsem_run_gibbs_exact_matches_reference(name, tmp_path):
     imd = os.path.join(dst, "temp", "s")
     shutil.copy(imd + ".iso_res.em", imd + ".iso_res")
     shutil.copy(imd + ".gene_res.em", imd + ".gene_res")
+    allele = os.path.exists(os.path.join(fx, "ref.ta"))
+    if allele:
+        shutil.copy(imd + ".allele_res.em", imd + ".allele_res")
     for k in range(meta["gibbs_threads"]):
         os.remove(imd + ".countvectors%d" % k)
     extra = []
@@ -111,6 +117,8 @@ def test_rsem_run_gibbs_exact_matches_reference(name, tmp_path):
             assert f1.read() == f2.read()
     _res_close(imd + ".iso_res", os.path.join(fx, "temp", "s.iso_res"))
     _res_close(imd + ".gene_res", os.path.join(fx, "temp", "s.gene_res"))
+    if allele:
+        _res_close(imd + ".allele_res", os.path.join(fx, "temp", "s.allele_res"))
 
 
 def test_rsem_run_gibbs_parallel_runs_and_is_close(tmp_path):

@@ -50,7 +50,7 @@ def test_step_matches_oracle_and_golden(name, variant):
     assert abs(s - os_) < 1e-9 * os_
     assert t == ot and abs(b - ob) <= 1e-9 * max(ob, 1e-12) + 1e-12  # bChange is a difference quotient of nearly equal numbers
     # golden: expected_count row of the reference's iso_res (printed %.2f)
-    gold = np.array(rf.read_res(os.path.join(d["fx"], "temp", "s.iso_res.em"))[4], float)
+    gold = rf.per_target_rows(d["fx"], em_only=True)["count"]
     assert np.allclose(counts[1:], gold, atol=0.00501)
     ctx.close()
 

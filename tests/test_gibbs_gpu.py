@@ -57,9 +57,9 @@ def test_exact_chain_bit_identical_to_reference(name):
             assert np.allclose(a, b, rtol=1e-10, atol=1e-9)
         tot = acc if tot is None else [x + y for x, y in zip(tot, acc)]
     pme_c = tot[0] / nsamples
-    res = rf.read_res(os.path.join(d["fx"], "temp", "s.iso_res"))
-    assert np.allclose(pme_c[1:], np.array(res[8], float), atol=0.00501)
-    assert np.allclose((tot[2] / nsamples)[1:], np.array(res[10], float), atol=0.00501)
+    res = rf.per_target_rows(d["fx"])
+    assert np.allclose(pme_c[1:], res["pme_c"], atol=0.00501)
+    assert np.allclose((tot[2] / nsamples)[1:], res["pme_tpm"], atol=0.00501)
     ctx.close()
 
 

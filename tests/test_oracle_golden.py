@@ -29,8 +29,7 @@ def test_estep_known_answer(name):
     d = _load(name)
     rp, sid, cp, ncp = rf.split_noise(*d["items"])
     counts = orc.em_estep(d["M"], rp, sid, cp, ncp, d["raw"])
-    res = rf.read_res(os.path.join(d["fx"], "temp", "s.iso_res.em"))
-    expected = np.array(res[4], float)
+    expected = rf.per_target_rows(d["fx"], em_only=True)["count"]
     # rows dropped from .ofg (all entries < 1e-300) contribute nothing, exactly as in the reference
     assert np.allclose(counts[1:], expected, atol=0.00501)
     N0, N1, N2, Ntot = rf.read_cnt(os.path.join(d["fx"], "stat", "s.cnt"))
@@ -44,13 +43,13 @@ def test_estep_known_answer(name):
 def test_polish_and_expression(name):
     d = _load(name)
     eel = orc.calc_eel(d["M"], d["full"], d["tot"], d["model"]["gld"])
-    res = rf.read_res(os.path.join(d["fx"], "temp", "s.iso_res.em"))
-    assert np.allclose(eel[1:], np.array(res[3], float), atol=0.00501)
+    res = rf.per_target_rows(d["fx"], em_only=True)
+    assert np.allclose(eel[1:], res["eel"], atol=0.00501)
     pol = orc.polish_theta(d["M"], d["raw"], eel, d["model"]["mw"])
     assert np.allclose(pol, d["pol"], rtol=1e-9, atol=1e-300)
     tpm, fpkm = orc.calc_expression(d["M"], pol, eel)
-    assert np.allclose(tpm[1:], np.array(res[5], float), atol=0.00501)
-    assert np.allclose(fpkm[1:], np.array(res[6], float), atol=0.00501)
+    assert np.allclose(tpm[1:], res["tpm"], atol=0.00501)
+    assert np.allclose(fpkm[1:], res["fpkm"], atol=0.00501)
 
 
 @pytest.mark.parametrize("name", rf.FIXTURES)
@@ -78,11 +77,11 @@ def test_gibbs_chain_bit_exact(name):
             a += b
     pme_c = tot[0] / nsamples
     pve_c = np.maximum((tot[1] - nsamples * pme_c * pme_c) / (nsamples - 1), 0)
-    res = rf.read_res(os.path.join(d["fx"], "temp", "s.iso_res"))
-    assert np.allclose(pme_c[1:], np.array(res[8], float), atol=0.00501)
-    assert np.allclose(np.sqrt(pve_c[1:]), np.array(res[9], float), atol=0.00501)
-    assert np.allclose((tot[2] / nsamples)[1:], np.array(res[10], float), atol=0.00501)
-    assert np.allclose((tot[3] / nsamples)[1:], np.array(res[11], float), atol=0.00501)
+    res = rf.per_target_rows(d["fx"])
+    assert np.allclose(pme_c[1:], res["pme_c"], atol=0.00501)
+    assert np.allclose(np.sqrt(pve_c[1:]), res["sd"], atol=0.00501)
+    assert np.allclose((tot[2] / nsamples)[1:], res["pme_tpm"], atol=0.00501)
+    assert np.allclose((tot[3] / nsamples)[1:], res["pme_fpkm"], atol=0.00501)
 
 
 def test_em_run_invariants():
