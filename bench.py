@@ -216,22 +216,18 @@ def main():
     if not args.no_gibbs:
         # Gibbs PARALLEL sweeps on the same matrix (one chain per GPU; single reduce of the accumulators)
         try:
-            sub_rows = min(N1, 2_000_000)
-            sub = dict(wl)
-            sub["row_ptr"] = wl["row_ptr"][:sub_rows + 1]
-            nz = int(sub["row_ptr"][-1])
-            sub["sid"], sub["conprb"], sub["ncp"] = wl["sid"][:nz], wl["conprb"][:nz], wl["ncp"][:sub_rows]
-            irp, isid, icp = to_gibbs_items(sub)
-            N0s = int(wl["N0"] * sub_rows / N1)
-            g = capi.GibbsContext(M, irp, isid, icp, np.zeros(M + 1, np.int32), None, 1.0, (M + 1) + N0s + sub_rows, N0s,
-                                  np.full(M + 1, 1000.0), np.ones(M + 1), np.array([1, M + 1], np.int32))
+            irp, isid, icp = to_gibbs_items(wl)
+            g = capi.GibbsContext(M, irp, isid, icp, np.zeros(M + 1, np.int32), None, 1.0, (M + 1) + wl["N0"] + N1, wl["N0"],
+                                  np.full(M + 1, 1000.0), np.ones(M + 1), np.arange(1, M + 2, 50, dtype=np.int32)[: (M // 50) + 1]
+                                  if (M % 50 == 0) else np.array([1, M + 1], np.int32), device=local)
             cv, acc, ms = g.run(capi.GIBBS_PARALLEL, 1 + rank, args.gibbs_sweeps - 2, 2, 1, thin=1, want_vectors=False)
             g.close()
             if world > 1:
                 buf = torch.from_numpy(np.concatenate(acc)).to(dev)
                 dist.reduce(buf, dst=0)  # Gibbs.cpp:372-388 across chains
+            b_g = 12 * (len(isid) - N1) + 16 * N1  # conprb + sid per alignment, noise conprb + row slot per read
             gibbs = {"mode": "parallel (data-augmentation)", "chains": world, "items_per_chain": int(len(isid)),
-                     "ms_per_sweep": ms, "sweeps_per_s_all_chains": world * 1e3 / ms if ms > 0 else None,
+                     "ms_per_sweep": ms, "algorithmic_GBps_per_chain": b_g / ms / 1e6 if ms > 0 else None, "sweeps_per_s_all_chains": world * 1e3 / ms if ms > 0 else None,
                      "items_per_s_all_chains": world * len(isid) * 1e3 / ms if ms > 0 else None}
         except Exception as e:  # the EM line must still be printed
             gibbs = {"error": str(e)}

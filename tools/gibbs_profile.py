@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Time / profile the PARALLEL Gibbs sweep on a synthetic C2-shaped matrix: python tools/gibbs_profile.py [scale] [sweeps]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rsem_amd import capi  # noqa: E402
+from tools.synth_data import make_em_workload, to_gibbs_items  # noqa: E402
+
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+sweeps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+wl = make_em_workload("C2", scale=scale)
+M = wl["M"]
+irp, isid, icp = to_gibbs_items(wl)
+N1 = len(irp) - 1
+t0 = time.time()
+g = capi.GibbsContext(M, irp, isid, icp, np.zeros(M + 1, np.int32), None, 1.0, (M + 1) + wl["N0"] + N1, wl["N0"],
+                      np.full(M + 1, 1000.0), np.ones(M + 1), np.array([1, M + 1], np.int32))
+print("create %.2f s" % (time.time() - t0))
+cv, acc, ms = g.run(capi.GIBBS_PARALLEL, 1, sweeps - 2, 2, 1, thin=1, want_vectors=False)
+nitems = len(isid)
+bytes_sweep = 12 * (nitems - N1) + 16 * N1  # conprb + sid per alignment, noise conprb + (unused) row pointer per read
+print("N1=%d items=%d: %.3f ms/sweep, %.1f G items/s, algorithmic %.2f GB/sweep -> %.2f TB/s" % (
+    N1, nitems, ms, nitems / ms / 1e6, bytes_sweep / 1e9, bytes_sweep / ms / 1e9))
