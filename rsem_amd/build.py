@@ -69,7 +69,7 @@ def build(force=False, verbose=False):
         out = os.path.join(BIN, prog)
         host_deps = ss + hdrs + [LIB]
         if force or _stale(out, host_deps):
-            cmd = [cc, "-O2", "-std=c++17", "-o", out] + ss + ["-L" + HERE, "-lrsem_hip", "-Wl,-rpath,$ORIGIN/..", "-lpthread"]
+            cmd = [cc, "-O2", "-std=c++17", "-o", out] + ss + ["-L" + HERE, "-lrsem_hip", "-Wl,-rpath,$ORIGIN/..", "-lpthread", "-lz"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

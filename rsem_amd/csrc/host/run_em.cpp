@@ -13,10 +13,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
 #include "../../../include/rsem_hip.h"
+#include "bam_io.hpp"
 #include "files.hpp"
 #include "model_host.hpp"
 #include "reads.hpp"
@@ -200,10 +202,18 @@ int main(int argc, char* argv[]) {
     const std::string refName = argv[1];
     const int read_type = atoi(argv[2]);
     const std::string outName = argv[3], imdName = argv[4], statName = argv[5];
-    bool verbose = true, genBamF = false, genGibbsOut = false, appendNames = false;
+    bool verbose = true, genBamF = false, genGibbsOut = false, appendNames = false, bamSampling = false, hasSeed = false;
+    uint32_t seed = 0;
+    std::string inpSamF;
     int device = 0;
     for (int i = 6; i < argc; i++) {  // EM.cpp:578-595; -p is accepted and irrelevant (the GPU is the parallelism)
-        if (!strcmp(argv[i], "-b")) genBamF = true;
+        if (!strcmp(argv[i], "-b") && i + 1 < argc) { genBamF = true; inpSamF = argv[i + 1]; }
+        if (!strcmp(argv[i], "--sampling")) bamSampling = true;
+        if (!strcmp(argv[i], "--seed") && i + 1 < argc) {
+            hasSeed = true;
+            seed = 0;
+            for (const char* c = argv[i + 1]; *c; ++c) seed = seed * 10 + (uint32_t)(*c - '0');
+        }
         if (!strcmp(argv[i], "-q")) verbose = false;
         if (!strcmp(argv[i], "--gibbs-out")) genGibbsOut = true;
         if (!strcmp(argv[i], "--append-names")) appendNames = true;
@@ -226,9 +236,13 @@ int main(int argc, char* argv[]) {
         std::vector<double> theta(M + 1, 0.0), eel(M + 1, 0.0), countv(M + 1, 0.0);
         for (int i = 1; i <= M; ++i) eel[i] = T.t[i].length;
         write_results_em(M, refName, imdName, T, theta, eel, countv.data(), appendNames);
+        if (genBamF) {  // EM.cpp:630-636: the input is copied
+            std::string command = "cp " + inpSamF + " " + outName + ".transcript.bam";
+            printf("%s\n", command.c_str());
+            if (system(command.c_str()) != 0) die("Fail to copy %s!", inpSamF.c_str());
+        }
         return 0;
     }
-    if (genBamF) fprintf(stderr, "Warning: this build of rsem-run-em does not write %s.transcript.bam (run rsem-calculate-expression with --no-bam-output).\n", outName.c_str());
 
     lap("refs + transcripts");
     ModelParams P = load_mparams(imdName + ".mparams");
@@ -388,7 +402,10 @@ int main(int argc, char* argv[]) {
     }
     lap("write .ofg");
     // ---- expected counts with the learned theta (EM.cpp:460-478) -------------------------------------------
-    hip_check(rsem_em_expected_weights(em, theta.data(), (double)N0, counts.data(), nullptr, nullptr), "rsem_em_expected_weights");
+    std::vector<double> w, w_noise;
+    if (genBamF) { w.resize(nnz); w_noise.resize(N1); }
+    hip_check(rsem_em_expected_weights(em, theta.data(), (double)N0, counts.data(), genBamF ? w.data() : nullptr,
+                                       genBamF ? w_noise.data() : nullptr), "rsem_em_expected_weights");
 
     // ---- stat.theta (EM.cpp:484-500) ------------------------------------------------------------------------
     FILE* fo = fopen((statName + ".theta").c_str(), "w");
@@ -407,6 +424,47 @@ int main(int argc, char* argv[]) {
     if (verbose) printf("Expression Results are written!\n");
 
     lap("expected counts + results");
+    if (genBamF) {  // EM.cpp:504-536
+        if (bamSampling) {  // one alignment per read, drawn from its posterior (EM.cpp:507-531), MT19937 as sampling.h
+            struct Mt {
+                uint32_t mt[624]; int idx;
+                explicit Mt(uint32_t s) { mt[0] = s; for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i; idx = 624; }
+                uint32_t next() {
+                    if (idx >= 624) {
+                        for (int k = 0; k < 624; k++) {
+                            uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                            mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                        }
+                        idx = 0;
+                    }
+                    uint32_t y = mt[idx++];
+                    y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+                    return y;
+                }
+            } engine(hasSeed ? seed : (uint32_t)time(NULL));
+            if (verbose) printf("Begin to sample reads from their posteriors.\n");
+            std::vector<double> arr;
+            for (uint64_t i = 0; i < N1; i++) {
+                const uint64_t fr = dat.row_ptr[i], to = dat.row_ptr[i + 1];
+                const int len = (int)(to - fr + 1);
+                arr.assign(len, 0.0);
+                arr[0] = w_noise[i];
+                for (uint64_t k = fr; k < to; k++) arr[k - fr + 1] = arr[k - fr] + w[k];
+                long id = -1;
+                if (!(arr[len - 1] < kEpsilon)) {  // sample() of sampling.h:50-65
+                    const double prb = ((double)engine.next() * (1.0 / 4294967296.0)) * arr[len - 1];
+                    int l = 0, r = len - 1;
+                    while (l <= r) { int mid = (l + r) / 2; if (arr[mid] <= prb) l = mid + 1; else r = mid - 1; }
+                    id = l;
+                }
+                for (uint64_t k = fr; k < to; k++) w[k] = ((long)(k - fr + 1) == id) ? 1.0 : 0.0;
+            }
+            if (verbose) printf("Sampling is finished.\n");
+        }
+        write_transcript_bam(inpSamF, outName + ".transcript.bam", pe, sid_abs.data(), w.data(), nnz, T);
+        if (verbose) printf("Bam output file is generated!\n");
+        lap("transcript.bam");
+    }
     rsem_model_destroy(mc);
     rsem_em_destroy(em);
     const auto secs = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t_start).count();

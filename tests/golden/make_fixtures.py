@@ -252,7 +252,7 @@ def load_ref_seq(path):
 
 def build_fixture(name, model_type, n_reads, seed, n_genes=14, max_iso=4, polyA=False, estRSPD=0,
                   read_len=(36, 50), gibbs=(20, 40, 1), gibbs_threads=2, theta0=0.06, probF=0.5, frag_mean=None,
-                  omit_last=0, pseudo_count=None, allele=False):
+                  omit_last=0, pseudo_count=None, allele=False, bam=False):
     rng = np.random.default_rng(seed)
     out = os.path.join(HERE, name)
     work = os.path.join("/tmp", "rsem_fixture_" + name)
@@ -333,8 +333,17 @@ def build_fixture(name, model_type, n_reads, seed, n_genes=14, max_iso=4, polyA=
     with open(imd + ".mparams", "w") as f:
         f.write("1 1000\n%g\n%d\n20\n1 1000\n%s\n25\n" % (probF, estRSPD, "%g %g" % frag_mean if frag_mean else "-1 0"))
 
+    bam_args = []
+    if bam:  # keep the alignments: golden <sample>.transcript.bam from the reference's BamWriter (SAM in, then BAM in + sampling)
+        shutil.copy(samf, os.path.join(out, "aln.sam"))
+        bam_args = ["-b", os.path.join(out, "aln.sam"), "0"]
     log = run([os.path.join(REFBIN, "rsem-run-em"), oref, str(model_type), os.path.join(out, "s"), imd, stat,
-               "-p", "1", "--gibbs-out"])
+               "-p", "1", "--gibbs-out"] + bam_args)
+    if bam:
+        os.rename(os.path.join(out, "s.transcript.bam"), os.path.join(out, "golden.transcript.bam"))
+        run([os.path.join(REFBIN, "rsem-run-em"), oref, str(model_type), os.path.join(out, "s"), imd, stat, "-p", "1", "--gibbs-out",
+             "-b", os.path.join(out, "golden.transcript.bam"), "0", "--sampling", "--seed", "77"])
+        os.rename(os.path.join(out, "s.transcript.bam"), os.path.join(out, "golden.sampled.transcript.bam"))
     with open(os.path.join(out, "em.log"), "w") as f:
         f.write("\n".join(l for l in log.split("\n") if l.startswith("ROUND")) + "\n")
     # keep pre-Gibbs result files
@@ -361,10 +370,10 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])
     specs = [
         dict(name="se_noq", model_type=0, n_reads=1500, seed=11),
-        dict(name="se_q", model_type=1, n_reads=1500, seed=12),
+        dict(name="se_q", model_type=1, n_reads=1500, seed=12, bam=True),
         dict(name="se_q_polya_rspd", model_type=1, n_reads=1500, seed=15, polyA=True, estRSPD=1),
         dict(name="pe_noq", model_type=2, n_reads=1200, seed=13),
-        dict(name="pe_q", model_type=3, n_reads=1200, seed=14),
+        dict(name="pe_q", model_type=3, n_reads=1200, seed=14, bam=True),
         dict(name="pe_q_polya_rspd", model_type=3, n_reads=1200, seed=16, polyA=True, estRSPD=1),
         # --fragment-length-mean/sd with single-end reads (mld != NULL paths, LenDist::setAsNormal)
         dict(name="se_q_fragmean", model_type=1, n_reads=1200, seed=17, frag_mean=(140, 25)),

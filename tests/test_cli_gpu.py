@@ -165,3 +165,58 @@ def test_generated_dataset_vs_reference_binary(read_type, n_reads, tmp_path):
     assert _rel(raw, graw, 1e-7) < 1e-6 and _rel(pol, gpol, 1e-7) < 1e-6
     res = rf.read_res(os.path.join(d, "temp", "s.iso_res"))
     assert np.allclose(np.array(res[5], float), np.array(gres[5], float), atol=0.011, rtol=1e-6)  # TPM
+
+
+def _bam_records(path):
+    """Decompress a BAM (BGZF = concatenated gzip members) and split it into (header bytes, [record bytes])."""
+    import gzip
+    import struct
+    raw = gzip.open(path, "rb").read()
+    assert raw[:4] == b"BAM\x01"
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, p)[0]
+    p += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", raw, p)[0]
+        p += 4 + l_name + 4
+    header = raw[:p]
+    recs = []
+    while p < len(raw):
+        bs = struct.unpack_from("<i", raw, p)[0]
+        recs.append(raw[p + 4:p + 4 + bs])
+        p += 4 + bs
+    return header, recs
+
+
+def _assert_bam_equal(mine, gold):
+    import struct
+    h1, r1 = _bam_records(mine)
+    h2, r2 = _bam_records(gold)
+    assert h1 == h2
+    assert len(r1) == len(r2)
+    n_diff = 0
+    for a, b in zip(r1, r2):
+        if a == b:
+            continue
+        # only MAPQ (byte 9) and the trailing ZW:f value may differ, and only by rounding of the posterior weight
+        assert len(a) == len(b) and a[:9] == b[:9] and a[10:-4] == b[10:-4]
+        assert abs(a[9] - b[9]) <= 1
+        fa, fb = struct.unpack("<f", a[-4:])[0], struct.unpack("<f", b[-4:])[0]
+        assert abs(fa - fb) <= 1e-6 * max(abs(fb), 1e-30) + 1e-12
+        n_diff += 1
+    assert n_diff <= max(2, len(r1) // 200)
+
+
+@pytest.mark.parametrize("name", ["se_q", "pe_q"])
+def test_transcript_bam_matches_reference(name, tmp_path):
+    """-b: <sample>.transcript.bam (MAPQ + ZW:f from the posteriors) from SAM input, and from BAM input with
+    --sampling --seed (one alignment per read drawn with the reference's MT19937 stream)."""
+    fx, dst = _stage(name, tmp_path)
+    meta = rf.read_meta(fx)
+    args = [os.path.join(dst, "ref"), str(meta["model_type"]), os.path.join(dst, "s"), os.path.join(dst, "temp", "s"),
+            os.path.join(dst, "stat", "s"), "-p", "1"]
+    _run([os.path.join(BIN, "rsem-run-em")] + args + ["-b", os.path.join(dst, "aln.sam"), "0"])
+    _assert_bam_equal(os.path.join(dst, "s.transcript.bam"), os.path.join(fx, "golden.transcript.bam"))
+    _run([os.path.join(BIN, "rsem-run-em")] + args + ["-b", os.path.join(fx, "golden.transcript.bam"), "0", "--sampling", "--seed", "77"])
+    _assert_bam_equal(os.path.join(dst, "s.transcript.bam"), os.path.join(fx, "golden.sampled.transcript.bam"))
