@@ -249,9 +249,11 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "em_iterations_per_s": K / elapsed,
-            "config": {"workload": "BASELINE configs[1]: SingleQModel-shaped EM matrix, %d reads x %d transcripts, "
+            "config": {"workload": "%s: EM matrix of %d reads x %d transcripts, "
                                    "%d alignments (%.2f/read) per GPU, frozen conprb (rounds >= 12)"
-                                   % (N1, M, nnz, nnz / max(N1, 1)),
+                                   % ({"C2": "BASELINE configs[1] (SingleQModel-shaped)", "C3": "BASELINE configs[2] (PairedEndQModel-shaped)",
+                                       "C5": "BASELINE configs[4] (multi-mapping stress)"}.get(args.config, args.config),
+                                      N1, M, nnz, nnz / max(N1, 1)),
                        "synthetic_config": args.config, "kernel": args.kernel,
                        "parallelism": "1 GPU" if world == 1 else "read-sharded x%d + RCCL all-reduce(M+1 f64)/round" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
