@@ -11,6 +11,8 @@ BIN = os.path.join(HERE, "bin")
 
 HIP_SOURCES = ["status.hip", "em.hip", "gibbs.hip", "model.hip"]
 HOST_PROGRAMS = {"rsem-run-em": ["host/run_em.cpp"], "rsem-run-gibbs": ["host/run_gibbs.cpp"]}
+# stages around the hot path that never touch the GPU: plain g++, no librsem_hip dependency
+HOST_ONLY_PROGRAMS = {"rsem-parse-alignments": ["host/parse_alignments.cpp"]}
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
                "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=off"]
 
@@ -70,6 +72,14 @@ def build(force=False, verbose=False):
         host_deps = ss + hdrs + [LIB]
         if force or _stale(out, host_deps):
             cmd = [cc, "-O2", "-std=c++17", "-o", out] + ss + ["-L" + HERE, "-lrsem_hip", "-Wl,-rpath,$ORIGIN/..", "-lpthread", "-lz"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    for prog, srcs in HOST_ONLY_PROGRAMS.items():
+        ss = [os.path.join(CSRC, s) for s in srcs]
+        out = os.path.join(BIN, prog)
+        if force or _stale(out, ss + hdrs):
+            cmd = ["g++", "-O2", "-std=c++17", "-o", out] + ss + ["-lpthread", "-lz"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

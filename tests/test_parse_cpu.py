@@ -1,0 +1,144 @@
+"""rsem-parse-alignments drop-in (rsem_amd/csrc/host/parse_alignments.cpp) against the reference's outputs.
+
+Host-only stage, so these run without a GPU.  Golden: the fixtures' .dat/.cnt/.omit/read files were written by the
+reference's parser (parseIt.cpp) from the committed aln.sam.  Where oracle/_ref/rsem-parse-alignments is present, more
+variants (FASTA read types, BAM input, the -tag filter, reverse-strand heavy input) are compared with it byte for byte.
+"""
+import filecmp
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+NEW = os.path.join(ROOT, "rsem_amd", "bin", "rsem-parse-alignments")
+REF = os.path.join(ROOT, "oracle", "_ref", "rsem-parse-alignments")
+
+
+def _need_new():
+    if not os.path.exists(NEW):
+        from rsem_amd import build
+        build.build()
+    assert os.path.exists(NEW), "rsem-parse-alignments was not built"
+
+
+def _run(exe, ref, out, aln, read_type, extra=()):
+    os.makedirs(os.path.join(out, "temp"), exist_ok=True)
+    os.makedirs(os.path.join(out, "stat"), exist_ok=True)
+    cmd = [exe, ref, os.path.join(out, "temp", "s"), os.path.join(out, "stat", "s"), aln, str(read_type), "-q"] + list(extra)
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def _files(d):
+    out = []
+    for sub in ("temp", "stat"):
+        for f in sorted(os.listdir(os.path.join(d, sub))):
+            out.append(os.path.join(sub, f))
+    return out
+
+
+def _same_tree(a, b):
+    fa, fb = _files(a), _files(b)
+    assert fa == fb, (fa, fb)
+    for f in fa:
+        assert filecmp.cmp(os.path.join(a, f), os.path.join(b, f), shallow=False), f
+
+
+@pytest.mark.parametrize("name,read_type", [("se_q", 1), ("pe_q", 3)])
+def test_parse_matches_golden(name, read_type, tmp_path):
+    _need_new()
+    fx = os.path.join(GOLD, name)
+    r = _run(NEW, os.path.join(fx, "ref"), str(tmp_path), os.path.join(fx, "aln.sam"), read_type)
+    assert r.returncode == 0, r.stderr
+    produced = _files(str(tmp_path))
+    assert "temp/s.dat" in produced and "stat/s.cnt" in produced and "temp/s.omit" in produced
+    for f in produced:
+        assert filecmp.cmp(os.path.join(str(tmp_path), f), os.path.join(fx, f), shallow=False), f
+    # and nothing the reference's parser wrote is missing
+    for f in os.listdir(os.path.join(fx, "temp")):
+        if f.startswith("s_") and (f.endswith(".fq") or f.endswith(".fa")):
+            assert os.path.join("temp", f) in produced, f
+
+
+def _tagged_sam(src, dst, paired):
+    """Mark every third unaligned read (pair) with ZT:i:2 (what `-tag ZT` treats as "filtered", SamParser.h:61-82)."""
+    k = 0
+    with open(src) as fi, open(dst, "w") as fo:
+        lines = fi.readlines()
+        i = 0
+        while i < len(lines):
+            ln = lines[i]
+            if ln.startswith("@"):
+                fo.write(ln); i += 1; continue
+            grp = lines[i:i + (2 if paired else 1)]
+            i += len(grp)
+            unal = int(grp[0].split("\t")[1]) & 4
+            if unal:
+                k += 1
+                if k % 3 == 0:
+                    grp = [grp[0].rstrip("\n") + "\tZT:i:2\n"] + [g.rstrip("\n") + "\tZT:i:0\n" for g in grp[1:]]
+                elif k % 3 == 1 and paired:
+                    grp = [grp[0], grp[1].rstrip("\n") + "\tXS:Z:abc\tZT:i:300\n"]
+            fo.writelines(grp)
+
+
+VARIANTS = [
+    ("se_q", 1, "aln.sam", ()), ("se_q", 0, "aln.sam", ()), ("pe_q", 3, "aln.sam", ()), ("pe_q", 2, "aln.sam", ()),
+    ("se_q", 1, "golden.transcript.bam", ()), ("pe_q", 3, "golden.transcript.bam", ()),
+    ("se_q", 1, "tagged", ("-tag", "ZT")), ("pe_q", 3, "tagged", ("-tag", "ZT")), ("pe_q", 2, "tagged", ("-tag", "ZT")),
+]
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/rsem-parse-alignments not built")
+@pytest.mark.parametrize("name,read_type,aln,extra", VARIANTS)
+def test_parse_matches_reference_binary(name, read_type, aln, extra, tmp_path):
+    _need_new()
+    fx = os.path.join(GOLD, name)
+    if aln == "tagged":
+        alnf = str(tmp_path / "tagged.sam")
+        _tagged_sam(os.path.join(fx, "aln.sam"), alnf, read_type >= 2)
+    else:
+        alnf = os.path.join(fx, aln)
+    a, b = str(tmp_path / "new"), str(tmp_path / "ref")
+    r1 = _run(NEW, os.path.join(fx, "ref"), a, alnf, read_type, extra)
+    r2 = _run(REF, os.path.join(fx, "ref"), b, alnf, read_type, extra)
+    assert r2.returncode == 0, r2.stderr
+    assert r1.returncode == 0, r1.stderr
+    _same_tree(a, b)
+    if extra:
+        assert any(f.startswith("temp/s_max") for f in _files(a))  # the filter really fired
+
+
+def test_parse_error_paths(tmp_path):
+    """Error behaviour of SamParser.h:121-141: message on stderr, non-zero exit."""
+    _need_new()
+    fx = os.path.join(GOLD, "se_q")
+    # paired-end records handed to a single-end parse
+    r = _run(NEW, os.path.join(GOLD, "pe_q", "ref"), str(tmp_path / "a"), os.path.join(GOLD, "pe_q", "aln.sam"), 1)
+    assert r.returncode != 0 and "paired end read" in r.stderr
+    # gapped alignment
+    bad = str(tmp_path / "gap.sam")
+    done = False
+    with open(os.path.join(fx, "aln.sam")) as fi, open(bad, "w") as fo:
+        for ln in fi:
+            f = ln.split("\t")
+            if not done and not ln.startswith("@") and not (int(f[1]) & 4):
+                L = len(f[9])
+                f[5] = "%dM1I%dM" % (L // 2, L - L // 2 - 1)
+                ln = "\t".join(f)
+                done = True
+            fo.write(ln)
+    r = _run(NEW, os.path.join(fx, "ref"), str(tmp_path / "b"), bad, 1)
+    assert r.returncode != 0 and "gapped alignments" in r.stderr
+    # unknown reference name
+    bad2 = str(tmp_path / "sq.sam")
+    with open(os.path.join(fx, "aln.sam")) as fi, open(bad2, "w") as fo:
+        first = True
+        for ln in fi:
+            if first and ln.startswith("@SQ"):
+                ln = ln.replace("SN:", "SN:zz_", 1)
+                first = False
+            fo.write(ln)
+    r = _run(NEW, os.path.join(fx, "ref"), str(tmp_path / "c"), bad2, 1)
+    assert r.returncode != 0 and "can not recognize reference sequence name" in r.stderr

@@ -1,7 +1,10 @@
 // gen_temp.cpp -- seeded generator of a complete rsem-run-em input directory at benchmark scale
 // (".temp generator without SAM").  TEST / BENCH INFRASTRUCTURE, not product.
 //
-//   gen_temp <outdir> <n_reads> <M> <read_type 1|3> [seed] [read_len]
+//   gen_temp <outdir> <n_reads> <M> <read_type 1|3> [seed] [read_len] [sam]
+//
+// with a 7th argument "sam" it also writes <outdir>/aln.sam (the same reads and alignments as SAM records, in the
+// order rsem-parse-alignments would need to reproduce the files above byte for byte).
 //
 // writes  <outdir>/ref.{seq,ti,grp}, <outdir>/temp/s.{dat,mparams,omit}, s_alignable*.fq, s_un*.fq,
 // <outdir>/stat/s.cnt   in the formats of SURVEY.md Appendix A, so that BOTH the reference binary
@@ -33,6 +36,7 @@ int main(int argc, char** argv) {
     const unsigned seed = argc > 5 ? (unsigned)atoll(argv[5]) : 20250925u;
     const int L = argc > 6 ? atoi(argv[6]) : 100;
     const bool pe = read_type == 3;
+    const bool want_sam = argc > 7 && std::string(argv[7]) == "sam";
     if (read_type != 1 && read_type != 3) { fprintf(stderr, "read_type must be 1 or 3\n"); return 1; }
     std::mt19937_64 rng(seed);
     auto uni = [&](double a, double b) { return std::uniform_real_distribution<double>(a, b)(rng); };
@@ -95,6 +99,24 @@ int main(int argc, char** argv) {
     static char buf1[1 << 16], buf2[1 << 16], buf3[1 << 16];
     setvbuf(fdat, nullptr, _IOFBF, 1 << 22); setvbuf(fq1, nullptr, _IOFBF, 1 << 22); if (fq2) setvbuf(fq2, nullptr, _IOFBF, 1 << 22);
     (void)buf1; (void)buf2; (void)buf3;
+    FILE* fsam = nullptr;
+    if (want_sam) {
+        fsam = fopen((out + "/aln.sam").c_str(), "w");
+        setvbuf(fsam, nullptr, _IOFBF, 1 << 22);
+        fprintf(fsam, "@HD\tVN:1.0\tSO:unsorted\n");
+        for (int t = 1; t <= M; t++) fprintf(fsam, "@SQ\tSN:t%d\tLN:%d\n", t, tlen(t));
+        fprintf(fsam, "@PG\tID:gen_temp\n");
+    }
+    auto revcomp = [&](const std::string& s) { std::string r(s.rbegin(), s.rend()); for (char& c : r) c = comp(c); return r; };
+    auto rev = [&](const std::string& s) { return std::string(s.rbegin(), s.rend()); };
+    // one SAM record; `fwd` = 0-based leftmost forward coordinate, is_rev = aligned to the reverse strand
+    auto sam_rec = [&](long long id, int flag, int s, int fwd, int mate_fwd, int tl, const std::string& sq, const std::string& ql, bool is_rev) {
+        if (s > 0) fprintf(fsam, "r%lld\t%d\tt%d\t%d\t255\t%dM\t%s\t%d\t%d\t", id, flag, s, fwd + 1, L, pe ? "=" : "*", pe ? mate_fwd + 1 : 0, tl);
+        else fprintf(fsam, "r%lld\t%d\t*\t0\t0\t*\t*\t0\t0\t", id, flag);
+        const std::string a = is_rev ? revcomp(sq) : sq, b = is_rev ? rev(ql) : ql;
+        fwrite(a.data(), 1, a.size(), fsam); fputc('\t', fsam);
+        fwrite(b.data(), 1, b.size(), fsam); fputc('\n', fsam);
+    };
     fprintf(fdat, "%-99s\n", "");  // header is patched at the end (parseIt.cpp:195-199)
     long long nHits = 0;
     std::string seq(L, 'A'), qual(L, 'I'), seq2(L, 'A'), qual2(L, 'I'), line;
@@ -144,6 +166,16 @@ int main(int argc, char** argv) {
                 else snprintf(tmp, sizeof(tmp), " %d %d", dir == 0 ? s : -s, p);
                 line += tmp;
                 ++k;
+                if (fsam) {
+                    if (!pe) sam_rec(r, dir == 0 ? 0 : 16, s, f2, 0, 0, seq, qual, dir != 0);
+                    else if (dir == 0) {
+                        sam_rec(r, 99, s, f2, f2 + frag - L, frag, seq, qual, false);
+                        sam_rec(r, 147, s, f2 + frag - L, f2, -frag, seq2, qual2, true);
+                    } else {
+                        sam_rec(r, 83, s, f2 + frag - L, f2, -frag, seq, qual, true);
+                        sam_rec(r, 163, s, f2, f2 + frag - L, frag, seq2, qual2, false);
+                    }
+                }
             }
         }
         fprintf(fdat, "%d%s\n", k, line.c_str());
@@ -160,9 +192,11 @@ int main(int argc, char** argv) {
                 int qv = irand(10, 40);
                 for (int i = 0; i < L; i++) { seq[i] = BASES[rng() & 3]; qual[i] = (char)(qv + 33); qv = next_q(qv); }
                 emit_read(mth ? fu2 : fu1, N1 + r, seq, qual);
+                if (fsam) sam_rec(N1 + r, pe ? (mth ? 141 : 77) : 4, 0, 0, 0, 0, seq, qual, false);
             }
         }
         fclose(fu1); if (fu2) fclose(fu2);
+        if (fsam) fclose(fsam);
     }
     FILE* f = fopen((out + "/stat/s.cnt").c_str(), "w");
     fprintf(f, "%lld %lld 0 %lld\n%lld 0 %lld\n%lld %d\n0\t%lld\nInf\t0\n", N0, N1, N, N1, N1, nHits, read_type, N0);
