@@ -46,6 +46,11 @@ def lib():
                                       C.c_uint64, _f64p, _f64p, C.c_int32, _i32p, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, _f64p, _f64p, _f64p, _f64p, _f64p]
         L.orc_gibbs_chain.restype = None
+        _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        L.orc_calc_ci.argtypes = [C.c_int, _f32p, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_calc_ci.restype = None
+        L.orc_ci_transform.argtypes = [C.c_int32, _f64p, _i32p, _f64p, _f64p, _f32p]
+        L.orc_ci_transform.restype = C.c_float
         _LIB = L
     return _LIB
 
@@ -113,3 +118,20 @@ def gibbs_chain(M, row_ptr, sid, conprb, init_counts, alpha, pseudoC, totc, N0, 
     lib().orc_gibbs_chain(M, len(row_ptr) - 1, row_ptr, sid, conprb, init_counts, _ptr(alpha), float(pseudoC), float(totc),
                           int(N0), eel, mw, m, grp, int(mt_seed), burnin, nsamples, gap, _ptr(cv), *acc)
     return cv, acc
+
+
+def calc_ci(samples, confidence):
+    """calcCI.cpp:216-284 on a copy of `samples` (float32) -> (lb, ub, cqv) as float32."""
+    a = np.ascontiguousarray(samples, np.float32).copy()
+    lb, ub, cqv = C.c_float(), C.c_float(), C.c_float()
+    lib().orc_calc_ci(len(a), a, float(confidence), C.byref(lb), C.byref(ub), C.byref(cqv))
+    return np.float32(lb.value), np.float32(ub.value), np.float32(cqv.value)
+
+
+def ci_transform(gam, cvec, eel, mw):
+    """calcCI.cpp:129-149 for one vector of gamma variates -> (tpm float32[M+1], l_bar)."""
+    M = len(gam) - 1
+    tpm = np.zeros(M + 1, np.float32)
+    lbar = lib().orc_ci_transform(M, np.ascontiguousarray(gam, np.float64), np.ascontiguousarray(cvec, np.int32),
+                                  np.ascontiguousarray(eel, np.float64), np.ascontiguousarray(mw, np.float64), tpm)
+    return tpm, np.float32(lbar)

@@ -265,3 +265,102 @@ void orc_gibbs_chain(int32_t M, uint64_t N1, const uint64_t* s, const int32_t* s
     }
     free(arr); free(z); free(counts); free(theta); free(tpm); free(fpkm);
 }
+
+
+/* ---- credibility intervals ----------------------------------------------------------------------------- */
+
+static int cmp_float(const void* a, const void* b) {
+    const float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+/* calcCI.cpp:216-284 */
+void orc_calc_ci(int nSamples, float* samples, double confidence, float* lb_out, float* ub_out, float* cqv_out) {
+    int p, q, newp, newq;
+    const int threshold = nSamples - ((int)(confidence * nSamples - 1e-8) + 1);
+    int nOutside = 0;
+    float lb, ub;
+
+    qsort(samples, (size_t)nSamples, sizeof(float), cmp_float);
+
+    p = 0; q = nSamples - 1;
+    newq = nSamples - 1;
+    do {
+        q = newq;
+        while (newq > 0 && samples[newq - 1] == samples[newq]) newq--;
+        newq--;
+    } while (newq >= 0 && nSamples - (newq + 1) <= threshold);
+
+    nOutside = nSamples - (q + 1);
+
+    lb = -1e30f; ub = 1e30f;
+    do {
+        if (samples[q] - samples[p] < ub - lb) {
+            lb = samples[p];
+            ub = samples[q];
+        }
+        newp = p;
+        while (newp < nSamples - 1 && samples[newp] == samples[newp + 1]) newp++;
+        newp++;
+        if (newp <= threshold) {
+            nOutside += newp - p;
+            p = newp;
+            while (nOutside > threshold && q < nSamples - 1) {
+                newq = q + 1;
+                while (newq < nSamples - 1 && samples[newq] == samples[newq + 1]) newq++;
+                nOutside -= newq - q;
+                q = newq;
+            }
+        } else p = newp;
+    } while (p <= threshold);
+
+    {
+        float Q1, Q3;
+        const int quotient = nSamples / 4, residue = nSamples % 4;
+        if (residue == 0) {
+            Q1 = (float)((samples[quotient - 1] + samples[quotient]) / 2.0);
+            Q3 = (float)((samples[3 * quotient - 1] + samples[3 * quotient]) / 2.0);
+        } else if (residue == 3) {
+            Q1 = (float)((samples[quotient] + samples[quotient + 1]) / 2.0);
+            Q3 = (float)((samples[quotient * 3 + 1] + samples[quotient * 3 + 2]) / 2.0);
+        } else {
+            Q1 = samples[quotient];
+            Q3 = samples[3 * quotient];
+        }
+        *cqv_out = (float)(Q3 - Q1 > 0.0 ? (Q3 - Q1) / (Q3 + Q1) : 0.0);
+    }
+    *lb_out = lb; *ub_out = ub;
+}
+
+/* calcCI.cpp:129-149 */
+float orc_ci_transform(int32_t M, const double* gam, const int32_t* cvec, const double* eel, const double* mw,
+                       float* tpm) {
+    const double EPSILON = 1e-300;
+    double* theta = (double*)malloc(sizeof(double) * ((size_t)M + 1));
+    double sum = 0.0;
+    float l_bar;
+    int j;
+    for (j = 0; j <= M; j++) {
+        theta[j] = ((j == 0 || (cvec[j] >= 0 && eel[j] >= EPSILON && mw[j] >= EPSILON)) ? gam[j] / mw[j] : 0.0);
+        sum += theta[j];
+    }
+    if (!(sum >= EPSILON)) { free(theta); return -1.0f; }
+    for (j = 0; j <= M; j++) theta[j] /= sum;
+    sum = 0.0;
+    tpm[0] = 0.0f;
+    for (j = 1; j <= M; j++) {
+        if (eel[j] >= EPSILON) {
+            tpm[j] = (float)(theta[j] / eel[j]);
+            sum += tpm[j];
+        } else tpm[j] = 0.0f;
+    }
+    if (!(sum >= EPSILON)) { free(theta); return -1.0f; }
+    l_bar = 0.0f;
+    for (j = 1; j <= M; j++) {
+        tpm[j] = (float)(tpm[j] / sum);
+        l_bar = (float)(l_bar + tpm[j] * eel[j]);
+        tpm[j] = (float)(tpm[j] * 1e6);
+    }
+    free(theta);
+    return l_bar;
+}
