@@ -211,6 +211,37 @@ int rsem_gibbs_destroy(rsem_gibbs_ctx* ctx);
 /* sampling.h:19-44: seeds of the first nchains chains for --seed seed. */
 int rsem_gibbs_chain_seeds(uint32_t seed, int nchains, uint32_t* out);
 
+/* ---- credibility intervals (rsem-calculate-credibility-intervals) -----------------------------------------
+ * Replaces sample_theta_from_c + Buffer (calcCI.cpp:93-164, Buffer.h:13-80) and calcCI / calcCI_batch
+ * (calcCI.cpp:216-388): for every Gibbs count vector, nSpC Dirichlet draws theta ~ Dir(c + pseudoC) / mw,
+ * TPM samples (float) and the mean effective length l_bar per draw; then per transcript / gene the shortest
+ * interval holding `confidence` of the samples and the coefficient of quartile variation, for TPM and FPKM.
+ * The gamma variates come from a counter-based generator (Philox4x32-10 keyed by `seed`), not from the
+ * reference's per-thread MT19937 streams: same distribution, different draws (the reference's own output
+ * depends on -p).  The interval arithmetic on a given sample row is bit-identical to the reference's. */
+typedef struct rsem_ci_profile {
+    double sample_ms, sort_ms, interval_ms, total_ms;
+    uint64_t n_draws, n_keys_sorted;
+} rsem_ci_profile;
+
+/* cvecs: nCV x (M+1) int32 count vectors (imd.countvectors*, Gibbs.cpp:257-262), row-major, index 0 = noise.
+ * eel, mw: M+1.  gene_starts: m+1 (ref.grp).  trans_starts: m_trans+1 (ref.ta) or NULL when not allele-specific.
+ * Outputs, each 3 x n floats laid out [lb[n] | ub[n] | cqv[n]]: tpm_ci / fpkm_ci n = M (sid 1..M),
+ * gene_*_ci n = m, iso_*_ci n = m_trans (NULL when trans_starts is NULL). */
+int rsem_ci_calculate(int device, int32_t M, int32_t nCV, int32_t nSpC, const int32_t* cvecs, const double* eel,
+                      const double* mw, double pseudoC, uint64_t seed, double confidence, int32_t m,
+                      const int32_t* gene_starts, int32_t m_trans, const int32_t* trans_starts, float* tpm_ci,
+                      float* fpkm_ci, float* gene_tpm_ci, float* gene_fpkm_ci, float* iso_tpm_ci, float* iso_fpkm_ci,
+                      rsem_ci_profile* prof);
+/* The sampling stage alone (tests): tpm_samples M x (nCV*nSpC) float, row j-1 = transcript j, as the reference's
+ * temporary file (Buffer.h:66-80); l_bars nCV*nSpC. */
+int rsem_ci_sample(int device, int32_t M, int32_t nCV, int32_t nSpC, const int32_t* cvecs, const double* eel,
+                   const double* mw, double pseudoC, uint64_t seed, float* tpm_samples, float* l_bars);
+/* The interval stage alone: nrows rows of nSamples floats (host, not modified) -> lb, ub, cqv [nrows]
+ * (calcCI, calcCI.cpp:216-284). */
+int rsem_ci_intervals(int device, int64_t nrows, int32_t nSamples, const float* rows, double confidence, float* lb,
+                      float* ub, float* cqv);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,8 +9,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librsem_hip.so")
 BIN = os.path.join(HERE, "bin")
 
-HIP_SOURCES = ["status.hip", "em.hip", "gibbs.hip", "model.hip"]
-HOST_PROGRAMS = {"rsem-run-em": ["host/run_em.cpp"], "rsem-run-gibbs": ["host/run_gibbs.cpp"]}
+HIP_SOURCES = ["status.hip", "em.hip", "gibbs.hip", "model.hip", "ci.hip"]
+HOST_PROGRAMS = {"rsem-run-em": ["host/run_em.cpp"], "rsem-run-gibbs": ["host/run_gibbs.cpp"],
+                 "rsem-calculate-credibility-intervals": ["host/calc_ci.cpp"]}
 # stages around the hot path that never touch the GPU: plain g++, no librsem_hip dependency
 HOST_ONLY_PROGRAMS = {"rsem-parse-alignments": ["host/parse_alignments.cpp"]}
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",

@@ -14,12 +14,18 @@ _u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 
 
 class RsemHipError(RuntimeError):
     def __init__(self, status, detail):
         super().__init__("librsem_hip: status %d (%s): %s" % (status, _strerror(status), detail))
         self.status = status
+
+
+class CiProfile(C.Structure):
+    _fields_ = [("sample_ms", C.c_double), ("sort_ms", C.c_double), ("interval_ms", C.c_double), ("total_ms", C.c_double),
+                ("n_draws", C.c_uint64), ("n_keys_sorted", C.c_uint64)]
 
 
 class EmProfile(C.Structure):
@@ -57,6 +63,10 @@ def lib():
         L.rsem_gibbs_run.argtypes = [vp, ci, C.c_uint32, ci, ci, ci, ci, vp, _f64p, _f64p, _f64p, _f64p, _f64p, vp]
         L.rsem_gibbs_destroy.argtypes = [vp]
         L.rsem_gibbs_chain_seeds.argtypes = [C.c_uint32, ci, _u32p]
+        L.rsem_ci_calculate.argtypes = [ci, i32, i32, i32, _i32p, _f64p, _f64p, dbl, u64, dbl, i32, _i32p, i32, vp,
+                                        _f32p, _f32p, _f32p, _f32p, vp, vp, vp]
+        L.rsem_ci_sample.argtypes = [ci, i32, i32, i32, _i32p, _f64p, _f64p, dbl, u64, _f32p, _f32p]
+        L.rsem_ci_intervals.argtypes = [ci, C.c_int64, i32, _f32p, dbl, _f32p, _f32p, _f32p]
         _lib = L
     return _lib
 
@@ -188,4 +198,50 @@ class GibbsContext:
 def gibbs_chain_seeds(seed, n):
     out = np.zeros(n, np.uint32)
     _check(lib().rsem_gibbs_chain_seeds(int(seed), n, out))
+    return out
+
+
+def ci_intervals(rows, confidence, device=0):
+    """calcCI (calcCI.cpp:216-284) for every row of a (nrows, nSamples) float32 array -> lb, ub, cqv."""
+    rows = np.ascontiguousarray(rows, np.float32)
+    n, ns = rows.shape
+    lb, ub, cqv = (np.zeros(n, np.float32) for _ in range(3))
+    _check(lib().rsem_ci_intervals(device, n, ns, rows, float(confidence), lb, ub, cqv))
+    return lb, ub, cqv
+
+
+def ci_sample(cvecs, nSpC, eel, mw, pseudoC=1.0, seed=0, device=0):
+    """Phase I of calcCI.cpp alone: (M, nCV*nSpC) float32 TPM samples and l_bars."""
+    cvecs = np.ascontiguousarray(cvecs, np.int32)
+    nCV, M1 = cvecs.shape
+    M = M1 - 1
+    tpm = np.zeros((M, nCV * nSpC), np.float32)
+    lbar = np.zeros(nCV * nSpC, np.float32)
+    _check(lib().rsem_ci_sample(device, M, nCV, nSpC, cvecs, np.ascontiguousarray(eel, np.float64),
+                                np.ascontiguousarray(mw, np.float64), float(pseudoC), int(seed), tpm, lbar))
+    return tpm, lbar
+
+
+def ci_calculate(cvecs, nSpC, eel, mw, gene_starts, confidence=0.95, pseudoC=1.0, seed=0, trans_starts=None, device=0):
+    """rsem-calculate-credibility-intervals in one call.  Returns a dict of (3, n) float32 arrays [lb, ub, cqv]:
+    tpm, fpkm (n = M), gene_tpm, gene_fpkm (n = m) and, with trans_starts, iso_tpm, iso_fpkm; plus 'profile'."""
+    cvecs = np.ascontiguousarray(cvecs, np.int32)
+    nCV, M1 = cvecs.shape
+    M = M1 - 1
+    gs = np.ascontiguousarray(gene_starts, np.int32)
+    m = len(gs) - 1
+    out = {k: np.zeros((3, n), np.float32) for k, n in (("tpm", M), ("fpkm", M), ("gene_tpm", m), ("gene_fpkm", m))}
+    ts = None
+    mt = 0
+    if trans_starts is not None:
+        ts = np.ascontiguousarray(trans_starts, np.int32)
+        mt = len(ts) - 1
+        out["iso_tpm"] = np.zeros((3, mt), np.float32)
+        out["iso_fpkm"] = np.zeros((3, mt), np.float32)
+    prof = CiProfile()
+    _check(lib().rsem_ci_calculate(device, M, nCV, nSpC, cvecs, np.ascontiguousarray(eel, np.float64),
+                                   np.ascontiguousarray(mw, np.float64), float(pseudoC), int(seed), float(confidence), m, gs, mt,
+                                   _ptr(ts), out["tpm"], out["fpkm"], out["gene_tpm"], out["gene_fpkm"], _ptr(out.get("iso_tpm")),
+                                   _ptr(out.get("iso_fpkm")), C.addressof(prof)))
+    out["profile"] = prof
     return out

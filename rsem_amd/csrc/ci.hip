@@ -1,0 +1,451 @@
+// ci.hip -- credibility intervals on MI355X (rsem-calculate-credibility-intervals).
+//
+// Reference: calcCI.cpp.  Phase I (sample_theta_from_c, :93-164): for each of nCV Gibbs count vectors, nSpC draws
+// theta ~ Dirichlet(c + pseudoC) (independent gammas / mw), TPM as float + the mean effective length l_bar of the
+// draw, transposed through a temporary file (Buffer.h) into M rows of nSamples floats.  Phase II (calcCI_batch,
+// :286-388): per transcript sort the row, shortest interval with >= confidence mass + coefficient of quartile
+// variation (calcCI, :216-284), for TPM and for FPKM = 1e3 / l_bar[k] * TPM[k]; per gene (and, allele-specific,
+// per transcript) the same on the float sums of its members' rows.
+//
+// Here the M x nSamples matrix lives in HBM (C2: 50 k x 50 k floats = 10 GB of 288 GB), is produced directly in
+// row-per-transcript order and never touches a file:
+//   k_ci_draw       lane = sample, loop over a chunk of transcripts: y = Gamma(c_j + pseudoC) / (mw_j eel_j) as float
+//                   into Y[j][s] (coalesced along s), per-sample normaliser T_s and sum(y eel) accumulated in
+//                   registers, two double atomics per lane per chunk.  (theta's own normaliser cancels in TPM.)
+//   k_ci_keys_*     rows (or float sums of member rows) scaled to TPM / FPKM into a key batch
+//   hipcub segmented radix sort of the batch (one segment per row)
+//   k_ci_intervals  one thread per sorted row runs the reference's two-pointer scan verbatim (ties included)
+// RNG: Philox4x32-10 counters (seed, sample, transcript) -- a different stream than the reference's per-thread
+// MT19937 + boost gamma (whose output depends on -p); the interval stage is bit-identical given the same row.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+#include "rng.hpp"
+
+namespace {
+
+using rsem::kEpsilon;
+using rsem::Philox;
+
+constexpr int kBlock = 256;
+constexpr uint32_t kDrawTag = 0x43495331u;  // 'CIS1'
+
+struct DevMem {  // frees what it owns on scope exit
+    std::vector<void*> ptrs;
+    ~DevMem() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T> hipError_t alloc(T** p, size_t n) {
+        hipError_t e = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+};
+
+// y[j][s] for transcripts j in this block's chunk, samples s = lane
+__global__ void __launch_bounds__(64) k_ci_draw(int32_t M, int32_t nS, int32_t nSpC, int32_t chunk, const int32_t* __restrict__ cvecs,
+                                                  const double* __restrict__ w, const double* __restrict__ eel, double pseudoC,
+                                                  Philox ph, float* __restrict__ Y, double* __restrict__ T, double* __restrict__ L) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= nS) return;
+    const int j0 = 1 + blockIdx.y * chunk, j1 = min(M + 1, j0 + chunk);
+    const int32_t* cv = cvecs + (size_t)(s / nSpC) * (size_t)(M + 1);
+    double t = 0.0, l = 0.0;
+    for (int j = j0; j < j1; j++) {
+        const double wj = w[j];
+        const int c = cv[j];
+        float y = 0.0f;
+        if (wj > 0.0 && c >= 0) y = (float)(rsem::gamma_draw_bulk(ph, (uint32_t)s, (uint32_t)j, kDrawTag, (double)c + pseudoC) * wj);
+        Y[(size_t)(j - 1) * nS + s] = y;
+        t += (double)y;
+        l += (double)y * eel[j];
+    }
+    atomicAdd(T + s, t);
+    atomicAdd(L + s, l);
+}
+
+// sc[s] = 1e6 / T_s ; lbar[s] = (float)(L_s / T_s)   (calcCI.cpp:143-148)
+__global__ void k_ci_scales(int32_t nS, const double* __restrict__ T, const double* __restrict__ L, double* sc, float* lbar) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nS) return;
+    const double t = T[s];
+    sc[s] = t >= kEpsilon ? 1e6 / t : 0.0;
+    lbar[s] = t >= kEpsilon ? (float)(L[s] / t) : 0.0f;
+}
+
+__device__ inline float tpm_of(float y, double sc) { return (float)((double)y * sc); }
+__device__ inline float fpkm_of(float tpm, float lbar) { return (float)(1e3 / (double)lbar * (double)tpm); }  // calcCI.cpp:345
+
+// keys[r][s] = TPM or FPKM sample s of row row0 + r
+__global__ void k_ci_keys_rows(int32_t nS, const float* __restrict__ Y, const double* __restrict__ sc, const float* __restrict__ lbar,
+                               int64_t row0, int64_t nrows, bool fpkm, float* __restrict__ keys) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * nS) return;
+    const size_t r = (size_t)(idx / nS);
+    const int s = (int)(idx - (int64_t)r * nS);
+    float v = tpm_of(Y[(size_t)(row0 + r) * nS + s], sc[s]);
+    if (fpkm) v = fpkm_of(v, lbar[s]);
+    keys[r * nS + s] = v;
+}
+
+// keys[g][s] = float sum over the group's member rows, in order (calcCI.cpp:346-351)
+__global__ void k_ci_keys_groups(int32_t nS, const float* __restrict__ Y, const double* __restrict__ sc, const float* __restrict__ lbar,
+                                 const int32_t* __restrict__ gb, const int32_t* __restrict__ ge, int64_t ngroups, bool fpkm,
+                                 float* __restrict__ keys) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ngroups * nS) return;
+    const size_t g = (size_t)(idx / nS);
+    const int s = (int)(idx - (int64_t)g * nS);
+    const double scs = sc[s];
+    const float lb = lbar[s];
+    float acc = 0.0f;
+    for (int j = gb[g]; j < ge[g]; j++) {  // member rows are sids gb..ge-1, stored at row sid-1
+        float v = tpm_of(Y[(size_t)(j - 1) * nS + s], scs);
+        if (fpkm) v = fpkm_of(v, lb);
+        acc += v;
+    }
+    keys[g * nS + s] = acc;
+}
+
+// plain rows (tests / the sampling-only entry point): tpm[j][s] in place of y
+__global__ void k_ci_finish_rows(int32_t nS, int64_t nrows, float* __restrict__ Y, const double* __restrict__ sc) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * nS) return;
+    const size_t r = (size_t)(idx / nS);
+    const int s = (int)(idx - (int64_t)r * nS);
+    Y[r * nS + s] = tpm_of(Y[r * nS + s], sc[s]);
+}
+
+// calcCI (calcCI.cpp:216-284) on an already sorted row; one thread per row
+__global__ void k_ci_intervals(int64_t nrows, int32_t nSamples, const float* __restrict__ sorted, double confidence,
+                               float* __restrict__ lb_out, float* __restrict__ ub_out, float* __restrict__ cqv_out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const float* samples = sorted + (size_t)r * nSamples;
+    int p, q, newp, newq;
+    const int threshold = nSamples - ((int)(confidence * nSamples - 1e-8) + 1);
+    int nOutside = 0;
+
+    p = 0; q = nSamples - 1;
+    newq = nSamples - 1;
+    do {
+        q = newq;
+        while (newq > 0 && samples[newq - 1] == samples[newq]) newq--;
+        newq--;
+    } while (newq >= 0 && nSamples - (newq + 1) <= threshold);
+
+    nOutside = nSamples - (q + 1);
+
+    float lb = -1e30f, ub = 1e30f;
+    do {
+        if (samples[q] - samples[p] < ub - lb) {
+            lb = samples[p];
+            ub = samples[q];
+        }
+        newp = p;
+        while (newp < nSamples - 1 && samples[newp] == samples[newp + 1]) newp++;
+        newp++;
+        if (newp <= threshold) {
+            nOutside += newp - p;
+            p = newp;
+            while (nOutside > threshold && q < nSamples - 1) {
+                newq = q + 1;
+                while (newq < nSamples - 1 && samples[newq] == samples[newq + 1]) newq++;
+                nOutside -= newq - q;
+                q = newq;
+            }
+        } else p = newp;
+    } while (p <= threshold);
+
+    // Tukey's hinges
+    float Q1, Q3;
+    const int quotient = nSamples / 4, residue = nSamples % 4;
+    if (residue == 0) {
+        Q1 = (float)((double)(samples[quotient - 1] + samples[quotient]) / 2.0);  // float add, as the reference
+        Q3 = (float)((double)(samples[3 * quotient - 1] + samples[3 * quotient]) / 2.0);
+    } else if (residue == 3) {
+        Q1 = (float)((double)(samples[quotient] + samples[quotient + 1]) / 2.0);
+        Q3 = (float)((double)(samples[quotient * 3 + 1] + samples[quotient * 3 + 2]) / 2.0);
+    } else {
+        Q1 = samples[quotient];
+        Q3 = samples[3 * quotient];
+    }
+    lb_out[r] = lb;
+    ub_out[r] = ub;
+    cqv_out[r] = (Q3 - Q1 > 0.0f) ? (Q3 - Q1) / (Q3 + Q1) : 0.0f;  // float division, as the reference
+}
+
+__global__ void k_ci_offsets(int64_t n, int32_t nS, int* off) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) off[i] = (int)(i * nS);
+}
+
+// sorts `nrows` rows held in d_keys (device, nrows x nS) and writes their intervals to the host arrays at [out0 ...)
+struct RowSorter {
+    int32_t nS = 0;
+    int64_t cap_rows = 0;
+    float* d_sorted = nullptr;
+    int* d_off = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    float *d_lb = nullptr, *d_ub = nullptr, *d_cqv = nullptr;
+    DevMem mem;
+    hipStream_t st = nullptr;
+    double sort_ms = 0.0, interval_ms = 0.0;
+    uint64_t n_keys = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+
+    int init(int32_t nSamples, int64_t rows, hipStream_t stream) {
+        nS = nSamples; cap_rows = rows; st = stream;
+        RSEM_HIP_TRY(mem.alloc(&d_sorted, (size_t)rows * nS));
+        RSEM_HIP_TRY(mem.alloc(&d_off, (size_t)rows + 1));
+        RSEM_HIP_TRY(mem.alloc(&d_lb, (size_t)rows));
+        RSEM_HIP_TRY(mem.alloc(&d_ub, (size_t)rows));
+        RSEM_HIP_TRY(mem.alloc(&d_cqv, (size_t)rows));
+        hipLaunchKernelGGL(k_ci_offsets, dim3(rsem::ceil_div(rows + 1, kBlock)), dim3(kBlock), 0, st, rows, nS, d_off);
+        RSEM_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tmp_bytes, (const float*)nullptr, d_sorted, (int)(rows * nS),
+                                                               (int)rows, d_off, d_off + 1, 0, 32, st));
+        RSEM_HIP_TRY(mem.alloc((char**)&d_tmp, tmp_bytes));
+        RSEM_HIP_TRY(hipEventCreate(&e0)); RSEM_HIP_TRY(hipEventCreate(&e1)); RSEM_HIP_TRY(hipEventCreate(&e2));
+        return RSEM_OK;
+    }
+    ~RowSorter() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (e2) (void)hipEventDestroy(e2);
+    }
+    int run(const float* d_keys, int64_t nrows, double confidence, float* lb, float* ub, float* cqv) {
+        if (nrows == 0) return RSEM_OK;
+        RSEM_HIP_TRY(hipEventRecord(e0, st));
+        RSEM_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(d_tmp, tmp_bytes, d_keys, d_sorted, (int)(nrows * nS), (int)nrows, d_off,
+                                                               d_off + 1, 0, 32, st));
+        RSEM_HIP_TRY(hipEventRecord(e1, st));
+        hipLaunchKernelGGL(k_ci_intervals, dim3(rsem::ceil_div(nrows, 64)), dim3(64), 0, st, nrows, nS, d_sorted, confidence, d_lb, d_ub,
+                           d_cqv);
+        RSEM_HIP_TRY(hipEventRecord(e2, st));
+        RSEM_HIP_TRY(hipMemcpyAsync(lb, d_lb, sizeof(float) * nrows, hipMemcpyDeviceToHost, st));
+        RSEM_HIP_TRY(hipMemcpyAsync(ub, d_ub, sizeof(float) * nrows, hipMemcpyDeviceToHost, st));
+        RSEM_HIP_TRY(hipMemcpyAsync(cqv, d_cqv, sizeof(float) * nrows, hipMemcpyDeviceToHost, st));
+        RSEM_HIP_TRY(hipStreamSynchronize(st));
+        float a = 0, b = 0;
+        RSEM_HIP_TRY(hipEventElapsedTime(&a, e0, e1));
+        RSEM_HIP_TRY(hipEventElapsedTime(&b, e1, e2));
+        sort_ms += a; interval_ms += b;
+        n_keys += (uint64_t)nrows * nS;
+        return RSEM_OK;
+    }
+};
+
+int64_t batch_rows(int32_t nS, int64_t total) {
+    const int64_t cap = std::max<int64_t>(1, ((int64_t)1 << 30) / nS);  // int offsets in the segmented sort; 4 GB of keys
+    return std::max<int64_t>(1, std::min(total, cap));
+}
+
+struct Sampler {  // Y (M x nS, unnormalised), scale and l_bar per sample, on the device
+    DevMem mem;
+    float* d_Y = nullptr;
+    double* d_sc = nullptr;
+    float* d_lbar = nullptr;
+    double sample_ms = 0.0;
+    int run(int32_t M, int32_t nCV, int32_t nSpC, const int32_t* cvecs, const double* eel, const double* mw, double pseudoC,
+            uint64_t seed, hipStream_t st) {
+        const int32_t nS = nCV * nSpC;
+        std::vector<double> w((size_t)M + 1, 0.0);
+        for (int j = 1; j <= M; j++)
+            if (eel[j] >= kEpsilon && mw[j] >= kEpsilon) w[j] = 1.0 / (mw[j] * eel[j]);  // calcCI.cpp:131,137-141
+        int32_t* d_cv; double *d_w, *d_eel, *d_T, *d_L;
+        RSEM_HIP_TRY(mem.alloc(&d_Y, (size_t)M * nS));
+        RSEM_HIP_TRY(mem.alloc(&d_sc, (size_t)nS));
+        RSEM_HIP_TRY(mem.alloc(&d_lbar, (size_t)nS));
+        RSEM_HIP_TRY(mem.alloc(&d_cv, (size_t)nCV * (M + 1)));
+        RSEM_HIP_TRY(mem.alloc(&d_w, (size_t)M + 1));
+        RSEM_HIP_TRY(mem.alloc(&d_eel, (size_t)M + 1));
+        RSEM_HIP_TRY(mem.alloc(&d_T, (size_t)nS));
+        RSEM_HIP_TRY(mem.alloc(&d_L, (size_t)nS));
+        RSEM_HIP_TRY(hipMemcpyAsync(d_cv, cvecs, sizeof(int32_t) * (size_t)nCV * (M + 1), hipMemcpyHostToDevice, st));
+        RSEM_HIP_TRY(hipMemcpyAsync(d_w, w.data(), sizeof(double) * ((size_t)M + 1), hipMemcpyHostToDevice, st));
+        RSEM_HIP_TRY(hipMemcpyAsync(d_eel, eel, sizeof(double) * ((size_t)M + 1), hipMemcpyHostToDevice, st));
+        RSEM_HIP_TRY(hipMemsetAsync(d_T, 0, sizeof(double) * nS, st));
+        RSEM_HIP_TRY(hipMemsetAsync(d_L, 0, sizeof(double) * nS, st));
+        hipEvent_t e0, e1;
+        RSEM_HIP_TRY(hipEventCreate(&e0)); RSEM_HIP_TRY(hipEventCreate(&e1));
+        RSEM_HIP_TRY(hipEventRecord(e0, st));
+        // enough (sample block, transcript chunk) waves to fill 256 CUs several times over
+        const int sblocks = rsem::ceil_div(nS, 64);
+        int nchunks = std::max(1, std::min<int>(M, (256 * 4 * 8 + sblocks - 1) / sblocks));
+        const int chunk = (M + nchunks - 1) / nchunks;
+        nchunks = (M + chunk - 1) / chunk;
+        Philox ph{(uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x52534349u};  // 'RSCI'
+        hipLaunchKernelGGL(k_ci_draw, dim3(sblocks, nchunks), dim3(64), 0, st, M, nS, nSpC, chunk, d_cv, d_w, d_eel, pseudoC, ph, d_Y,
+                           d_T, d_L);
+        hipLaunchKernelGGL(k_ci_scales, dim3(rsem::ceil_div(nS, kBlock)), dim3(kBlock), 0, st, nS, d_T, d_L, d_sc, d_lbar);
+        RSEM_HIP_TRY(hipEventRecord(e1, st));
+        RSEM_HIP_TRY(hipStreamSynchronize(st));
+        RSEM_HIP_TRY(hipGetLastError());
+        float ms = 0;
+        RSEM_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        sample_ms = ms;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        return RSEM_OK;
+    }
+};
+
+int check_common(int32_t M, int32_t nCV, int32_t nSpC) {
+    RSEM_REQUIRE(M > 0 && nCV > 0 && nSpC > 0, "M, nCV and nSpC must be positive");
+    RSEM_REQUIRE((int64_t)nCV * nSpC < ((int64_t)1 << 30), "nCV * nSpC too large");
+    return RSEM_OK;
+}
+
+}  // namespace
+
+extern "C" int rsem_ci_intervals(int device, int64_t nrows, int32_t nSamples, const float* rows, double confidence, float* lb,
+                                 float* ub, float* cqv) {
+    RSEM_REQUIRE(nrows >= 0 && nSamples > 0 && rows && lb && ub && cqv, "bad arguments");
+    RSEM_REQUIRE(confidence > 0.0 && confidence <= 1.0, "confidence must be in (0, 1]");
+    RSEM_HIP_TRY(hipSetDevice(device));
+    hipStream_t st;
+    RSEM_HIP_TRY(hipStreamCreate(&st));
+    int rc = RSEM_OK;
+    {
+        const int64_t R = batch_rows(nSamples, std::max<int64_t>(nrows, 1));
+        RowSorter sorter;
+        DevMem mem;
+        float* d_keys = nullptr;
+        rc = sorter.init(nSamples, R, st);
+        if (rc == RSEM_OK && mem.alloc(&d_keys, (size_t)R * nSamples) != hipSuccess) { rsem::set_last_error("out of device memory"); rc = RSEM_ERR_NOMEM; }
+        for (int64_t r0 = 0; rc == RSEM_OK && r0 < nrows; r0 += R) {
+            const int64_t n = std::min(R, nrows - r0);
+            if (hipMemcpyAsync(d_keys, rows + (size_t)r0 * nSamples, sizeof(float) * (size_t)n * nSamples, hipMemcpyHostToDevice, st) != hipSuccess) {
+                rsem::set_last_error("upload failed"); rc = RSEM_ERR_HIP; break;
+            }
+            rc = sorter.run(d_keys, n, confidence, lb + r0, ub + r0, cqv + r0);
+        }
+    }
+    (void)hipStreamDestroy(st);
+    return rc;
+}
+
+extern "C" int rsem_ci_sample(int device, int32_t M, int32_t nCV, int32_t nSpC, const int32_t* cvecs, const double* eel,
+                              const double* mw, double pseudoC, uint64_t seed, float* tpm_samples, float* l_bars) {
+    int rc = check_common(M, nCV, nSpC);
+    if (rc != RSEM_OK) return rc;
+    RSEM_REQUIRE(cvecs && eel && mw && tpm_samples && l_bars, "null argument");
+    RSEM_HIP_TRY(hipSetDevice(device));
+    hipStream_t st;
+    RSEM_HIP_TRY(hipStreamCreate(&st));
+    const int32_t nS = nCV * nSpC;
+    {
+        Sampler S;
+        rc = S.run(M, nCV, nSpC, cvecs, eel, mw, pseudoC, seed, st);
+        if (rc == RSEM_OK) {
+            hipLaunchKernelGGL(k_ci_finish_rows, dim3(rsem::ceil_div((uint64_t)M * nS, kBlock)), dim3(kBlock), 0, st, nS, (int64_t)M, S.d_Y, S.d_sc);
+            if (hipMemcpyAsync(tpm_samples, S.d_Y, sizeof(float) * (size_t)M * nS, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(l_bars, S.d_lbar, sizeof(float) * nS, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) {
+                rsem::set_last_error("download failed"); rc = RSEM_ERR_HIP;
+            }
+        }
+    }
+    (void)hipStreamDestroy(st);
+    return rc;
+}
+
+extern "C" int rsem_ci_calculate(int device, int32_t M, int32_t nCV, int32_t nSpC, const int32_t* cvecs, const double* eel,
+                                 const double* mw, double pseudoC, uint64_t seed, double confidence, int32_t m,
+                                 const int32_t* gene_starts, int32_t m_trans, const int32_t* trans_starts, float* tpm_ci,
+                                 float* fpkm_ci, float* gene_tpm_ci, float* gene_fpkm_ci, float* iso_tpm_ci, float* iso_fpkm_ci,
+                                 rsem_ci_profile* prof) {
+    int rc = check_common(M, nCV, nSpC);
+    if (rc != RSEM_OK) return rc;
+    RSEM_REQUIRE(cvecs && eel && mw && gene_starts && tpm_ci && fpkm_ci && gene_tpm_ci && gene_fpkm_ci, "null argument");
+    RSEM_REQUIRE(m > 0 && gene_starts[0] == 1 && gene_starts[m] == M + 1, "gene_starts must run from 1 to M+1");
+    RSEM_REQUIRE(confidence > 0.0 && confidence <= 1.0, "confidence must be in (0, 1]");
+    const bool allele = trans_starts != nullptr;
+    if (allele) RSEM_REQUIRE(m_trans > 0 && iso_tpm_ci && iso_fpkm_ci && trans_starts[0] == 1 && trans_starts[m_trans] == M + 1, "bad trans_starts");
+    RSEM_HIP_TRY(hipSetDevice(device));
+    hipStream_t st;
+    RSEM_HIP_TRY(hipStreamCreate(&st));
+    const int32_t nS = nCV * nSpC;
+    hipEvent_t t0, t1;
+    RSEM_HIP_TRY(hipEventCreate(&t0)); RSEM_HIP_TRY(hipEventCreate(&t1));
+    RSEM_HIP_TRY(hipEventRecord(t0, st));
+    {
+        Sampler S;
+        RowSorter sorter;
+        DevMem mem;
+        float* d_keys = nullptr;
+        int32_t *d_gb = nullptr, *d_ge = nullptr;
+        const int64_t R = batch_rows(nS, M);
+        rc = S.run(M, nCV, nSpC, cvecs, eel, mw, pseudoC, seed, st);
+        if (rc == RSEM_OK) rc = sorter.init(nS, R, st);
+        if (rc == RSEM_OK && (mem.alloc(&d_keys, (size_t)R * nS) != hipSuccess || mem.alloc(&d_gb, (size_t)R) != hipSuccess ||
+                              mem.alloc(&d_ge, (size_t)R) != hipSuccess)) {
+            rsem::set_last_error("out of device memory"); rc = RSEM_ERR_NOMEM;
+        }
+        // per transcript (calcCI.cpp:343-354)
+        for (int pass = 0; rc == RSEM_OK && pass < 2; pass++) {
+            float* out = pass ? fpkm_ci : tpm_ci;
+            for (int64_t r0 = 0; rc == RSEM_OK && r0 < M; r0 += R) {
+                const int64_t n = std::min<int64_t>(R, M - r0);
+                hipLaunchKernelGGL(k_ci_keys_rows, dim3(rsem::ceil_div((uint64_t)n * nS, kBlock)), dim3(kBlock), 0, st, nS, S.d_Y, S.d_sc,
+                                   S.d_lbar, r0, n, pass == 1, d_keys);
+                rc = sorter.run(d_keys, n, confidence, out + r0, out + (size_t)M + r0, out + 2 * (size_t)M + r0);
+            }
+        }
+        // groups: genes, and transcripts of an allele-specific reference.  Single-member groups copy their member's
+        // interval (calcCI.cpp:356-363, 330-337); the others sort the float sums of their members' rows.
+        auto groups = [&](int32_t ng, const int32_t* starts, float* out_t, float* out_f) -> int {
+            std::vector<int32_t> multi;
+            for (int g = 0; g < ng; g++) {
+                const int b = starts[g], e = starts[g + 1];
+                if (e - b > 1) multi.push_back(g);
+                else if (e - b == 1)
+                    for (int k = 0; k < 3; k++) {
+                        out_t[(size_t)k * ng + g] = tpm_ci[(size_t)k * M + b - 1];
+                        out_f[(size_t)k * ng + g] = fpkm_ci[(size_t)k * M + b - 1];
+                    }
+                else
+                    for (int k = 0; k < 3; k++) out_t[(size_t)k * ng + g] = out_f[(size_t)k * ng + g] = 0.0f;
+            }
+            std::vector<int32_t> gb, ge;
+            std::vector<float> lb, ub, cq;
+            for (size_t i0 = 0; i0 < multi.size(); i0 += (size_t)R) {
+                const size_t n = std::min<size_t>((size_t)R, multi.size() - i0);
+                gb.resize(n); ge.resize(n); lb.resize(n); ub.resize(n); cq.resize(n);
+                for (size_t i = 0; i < n; i++) { gb[i] = starts[multi[i0 + i]]; ge[i] = starts[multi[i0 + i] + 1]; }
+                RSEM_HIP_TRY(hipMemcpyAsync(d_gb, gb.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+                RSEM_HIP_TRY(hipMemcpyAsync(d_ge, ge.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+                for (int pass = 0; pass < 2; pass++) {
+                    hipLaunchKernelGGL(k_ci_keys_groups, dim3(rsem::ceil_div((uint64_t)n * nS, kBlock)), dim3(kBlock), 0, st, nS, S.d_Y, S.d_sc,
+                                       S.d_lbar, d_gb, d_ge, (int64_t)n, pass == 1, d_keys);
+                    int r = sorter.run(d_keys, (int64_t)n, confidence, lb.data(), ub.data(), cq.data());
+                    if (r != RSEM_OK) return r;
+                    float* out = pass ? out_f : out_t;
+                    for (size_t i = 0; i < n; i++) {
+                        const int g = multi[i0 + i];
+                        out[g] = lb[i]; out[(size_t)ng + g] = ub[i]; out[2 * (size_t)ng + g] = cq[i];
+                    }
+                }
+            }
+            return RSEM_OK;
+        };
+        if (rc == RSEM_OK) rc = groups(m, gene_starts, gene_tpm_ci, gene_fpkm_ci);
+        if (rc == RSEM_OK && allele) rc = groups(m_trans, trans_starts, iso_tpm_ci, iso_fpkm_ci);
+        if (rc == RSEM_OK) {
+            hipError_t e = hipEventRecord(t1, st);
+            if (e == hipSuccess) e = hipEventSynchronize(t1);
+            float ms = 0;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, t0, t1);
+            if (e != hipSuccess) { rsem::set_last_error("event timing failed"); rc = RSEM_ERR_HIP; }
+            if (prof) {
+                prof->sample_ms = S.sample_ms; prof->sort_ms = sorter.sort_ms; prof->interval_ms = sorter.interval_ms; prof->total_ms = ms;
+                prof->n_draws = (uint64_t)M * nS; prof->n_keys_sorted = sorter.n_keys;
+            }
+        }
+    }
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    (void)hipStreamDestroy(st);
+    return rc;
+}

@@ -1,0 +1,165 @@
+"""Credibility intervals on the GPU (rsem_amd/csrc/ci.hip) against the oracle and the reference's golden rows.
+
+* interval stage: bit-exact with orc_calc_ci (itself pinned on the reference's sample matrices, test_ci_cpu.py);
+* sampling stage: identities that hold per draw (TPM sums to 1e6, l_bar = sum tpm*eel/1e6, omitted transcripts are 0)
+  and the distribution against a CPU Monte-Carlo of the same posterior through the oracle's transform;
+* the whole calculation against tests/golden/<fx>/ci_stat (reference binary, 20 000 samples): different random
+  streams, so the tolerance is Monte-Carlo: a few standard errors of the interval end points.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from rsem_amd import capi
+from tests import rsem_files as rf
+from tests.test_ci_cpu import CI_FIXTURES, load_pin
+
+pytestmark = pytest.mark.gpu
+
+
+def fixture_inputs(name):
+    fx = rf.fixture(name)
+    full, tot = rf.read_seq_lens(os.path.join(fx, "ref.seq"))
+    M = len(full) - 1
+    model = rf.read_model(os.path.join(fx, "stat", "s.model"))
+    eel = orc.calc_eel(M, full, tot, model["gld"])
+    mw = model["mw"]
+    meta = rf.read_meta(fx)
+    cv = np.concatenate([rf.read_countvectors(os.path.join(fx, "temp", "s.countvectors%d" % k)) for k in range(int(meta["gibbs_threads"]))])
+    pseudoC = meta.get("pseudo_count_x1000", 1000) / 1000.0
+    grp = rf.read_grp(os.path.join(fx, "ref.grp"))
+    ta = rf.read_grp(os.path.join(fx, "ref.ta")) if os.path.exists(os.path.join(fx, "ref.ta")) else None
+    return fx, M, cv, eel, mw, pseudoC, grp, ta
+
+
+@pytest.mark.parametrize("name", CI_FIXTURES)
+def test_intervals_bit_exact_on_reference_rows(name):
+    fx, M, S, rows = load_pin(name)
+    lb, ub, cqv = capi.ci_intervals(S, 0.95)
+    for j in range(M):
+        o = orc.calc_ci(S[j], 0.95)
+        assert (lb[j], ub[j], cqv[j]) == o, j
+    per_target = rows["allele_res"] if "allele_res" in rows else rows["iso_res"]
+    assert ["%.6g" % v for v in lb] == per_target[0] and ["%.6g" % v for v in ub] == per_target[1]
+    assert ["%.6g" % v for v in cqv] == per_target[2]
+
+
+@pytest.mark.parametrize("n,conf", [(1, 0.95), (2, 0.95), (4, 0.5), (5, 0.95), (6, 0.9), (7, 0.95), (400, 0.95), (2000, 0.99), (50000, 0.95)])
+def test_intervals_bit_exact_random_rows(n, conf):
+    rng = np.random.default_rng(n)
+    rows = rng.gamma(0.7, 3.0, size=(37, n)).astype(np.float32)
+    rows[3] = 0.0                                   # all ties
+    rows[4, : n // 2] = 0.0                          # half zeros
+    rows[5] = np.round(rows[5])                      # many ties
+    rows[6] = rows[6, 0]
+    lb, ub, cqv = capi.ci_intervals(rows, conf)
+    for r in range(rows.shape[0]):
+        assert (lb[r], ub[r], cqv[r]) == orc.calc_ci(rows[r], conf), r
+
+
+def test_sampler_identities_and_distribution():
+    fx, M, cv, eel, mw, pseudoC, grp, ta = fixture_inputs("se_q_polya_rspd")
+    nSpC = 200
+    tpm, lbar = capi.ci_sample(cv, nSpC, eel, mw, pseudoC, seed=5)
+    nS = cv.shape[0] * nSpC
+    assert tpm.shape == (M, nS)
+    np.testing.assert_allclose(tpm.sum(axis=0, dtype=np.float64), 1e6, rtol=2e-6)
+    np.testing.assert_allclose((tpm.astype(np.float64) * eel[1:, None]).sum(axis=0) / 1e6, lbar, rtol=1e-5)
+    dead = [j for j in range(1, M + 1) if cv[0, j] < 0 or eel[j] < 1e-300 or mw[j] < 1e-300]
+    for j in dead:
+        assert not tpm[j - 1].any()
+    assert (tpm >= 0).all()
+    # same seed -> same draws; other seed -> different
+    tpm2, _ = capi.ci_sample(cv, nSpC, eel, mw, pseudoC, seed=5)
+    assert np.array_equal(tpm, tpm2)
+    tpm3, _ = capi.ci_sample(cv, nSpC, eel, mw, pseudoC, seed=6)
+    assert not np.array_equal(tpm, tpm3)
+    # CPU Monte-Carlo of the same posterior through the oracle's transform (calcCI.cpp:129-149)
+    rng = np.random.default_rng(99)
+    ref = np.zeros((M, nS), np.float32)
+    k = 0
+    for c in cv:
+        shape = np.where(c >= 0, c + pseudoC, 1.0)
+        for _ in range(nSpC):
+            t, lb_ = orc.ci_transform(rng.gamma(shape), c, eel, mw)
+            ref[:, k] = t[1:]
+            k += 1
+    mu_g, mu_r = tpm.mean(axis=1, dtype=np.float64), ref.mean(axis=1, dtype=np.float64)
+    sd = ref.std(axis=1, dtype=np.float64)
+    se = np.sqrt(2.0) * sd / np.sqrt(nS) * 8.0 + 1e-9  # both are Monte-Carlo; count vectors are shared, so this is generous
+    assert (np.abs(mu_g - mu_r) <= 6 * se + 1e-6 * mu_r).all(), np.max(np.abs(mu_g - mu_r) / (se + 1e-30))
+    for q in (0.05, 0.5, 0.95):
+        a, b = np.quantile(tpm, q, axis=1), np.quantile(ref, q, axis=1)
+        assert (np.abs(a - b) <= 0.08 * (np.quantile(ref, 0.975, axis=1) - np.quantile(ref, 0.025, axis=1)) + 1e-6).all(), q
+
+
+def golden_rows(fx, which):
+    f = os.path.join(fx, "ci_stat", which + ".txt")
+    return np.array([[float(x) for x in l.split("\t")] for l in open(f).read().strip().split("\n")])
+
+
+@pytest.mark.parametrize("name", CI_FIXTURES)
+def test_calculate_matches_reference_statistically(name):
+    fx, M, cv, eel, mw, pseudoC, grp, ta = fixture_inputs(name)
+    out = capi.ci_calculate(cv, 500, eel, mw, grp, 0.95, pseudoC, seed=2024, trans_starts=ta)
+    per_target = golden_rows(fx, "allele_res" if ta is not None else "iso_res")
+    gene = golden_rows(fx, "gene_res")
+
+    def close(got, ref, what):
+        # rows: lb ub cqv (TPM) lb ub cqv (FPKM).  End points within 10% of the interval width (Monte-Carlo error of a
+        # 2.5% tail quantile from 20 000 draws is ~1-2% of the width; the shortest-interval search adds some);
+        # cqv within 0.02 absolute.
+        for k in (0, 3):
+            width = ref[k + 1] - ref[k]
+            tol = 0.10 * width + 1e-3 * np.abs(ref[k + 1]) + 1e-6
+            assert (np.abs(got[k] - ref[k]) <= tol).all(), (what, k, np.max(np.abs(got[k] - ref[k]) / tol))
+            assert (np.abs(got[k + 1] - ref[k + 1]) <= tol).all(), (what, k + 1, np.max(np.abs(got[k + 1] - ref[k + 1]) / tol))
+            assert (np.abs(got[k + 2] - ref[k + 2]) <= 0.02).all(), (what, k + 2)
+
+    close(np.vstack([out["tpm"], out["fpkm"]]), per_target, "target")
+    close(np.vstack([out["gene_tpm"], out["gene_fpkm"]]), gene, "gene")
+    # single-isoform genes copy their transcript's interval (calcCI.cpp:356-363)
+    for g in range(len(grp) - 1):
+        if grp[g + 1] - grp[g] == 1:
+            assert np.array_equal(out["gene_tpm"][:, g], out["tpm"][:, grp[g] - 1])
+            assert np.array_equal(out["gene_fpkm"][:, g], out["fpkm"][:, grp[g] - 1])
+    if ta is not None:
+        # the reference's isoform-level rows of an allele-specific run carry its accumulator quirk (test_ci_cpu.py);
+        # the drop-in sums each transcript's alleles afresh, so compare against sums built from its own samples
+        tpm, lbar = capi.ci_sample(cv, 500, eel, mw, pseudoC, seed=2024)
+        for t in range(len(ta) - 1):
+            b, e = ta[t], ta[t + 1]
+            if e - b == 1:
+                assert np.array_equal(out["iso_tpm"][:, t], out["tpm"][:, b - 1])
+                continue
+            acc = np.zeros(tpm.shape[1], np.float32)
+            for j in range(b, e):
+                acc = (acc + tpm[j - 1]).astype(np.float32)
+            assert tuple(out["iso_tpm"][:, t]) == orc.calc_ci(acc, 0.95), t
+    p = out["profile"]
+    assert p.n_draws == M * cv.shape[0] * 500 and p.total_ms > 0
+
+
+def test_calculate_consistent_with_own_samples():
+    """rsem_ci_calculate == interval stage applied to rsem_ci_sample's rows (same seed): ties the two entry points."""
+    fx, M, cv, eel, mw, pseudoC, grp, ta = fixture_inputs("pe_q")
+    out = capi.ci_calculate(cv, 50, eel, mw, grp, 0.9, pseudoC, seed=31)
+    tpm, lbar = capi.ci_sample(cv, 50, eel, mw, pseudoC, seed=31)
+    for j in range(M):
+        assert tuple(out["tpm"][:, j]) == orc.calc_ci(tpm[j], 0.9), j
+        f = (1e3 / lbar.astype(np.float64) * tpm[j]).astype(np.float32)
+        assert tuple(out["fpkm"][:, j]) == orc.calc_ci(f, 0.9), j
+    for g in range(len(grp) - 1):
+        b, e = grp[g], grp[g + 1]
+        if e - b > 1:
+            acc = np.zeros(tpm.shape[1], np.float32)
+            for j in range(b, e):
+                acc = (acc + tpm[j - 1]).astype(np.float32)
+            assert tuple(out["gene_tpm"][:, g]) == orc.calc_ci(acc, 0.9), g
+
+
+def test_bad_arguments():
+    with pytest.raises(capi.RsemHipError):
+        capi.ci_intervals(np.zeros((2, 5), np.float32), 1.5)

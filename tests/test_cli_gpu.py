@@ -220,3 +220,47 @@ def test_transcript_bam_matches_reference(name, tmp_path):
     _assert_bam_equal(os.path.join(dst, "s.transcript.bam"), os.path.join(fx, "golden.transcript.bam"))
     _run([os.path.join(BIN, "rsem-run-em")] + args + ["-b", os.path.join(fx, "golden.transcript.bam"), "0", "--sampling", "--seed", "77"])
     _assert_bam_equal(os.path.join(dst, "s.transcript.bam"), os.path.join(fx, "golden.sampled.transcript.bam"))
+
+
+@pytest.mark.parametrize("name", ["se_noq", "se_q", "pe_q", "se_q_polya_rspd", "se_q_allele"])
+def test_rsem_calculate_credibility_intervals_cli(name, tmp_path):
+    """Drop-in rsem-calculate-credibility-intervals on the fixture's own count vectors: six "%.6g" rows appended to
+    every result file, statistically equal to the rows the reference binary appended (ci_stat golden, same argv;
+    tolerances as tests/test_ci_gpu.py), nothing else in the files touched, no imd.tmp left behind."""
+    fx, dst = _stage(name, tmp_path)
+    meta = rf.read_meta(fx)
+    nCV = int(meta["gibbs"][1])
+    threads = int(meta["gibbs_threads"])
+    pc = meta.get("pseudo_count_x1000", 1000) / 1000.0
+    imd = os.path.join(dst, "temp", "s")
+    res_files = [f for f in ("iso_res", "gene_res", "allele_res") if os.path.exists(imd + "." + f)]
+    before = {f: open(imd + "." + f).read() for f in res_files}
+    cmd = [os.path.join(BIN, "rsem-calculate-credibility-intervals"), os.path.join(dst, "ref"), imd, os.path.join(dst, "stat", "s"),
+           "0.95", str(nCV), "500", "1024", "-p", str(threads), "--seed", "777", "-q"]
+    if pc != 1.0:
+        cmd += ["--pseudo-count", str(pc)]
+    _run(cmd)
+    assert not os.path.exists(imd + ".tmp")
+    for f in res_files:
+        after = open(imd + "." + f).read()
+        assert after.startswith(before[f])
+        new = after[len(before[f]):].strip("\n").split("\n")
+        assert len(new) == 6
+        got = np.array([[float(x) for x in l.split("\t")] for l in new])
+        for l in new:  # "%.6g"
+            assert all(("%.6g" % float(x)) == x for x in l.split("\t"))
+        ref = np.array([[float(x) for x in l.split("\t")] for l in open(os.path.join(fx, "ci_stat", f + ".txt")).read().strip().split("\n")])
+        assert got.shape == ref.shape
+        if f == "iso_res" and "allele_res" in res_files:
+            continue  # the reference's rows here carry its accumulator quirk (tests/test_ci_cpu.py)
+        for k in (0, 3):
+            tol = 0.10 * (ref[k + 1] - ref[k]) + 1e-3 * np.abs(ref[k + 1]) + 1e-6
+            assert (np.abs(got[k] - ref[k]) <= tol).all() and (np.abs(got[k + 1] - ref[k + 1]) <= tol).all(), (f, k)
+            assert (np.abs(got[k + 2] - ref[k + 2]) <= 0.02).all(), (f, k)
+    # same seed -> same rows
+    first = {f: open(imd + "." + f).read() for f in res_files}
+    for f in res_files:
+        open(imd + "." + f, "w").write(before[f])
+    _run(cmd)
+    for f in res_files:
+        assert open(imd + "." + f).read() == first[f]
