@@ -6,6 +6,7 @@
 //
 // -p N keeps its meaning "N independent chains, N count-vector files" (Gibbs.cpp:211-226, calcCI opens one
 // file per thread); the chains run on the available GPUs through librsem_hip (include/rsem_hip.h).
+#include <charconv>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -153,10 +154,18 @@ int main(int argc, char* argv[]) {
                 // writeCountVector (Gibbs.cpp:257-262): one file per chain
                 FILE* fo = fopen((imdName + ".countvectors" + std::to_string(k)).c_str(), "w");
                 if (!fo) { errors[w] = "cannot write count vectors"; break; }
+                std::string line;
+                line.reserve((size_t)(M + 1) * 8);
+                char tmp[16];
                 for (int s = 0; s < ns; s++) {
                     const int32_t* c = cv.data() + (size_t)s * (M + 1);
-                    for (int i = 0; i < M; i++) fprintf(fo, "%d ", c[i]);
-                    fprintf(fo, "%d\n", c[M]);
+                    line.clear();
+                    for (int i = 0; i <= M; i++) {
+                        auto r = std::to_chars(tmp, tmp + sizeof(tmp), c[i]);
+                        line.append(tmp, r.ptr - tmp);
+                        line.push_back(i < M ? ' ' : '\n');
+                    }
+                    fwrite(line.data(), 1, line.size(), fo);
                 }
                 fclose(fo);
                 if (verbose) printf("Chain %d is finished!\n", k);
