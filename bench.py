@@ -110,6 +110,28 @@ def cpu_baseline_reference(n_reads=1_000_000, M=20_000, limit_s=150.0):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def ci_leg(capi, M, nCV=1000, nSpC=50):
+    """rsem-calculate-credibility-intervals at the workload's M with rsem-calculate-expression's defaults
+    (1000 count vectors x 50 draws): synthetic count vectors, device-side times from rsem_ci_profile."""
+    try:
+        rng = np.random.default_rng(3)
+        mean = np.exp(rng.normal(3.0, 2.5, M + 1)) * (rng.random(M + 1) > 0.3)
+        cv = rng.poisson(mean, size=(nCV, M + 1)).astype(np.int32)
+        eel = np.concatenate([[0.0], rng.uniform(300, 4000, M)])
+        starts = np.arange(1, M + 2, 5, dtype=np.int32)
+        if starts[-1] != M + 1:
+            starts = np.append(starts, M + 1).astype(np.int32)
+        t0 = time.perf_counter()
+        out = capi.ci_calculate(cv, nSpC, eel, np.ones(M + 1), starts, 0.95, 1.0, seed=1)
+        wall = time.perf_counter() - t0
+        p = out["profile"]
+        return {"transcripts": M, "samples": nCV * nSpC, "wall_s": wall, "device_ms": p.total_ms,
+                "gamma_draws_per_s": p.n_draws / p.sample_ms * 1e3, "keys_sorted_per_s": p.n_keys_sorted / p.sort_ms * 1e3,
+                "interval_ms": p.interval_ms}
+    except Exception as e:
+        return {"error": str(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +142,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gibbs", action="store_true")
+    ap.add_argument("--no-ci", action="store_true")
     ap.add_argument("--gibbs-sweeps", type=int, default=30)
     args = ap.parse_args()
 
@@ -263,7 +286,9 @@ def main():
             "checks": {"theta_sum": theta_sum},
             "gibbs": gibbs,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_ci and world == 1:
+            line["credibility_intervals"] = ci_leg(capi, M)
+        if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N=1 only
             cb = cpu_baseline_reference()
             if cb is None:
                 cb = cpu_baseline_port(wl)
