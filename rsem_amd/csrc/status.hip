@@ -43,4 +43,10 @@ int rsem_hip_device_count(int* n) {
     return RSEM_OK;
 }
 
+int rsem_hip_warmup(int device) {
+    RSEM_HIP_TRY(hipSetDevice(device));
+    RSEM_HIP_TRY(hipFree(nullptr));
+    return RSEM_OK;
+}
+
 }  // extern "C"
