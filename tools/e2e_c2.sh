@@ -11,7 +11,7 @@ grep ROUND gpurun_out/e2e_new_$RT.log | tail -1
 if [ "$4" == "ref" ]; then
   cp $D/stat/s.theta gpurun_out/e2e_new_$RT.theta
   if [ "$RT" == "1" ]; then oracle/_ref/rsem-build-read-index 32 1 1 $D/temp/s_alignable.fq > /dev/null; else oracle/_ref/rsem-build-read-index 32 1 1 $D/temp/s_alignable_1.fq $D/temp/s_alignable_2.fq > /dev/null; fi
-  ( time timeout 3000 oracle/_ref/rsem-run-em $D/ref $RT $D/s $D/temp/s $D/stat/s -p 64 --gibbs-out ) > gpurun_out/e2e_ref_$RT.log 2>&1 || true
+  ( time timeout 3000 oracle/_ref/rsem-run-em $D/ref $RT $D/s $D/temp/s $D/stat/s -p ${REF_P:-64} --gibbs-out ) > gpurun_out/e2e_ref_$RT.log 2>&1 || true
   grep -E "ROUND|real" gpurun_out/e2e_ref_$RT.log | tail -3
   python - <<PY
 import numpy as np
