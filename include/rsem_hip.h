@@ -64,6 +64,9 @@ int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64
 /* Replace the CSR values (hit.setConPrb / ncpv[i], EM.cpp:210,216) in the caller's (file) order. */
 int rsem_em_set_values(rsem_em_ctx* ctx, const double* conprb, const double* ncp);
 int rsem_em_set_option(rsem_em_ctx* ctx, const char* key, int64_t value);
+/* Tuning aid (not part of the reference's surface): one E-step launch of the LANE kernel with per-workgroup start/end
+ * timestamps (100 MHz clock), out[2u], out[2u+1] in dispatch order; *n_units_io = capacity in, units written out. */
+int rsem_em_debug_trace(rsem_em_ctx* ctx, const double* theta, unsigned long long* out, uint32_t* n_units_io);
 int rsem_em_destroy(rsem_em_ctx* ctx);
 
 /* One E step + M step.  theta[M+1] in; counts[M+1] out = fractional counts incl. +N0 in bin 0

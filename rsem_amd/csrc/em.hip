@@ -192,6 +192,16 @@ __global__ __launch_bounds__(kBlock) void k_estep_sell(
 // and adds the normalised fractions into registers; on a change it spills its registers to the
 // LDS window and reloads sid / theta for the new tuple.  The loads of slice s+1 are issued before
 // slice s is reduced (software pipeline, static instruction stream per K).
+// theta[base, base+span) -> LDS, count window zeroed; every wave of the workgroup calls this exactly once
+__device__ inline void stage_windows(int base, int span, int M, const double* __restrict__ theta, double* th_win, double* cnt_win) {
+    for (int i = threadIdx.x; i < span; i += blockDim.x) {
+        const int sidv = base + i;
+        th_win[i] = (sidv >= 0 && sidv <= M) ? theta[sidv] : 0.0;
+        cnt_win[i] = 0.0;
+    }
+    __syncthreads();
+}
+
 template <int K>
 struct SliceRegs {
     int id[K];
@@ -201,10 +211,10 @@ struct SliceRegs {
 
 template <int K>
 __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
-                                   const double* __restrict__ theta, double th0, const double* th_win, double* cnt_win,
+                                   const double* __restrict__ theta, double th0, double* th_win, double* cnt_win,
                                    const double* __restrict__ scp, const int32_t* __restrict__ ssid,
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
-                                   double* counts, double& noise) {
+                                   double* counts, double& noise, int M) {
     const int lg = S.lg;
     const int g = lane & ((1 << lg) - 1);
     const bool g0 = (g == 0);
@@ -282,6 +292,7 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
     SliceRegs<K> A, B;
     unsigned long long mA = ~0ull, mB = 0;  // a block always starts fresh
     issue(s_begin, mA, A);
+    stage_windows(base, span, M, theta, th_win, cnt_win);  // the first slice's loads fly while the windows are staged
     for (uint32_t s = s_begin; s < s_end; s += 2) {
         if (s + 1 < s_end) {
             mB = mask_of(s + 1);
@@ -302,42 +313,35 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
     const Shape* __restrict__ shapes, const Unit* __restrict__ units, uint32_t T, int M,
     const double* __restrict__ theta, const double* __restrict__ scp, const int32_t* __restrict__ ssid,
     const double* __restrict__ sncp, const unsigned long long* __restrict__ masks, double* counts,
-    double* noise_partial, const Ctrl* ctrl) {
+    double* noise_partial, const Ctrl* ctrl, unsigned long long* trace) {
     if (ctrl->done) return;
+    if (trace && threadIdx.x == 0) trace[2 * blockIdx.x] = wall_clock64();  // rsem_em_debug_trace only
     __shared__ double th_win[kWindow];
     __shared__ double cnt_win[kWindow];
-    __shared__ Shape sS;
     const Unit U = units[blockIdx.x];
-    if (threadIdx.x == 0) sS = shapes[U.shape];
-    for (int i = threadIdx.x; i < U.span; i += blockDim.x) {
-        const int sidv = U.base + i;
-        th_win[i] = (sidv >= 0 && sidv <= M) ? theta[sidv] : 0.0;
-        cnt_win[i] = 0.0;
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double noise = 0.0;
-    if (w < U.n_blocks) {
-        Shape S;  // wave-uniform copy in SGPRs
-        S.plane_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sS.plane_base >> 32)) << 32) |
-                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sS.plane_base);
-        S.slice_base = __builtin_amdgcn_readfirstlane(sS.slice_base);
-        S.n_slices = __builtin_amdgcn_readfirstlane(sS.n_slices);
+    {
+        const Shape& G = shapes[U.shape];  // uniform address: scalar loads
+        Shape S;
+        S.plane_base = G.plane_base;
+        S.slice_base = G.slice_base;
+        S.n_slices = G.n_slices;
         S.row_base = 0;
         S.n_rows = 0;
-        S.slot_base = __builtin_amdgcn_readfirstlane(sS.slot_base);
-        S.K = __builtin_amdgcn_readfirstlane(sS.K);
-        S.lg = __builtin_amdgcn_readfirstlane(sS.lg);
-        const uint32_t blk = U.block_begin + w;
-        const uint32_t s_begin = S.slice_base + blk * T;
-        const uint32_t s_end = min(S.slice_base + S.n_slices, s_begin + T);
+        S.slot_base = G.slot_base;
+        S.K = G.K;
+        S.lg = G.lg;
+        const uint32_t u_end = S.slice_base + U.slice_begin + U.n_slices;
+        const uint32_t s_begin = S.slice_base + U.slice_begin + (uint32_t)w * U.per_wave;
+        const uint32_t s_end = min(u_end, s_begin + U.per_wave);
         const double th0 = theta[0];
-        switch (S.K) {
-            case 1: estep_block<1>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
-            case 2: estep_block<2>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
-            case 3: estep_block<3>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
-            default: estep_block<4>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise); break;
-        }
+        if (s_begin < u_end) switch (S.K) {
+            case 1: estep_block<1>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, M); break;
+            case 2: estep_block<2>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, M); break;
+            case 3: estep_block<3>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, M); break;
+            default: estep_block<4>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, M); break;
+        } else stage_windows(U.base, U.span, M, theta, th_win, cnt_win);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < U.span; i += blockDim.x) {
@@ -345,6 +349,7 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
         if (v != 0.0) unsafeAtomicAdd(&counts[U.base + i], v);
     }
     block_store_partial(noise, noise_partial);
+    if (trace && threadIdx.x == 0) trace[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 // ---- M step ----------------------------------------------------------------------------------
@@ -564,6 +569,7 @@ struct rsem_em_ctx {
     double* d_sncp = nullptr;
     // LANE variant work list
     Unit* d_units = nullptr;
+    unsigned long long* d_trace = nullptr;  // rsem_em_debug_trace only
     uint32_t n_units = 0;
     int noise_n = 0;  // workgroups of the last main E-step launch (= valid entries of d_noise_a)
     size_t noise_cap = 0;
@@ -606,7 +612,7 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
     if (kern == RSEM_EM_KERNEL_LANE) {
         if (c->n_units)
             hipLaunchKernelGGL(k_estep_lane, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
-                               d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, ctrl);
+                               d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, ctrl, c->d_trace);
     } else {
         hipLaunchKernelGGL(k_estep_sell, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
                            c->L.n_slices, d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, d_counts, c->d_noise_a, ctrl);
@@ -774,6 +780,33 @@ int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
     }
     rsem::set_last_error("unknown option '%s'", key);
     return RSEM_ERR_INVALID;
+}
+
+// Tuning aid: one E-step launch with per-workgroup start / end timestamps (100 MHz wall clock): out[2u], out[2u+1] for
+// unit u in dispatch order; *n_units_io in: capacity (units), out: units written.
+int rsem_em_debug_trace(rsem_em_ctx* c, const double* theta, unsigned long long* out, uint32_t* n_units_io) {
+    RSEM_REQUIRE(c && theta && out && n_units_io, "NULL argument");
+    RSEM_REQUIRE(resolved_kernel(c) == RSEM_EM_KERNEL_LANE && c->have_values, "needs the LANE kernel with values set");
+    RSEM_REQUIRE(*n_units_io >= c->n_units, "trace buffer too small");
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    unsigned long long* d = nullptr;
+    RSEM_HIP_TRY(hipMalloc((void**)&d, sizeof(unsigned long long) * 2 * std::max<uint32_t>(c->n_units, 1)));
+    RSEM_HIP_TRY(hipMemcpyAsync(c->d_theta[0], theta, sizeof(double) * ((size_t)c->M + 1), hipMemcpyHostToDevice, c->stream));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), c->stream));
+    int rc = RSEM_OK;
+    for (int rep = 0; rep < 3 && rc == RSEM_OK; rep++) {  // the last repetition is the one reported (caches warm)
+        c->d_trace = d;
+        rc = launch_estep(c, c->d_theta[0], c->d_counts, c->stream, true);
+        c->d_trace = nullptr;
+    }
+    hipError_t e = hipMemcpyAsync(out, d, sizeof(unsigned long long) * 2 * c->n_units, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipMemsetAsync(c->d_counts, 0, sizeof(double) * ((size_t)c->M + 1), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) { rsem::set_last_error("trace download failed"); return RSEM_ERR_HIP; }
+    *n_units_io = c->n_units;
+    return rc;
 }
 
 int rsem_em_destroy(rsem_em_ctx* c) {

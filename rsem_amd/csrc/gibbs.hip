@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void k_sample_z_lane(
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int noise = 0;
-    if (w < U.n_blocks) {
+    {
         Shape S;
         S.plane_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sS.plane_base >> 32)) << 32) |
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sS.plane_base);
@@ -220,11 +220,11 @@ __global__ __launch_bounds__(kBlock) void k_sample_z_lane(
         S.slot_base = __builtin_amdgcn_readfirstlane(sS.slot_base);
         S.K = __builtin_amdgcn_readfirstlane(sS.K);
         S.lg = __builtin_amdgcn_readfirstlane(sS.lg);
-        const uint32_t blk = U.block_begin + w;
-        const uint32_t s_begin = S.slice_base + blk * T;
-        const uint32_t s_end = min(S.slice_base + S.n_slices, s_begin + T);
+        const uint32_t u_end = S.slice_base + U.slice_begin + U.n_slices;
+        const uint32_t s_begin = S.slice_base + U.slice_begin + (uint32_t)w * U.per_wave;
+        const uint32_t s_end = min(u_end, s_begin + U.per_wave);
         const double g0 = g[0];
-        switch (S.K) {
+        if (s_begin < u_end) switch (S.K) {
             case 1: gibbs_block<1>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
             case 2: gibbs_block<2>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
             case 3: gibbs_block<3>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;

@@ -323,15 +323,18 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     return RSEM_OK;
 }
 
-// One workgroup's work: up to 4 consecutive blocks (one per wave) of one shape, plus the base of its
-// LDS windows = the smallest sid any of its reads can touch.
+// One workgroup's work: a run of consecutive slices of one shape, `per_wave` of them for each of its 4 waves, plus
+// the base of its LDS windows = the smallest sid any of its reads can touch.  Most units are 4 whole blocks (one per
+// wave); the last part of every shape is cut into half- and quarter-size units so that the launch does not end with
+// a few long-lived workgroups (the tail of a launch costs about half a workgroup lifetime).
 struct Unit {
     int32_t shape;
-    uint32_t block_begin;  // block index within the shape
-    int32_t n_blocks;      // 1..4
+    uint32_t slice_begin;  // first slice, relative to the shape
+    uint32_t n_slices;
+    uint32_t per_wave;     // wave w walks slices [slice_begin + w * per_wave, + per_wave)
     int32_t base;
     int32_t span;          // sids [base, base + span) are staged in LDS (<= the window capacity)
-    int32_t pad[3];
+    int32_t pad[2];
 };
 
 inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units, int window_cap) {
@@ -340,29 +343,51 @@ inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units, int w
         RSEM_HIP_TRY(hipMemcpy(ms.data(), L.d_slice_minsid, sizeof(uint32_t) * L.n_slices, hipMemcpyDeviceToHost));
         RSEM_HIP_TRY(hipMemcpy(mx.data(), L.d_slice_maxsid, sizeof(uint32_t) * L.n_slices, hipMemcpyDeviceToHost));
     }
+    // fractions of a shape's blocks that go into full-size and half-size units (the rest: quarter-size)
+    double f_full = 1.0, f_half = 0.0;
+    if (const char* e = getenv("RSEM_HIP_TAPER")) {  // tuning knob: "full,half"
+        double a = 0, b = 0;
+        if (sscanf(e, "%lf,%lf", &a, &b) == 2 && a >= 0 && b >= 0 && a + b <= 1.0) { f_full = a; f_half = b; }
+    }
+    constexpr uint32_t W = 4;  // waves per workgroup
     units.clear();
+    auto add = [&](int sh, const Shape& S, uint32_t sl0, uint32_t n, uint32_t per_wave) {
+        Unit U;
+        U.shape = sh;
+        U.slice_begin = sl0;
+        U.n_slices = n;
+        U.per_wave = std::max<uint32_t>(per_wave, 1);
+        const uint32_t s0 = S.slice_base + sl0, s1 = s0 + n;
+        U.base = (int32_t)ms[s0];
+        uint32_t top = 0;
+        for (uint32_t t = s0; t < s1; t++) top = std::max(top, mx[t]);
+        const long long span = (long long)top - U.base + 1;
+        U.span = (int32_t)std::min<long long>(std::max<long long>(span, 1), window_cap);
+        U.pad[0] = U.pad[1] = 0;
+        units.push_back(U);
+    };
     for (int sh = 0; sh < L.n_shapes; sh++) {
         const Shape& S = L.h_shapes[sh];
-        const uint32_t nb = (S.n_slices + L.T - 1) / L.T;
-        for (uint32_t b = 0; b < nb; b += kBlock / 64) {
-            Unit U;
-            U.shape = sh;
-            U.block_begin = b;
-            U.n_blocks = (int32_t)std::min<uint32_t>(kBlock / 64, nb - b);
-            U.base = (int32_t)ms[S.slice_base + b * L.T];
-            const uint32_t s0 = S.slice_base + b * L.T;
-            const uint32_t s1 = std::min(S.slice_base + S.n_slices, s0 + (uint32_t)U.n_blocks * L.T);
-            uint32_t top = 0;
-            for (uint32_t t = s0; t < s1; t++) top = std::max(top, mx[t]);
-            long long span = (long long)top - U.base + 1;
-            U.span = (int32_t)std::min<long long>(std::max<long long>(span, 1), window_cap);
-            U.pad[0] = U.pad[1] = U.pad[2] = 0;
-            units.push_back(U);
-        }
+        const uint32_t T = L.T, nb = (S.n_slices + T - 1) / T;
+        // full units: 4 blocks; half units: 2 blocks (T/2 per wave); quarter units: 1 block (T/4 per wave)
+        uint32_t b_full = (uint32_t)(nb * f_full) / W * W;
+        uint32_t b_half = (uint32_t)(nb * f_half) / 2 * 2;
+        if (T < 4) { b_full = nb / W * W; b_half = 0; }
+        if (b_full + b_half > nb) b_half = (nb - b_full) / 2 * 2;
+        uint32_t b = 0;
+        auto emit = [&](uint32_t nblocks, uint32_t per_wave) {
+            const uint32_t sl0 = b * T, n = std::min(S.n_slices, (b + nblocks) * T) - sl0;
+            add(sh, S, sl0, n, per_wave);
+            b += nblocks;
+        };
+        while (b < b_full) emit(W, T);
+        while (b < b_full + b_half) emit(2, (T + 1) / 2);
+        if (T < 4) while (b < nb) emit(std::min<uint32_t>(W, nb - b), T);
+        else while (b < nb) emit(1, (T + 3) / 4);
     }
     // longest-processing-time-first: the hardware hands workgroups out in order
     std::stable_sort(units.begin(), units.end(), [&](const Unit& a, const Unit& b) {
-        return L.h_shapes[a.shape].K * a.n_blocks > L.h_shapes[b.shape].K * b.n_blocks;
+        return (uint64_t)L.h_shapes[a.shape].K * a.n_slices > (uint64_t)L.h_shapes[b.shape].K * b.n_slices;
     });
     return RSEM_OK;
 }
