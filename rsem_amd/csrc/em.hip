@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double noise = 0.0;
     {
-        const Shape& G = shapes[U.shape];  // uniform address: scalar loads
+        const Shape& G = U.S;
         Shape S;
         S.plane_base = G.plane_base;
         S.slice_base = G.slice_base;
@@ -569,7 +569,9 @@ struct rsem_em_ctx {
     double* d_sncp = nullptr;
     // LANE variant work list
     Unit* d_units = nullptr;
-    unsigned long long* d_trace = nullptr;  // rsem_em_debug_trace only
+    unsigned long long* d_trace = nullptr;  // per-workgroup timestamps (tune_unit_order, rsem_em_debug_trace)
+    std::vector<Unit> h_units;
+    int tune_passes_left = 1;               // measured-lifetime reordering of the units, done on first use
     uint32_t n_units = 0;
     int noise_n = 0;  // workgroups of the last main E-step launch (= valid entries of d_noise_a)
     size_t noise_cap = 0;
@@ -664,6 +666,8 @@ int build_layout(rsem_em_ctx* c) {
     rc = sell_build_units(c->L, units, kWindow);
     if (rc != RSEM_OK) return rc;
     c->n_units = (uint32_t)units.size();
+    c->h_units = units;
+    if (const char* e = getenv("RSEM_HIP_TUNE")) c->tune_passes_left = atoi(e);  // tuning knob: 0 disables
     RSEM_HIP_TRY(dmalloc(&c->d_units, units.size()));
     if (!units.empty())
         RSEM_HIP_TRY(hipMemcpy(c->d_units, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice));
@@ -823,6 +827,41 @@ int rsem_em_destroy(rsem_em_ctx* c) {
     return RSEM_OK;
 }
 
+// Longest-processing-time-first with MEASURED workgroup lifetimes: one traced E-step launch, then the units are
+// re-sorted by how long they actually ran (tuple changes, window misses and the sid spread make equal-sized units
+// differ 5x), so the launch does not end on a few long-lived workgroups.  Scratch use of d_counts: the caller
+// clears it afterwards.
+static int tune_unit_order(rsem_em_ctx* c, const double* d_theta) {
+    while (c->tune_passes_left > 0) {
+        --c->tune_passes_left;
+        if (resolved_kernel(c) != RSEM_EM_KERNEL_LANE || c->n_units < 2048) return RSEM_OK;
+        const uint32_t n = c->n_units;
+        unsigned long long* d = nullptr;
+        RSEM_HIP_TRY(hipMalloc((void**)&d, sizeof(unsigned long long) * 2 * n));
+        std::vector<unsigned long long> t(2 * (size_t)n);
+        int rc = RSEM_OK;
+        for (int rep = 0; rep < 2 && rc == RSEM_OK; rep++) {  // second launch: caches and clocks warm
+            c->d_trace = d;
+            rc = launch_estep(c, d_theta, c->d_counts, c->stream, true);
+            c->d_trace = nullptr;
+        }
+        hipError_t e = hipMemcpyAsync(t.data(), d, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d);
+        if (rc != RSEM_OK) return rc;
+        if (e != hipSuccess) { rsem::set_last_error("unit tuning: trace download failed"); return RSEM_ERR_HIP; }
+        std::vector<uint32_t> order(n);
+        for (uint32_t i = 0; i < n; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return t[2 * a + 1] - t[2 * a] > t[2 * b + 1] - t[2 * b]; });
+        std::vector<Unit> sorted(n);
+        for (uint32_t i = 0; i < n; i++) sorted[i] = c->h_units[order[i]];
+        c->h_units.swap(sorted);
+        RSEM_HIP_TRY(hipMemcpyAsync(c->d_units, c->h_units.data(), sizeof(Unit) * n, hipMemcpyHostToDevice, c->stream));
+        RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return RSEM_OK;
+}
+
 int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_round, int max_round, int* rounds_done,
                 double* counts, double* bChange, int32_t* totNum, rsem_em_profile* prof) {
     RSEM_REQUIRE(c && theta, "NULL argument");
@@ -833,6 +872,10 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
     const size_t nb = sizeof(double) * ((size_t)c->M + 1);
     RSEM_HIP_TRY(hipMemcpyAsync(c->d_theta[round0 & 1], theta, nb, hipMemcpyHostToDevice, st));
     RSEM_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), st));
+    if (c->tune_passes_left > 0) {
+        int trc = tune_unit_order(c, c->d_theta[round0 & 1]);
+        if (trc != RSEM_OK) return trc;
+    }
     RSEM_HIP_TRY(hipMemsetAsync(c->d_counts, 0, nb, st));
     const int timed = prof ? std::min(max_round - round0, kMaxTimedRounds) : 0;
     if (prof) {

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void k_sample_z_lane(
     __shared__ Shape sS;
     __shared__ int s_noise;
     const Unit U = units[blockIdx.x];
-    if (threadIdx.x == 0) { sS = shapes[U.shape]; s_noise = 0; }
+    if (threadIdx.x == 0) { sS = U.S; s_noise = 0; }
     for (int i = threadIdx.x; i < U.span; i += blockDim.x) {
         const int sidv = U.base + i;
         g_win[i] = (sidv >= 0 && sidv <= M) ? g[sidv] : 0.0;

@@ -335,6 +335,7 @@ struct Unit {
     int32_t base;
     int32_t span;          // sids [base, base + span) are staged in LDS (<= the window capacity)
     int32_t pad[2];
+    Shape S;               // copy of the shape: one dependent load less at the start of every workgroup
 };
 
 inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units, int window_cap) {
@@ -364,6 +365,7 @@ inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units, int w
         const long long span = (long long)top - U.base + 1;
         U.span = (int32_t)std::min<long long>(std::max<long long>(span, 1), window_cap);
         U.pad[0] = U.pad[1] = 0;
+        U.S = S;
         units.push_back(U);
     };
     for (int sh = 0; sh < L.n_shapes; sh++) {

@@ -13,6 +13,7 @@ from tools.synth_data import make_em_workload  # noqa: E402
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 wl = make_em_workload("C2", scale=scale)
 ctx = capi.EmContext(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], device=0)
+ctx.run(wl["theta0"], wl["N0"], min_round=3, max_round=3)  # first use: the units are re-sorted by measured lifetime
 L = capi.lib()
 L.rsem_em_debug_trace.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.float64), np.ctypeslib.ndpointer(np.uint64), C.POINTER(C.c_uint32)]
 cap = 1 << 20
