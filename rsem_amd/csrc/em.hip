@@ -40,6 +40,8 @@ constexpr int kReduceBlocks = 64;   // partial sums of the M step
 constexpr int kMaxTimedRounds = 4096;
 constexpr int kWindow = 2048;        // doubles of LDS count window per workgroup (16 KB)
 
+constexpr int kTotSlots = 64;  // addresses per device-wide total (E-step workgroups add round-robin)
+
 struct Ctrl {  // device-resident loop control, one per ctx
     int done;
     int final_round;
@@ -51,6 +53,7 @@ struct Ctrl {  // device-resident loop control, one per ctx
     double last_bchange;
     int last_totNum;
     int last_round;
+    unsigned long long tick2;  // k_mstep_fast: (sum of totNum) << 32 | arrivals, one atomic per workgroup
 };
 
 
@@ -74,6 +77,27 @@ __device__ inline void block_store_partial(double v, double* out) {
     }
 }
 
+// per-workgroup noise partial (for the callers that reduce the partials themselves) and, when `tot` is given, two
+// device-wide totals: tot[0] += v (noise fraction), tot[1] += u (reads with a non-zero normaliser: an integer
+// count, so its total is exact in any order)
+__device__ inline void block_add_totals(double v, double u, double* out_v, double* tot) {
+    __shared__ double red3[2 * (kBlock / 64)];
+    v = wave_sum(v);
+    u = wave_sum(u);
+    if ((threadIdx.x & 63) == 0) { red3[threadIdx.x >> 6] = v; red3[kBlock / 64 + (threadIdx.x >> 6)] = u; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0, tu = 0.0;
+        for (int i = 0; i < kBlock / 64; i++) { t += red3[i]; tu += red3[kBlock / 64 + i]; }
+        out_v[blockIdx.x] = t;
+        if (tot) {  // kTotSlots addresses per total: a single hot address serialises the whole launch behind it
+            const int slot = blockIdx.x & (kTotSlots - 1);
+            if (t != 0.0) unsafeAtomicAdd(&tot[slot], t);
+            if (tu != 0.0) unsafeAtomicAdd(&tot[kTotSlots + slot], tu);
+        }
+    }
+}
+
 // Thread-per-read over the caller's CSR (EM.cpp:199-244 literally).  Used as the baseline
 // variant, for reads with > 256 alignments, and for the final expected-weights pass.
 template <bool kWriteW>
@@ -81,9 +105,9 @@ __global__ __launch_bounds__(kBlock) void k_estep_csr(
     uint64_t n_rows, const uint32_t* __restrict__ row_list, const uint64_t* __restrict__ row_ptr,
     const int32_t* __restrict__ sid, const double* __restrict__ cp, const double* __restrict__ ncp,
     const double* __restrict__ theta, double* counts, double* noise_partial, double* w,
-    double* w_noise, const Ctrl* ctrl) {
+    double* w_noise, const Ctrl* ctrl, double* totals = nullptr) {
     if (ctrl && ctrl->done) return;
-    double noise = 0.0;
+    double noise = 0.0, neff = 0.0;
     const double th0 = theta[0];
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_rows;
          t += (uint64_t)gridDim.x * blockDim.x) {
@@ -99,6 +123,7 @@ __global__ __launch_bounds__(kBlock) void k_estep_csr(
         }
         if (sum >= kEpsilon) {
             noise += f0 / sum;
+            neff += 1.0;
             if (kWriteW) w_noise[i] = f0 / sum;
             for (uint64_t j = fr; j < to; j++) {
                 int s = sid[j];
@@ -113,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_estep_csr(
             for (uint64_t j = fr; j < to; j++) w[j] = 0.0;
         }
     }
-    block_store_partial(noise, noise_partial);
+    block_add_totals(noise, neff, noise_partial, totals);
 }
 
 // segmented sum of v over lanes {g, g+G, g+2G, ...} keyed by `key`; returns true on the tail lane
@@ -214,7 +239,7 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
                                    const double* __restrict__ theta, double th0, double* th_win, double* cnt_win,
                                    const double* __restrict__ scp, const int32_t* __restrict__ ssid,
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
-                                   double* counts, double& noise, int M) {
+                                   double* counts, double& noise, double& neff, int M) {
     const int lg = S.lg;
     const int g = lane & ((1 << lg) - 1);
     const bool g0 = (g == 0);
@@ -285,6 +310,7 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
         for (int d = 1; d < (1 << lg); d <<= 1) part += __shfl_xor(part, d);
         const double inv = (part >= kEpsilon) ? 1.0 / part : 0.0;
         noise += f0 * inv;
+        neff += (g0 && part >= kEpsilon) ? 1.0 : 0.0;  // reads whose fractions sum to one: sum(counts) without a reduction
 #pragma unroll
         for (int k = 0; k < K; k++) acc[k] += f[k] * inv;
     };
@@ -313,14 +339,14 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
     const Shape* __restrict__ shapes, const Unit* __restrict__ units, uint32_t T, int M,
     const double* __restrict__ theta, const double* __restrict__ scp, const int32_t* __restrict__ ssid,
     const double* __restrict__ sncp, const unsigned long long* __restrict__ masks, double* counts,
-    double* noise_partial, const Ctrl* ctrl, unsigned long long* trace) {
+    double* noise_partial, double* totals, const Ctrl* ctrl, unsigned long long* trace) {
     if (ctrl->done) return;
     if (trace && threadIdx.x == 0) trace[2 * blockIdx.x] = wall_clock64();  // rsem_em_debug_trace only
     __shared__ double th_win[kWindow];
     __shared__ double cnt_win[kWindow];
     const Unit U = units[blockIdx.x];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double noise = 0.0;
+    double noise = 0.0, neff = 0.0;
     {
         const Shape& G = U.S;
         Shape S;
@@ -337,10 +363,10 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
         const double th0 = theta[0];
         if (s_begin < u_end) switch (S.K) {
-            case 1: estep_block<1>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, M); break;
-            case 2: estep_block<2>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, M); break;
-            case 3: estep_block<3>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, M); break;
-            default: estep_block<4>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, M); break;
+            case 1: estep_block<1>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
+            case 2: estep_block<2>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
+            case 3: estep_block<3>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
+            default: estep_block<4>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
         } else stage_windows(U.base, U.span, M, theta, th_win, cnt_win);
     }
     __syncthreads();
@@ -348,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
         const double v = cnt_win[i];
         if (v != 0.0) unsafeAtomicAdd(&counts[U.base + i], v);
     }
-    block_store_partial(noise, noise_partial);
+    block_add_totals(noise, neff, noise_partial, totals);
     if (trace && threadIdx.x == 0) trace[2 * blockIdx.x + 1] = wall_clock64();
 }
 
@@ -547,6 +573,103 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fused(int32_t M, double N0, do
     }
 }
 
+// M step without a grid-wide reduction.  Every read whose normaliser is >= EPSILON contributes fractions that sum to
+// one, so sum(counts) (EM.cpp:395) = N0 + (number of such reads), which the E-step workgroups count on the side
+// (one atomic per E-step workgroup into one of kTotSlots slots; exact, the addends are integers), like the noise
+// fraction (a second set of slots).  No reduction, no barrier before theta = counts / sum.
+__global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, double* counts, double* totals,
+                                                        const double* __restrict__ theta_old, double* theta_new,
+                                                        double* counts_last, Ctrl* ctrl, int round, int min_round, int max_round) {
+    if (ctrl->done) return;
+    const int n = M + 1;
+    const int nb = gridDim.x;
+    const int per = (n + nb - 1) / nb;
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    // wave 0: lanes 0..63 fetch the slots of both totals (fixed summation order)
+    __shared__ double s_totals[2];
+    if (threadIdx.x < 64) {
+        double a = __hip_atomic_load(&totals[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double b = __hip_atomic_load(&totals[kTotSlots + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a = wave_sum(a);
+        b = wave_sum(b);
+        if (threadIdx.x == 0) { s_totals[0] = a; s_totals[1] = b; }
+    }
+    // this workgroup's slice of counts / theta_old is requested first, so it arrives while the partials are reduced
+    constexpr int kPre = 8;
+    const bool pre = (hi - lo) <= kPre * (int)blockDim.x;
+    double pc[kPre], po[kPre];
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < kPre; k++) {
+            const int i = lo + (int)threadIdx.x + k * (int)blockDim.x;
+            pc[k] = i < hi ? counts[i] : 0.0;
+            po[k] = i < hi ? theta_old[i] : 0.0;
+        }
+    }
+    __syncthreads();
+    const double extra0 = s_totals[0] + N0;  // counts[0] += noise + N0 (EM.cpp:392)
+    const double sum = s_totals[1] + N0;
+    int tot = 0;
+    double bmax = 0.0;
+    auto one = [&](int i, double craw, double old) {
+        const double c = craw + (i == 0 ? extra0 : 0.0);
+        const double th = c / sum;
+        theta_new[i] = th;
+        counts_last[i] = c;
+        counts[i] = 0.0;
+        if (old >= 1e-7) {
+            const double change = fabs(th - old) / old;
+            if (change >= 0.001) ++tot;
+            bmax = fmax(bmax, change);
+        }
+    };
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < kPre; k++) {
+            const int i = lo + (int)threadIdx.x + k * (int)blockDim.x;
+            if (i < hi) one(i, pc[k], po[k]);
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) one(i, counts[i], theta_old[i]);
+    }
+    __shared__ int s_tot[kBlock / 64];
+    __shared__ double s_b[kBlock / 64];
+    for (int d = 32; d >= 1; d >>= 1) {
+        tot += __shfl_xor(tot, d);
+        bmax = fmax(bmax, __shfl_xor(bmax, d));
+    }
+    __shared__ int s_last;
+    if ((threadIdx.x & 63) == 0) { s_tot[threadIdx.x >> 6] = tot; s_b[threadIdx.x >> 6] = bmax; }
+    if (threadIdx.x == 0) s_last = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kBlock / 64; i++) { tot += s_tot[i]; bmax = fmax(bmax, s_b[i]); }
+        // one fire-and-forget max, one returning add that carries both this workgroup's count and its arrival
+        (void)__hip_atomic_fetch_max(&ctrl->bbits, (unsigned long long)__double_as_longlong(bmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned long long old = __hip_atomic_fetch_add(&ctrl->tick2, ((unsigned long long)(unsigned)tot << 32) | 1ull,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(old & 0xffffffffull) == gridDim.x - 1) {  // last workgroup: stop rule (EM.cpp:416)
+            const int totNum = (int)(old >> 32) + tot;
+            const unsigned long long bb = __hip_atomic_load(&ctrl->bbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctrl->last_sum = sum;
+            ctrl->last_bchange = __longlong_as_double((long long)bb);
+            ctrl->last_totNum = totNum;
+            ctrl->last_round = round;
+            if (!(round < min_round || (totNum > 0 && round < max_round))) {
+                ctrl->done = 1;
+                ctrl->final_round = round;
+            }
+            __hip_atomic_store(&ctrl->bbits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctrl->tick2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = 1;
+        }
+    }
+    __syncthreads();
+    // the last workgroup to arrive clears the totals for the next round: every workgroup has read them by now
+    if (s_last && threadIdx.x < 2 * kTotSlots) __hip_atomic_store(&totals[threadIdx.x], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace
 
 // ---- ctx -------------------------------------------------------------------------------------
@@ -581,6 +704,8 @@ struct rsem_em_ctx {
     double* d_counts_last = nullptr;
     double* d_noise_a = nullptr;  // per-workgroup noise partials of the main E-step launch
     double* d_noise_b = nullptr;  // ... of the long-row launch
+    double* d_totals = nullptr;   // [0] noise fraction, [1] reads with a non-zero normaliser, of the current round (rsem_em_run)
+    bool use_totals = false;
     double* d_partials = nullptr;
     double* d_w = nullptr;        // expected-weights scratch (nnz), lazily allocated
     double* d_wn = nullptr;
@@ -614,7 +739,7 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
     if (kern == RSEM_EM_KERNEL_LANE) {
         if (c->n_units)
             hipLaunchKernelGGL(k_estep_lane, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
-                               d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, ctrl, c->d_trace);
+                               d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace);
     } else {
         hipLaunchKernelGGL(k_estep_sell, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
                            c->L.n_slices, d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, d_counts, c->d_noise_a, ctrl);
@@ -623,7 +748,7 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
     if (c->L.n_long_rows) {
         hipLaunchKernelGGL(k_estep_csr<false>, dim3(c->grid_long), dim3(kBlock), 0, st, (uint64_t)c->L.n_long_rows,
                            c->L.d_order + c->L.n_sell_rows, c->d_row_ptr, c->d_sid, c->d_cp, c->d_ncp, d_theta, d_counts,
-                           c->d_noise_b, (double*)nullptr, (double*)nullptr, ctrl);
+                           c->d_noise_b, (double*)nullptr, (double*)nullptr, ctrl, c->use_totals ? c->d_totals : nullptr);
         RSEM_HIP_TRY(hipGetLastError());
     }
     return RSEM_OK;
@@ -637,6 +762,13 @@ int n_noise_b(const rsem_em_ctx* c) {
 int launch_mstep(rsem_em_ctx* c, double N0, double* d_counts, const double* d_theta_old, double* d_theta_new,
                  int round, int min_round, int max_round, hipStream_t st) {
     const int grid = std::max(1, std::min(kMstepBlocks, rsem::ceil_div((uint64_t)c->M + 1, kBlock * 4)));
+    if (c->use_totals) {
+        const int gridf = std::max(1, std::min(2 * kMstepBlocks, rsem::ceil_div((uint64_t)c->M + 1, kBlock * 2)));
+        hipLaunchKernelGGL(k_mstep_fast, dim3(gridf), dim3(kBlock), 0, st, c->M, N0, d_counts, c->d_totals, d_theta_old, d_theta_new,
+                           c->d_counts_last, c->d_ctrl, round, min_round, max_round);
+        RSEM_HIP_TRY(hipGetLastError());
+        return RSEM_OK;
+    }
     hipLaunchKernelGGL(k_mstep_fused, dim3(grid), dim3(kBlock), 0, st, c->M, N0, d_counts, c->d_noise_a, c->noise_n,
                        c->d_noise_b, n_noise_b(c), c->d_partials, d_theta_old, d_theta_new, c->d_counts_last, c->d_ctrl,
                        round, min_round, max_round);
@@ -675,6 +807,7 @@ int build_layout(rsem_em_ctx* c) {
     c->noise_cap = std::max<size_t>((size_t)c->n_cus * 8, c->n_units);
     RSEM_HIP_TRY(dmalloc(&c->d_noise_a, c->noise_cap));
     RSEM_HIP_TRY(hipMemsetAsync(c->d_noise_a, 0, sizeof(double) * c->noise_cap, c->stream));
+
     c->grid_long = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_long_rows, kBlock)));
     return RSEM_OK;
 }
@@ -742,6 +875,8 @@ int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64
     TRY_OR_FAIL(dmalloc(&c->d_counts, (size_t)M + 1));
     TRY_OR_FAIL(dmalloc(&c->d_counts_last, (size_t)M + 1));
     TRY_OR_FAIL(dmalloc(&c->d_noise_b, (size_t)c->n_cus * 8));
+    TRY_OR_FAIL(dmalloc(&c->d_totals, 2 * kTotSlots));
+    TRY_OR_FAIL(hipMemsetAsync(c->d_totals, 0, sizeof(double) * 2 * kTotSlots, c->stream));
     TRY_OR_FAIL(dmalloc(&c->d_partials, 2 * kReduceBlocks));
     TRY_OR_FAIL(dmalloc(&c->d_ctrl, 1));
     TRY_OR_FAIL(hipMemsetAsync(c->d_counts, 0, sizeof(double) * ((size_t)M + 1), c->stream));
@@ -820,7 +955,7 @@ int rsem_em_destroy(rsem_em_ctx* c) {
     hipFree(c->d_row_ptr); hipFree(c->d_sid); hipFree(c->d_cp); hipFree(c->d_ncp);
     sell_free(c->L); hipFree(c->d_scp); hipFree(c->d_sncp);
     hipFree(c->d_theta[0]); hipFree(c->d_theta[1]); hipFree(c->d_counts);
-    hipFree(c->d_counts_last); hipFree(c->d_noise_a); hipFree(c->d_noise_b); hipFree(c->d_partials);
+    hipFree(c->d_counts_last); hipFree(c->d_noise_a); hipFree(c->d_noise_b); hipFree(c->d_totals); hipFree(c->d_partials);
     hipFree(c->d_w); hipFree(c->d_wn); hipFree(c->d_ctrl); hipFree(c->d_units);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -877,6 +1012,9 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
         if (trc != RSEM_OK) return trc;
     }
     RSEM_HIP_TRY(hipMemsetAsync(c->d_counts, 0, nb, st));
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_totals, 0, sizeof(double) * 2 * kTotSlots, st));
+    c->use_totals = resolved_kernel(c) == RSEM_EM_KERNEL_LANE;  // E-step workgroups also feed the two device-wide totals
+    struct TotalsOff { rsem_em_ctx* c; ~TotalsOff() { c->use_totals = false; } } totals_off{c};
     const int timed = prof ? std::min(max_round - round0, kMaxTimedRounds) : 0;
     if (prof) {
         while ((int)c->events.size() < 2 * timed + 2) {
