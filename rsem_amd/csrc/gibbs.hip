@@ -37,12 +37,16 @@ using rsem::u53;
 using rsem::gamma_draw;
 
 // g[i] = Gamma(counts[i] + alpha_i) (unnormalised Dirichlet draw); omitted transcripts (counts < 0) get 0
-__global__ void k_sample_theta(int32_t M, const int32_t* __restrict__ counts, const double* __restrict__ alpha,
-                               double pseudoC, Philox ph, uint32_t sweep, double* g) {
+// ... and the counts are re-armed for the z pass that follows (init_counts: 0, or -1 for omitted transcripts; the noise
+// bin starts at N0), which saves the separate reset launch of every sweep
+__global__ void k_sample_theta(int32_t M, int32_t* __restrict__ counts, const double* __restrict__ alpha,
+                               double pseudoC, Philox ph, uint32_t sweep, double* g, const int32_t* __restrict__ init_counts,
+                               int32_t n0) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > M) return;
     int c = counts[i];
     g[i] = (c < 0) ? 0.0 : gamma_draw(ph, (uint32_t)i, sweep, (double)c + (alpha ? alpha[i] : pseudoC));
+    counts[i] = init_counts[i] + (i == 0 ? n0 : 0);
 }
 
 __global__ void k_fill_double(int32_t n, double v, double* g) {
@@ -57,6 +61,16 @@ __global__ void k_reset_counts(int32_t M, const int32_t* __restrict__ init_count
 
 constexpr int kGWindow = 2048;  // sids per workgroup window (g values: 16 KB, int counts: 8 KB of LDS)
 
+// g[base, base+span) -> LDS, count window zeroed; every wave of the workgroup calls this exactly once
+__device__ inline void stage_gwindows(int base, int span, int M, const double* __restrict__ g, double* g_win, int* cnt_win) {
+    for (int i = threadIdx.x; i < span; i += blockDim.x) {
+        const int sidv = base + i;
+        g_win[i] = (sidv >= 0 && sidv <= M) ? g[sidv] : 0.0;
+        cnt_win[i] = 0;
+    }
+    __syncthreads();
+}
+
 template <int K>
 struct SliceRegs {
     int id[K];
@@ -70,10 +84,10 @@ struct SliceRegs {
 // then the G lanes of the read in order, each lane's K planes in order.
 template <int K>
 __device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
-                                   const double* __restrict__ g, double g0, const double* g_win, int* cnt_win,
+                                   const double* __restrict__ g, double g0, double* g_win, int* cnt_win,
                                    const double* __restrict__ scp, const int32_t* __restrict__ ssid,
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
-                                   const Philox& ph, uint32_t sweep, int32_t* counts, int& noise) {
+                                   const Philox& ph, uint32_t sweep, int32_t* counts, int& noise, int M) {
     const int lg = S.lg, G = 1 << lg;
     const int gl = lane & (G - 1);
     const bool g0lane = (gl == 0);
@@ -180,6 +194,7 @@ __device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin,
     SliceRegs<K> A, B;
     unsigned long long mA = ~0ull, mB = 0;
     issue(s_begin, mA, A);
+    stage_gwindows(base, span, M, g, g_win, cnt_win);  // the first slice's loads fly while the windows are staged
     for (uint32_t s = s_begin; s < s_end; s += 2) {
         if (s + 1 < s_end) { mB = mask_of(s + 1); issue(s + 1, mB, B); }
         sample(A, mA, s);
@@ -197,39 +212,23 @@ __global__ __launch_bounds__(kBlock) void k_sample_z_lane(
     int32_t* counts) {
     __shared__ double g_win[kGWindow];
     __shared__ int cnt_win[kGWindow];
-    __shared__ Shape sS;
     __shared__ int s_noise;
     const Unit U = units[blockIdx.x];
-    if (threadIdx.x == 0) { sS = U.S; s_noise = 0; }
-    for (int i = threadIdx.x; i < U.span; i += blockDim.x) {
-        const int sidv = U.base + i;
-        g_win[i] = (sidv >= 0 && sidv <= M) ? g[sidv] : 0.0;
-        cnt_win[i] = 0;
-    }
-    __syncthreads();
+    if (threadIdx.x == 0) s_noise = 0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int noise = 0;
     {
-        Shape S;
-        S.plane_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sS.plane_base >> 32)) << 32) |
-                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sS.plane_base);
-        S.slice_base = __builtin_amdgcn_readfirstlane(sS.slice_base);
-        S.n_slices = __builtin_amdgcn_readfirstlane(sS.n_slices);
-        S.row_base = __builtin_amdgcn_readfirstlane(sS.row_base);
-        S.n_rows = __builtin_amdgcn_readfirstlane(sS.n_rows);
-        S.slot_base = __builtin_amdgcn_readfirstlane(sS.slot_base);
-        S.K = __builtin_amdgcn_readfirstlane(sS.K);
-        S.lg = __builtin_amdgcn_readfirstlane(sS.lg);
+        const Shape S = U.S;
         const uint32_t u_end = S.slice_base + U.slice_begin + U.n_slices;
         const uint32_t s_begin = S.slice_base + U.slice_begin + (uint32_t)w * U.per_wave;
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
         const double g0 = g[0];
         if (s_begin < u_end) switch (S.K) {
-            case 1: gibbs_block<1>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
-            case 2: gibbs_block<2>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
-            case 3: gibbs_block<3>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
-            default: gibbs_block<4>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise); break;
-        }
+            case 1: gibbs_block<1>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise, M); break;
+            case 2: gibbs_block<2>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise, M); break;
+            case 3: gibbs_block<3>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise, M); break;
+            default: gibbs_block<4>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise, M); break;
+        } else stage_gwindows(U.base, U.span, M, g, g_win, cnt_win);
     }
     for (int d = 32; d >= 1; d >>= 1) noise += __shfl_xor(noise, d);
     if (lane == 0 && noise) atomicAdd(&s_noise, noise);
@@ -691,9 +690,10 @@ int rsem_gibbs_run(rsem_gibbs_ctx* c, int mode, uint32_t seed, int burnin, int n
     Philox ph{seed, 0x52534547u};  // 'RSEG'
     uint32_t sweep_no = 0;
 
-    auto parallel_z = [&](uint32_t sw) -> int {
-        hipLaunchKernelGGL(k_reset_counts, dim3(gM), dim3(kBlock), 0, st, c->M, c->d_init_counts, (int32_t)c->N0,
-                           c->d_counts);
+    auto parallel_z = [&](uint32_t sw, bool reset) -> int {
+        if (reset)
+            hipLaunchKernelGGL(k_reset_counts, dim3(gM), dim3(kBlock), 0, st, c->M, c->d_init_counts, (int32_t)c->N0,
+                               c->d_counts);
         if (c->n_units)
             hipLaunchKernelGGL(k_sample_z_lane, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
                                c->d_g, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, ph, sw, c->d_counts);
@@ -718,7 +718,7 @@ int rsem_gibbs_run(rsem_gibbs_ctx* c, int mode, uint32_t seed, int burnin, int n
         RSEM_HIP_TRY(hipStreamSynchronize(st));  // h must outlive the copy
     } else {
         hipLaunchKernelGGL(k_fill_double, dim3(gM), dim3(kBlock), 0, st, (int32_t)nM, 1.0, c->d_g);
-        rc = parallel_z(sweep_no++);
+        rc = parallel_z(sweep_no++, true);
         if (rc != RSEM_OK) return rc;
     }
     const int chainlen = 1 + (nsamples - 1) * gap;
@@ -732,8 +732,8 @@ int rsem_gibbs_run(rsem_gibbs_ctx* c, int mode, uint32_t seed, int burnin, int n
         } else {
             for (int t = 0; t < thin; t++) {
                 hipLaunchKernelGGL(k_sample_theta, dim3(gM), dim3(kBlock), 0, st, c->M, c->d_counts, c->d_alpha, c->pseudoC,
-                                   ph, sweep_no, c->d_g);
-                rc = parallel_z(sweep_no++);
+                                   ph, sweep_no, c->d_g, c->d_init_counts, (int32_t)c->N0);
+                rc = parallel_z(sweep_no++, false);
                 if (rc != RSEM_OK) return rc;
             }
         }

@@ -18,7 +18,7 @@ irp, isid, icp = to_gibbs_items(wl)
 N1 = len(irp) - 1
 t0 = time.time()
 g = capi.GibbsContext(M, irp, isid, icp, np.zeros(M + 1, np.int32), None, 1.0, (M + 1) + wl["N0"] + N1, wl["N0"],
-                      np.full(M + 1, 1000.0), np.ones(M + 1), np.array([1, M + 1], np.int32))
+                      np.full(M + 1, 1000.0), np.ones(M + 1), np.arange(1, M + 2, 5, dtype=np.int32) if M % 5 == 0 else np.array([1, M + 1], np.int32))
 print("create %.2f s" % (time.time() - t0))
 cv, acc, ms = g.run(capi.GIBBS_PARALLEL, 1, sweeps - 2, 2, 1, thin=1, want_vectors=False)
 nitems = len(isid)
