@@ -6,7 +6,7 @@ set -u
 tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out
-B="python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-gibbs"
+B="python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-gibbs --no-ci"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_bench -o b -- $B > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_$c -o p -- $B > /dev/null 2> $out/${tag}_pmc_$c.err
