@@ -118,63 +118,66 @@ __global__ void k_ci_finish_rows(int32_t nS, int64_t nrows, float* __restrict__ 
     Y[r * nS + s] = tpm_of(Y[r * nS + s], sc[s]);
 }
 
-// calcCI (calcCI.cpp:216-284) on an already sorted row; one thread per row
-__global__ void k_ci_intervals(int64_t nrows, int32_t nSamples, const float* __restrict__ sorted, double confidence,
+// Interval + quartile statistics of one sorted row; one thread per row.  Same results as calcCI (calcCI.cpp:216-284),
+// written around runs of equal values: with t = the number of samples allowed outside, start from the lowest upper
+// end (always the LAST index of a run) that leaves <= t samples above it, then slide the lower end up run by run,
+// re-extending the upper end by whole runs whenever more than t samples fall outside; the first strictly shortest
+// [x[lo], x[hi]] wins.  Quartiles are Tukey's hinges.
+__device__ inline int run_last(const float* x, int n, int i) {   // last index of the run of equal values containing i
+    while (i < n - 1 && x[i + 1] == x[i]) ++i;
+    return i;
+}
+__device__ inline int run_first(const float* x, int i) {         // first index of that run
+    while (i > 0 && x[i - 1] == x[i]) --i;
+    return i;
+}
+
+__global__ void k_ci_intervals(int64_t nrows, int32_t n, const float* __restrict__ sorted, double confidence,
                                float* __restrict__ lb_out, float* __restrict__ ub_out, float* __restrict__ cqv_out) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrows) return;
-    const float* samples = sorted + (size_t)r * nSamples;
-    int p, q, newp, newq;
-    const int threshold = nSamples - ((int)(confidence * nSamples - 1e-8) + 1);
-    int nOutside = 0;
+    const float* x = sorted + (size_t)r * n;
+    const int allowed = n - ((int)(confidence * n - 1e-8) + 1);  // samples that may lie outside the interval
 
-    p = 0; q = nSamples - 1;
-    newq = nSamples - 1;
-    do {
-        q = newq;
-        while (newq > 0 && samples[newq - 1] == samples[newq]) newq--;
-        newq--;
-    } while (newq >= 0 && nSamples - (newq + 1) <= threshold);
-
-    nOutside = nSamples - (q + 1);
-
-    float lb = -1e30f, ub = 1e30f;
-    do {
-        if (samples[q] - samples[p] < ub - lb) {
-            lb = samples[p];
-            ub = samples[q];
-        }
-        newp = p;
-        while (newp < nSamples - 1 && samples[newp] == samples[newp + 1]) newp++;
-        newp++;
-        if (newp <= threshold) {
-            nOutside += newp - p;
-            p = newp;
-            while (nOutside > threshold && q < nSamples - 1) {
-                newq = q + 1;
-                while (newq < nSamples - 1 && samples[newq] == samples[newq + 1]) newq++;
-                nOutside -= newq - q;
-                q = newq;
-            }
-        } else p = newp;
-    } while (p <= threshold);
-
-    // Tukey's hinges
-    float Q1, Q3;
-    const int quotient = nSamples / 4, residue = nSamples % 4;
-    if (residue == 0) {
-        Q1 = (float)((double)(samples[quotient - 1] + samples[quotient]) / 2.0);  // float add, as the reference
-        Q3 = (float)((double)(samples[3 * quotient - 1] + samples[3 * quotient]) / 2.0);
-    } else if (residue == 3) {
-        Q1 = (float)((double)(samples[quotient] + samples[quotient + 1]) / 2.0);
-        Q3 = (float)((double)(samples[quotient * 3 + 1] + samples[quotient * 3 + 2]) / 2.0);
-    } else {
-        Q1 = samples[quotient];
-        Q3 = samples[3 * quotient];
+    // upper end: walk down over whole runs while the samples above still fit into `allowed`
+    int hi = n - 1;
+    for (;;) {
+        const int below = run_first(x, hi) - 1;  // last index of the next lower run, -1 if none
+        if (below < 0 || n - 1 - below > allowed) break;
+        hi = below;
     }
-    lb_out[r] = lb;
-    ub_out[r] = ub;
-    cqv_out[r] = (Q3 - Q1 > 0.0f) ? (Q3 - Q1) / (Q3 + Q1) : 0.0f;  // float division, as the reference
+    int outside = n - 1 - hi;
+
+    float best_lo = -1e30f, best_hi = 1e30f;
+    for (int lo = 0; lo <= allowed;) {
+        if (x[hi] - x[lo] < best_hi - best_lo) { best_lo = x[lo]; best_hi = x[hi]; }
+        const int next = run_last(x, n, lo) + 1;  // first index of the next higher run
+        if (next <= allowed) {
+            outside += next - lo;
+            while (outside > allowed && hi < n - 1) {  // take back whole runs at the top
+                const int up = run_last(x, n, hi + 1);
+                outside -= up - hi;
+                hi = up;
+            }
+        }
+        lo = next;
+    }
+
+    const int q = n / 4, rem = n % 4;
+    float q1, q3;
+    if (rem == 0) {
+        q1 = (float)((double)(x[q - 1] + x[q]) / 2.0);  // float add, then halved in double, as the reference
+        q3 = (float)((double)(x[3 * q - 1] + x[3 * q]) / 2.0);
+    } else if (rem == 3) {
+        q1 = (float)((double)(x[q] + x[q + 1]) / 2.0);
+        q3 = (float)((double)(x[3 * q + 1] + x[3 * q + 2]) / 2.0);
+    } else {
+        q1 = x[q];
+        q3 = x[3 * q];
+    }
+    lb_out[r] = best_lo;
+    ub_out[r] = best_hi;
+    cqv_out[r] = (q3 - q1 > 0.0f) ? (q3 - q1) / (q3 + q1) : 0.0f;  // float division
 }
 
 __global__ void k_ci_offsets(int64_t n, int32_t nS, int* off) {
