@@ -7,6 +7,7 @@
 // -p N keeps its meaning "N independent chains, N count-vector files" (Gibbs.cpp:211-226, calcCI opens one
 // file per thread); the chains run on the available GPUs through librsem_hip (include/rsem_hip.h).
 #include <charconv>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -117,9 +118,14 @@ int main(int argc, char* argv[]) {
     int mode;
     if (mode_s == "exact") mode = RSEM_GIBBS_EXACT;
     else if (mode_s == "parallel") mode = RSEM_GIBBS_PARALLEL;
-    else {  // auto: the reference chain when it is affordable, the parallel sampler otherwise
-        double chain_rows = (double)N1 * (BURNIN + 1.0 + (NSAMPLES / (double)nThreads) * GAP);
-        mode = chain_rows <= 2e8 ? RSEM_GIBBS_EXACT : RSEM_GIBBS_PARALLEL;
+    else {
+        // auto: the reference's own chain (bit-identical count vectors) only when it is cheap.  It is one wave walking
+        // the reads in order, ~0.4 us per read and round, and the chains of one GPU run one after the other -- so the
+        // budget is on read-rounds per GPU (2.5e7 ~ 10 s); everything larger takes the parallel sampler.
+        const double chain_rows = (double)N1 * (BURNIN + 1.0 + std::ceil(NSAMPLES / (double)nThreads) * GAP);
+        const int gpus = device >= 0 ? 1 : std::max(1, std::min(ndev, nThreads));
+        const double rows_per_gpu = chain_rows * std::ceil(nThreads / (double)gpus);
+        mode = rows_per_gpu <= 2.5e7 ? RSEM_GIBBS_EXACT : RSEM_GIBBS_PARALLEL;
     }
     if (thin <= 0) thin = (mode == RSEM_GIBBS_PARALLEL) ? 8 : 1;
     if (verbose) printf("Gibbs started! (%s sampler, %d chain(s), %d GPU(s))\n", mode == RSEM_GIBBS_EXACT ? "exact" : "parallel", nThreads, ndev);
