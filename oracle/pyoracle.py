@@ -46,6 +46,9 @@ def lib():
                                       C.c_uint64, _f64p, _f64p, C.c_int32, _i32p, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, _f64p, _f64p, _f64p, _f64p, _f64p]
         L.orc_gibbs_chain.restype = None
+        L.orc_gibbs_da_chain.argtypes = [C.c_int32, C.c_uint64, _u64p, _i32p, _f64p, _i32p, C.c_double, C.c_uint64, C.c_uint32,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, _f64p, _f64p]
+        L.orc_gibbs_da_chain.restype = None
         _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
         L.orc_calc_ci.argtypes = [C.c_int, _f32p, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_calc_ci.restype = None
@@ -135,3 +138,11 @@ def ci_transform(gam, cvec, eel, mw):
     lbar = lib().orc_ci_transform(M, np.ascontiguousarray(gam, np.float64), np.ascontiguousarray(cvec, np.int32),
                                   np.ascontiguousarray(eel, np.float64), np.ascontiguousarray(mw, np.float64), tpm)
     return tpm, np.float32(lbar)
+
+
+def gibbs_da_chain(M, row_ptr, sid, conprb, init_counts, pseudoC, N0, mt_seed, burnin, nsamples, gap, thin):
+    """CPU model of the drop-in's PARALLEL sampler (see rsem_oracle.h) -> (sum of counts, sum of counts^2) over the samples."""
+    a, b = np.zeros(M + 1), np.zeros(M + 1)
+    lib().orc_gibbs_da_chain(M, len(row_ptr) - 1, row_ptr, sid, conprb, init_counts, float(pseudoC), int(N0), int(mt_seed),
+                             burnin, nsamples, gap, thin, a, b)
+    return a, b

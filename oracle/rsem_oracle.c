@@ -364,3 +364,69 @@ float orc_ci_transform(int32_t M, const double* gam, const int32_t* cvec, const 
     free(theta);
     return l_bar;
 }
+
+
+/* ---- data-augmentation sampler (CPU model of the drop-in's PARALLEL Gibbs mode) ---------------------------- */
+
+static double da_u01(orc_mt19937* g) {  /* (0,1), 53 bits */
+    const uint32_t a = orc_mt_next(g) >> 5, b = orc_mt_next(g) >> 6;
+    return ((double)a * 67108864.0 + (double)b + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+static double da_gamma(orc_mt19937* g, double a) {  /* Marsaglia & Tsang (2000) */
+    double boost = 1.0, d, c;
+    if (a < 1.0) { boost = exp(log(da_u01(g)) / a); a += 1.0; }
+    d = a - 1.0 / 3.0; c = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        const double u1 = da_u01(g), u2 = da_u01(g);
+        const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        double v = 1.0 + c * x, u, x2;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        u = da_u01(g);
+        x2 = x * x;
+        if (u < 1.0 - 0.0331 * x2 * x2) return d * v * boost;
+        if (log(u) < 0.5 * x2 + d * (1.0 - v + log(v))) return d * v * boost;
+    }
+}
+
+void orc_gibbs_da_chain(int32_t M, uint64_t N1, const uint64_t* row_ptr, const int32_t* sid,
+                        const double* conprb, const int32_t* init_counts, double pseudoC, uint64_t N0,
+                        uint32_t mt_seed, int burnin, int nsamples, int gap, int thin, double* pme_c, double* pve_c) {
+    orc_mt19937 g;
+    double* th = (double*)malloc(sizeof(double) * ((size_t)M + 1));
+    int32_t* counts = (int32_t*)malloc(sizeof(int32_t) * ((size_t)M + 1));
+    const int chainlen = 1 + (nsamples - 1) * gap;
+    int round, t, first = 1;
+    int32_t j;
+    uint64_t i, k;
+    orc_mt_seed(&g, mt_seed);
+    for (j = 0; j <= M; j++) th[j] = 1.0;  /* initial state: z ~ conprb alone, as Gibbs.cpp:283-293 */
+    for (round = 0; round <= burnin + chainlen; round++) {
+        const int sweeps = first ? 1 : thin;
+        for (t = 0; t < sweeps; t++) {
+            if (!first)
+                for (j = 0; j <= M; j++) th[j] = counts[j] < 0 ? 0.0 : da_gamma(&g, (double)counts[j] + pseudoC);
+            for (j = 0; j <= M; j++) counts[j] = init_counts[j];
+            counts[0] += (int32_t)N0;
+            for (i = 0; i < N1; i++) {
+                double tot = 0.0, target, run = 0.0;
+                int32_t pick = -1;
+                for (k = row_ptr[i]; k < row_ptr[i + 1]; k++) tot += th[sid[k]] * conprb[k];
+                if (!(tot > 0.0)) continue;
+                target = da_u01(&g) * tot;
+                for (k = row_ptr[i]; k < row_ptr[i + 1]; k++) {
+                    const double f = th[sid[k]] * conprb[k];
+                    run += f;
+                    if (f > 0.0) pick = sid[k];
+                    if (target < run) break;
+                }
+                if (pick >= 0) ++counts[pick];
+            }
+            first = 0;
+        }
+        if (round > burnin && (round - burnin - 1) % gap == 0)
+            for (j = 0; j <= M; j++) { pme_c[j] += counts[j]; pve_c[j] += (double)counts[j] * counts[j]; }
+    }
+    free(th); free(counts);
+}

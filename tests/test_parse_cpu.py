@@ -171,3 +171,84 @@ def test_parse_round_trip_generated(read_type, tmp_path):
     assert cnt[0].split() == ["1500", "28500", "0", "30000"]
     hist = dict(l.split("\t") for l in cnt[3:] if "\t" in l)
     assert sum(int(v) for k, v in hist.items() if k not in ("0", "Inf")) == 28500
+
+
+def _edit_sam(src, dst, fn):
+    with open(src) as fi, open(dst, "w", newline="") as fo:
+        body = [l for l in fi]
+        fo.writelines(fn(body))
+
+
+EDGE_CASES = {
+    # name: (fixture, read_type, transformation of the SAM lines)
+    "no_trailing_newline": ("se_q", 1, lambda L: L[:-1] + [L[-1].rstrip("\n")]),
+    "crlf_line_ends": ("se_q", 1, lambda L: [l.rstrip("\n") + "\r\n" for l in L]),
+    "lower_case_bases": ("se_q", 1, lambda L: [l if l.startswith("@") else "\t".join(f.lower() if i == 9 else f for i, f in enumerate(l.split("\t"))) for l in L]),
+    "qname_with_spaces": ("se_q", 1, lambda L: [l if l.startswith("@") else l.replace("\t", " extra words\t", 1) for l in L]),
+    "missing_qualities": ("se_q", 1, lambda L: [l if l.startswith("@") else "\t".join("*" if i == 10 else f for i, f in enumerate(l.rstrip("\n").split("\t"))) + "\n" for l in L]),
+    "eq_and_x_cigar": ("se_q", 1, lambda L: [l if l.startswith("@") or l.split("\t")[5] == "*" else "\t".join((f[:-1] + ("=" if n % 2 else "X")) if i == 5 else f for i, f in enumerate(l.split("\t"))) for n, l in enumerate(L)]),
+    "header_only": ("se_q", 1, lambda L: [l for l in L if l.startswith("@")]),
+    "pe_mates_swapped": ("pe_q", 3, lambda L: [l for l in L if l.startswith("@")] + [x for a, b in zip(*[iter([l for l in L if not l.startswith("@")])] * 2) for x in (b, a)]),
+    "pe_mate_names_differ": ("pe_q", 3, lambda L: [l if l.startswith("@") or not (int(l.split("\t")[1]) & 128) else "m2_" + l for l in L]),
+}
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/rsem-parse-alignments not built")
+@pytest.mark.parametrize("case", sorted(EDGE_CASES))
+def test_parse_edge_cases_match_reference_binary(case, tmp_path):
+    """Inputs htslib accepts in more than one spelling: the drop-in's own SAM decoder must land on the same bytes."""
+    _need_new()
+    name, read_type, fn = EDGE_CASES[case]
+    fx = os.path.join(GOLD, name)
+    alnf = str(tmp_path / "in.sam")
+    _edit_sam(os.path.join(fx, "aln.sam"), alnf, fn)
+    a, b = str(tmp_path / "new"), str(tmp_path / "ref")
+    r2 = _run(REF, os.path.join(fx, "ref"), b, alnf, read_type)
+    for extra in ((), ("--wave-bytes", "2500", "-p", "3")):
+        r1 = _run(NEW, os.path.join(fx, "ref"), a, alnf, read_type, extra)
+        assert r2.returncode == 0, r2.stderr
+        assert r1.returncode == 0, r1.stderr
+        _same_tree(a, b)
+        if case == "pe_mate_names_differ":
+            assert "two mates have different names" in r1.stderr and "two mates have different names" in r2.stderr
+        import shutil
+        shutil.rmtree(a)
+
+
+def test_parse_more_error_paths(tmp_path):
+    _need_new()
+    fx = os.path.join(GOLD, "se_q")
+    src = os.path.join(fx, "aln.sam")
+    lines = open(src).read().split("\n")
+    body0 = next(i for i, l in enumerate(lines) if l and not l.startswith("@"))
+    first_aligned = next(i for i, l in enumerate(lines) if l and not l.startswith("@") and not (int(l.split("\t")[1]) & 4))
+
+    def write(name, L):
+        p = str(tmp_path / name)
+        open(p, "w").write("\n".join(L))
+        return p
+
+    # an unaligned record followed by an alignment of the same read name (parseIt.cpp:97)
+    f = lines[first_aligned].split("\t")
+    un = "\t".join([f[0], "4", "*", "0", "0", "*", "*", "0", "0", f[9], f[10]])
+    p = write("both.sam", lines[:first_aligned] + [un] + lines[first_aligned:])
+    r = _run(NEW, os.path.join(fx, "ref"), str(tmp_path / "a"), p, 1)
+    assert r.returncode != 0 and "both unalignable and alignable" in r.stderr
+    # two alignments of one read with different read lengths (SamParser.h:133)
+    g = list(f)
+    g[9], g[10], g[5] = g[9][:-1], g[10][:-1], "%dM" % (len(g[9]) - 1)
+    p = write("len.sam", lines[:first_aligned + 1] + ["\t".join(g)] + lines[first_aligned + 1:])
+    r = _run(NEW, os.path.join(fx, "ref"), str(tmp_path / "b"), p, 1)
+    assert r.returncode != 0 and "inconsistent read lengths" in r.stderr
+    # an ambiguity code the reference asserts on (sam_utils.h:88-96)
+    g = list(f)
+    g[9] = "R" + g[9][1:]
+    p = write("iupac.sam", lines[:first_aligned] + ["\t".join(g)] + lines[first_aligned + 1:])
+    r = _run(NEW, os.path.join(fx, "ref"), str(tmp_path / "c"), p, 1)
+    assert r.returncode != 0 and "base other than A, C, G, T, N" in r.stderr
+    # missing file / not enough arguments
+    r = _run(NEW, os.path.join(fx, "ref"), str(tmp_path / "d"), str(tmp_path / "nope.sam"), 1)
+    assert r.returncode != 0 and "Cannot open" in r.stderr
+    r = subprocess.run([NEW, "x"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and "Usage" in r.stdout
+    assert body0 > 0
