@@ -31,7 +31,7 @@ int main(int argc, char* argv[]) {
     const std::string refName = argv[1], imdName = argv[2], statName = argv[3];
     const int BURNIN = atoi(argv[4]), NSAMPLES = atoi(argv[5]), GAP = atoi(argv[6]);
     int nThreads = 1, thin = 0, device = -1;
-    bool hasSeed = false, quiet = false, has_prior = false;
+    bool hasSeed = false, quiet = false, has_prior = false, dry_run = false;
     uint32_t seed = 0;
     double pseudoC = 1.0;
     std::string fprior, mode_s = "auto";
@@ -48,6 +48,7 @@ int main(int argc, char* argv[]) {
         if (!strcmp(argv[i], "--gibbs-mode") && i + 1 < argc) mode_s = argv[i + 1];
         if (!strcmp(argv[i], "--gibbs-thin") && i + 1 < argc) thin = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--dry-run")) dry_run = true;  // load the inputs, print the sampler that would run, exit (no GPU work)
     }
     const bool verbose = !quiet;
     if (NSAMPLES <= 1) die("NSAMPLES must be larger than 1, otherwise the posterior variance cannot be calculated!");
@@ -114,20 +115,29 @@ int main(int argc, char* argv[]) {
 
     int ndev = 0;
     rsem_hip_device_count(&ndev);
-    if (ndev < 1) die("rsem-run-gibbs: no usable GPU (this program has no CPU path)");
+    if (ndev < 1 && !dry_run) die("rsem-run-gibbs: no usable GPU (this program has no CPU path)");
+    if (dry_run) ndev = std::max(ndev, 1);
+    // The reference's own chain (EXACT: bit-identical count vectors) is one wave walking the reads in order, ~0.4 us per
+    // read and round, and the chains of one GPU run one after the other -- so its cost is read-rounds per GPU.
+    const double chain_rows = (double)N1 * (BURNIN + 1.0 + std::ceil(NSAMPLES / (double)nThreads) * GAP);
+    const int gpus = device >= 0 ? 1 : std::max(1, std::min(ndev, nThreads));
+    const double rows_per_gpu = chain_rows * std::ceil(nThreads / (double)gpus);
+    const double kExactBudget = 2.5e7;  // ~10 s
     int mode;
-    if (mode_s == "exact") mode = RSEM_GIBBS_EXACT;
-    else if (mode_s == "parallel") mode = RSEM_GIBBS_PARALLEL;
-    else {
-        // auto: the reference's own chain (bit-identical count vectors) only when it is cheap.  It is one wave walking
-        // the reads in order, ~0.4 us per read and round, and the chains of one GPU run one after the other -- so the
-        // budget is on read-rounds per GPU (2.5e7 ~ 10 s); everything larger takes the parallel sampler.
-        const double chain_rows = (double)N1 * (BURNIN + 1.0 + std::ceil(NSAMPLES / (double)nThreads) * GAP);
-        const int gpus = device >= 0 ? 1 : std::max(1, std::min(ndev, nThreads));
-        const double rows_per_gpu = chain_rows * std::ceil(nThreads / (double)gpus);
-        mode = rows_per_gpu <= 2.5e7 ? RSEM_GIBBS_EXACT : RSEM_GIBBS_PARALLEL;
-    }
+    if (mode_s == "exact") {
+        mode = RSEM_GIBBS_EXACT;
+        if (rows_per_gpu > kExactBudget)  // honoured, but never silently: this can be hours
+            fprintf(stderr, "Warning: --gibbs-mode exact on %.3g read-rounds per GPU will take about %.0f s (one wave per chain, chains in "
+                            "sequence); --gibbs-mode parallel samples the same posterior in a fraction of that.\n",
+                    rows_per_gpu, rows_per_gpu * 0.4e-6);
+    } else if (mode_s == "parallel") mode = RSEM_GIBBS_PARALLEL;
+    else mode = rows_per_gpu <= kExactBudget ? RSEM_GIBBS_EXACT : RSEM_GIBBS_PARALLEL;  // auto: exact only when it is cheap
     if (thin <= 0) thin = (mode == RSEM_GIBBS_PARALLEL) ? 8 : 1;
+    if (dry_run) {
+        printf("dry run: %s sampler, %d chain(s), %d sweep(s) per round, N1 = %llu, M = %d\n", mode == RSEM_GIBBS_EXACT ? "exact" : "parallel",
+               nThreads, mode == RSEM_GIBBS_PARALLEL ? thin : 1, (unsigned long long)N1, M);
+        return 0;
+    }
     if (verbose) printf("Gibbs started! (%s sampler, %d chain(s), %d GPU(s))\n", mode == RSEM_GIBBS_EXACT ? "exact" : "parallel", nThreads, ndev);
 
     // chain seeds: engineFactory (sampling.h:19-44); without --seed the reference seeds from time(NULL)
