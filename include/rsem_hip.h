@@ -42,6 +42,30 @@ int rsem_hip_warmup(int device);
 int rsem_hip_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Communicators of the multi-GPU paths.  The reference's parallelism is pthreads over one address
+ * space: its "collectives" are the serial sums countvs[0][j] += countvs[i][j] (EM.cpp:385-389) and
+ * pme_c[j] += params[i].pme_c[j] (Gibbs.cpp:372-388).  With the shards / chains on different GPUs
+ * those sums are RCCL collectives enqueued on the ctx stream.  One rank per GPU; the ranks may be
+ * threads of one process (the CLI programs) or one process each (bench.py: the id travels through
+ * torch.distributed).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rsem_comm rsem_comm;
+#define RSEM_COMM_ID_BYTES 128
+/* ncclGetUniqueId: call on one rank, hand the bytes to all the others. */
+int rsem_comm_unique_id(char* id /* RSEM_COMM_ID_BYTES */);
+/* ncclCommInitRank on `device`; collective over all `world` ranks (call concurrently). */
+int rsem_comm_create(rsem_comm** out, int device, int rank, int world, const char* id);
+/* A group of `world` ranks inside one process that may share devices (RCCL refuses two ranks on one GPU): the
+ * exchange goes through the ranks' device buffers with host barriers.  For exercising the sharded paths on a
+ * single-GPU machine; out[world]. */
+int rsem_comm_create_local(rsem_comm** out, int world, const int* devices);
+int rsem_comm_rank(const rsem_comm* comm);
+int rsem_comm_world(const rsem_comm* comm);
+/* In-place sum of n doubles at device pointer d_buf over all ranks, ordered on `stream` (tests / tools). */
+int rsem_comm_allreduce_f64(rsem_comm* comm, void* d_buf, uint64_t n, void* stream);
+int rsem_comm_destroy(rsem_comm* comm);
+
+/* ------------------------------------------------------------------------------------------
  * EM (rsem-run-em).  Replaces: HitContainer<HitType> (HitContainer.h:12-59, SingleHit.h:8-51),
  * init<> sharding (EM.cpp:97-174), E_STEP<> (EM.cpp:176-247) and the count reduction / M step /
  * convergence test of EM<> (EM.cpp:383-416).
@@ -201,17 +225,39 @@ int rsem_gibbs_create(rsem_gibbs_ctx** out, int device, int32_t M, uint64_t N1, 
                       const uint64_t* row_ptr, const int32_t* sid, const double* conprb,
                       const int32_t* init_counts, const double* alpha, double pseudoC, double totc,
                       uint64_t N0, const double* eel, const double* mw, int32_t m, const int32_t* grp);
-/* Run one chain.  count_vectors: nsamples x (M+1) int32 or NULL.  The five accumulators receive
- * this chain's SUMS (not divided; Gibbs.cpp:322-345), overwriting their previous contents. */
+/* Per-run measurements filled by rsem_gibbs_run_chains when non-NULL (HIP events on the ctx stream). */
+typedef struct {
+    double total_ms;   /* first sweep .. last per-sample statistics kernel */
+    double sweep_ms;   /* total_ms / sweeps */
+    int64_t sweeps;    /* EXACT: rounds (every chain advances in each); PARALLEL: z passes summed over the chains */
+    int32_t chains;
+} rsem_gibbs_profile;
+
+/* Run nchains independent chains on this GPU -- the reference's worker threads (Gibbs.cpp:207-254): chain k starts
+ * from MT19937(seeds[k]) (EXACT) / Philox keyed by seeds[k] (PARALLEL), keeps nsamples[k] samples after `burnin`
+ * rounds, one every `gap` rounds.  EXACT: one wave per chain, all chains in every launch.  PARALLEL: one chain after
+ * the other (a sweep fills the GPU).  count_vectors: NULL, or nchains host pointers (each NULL or nsamples[k] x (M+1)
+ * int32 = the lines of imd.countvectors<k>, Gibbs.cpp:257-262).  The accumulators receive the SUMS over the kept
+ * samples of all chains, added in chain order (release(), Gibbs.cpp:372-388; not yet divided): pme_c, pve_c (sum of
+ * squares), pme_tpm, pme_fpkm [M+1], pve_c_genes [m], pve_c_trans [m_trans] (NULL unless allele groups are set).
+ * With rsem_gibbs_set_comm the sums are additionally reduced over the communicator and valid on rank 0 only. */
+int rsem_gibbs_run_chains(rsem_gibbs_ctx* ctx, int mode, int nchains, const uint32_t* seeds, int burnin,
+                          const int32_t* nsamples, int gap, int thin /* PARALLEL only: z passes per round, >= 1 */,
+                          int32_t* const* count_vectors, double* pme_c, double* pve_c, double* pme_tpm,
+                          double* pme_fpkm, double* pve_c_genes, double* pve_c_trans, rsem_gibbs_profile* prof);
+/* One chain: rsem_gibbs_run_chains with nchains = 1 (sweep_ms may be NULL). */
 int rsem_gibbs_run(rsem_gibbs_ctx* ctx, int mode, uint32_t seed, int burnin, int nsamples, int gap,
-                   int thin /* PARALLEL only: internal sweeps per counted round, >=1 */,
-                   int32_t* count_vectors, double* pme_c, double* pve_c, double* pme_tpm,
+                   int thin, int32_t* count_vectors, double* pme_c, double* pve_c, double* pme_tpm,
                    double* pme_fpkm, double* pve_c_genes, double* sweep_ms /* may be NULL */);
 /* Allele-specific references (ref.ta, GroupInfo.h): ta[m_trans+1] = first allele of every transcript.  After this
  * call every rsem_gibbs_run also accumulates, per kept sample, the squared per-transcript count sums
  * (pve_c_trans, Gibbs.cpp:339-345); rsem_gibbs_get_pve_c_trans returns the last run's sums [m_trans]. */
 int rsem_gibbs_set_allele_groups(rsem_gibbs_ctx* ctx, int32_t m_trans, const int32_t* ta);
 int rsem_gibbs_get_pve_c_trans(rsem_gibbs_ctx* ctx, double* pve_c_trans);
+/* Chains sharded over GPUs: every later rsem_gibbs_run_chains ends with ONE reduce of its
+ * accumulator sums to rank 0 of `comm` (RCCL over xGMI), replacing the host loop of release() (Gibbs.cpp:372-388).
+ * Count vectors need no communication: a rank writes the files of its own chains.  comm is not owned; NULL detaches. */
+int rsem_gibbs_set_comm(rsem_gibbs_ctx* ctx, rsem_comm* comm);
 int rsem_gibbs_destroy(rsem_gibbs_ctx* ctx);
 /* sampling.h:19-44: seeds of the first nchains chains for --seed seed. */
 int rsem_gibbs_chain_seeds(uint32_t seed, int nchains, uint32_t* out);

@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librsem_hip.so")
 BIN = os.path.join(HERE, "bin")
 
-HIP_SOURCES = ["status.hip", "em.hip", "gibbs.hip", "model.hip", "ci.hip"]
+HIP_SOURCES = ["status.hip", "comm.hip", "em.hip", "gibbs.hip", "model.hip", "ci.hip"]
 HOST_PROGRAMS = {"rsem-run-em": ["host/run_em.cpp"], "rsem-run-gibbs": ["host/run_gibbs.cpp"],
                  "rsem-calculate-credibility-intervals": ["host/calc_ci.cpp"]}
 # stages around the hot path that never touch the GPU: plain g++, no librsem_hip dependency
@@ -60,7 +60,7 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError("compile failed: " + " ".join(cmd))
     if force or _stale(LIB, objs):
-        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

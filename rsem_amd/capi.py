@@ -28,6 +28,10 @@ class CiProfile(C.Structure):
                 ("n_draws", C.c_uint64), ("n_keys_sorted", C.c_uint64)]
 
 
+class GibbsProfile(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("sweep_ms", C.c_double), ("sweeps", C.c_int64), ("chains", C.c_int32)]
+
+
 class EmProfile(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("estep_ms_sum", C.c_double), ("estep_launches", C.c_int32),
                 ("rounds", C.c_int32), ("algorithmic_bytes_per_round", C.c_uint64)]
@@ -61,7 +65,17 @@ def lib():
         L.rsem_gibbs_create.argtypes = [C.POINTER(vp), ci, i32, u64, u64, _u64p, _i32p, _f64p, _i32p, vp, dbl, dbl, u64,
                                         _f64p, _f64p, i32, _i32p]
         L.rsem_gibbs_run.argtypes = [vp, ci, C.c_uint32, ci, ci, ci, ci, vp, _f64p, _f64p, _f64p, _f64p, _f64p, vp]
+        L.rsem_gibbs_run_chains.argtypes = [vp, ci, ci, _u32p, ci, _i32p, ci, ci, vp, _f64p, _f64p, _f64p, _f64p, _f64p, vp, vp]
+        L.rsem_gibbs_set_comm.argtypes = [vp, vp]
+        L.rsem_gibbs_set_allele_groups.argtypes = [vp, i32, _i32p]
         L.rsem_gibbs_destroy.argtypes = [vp]
+        L.rsem_comm_unique_id.argtypes = [C.c_char_p]
+        L.rsem_comm_create.argtypes = [C.POINTER(vp), ci, ci, ci, C.c_char_p]
+        L.rsem_comm_create_local.argtypes = [C.POINTER(vp), ci, C.POINTER(ci)]
+        L.rsem_comm_rank.argtypes = [vp]
+        L.rsem_comm_world.argtypes = [vp]
+        L.rsem_comm_allreduce_f64.argtypes = [vp, vp, u64, vp]
+        L.rsem_comm_destroy.argtypes = [vp]
         L.rsem_gibbs_chain_seeds.argtypes = [C.c_uint32, ci, _u32p]
         L.rsem_ci_calculate.argtypes = [ci, i32, i32, i32, _i32p, _f64p, _f64p, dbl, u64, dbl, i32, _i32p, i32, vp,
                                         _f32p, _f32p, _f32p, _f32p, vp, vp, vp]
@@ -193,6 +207,78 @@ class GibbsContext:
         _check(lib().rsem_gibbs_run(self._h, mode, int(seed), burnin, nsamples, gap, thin, _ptr(cv), *acc,
                                     C.cast(C.pointer(ms), C.c_void_p)))
         return cv, acc, ms.value
+
+    def set_comm(self, comm):
+        _check(lib().rsem_gibbs_set_comm(self._h, comm._h if comm is not None else None))
+
+    def set_allele_groups(self, ta):
+        ta = np.ascontiguousarray(ta, np.int32)
+        self.m_trans = len(ta) - 1
+        _check(lib().rsem_gibbs_set_allele_groups(self._h, self.m_trans, ta))
+
+    def run_chains(self, mode, seeds, burnin, nsamples, gap, thin=1, want_vectors=True):
+        """rsem_gibbs_run_chains: all chains of this GPU in one call.  Returns (list of count-vector arrays or None,
+        [pme_c, pve_c, pme_tpm, pme_fpkm, pve_c_genes] summed over the chains, pve_c_trans or None, GibbsProfile)."""
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        ns = np.ascontiguousarray(nsamples, np.int32)
+        n = len(seeds)
+        assert len(ns) == n
+        cvs, ptrs = None, None
+        if want_vectors:
+            cvs = [np.zeros((int(k), self.M + 1), np.int32) for k in ns]
+            ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in cvs])
+        acc = [np.zeros(self.M + 1) for _ in range(4)] + [np.zeros(self.m)]
+        mt = getattr(self, "m_trans", 0)
+        trans = np.zeros(mt) if mt else None
+        prof = GibbsProfile()
+        _check(lib().rsem_gibbs_run_chains(self._h, mode, n, seeds, burnin, ns, gap, thin, ptrs, *acc, _ptr(trans),
+                                           C.cast(C.pointer(prof), C.c_void_p)))
+        return cvs, acc, trans, prof
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """rsem_comm: one rank of a communicator (RCCL, or the same-process LOCAL kind)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(lib().rsem_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def create(cls, device, rank, world, uid):
+        h = C.c_void_p()
+        _check(lib().rsem_comm_create(C.byref(h), device, rank, world, uid))
+        return cls(h)
+
+    @classmethod
+    def create_local(cls, devices):
+        n = len(devices)
+        hs = (C.c_void_p * n)()
+        _check(lib().rsem_comm_create_local(hs, n, (C.c_int * n)(*devices)))
+        return [cls(C.c_void_p(h)) for h in hs]
+
+    @property
+    def rank(self):
+        return lib().rsem_comm_rank(self._h)
+
+    @property
+    def world(self):
+        return lib().rsem_comm_world(self._h)
+
+    def allreduce(self, d_ptr, n, stream=0):
+        _check(lib().rsem_comm_allreduce_f64(self._h, d_ptr, n, stream))
+
+    def close(self):
+        if self._h:
+            lib().rsem_comm_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 def gibbs_chain_seeds(seed, n):

@@ -25,6 +25,9 @@
 // calcExpressionValues (WriteResults.h:55-104) and the running sums -- on the device.
 #include <cmath>
 
+#include <cstdlib>
+
+#include "comm_internal.hpp"
 #include "rng.hpp"
 #include "sell_layout.hpp"
 
@@ -52,11 +55,6 @@ __global__ void k_sample_theta(int32_t M, int32_t* __restrict__ counts, const do
 __global__ void k_fill_double(int32_t n, double v, double* g) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) g[i] = v;
-}
-
-__global__ void k_reset_counts(int32_t M, const int32_t* __restrict__ init_counts, int32_t n0, int32_t* counts) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= M) counts[i] = init_counts[i] + (i == 0 ? n0 : 0);
 }
 
 constexpr int kGWindow = 2048;  // sids per workgroup window (g values: 16 KB, int counts: 8 KB of LDS)
@@ -272,12 +270,31 @@ __global__ void k_sample_z_long(uint32_t n_rows, const uint32_t* __restrict__ ro
     atomicAdd(&counts[pick], 1);
 }
 
-// ---- EXACT mode: the reference chain on one wave ------------------------------------------------
+// ---- EXACT mode: the reference chain, one wave per chain, all chains of a GPU in one launch -----------
+//
+// The chain is sequential from read to read only through `counts`, and one visit changes at most two of its entries
+// (counts[z_old]--, counts[z_new]++).  k_gibbs_exact_coop therefore evaluates a TILE of up to 64 consecutive reads
+// speculatively, one read per lane, against the counts as they were before the tile, and then commits them in file
+// order: only reads whose draw actually changed their transcript are walked (a ballot mask), each of them broadcasts
+// its (z_old, z_new) pair, later lanes whose transcript range contains one of the two patch their private copy of the
+// counts and redo their draw with the SAME random number.  The result is the reference chain itself -- same visiting
+// order, same left-to-right cumulative sums (one lane sums one read), same MT19937 stream (read r of the tile takes the
+// r-th next output) -- hence the same integer count vectors bit for bit (tests/test_gibbs_gpu.py, tests/test_cli_gpu.py
+// against the reference's own countvectors files).  k_gibbs_exact_serial is the previous kernel (lane 0 walks, the
+// other lanes stage): kept as the cross-check (RSEM_GIBBS_EXACT_IMPL=serial).
 
 constexpr int kTileRows = 64;
-constexpr int kTileItems = 3072;
+constexpr int kTileItems = 2048;
 
 struct MtState { uint32_t mt[624]; int idx; };
+
+__device__ inline uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
 
 __device__ inline uint32_t mt_next(uint32_t* mt, int& idx) {  // lane 0 only; mt in LDS
     if (idx >= 624) {
@@ -287,27 +304,229 @@ __device__ inline uint32_t mt_next(uint32_t* mt, int& idx) {  // lane 0 only; mt
         }
         idx = 0;
     }
-    uint32_t y = mt[idx++];
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
+    return mt_temper(mt[idx++]);
 }
 
-// One sweep over all reads in file order (Gibbs.cpp:297-311), or the initial assignment
-// (Gibbs.cpp:281-291) when kInit.  blockDim = 64.
+// The in-place twist of all 624 words by one wave, 64 words per pass in increasing order.  Word k needs the OLD k+1
+// (same pass: every lane reads before any lane writes; next pass: not yet written) and word (k+397)%624, which is old
+// for k < 227 (indices >= 397, written by later passes) and new for k >= 227 (index k-227, at least one pass back);
+// k = 623 needs the new words 0 and 396.  So the plain pass order reproduces the sequential loop.
+__device__ inline void mt_regen_wave(uint32_t* mt, int lane) {
+    for (int k0 = 0; k0 < 624; k0 += 64) {
+        const int k = k0 + lane;
+        uint32_t v = 0;
+        if (k < 624) {
+            const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+            v = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        __syncthreads();
+        if (k < 624) mt[k] = v;
+        __syncthreads();
+    }
+}
+
+// One sweep over all reads in file order (Gibbs.cpp:297-311), or the initial assignment (Gibbs.cpp:281-291) when
+// kInit.  grid = chains, blockDim = 64.  Chain c owns counts_base + c * stride_c, z_base + c * stride_z, mt_base[c]
+// and takes part in rounds 1 .. last_round[c].
 template <bool kInit>
-__global__ __launch_bounds__(64) void k_gibbs_exact(uint64_t N1, const uint64_t* __restrict__ row_ptr,
-                                                     const int32_t* __restrict__ sid,
-                                                     const double* __restrict__ cp, int32_t* counts, int32_t* z,
-                                                     const double* __restrict__ alpha, double pseudoC,
-                                                     MtState* mt_state) {
+__global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint64_t* __restrict__ row_ptr,
+                                                          const int32_t* __restrict__ sid, const double* __restrict__ cp,
+                                                          int32_t* counts_base, int32_t* z_base,
+                                                          const double* __restrict__ alpha, double pseudoC, MtState* mt_base,
+                                                          const int32_t* __restrict__ last_round, int round, uint64_t stride_c,
+                                                          uint64_t stride_z) {
+    const int chain = blockIdx.x;
+    if (round > last_round[chain]) return;
+    int32_t* counts = counts_base + (uint64_t)chain * stride_c;
+    int32_t* z = z_base + (uint64_t)chain * stride_z;
+    MtState* mt_state = mt_base + chain;
     __shared__ uint32_t mt[624];
     __shared__ uint64_t t_rp[kTileRows + 1];
     __shared__ int32_t t_sid[kTileItems];
-    __shared__ double t_cp[kTileItems];
-    __shared__ double arr[kTileItems];
+    __shared__ double t_p[kTileItems];
+    __shared__ int32_t t_c[kTileItems];
+    __shared__ double t_al[kTileItems];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 624; i += 64) mt[i] = mt_state->mt[i];
+    int idx = mt_state->idx;  // wave-uniform
+    __syncthreads();
+
+    // weight of item j of this lane's read under its private view of the counts
+    auto weight = [&](uint32_t j) -> double {
+        if (kInit) return t_p[j];
+        return ((double)t_c[j] + (alpha ? t_al[j] : pseudoC)) * t_p[j];
+    };
+    // sample() of sampling.h:50-65 on arr[k] = arr[k-1] + weight_k: the index of the first partial sum > prb, which for
+    // a non-decreasing array is the number of partial sums <= prb (what the binary search there finds), capped at len-1
+    auto draw = [&](uint32_t fr, int len, uint32_t rnd) -> int {
+        double cum = 0.0;
+        for (int k = 0; k < len; k++) {
+            const double a = weight(fr + k);
+            cum = (k == 0) ? a : cum + a;
+        }
+        const double prb = ((double)rnd * (1.0 / 4294967296.0)) * cum;
+        int cnt = 0;
+        double run = 0.0;
+        for (int k = 0; k < len; k++) {
+            const double a = weight(fr + k);
+            run = (k == 0) ? a : run + a;
+            cnt += (run <= prb) ? 1 : 0;
+        }
+        const int l = cnt < len ? cnt : len - 1;
+        return t_sid[fr + l];
+    };
+
+    uint64_t i0 = 0;
+    while (i0 < N1) {
+        const int nrt = (int)min((uint64_t)kTileRows, N1 - i0);
+        __syncthreads();  // the previous tile's LDS reads are done
+        t_rp[lane] = row_ptr[i0 + min(lane, nrt)];  // entries past nrt repeat the tile's end
+        if (lane == 0) t_rp[kTileRows] = row_ptr[i0 + nrt];
+        __syncthreads();
+        const uint64_t base = t_rp[0];
+        // reads of this tile = the longest prefix whose items fit the LDS tile
+        const bool fits = lane < nrt && (t_rp[lane + 1] - base) <= (uint64_t)kTileItems;
+        const int nr = __popcll(__ballot(fits));
+        if (nr == 0) {
+            // one read with more items than the tile holds: lane 0 walks it over global memory (two passes)
+            if (lane == 0) {
+                const uint64_t fr = base, to = t_rp[1];
+                const uint64_t len = to - fr;
+                int zo = 0;
+                if (!kInit) {
+                    zo = z[i0];
+                    __hip_atomic_fetch_add(&counts[zo], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                auto wt = [&](uint64_t j) -> double {
+                    const int s = sid[j];
+                    const double p = cp[j];
+                    if (kInit) return p;
+                    const int c = __hip_atomic_load(&counts[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return ((double)c + (alpha ? alpha[s] : pseudoC)) * p;
+                };
+                double tot = 0.0;
+                for (uint64_t j = 0; j < len; j++) { const double a = wt(fr + j); tot = (j == 0) ? a : tot + a; }
+                const double prb = ((double)mt_next(mt, idx) * (1.0 / 4294967296.0)) * tot;
+                double cum = 0.0;
+                uint64_t l = len - 1;
+                for (uint64_t j = 0; j < len; j++) {
+                    const double a = wt(fr + j);
+                    cum = (j == 0) ? a : cum + a;
+                    if (cum > prb) { l = j; break; }
+                }
+                const int zn = sid[fr + l];
+                __hip_atomic_fetch_add(&counts[zn], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                z[i0] = zn;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            idx = __shfl(idx, 0);
+            i0 += 1;
+            continue;
+        }
+        const uint32_t T = (uint32_t)(t_rp[nr] - base);
+        // items of the tile: coalesced loads; the counts as they are now (L2 copy: the updates below are device atomics)
+        for (uint32_t j = lane; j < T; j += 64) {
+            const int s = sid[base + j];
+            t_sid[j] = s;
+            t_p[j] = cp[base + j];
+            if (!kInit) {
+                t_c[j] = __hip_atomic_load(&counts[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (alpha) t_al[j] = alpha[s];
+            }
+        }
+        const bool mine = lane < nr;
+        int z_old = (!kInit && mine) ? z[i0 + lane] : 0;
+        // the next nr MT19937 outputs, read r of the tile takes the r-th (= the order the sequential chain draws them)
+        uint32_t rnd = 0;
+        {
+            if (idx >= 624) { mt_regen_wave(mt, lane); idx = 0; }
+            const int avail = 624 - idx;
+            if (lane < avail && mine) rnd = mt_temper(mt[idx + lane]);
+            if (nr > avail) {
+                __syncthreads();
+                mt_regen_wave(mt, lane);
+                if (lane >= avail && mine) rnd = mt_temper(mt[lane - avail]);
+                idx = nr - avail;
+            } else {
+                idx += nr;
+            }
+        }
+        __syncthreads();  // tile staged
+        const uint32_t fr = mine ? (uint32_t)(t_rp[lane] - base) : 0;
+        const int len = mine ? (int)(t_rp[lane + 1] - t_rp[lane]) : 0;
+        // smallest / largest transcript id of the read (noise, id 0, apart): the commit loop's membership filter
+        int lo = 0x7fffffff, hi = -1;
+        bool has_noise = false;
+        for (int k = 0; k < len; k++) {
+            const int s = t_sid[fr + k];
+            if (s == 0) has_noise = true;
+            else { lo = min(lo, s); hi = max(hi, s); }
+            if (!kInit && s == z_old) t_c[fr + k] -= 1;  // the read leaves its current transcript (Gibbs.cpp:298)
+        }
+        int z_new = mine ? draw(fr, len, rnd) : 0;
+        if (!kInit) {
+            unsigned long long changed = __ballot(mine && z_new != z_old);
+            while (changed) {
+                const int r1 = __ffsll((long long)changed) - 1;
+                const int zo = __shfl(z_old, r1), zn = __shfl(z_new, r1);
+                changed &= ~(1ull << r1);
+                // later reads see counts[zo] - 1 and counts[zn] + 1
+                bool hit = false;
+                if (mine && lane > r1) {
+                    const bool in_o = (zo == 0) ? has_noise : (zo >= lo && zo <= hi);
+                    const bool in_n = (zn == 0) ? has_noise : (zn >= lo && zn <= hi);
+                    if (in_o || in_n) {
+                        for (int k = 0; k < len; k++) {
+                            const int s = t_sid[fr + k];
+                            const int d = (s == zn ? 1 : 0) - (s == zo ? 1 : 0);
+                            if (d != 0) { t_c[fr + k] += d; hit = true; }
+                        }
+                    }
+                }
+                if (__ballot(hit)) {
+                    if (hit) z_new = draw(fr, len, rnd);
+                    const unsigned long long later = (r1 >= 63) ? 0ull : (~0ull << (r1 + 1));
+                    changed = __ballot(mine && z_new != z_old) & later;
+                }
+            }
+            if (mine && z_new != z_old) {
+                __hip_atomic_fetch_add(&counts[z_old], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&counts[z_new], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                z[i0 + lane] = z_new;
+            }
+        } else if (mine) {
+            __hip_atomic_fetch_add(&counts[z_new], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            z[i0 + lane] = z_new;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the updates are in L2 before the next tile reads the counts
+        i0 += (uint64_t)nr;
+    }
+    __syncthreads();
+    for (int i = lane; i < 624; i += 64) mt_state->mt[i] = mt[i];
+    if (lane == 0) mt_state->idx = idx;
+}
+
+constexpr int kSerialTileItems = 3072;
+
+// The previous implementation: lane 0 walks the chain, the other 63 lanes stage the next tile of reads into LDS.
+template <bool kInit>
+__global__ __launch_bounds__(64) void k_gibbs_exact_serial(uint64_t N1, const uint64_t* __restrict__ row_ptr,
+                                                            const int32_t* __restrict__ sid,
+                                                            const double* __restrict__ cp, int32_t* counts_base, int32_t* z_base,
+                                                            const double* __restrict__ alpha, double pseudoC,
+                                                            MtState* mt_base, const int32_t* __restrict__ last_round, int round,
+                                                            uint64_t stride_c, uint64_t stride_z) {
+    const int chain = blockIdx.x;
+    if (round > last_round[chain]) return;
+    int32_t* counts = counts_base + (uint64_t)chain * stride_c;
+    int32_t* z = z_base + (uint64_t)chain * stride_z;
+    MtState* mt_state = mt_base + chain;
+    __shared__ uint32_t mt[624];
+    __shared__ uint64_t t_rp[kTileRows + 1];
+    __shared__ int32_t t_sid[kSerialTileItems];
+    __shared__ double t_cp[kSerialTileItems];
+    __shared__ double arr[kSerialTileItems];
     __shared__ int32_t t_z[kTileRows];
     const int lane = threadIdx.x;
     for (int i = lane; i < 624; i += 64) mt[i] = mt_state->mt[i];
@@ -321,7 +540,7 @@ __global__ __launch_bounds__(64) void k_gibbs_exact(uint64_t N1, const uint64_t*
         __syncthreads();
         const uint64_t base = t_rp[0];
         const uint64_t n_items = t_rp[nr] - base;
-        const bool staged = n_items <= (uint64_t)kTileItems;
+        const bool staged = n_items <= (uint64_t)kSerialTileItems;
         if (staged) {
             for (uint64_t j = lane; j < n_items; j += 64) { t_sid[j] = sid[base + j]; t_cp[j] = cp[base + j]; }
         }
@@ -332,7 +551,7 @@ __global__ __launch_bounds__(64) void k_gibbs_exact(uint64_t N1, const uint64_t*
                 const int len = (int)(to - fr);
                 if (!kInit) --counts[t_z[r]];
                 int l = 0;
-                if (staged || len <= kTileItems) {
+                if (staged || len <= kSerialTileItems) {
                     double cum = 0.0;
                     for (int j = 0; j < len; j++) {
                         int s = staged ? t_sid[fr + j] : sid[base + fr + j];
@@ -382,73 +601,129 @@ __global__ __launch_bounds__(64) void k_gibbs_exact(uint64_t N1, const uint64_t*
 }
 
 // ---- per-sample statistics (Gibbs.cpp:313-346, WriteResults.h:55-104) ---------------------------
+//
+// theta_i = (counts_i + alpha_i) / totc, polishTheta, calcExpressionValues.  Written out, with
+//   t_i = theta_i / mw_i  (0 when i >= 1 and (mw_i < EPS or eel_i < EPS)),  S1 = sum_i t_i,
+//   S2 = sum_{i >= 1, eel_i >= EPS} t_i,  S3 = sum_{i >= 1, eel_i >= EPS} t_i / eel_i:
+//   frac_i = t_i / S1 / denom with denom = S2 / S1 (1 when < EPS); fpkm_i = frac_i * 1e9 / eel_i;
+//   tpm_i = fpkm_i / denom2 * 1e6 with denom2 = sum fpkm (1 when < EPS).
+// Pass A leaves one (S1, S2, S3) partial per workgroup and chain, pass B folds them in a fixed order and adds the
+// sample to the chain's accumulators (and copies the count vector out), so the result does not depend on scheduling.
 
-constexpr int kStatBlock = 1024;
+constexpr int kStatMaxBlocks = 64;
 
-__device__ inline double block_sum_1024(double v) {
-    __shared__ double red[kStatBlock / 64];
+__device__ inline double stat_t(int i, int c, const double* __restrict__ alpha, double pseudoC, double totc,
+                                const double* __restrict__ eel, const double* __restrict__ mw) {
+    double th = (c < 0) ? 0.0 : ((double)c + (alpha ? alpha[i] : pseudoC)) / totc;
+    if (i > 0 && (mw[i] < kEpsilon || eel[i] < kEpsilon)) return 0.0;
+    return th / mw[i];
+}
+
+__device__ inline double block_sum_256(double v) {  // fixed tree
+    __shared__ double red[kBlock / 64];
     __syncthreads();
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     double t = 0.0;
-    for (int i = 0; i < kStatBlock / 64; i++) t += red[i];
+    for (int i = 0; i < kBlock / 64; i++) t += red[i];
     return t;
 }
 
-__global__ __launch_bounds__(kStatBlock) void k_gibbs_stats(int32_t M, const int32_t* __restrict__ counts,
-                                                             const double* __restrict__ alpha, double pseudoC,
-                                                             double totc, const double* __restrict__ eel,
-                                                             const double* __restrict__ mw, double* tmp,
-                                                             double* pme_c, double* pve_c, double* pme_tpm,
-                                                             double* pme_fpkm) {
-    // theta = (counts + alpha) / totc, then polishTheta
-    double s = 0.0;
-    for (int i = threadIdx.x; i <= M; i += blockDim.x) {
-        int c = counts[i];
-        double th = (c < 0) ? 0.0 : ((double)c + (alpha ? alpha[i] : pseudoC)) / totc;
-        if (i > 0 && (mw[i] < kEpsilon || eel[i] < kEpsilon)) th = 0.0;
-        else th = th / mw[i];
-        tmp[i] = th;
-        s += th;
+// grid (nblk, chains); chain c takes part while kept < nsamples[c]
+__global__ __launch_bounds__(kBlock) void k_gibbs_stats_a(int32_t M, const int32_t* __restrict__ counts_base, uint64_t stride_c,
+                                                           int chain0, const int32_t* __restrict__ nsamples, int kept,
+                                                           const double* __restrict__ alpha, double pseudoC, double totc,
+                                                           const double* __restrict__ eel, const double* __restrict__ mw,
+                                                           double* partials) {
+    const int chain = chain0 + blockIdx.y;
+    if (kept >= nsamples[chain]) return;
+    const int32_t* counts = counts_base + (uint64_t)chain * stride_c;
+    const int n = M + 1, nb = gridDim.x;
+    const int per = (n + nb - 1) / nb;
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const double t = stat_t(i, counts[i], alpha, pseudoC, totc, eel, mw);
+        s1 += t;
+        if (i >= 1 && eel[i] >= kEpsilon) { s2 += t; s3 += t / eel[i]; }
     }
-    const double sum = block_sum_1024(s);
-    // calcExpressionValues: frac over eel >= EPS (i >= 1)
-    double d1 = 0.0;
-    for (int i = threadIdx.x; i <= M; i += blockDim.x) {
-        double th = tmp[i] / sum;
-        double fr = (i >= 1 && eel[i] >= kEpsilon) ? th : 0.0;
-        tmp[i] = fr;
-        d1 += fr;
+    s1 = block_sum_256(s1);
+    s2 = block_sum_256(s2);
+    s3 = block_sum_256(s3);
+    if (threadIdx.x == 0) {
+        double* p = partials + ((uint64_t)chain * kStatMaxBlocks + blockIdx.x) * 3;
+        p[0] = s1; p[1] = s2; p[2] = s3;
     }
-    double denom = block_sum_1024(d1);
+}
+
+__global__ __launch_bounds__(kBlock) void k_gibbs_stats_b(int32_t M, const int32_t* __restrict__ counts_base, uint64_t stride_c,
+                                                           int chain0, const int32_t* __restrict__ nsamples, int kept,
+                                                           const double* __restrict__ alpha, double pseudoC, double totc,
+                                                           const double* __restrict__ eel, const double* __restrict__ mw,
+                                                           const double* __restrict__ partials, double* acc_base,
+                                                           int32_t* cv_base, const uint64_t* __restrict__ cv_off) {
+    const int chain = chain0 + blockIdx.y;
+    if (kept >= nsamples[chain]) return;
+    const int32_t* counts = counts_base + (uint64_t)chain * stride_c;
+    const int n = M + 1, nb = gridDim.x;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int b = 0; b < nb; b++) {
+        const double* p = partials + ((uint64_t)chain * kStatMaxBlocks + b) * 3;
+        s1 += p[0]; s2 += p[1]; s3 += p[2];
+    }
+    double denom = s2 / s1;
     if (denom < kEpsilon) denom = 1.0;
-    double d2 = 0.0;
-    for (int i = threadIdx.x; i <= M; i += blockDim.x) {
-        double fp = 0.0;
-        if (i >= 1 && eel[i] >= kEpsilon) fp = (tmp[i] / denom) * 1e9 / eel[i];
-        tmp[i] = fp;
-        d2 += fp;
-    }
-    double denom2 = block_sum_1024(d2);
+    double denom2 = (s3 / s1 / denom) * 1e9;
     if (denom2 < kEpsilon) denom2 = 1.0;
-    for (int i = threadIdx.x; i <= M; i += blockDim.x) {
-        double c = (double)counts[i];
-        double fp = tmp[i];
+    double* pme_c = acc_base + (uint64_t)chain * 4 * n;
+    double* pve_c = pme_c + n;
+    double* pme_tpm = pve_c + n;
+    double* pme_fpkm = pme_tpm + n;
+    int32_t* cv = cv_base ? cv_base + cv_off[chain] + (uint64_t)kept * n : nullptr;
+    const int per = (n + nb - 1) / nb;
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int ci = counts[i];
+        double fp = 0.0;
+        if (i >= 1 && eel[i] >= kEpsilon) fp = (stat_t(i, ci, alpha, pseudoC, totc, eel, mw) / s1 / denom) * 1e9 / eel[i];
+        const double c = (double)ci;
         pme_c[i] += c;
         pve_c[i] += c * c;
         pme_fpkm[i] += fp;
         pme_tpm[i] += (i >= 1) ? fp / denom2 * 1e6 : 0.0;
+        if (cv) cv[i] = ci;
     }
 }
 
-__global__ void k_gibbs_gene_stats(int32_t m, const int32_t* __restrict__ grp, const int32_t* __restrict__ counts,
-                                   double* pve_c_genes) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// squared per-group count sums (genes, or transcripts over alleles): grid (ceil(m/256), chains)
+__global__ void k_gibbs_group_stats(int32_t m, const int32_t* __restrict__ grp, const int32_t* __restrict__ counts_base,
+                                    uint64_t stride_c, int chain0, const int32_t* __restrict__ nsamples, int kept,
+                                    double* acc_base) {
+    const int chain = chain0 + blockIdx.y;
+    if (kept >= nsamples[chain]) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
+    const int32_t* counts = counts_base + (uint64_t)chain * stride_c;
     double c = 0.0;
     for (int j = grp[i]; j < grp[i + 1]; j++) c += (double)counts[j];
-    pve_c_genes[i] += c * c;
+    acc_base[(uint64_t)chain * m + i] += c * c;
+}
+
+// per-chain state for the start of a run
+__global__ void k_reset_chains(int32_t M, const int32_t* __restrict__ init_counts, int32_t n0, int32_t* counts_base,
+                               uint64_t stride_c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= M) counts_base[(uint64_t)blockIdx.y * stride_c + i] = init_counts[i] + (i == 0 ? n0 : 0);
+}
+
+// out[i] = sum over chains, in chain order (release(), Gibbs.cpp:372-388)
+__global__ void k_sum_chains(uint64_t n, int nchains, uint64_t stride, const double* __restrict__ acc_base, double* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int c = 0; c < nchains; c++) s += acc_base[(uint64_t)c * stride + i];
+    out[i] = s;
 }
 
 void host_mt_seed(MtState& g, uint32_t seed) {  // boost::random::mt19937 seeding
@@ -482,11 +757,13 @@ struct rsem_gibbs_ctx {
     double pseudoC = 1.0, totc = 0.0;
     hipStream_t stream = nullptr;
     int n_cus = 256;
+    rsem_comm* comm = nullptr;  // not owned: chain sums are reduced to rank 0 when set
     // items exactly as given (noise column inline): EXACT mode
     uint64_t* d_irp = nullptr;
     int32_t* d_isid = nullptr;
     double* d_icp = nullptr;
-    // noise split out: PARALLEL mode
+    // PARALLEL mode, built on the device at its first use: noise split out + the sliced layout
+    bool have_parallel = false;
     uint64_t* d_row_ptr = nullptr;
     int32_t* d_sid = nullptr;
     double* d_cp = nullptr;
@@ -496,24 +773,142 @@ struct rsem_gibbs_ctx {
     double* d_sncp = nullptr;
     Unit* d_units = nullptr;
     uint32_t n_units = 0;
-    // state
-    int32_t* d_init_counts = nullptr;
-    int32_t* d_counts = nullptr;
-    int32_t* d_z = nullptr;
     double* d_g = nullptr;
+    // shared by all chains
+    int32_t* d_init_counts = nullptr;
     double* d_alpha = nullptr;
     double* d_eel = nullptr;
     double* d_mw = nullptr;
     int32_t* d_grp = nullptr;
-    double* d_tmp = nullptr;
-    double* d_acc[4] = {nullptr, nullptr, nullptr, nullptr};
-    double* d_acc_genes = nullptr;
-    MtState* d_mt = nullptr;
     // allele-specific: transcript groups over alleles
     int32_t m_trans = 0;
     int32_t* d_ta = nullptr;
-    double* d_acc_trans = nullptr;
+    std::vector<double> last_pve_c_trans;
 };
+
+namespace {
+
+// device memory / events released on every exit path of a run
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <typename T> T* as() const { return (T*)p; }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 8)); }
+};
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+
+// noise column (sid 0) of every read summed into ncp, the other items counted: thread per read
+__global__ void k_split_count(uint64_t N1, int32_t M, const uint64_t* __restrict__ irp, const int32_t* __restrict__ isid,
+                              const double* __restrict__ icp, uint64_t* nh, double* ncp, int* err) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N1) return;
+    const uint64_t fr = irp[i], to = irp[i + 1];
+    if (to <= fr) { *err = (to < fr) ? 1 : 3; nh[i] = 0; ncp[i] = 0.0; return; }
+    uint64_t n = 0;
+    double nc = 0.0;
+    for (uint64_t j = fr; j < to; j++) {
+        const int s = isid[j];
+        if (s < 0 || s > M) { *err = 2; continue; }
+        if (s == 0) nc += icp[j];
+        else ++n;
+    }
+    nh[i] = n;
+    ncp[i] = nc;
+}
+
+__global__ void k_split_fill(uint64_t N1, const uint64_t* __restrict__ irp, const int32_t* __restrict__ isid,
+                             const double* __restrict__ icp, const uint64_t* __restrict__ rp, int32_t* sid, double* cp) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N1) return;
+    uint64_t o = rp[i];
+    for (uint64_t j = irp[i]; j < irp[i + 1]; j++) {
+        const int s = isid[j];
+        if (s > 0) { sid[o] = s; cp[o] = icp[j]; ++o; }
+    }
+}
+
+// items CSR sanity (the EXACT kernels index counts[] with these ids): thread per read
+__global__ void k_check_items(uint64_t N1, int32_t M, const uint64_t* __restrict__ irp, const int32_t* __restrict__ isid, int* err) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N1) return;
+    const uint64_t fr = irp[i], to = irp[i + 1];
+    if (to < fr) { *err = 1; return; }
+    if (to == fr) { *err = 3; return; }
+    for (uint64_t j = fr; j < to; j++)
+        if (isid[j] < 0 || isid[j] > M) *err = 2;
+}
+
+int items_error(int code) {
+    rsem::set_last_error(code == 1 ? "row_ptr is not monotone" : code == 2 ? "sid outside 0..M" : "a read without any item cannot be sampled");
+    return RSEM_ERR_INVALID;
+}
+
+// PARALLEL mode's structures, all built on the device from the items CSR
+int ensure_parallel_layout(rsem_gibbs_ctx* c) {
+    if (c->have_parallel) return RSEM_OK;
+    hipStream_t st = c->stream;
+    const uint64_t N1 = c->N1;
+    DevBuf nh, err, tmp;
+    RSEM_HIP_TRY(nh.alloc(sizeof(uint64_t) * (N1 + 1)));
+    RSEM_HIP_TRY(err.alloc(sizeof(int)));
+    RSEM_HIP_TRY(hipMemsetAsync(err.p, 0, sizeof(int), st));
+    RSEM_HIP_TRY(hipMemsetAsync(nh.p, 0, sizeof(uint64_t) * (N1 + 1), st));
+    RSEM_HIP_TRY(dmalloc(&c->d_row_ptr, N1 + 1));
+    RSEM_HIP_TRY(dmalloc(&c->d_ncp, N1));
+    if (N1) {
+        hipLaunchKernelGGL(k_split_count, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, c->M, c->d_irp, c->d_isid, c->d_icp,
+                           nh.as<uint64_t>(), c->d_ncp, err.as<int>());
+        RSEM_HIP_TRY(hipGetLastError());
+    }
+    size_t tb = 0;
+    RSEM_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, nh.as<uint64_t>(), c->d_row_ptr, N1 + 1, st));
+    RSEM_HIP_TRY(tmp.alloc(tb));
+    RSEM_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, nh.as<uint64_t>(), c->d_row_ptr, N1 + 1, st));
+    uint64_t nhits = 0;
+    int h_err = 0;
+    RSEM_HIP_TRY(hipMemcpyAsync(&nhits, c->d_row_ptr + N1, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipStreamSynchronize(st));
+    if (h_err) return items_error(h_err);
+    c->nhits = nhits;
+    RSEM_HIP_TRY(dmalloc(&c->d_sid, nhits));
+    RSEM_HIP_TRY(dmalloc(&c->d_cp, nhits));
+    if (N1) {
+        hipLaunchKernelGGL(k_split_fill, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, c->d_irp, c->d_isid, c->d_icp,
+                           c->d_row_ptr, c->d_sid, c->d_cp);
+        RSEM_HIP_TRY(hipGetLastError());
+    }
+    int rc = sell_build(c->L, st, N1, c->M, c->d_row_ptr, c->d_sid, (uint32_t)c->n_cus * 4 * 6 * 5 / 2);
+    if (rc != RSEM_OK) return rc;
+    RSEM_HIP_TRY(dmalloc(&c->d_scp, c->L.n_planes * 64));
+    RSEM_HIP_TRY(dmalloc(&c->d_sncp, (size_t)c->L.n_slots));
+    rc = sell_fill_values(c->L, st, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_scp, c->d_sncp);
+    if (rc != RSEM_OK) return rc;
+    RSEM_HIP_TRY(hipStreamSynchronize(st));
+    std::vector<Unit> units;
+    rc = sell_build_units(c->L, units, kGWindow);
+    if (rc != RSEM_OK) return rc;
+    c->n_units = (uint32_t)units.size();
+    RSEM_HIP_TRY(dmalloc(&c->d_units, units.size()));
+    if (!units.empty()) RSEM_HIP_TRY(hipMemcpy(c->d_units, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice));
+    RSEM_HIP_TRY(dmalloc(&c->d_g, (size_t)c->M + 1));
+    if (c->L.n_long_rows == 0) {  // the split CSR was only needed to build the slices
+        hipFree(c->d_sid); hipFree(c->d_cp); hipFree(c->d_row_ptr); hipFree(c->d_ncp);
+        c->d_sid = nullptr; c->d_cp = nullptr; c->d_row_ptr = nullptr; c->d_ncp = nullptr;
+    }
+    c->have_parallel = true;
+    return RSEM_OK;
+}
+
+bool exact_serial_requested() {
+    const char* e = getenv("RSEM_GIBBS_EXACT_IMPL");
+    return e && !strcmp(e, "serial");
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -536,10 +931,9 @@ int rsem_gibbs_destroy(rsem_gibbs_ctx* c) {
     (void)hipSetDevice(c->device);
     hipFree(c->d_irp); hipFree(c->d_isid); hipFree(c->d_icp); hipFree(c->d_row_ptr); hipFree(c->d_sid);
     hipFree(c->d_cp); hipFree(c->d_ncp); sell_free(c->L); hipFree(c->d_scp); hipFree(c->d_sncp);
-    hipFree(c->d_init_counts); hipFree(c->d_counts); hipFree(c->d_z); hipFree(c->d_g); hipFree(c->d_alpha);
-    hipFree(c->d_eel); hipFree(c->d_mw); hipFree(c->d_grp); hipFree(c->d_tmp);
-    for (int i = 0; i < 4; i++) hipFree(c->d_acc[i]);
-    hipFree(c->d_acc_genes); hipFree(c->d_mt); hipFree(c->d_units); hipFree(c->d_ta); hipFree(c->d_acc_trans);
+    hipFree(c->d_init_counts); hipFree(c->d_g); hipFree(c->d_alpha);
+    hipFree(c->d_eel); hipFree(c->d_mw); hipFree(c->d_grp);
+    hipFree(c->d_units); hipFree(c->d_ta);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RSEM_OK;
@@ -548,21 +942,28 @@ int rsem_gibbs_destroy(rsem_gibbs_ctx* c) {
 int rsem_gibbs_set_allele_groups(rsem_gibbs_ctx* c, int32_t m_trans, const int32_t* ta) {
     RSEM_REQUIRE(c && ta && m_trans >= 1, "bad argument");
     RSEM_HIP_TRY(hipSetDevice(c->device));
-    hipFree(c->d_ta); hipFree(c->d_acc_trans);
-    c->d_ta = nullptr; c->d_acc_trans = nullptr;
+    hipFree(c->d_ta);
+    c->d_ta = nullptr;
+    c->m_trans = 0;
     RSEM_HIP_TRY(dmalloc(&c->d_ta, (size_t)m_trans + 1));
-    RSEM_HIP_TRY(dmalloc(&c->d_acc_trans, (size_t)m_trans));
     RSEM_HIP_TRY(hipMemcpy(c->d_ta, ta, sizeof(int32_t) * ((size_t)m_trans + 1), hipMemcpyHostToDevice));
-    RSEM_HIP_TRY(hipMemset(c->d_acc_trans, 0, sizeof(double) * m_trans));
     c->m_trans = m_trans;
     return RSEM_OK;
 }
 
 int rsem_gibbs_get_pve_c_trans(rsem_gibbs_ctx* c, double* out) {
     RSEM_REQUIRE(c && out, "NULL argument");
-    if (!c->m_trans) { rsem::set_last_error("allele groups were never set"); return RSEM_ERR_STATE; }
-    RSEM_HIP_TRY(hipSetDevice(c->device));
-    RSEM_HIP_TRY(hipMemcpy(out, c->d_acc_trans, sizeof(double) * c->m_trans, hipMemcpyDeviceToHost));
+    if (!c->m_trans || (int32_t)c->last_pve_c_trans.size() != c->m_trans) {
+        rsem::set_last_error("allele groups were never set, or no chain has run since");
+        return RSEM_ERR_STATE;
+    }
+    memcpy(out, c->last_pve_c_trans.data(), sizeof(double) * c->m_trans);
+    return RSEM_OK;
+}
+
+int rsem_gibbs_set_comm(rsem_gibbs_ctx* c, rsem_comm* comm) {
+    RSEM_REQUIRE(c != nullptr, "NULL argument");
+    c->comm = comm;
     return RSEM_OK;
 }
 
@@ -583,28 +984,12 @@ int rsem_gibbs_create(rsem_gibbs_ctx** out, int device, int32_t M, uint64_t N1, 
         rsem::set_last_error("no HIP device %d (have %d)", device, ndev);
         return RSEM_ERR_NODEVICE;
     }
-    // split the noise column out (host, once): hits CSR + per-read noise conprb
-    std::vector<uint64_t> rp(N1 + 1, 0);
-    std::vector<int32_t> hs;
-    std::vector<double> hc, nc(N1, 0.0);
-    hs.reserve(nitems);
-    hc.reserve(nitems);
-    for (uint64_t i = 0; i < N1; i++) {
-        RSEM_REQUIRE(row_ptr[i + 1] >= row_ptr[i], "row_ptr is not monotone");
-        RSEM_REQUIRE(row_ptr[i + 1] > row_ptr[i], "a read without any item cannot be sampled");
-        for (uint64_t j = row_ptr[i]; j < row_ptr[i + 1]; j++) {
-            RSEM_REQUIRE(sid[j] >= 0 && sid[j] <= M, "sid outside 0..M");
-            if (sid[j] == 0) nc[i] += conprb[j];
-            else { hs.push_back(sid[j]); hc.push_back(conprb[j]); }
-        }
-        rp[i + 1] = hs.size();
-    }
     RSEM_HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     RSEM_HIP_TRY(hipGetDeviceProperties(&prop, device));
     rsem_gibbs_ctx* c = new (std::nothrow) rsem_gibbs_ctx();
     if (!c) return RSEM_ERR_NOMEM;
-    c->device = device; c->M = M; c->m = m; c->N1 = N1; c->nitems = nitems; c->nhits = hs.size(); c->N0 = N0;
+    c->device = device; c->M = M; c->m = m; c->N1 = N1; c->nitems = nitems; c->N0 = N0;
     c->pseudoC = pseudoC; c->totc = totc;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 #define G_TRY(expr)                                                                                     \
@@ -620,22 +1005,13 @@ int rsem_gibbs_create(rsem_gibbs_ctx** out, int device, int32_t M, uint64_t N1, 
     hipStream_t st = c->stream;
     const size_t nM = (size_t)M + 1;
     G_TRY(dmalloc(&c->d_irp, N1 + 1)); G_TRY(dmalloc(&c->d_isid, nitems)); G_TRY(dmalloc(&c->d_icp, nitems));
-    G_TRY(dmalloc(&c->d_row_ptr, N1 + 1)); G_TRY(dmalloc(&c->d_sid, hs.size())); G_TRY(dmalloc(&c->d_cp, hs.size()));
-    G_TRY(dmalloc(&c->d_ncp, N1));
-    G_TRY(dmalloc(&c->d_init_counts, nM)); G_TRY(dmalloc(&c->d_counts, nM)); G_TRY(dmalloc(&c->d_z, N1));
-    G_TRY(dmalloc(&c->d_g, nM)); G_TRY(dmalloc(&c->d_eel, nM)); G_TRY(dmalloc(&c->d_mw, nM));
-    G_TRY(dmalloc(&c->d_grp, (size_t)m + 1)); G_TRY(dmalloc(&c->d_tmp, nM)); G_TRY(dmalloc(&c->d_mt, 1));
-    for (int i = 0; i < 4; i++) G_TRY(dmalloc(&c->d_acc[i], nM));
-    G_TRY(dmalloc(&c->d_acc_genes, (size_t)m));
+    G_TRY(dmalloc(&c->d_init_counts, nM)); G_TRY(dmalloc(&c->d_eel, nM)); G_TRY(dmalloc(&c->d_mw, nM));
+    G_TRY(dmalloc(&c->d_grp, (size_t)m + 1));
     G_TRY(hipMemcpyAsync(c->d_irp, row_ptr, sizeof(uint64_t) * (N1 + 1), hipMemcpyHostToDevice, st));
-    G_TRY(hipMemcpyAsync(c->d_isid, sid, sizeof(int32_t) * nitems, hipMemcpyHostToDevice, st));
-    G_TRY(hipMemcpyAsync(c->d_icp, conprb, sizeof(double) * nitems, hipMemcpyHostToDevice, st));
-    G_TRY(hipMemcpyAsync(c->d_row_ptr, rp.data(), sizeof(uint64_t) * (N1 + 1), hipMemcpyHostToDevice, st));
-    if (!hs.empty()) {
-        G_TRY(hipMemcpyAsync(c->d_sid, hs.data(), sizeof(int32_t) * hs.size(), hipMemcpyHostToDevice, st));
-        G_TRY(hipMemcpyAsync(c->d_cp, hc.data(), sizeof(double) * hc.size(), hipMemcpyHostToDevice, st));
+    if (nitems) {
+        G_TRY(hipMemcpyAsync(c->d_isid, sid, sizeof(int32_t) * nitems, hipMemcpyHostToDevice, st));
+        G_TRY(hipMemcpyAsync(c->d_icp, conprb, sizeof(double) * nitems, hipMemcpyHostToDevice, st));
     }
-    if (N1) G_TRY(hipMemcpyAsync(c->d_ncp, nc.data(), sizeof(double) * N1, hipMemcpyHostToDevice, st));
     G_TRY(hipMemcpyAsync(c->d_init_counts, init_counts, sizeof(int32_t) * nM, hipMemcpyHostToDevice, st));
     G_TRY(hipMemcpyAsync(c->d_eel, eel, sizeof(double) * nM, hipMemcpyHostToDevice, st));
     G_TRY(hipMemcpyAsync(c->d_mw, mw, sizeof(double) * nM, hipMemcpyHostToDevice, st));
@@ -644,131 +1020,221 @@ int rsem_gibbs_create(rsem_gibbs_ctx** out, int device, int32_t M, uint64_t N1, 
         G_TRY(dmalloc(&c->d_alpha, nM));
         G_TRY(hipMemcpyAsync(c->d_alpha, alpha, sizeof(double) * nM, hipMemcpyHostToDevice, st));
     }
-    G_TRY(hipStreamSynchronize(st));
+    // the ids index counts[] on the device: check them there (the host copy is not walked)
+    int* d_err = nullptr;
+    int h_err = 0;
+    G_TRY(dmalloc(&d_err, 1));
+    hipError_t e = hipMemsetAsync(d_err, 0, sizeof(int), st);
+    if (e == hipSuccess && N1) {
+        hipLaunchKernelGGL(k_check_items, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, M, c->d_irp, c->d_isid, d_err);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_err);
+    G_TRY(e);
 #undef G_TRY
-    // a fixed block length keeps the layout (and with it nothing but performance) device independent
-    int rc = sell_build(c->L, st, N1, M, c->d_row_ptr, c->d_sid, (uint32_t)c->n_cus * 4 * 6 * 5 / 2);
-    if (rc == RSEM_OK) {
-        hipError_t e1 = dmalloc(&c->d_scp, c->L.n_planes * 64), e2 = dmalloc(&c->d_sncp, (size_t)c->L.n_slots);
-        if (e1 != hipSuccess || e2 != hipSuccess) rc = RSEM_ERR_NOMEM;
-    }
-    if (rc == RSEM_OK) rc = sell_fill_values(c->L, st, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_scp, c->d_sncp);
-    if (rc == RSEM_OK && hipStreamSynchronize(st) != hipSuccess) rc = RSEM_ERR_HIP;
-    std::vector<Unit> units;
-    if (rc == RSEM_OK) rc = sell_build_units(c->L, units, kGWindow);
-    if (rc == RSEM_OK) {
-        c->n_units = (uint32_t)units.size();
-        if (dmalloc(&c->d_units, units.size()) != hipSuccess) rc = RSEM_ERR_NOMEM;
-        else if (!units.empty() &&
-                 hipMemcpy(c->d_units, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice) != hipSuccess)
-            rc = RSEM_ERR_HIP;
-    }
-    if (rc != RSEM_OK) { rsem_gibbs_destroy(c); return rc; }
+    if (h_err) { rsem_gibbs_destroy(c); return items_error(h_err); }
     *out = c;
+    return RSEM_OK;
+}
+
+int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32_t* seeds, int burnin, const int32_t* nsamples,
+                          int gap, int thin, int32_t* const* count_vectors, double* pme_c, double* pve_c, double* pme_tpm,
+                          double* pme_fpkm, double* pve_c_genes, double* pve_c_trans, rsem_gibbs_profile* prof) {
+    RSEM_REQUIRE(c && seeds && nsamples && pme_c && pve_c && pme_tpm && pme_fpkm && pve_c_genes, "NULL argument");
+    RSEM_REQUIRE(mode == RSEM_GIBBS_EXACT || mode == RSEM_GIBBS_PARALLEL, "unknown mode");
+    RSEM_REQUIRE(nchains >= 1 && nchains <= 65535, "nchains out of range");
+    RSEM_REQUIRE(burnin >= 0 && gap >= 1, "bad chain parameters");
+    int max_ns = 0;
+    uint64_t cv_total = 0;
+    std::vector<uint64_t> cv_off(nchains, 0);
+    std::vector<int32_t> last_round(nchains, 0);
+    for (int k = 0; k < nchains; k++) {
+        RSEM_REQUIRE(nsamples[k] >= 1, "every chain must keep at least one sample");
+        max_ns = std::max(max_ns, (int)nsamples[k]);
+        cv_off[k] = cv_total;
+        cv_total += (uint64_t)nsamples[k] * ((uint64_t)c->M + 1);
+        last_round[k] = burnin + 1 + (nsamples[k] - 1) * gap;
+    }
+    if (thin < 1) thin = 1;
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    if (mode == RSEM_GIBBS_PARALLEL) {
+        int rc = ensure_parallel_layout(c);
+        if (rc != RSEM_OK) return rc;
+    }
+    const size_t nM = (size_t)c->M + 1;
+    const int gM = rsem::ceil_div(nM, kBlock);
+    const uint64_t stride_c = nM, stride_z = c->N1;
+    const bool exact = mode == RSEM_GIBBS_EXACT;
+    const size_t m = (size_t)c->m, mt = (size_t)c->m_trans;
+    // per-chain state; out = [pme_c | pve_c | pme_tpm | pme_fpkm | pve_c_genes | pve_c_trans] summed over the chains
+    const size_t n_out = 4 * nM + m + mt;
+    DevBuf counts, z, mts, acc, acc_g, acc_t, partials, d_ns, d_last, d_cvoff, cv, outb;
+    RSEM_HIP_TRY(counts.alloc(sizeof(int32_t) * nM * nchains));
+    if (exact) RSEM_HIP_TRY(z.alloc(sizeof(int32_t) * c->N1 * nchains));
+    if (exact) RSEM_HIP_TRY(mts.alloc(sizeof(MtState) * nchains));
+    RSEM_HIP_TRY(acc.alloc(sizeof(double) * 4 * nM * nchains));
+    RSEM_HIP_TRY(acc_g.alloc(sizeof(double) * m * nchains));
+    RSEM_HIP_TRY(acc_t.alloc(sizeof(double) * mt * nchains));
+    RSEM_HIP_TRY(partials.alloc(sizeof(double) * 3 * kStatMaxBlocks * nchains));
+    RSEM_HIP_TRY(d_ns.alloc(sizeof(int32_t) * nchains));
+    RSEM_HIP_TRY(d_last.alloc(sizeof(int32_t) * nchains));
+    RSEM_HIP_TRY(d_cvoff.alloc(sizeof(uint64_t) * nchains));
+    RSEM_HIP_TRY(outb.alloc(sizeof(double) * n_out));
+    if (count_vectors) RSEM_HIP_TRY(cv.alloc(sizeof(int32_t) * cv_total));
+    EventPair ev;
+    RSEM_HIP_TRY(hipEventCreate(&ev.a));
+    RSEM_HIP_TRY(hipEventCreate(&ev.b));
+    RSEM_HIP_TRY(hipMemsetAsync(acc.p, 0, sizeof(double) * 4 * nM * nchains, st));
+    RSEM_HIP_TRY(hipMemsetAsync(acc_g.p, 0, sizeof(double) * m * nchains, st));
+    if (mt) RSEM_HIP_TRY(hipMemsetAsync(acc_t.p, 0, sizeof(double) * mt * nchains, st));
+    RSEM_HIP_TRY(hipMemcpyAsync(d_ns.p, nsamples, sizeof(int32_t) * nchains, hipMemcpyHostToDevice, st));
+    RSEM_HIP_TRY(hipMemcpyAsync(d_last.p, last_round.data(), sizeof(int32_t) * nchains, hipMemcpyHostToDevice, st));
+    RSEM_HIP_TRY(hipMemcpyAsync(d_cvoff.p, cv_off.data(), sizeof(uint64_t) * nchains, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_reset_chains, dim3(gM, nchains), dim3(kBlock), 0, st, c->M, c->d_init_counts, (int32_t)c->N0,
+                       counts.as<int32_t>(), stride_c);
+    RSEM_HIP_TRY(hipGetLastError());
+    const int nblk = std::max(1, std::min(kStatMaxBlocks, rsem::ceil_div(nM, 2048)));
+
+    // statistics of the `kept`-th sample of chains [chain0, chain0 + n)
+    auto keep_sample = [&](int kept, int chain0, int n) -> int {
+        hipLaunchKernelGGL(k_gibbs_stats_a, dim3(nblk, n), dim3(kBlock), 0, st, c->M, counts.as<int32_t>(), stride_c, chain0,
+                           d_ns.as<int32_t>(), kept, c->d_alpha, c->pseudoC, c->totc, c->d_eel, c->d_mw, partials.as<double>());
+        hipLaunchKernelGGL(k_gibbs_stats_b, dim3(nblk, n), dim3(kBlock), 0, st, c->M, counts.as<int32_t>(), stride_c, chain0,
+                           d_ns.as<int32_t>(), kept, c->d_alpha, c->pseudoC, c->totc, c->d_eel, c->d_mw, partials.as<double>(),
+                           acc.as<double>(), count_vectors ? cv.as<int32_t>() : nullptr, d_cvoff.as<uint64_t>());
+        hipLaunchKernelGGL(k_gibbs_group_stats, dim3(rsem::ceil_div(m, kBlock), n), dim3(kBlock), 0, st, c->m, c->d_grp,
+                           counts.as<int32_t>(), stride_c, chain0, d_ns.as<int32_t>(), kept, acc_g.as<double>());
+        if (mt)
+            hipLaunchKernelGGL(k_gibbs_group_stats, dim3(rsem::ceil_div(mt, kBlock), n), dim3(kBlock), 0, st, c->m_trans, c->d_ta,
+                               counts.as<int32_t>(), stride_c, chain0, d_ns.as<int32_t>(), kept, acc_t.as<double>());
+        RSEM_HIP_TRY(hipGetLastError());
+        return RSEM_OK;
+    };
+
+    long long sweeps = 0;
+    RSEM_HIP_TRY(hipEventRecord(ev.a, st));
+    if (exact) {
+        // all chains advance together, one wave each (Gibbs.cpp:207-254: the reference's threads)
+        std::vector<MtState> h(nchains);
+        for (int k = 0; k < nchains; k++) host_mt_seed(h[k], seeds[k]);
+        RSEM_HIP_TRY(hipMemcpyAsync(mts.p, h.data(), sizeof(MtState) * nchains, hipMemcpyHostToDevice, st));
+        const bool serial = exact_serial_requested();
+        auto sweep = [&](bool init, int round) {
+#define EXACT_ARGS c->N1, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->d_alpha, c->pseudoC, \
+                   mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z
+            if (serial) {
+                if (init) hipLaunchKernelGGL(k_gibbs_exact_serial<true>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
+                else hipLaunchKernelGGL(k_gibbs_exact_serial<false>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
+            } else {
+                if (init) hipLaunchKernelGGL(k_gibbs_exact_coop<true>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
+                else hipLaunchKernelGGL(k_gibbs_exact_coop<false>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
+            }
+#undef EXACT_ARGS
+        };
+        sweep(true, 0);  // initial state: z_i ~ conprb (Gibbs.cpp:281-291)
+        RSEM_HIP_TRY(hipGetLastError());
+        RSEM_HIP_TRY(hipStreamSynchronize(st));  // h must outlive the copy
+        const int rounds = burnin + 1 + (max_ns - 1) * gap;
+        for (int round = 1; round <= rounds; round++) {
+            sweep(false, round);
+            RSEM_HIP_TRY(hipGetLastError());
+            ++sweeps;
+            if (round > burnin && (round - burnin - 1) % gap == 0) {
+                int rc = keep_sample((round - burnin - 1) / gap, 0, nchains);
+                if (rc != RSEM_OK) return rc;
+            }
+        }
+    } else {
+        // one chain after the other: a sweep of this sampler fills the GPU by itself
+        for (int k = 0; k < nchains; k++) {
+            Philox ph{seeds[k], 0x52534547u};  // 'RSEG'
+            uint32_t sweep_no = 0;
+            int32_t* ck = counts.as<int32_t>() + (size_t)k * stride_c;
+            auto parallel_z = [&](uint32_t sw) -> int {
+                if (c->n_units)
+                    hipLaunchKernelGGL(k_sample_z_lane, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
+                                       c->d_g, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, ph, sw, ck);
+                if (c->L.n_long_rows)
+                    hipLaunchKernelGGL(k_sample_z_long, dim3(rsem::ceil_div(c->L.n_long_rows, kBlock)), dim3(kBlock), 0, st,
+                                       c->L.n_long_rows, c->L.d_order + c->L.n_sell_rows, c->L.n_sell_rows, c->d_row_ptr, c->d_sid,
+                                       c->d_cp, c->d_ncp, c->d_g, ph, sw, ck);
+                RSEM_HIP_TRY(hipGetLastError());
+                return RSEM_OK;
+            };
+            // initial state: z_i ~ conprb (Gibbs.cpp:281-291) = a z pass with all weights 1
+            hipLaunchKernelGGL(k_fill_double, dim3(gM), dim3(kBlock), 0, st, (int32_t)nM, 1.0, c->d_g);
+            int rc = parallel_z(sweep_no++);
+            if (rc != RSEM_OK) return rc;
+            int kept = 0;
+            for (int round = 1; round <= last_round[k]; round++) {
+                for (int t = 0; t < thin; t++) {
+                    hipLaunchKernelGGL(k_sample_theta, dim3(gM), dim3(kBlock), 0, st, c->M, ck, c->d_alpha, c->pseudoC, ph, sweep_no,
+                                       c->d_g, c->d_init_counts, (int32_t)c->N0);
+                    rc = parallel_z(sweep_no++);
+                    if (rc != RSEM_OK) return rc;
+                    ++sweeps;
+                }
+                if (round > burnin && (round - burnin - 1) % gap == 0) {
+                    rc = keep_sample(kept++, k, 1);
+                    if (rc != RSEM_OK) return rc;
+                }
+            }
+        }
+    }
+    RSEM_HIP_TRY(hipEventRecord(ev.b, st));
+    // release() part 1 (Gibbs.cpp:372-388): the chains' sums, in chain order; across GPUs: one reduce to rank 0
+    double* o = outb.as<double>();
+    hipLaunchKernelGGL(k_sum_chains, dim3(rsem::ceil_div(4 * nM, kBlock)), dim3(kBlock), 0, st, (uint64_t)(4 * nM), nchains,
+                       (uint64_t)(4 * nM), acc.as<double>(), o);
+    hipLaunchKernelGGL(k_sum_chains, dim3(rsem::ceil_div(m, kBlock)), dim3(kBlock), 0, st, (uint64_t)m, nchains, (uint64_t)m,
+                       acc_g.as<double>(), o + 4 * nM);
+    if (mt)
+        hipLaunchKernelGGL(k_sum_chains, dim3(rsem::ceil_div(mt, kBlock)), dim3(kBlock), 0, st, (uint64_t)mt, nchains, (uint64_t)mt,
+                           acc_t.as<double>(), o + 4 * nM + m);
+    RSEM_HIP_TRY(hipGetLastError());
+    if (c->comm) {
+        int rc = rsem::comm_reduce_sum_f64(c->comm, o, n_out, 0, st);
+        if (rc != RSEM_OK) return rc;
+    }
+    RSEM_HIP_TRY(hipMemcpyAsync(pme_c, o, sizeof(double) * nM, hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipMemcpyAsync(pve_c, o + nM, sizeof(double) * nM, hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipMemcpyAsync(pme_tpm, o + 2 * nM, sizeof(double) * nM, hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipMemcpyAsync(pme_fpkm, o + 3 * nM, sizeof(double) * nM, hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipMemcpyAsync(pve_c_genes, o + 4 * nM, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+    c->last_pve_c_trans.assign(mt, 0.0);
+    if (mt) RSEM_HIP_TRY(hipMemcpyAsync(c->last_pve_c_trans.data(), o + 4 * nM + m, sizeof(double) * mt, hipMemcpyDeviceToHost, st));
+    if (count_vectors)
+        for (int k = 0; k < nchains; k++)
+            if (count_vectors[k])
+                RSEM_HIP_TRY(hipMemcpyAsync(count_vectors[k], cv.as<int32_t>() + cv_off[k], sizeof(int32_t) * (size_t)nsamples[k] * nM,
+                                            hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipStreamSynchronize(st));
+    if (mt && pve_c_trans) memcpy(pve_c_trans, c->last_pve_c_trans.data(), sizeof(double) * mt);
+    if (prof) {
+        float ms = 0.f;
+        RSEM_HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+        prof->total_ms = ms;
+        prof->sweeps = sweeps;
+        prof->sweep_ms = sweeps ? ms / (double)sweeps : 0.0;
+        prof->chains = nchains;
+    }
     return RSEM_OK;
 }
 
 int rsem_gibbs_run(rsem_gibbs_ctx* c, int mode, uint32_t seed, int burnin, int nsamples, int gap, int thin,
                    int32_t* count_vectors, double* pme_c, double* pve_c, double* pme_tpm, double* pme_fpkm,
                    double* pve_c_genes, double* sweep_ms) {
-    RSEM_REQUIRE(c && pme_c && pve_c && pme_tpm && pme_fpkm && pve_c_genes, "NULL argument");
-    RSEM_REQUIRE(mode == RSEM_GIBBS_EXACT || mode == RSEM_GIBBS_PARALLEL, "unknown mode");
-    RSEM_REQUIRE(burnin >= 0 && nsamples >= 1 && gap >= 1, "bad chain parameters");
-    if (thin < 1) thin = 1;
-    RSEM_HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = c->stream;
-    const size_t nM = (size_t)c->M + 1;
-    const int gM = rsem::ceil_div(nM, kBlock);
-    for (int i = 0; i < 4; i++) RSEM_HIP_TRY(hipMemsetAsync(c->d_acc[i], 0, sizeof(double) * nM, st));
-    RSEM_HIP_TRY(hipMemsetAsync(c->d_acc_genes, 0, sizeof(double) * c->m, st));
-    if (c->m_trans) RSEM_HIP_TRY(hipMemsetAsync(c->d_acc_trans, 0, sizeof(double) * c->m_trans, st));
-    int32_t* d_cv = nullptr;
-    if (count_vectors) RSEM_HIP_TRY(dmalloc(&d_cv, (size_t)nsamples * nM));
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    RSEM_HIP_TRY(hipEventCreate(&ev0));
-    RSEM_HIP_TRY(hipEventCreate(&ev1));
-    Philox ph{seed, 0x52534547u};  // 'RSEG'
-    uint32_t sweep_no = 0;
-
-    auto parallel_z = [&](uint32_t sw, bool reset) -> int {
-        if (reset)
-            hipLaunchKernelGGL(k_reset_counts, dim3(gM), dim3(kBlock), 0, st, c->M, c->d_init_counts, (int32_t)c->N0,
-                               c->d_counts);
-        if (c->n_units)
-            hipLaunchKernelGGL(k_sample_z_lane, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
-                               c->d_g, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, ph, sw, c->d_counts);
-        if (c->L.n_long_rows)
-            hipLaunchKernelGGL(k_sample_z_long, dim3(rsem::ceil_div(c->L.n_long_rows, kBlock)), dim3(kBlock), 0, st,
-                               c->L.n_long_rows, c->L.d_order + c->L.n_sell_rows, c->L.n_sell_rows, c->d_row_ptr, c->d_sid,
-                               c->d_cp, c->d_ncp, c->d_g, ph, sw, c->d_counts);
-        RSEM_HIP_TRY(hipGetLastError());
-        return RSEM_OK;
-    };
-
-    int rc = RSEM_OK;
-    // initial state: z_i ~ conprb (Gibbs.cpp:281-291)
-    if (mode == RSEM_GIBBS_EXACT) {
-        MtState h;
-        host_mt_seed(h, seed);
-        RSEM_HIP_TRY(hipMemcpyAsync(c->d_mt, &h, sizeof(MtState), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_reset_counts, dim3(gM), dim3(kBlock), 0, st, c->M, c->d_init_counts, (int32_t)c->N0, c->d_counts);
-        hipLaunchKernelGGL(k_gibbs_exact<true>, dim3(1), dim3(64), 0, st, c->N1, c->d_irp, c->d_isid, c->d_icp, c->d_counts,
-                           c->d_z, c->d_alpha, c->pseudoC, c->d_mt);
-        RSEM_HIP_TRY(hipGetLastError());
-        RSEM_HIP_TRY(hipStreamSynchronize(st));  // h must outlive the copy
-    } else {
-        hipLaunchKernelGGL(k_fill_double, dim3(gM), dim3(kBlock), 0, st, (int32_t)nM, 1.0, c->d_g);
-        rc = parallel_z(sweep_no++, true);
-        if (rc != RSEM_OK) return rc;
-    }
-    const int chainlen = 1 + (nsamples - 1) * gap;
-    int kept = 0;
-    RSEM_HIP_TRY(hipEventRecord(ev0, st));
-    for (int round = 1; round <= burnin + chainlen; round++) {
-        if (mode == RSEM_GIBBS_EXACT) {
-            hipLaunchKernelGGL(k_gibbs_exact<false>, dim3(1), dim3(64), 0, st, c->N1, c->d_irp, c->d_isid, c->d_icp,
-                               c->d_counts, c->d_z, c->d_alpha, c->pseudoC, c->d_mt);
-            RSEM_HIP_TRY(hipGetLastError());
-        } else {
-            for (int t = 0; t < thin; t++) {
-                hipLaunchKernelGGL(k_sample_theta, dim3(gM), dim3(kBlock), 0, st, c->M, c->d_counts, c->d_alpha, c->pseudoC,
-                                   ph, sweep_no, c->d_g, c->d_init_counts, (int32_t)c->N0);
-                rc = parallel_z(sweep_no++, false);
-                if (rc != RSEM_OK) return rc;
-            }
-        }
-        if (round > burnin && (round - burnin - 1) % gap == 0) {
-            if (d_cv) RSEM_HIP_TRY(hipMemcpyAsync(d_cv + (size_t)kept * nM, c->d_counts, sizeof(int32_t) * nM,
-                                                  hipMemcpyDeviceToDevice, st));
-            ++kept;
-            hipLaunchKernelGGL(k_gibbs_stats, dim3(1), dim3(kStatBlock), 0, st, c->M, c->d_counts, c->d_alpha, c->pseudoC,
-                               c->totc, c->d_eel, c->d_mw, c->d_tmp, c->d_acc[0], c->d_acc[1], c->d_acc[2], c->d_acc[3]);
-            hipLaunchKernelGGL(k_gibbs_gene_stats, dim3(rsem::ceil_div(c->m, kBlock)), dim3(kBlock), 0, st, c->m, c->d_grp,
-                               c->d_counts, c->d_acc_genes);
-            if (c->m_trans)
-                hipLaunchKernelGGL(k_gibbs_gene_stats, dim3(rsem::ceil_div(c->m_trans, kBlock)), dim3(kBlock), 0, st, c->m_trans,
-                                   c->d_ta, c->d_counts, c->d_acc_trans);
-            RSEM_HIP_TRY(hipGetLastError());
-        }
-    }
-    RSEM_HIP_TRY(hipEventRecord(ev1, st));
-    RSEM_HIP_TRY(hipMemcpyAsync(pme_c, c->d_acc[0], sizeof(double) * nM, hipMemcpyDeviceToHost, st));
-    RSEM_HIP_TRY(hipMemcpyAsync(pve_c, c->d_acc[1], sizeof(double) * nM, hipMemcpyDeviceToHost, st));
-    RSEM_HIP_TRY(hipMemcpyAsync(pme_tpm, c->d_acc[2], sizeof(double) * nM, hipMemcpyDeviceToHost, st));
-    RSEM_HIP_TRY(hipMemcpyAsync(pme_fpkm, c->d_acc[3], sizeof(double) * nM, hipMemcpyDeviceToHost, st));
-    RSEM_HIP_TRY(hipMemcpyAsync(pve_c_genes, c->d_acc_genes, sizeof(double) * c->m, hipMemcpyDeviceToHost, st));
-    if (d_cv) RSEM_HIP_TRY(hipMemcpyAsync(count_vectors, d_cv, sizeof(int32_t) * (size_t)nsamples * nM, hipMemcpyDeviceToHost, st));
-    RSEM_HIP_TRY(hipStreamSynchronize(st));
-    if (sweep_ms) {
-        float ms = 0.f;
-        RSEM_HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-        int sweeps = (burnin + chainlen) * (mode == RSEM_GIBBS_PARALLEL ? thin : 1);
-        *sweep_ms = sweeps ? ms / sweeps : 0.0;
-    }
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-    hipFree(d_cv);
-    return RSEM_OK;
+    RSEM_REQUIRE(nsamples >= 1, "bad chain parameters");
+    const int32_t ns = nsamples;
+    int32_t* cvs[1] = {count_vectors};
+    rsem_gibbs_profile prof;
+    int rc = rsem_gibbs_run_chains(c, mode, 1, &seed, burnin, &ns, gap, thin, count_vectors ? cvs : nullptr, pme_c, pve_c, pme_tpm,
+                                   pme_fpkm, pve_c_genes, nullptr, &prof);
+    if (rc == RSEM_OK && sweep_ms) *sweep_ms = prof.sweep_ms;
+    return rc;
 }
 
 }  // extern "C"

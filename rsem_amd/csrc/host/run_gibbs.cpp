@@ -2,10 +2,12 @@
 //
 //   rsem-run-gibbs refName imdName statName BURNIN NSAMPLES GAP [-p N] [--seed s] [--pseudo-count a]
 //                  [--prior file] [-q]   + ignored-by-the-reference extras:
-//                  [--gibbs-mode exact|parallel] [--gibbs-thin k] [--device d]
+//                  [--gibbs-mode exact|parallel] [--gibbs-thin k] [--device d | --devices d0,d1,..]
 //
 // -p N keeps its meaning "N independent chains, N count-vector files" (Gibbs.cpp:211-226, calcCI opens one
-// file per thread); the chains run on the available GPUs through librsem_hip (include/rsem_hip.h).
+// file per thread).  The chains are dealt to the available GPUs; a GPU advances all of its chains together (one wave
+// per chain) and the per-chain accumulators meet in one RCCL reduce (include/rsem_hip.h: rsem_gibbs_run_chains,
+// rsem_comm_*).
 #include <charconv>
 #include <cmath>
 #include <cstdio>
@@ -34,7 +36,7 @@ int main(int argc, char* argv[]) {
     bool hasSeed = false, quiet = false, has_prior = false, dry_run = false;
     uint32_t seed = 0;
     double pseudoC = 1.0;
-    std::string fprior, mode_s = "auto";
+    std::string fprior, mode_s = "auto", devices_s;
     for (int i = 7; i < argc; i++) {  // order-insensitive strcmp scan, unknown tokens ignored (Gibbs.cpp:456-473)
         if (!strcmp(argv[i], "-p") && i + 1 < argc) nThreads = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--seed") && i + 1 < argc) {
@@ -48,6 +50,7 @@ int main(int argc, char* argv[]) {
         if (!strcmp(argv[i], "--gibbs-mode") && i + 1 < argc) mode_s = argv[i + 1];
         if (!strcmp(argv[i], "--gibbs-thin") && i + 1 < argc) thin = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices_s = argv[i + 1];
         if (!strcmp(argv[i], "--dry-run")) dry_run = true;  // load the inputs, print the sampler that would run, exit (no GPU work)
     }
     const bool verbose = !quiet;
@@ -117,64 +120,118 @@ int main(int argc, char* argv[]) {
     rsem_hip_device_count(&ndev);
     if (ndev < 1 && !dry_run) die("rsem-run-gibbs: no usable GPU (this program has no CPU path)");
     if (dry_run) ndev = std::max(ndev, 1);
-    // The reference's own chain (EXACT: bit-identical count vectors) is one wave walking the reads in order, ~0.4 us per
-    // read and round, and the chains of one GPU run one after the other -- so its cost is read-rounds per GPU.
-    const double chain_rows = (double)N1 * (BURNIN + 1.0 + std::ceil(NSAMPLES / (double)nThreads) * GAP);
-    const int gpus = device >= 0 ? 1 : std::max(1, std::min(ndev, nThreads));
-    const double rows_per_gpu = chain_rows * std::ceil(nThreads / (double)gpus);
-    const double kExactBudget = 2.5e7;  // ~10 s
+    // GPUs that take part: --devices a,b,.. (a device may be named twice: its chains then form two groups, which is how
+    // the multi-GPU code path is exercised on a one-GPU machine), --device d, or the first min(#GPUs, #chains) devices
+    std::vector<int> devs;
+    if (!devices_s.empty()) {
+        for (size_t p = 0; p < devices_s.size();) {
+            size_t q = devices_s.find(',', p);
+            if (q == std::string::npos) q = devices_s.size();
+            const int d = atoi(devices_s.substr(p, q - p).c_str());
+            if (d < 0 || (d >= ndev && !dry_run)) die("rsem-run-gibbs: --devices names GPU %d, but there are %d", d, ndev);
+            devs.push_back(d);
+            p = q + 1;
+        }
+    } else if (device >= 0) {
+        if (device >= ndev && !dry_run) die("rsem-run-gibbs: --device %d, but there are %d GPUs", device, ndev);
+        devs.push_back(device);
+    } else {
+        for (int d = 0; d < std::min(ndev, nThreads); d++) devs.push_back(d);
+    }
+    if ((int)devs.size() > nThreads) devs.resize(nThreads);
+    const int nworkers = (int)devs.size();
+    // Sampler.  exact = the reference's collapsed chain (bit-identical count vectors), one wave per chain, all the chains
+    // of a GPU advancing together; parallel = the data-augmentation sampler for the same posterior (every sweep fills
+    // the GPU; the chains of a GPU run one after the other).
     int mode;
-    if (mode_s == "exact") {
-        mode = RSEM_GIBBS_EXACT;
-        if (rows_per_gpu > kExactBudget)  // honoured, but never silently: this can be hours
-            fprintf(stderr, "Warning: --gibbs-mode exact on %.3g read-rounds per GPU will take about %.0f s (one wave per chain, chains in "
-                            "sequence); --gibbs-mode parallel samples the same posterior in a fraction of that.\n",
-                    rows_per_gpu, rows_per_gpu * 0.4e-6);
-    } else if (mode_s == "parallel") mode = RSEM_GIBBS_PARALLEL;
-    else mode = rows_per_gpu <= kExactBudget ? RSEM_GIBBS_EXACT : RSEM_GIBBS_PARALLEL;  // auto: exact only when it is cheap
+    if (mode_s == "exact" || mode_s == "auto") mode = RSEM_GIBBS_EXACT;
+    else if (mode_s == "parallel") mode = RSEM_GIBBS_PARALLEL;
+    else die("rsem-run-gibbs: unknown --gibbs-mode '%s' (exact, parallel or auto)", mode_s.c_str());
     if (thin <= 0) thin = (mode == RSEM_GIBBS_PARALLEL) ? 8 : 1;
+    if (mode == RSEM_GIBBS_PARALLEL)  // never silently: these draws are a different Markov chain than the reference's
+        fprintf(stderr, "rsem-run-gibbs: data-augmentation sampler (--gibbs-mode parallel), %d sweeps per round\n", thin);
     if (dry_run) {
-        printf("dry run: %s sampler, %d chain(s), %d sweep(s) per round, N1 = %llu, M = %d\n", mode == RSEM_GIBBS_EXACT ? "exact" : "parallel",
-               nThreads, mode == RSEM_GIBBS_PARALLEL ? thin : 1, (unsigned long long)N1, M);
+        printf("dry run: %s sampler, %d chain(s) on %d GPU group(s), %d sweep(s) per round, N1 = %llu, M = %d\n",
+               mode == RSEM_GIBBS_EXACT ? "exact" : "parallel", nThreads, nworkers, mode == RSEM_GIBBS_PARALLEL ? thin : 1,
+               (unsigned long long)N1, M);
         return 0;
     }
-    if (verbose) printf("Gibbs started! (%s sampler, %d chain(s), %d GPU(s))\n", mode == RSEM_GIBBS_EXACT ? "exact" : "parallel", nThreads, ndev);
+    if (verbose) printf("Gibbs started! (%s sampler, %d chain(s), %d GPU(s))\n", mode == RSEM_GIBBS_EXACT ? "exact" : "parallel", nThreads, nworkers);
 
     // chain seeds: engineFactory (sampling.h:19-44); without --seed the reference seeds from time(NULL)
     std::vector<uint32_t> seeds(nThreads);
     rsem_gibbs_chain_seeds(hasSeed ? seed : (uint32_t)time(NULL), nThreads, seeds.data());
 
     const int quotient = NSAMPLES / nThreads, left = NSAMPLES % nThreads;  // Gibbs.cpp:215-223
-    std::vector<std::vector<double>> acc(nThreads * 4, std::vector<double>(M + 1, 0.0));
-    std::vector<std::vector<double>> acc_g(nThreads, std::vector<double>(gi.m, 0.0));
-    std::vector<std::vector<double>> acc_t(nThreads, std::vector<double>(m_trans, 0.0));
-    std::vector<std::string> errors(nThreads);
-    const int nworkers = device >= 0 ? 1 : std::min(ndev, nThreads);
+    // Chains are dealt round-robin to the GPU groups; a group runs its chains in ONE rsem_gibbs_run_chains call and the
+    // groups' accumulator sums meet in a single reduce to group 0 (RCCL over xGMI; release(), Gibbs.cpp:372-388).
+    bool shared_device = false;
+    for (int a = 0; a < nworkers; a++)
+        for (int b2 = a + 1; b2 < nworkers; b2++) shared_device = shared_device || devs[a] == devs[b2];
+    std::vector<rsem_comm*> comms(nworkers, nullptr);
+    char comm_id[RSEM_COMM_ID_BYTES];
+    const bool want_comm = nworkers > 1 || getenv("RSEM_HIP_FORCE_COMM");
+    if (want_comm) {
+        if (shared_device) {
+            int rc = rsem_comm_create_local(comms.data(), nworkers, devs.data());
+            if (rc != RSEM_OK) die("rsem-run-gibbs: rsem_comm_create_local: %s (%s)", rsem_hip_strerror(rc), rsem_hip_last_error());
+        } else {
+            int rc = rsem_comm_unique_id(comm_id);
+            if (rc != RSEM_OK) die("rsem-run-gibbs: rsem_comm_unique_id: %s (%s)", rsem_hip_strerror(rc), rsem_hip_last_error());
+        }
+    }
+    std::vector<double> pme_c(M + 1, 0.0), pve_c(M + 1, 0.0), pme_tpm(M + 1, 0.0), pme_fpkm(M + 1, 0.0), pve_c_genes(gi.m, 0.0);
+    std::vector<double> pve_c_trans(m_trans, 0.0);
+    std::vector<std::string> errors(nworkers);
     std::vector<std::thread> workers;
     for (int w = 0; w < nworkers; w++) {
         workers.emplace_back([&, w]() {
-            const int dev = device >= 0 ? device : w;
+            const int dev = devs[w];
+            auto fail = [&](const char* what, int rc) { errors[w] = std::string(what) + ": " + rsem_hip_strerror(rc) + ": " + rsem_hip_last_error(); };
+            int rc = RSEM_OK;
+            if (want_comm && !shared_device) {  // collective: every group calls it
+                rc = rsem_comm_create(&comms[w], dev, w, nworkers, comm_id);
+                if (rc != RSEM_OK) { fail("rsem_comm_create", rc); return; }
+            }
             rsem_gibbs_ctx* g = nullptr;
-            int rc = rsem_gibbs_create(&g, dev, M, N1, ofg.sid.size(), ofg.row_ptr.data(), ofg.sid.data(), ofg.conprb.data(),
-                                       init_counts.data(), has_prior ? pseudo_counts.data() : nullptr, pseudoC, totc, N0,
-                                       eel.data(), model.mw.data(), gi.m, gi.starts.data());
+            rc = rsem_gibbs_create(&g, dev, M, N1, ofg.sid.size(), ofg.row_ptr.data(), ofg.sid.data(), ofg.conprb.data(),
+                                   init_counts.data(), has_prior ? pseudo_counts.data() : nullptr, pseudoC, totc, N0,
+                                   eel.data(), model.mw.data(), gi.m, gi.starts.data());
             if (rc == RSEM_OK && alleleS) rc = rsem_gibbs_set_allele_groups(g, m_trans, ta.starts.data());
-            if (rc != RSEM_OK) { errors[w] = std::string(rsem_hip_strerror(rc)) + ": " + rsem_hip_last_error(); return; }
-            for (int k = w; k < nThreads; k += nworkers) {
-                const int ns = quotient + (k < left ? 1 : 0);
-                std::vector<int32_t> cv((size_t)ns * (M + 1));
-                rc = rsem_gibbs_run(g, mode, seeds[k], BURNIN, ns, GAP, thin, cv.data(), acc[k * 4 + 0].data(), acc[k * 4 + 1].data(),
-                                    acc[k * 4 + 2].data(), acc[k * 4 + 3].data(), acc_g[k].data(), nullptr);
-                if (rc == RSEM_OK && alleleS) rc = rsem_gibbs_get_pve_c_trans(g, acc_t[k].data());
-                if (rc != RSEM_OK) { errors[w] = std::string(rsem_hip_strerror(rc)) + ": " + rsem_hip_last_error(); break; }
-                // writeCountVector (Gibbs.cpp:257-262): one file per chain
+            if (rc == RSEM_OK && comms[w]) rc = rsem_gibbs_set_comm(g, comms[w]);
+            if (rc != RSEM_OK) { fail("rsem_gibbs_create", rc); return; }
+            std::vector<int> mine;
+            for (int k = w; k < nThreads; k += nworkers) mine.push_back(k);
+            std::vector<uint32_t> my_seeds;
+            std::vector<int32_t> my_ns;
+            std::vector<std::vector<int32_t>> cv(mine.size());
+            std::vector<int32_t*> cv_ptr;
+            for (size_t j = 0; j < mine.size(); j++) {
+                const int k = mine[j];
+                my_seeds.push_back(seeds[k]);
+                my_ns.push_back(quotient + (k < left ? 1 : 0));
+                cv[j].resize((size_t)my_ns.back() * (M + 1));
+                cv_ptr.push_back(cv[j].data());
+            }
+            // group 0 receives the totals; the other groups' outputs are scratch
+            std::vector<double> s0, s1, s2, s3, s4, s5;
+            const bool root = (w == 0);
+            if (!root) { s0.resize(M + 1); s1.resize(M + 1); s2.resize(M + 1); s3.resize(M + 1); s4.resize(gi.m); s5.resize(m_trans); }
+            rc = rsem_gibbs_run_chains(g, mode, (int)mine.size(), my_seeds.data(), BURNIN, my_ns.data(), GAP, thin, cv_ptr.data(),
+                                       root ? pme_c.data() : s0.data(), root ? pve_c.data() : s1.data(), root ? pme_tpm.data() : s2.data(),
+                                       root ? pme_fpkm.data() : s3.data(), root ? pve_c_genes.data() : s4.data(),
+                                       alleleS ? (root ? pve_c_trans.data() : s5.data()) : nullptr, nullptr);
+            if (rc != RSEM_OK) { fail("rsem_gibbs_run_chains", rc); rsem_gibbs_destroy(g); return; }
+            // writeCountVector (Gibbs.cpp:257-262): one file per chain, written by the group that ran it
+            for (size_t j = 0; j < mine.size(); j++) {
+                const int k = mine[j];
                 FILE* fo = fopen((imdName + ".countvectors" + std::to_string(k)).c_str(), "w");
                 if (!fo) { errors[w] = "cannot write count vectors"; break; }
                 std::string line;
                 line.reserve((size_t)(M + 1) * 8);
                 char tmp[16];
-                for (int s = 0; s < ns; s++) {
-                    const int32_t* c = cv.data() + (size_t)s * (M + 1);
+                for (int s = 0; s < my_ns[j]; s++) {
+                    const int32_t* c = cv[j].data() + (size_t)s * (M + 1);
                     line.clear();
                     for (int i = 0; i <= M; i++) {
                         auto r = std::to_chars(tmp, tmp + sizeof(tmp), c[i]);
@@ -190,20 +247,11 @@ int main(int argc, char* argv[]) {
         });
     }
     for (auto& t : workers) t.join();
+    for (auto* cm : comms) rsem_comm_destroy(cm);
     for (auto& e : errors)
         if (!e.empty()) die("rsem-run-gibbs: %s", e.c_str());
 
-    // release() (Gibbs.cpp:355-423)
-    std::vector<double> pme_c(M + 1, 0.0), pve_c(M + 1, 0.0), pme_tpm(M + 1, 0.0), pme_fpkm(M + 1, 0.0), pve_c_genes(gi.m, 0.0);
-    for (int k = 0; k < nThreads; k++) {
-        for (int j = 0; j <= M; j++) {
-            pme_c[j] += acc[k * 4 + 0][j];
-            pve_c[j] += acc[k * 4 + 1][j];
-            pme_tpm[j] += acc[k * 4 + 2][j];
-            pme_fpkm[j] += acc[k * 4 + 3][j];
-        }
-        for (int j = 0; j < gi.m; j++) pve_c_genes[j] += acc_g[k][j];
-    }
+    // release() part 2 (Gibbs.cpp:389-423): means and variances from the sums
     for (int i = 0; i <= M; i++) {
         pme_c[i] /= NSAMPLES;
         pve_c[i] = (pve_c[i] - double(NSAMPLES) * pme_c[i] * pme_c[i]) / double(NSAMPLES - 1);
@@ -217,10 +265,7 @@ int main(int argc, char* argv[]) {
         pve_c_genes[i] = (pve_c_genes[i] - double(NSAMPLES) * pme_c_gene * pme_c_gene) / double(NSAMPLES - 1);
         if (pve_c_genes[i] < 0.0) pve_c_genes[i] = 0.0;
     }
-    std::vector<double> pve_c_trans(m_trans, 0.0);
     if (alleleS) {
-        for (int k = 0; k < nThreads; k++)
-            for (int j = 0; j < m_trans; j++) pve_c_trans[j] += acc_t[k][j];
         for (int i = 0; i < m_trans; i++) {
             double pme_c_tran = 0.0;
             for (int j = ta.starts[i]; j < ta.starts[i + 1]; j++) pme_c_tran += pme_c[j];

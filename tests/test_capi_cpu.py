@@ -32,7 +32,7 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.rsem_hip_abi_version() == 1
+    assert lib.rsem_hip_abi_version() == 2
     assert lib.rsem_hip_strerror(0) == b"ok"
     assert b"gfx950" in lib.rsem_hip_strerror(-4)
 
@@ -80,41 +80,40 @@ def test_product_never_imports_oracle():
     assert not bad, bad
 
 
-def test_gibbs_auto_mode_budget(tmp_path):
-    """rsem-run-gibbs --gibbs-mode auto (the default) may only pick the exact single-wave chain when it is cheap:
-    <= 2.5e7 read-rounds per GPU, counting that a GPU's chains run one after the other.  --dry-run prints the choice
-    without touching a device, so the rule is checked here on CPU.  (The first version of the rule budgeted one chain's
-    rows and ignored how many chains share the GPU.)  An explicit --gibbs-mode exact is honoured whatever it costs, with
-    a warning and a time estimate on stderr -- forcing it for 64 chains on 190 k reads once ran for 20 minutes."""
+def test_gibbs_sampler_choice(tmp_path):
+    """rsem-run-gibbs's sampler choice, checked with --dry-run (no device needed): the default (auto) is the reference's
+    own chain (exact: bit-identical count vectors; every chain is one wave and all chains of a GPU advance together, so
+    its cost no longer grows with -p); the data-augmentation sampler is only taken on request and says so on stderr even
+    with -q; an unknown --gibbs-mode is an error, not a silent fallback; --devices deals the chains to GPU groups."""
     import shutil
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "rsem_amd", "bin", "rsem-run-gibbs")
     assert os.path.exists(exe), "rsem-run-gibbs was not built"
     d = str(tmp_path / "fx")
-    shutil.copytree(os.path.join(root, "tests", "golden", "se_q"), d)  # N1 = 1410 alignable reads with hits in .ofg
+    shutil.copytree(os.path.join(root, "tests", "golden", "se_q"), d)
+
+    def run(*args):
+        return subprocess.run([exe, d + "/ref", d + "/temp/s", d + "/stat/s"] + list(args) + ["-q", "--dry-run"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 
     def choice(*args):
-        r = subprocess.run([exe, d + "/ref", d + "/temp/s", d + "/stat/s"] + list(args) + ["-q", "--dry-run"], stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, text=True)
+        r = run(*args)
         assert r.returncode == 0, r.stderr
         line = r.stdout.strip().split("\n")[-1]
         assert line.startswith("dry run: ")
-        return line.split()[2], int(line.split("chain(s), ")[1].split()[0])
+        return line.split()[2], int(line.split("GPU group(s), ")[1].split()[0]), int(line.split("on ")[1].split()[0])
 
-    n1 = 1410
-    assert choice("20", "40", "1", "-p", "2") == ("exact", 1)                      # the fixtures' own settings
-    assert choice("200", "1000", "1", "-p", "8") == ("exact", 1)                   # 1410 * 326 * 8 = 3.7e6
-    assert n1 * (200 + 1 + 16) * 64 <= 2.5e7 and choice("200", "1000", "1", "-p", "64") == ("exact", 1)
-    assert n1 * (2200 + 1 + 16) * 8 > 2.5e7 and choice("2200", "1000", "1", "-p", "8") == ("parallel", 8)   # per-chain rows alone: 3.1e6
-    assert n1 * (2200 + 1 + 125) * 8 > 2.5e7 and n1 * (2200 + 1 + 1000) * 1 <= 2.5e7
-    assert choice("2200", "1000", "1", "-p", "1") == ("exact", 1)                  # same burn-in, one chain: affordable
-    assert choice("200", "1000", "1", "-p", "8", "--gibbs-mode", "parallel") == ("parallel", 8)
-    assert choice("200", "1000", "1", "-p", "8", "--gibbs-mode", "parallel", "--gibbs-thin", "3") == ("parallel", 3)
-    assert choice("20000", "1000", "1", "-p", "8", "--gibbs-mode", "exact") == ("exact", 1)  # explicit request is honoured ...
-    r = subprocess.run([exe, d + "/ref", d + "/temp/s", d + "/stat/s", "20000", "1000", "1", "-p", "8", "--gibbs-mode", "exact", "--dry-run"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    assert r.returncode == 0 and "Warning" in r.stderr and "exact" in r.stderr and "parallel" in r.stderr  # ... but not silently
-    r = subprocess.run([exe, d + "/ref", d + "/temp/s", d + "/stat/s", "20", "40", "1", "-p", "2", "--gibbs-mode", "exact", "--dry-run"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    assert r.returncode == 0 and "Warning" not in r.stderr
+    assert choice("20", "40", "1", "-p", "2") == ("exact", 1, 1)
+    assert choice("200", "1000", "1", "-p", "64") == ("exact", 1, 1)
+    assert choice("20000", "1000", "1", "-p", "8", "--gibbs-mode", "exact") == ("exact", 1, 1)
+    assert choice("200", "1000", "1", "-p", "8", "--gibbs-mode", "parallel") == ("parallel", 8, 1)
+    assert choice("200", "1000", "1", "-p", "8", "--gibbs-mode", "parallel", "--gibbs-thin", "3") == ("parallel", 3, 1)
+    assert choice("200", "1000", "1", "-p", "8", "--devices", "0,0") == ("exact", 1, 2)
+    assert choice("200", "1000", "1", "-p", "1", "--devices", "0,0") == ("exact", 1, 1)  # never more groups than chains
+    r = run("200", "1000", "1", "-p", "8", "--gibbs-mode", "parallel")
+    assert "data-augmentation" in r.stderr
+    r = run("200", "1000", "1", "-p", "8")
+    assert "data-augmentation" not in r.stderr
+    r = run("200", "1000", "1", "-p", "8", "--gibbs-mode", "Exact")
+    assert r.returncode != 0 and "unknown --gibbs-mode" in r.stderr

@@ -63,6 +63,106 @@ def test_exact_chain_bit_identical_to_reference(name):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", rf.FIXTURES)
+def test_all_chains_in_one_launch_match_reference_files(name):
+    """rsem_gibbs_run_chains: the reference's -p T chains advance together (one wave each); every chain's count vectors
+    equal the reference's imd.countvectors<k> bit for bit and the summed accumulators equal the per-chain runs'."""
+    d = _load(name)
+    burnin, nsamples, gap = d["meta"]["gibbs"]
+    T = d["meta"]["gibbs_threads"]
+    seeds = capi().gibbs_chain_seeds(d["meta"]["gibbs_seed"], T)
+    ns = [nsamples // T + (1 if k < nsamples % T else 0) for k in range(T)]
+    ctx = _ctx(d)
+    cvs, acc, _, prof = ctx.run_chains(capi().GIBBS_EXACT, seeds, burnin, ns, gap)
+    assert prof.chains == T
+    tot = None
+    for k in range(T):
+        gold = rf.read_countvectors(os.path.join(d["fx"], "temp", "s.countvectors%d" % k))
+        assert np.array_equal(cvs[k], gold)
+        _, oacc = orc.gibbs_chain(d["M"], d["rp"], d["sid"], d["val"], d["init"], None, d["pseudoC"],
+                                  d["totc"], d["N0"], d["eel"], d["mw"], d["grp"], seeds[k], burnin, ns[k], gap)
+        tot = oacc if tot is None else [x + y for x, y in zip(tot, oacc)]
+    for a, b in zip(acc, tot):
+        assert np.allclose(a, b, rtol=1e-10, atol=1e-9)
+    ctx.close()
+
+
+def _synthetic_items(n_reads, config="small", long_row_every=0):
+    from tools.synth_data import make_em_workload, to_gibbs_items
+    wl = make_em_workload(config, seed=5, long_row_every=long_row_every)
+    rp = wl["row_ptr"][:n_reads + 1]
+    nz = int(rp[-1])
+    sub = dict(wl, row_ptr=rp, sid=wl["sid"][:nz], conprb=wl["conprb"][:nz], ncp=wl["ncp"][:n_reads])
+    return wl["M"], to_gibbs_items(sub)
+
+
+@pytest.mark.parametrize("n_reads,long_every", [(200_000, 0), (30_000, 4000)])
+def test_exact_tile_kernel_at_scale_vs_oracle_and_serial_kernel(n_reads, long_every, monkeypatch):
+    """200 k reads x 5000 transcripts, 5 concurrent chains with unequal lengths: the cooperative tile kernel, the
+    previous lane-0 kernel (RSEM_GIBBS_EXACT_IMPL=serial) and the oracle's sequential chain give the same count
+    vectors; the second case carries reads with more items than an LDS tile (walked alone)."""
+    M, (irp, isid, icp) = _synthetic_items(n_reads, long_row_every=long_every)
+    init = np.zeros(M + 1, np.int32)
+    N0, pseudoC = 12345, 1.0
+    eel, mw = np.full(M + 1, 700.0), np.ones(M + 1)
+    grp = np.arange(1, M + 2, 10, dtype=np.int32)
+    if grp[-1] != M + 1:
+        grp = np.append(grp, M + 1).astype(np.int32)
+    totc = (M + 1) * pseudoC + N0 + n_reads
+    seeds = capi().gibbs_chain_seeds(99, 5)
+    ns = [3, 3, 2, 2, 2]
+    burnin, gap = 3, 2
+    ctx = capi().GibbsContext(M, irp, isid, icp, init, None, pseudoC, totc, N0, eel, mw, grp)
+    cvs, acc, _, prof = ctx.run_chains(capi().GIBBS_EXACT, seeds, burnin, ns, gap)
+    monkeypatch.setenv("RSEM_GIBBS_EXACT_IMPL", "serial")
+    cvs_s, acc_s, _, prof_s = ctx.run_chains(capi().GIBBS_EXACT, seeds, burnin, ns, gap)
+    monkeypatch.delenv("RSEM_GIBBS_EXACT_IMPL")
+    for k in range(5):
+        assert np.array_equal(cvs[k], cvs_s[k])
+    for a, b in zip(acc, acc_s):
+        assert np.array_equal(a, b)
+    for k in (0, 4):
+        ocv, _ = orc.gibbs_chain(M, irp, isid, icp, init, None, pseudoC, totc, N0, eel, mw, grp, seeds[k], burnin, ns[k], gap)
+        assert np.array_equal(cvs[k], ocv)
+    assert np.all(cvs[0].sum(1) == N0 + n_reads)
+    print("exact sweeps: tile kernel %.3f ms, lane-0 kernel %.3f ms per round (5 chains, %d reads)" % (prof.sweep_ms, prof_s.sweep_ms, n_reads))
+    ctx.close()
+
+
+def test_chain_groups_reduce_over_local_comm():
+    """Chains dealt to two groups (here: both on GPU 0, the LOCAL communicator; on a multi-GPU node the same calls run
+    over RCCL): group sums meet in one reduce on rank 0 and equal the single-group run; count vectors stay with the
+    group that ran the chain (file ownership: Gibbs.cpp:225-226)."""
+    import threading
+    d = _load("pe_q")
+    seeds = capi().gibbs_chain_seeds(17, 4)
+    ns = [5, 5, 4, 4]
+    ctx = _ctx(d)
+    cvs, acc, _, _ = ctx.run_chains(capi().GIBBS_EXACT, seeds, 4, ns, 1)
+    ctx.close()
+    comms = capi().Comm.create_local([0, 0])
+    assert [c.rank for c in comms] == [0, 1] and comms[0].world == 2
+    out = [None, None]
+
+    def group(w):
+        g = _ctx(d)
+        g.set_comm(comms[w])
+        mine = list(range(w, 4, 2))
+        out[w] = g.run_chains(capi().GIBBS_EXACT, seeds[mine], 4, [ns[k] for k in mine], 1)
+        g.close()
+
+    ts = [threading.Thread(target=group, args=(w,)) for w in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for c in comms:
+        c.close()
+    assert out[0] is not None and out[1] is not None
+    for a, b in zip(out[0][1], acc):  # rank 0 holds the totals
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-9)
+    assert np.array_equal(out[0][0][0], cvs[0]) and np.array_equal(out[0][0][1], cvs[2])
+    assert np.array_equal(out[1][0][0], cvs[1]) and np.array_equal(out[1][0][1], cvs[3])
+
+
 def test_parallel_sampler_invariants_and_determinism():
     d = _load("se_q")
     ctx = _ctx(d)
