@@ -116,20 +116,27 @@ int rsem_em_run(rsem_em_ctx* ctx, double* theta_inout, double N0, int round0, in
                 int max_round, int* rounds_done, double* counts, double* bChange, int32_t* totNum,
                 rsem_em_profile* profile);
 
+/* The line the reference prints after every round (EM.cpp:415): ROUND, SUM, bChange, totNum.  When set, rsem_em_run
+ * calls fn on the calling thread for every round it executes, in order, shortly after the round finished on the
+ * device (the loop itself never waits for the host).  fn = NULL switches it off. */
+typedef void (*rsem_em_progress_fn)(int round, double sum, double bChange, int totNum, void* user);
+int rsem_em_set_progress(rsem_em_ctx* ctx, rsem_em_progress_fn fn, void* user);
+
+/* Rows sharded over the ranks of `comm` (the reference's thread split, EM.cpp:135-157): every
+ * rank holds a ctx over its own reads and the same M; rsem_em_run then must be called on all ranks with the same
+ * theta, the GLOBAL N0 and the same round arguments, and sums the fractional counts of every round over the ranks
+ * with one all-reduce of M+1 (+ a few) doubles on the ctx stream (EM.cpp:385-389) before the M step, which every
+ * rank computes identically.  comm is not owned; NULL detaches. */
+int rsem_em_set_comm(rsem_em_ctx* ctx, rsem_comm* comm);
+/* The reference's split of the reads over T workers (EM.cpp:135-157): worker i takes rows until it holds >= nHits / T
+ * alignments, the last one the rest, every later worker at least one row.  Host-only; bounds[world + 1]. */
+int rsem_em_shard_rows(uint64_t N1, const uint64_t* row_ptr, int world, uint64_t* bounds);
+
 /* Final pass with calcExpectedWeights = true (EM.cpp:460-478): counts incl. +N0, posterior weight
  * of every alignment w[nnz] (file order) and of the noise transcript w_noise[N1]; rows whose
  * normaliser is < 1e-300 get zeros (EM.cpp:237-243). */
 int rsem_em_expected_weights(rsem_em_ctx* ctx, const double* theta, double N0, double* counts,
                              double* w, double* w_noise);
-
-/* Multi-GPU EM: rows sharded over ranks, theta replicated, one all-reduce of the
- * counts per round issued by the caller between the two halves below.  d_counts / d_theta are
- * device buffers of M+1 doubles owned by the CALLER (e.g. torch tensors) and stream is the HIP
- * stream the caller's collective is ordered on. */
-int rsem_em_estep_device(rsem_em_ctx* ctx, const void* d_theta, void* d_counts, void* stream);
-int rsem_em_mstep_device(rsem_em_ctx* ctx, void* d_counts, double N0_global, const void* d_theta_old,
-                         void* d_theta_new, void* d_stats /* 3 doubles: sum,bChange,totNum */,
-                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Read models (rounds 1-11 of rsem-run-em).  Replaces the per-read / per-alignment work of

@@ -37,6 +37,8 @@ class EmProfile(C.Structure):
                 ("rounds", C.c_int32), ("algorithmic_bytes_per_round", C.c_uint64)]
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p)
+
 _lib = None
 
 
@@ -57,11 +59,12 @@ def lib():
         L.rsem_em_set_values.argtypes = [vp, _f64p, _f64p]
         L.rsem_em_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         L.rsem_em_destroy.argtypes = [vp]
+        L.rsem_em_set_comm.argtypes = [vp, vp]
+        L.rsem_em_set_progress.argtypes = [vp, vp, vp]
+        L.rsem_em_shard_rows.argtypes = [u64, _u64p, ci, _u64p]
         L.rsem_em_step.argtypes = [vp, _f64p, dbl, vp, vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(i32)]
         L.rsem_em_run.argtypes = [vp, _f64p, dbl, ci, ci, ci, C.POINTER(ci), vp, C.POINTER(dbl), C.POINTER(i32), vp]
         L.rsem_em_expected_weights.argtypes = [vp, _f64p, dbl, vp, vp, vp]
-        L.rsem_em_estep_device.argtypes = [vp, vp, vp, vp]
-        L.rsem_em_mstep_device.argtypes = [vp, vp, dbl, vp, vp, vp, vp]
         L.rsem_gibbs_create.argtypes = [C.POINTER(vp), ci, i32, u64, u64, _u64p, _i32p, _f64p, _i32p, vp, dbl, dbl, u64,
                                         _f64p, _f64p, i32, _i32p]
         L.rsem_gibbs_run.argtypes = [vp, ci, C.c_uint32, ci, ci, ci, ci, vp, _f64p, _f64p, _f64p, _f64p, _f64p, vp]
@@ -138,6 +141,14 @@ class EmContext:
     def set_option(self, key, value):
         _check(lib().rsem_em_set_option(self._h, key.encode(), int(value)))
 
+    def set_comm(self, comm):
+        _check(lib().rsem_em_set_comm(self._h, comm._h if comm is not None else None))
+
+    def set_progress(self, fn):
+        """fn(round, sum, bChange, totNum) for every round of run() (EM.cpp:415), or None."""
+        self._cb = PROGRESS_FN(lambda r, s, b, t, u: fn(r, s, b, t)) if fn else None
+        _check(lib().rsem_em_set_progress(self._h, C.cast(self._cb, C.c_void_p) if fn else None, None))
+
     def step(self, theta, N0):
         theta = np.ascontiguousarray(theta, np.float64)
         counts, theta_new = np.zeros(self.M + 1), np.zeros(self.M + 1)
@@ -165,13 +176,6 @@ class EmContext:
         wn = np.zeros(self.N1) if want_weights else None
         _check(lib().rsem_em_expected_weights(self._h, theta, float(N0), _ptr(counts), _ptr(w), _ptr(wn)))
         return counts, w, wn
-
-    # multi-GPU halves: raw device pointers + stream (ints)
-    def estep_device(self, d_theta, d_counts, stream):
-        _check(lib().rsem_em_estep_device(self._h, d_theta, d_counts, stream))
-
-    def mstep_device(self, d_counts, N0_global, d_theta_old, d_theta_new, d_stats, stream):
-        _check(lib().rsem_em_mstep_device(self._h, d_counts, float(N0_global), d_theta_old, d_theta_new, d_stats, stream))
 
 
 class GibbsContext:
@@ -279,6 +283,14 @@ class Comm:
         if self._h:
             lib().rsem_comm_destroy(self._h)
             self._h = C.c_void_p()
+
+
+def em_shard_rows(row_ptr, world):
+    """rsem_em_shard_rows: the reference's split of the reads over `world` workers (EM.cpp:135-157)."""
+    rp = np.ascontiguousarray(row_ptr, np.uint64)
+    out = np.zeros(world + 1, np.uint64)
+    _check(lib().rsem_em_shard_rows(len(rp) - 1, rp, world, out))
+    return [int(x) for x in out]
 
 
 def gibbs_chain_seeds(seed, n):

@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 
 #include <condition_variable>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -103,15 +104,22 @@ static int local_exchange(rsem_comm* c, double* d_buf, size_t n, hipStream_t st,
     return RSEM_OK;
 }
 
+// a one-rank communicator normally skips the collective; RSEM_COMM_FORCE=1 issues it anyway (single-GPU test of the RCCL calls)
+static bool skip_single(const rsem_comm* c) {
+    return !c || (c->world == 1 && getenv("RSEM_COMM_FORCE") == nullptr);
+}
+
+bool comm_active(const rsem_comm* c) { return !skip_single(c); }
+
 int comm_allreduce_sum_f64(rsem_comm* c, double* d_buf, size_t n, hipStream_t st) {
-    if (!c || c->world == 1) return RSEM_OK;
+    if (skip_single(c)) return RSEM_OK;
     if (c->kind == 1) return local_exchange(c, d_buf, n, st, true, 0);
     RSEM_NCCL_TRY(ncclAllReduce(d_buf, d_buf, n, ncclDouble, ncclSum, c->nccl, st));
     return RSEM_OK;
 }
 
 int comm_reduce_sum_f64(rsem_comm* c, double* d_buf, size_t n, int root, hipStream_t st) {
-    if (!c || c->world == 1) return RSEM_OK;
+    if (skip_single(c)) return RSEM_OK;
     if (c->kind == 1) return local_exchange(c, d_buf, n, st, false, root);
     RSEM_NCCL_TRY(ncclReduce(d_buf, d_buf, n, ncclDouble, ncclSum, root, c->nccl, st));
     return RSEM_OK;

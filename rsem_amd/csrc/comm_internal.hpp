@@ -18,6 +18,8 @@ namespace rsem {
 int comm_allreduce_sum_f64(rsem_comm* c, double* d_buf, size_t n, hipStream_t st);
 // in-place sum over all ranks, result on `root` only (the other ranks' buffers are unspecified afterwards)
 int comm_reduce_sum_f64(rsem_comm* c, double* d_buf, size_t n, int root, hipStream_t st);
+// false for NULL and for a one-rank communicator (unless RSEM_COMM_FORCE is set): the collectives are no-ops then
+bool comm_active(const rsem_comm* c);
 int comm_rank(const rsem_comm* c);
 int comm_world(const rsem_comm* c);
 

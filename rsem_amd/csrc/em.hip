@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cmath>
 
+#include "comm_internal.hpp"
 #include "em_internal.hpp"
 #include "sell_layout.hpp"
 
@@ -54,6 +55,19 @@ struct Ctrl {  // device-resident loop control, one per ctx
     int last_totNum;
     int last_round;
     unsigned long long tick2;  // k_mstep_fast: (sum of totNum) << 32 | arrivals, one atomic per workgroup
+};
+
+// What the host reads while the loop runs, in pinned host memory the M-step kernel writes directly (no stream sync, no
+// copy): the statistics line of every finished round (EM.cpp:415) and the stop flag.  hist is a ring; the host keeps
+// fewer than kHistCap rounds in flight.
+constexpr int kHistCap = 1024;
+struct RoundStat { double sum, bchange; int totNum, round; };
+struct HostMirror {
+    int last_round;  // rounds <= last_round have their RoundStat in hist[(round - 1) % kHistCap]
+    int done;
+    int final_round;
+    int pad;
+    RoundStat hist[kHistCap];
 };
 
 
@@ -139,6 +153,35 @@ __global__ __launch_bounds__(kBlock) void k_estep_csr(
         }
     }
     block_add_totals(noise, neff, noise_partial, totals);
+}
+
+// Posterior weight of every alignment in file order (calcExpectedWeights, EM.cpp:237-243): w[j] = f_j / sum_i and
+// w_noise[i]; rows whose normaliser is < 1e-300 get zeros.  Thread per read over the caller's CSR, no atomics: the
+// counts of the same round come from the main E-step kernel, this pass only serves the consumers that need the
+// weights themselves (the model statistics of rounds 1-10, the transcript BAM).
+__global__ __launch_bounds__(kBlock) void k_weights_csr(uint64_t N1, const uint64_t* __restrict__ row_ptr,
+                                                         const int32_t* __restrict__ sid, const double* __restrict__ cp,
+                                                         const double* __restrict__ ncp, const double* __restrict__ theta,
+                                                         double* __restrict__ w, double* __restrict__ w_noise) {
+    const double th0 = theta[0];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N1; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t fr = row_ptr[i], to = row_ptr[i + 1];
+        double f0 = th0 * ncp[i];
+        if (f0 < kEpsilon) f0 = 0.0;
+        double sum = f0;
+        for (uint64_t j = fr; j < to; j++) {
+            double f = theta[sid[j]] * cp[j];
+            if (f < kEpsilon) f = 0.0;
+            sum += f;
+        }
+        const bool ok = sum >= kEpsilon;
+        w_noise[i] = ok ? f0 / sum : 0.0;
+        for (uint64_t j = fr; j < to; j++) {
+            double f = theta[sid[j]] * cp[j];
+            if (f < kEpsilon) f = 0.0;
+            w[j] = ok ? f / sum : 0.0;
+        }
+    }
 }
 
 // segmented sum of v over lanes {g, g+G, g+2G, ...} keyed by `key`; returns true on the tail lane
@@ -579,7 +622,8 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fused(int32_t M, double N0, do
 // fraction (a second set of slots).  No reduction, no barrier before theta = counts / sum.
 __global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, double* counts, double* totals,
                                                         const double* __restrict__ theta_old, double* theta_new,
-                                                        double* counts_last, Ctrl* ctrl, int round, int min_round, int max_round) {
+                                                        double* counts_last, Ctrl* ctrl, int round, int min_round, int max_round,
+                                                        HostMirror* mirror) {
     if (ctrl->done) return;
     const int n = M + 1;
     const int nb = gridDim.x;
@@ -656,9 +700,20 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, dou
             ctrl->last_bchange = __longlong_as_double((long long)bb);
             ctrl->last_totNum = totNum;
             ctrl->last_round = round;
-            if (!(round < min_round || (totNum > 0 && round < max_round))) {
+            const bool stop = !(round < min_round || (totNum > 0 && round < max_round));
+            if (stop) {
                 ctrl->done = 1;
                 ctrl->final_round = round;
+            }
+            if (mirror) {  // the host's view: this round's line first, then the counters that announce it
+                RoundStat* h = &mirror->hist[(round - 1) % kHistCap];
+                h->sum = sum;
+                h->bchange = __longlong_as_double((long long)bb);
+                h->totNum = totNum;
+                h->round = round;
+                if (stop) mirror->final_round = round;
+                __hip_atomic_store(&mirror->last_round, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (stop) __hip_atomic_store(&mirror->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             __hip_atomic_store(&ctrl->bbits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctrl->tick2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -700,11 +755,12 @@ struct rsem_em_ctx {
     size_t noise_cap = 0;
     // EM state
     double* d_theta[2] = {nullptr, nullptr};
-    double* d_counts = nullptr;
+    double* d_red = nullptr;      // [counts (M+1) | totals (2 * kTotSlots)]: one buffer, so that one all-reduce covers both
+    double* d_counts = nullptr;   // = d_red
     double* d_counts_last = nullptr;
     double* d_noise_a = nullptr;  // per-workgroup noise partials of the main E-step launch
     double* d_noise_b = nullptr;  // ... of the long-row launch
-    double* d_totals = nullptr;   // [0] noise fraction, [1] reads with a non-zero normaliser, of the current round (rsem_em_run)
+    double* d_totals = nullptr;   // = d_red + M + 1: kTotSlots slots of the noise fraction, then of the reads with a non-zero normaliser
     bool use_totals = false;
     double* d_partials = nullptr;
     double* d_w = nullptr;        // expected-weights scratch (nnz), lazily allocated
@@ -713,9 +769,14 @@ struct rsem_em_ctx {
     int grid_main = 0, grid_long = 0, grid_apply = 0;
     int kernel = RSEM_EM_KERNEL_AUTO;
     uint32_t forced_T = 0;
-    int check_every = 16;
+    int check_every = 64;
     int n_cus = 256;
     std::vector<hipEvent_t> events;
+    HostMirror* mirror = nullptr;  // pinned host memory, written by the M-step kernel
+    hipEvent_t lag_ev[2] = {nullptr, nullptr};
+    rsem_comm* comm = nullptr;     // not owned; rows sharded over its ranks when set
+    rsem_em_progress_fn progress = nullptr;
+    void* progress_user = nullptr;
 };
 
 namespace {
@@ -759,13 +820,21 @@ int n_noise_b(const rsem_em_ctx* c) {
     return (kern != RSEM_EM_KERNEL_CSR && c->L.n_long_rows) ? c->grid_long : 0;
 }
 
+int launch_weights(rsem_em_ctx* c, const double* d_theta, hipStream_t st) {
+    const int grid = std::max(1, std::min<int>(c->n_cus * 16, rsem::ceil_div(c->N1, kBlock)));
+    hipLaunchKernelGGL(k_weights_csr, dim3(grid), dim3(kBlock), 0, st, c->N1, c->d_row_ptr, c->d_sid, c->d_cp, c->d_ncp, d_theta,
+                       c->d_w, c->d_wn);
+    RSEM_HIP_TRY(hipGetLastError());
+    return RSEM_OK;
+}
+
 int launch_mstep(rsem_em_ctx* c, double N0, double* d_counts, const double* d_theta_old, double* d_theta_new,
-                 int round, int min_round, int max_round, hipStream_t st) {
+                 int round, int min_round, int max_round, hipStream_t st, HostMirror* mirror = nullptr) {
     const int grid = std::max(1, std::min(kMstepBlocks, rsem::ceil_div((uint64_t)c->M + 1, kBlock * 4)));
     if (c->use_totals) {
         const int gridf = std::max(1, std::min(2 * kMstepBlocks, rsem::ceil_div((uint64_t)c->M + 1, kBlock * 2)));
         hipLaunchKernelGGL(k_mstep_fast, dim3(gridf), dim3(kBlock), 0, st, c->M, N0, d_counts, c->d_totals, d_theta_old, d_theta_new,
-                           c->d_counts_last, c->d_ctrl, round, min_round, max_round);
+                           c->d_counts_last, c->d_ctrl, round, min_round, max_round, mirror);
         RSEM_HIP_TRY(hipGetLastError());
         return RSEM_OK;
     }
@@ -872,11 +941,15 @@ int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64
         c->have_values = true;
     }
     for (int i = 0; i < 2; i++) TRY_OR_FAIL(dmalloc(&c->d_theta[i], (size_t)M + 1));
-    TRY_OR_FAIL(dmalloc(&c->d_counts, (size_t)M + 1));
+    TRY_OR_FAIL(dmalloc(&c->d_red, (size_t)M + 1 + 2 * kTotSlots));
+    c->d_counts = c->d_red;
+    c->d_totals = c->d_red + (size_t)M + 1;
     TRY_OR_FAIL(dmalloc(&c->d_counts_last, (size_t)M + 1));
     TRY_OR_FAIL(dmalloc(&c->d_noise_b, (size_t)c->n_cus * 8));
-    TRY_OR_FAIL(dmalloc(&c->d_totals, 2 * kTotSlots));
     TRY_OR_FAIL(hipMemsetAsync(c->d_totals, 0, sizeof(double) * 2 * kTotSlots, c->stream));
+    TRY_OR_FAIL(hipHostMalloc((void**)&c->mirror, sizeof(HostMirror), hipHostMallocDefault));
+    memset(c->mirror, 0, sizeof(HostMirror));
+    for (int i = 0; i < 2; i++) TRY_OR_FAIL(hipEventCreateWithFlags(&c->lag_ev[i], hipEventDisableTiming));
     TRY_OR_FAIL(dmalloc(&c->d_partials, 2 * kReduceBlocks));
     TRY_OR_FAIL(dmalloc(&c->d_ctrl, 1));
     TRY_OR_FAIL(hipMemsetAsync(c->d_counts, 0, sizeof(double) * ((size_t)M + 1), c->stream));
@@ -904,6 +977,41 @@ int rsem_em_set_values(rsem_em_ctx* c, const double* conprb, const double* ncp) 
     return RSEM_OK;
 }
 
+int rsem_em_shard_rows(uint64_t N1, const uint64_t* row_ptr, int world, uint64_t* bounds) {
+    RSEM_REQUIRE(row_ptr && bounds && world >= 1, "bad argument");
+    // EM.cpp:135-157: thread i reads rows while (rows left > threads left) and (it is the last thread or it holds
+    // fewer than nHits / T alignments).  Same boundaries, found by bisection instead of by reading.
+    const uint64_t nhT = row_ptr[N1] / (uint64_t)world;
+    uint64_t cur = 0;
+    bounds[0] = 0;
+    for (int i = 0; i < world; i++) {
+        const uint64_t left_threads = (uint64_t)(world - i - 1);
+        if (i == world - 1) cur = N1;
+        else {
+            const uint64_t cap = N1 > left_threads ? N1 - left_threads : 0;  // leave one row for every later thread
+            const uint64_t target = row_ptr[cur] + nhT;
+            uint64_t nxt = (uint64_t)(std::lower_bound(row_ptr + cur, row_ptr + N1 + 1, target) - row_ptr);
+            nxt = std::min(nxt, std::max(cap, cur));
+            cur = std::max(cur, nxt);
+        }
+        bounds[i + 1] = cur;
+    }
+    return RSEM_OK;
+}
+
+int rsem_em_set_comm(rsem_em_ctx* c, rsem_comm* comm) {
+    RSEM_REQUIRE(c != nullptr, "NULL argument");
+    c->comm = comm;
+    return RSEM_OK;
+}
+
+int rsem_em_set_progress(rsem_em_ctx* c, rsem_em_progress_fn fn, void* user) {
+    RSEM_REQUIRE(c != nullptr, "NULL argument");
+    c->progress = fn;
+    c->progress_user = user;
+    return RSEM_OK;
+}
+
 int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
     RSEM_REQUIRE(c && key, "NULL argument");
     if (!strcmp(key, "kernel")) {
@@ -913,7 +1021,7 @@ int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
         return RSEM_OK;
     }
     if (!strcmp(key, "check_every")) {
-        RSEM_REQUIRE(value >= 1 && value <= 1024, "check_every out of range");
+        RSEM_REQUIRE(value >= 1 && value <= kHistCap / 4, "check_every out of range");
         c->check_every = (int)value;
         return RSEM_OK;
     }
@@ -954,8 +1062,10 @@ int rsem_em_destroy(rsem_em_ctx* c) {
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     hipFree(c->d_row_ptr); hipFree(c->d_sid); hipFree(c->d_cp); hipFree(c->d_ncp);
     sell_free(c->L); hipFree(c->d_scp); hipFree(c->d_sncp);
-    hipFree(c->d_theta[0]); hipFree(c->d_theta[1]); hipFree(c->d_counts);
-    hipFree(c->d_counts_last); hipFree(c->d_noise_a); hipFree(c->d_noise_b); hipFree(c->d_totals); hipFree(c->d_partials);
+    hipFree(c->d_theta[0]); hipFree(c->d_theta[1]); hipFree(c->d_red);
+    hipFree(c->d_counts_last); hipFree(c->d_noise_a); hipFree(c->d_noise_b); hipFree(c->d_partials);
+    if (c->mirror) (void)hipHostFree(c->mirror);
+    for (int i = 0; i < 2; i++) if (c->lag_ev[i]) (void)hipEventDestroy(c->lag_ev[i]);
     hipFree(c->d_w); hipFree(c->d_wn); hipFree(c->d_ctrl); hipFree(c->d_units);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1026,6 +1136,29 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
     }
     Ctrl h;
     memset(&h, 0, sizeof(h));
+    // The host never drains the stream inside the loop.  The last workgroup of every M step writes the round's line and
+    // the stop flag into pinned host memory (HostMirror); the host reads them between launches and only waits on the
+    // event recorded check_every rounds earlier, so that at most 2 * check_every rounds are in flight.  Launches made
+    // after the device set its stop flag return at once (theta is frozen at exactly the reference's stopping round).
+    // With a communicator the enqueued collectives must be the same on every rank, so there the decision is taken at
+    // fixed rounds from the device flag itself (identical on all ranks: they reduce to the same bits).
+    HostMirror* mir = c->use_totals ? c->mirror : nullptr;
+    if (mir) {
+        mir->done = 0;
+        mir->final_round = 0;
+        mir->last_round = round0;
+    }
+    const bool sharded = rsem::comm_active(c->comm);
+    if (sharded && !c->use_totals) { rsem::set_last_error("sharded EM needs the LANE kernel"); return RSEM_ERR_STATE; }
+    int printed = round0, lag = 0;
+    auto report = [&](int upto) {  // the reference prints this line after every round (EM.cpp:415)
+        if (!mir || !c->progress) return;
+        for (int q = printed + 1; q <= upto; q++) {
+            const RoundStat& rs = mir->hist[(q - 1) % kHistCap];
+            c->progress(rs.round, rs.sum, rs.bchange, rs.totNum, c->progress_user);
+        }
+        printed = std::max(printed, upto);
+    };
     int r = round0;
     while (r < max_round) {
         ++r;
@@ -1036,19 +1169,37 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
         int rc = launch_estep(c, th_old, c->d_counts, st, true);
         if (rc != RSEM_OK) return rc;
         if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));
-        rc = launch_mstep(c, N0, c->d_counts, th_old, th_new, r, min_round, max_round, st);
-        if (rc != RSEM_OK) return rc;
-        if (r >= min_round && ((r - round0) % c->check_every == 0 || r == max_round)) {
-            RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
-            RSEM_HIP_TRY(hipStreamSynchronize(st));
-            if (h.done) break;
+        if (sharded) {  // EM.cpp:385-389 across shards: counts and the two totals in one all-reduce
+            rc = rsem::comm_allreduce_sum_f64(c->comm, c->d_red, (size_t)c->M + 1 + 2 * kTotSlots, st);
+            if (rc != RSEM_OK) return rc;
         }
+        rc = launch_mstep(c, N0, c->d_counts, th_old, th_new, r, min_round, max_round, st, mir);
+        if (rc != RSEM_OK) return rc;
+        const bool checkpoint = ((r - round0) % c->check_every == 0) || r == max_round;
+        if (sharded || !mir) {
+            if (r >= min_round && checkpoint) {
+                RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
+                RSEM_HIP_TRY(hipStreamSynchronize(st));
+                if (mir) report(h.done ? h.final_round : r);
+                if (h.done) break;
+            }
+            continue;
+        }
+        if (checkpoint) {
+            RSEM_HIP_TRY(hipEventRecord(c->lag_ev[lag & 1], st));
+            if (lag > 0) RSEM_HIP_TRY(hipEventSynchronize(c->lag_ev[(lag - 1) & 1]));
+            ++lag;
+        }
+        const int seen = __atomic_load_n(&mir->last_round, __ATOMIC_ACQUIRE);
+        if (c->progress && seen > printed) report(seen);
+        if (__atomic_load_n(&mir->done, __ATOMIC_ACQUIRE)) break;
     }
     if (prof) RSEM_HIP_TRY(hipEventRecord(c->events[1], st));
     RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
     RSEM_HIP_TRY(hipStreamSynchronize(st));
     if (!h.done) { rsem::set_last_error("EM loop ended without the device stop flag"); return RSEM_ERR_STATE; }
     const int fr = h.final_round;
+    report(fr);
     RSEM_HIP_TRY(hipMemcpyAsync(theta, c->d_theta[fr & 1], nb, hipMemcpyDeviceToHost, st));
     if (counts) RSEM_HIP_TRY(hipMemcpyAsync(counts, c->d_counts_last, nb, hipMemcpyDeviceToHost, st));
     RSEM_HIP_TRY(hipStreamSynchronize(st));
@@ -1104,19 +1255,21 @@ int rsem_em_expected_weights(rsem_em_ctx* c, const double* theta, double N0, dou
     RSEM_HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const size_t nb = sizeof(double) * ((size_t)c->M + 1);
-    if (!c->d_w) RSEM_HIP_TRY(dmalloc(&c->d_w, c->nnz));
-    if (!c->d_wn) RSEM_HIP_TRY(dmalloc(&c->d_wn, c->N1));
+    if ((w || w_noise) && !c->d_w) RSEM_HIP_TRY(dmalloc(&c->d_w, c->nnz));
+    if ((w || w_noise) && !c->d_wn) RSEM_HIP_TRY(dmalloc(&c->d_wn, c->N1));
     RSEM_HIP_TRY(hipMemcpyAsync(c->d_theta[0], theta, nb, hipMemcpyHostToDevice, st));
     RSEM_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), st));
     RSEM_HIP_TRY(hipMemsetAsync(c->d_counts, 0, nb, st));
-    int grid = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->N1, kBlock)));
-    hipLaunchKernelGGL(k_estep_csr<true>, dim3(grid), dim3(kBlock), 0, st, c->N1, (const uint32_t*)nullptr, c->d_row_ptr,
-                       c->d_sid, c->d_cp, c->d_ncp, c->d_theta[0], c->d_counts, c->d_noise_a, c->d_w, c->d_wn,
-                       (const Ctrl*)c->d_ctrl);
+    // counts: the main E-step kernel (same launch as every theta-only round); weights: their own file-order pass
+    int rc = launch_estep(c, c->d_theta[0], c->d_counts, st, true);
+    if (rc != RSEM_OK) return rc;
+    hipLaunchKernelGGL(k_mstep_reduce, dim3(kReduceBlocks), dim3(kBlock), 0, st, c->M, N0, c->d_counts, c->d_noise_a, c->noise_n,
+                       c->d_noise_b, n_noise_b(c), c->d_partials, (const Ctrl*)c->d_ctrl);
     RSEM_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_mstep_reduce, dim3(kReduceBlocks), dim3(kBlock), 0, st, c->M, N0, c->d_counts, c->d_noise_a, grid,
-                       c->d_noise_b, 0, c->d_partials, (const Ctrl*)c->d_ctrl);
-    RSEM_HIP_TRY(hipGetLastError());
+    if ((w || w_noise) && c->N1) {
+        rc = launch_weights(c, c->d_theta[0], st);
+        if (rc != RSEM_OK) return rc;
+    }
     if (counts) RSEM_HIP_TRY(hipMemcpyAsync(counts, c->d_counts, nb, hipMemcpyDeviceToHost, st));
     if (w && c->nnz) RSEM_HIP_TRY(hipMemcpyAsync(w, c->d_w, sizeof(double) * c->nnz, hipMemcpyDeviceToHost, st));
     if (w_noise && c->N1) RSEM_HIP_TRY(hipMemcpyAsync(w_noise, c->d_wn, sizeof(double) * c->N1, hipMemcpyDeviceToHost, st));
@@ -1125,72 +1278,7 @@ int rsem_em_expected_weights(rsem_em_ctx* c, const double* theta, double N0, dou
     return RSEM_OK;
 }
 
-int rsem_em_estep_device(rsem_em_ctx* c, const void* d_theta, void* d_counts, void* stream) {
-    RSEM_REQUIRE(c && d_theta && d_counts, "NULL argument");
-    if (!c->have_values) { rsem::set_last_error("CSR values were never set"); return RSEM_ERR_STATE; }
-    RSEM_HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
-    // counts is an accumulator: the caller zeroes it (or mstep_device did after the previous round)
-    int rc = launch_estep(c, (const double*)d_theta, (double*)d_counts, st, false);
-    if (rc != RSEM_OK) return rc;
-    // fold this rank's noise partials into counts[0] now, so that the caller's all-reduce sees them
-    hipLaunchKernelGGL(k_mstep_reduce, dim3(1), dim3(kBlock), 0, st, 0, 0.0, (double*)d_counts, c->d_noise_a, c->noise_n,
-                       c->d_noise_b, n_noise_b(c), c->d_partials, (const Ctrl*)c->d_ctrl);
-    RSEM_HIP_TRY(hipGetLastError());
-    return RSEM_OK;
-}
-
 }  // extern "C"
-
-namespace {
-// stats[0..2] = sum, bChange, totNum of this round (written by block 0 after a grid-wide ticket)
-__global__ __launch_bounds__(kBlock) void k_mstep_device(int32_t M, double N0, double* counts,
-                                                          const double* __restrict__ theta_old, double* theta_new,
-                                                          double* stats, Ctrl* ctrl) {
-    // single workgroup: M+1 <= a few 1e5 doubles, once per round after the all-reduce
-    double v = 0.0;
-    if (threadIdx.x == 0) counts[0] += N0;
-    __syncthreads();
-    for (int i = threadIdx.x; i <= M; i += blockDim.x) v += counts[i];
-    double sum = block_sum_det(v);
-    int tot = 0;
-    double bmax = 0.0;
-    for (int i = threadIdx.x; i <= M; i += blockDim.x) {
-        double th = counts[i] / sum;
-        theta_new[i] = th;
-        counts[i] = 0.0;
-        double old = theta_old[i];
-        if (old >= 1e-7) {
-            double change = fabs(th - old) / old;
-            if (change >= 0.001) ++tot;
-            bmax = fmax(bmax, change);
-        }
-    }
-    double t = block_sum_det((double)tot);
-    __shared__ double s_b[kBlock / 64];
-    for (int d = 32; d >= 1; d >>= 1) bmax = fmax(bmax, __shfl_xor(bmax, d));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6] = bmax;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < kBlock / 64; i++) bmax = fmax(bmax, s_b[i]);
-        stats[0] = sum;
-        stats[1] = bmax;
-        stats[2] = t;
-    }
-    (void)ctrl;
-}
-}  // namespace
-
-extern "C" int rsem_em_mstep_device(rsem_em_ctx* c, void* d_counts, double N0_global, const void* d_theta_old,
-                                    void* d_theta_new, void* d_stats, void* stream) {
-    RSEM_REQUIRE(c && d_counts && d_theta_old && d_theta_new && d_stats, "NULL argument");
-    RSEM_HIP_TRY(hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_mstep_device, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, c->M, N0_global, (double*)d_counts,
-                       (const double*)d_theta_old, (double*)d_theta_new, (double*)d_stats, c->d_ctrl);
-    RSEM_HIP_TRY(hipGetLastError());
-    return RSEM_OK;
-}
 
 
 // ---- internal hooks for model.hip (em_internal.hpp) ------------------------------------------------
@@ -1234,16 +1322,13 @@ int em_step_with_weights(rsem_em_ctx* c, const double* theta, double N0, double*
     RSEM_HIP_TRY(hipMemcpyAsync(c->d_theta[0], theta, nb, hipMemcpyHostToDevice, st));
     RSEM_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), st));
     RSEM_HIP_TRY(hipMemsetAsync(c->d_counts, 0, nb, st));
-    const int grid = std::max(1, std::min<int>(c->n_cus * 8, ceil_div(c->N1, kBlock)));
-    hipLaunchKernelGGL(k_estep_csr<true>, dim3(grid), dim3(kBlock), 0, st, c->N1, (const uint32_t*)nullptr, c->d_row_ptr,
-                       c->d_sid, c->d_cp, c->d_ncp, c->d_theta[0], c->d_counts, c->d_noise_a, c->d_w, c->d_wn,
-                       (const Ctrl*)c->d_ctrl);
-    RSEM_HIP_TRY(hipGetLastError());
-    c->noise_n = grid;
-    const int save_kernel = c->kernel;
-    c->kernel = RSEM_EM_KERNEL_CSR;  // n_noise_b(): the CSR launch covered the long rows too
-    int rc = launch_mstep(c, N0, c->d_counts, c->d_theta[0], c->d_theta[1], 1, 1, 1, st);
-    c->kernel = save_kernel;
+    // the round's counts / theta come from the main E-step kernel, exactly as in a theta-only round; the weights the
+    // model statistics need (d_w, d_wn: EM.cpp:227,234) from their own file-order pass with the same theta
+    int rc = launch_estep(c, c->d_theta[0], c->d_counts, st, true);
+    if (rc != RSEM_OK) return rc;
+    rc = launch_mstep(c, N0, c->d_counts, c->d_theta[0], c->d_theta[1], 1, 1, 1, st);
+    if (rc != RSEM_OK) return rc;
+    if (c->N1) rc = launch_weights(c, c->d_theta[0], st);
     if (rc != RSEM_OK) return rc;
     Ctrl h;
     RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));

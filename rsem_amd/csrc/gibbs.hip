@@ -357,31 +357,47 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
         return ((double)t_c[j] + (alpha ? t_al[j] : pseudoC)) * t_p[j];
     };
     // sample() of sampling.h:50-65 on arr[k] = arr[k-1] + weight_k: the index of the first partial sum > prb, which for
-    // a non-decreasing array is the number of partial sums <= prb (what the binary search there finds), capped at len-1
+    // a non-decreasing array is the number of partial sums <= prb (what the binary search there finds), capped at len-1.
+    // The first kChunk partial sums stay in registers (their LDS reads are independent and overlap); 0.0 + a == a and
+    // x + 0.0 == x exactly, so the padded positions leave the left-to-right sums bit-identical.
+    constexpr int kChunk = 16;
     auto draw = [&](uint32_t fr, int len, uint32_t rnd) -> int {
-        double cum = 0.0;
-        for (int k = 0; k < len; k++) {
-            const double a = weight(fr + k);
-            cum = (k == 0) ? a : cum + a;
-        }
-        const double prb = ((double)rnd * (1.0 / 4294967296.0)) * cum;
-        int cnt = 0;
+        double part[kChunk];
         double run = 0.0;
-        for (int k = 0; k < len; k++) {
-            const double a = weight(fr + k);
-            run = (k == 0) ? a : run + a;
-            cnt += (run <= prb) ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) {
+            const double a = (j < len) ? weight(fr + j) : 0.0;
+            run += a;
+            part[j] = run;
+        }
+        for (int k = kChunk; k < len; k++) run += weight(fr + k);
+        const double prb = ((double)rnd * (1.0 / 4294967296.0)) * run;
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) cnt += (j < len && part[j] <= prb) ? 1 : 0;
+        if (len > kChunk) {
+            double r2 = part[kChunk - 1];
+            for (int k = kChunk; k < len; k++) {
+                r2 += weight(fr + k);
+                cnt += (r2 <= prb) ? 1 : 0;
+            }
         }
         const int l = cnt < len ? cnt : len - 1;
         return t_sid[fr + l];
     };
 
     uint64_t i0 = 0;
+    // row pointers and current assignments of the NEXT tile are requested while this one is worked on
+    uint64_t pf_i0 = ~0ull, pf_rp = 0, pf_rp_last = 0;
+    int pf_z = 0;
     while (i0 < N1) {
         const int nrt = (int)min((uint64_t)kTileRows, N1 - i0);
         __syncthreads();  // the previous tile's LDS reads are done
-        t_rp[lane] = row_ptr[i0 + min(lane, nrt)];  // entries past nrt repeat the tile's end
-        if (lane == 0) t_rp[kTileRows] = row_ptr[i0 + nrt];
+        const bool have_pf = (pf_i0 == i0);
+        t_rp[lane] = have_pf ? pf_rp : row_ptr[i0 + min(lane, nrt)];  // entries past nrt repeat the tile's end
+        if (lane == 0) t_rp[kTileRows] = have_pf ? pf_rp_last : row_ptr[i0 + nrt];
+        int z_old = 0;
+        if (!kInit) z_old = have_pf ? pf_z : ((lane < nrt) ? z[i0 + lane] : 0);
         __syncthreads();
         const uint64_t base = t_rp[0];
         // reads of this tile = the longest prefix whose items fit the LDS tile
@@ -392,10 +408,8 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
             if (lane == 0) {
                 const uint64_t fr = base, to = t_rp[1];
                 const uint64_t len = to - fr;
-                int zo = 0;
                 if (!kInit) {
-                    zo = z[i0];
-                    __hip_atomic_fetch_add(&counts[zo], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&counts[z_old], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 auto wt = [&](uint64_t j) -> double {
@@ -420,23 +434,54 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
                 z[i0] = zn;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            idx = __shfl(idx, 0);
+            idx = __builtin_amdgcn_readfirstlane(idx);
             i0 += 1;
             continue;
         }
+        {   // prefetch for the tile that starts at i0 + nr
+            const uint64_t nxt = i0 + (uint64_t)nr;
+            pf_i0 = nxt;
+            if (nxt < N1) {
+                const int nrn = (int)min((uint64_t)kTileRows, N1 - nxt);
+                pf_rp = row_ptr[nxt + min(lane, nrn)];
+                pf_rp_last = row_ptr[nxt + nrn];
+                if (!kInit) pf_z = (lane < nrn) ? z[nxt + lane] : 0;
+            }
+        }
         const uint32_t T = (uint32_t)(t_rp[nr] - base);
-        // items of the tile: coalesced loads; the counts as they are now (L2 copy: the updates below are device atomics)
-        for (uint32_t j = lane; j < T; j += 64) {
-            const int s = sid[base + j];
-            t_sid[j] = s;
-            t_p[j] = cp[base + j];
+        // items of the tile: coalesced loads, eight in flight per lane; the counts as they are now (L2 copy: the
+        // updates below are device atomics)
+        for (uint32_t j0 = 0; j0 < T; j0 += 64 * 8) {
+            int s8[8], c8[8];
+            double p8[8], a8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t j = j0 + u * 64 + lane;
+                s8[u] = j < T ? sid[base + j] : 0;
+                p8[u] = j < T ? cp[base + j] : 0.0;
+            }
             if (!kInit) {
-                t_c[j] = __hip_atomic_load(&counts[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (alpha) t_al[j] = alpha[s];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t j = j0 + u * 64 + lane;
+                    c8[u] = j < T ? __hip_atomic_load(&counts[s8[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    a8[u] = (alpha && j < T) ? alpha[s8[u]] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t j = j0 + u * 64 + lane;
+                if (j < T) {
+                    t_sid[j] = s8[u];
+                    t_p[j] = p8[u];
+                    if (!kInit) {
+                        t_c[j] = c8[u];
+                        if (alpha) t_al[j] = a8[u];
+                    }
+                }
             }
         }
         const bool mine = lane < nr;
-        int z_old = (!kInit && mine) ? z[i0 + lane] : 0;
         // the next nr MT19937 outputs, read r of the tile takes the r-th (= the order the sequential chain draws them)
         uint32_t rnd = 0;
         {
@@ -469,7 +514,7 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
             unsigned long long changed = __ballot(mine && z_new != z_old);
             while (changed) {
                 const int r1 = __ffsll((long long)changed) - 1;
-                const int zo = __shfl(z_old, r1), zn = __shfl(z_new, r1);
+                const int zo = __builtin_amdgcn_readlane(z_old, r1), zn = __builtin_amdgcn_readlane(z_new, r1);
                 changed &= ~(1ull << r1);
                 // later reads see counts[zo] - 1 and counts[zn] + 1
                 bool hit = false;
@@ -1195,7 +1240,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         hipLaunchKernelGGL(k_sum_chains, dim3(rsem::ceil_div(mt, kBlock)), dim3(kBlock), 0, st, (uint64_t)mt, nchains, (uint64_t)mt,
                            acc_t.as<double>(), o + 4 * nM + m);
     RSEM_HIP_TRY(hipGetLastError());
-    if (c->comm) {
+    if (rsem::comm_active(c->comm)) {
         int rc = rsem::comm_reduce_sum_f64(c->comm, o, n_out, 0, st);
         if (rc != RSEM_OK) return rc;
     }

@@ -1,19 +1,24 @@
 // rsem-run-em on MI355X: same argv, same files as the reference program (EM.cpp:541-675).
 //
 //   rsem-run-em refName read_type sampleName imdName statName [-p N] [-b samInpF has_fai [fai]] [-q]
-//               [--gibbs-out] [--sampling] [--seed u32] [--append-names]     + ignored-by-the-reference: [--device d]
+//               [--gibbs-out] [--sampling] [--seed u32] [--append-names]
+//               + ignored-by-the-reference: [--device d] [--ngpus N] [--devices d0,d1,..]
 //
 // Structure (EM<>() of EM.cpp:313-539): text inputs are parsed ONCE into packed arrays and uploaded;
 // rounds 1-11 recompute the alignment probabilities with the current read model on the GPU
 // (rsem_model_calc_conprb) and, in rounds 1-10, accumulate the model's sufficient statistics
 // (rsem_model_estep_update); the O(table) renormalisation between rounds runs here on the host
 // (model_host.hpp); from round 12 the device-resident loop rsem_em_run takes over.
+// With --ngpus N the reads are split over N GPUs by the reference's own rule for its threads (EM.cpp:135-157,
+// rsem_em_shard_rows): rounds 1-11 sum the shards' counts and model statistics on the host in shard order
+// (EM.cpp:385-389,400-404), the device loop sums the counts of every round with one RCCL all-reduce.
 #include <charconv>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <functional>
 #include <string>
 #include <unistd.h>
 #include <thread>
@@ -169,6 +174,81 @@ static void estimate_from_reads(Model& model, const ReadSetFiles& rs, const RefI
     model.calc_mw(refs);
 }
 
+// name of the i-th record of a read file (only used on an error path)
+static std::string read_name_at(const std::string& path, bool fastq, uint64_t i) {
+    MappedFile f;
+    if (!f.open(path)) return "#" + std::to_string(i);
+    const uint64_t want = i * (fastq ? 4 : 2);
+    const char* p = f.data;
+    const char* e = f.data + f.size;
+    for (uint64_t line = 0; p < e; line++) {
+        const char* q = (const char*)memchr(p, '\n', e - p);
+        if (!q) q = e;
+        if (line == want) {
+            std::string n(p + 1, q);
+            while (!n.empty() && (n.back() == '\r' || n.back() == ' ')) n.pop_back();
+            return n;
+        }
+        p = q + 1;
+    }
+    return "#" + std::to_string(i);
+}
+
+// The coordinate checks of getConPrb (SingleModel.h:108-114, SingleQModel.h:114-120, PairedEndModel.h:105-111,
+// PairedEndQModel.h:109-115): the reference exits with these messages when an aligner reported inconsistent read
+// lengths; the device kernels index reference sequences and masks with these coordinates, so they are checked here,
+// once, before anything is uploaded.  Low-quality reads are skipped exactly as there (getConPrb returns before the
+// assertions).
+static void validate_alignments(const DatData& dat, const ReadFile* mates, const std::vector<uint8_t>& lq, const RefInfo& refs, int seedLen,
+                                bool pe, const std::string& imdName, int read_type) {
+    (void)seedLen;
+    const uint64_t N1 = dat.N1;
+    const int nt = N1 > 200000 ? hardware_threads() : 1;
+    struct Bad { uint64_t read = ~0ull, hit = 0; int kind = 0; };
+    std::vector<Bad> bad(nt);
+    parallel_for(nt, [&](int t) {
+        const uint64_t lo = N1 * t / nt, hi = N1 * (t + 1) / nt;
+        for (uint64_t i = lo; i < hi && bad[t].read == ~0ull; i++) {
+            if (lq[i]) continue;
+            const int len1 = mates[0].len(i), len2 = pe ? mates[1].len(i) : 0;
+            for (uint64_t k = dat.row_ptr[i]; k < dat.row_ptr[i + 1]; k++) {
+                const int32_t sv = dat.sid_signed[k];
+                const int sid = sv < 0 ? -sv : sv, dir = sv < 0 ? 1 : 0;
+                const long long totLen = refs.totLen[sid], pos = dat.pos[k];
+                const long long span = pe ? dat.insertL[k] : len1;
+                const long long fpos = dir == 0 ? pos : totLen - pos - span;
+                int kind = 0;
+                if (fpos < 0) kind = 1;
+                else if (fpos + span > totLen) kind = 2;
+                else if (span > totLen) kind = 3;
+                else if (pe && (span < len1 || span < len2)) kind = 4;
+                if (kind) { bad[t].read = i; bad[t].hit = k; bad[t].kind = kind; break; }
+            }
+        }
+    });
+    for (const Bad& B : bad) {
+        if (B.read == ~0ull) continue;
+        std::string name = read_name_at(read_file_names(imdName, 1, read_type)[0], read_type == 1 || read_type == 3, B.read);
+        if (pe && name.size() > 2 && name.compare(name.size() - 2, 2, "/1") == 0) name.resize(name.size() - 2);
+        const int32_t sv = dat.sid_signed[B.hit];
+        const int sid = sv < 0 ? -sv : sv;
+        const long long totLen = refs.totLen[sid], pos = dat.pos[B.hit];
+        const long long span = pe ? dat.insertL[B.hit] : mates[0].len(B.read);
+        const long long fpos = sv < 0 ? totLen - pos - span : pos;
+        const char* what = pe ? "fragment" : "read";
+        const char* What = pe ? "Fragment" : "Read";
+        static const char* hint = "It is possible that the aligner you use gave different read lengths for a same read in SAM file.";
+        switch (B.kind) {
+            case 1: die("The alignment of %s %s to transcript %d starts at %lld from the forward direction, which should be a non-negative number! %s",
+                        what, name.c_str(), sid, fpos, hint);
+            case 2: die("%s %s is hung over the end of transcript %d! %s", What, name.c_str(), sid, hint);
+            case 3: die("%s %s has length %lld, but it is aligned to transcript %d, whose length (%lld) is shorter than the %s's length!",
+                        What, name.c_str(), span, sid, totLen, what);
+            default: die("Fragment %s has length %lld, which is shorter than one of its mates! %s", name.c_str(), span, hint);
+        }
+    }
+}
+
 static rsem_model_tables tables_of(const Model& m) {
     rsem_model_tables t;
     memset(&t, 0, sizeof(t));
@@ -206,8 +286,8 @@ int main(int argc, char* argv[]) {
     const std::string outName = argv[3], imdName = argv[4], statName = argv[5];
     bool verbose = true, genBamF = false, genGibbsOut = false, appendNames = false, bamSampling = false, hasSeed = false;
     uint32_t seed = 0;
-    std::string inpSamF;
-    int device = 0;
+    std::string inpSamF, devices_s;
+    int device = 0, ngpus = 1;
     for (int i = 6; i < argc; i++) {  // EM.cpp:578-595; -p is accepted and irrelevant (the GPU is the parallelism)
         if (!strcmp(argv[i], "-b") && i + 1 < argc) { genBamF = true; inpSamF = argv[i + 1]; }
         if (!strcmp(argv[i], "--sampling")) bamSampling = true;
@@ -220,7 +300,21 @@ int main(int argc, char* argv[]) {
         if (!strcmp(argv[i], "--gibbs-out")) genGibbsOut = true;
         if (!strcmp(argv[i], "--append-names")) appendNames = true;
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--ngpus") && i + 1 < argc) ngpus = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices_s = argv[i + 1];
     }
+    std::vector<int> devs;  // one entry per shard; a device named twice shares it between two shards (single-GPU testing)
+    if (!devices_s.empty()) {
+        for (size_t p = 0; p < devices_s.size();) {
+            size_t q = devices_s.find(',', p);
+            if (q == std::string::npos) q = devices_s.size();
+            devs.push_back(atoi(devices_s.substr(p, q - p).c_str()));
+            p = q + 1;
+        }
+    } else {
+        for (int d = 0; d < std::max(1, ngpus); d++) devs.push_back(ngpus > 1 ? d : device);
+    }
+    device = devs[0];
     if (read_type < 0 || read_type > 3) die("Unknown Read Type!");
     // HIP runtime + device context come up (0.5 s) while the text inputs are parsed
     std::thread warm([device]() { rsem_hip_warmup(device); });
@@ -262,20 +356,67 @@ int main(int argc, char* argv[]) {
     int ndev = 0;
     const uint64_t nnz = dat.sid_signed.size();
     std::vector<int32_t> sid_abs(nnz);
-    rsem_em_ctx* em = nullptr;
-    int em_rc = RSEM_OK;
-    std::string em_err;
+    // shards: contiguous read ranges by the reference's thread rule (EM.cpp:135-157); never an empty one
+    int S = (int)std::min<uint64_t>(devs.size(), N1);
+    std::vector<uint64_t> bounds;
+    for (;; --S) {
+        bounds.assign(S + 1, 0);
+        rsem_em_shard_rows(N1, dat.row_ptr.data(), S, bounds.data());
+        bool empty = false;
+        for (int k = 0; k < S; k++) empty = empty || bounds[k + 1] == bounds[k];
+        if (!empty || S == 1) break;
+    }
+    devs.resize(S);
+    struct Shard {
+        int device = 0;
+        uint64_t lo = 0, hi = 0, a = 0, b = 0;  // reads [lo, hi), alignments [a, b)
+        std::vector<uint64_t> row_ptr;          // rebased copy (only when there is more than one shard)
+        const uint64_t* rp = nullptr;
+        rsem_em_ctx* em = nullptr;
+        rsem_model_ctx* mc = nullptr;
+        rsem_comm* comm = nullptr;
+        int rc = RSEM_OK;
+        std::string err;
+    };
+    std::vector<Shard> sh(S);
+    for (int k = 0; k < S; k++) {
+        Shard& X = sh[k];
+        X.device = devs[k];
+        X.lo = bounds[k]; X.hi = bounds[k + 1];
+        X.a = dat.row_ptr[X.lo]; X.b = dat.row_ptr[X.hi];
+        if (S == 1) X.rp = dat.row_ptr.data();
+        else {
+            X.row_ptr.resize(X.hi - X.lo + 1);
+            for (uint64_t i = X.lo; i <= X.hi; i++) X.row_ptr[i - X.lo] = dat.row_ptr[i] - X.a;
+            X.rp = X.row_ptr.data();
+        }
+    }
+    auto each_shard = [&](const std::function<void(Shard&, int)>& fn) {  // one host thread per shard (= per GPU)
+        if (S == 1) { fn(sh[0], 0); return; }
+        std::vector<std::thread> th;
+        for (int k = 0; k < S; k++) th.emplace_back([&, k]() { fn(sh[k], k); });
+        for (auto& t : th) t.join();
+    };
+    auto check_shards = [&](const char* what) {
+        for (int k = 0; k < S; k++)
+            if (sh[k].rc != RSEM_OK)
+                die("rsem-run-em: %s failed on shard %d (GPU %d): %s (%s)", what, k, sh[k].device, rsem_hip_strerror(sh[k].rc), sh[k].err.c_str());
+    };
     std::thread em_builder([&]() {
         if (warm.joinable()) warm.join();
         rsem_hip_device_count(&ndev);
         if (ndev < 1) return;
         for (uint64_t j = 0; j < nnz; j++) {
-            int32_t s = dat.sid_signed[j];
-            sid_abs[j] = s < 0 ? -s : s;
-            if (sid_abs[j] < 1 || sid_abs[j] > M) { em_rc = RSEM_ERR_INVALID; em_err = "transcript id " + std::to_string(s) + " out of range"; return; }
+            int32_t v = dat.sid_signed[j];
+            sid_abs[j] = v < 0 ? -v : v;
+            if (sid_abs[j] < 1 || sid_abs[j] > M) { sh[0].rc = RSEM_ERR_INVALID; sh[0].err = "transcript id " + std::to_string(v) + " out of range"; return; }
         }
-        em_rc = rsem_em_create(&em, device, M, N1, nnz, dat.row_ptr.data(), sid_abs.data(), nullptr, nullptr);
-        if (em_rc != RSEM_OK) em_err = rsem_hip_last_error();
+        for (int k = 0; k < S; k++)
+            if (sh[k].device < 0 || sh[k].device >= ndev) { sh[k].rc = RSEM_ERR_NODEVICE; sh[k].err = "no such GPU"; return; }
+        each_shard([&](Shard& X, int) {
+            X.rc = rsem_em_create(&X.em, X.device, M, X.hi - X.lo, X.b - X.a, X.rp, sid_abs.data() + X.a, nullptr, nullptr);
+            if (X.rc != RSEM_OK) X.err = rsem_hip_last_error();
+        });
     });
     Joiner em_joiner{em_builder};
     ReadSetFiles rs;
@@ -298,9 +439,10 @@ int main(int argc, char* argv[]) {
     rs.mate[0][0] = ReadFile(); rs.mate[0][1] = ReadFile(); rs.mate[2][0] = ReadFile(); rs.mate[2][1] = ReadFile();
 
     // ---- device contexts -----------------------------------------------------------------------------
+    validate_alignments(dat, rs.mate[1], lq, refs, model.P.seedLen, pe, imdName, read_type);
     em_builder.join();
     if (ndev < 1) die("rsem-run-em: no usable GPU (this program has no CPU path)");
-    if (em_rc != RSEM_OK) die("rsem-run-em: rsem_em_create: %s: %s (%s.dat)", rsem_hip_strerror(em_rc), em_err.c_str(), imdName.c_str());
+    check_shards("rsem_em_create");
     // packed references
     std::vector<uint64_t> ref_off(M + 2, 0), mask_off(M + 2, 0);
     for (int i = 1; i <= M; i++) {
@@ -319,21 +461,47 @@ int main(int argc, char* argv[]) {
         }
         std::copy(refs.masks[i].begin(), refs.masks[i].end(), mask_words.begin() + mask_off[i]);
     }
-    rsem_model_data md;
-    memset(&md, 0, sizeof(md));
-    md.model_type = read_type; md.M = M; md.N1 = N1; md.nnz = nnz;
-    md.row_ptr = dat.row_ptr.data(); md.sid_signed = dat.sid_signed.data(); md.pos = dat.pos.data();
-    md.insertL = pe ? dat.insertL.data() : nullptr;
-    for (int m = 0; m < (pe ? 2 : 1); m++) {
-        md.read_off[m] = rs.mate[1][m].off.data();
-        md.read_seq[m] = rs.mate[1][m].seq.data();
-        md.read_qual[m] = hasQ ? rs.mate[1][m].qual.data() : nullptr;
+    each_shard([&](Shard& X, int) {
+        rsem_model_data md;
+        memset(&md, 0, sizeof(md));
+        md.model_type = read_type; md.M = M; md.N1 = X.hi - X.lo; md.nnz = X.b - X.a;
+        md.row_ptr = X.rp; md.sid_signed = dat.sid_signed.data() + X.a; md.pos = dat.pos.data() + X.a;
+        md.insertL = pe ? dat.insertL.data() + X.a : nullptr;
+        for (int m = 0; m < (pe ? 2 : 1); m++) {  // offsets stay absolute: only differences and base + offset are used
+            md.read_off[m] = rs.mate[1][m].off.data() + X.lo;
+            md.read_seq[m] = rs.mate[1][m].seq.data();
+            md.read_qual[m] = hasQ ? rs.mate[1][m].qual.data() : nullptr;
+        }
+        md.low_quality = lq.data() + X.lo;
+        md.ref_off = ref_off.data(); md.ref_seq = ref_seq.data(); md.fullLen = refs.fullLen.data(); md.totLen = refs.totLen.data();
+        md.mask_off = mask_off.data(); md.mask_words = mask_words.data();
+        X.rc = rsem_model_create(&X.mc, X.em, &md);
+        if (X.rc != RSEM_OK) X.err = rsem_hip_last_error();
+    });
+    check_shards("rsem_model_create");
+    // the communicator of the device loop: RCCL, one rank per GPU; shards that share a GPU exchange inside the process
+    if (S > 1) {
+        bool shared_device = false;
+        for (int x = 0; x < S; x++)
+            for (int y = x + 1; y < S; y++) shared_device = shared_device || devs[x] == devs[y];
+        if (shared_device) {
+            std::vector<rsem_comm*> cs(S, nullptr);
+            hip_check(rsem_comm_create_local(cs.data(), S, devs.data()), "rsem_comm_create_local");
+            for (int k = 0; k < S; k++) sh[k].comm = cs[k];
+        } else {
+            char id[RSEM_COMM_ID_BYTES];
+            hip_check(rsem_comm_unique_id(id), "rsem_comm_unique_id");
+            each_shard([&](Shard& X, int k) {
+                X.rc = rsem_comm_create(&X.comm, X.device, k, S, id);
+                if (X.rc != RSEM_OK) X.err = rsem_hip_last_error();
+            });
+            check_shards("rsem_comm_create");
+        }
+        for (int k = 0; k < S; k++) hip_check(rsem_em_set_comm(sh[k].em, sh[k].comm), "rsem_em_set_comm");
+        if (verbose)
+            for (int k = 0; k < S; k++)  // the reference's "Thread i : N = .., NHit = .." (EM.cpp:155)
+                printf("GPU %d : N = %llu, NHit = %llu\n", sh[k].device, (unsigned long long)(sh[k].hi - sh[k].lo), (unsigned long long)(sh[k].b - sh[k].a));
     }
-    md.low_quality = lq.data();
-    md.ref_off = ref_off.data(); md.ref_seq = ref_seq.data(); md.fullLen = refs.fullLen.data(); md.totLen = refs.totLen.data();
-    md.mask_off = mask_off.data(); md.mask_words = mask_words.data();
-    rsem_model_ctx* mc = nullptr;
-    hip_check(rsem_model_create(&mc, em, &md), "rsem_model_create");
     lap("device contexts + upload");
     if (verbose) printf("EM_init finished!\n");
 
@@ -348,38 +516,93 @@ int main(int argc, char* argv[]) {
     acc.gld.assign((size_t)(P.maxL - (P.minL - 1)) + 1, 0.0);
     int ROUND = 0, totNum = 0;
     double sum = 0.0, bChange = 0.0;
+    // per-shard outputs of a round (more than one shard: summed on the host in shard order, EM.cpp:385-389,400-404)
+    std::vector<std::vector<double>> s_counts(S > 1 ? S : 0, std::vector<double>(M + 1, 0.0));
+    std::vector<Model::Accum> s_acc(S > 1 ? S : 0, acc);
     do {
         ++ROUND;
         const bool updateModel = ROUND <= 10;  // doesUpdateModel (EM.cpp:307-310)
-        if (model.needCalcConPrb) {
-            rsem_model_tables t = tables_of(model);
-            hip_check(rsem_model_set_tables(mc, &t), "rsem_model_set_tables");
-            hip_check(rsem_model_calc_conprb(mc), "rsem_model_calc_conprb");
-            model.needCalcConPrb = false;  // EM.cpp:383
+        const bool calc = model.needCalcConPrb;
+        rsem_model_tables t = tables_of(model);
+        each_shard([&](Shard& X, int k) {
+            X.rc = RSEM_OK;
+            if (calc) {
+                X.rc = rsem_model_set_tables(X.mc, &t);
+                if (X.rc == RSEM_OK) X.rc = rsem_model_calc_conprb(X.mc);
+            }
+            if (X.rc != RSEM_OK) { X.err = rsem_hip_last_error(); return; }
+            // one shard: the device M step is the round's M step; several: raw counts (N0 = 0), reduced below
+            double* cts = S == 1 ? counts.data() : s_counts[k].data();
+            double s1 = 0.0, b1 = 0.0;
+            int32_t t1 = 0;
+            if (updateModel) {
+                Model::Accum& A = S == 1 ? acc : s_acc[k];
+                rsem_model_accum a;
+                a.prof = A.prof.data(); a.noise = A.noise.data(); a.rspd = A.rspd.data(); a.gld = A.gld.data();
+                a.gld0_lb = P.minL - 1; a.gld0_ub = P.maxL;
+                X.rc = rsem_model_estep_update(X.mc, theta.data(), S == 1 ? (double)N0 : 0.0, cts, S == 1 ? theta_new.data() : nullptr, &s1, &b1, &t1, &a);
+            } else {
+                X.rc = rsem_em_step(X.em, theta.data(), S == 1 ? (double)N0 : 0.0, cts, S == 1 ? theta_new.data() : nullptr, &s1, &b1, &t1);
+            }
+            if (X.rc != RSEM_OK) { X.err = rsem_hip_last_error(); return; }
+            if (S == 1) { sum = s1; bChange = b1; totNum = t1; }
+        });
+        check_shards(updateModel ? "rsem_model_estep_update" : "rsem_em_step");
+        model.needCalcConPrb = false;  // EM.cpp:383
+        if (S > 1) {
+            for (int j = 0; j <= M; j++) {
+                double c = s_counts[0][j];
+                for (int k = 1; k < S; k++) c += s_counts[k][j];
+                counts[j] = c;
+            }
+            counts[0] += N0;  // EM.cpp:392
+            sum = 0.0;
+            for (int j = 0; j <= M; j++) sum += counts[j];
+            if (!(sum >= kEpsilon)) die("rsem-run-em: the fractional counts sum to %g", sum);
+            bChange = 0.0; totNum = 0;
+            for (int j = 0; j <= M; j++) {
+                theta_new[j] = counts[j] / sum;
+                if (theta[j] >= 1e-7) {  // EM.cpp:406-413
+                    const double change = fabs(theta_new[j] - theta[j]) / theta[j];
+                    if (change >= 0.001) ++totNum;
+                    if (bChange < change) bChange = change;
+                }
+            }
+            if (updateModel) {
+                for (size_t i = 0; i < acc.prof.size(); i++) { double v = s_acc[0].prof[i]; for (int k = 1; k < S; k++) v += s_acc[k].prof[i]; acc.prof[i] = v; }
+                for (size_t i = 0; i < acc.noise.size(); i++) { double v = s_acc[0].noise[i]; for (int k = 1; k < S; k++) v += s_acc[k].noise[i]; acc.noise[i] = v; }
+                for (size_t i = 0; i < acc.rspd.size(); i++) { double v = s_acc[0].rspd[i]; for (int k = 1; k < S; k++) v += s_acc[k].rspd[i]; acc.rspd[i] = v; }
+                for (size_t i = 0; i < acc.gld.size(); i++) { double v = s_acc[0].gld[i]; for (int k = 1; k < S; k++) v += s_acc[k].gld[i]; acc.gld[i] = v; }
+            }
         }
-        if (updateModel) {
-            rsem_model_accum a;
-            a.prof = acc.prof.data(); a.noise = acc.noise.data(); a.rspd = acc.rspd.data(); a.gld = acc.gld.data();
-            a.gld0_lb = P.minL - 1; a.gld0_ub = P.maxL;
-            hip_check(rsem_model_estep_update(mc, theta.data(), (double)N0, counts.data(), theta_new.data(), &sum, &bChange, &totNum, &a),
-                      "rsem_model_estep_update");
-            model.finish_round(acc, refs);  // model.init(); collect; finish  (EM.cpp:400-404)
-        } else {
-            hip_check(rsem_em_step(em, theta.data(), (double)N0, counts.data(), theta_new.data(), &sum, &bChange, &totNum), "rsem_em_step");
-        }
+        if (updateModel) model.finish_round(acc, refs);  // model.init(); collect; finish  (EM.cpp:400-404)
         theta.swap(theta_new);
         if (verbose) printf("ROUND = %d, SUM = %.15g, bChange = %g, totNum = %d\n", ROUND, sum, bChange, totNum);
         if (ROUND >= 11 && !model.needCalcConPrb) break;  // the CSR values are frozen from here on
     } while (ROUND < MIN_ROUND || (totNum > 0 && ROUND < MAX_ROUND));
     lap("rounds 1-11 (model rounds)");
     if (ROUND < MIN_ROUND || (totNum > 0 && ROUND < MAX_ROUND)) {
-        int rounds = ROUND;
-        int32_t tn = 0;
-        hip_check(rsem_em_run(em, theta.data(), (double)N0, ROUND, MIN_ROUND, MAX_ROUND, &rounds, counts.data(), &bChange, &tn, nullptr),
-                  "rsem_em_run");
-        ROUND = rounds;
-        totNum = tn;
-        if (verbose) printf("ROUND = %d, bChange = %g, totNum = %d\n", ROUND, bChange, totNum);
+        const int round0 = ROUND;
+        std::vector<std::vector<double>> s_theta(S, theta);
+        std::vector<int> s_rounds(S, ROUND);
+        std::vector<int32_t> s_tn(S, 0);
+        std::vector<double> s_bc(S, 0.0);
+        if (verbose)  // the reference's line after every round (EM.cpp:415), from the device's own record of the round
+            hip_check(rsem_em_set_progress(sh[0].em, [](int r, double sm, double bc, int tn, void*) {
+                printf("ROUND = %d, SUM = %.15g, bChange = %g, totNum = %d\n", r, sm, bc, tn);
+            }, nullptr), "rsem_em_set_progress");
+        each_shard([&](Shard& X, int k) {
+            X.rc = rsem_em_run(X.em, s_theta[k].data(), (double)N0, round0, MIN_ROUND, MAX_ROUND, &s_rounds[k], k == 0 ? counts.data() : nullptr,
+                               &s_bc[k], &s_tn[k], nullptr);
+            if (X.rc != RSEM_OK) X.err = rsem_hip_last_error();
+        });
+        check_shards("rsem_em_run");
+        for (int k = 1; k < S; k++)
+            if (s_rounds[k] != s_rounds[0]) die("rsem-run-em: shard %d stopped at round %d, shard 0 at round %d", k, s_rounds[k], s_rounds[0]);
+        theta = s_theta[0];
+        ROUND = s_rounds[0];
+        totNum = s_tn[0];
+        bChange = s_bc[0];
     }
     lap("rounds >= 12 (device loop)");
     if (totNum > 0) fprintf(stderr, "Warning: RSEM reaches %d iterations before meeting the convergence criteria.\n", MAX_ROUND);
@@ -387,7 +610,11 @@ int main(int argc, char* argv[]) {
     // ---- imd.ofg for the Gibbs sampler (EM.cpp:421-458) ---------------------------------------------------
     if (genGibbsOut) {
         std::vector<double> cp(nnz), ncp(N1);
-        hip_check(rsem_model_get_values(mc, cp.data(), ncp.data()), "rsem_model_get_values");
+        each_shard([&](Shard& X, int) {
+            X.rc = rsem_model_get_values(X.mc, cp.data() + X.a, ncp.data() + X.lo);
+            if (X.rc != RSEM_OK) X.err = rsem_hip_last_error();
+        });
+        check_shards("rsem_model_get_values");
         FILE* fo = fopen((imdName + ".ofg").c_str(), "w");
         if (!fo) die("Cannot open %s.ofg for writing!", imdName.c_str());
         fprintf(fo, "%d %llu\n", M, (unsigned long long)N0);
@@ -421,8 +648,23 @@ int main(int argc, char* argv[]) {
     // ---- expected counts with the learned theta (EM.cpp:460-478) -------------------------------------------
     std::vector<double> w, w_noise;
     if (genBamF) { w.resize(nnz); w_noise.resize(N1); }
-    hip_check(rsem_em_expected_weights(em, theta.data(), (double)N0, counts.data(), genBamF ? w.data() : nullptr,
-                                       genBamF ? w_noise.data() : nullptr), "rsem_em_expected_weights");
+    if (S == 1) {
+        hip_check(rsem_em_expected_weights(sh[0].em, theta.data(), (double)N0, counts.data(), genBamF ? w.data() : nullptr,
+                                           genBamF ? w_noise.data() : nullptr), "rsem_em_expected_weights");
+    } else {
+        each_shard([&](Shard& X, int k) {
+            X.rc = rsem_em_expected_weights(X.em, theta.data(), 0.0, s_counts[k].data(), genBamF ? w.data() + X.a : nullptr,
+                                            genBamF ? w_noise.data() + X.lo : nullptr);
+            if (X.rc != RSEM_OK) X.err = rsem_hip_last_error();
+        });
+        check_shards("rsem_em_expected_weights");
+        for (int j = 0; j <= M; j++) {
+            double c = s_counts[0][j];
+            for (int k = 1; k < S; k++) c += s_counts[k][j];
+            counts[j] = c;
+        }
+        counts[0] += N0;
+    }
 
     // ---- stat.theta (EM.cpp:484-500) ------------------------------------------------------------------------
     FILE* fo = fopen((statName + ".theta").c_str(), "w");
@@ -482,8 +724,11 @@ int main(int argc, char* argv[]) {
         if (verbose) printf("Bam output file is generated!\n");
         lap("transcript.bam");
     }
-    rsem_model_destroy(mc);
-    rsem_em_destroy(em);
+    for (Shard& X : sh) {
+        rsem_model_destroy(X.mc);
+        rsem_em_destroy(X.em);
+        rsem_comm_destroy(X.comm);
+    }
     lap("device teardown");
     const auto secs = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t_start).count();
     printf("Time Used for EM.cpp : %d h %02d m %02d s\n", (int)(secs / 3600), (int)(secs % 3600 / 60), (int)(secs % 60));

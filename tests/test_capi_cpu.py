@@ -117,3 +117,45 @@ def test_gibbs_sampler_choice(tmp_path):
     assert "data-augmentation" not in r.stderr
     r = run("200", "1000", "1", "-p", "8", "--gibbs-mode", "Exact")
     assert r.returncode != 0 and "unknown --gibbs-mode" in r.stderr
+
+
+def test_run_em_rejects_inconsistent_alignment_coordinates(tmp_path):
+    """getConPrb's coordinate assertions (SingleQModel.h:114-120, PairedEndQModel.h:109-115): an alignment that hangs over
+    the end of its transcript, or starts before it, stops rsem-run-em with the reference's message -- before any device
+    work (the kernels index reference sequences with these coordinates), so the check is visible without a GPU."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "rsem_amd", "bin", "rsem-run-em")
+
+    def run(name, read_type, edit):
+        d = str(tmp_path / (name + "_" + edit.__name__))
+        shutil.copytree(os.path.join(root, "tests", "golden", name), d)
+        dat = os.path.join(d, "temp", "s.dat")
+        lines = open(dat).read().split("\n")
+        lines[1] = edit(lines[1].split())
+        open(dat, "w").write("\n".join(lines))
+        return subprocess.run([exe, d + "/ref", str(read_type), d + "/s", d + "/temp/s", d + "/stat/s", "-q"], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True)
+
+    def hang_over(f):       # first alignment of the first read: push it past the end of the transcript
+        f[2] = "1000000"
+        return " ".join(f)
+
+    def negative_start(f):  # reverse-strand coordinate that maps before position 0
+        f[1] = "-" + f[1].lstrip("-")
+        f[2] = "1000000"
+        return " ".join(f)
+
+    r = run("se_q", 1, hang_over)
+    assert r.returncode != 0 and ("is hung over the end of transcript" in r.stderr or "starts at" in r.stderr), r.stderr
+    assert "different read lengths" in r.stderr
+    r = run("se_q", 1, negative_start)
+    assert r.returncode != 0 and "starts at" in r.stderr and "non-negative" in r.stderr, r.stderr
+    r = run("pe_q", 3, hang_over)
+    assert r.returncode != 0 and "ragment" in r.stderr, r.stderr
+    # untouched input passes the check (and then stops for the missing GPU here, or runs on a GPU box)
+    d = str(tmp_path / "ok")
+    shutil.copytree(os.path.join(root, "tests", "golden", "se_q"), d)
+    r = subprocess.run([exe, d + "/ref", "1", d + "/s", d + "/temp/s", d + "/stat/s", "-q"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert "hung over" not in r.stderr and "starts at" not in r.stderr

@@ -51,19 +51,31 @@ def _res_close(path_a, path_b, atol=0.011):
         assert np.allclose(va, vb, atol=atol, rtol=1e-6), (ra[:5], rb[:5])
 
 
+SHARDED = ["--ngpus", "2", "--devices", "0,0"]  # two row shards on GPU 0 (LOCAL communicator); on a node: RCCL, one GPU each
+
+
+@pytest.mark.parametrize("extra", [[], SHARDED], ids=["1gpu", "2shards"])
 @pytest.mark.parametrize("name", rf.FIXTURES)
-def test_rsem_run_em_matches_reference(name, tmp_path):
+def test_rsem_run_em_matches_reference(name, extra, tmp_path):
     fx, dst = _stage(name, tmp_path)
     meta = rf.read_meta(fx)
     allele = os.path.exists(os.path.join(fx, "ref.ta"))
     for f in ("stat/s.theta", "stat/s.model", "temp/s.ofg", "temp/s.iso_res", "temp/s.gene_res") + (("temp/s.allele_res",) if allele else ()):
         os.remove(os.path.join(dst, f))
     out = _run([os.path.join(BIN, "rsem-run-em"), os.path.join(dst, "ref"), str(meta["model_type"]), os.path.join(dst, "s"),
-                os.path.join(dst, "temp", "s"), os.path.join(dst, "stat", "s"), "-p", "1", "--gibbs-out"])
-    # same number of rounds as the reference run
-    ref_rounds = int(open(os.path.join(fx, "em.log")).read().strip().split("\n")[-1].split(",")[0].split("=")[1])
-    my_rounds = int([l for l in out.split("\n") if l.startswith("ROUND")][-1].split(",")[0].split("=")[1])
+                os.path.join(dst, "temp", "s"), os.path.join(dst, "stat", "s"), "-p", "1", "--gibbs-out"] + extra)
+    # same number of rounds as the reference run, and one ROUND line per round like the reference (EM.cpp:415)
+    ref_log = [l for l in open(os.path.join(fx, "em.log")).read().strip().split("\n") if l.startswith("ROUND")]
+    ref_rounds = int(ref_log[-1].split(",")[0].split("=")[1])
+    my_log = [l for l in out.split("\n") if l.startswith("ROUND")]
+    my_rounds = int(my_log[-1].split(",")[0].split("=")[1])
     assert my_rounds == ref_rounds
+    assert [int(l.split(",")[0].split("=")[1]) for l in my_log] == list(range(1, ref_rounds + 1))
+    for a, b in zip(my_log[11:], ref_log[11:]):  # rounds >= 12: same totNum, bChange to the printed precision
+        fa, fb = a.replace(",", "").split(), b.replace(",", "").split()
+        assert fa[-1] == fb[-1] and abs(float(fa[8]) - float(fb[8])) <= 2e-5 * max(float(fb[8]), 1e-3), (a, b)
+    if extra:
+        assert sum(l.startswith("GPU ") for l in out.split("\n")) == 2
     # the first 11 rounds print the same SUM / totNum lines as the reference
     ref_lines = open(os.path.join(fx, "em.log")).read().strip().split("\n")[:11]
     my_lines = [l for l in out.split("\n") if l.startswith("ROUND")][:11]
@@ -94,8 +106,9 @@ def test_rsem_run_em_matches_reference(name, tmp_path):
     assert np.allclose(val, gval, rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("extra_dev", [[], ["--devices", "0,0"]], ids=["1gpu", "2groups"])
 @pytest.mark.parametrize("name", rf.FIXTURES)
-def test_rsem_run_gibbs_exact_matches_reference(name, tmp_path):
+def test_rsem_run_gibbs_exact_matches_reference(name, extra_dev, tmp_path):
     fx, dst = _stage(name, tmp_path)
     meta = rf.read_meta(fx)
     b, n, g = meta["gibbs"]
@@ -111,7 +124,7 @@ def test_rsem_run_gibbs_exact_matches_reference(name, tmp_path):
     if meta.get("pseudo_count_x1000", 1000) != 1000:
         extra = ["--pseudo-count", str(meta["pseudo_count_x1000"] / 1000.0)]
     _run([os.path.join(BIN, "rsem-run-gibbs"), os.path.join(dst, "ref"), imd, os.path.join(dst, "stat", "s"), str(b), str(n), str(g),
-          "-p", str(meta["gibbs_threads"]), "--seed", str(meta["gibbs_seed"]), "-q", "--gibbs-mode", "exact"] + extra)
+          "-p", str(meta["gibbs_threads"]), "--seed", str(meta["gibbs_seed"]), "-q", "--gibbs-mode", "exact"] + extra + extra_dev)
     for k in range(meta["gibbs_threads"]):
         with open(imd + ".countvectors%d" % k, "rb") as f1, open(os.path.join(fx, "temp", "s.countvectors%d" % k), "rb") as f2:
             assert f1.read() == f2.read()

@@ -81,6 +81,20 @@ def test_shard_rows_matches_reference_rule():
                 hits += int(lens[cur]); cur += 1; left -= 1
             exp.append(cur)
         assert b == exp
+        from rsem_amd import capi
+        assert capi.em_shard_rows(rp, T) == exp  # the C ABI's restatement (what rsem-run-em --ngpus uses)
+    # fewer alignments than workers, and fewer reads than workers
+    from rsem_amd import capi
+    for lens2, T in ((np.array([1, 1, 1]), 8), (np.array([5, 1, 1, 9, 2]), 4), (np.array([3]), 2)):
+        rp2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.uint64)
+        n = len(lens2)
+        nhT, left, cur, exp = int(rp2[-1]) // T, n, 0, [0]
+        for i in range(T):
+            ntLeft, hits = T - i - 1, 0
+            while left > ntLeft and (i == T - 1 or hits < nhT):
+                hits += int(lens2[cur]); cur += 1; left -= 1
+            exp.append(cur)
+        assert capi.em_shard_rows(rp2, T) == exp, (lens2, T)
 
 
 def test_gibbs_chain_plan():

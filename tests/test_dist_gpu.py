@@ -1,68 +1,79 @@
-"""Multi-rank EM on the device halves of the C ABI (rsem_em_estep_device / rsem_em_mstep_device): two ranks share
-GPU 0, reads sharded by the reference's rule, counts all-reduced each round (gloo here; RCCL in bench.py).
-The result must equal a single-context run on the whole matrix."""
+"""Sharded EM through the C ABI: rows split by the reference's thread rule (rsem_em_shard_rows, EM.cpp:135-157), one
+rsem_em_ctx per shard, rsem_em_run on every rank with one all-reduce of the counts per round (rsem_em_set_comm).
+
+The GPU box has ONE GPU, and RCCL refuses two ranks on one device, so the sharded path is exercised here with the LOCAL
+communicator (ranks = threads sharing GPU 0; same rsem_em_run code, same collective call sites) and the RCCL calls
+themselves with a one-rank communicator that is forced to issue its collectives.  The result must equal a
+single-context run on the whole matrix: same ROUND count, theta to 1e-9."""
 import os
-import sys
+import threading
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-
-def _worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    import torch
-    import torch.distributed as dist
+def _shards(wl, world):
     from rsem_amd import capi, dist as rd
-    from tools.synth_data import make_em_workload
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    wl = make_em_workload("small", seed=9)
-    M = wl["M"]
-    b = rd.shard_rows(wl["row_ptr"], world)
-    rp, sid, cp, ncp = rd.take_shard(wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], b[rank], b[rank + 1])
-    ctx = capi.EmContext(M, rp, np.ascontiguousarray(sid), np.ascontiguousarray(cp), np.ascontiguousarray(ncp), device=0)
-    theta = [torch.from_numpy(wl["theta0"]).to(dev), torch.zeros(M + 1, dtype=torch.float64, device=dev)]
-    counts = torch.zeros(M + 1, dtype=torch.float64, device=dev)
-    stats = torch.zeros(3, dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    for r in range(6):
-        a, bb = theta[r & 1], theta[(r + 1) & 1]
-        ctx.estep_device(a.data_ptr(), counts.data_ptr(), stream)
-        dist.all_reduce(counts)
-        ctx.mstep_device(counts.data_ptr(), float(wl["N0"]), a.data_ptr(), bb.data_ptr(), stats.data_ptr(), stream)
-    torch.cuda.synchronize()
-    if rank == 0:
-        q.put((theta[0].cpu().numpy(), stats.cpu().numpy()))
-    dist.barrier()
-    ctx.close()
-    dist.destroy_process_group()
+    b = capi.em_shard_rows(wl["row_ptr"], world)
+    assert b == rd.shard_rows(wl["row_ptr"], world)
+    return [rd.take_shard(wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], b[r], b[r + 1]) for r in range(world)]
 
 
-def test_two_rank_em_equals_single_context():
-    import torch.multiprocessing as mp
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_em_run_equals_single_context(world):
     from rsem_amd import capi
     from tools.synth_data import make_em_workload
-    ctx_mp = mp.get_context("spawn")
-    q = ctx_mp.Queue()
-    port = 29700 + os.getpid() % 1000
-    procs = [ctx_mp.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    theta_d, stats = q.get(timeout=300)
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
-    wl = make_em_workload("small", seed=9)
-    ctx = capi.EmContext(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
-    out = ctx.run(wl["theta0"], wl["N0"], min_round=6, max_round=6)
-    assert np.allclose(theta_d, out["theta"], rtol=1e-9, atol=1e-18)
-    assert abs(stats[0] - (wl["N0"] + len(wl["row_ptr"]) - 1)) < 1e-6
-    assert int(stats[2]) == out["totNum"]
+    wl = make_em_workload("small", seed=9, long_row_every=50000)
+    M = wl["M"]
+    ctx = capi.EmContext(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
+    ref = ctx.run(wl["theta0"], wl["N0"], max_round=400)
     ctx.close()
+    comms = capi.Comm.create_local([0] * world)
+    out = [None] * world
+    lines = []
+
+    def rank(r, shard):
+        rp, sid, cp, ncp = shard
+        c = capi.EmContext(M, rp, np.ascontiguousarray(sid), np.ascontiguousarray(cp), np.ascontiguousarray(ncp), device=0)
+        c.set_comm(comms[r])
+        if r == 0:
+            c.set_progress(lambda rd_, s, b, t: lines.append((rd_, s, b, t)))
+        out[r] = c.run(wl["theta0"], wl["N0"], max_round=400)  # GLOBAL N0 on every rank
+        c.close()
+
+    ts = [threading.Thread(target=rank, args=(r, s)) for r, s in enumerate(_shards(wl, world))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for c in comms:
+        c.close()
+    assert all(o is not None for o in out)
+    for o in out:
+        assert o["rounds"] == ref["rounds"]
+        assert np.allclose(o["theta"], ref["theta"], rtol=1e-9, atol=1e-18)
+        assert np.array_equal(o["theta"], out[0]["theta"])  # every rank computes the same M step from the same sums
+    assert np.allclose(out[0]["counts"], ref["counts"], rtol=1e-9, atol=1e-9)
+    # one line per round, in order, SUM = N0 + reads with a non-zero normaliser over ALL shards
+    assert [l[0] for l in lines] == list(range(1, ref["rounds"] + 1))
+    assert abs(lines[-1][1] - (wl["N0"] + len(wl["row_ptr"]) - 1)) < 1e-6
+    assert lines[-1][3] == 0 and lines[-1][2] == out[0]["bChange"]
+
+
+def test_rccl_calls_with_a_one_rank_communicator(monkeypatch):
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllReduce on the ctx stream, forced to run for a single rank."""
+    from rsem_amd import capi
+    from tools.synth_data import make_em_workload
+    monkeypatch.setenv("RSEM_COMM_FORCE", "1")
+    wl = make_em_workload("tiny", seed=3)
+    uid = capi.Comm.unique_id()
+    assert len(uid) == capi.COMM_ID_BYTES and any(uid)
+    comm = capi.Comm.create(0, 0, 1, uid)
+    assert (comm.rank, comm.world) == (0, 1)
+    ctx = capi.EmContext(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
+    plain = ctx.run(wl["theta0"], wl["N0"], max_round=60)
+    ctx.set_comm(comm)
+    viarccl = ctx.run(wl["theta0"], wl["N0"], max_round=60)
+    ctx.close()
+    comm.close()
+    assert viarccl["rounds"] == plain["rounds"] and np.array_equal(viarccl["theta"], plain["theta"])
