@@ -1,7 +1,9 @@
 // gen_temp.cpp -- seeded generator of a complete rsem-run-em input directory at benchmark scale
 // (".temp generator without SAM").  TEST / BENCH INFRASTRUCTURE, not product.
 //
-//   gen_temp <outdir> <n_reads> <M> <read_type 1|3> [seed] [read_len] [sam]
+//   gen_temp <outdir> <n_reads> <M> <read_type 1|3> [seed] [read_len] [sam|nosam] [kmin-kmax]
+//
+// kmin-kmax = isoforms per gene (default 2-9, ~6 alignments per read; 6-20 gives the ~12 per read of BASELINE configs[2])
 //
 // with a 7th argument "sam" it also writes <outdir>/aln.sam (the same reads and alignments as SAM records, in the
 // order rsem-parse-alignments would need to reproduce the files above byte for byte).
@@ -21,6 +23,7 @@
 #include <cstdlib>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 static const char BASES[4] = {'A', 'C', 'G', 'T'};
@@ -37,6 +40,9 @@ int main(int argc, char** argv) {
     const int L = argc > 6 ? atoi(argv[6]) : 100;
     const bool pe = read_type == 3;
     const bool want_sam = argc > 7 && std::string(argv[7]) == "sam";
+    int kmin = 2, kmax = 9;
+    if (argc > 8 && sscanf(argv[8], "%d-%d", &kmin, &kmax) != 2) { fprintf(stderr, "isoforms per gene: kmin-kmax\n"); return 1; }
+    if (kmin < 1 || kmax < kmin) { fprintf(stderr, "isoforms per gene: 1 <= kmin <= kmax\n"); return 1; }
     if (read_type != 1 && read_type != 3) { fprintf(stderr, "read_type must be 1 or 3\n"); return 1; }
     std::mt19937_64 rng(seed);
     auto uni = [&](double a, double b) { return std::uniform_real_distribution<double>(a, b)(rng); };
@@ -47,7 +53,7 @@ int main(int argc, char** argv) {
     std::vector<Tx> tx(1);
     std::vector<int> gstart;  // first transcript id of each gene
     while ((int)tx.size() - 1 < M) {
-        int k = std::min(irand(2, 9), M - ((int)tx.size() - 1));
+        int k = std::min(irand(kmin, kmax), M - ((int)tx.size() - 1));
         int Lg = irand(1500, 4000);
         std::string s(Lg, 'A');
         for (int i = 0; i < Lg; i++) s[i] = BASES[rng() & 3];
@@ -96,9 +102,7 @@ int main(int argc, char** argv) {
     FILE* fdat = fopen((out + "/temp/s.dat").c_str(), "w");
     FILE* fq1 = fopen((out + (pe ? "/temp/s_alignable_1.fq" : "/temp/s_alignable.fq")).c_str(), "w");
     FILE* fq2 = pe ? fopen((out + "/temp/s_alignable_2.fq").c_str(), "w") : nullptr;
-    static char buf1[1 << 16], buf2[1 << 16], buf3[1 << 16];
     setvbuf(fdat, nullptr, _IOFBF, 1 << 22); setvbuf(fq1, nullptr, _IOFBF, 1 << 22); if (fq2) setvbuf(fq2, nullptr, _IOFBF, 1 << 22);
-    (void)buf1; (void)buf2; (void)buf3;
     FILE* fsam = nullptr;
     if (want_sam) {
         fsam = fopen((out + "/aln.sam").c_str(), "w");
@@ -107,83 +111,129 @@ int main(int argc, char** argv) {
         for (int t = 1; t <= M; t++) fprintf(fsam, "@SQ\tSN:t%d\tLN:%d\n", t, tlen(t));
         fprintf(fsam, "@PG\tID:gen_temp\n");
     }
-    auto revcomp = [&](const std::string& s) { std::string r(s.rbegin(), s.rend()); for (char& c : r) c = comp(c); return r; };
-    auto rev = [&](const std::string& s) { return std::string(s.rbegin(), s.rend()); };
-    // one SAM record; `fwd` = 0-based leftmost forward coordinate, is_rev = aligned to the reverse strand
-    auto sam_rec = [&](long long id, int flag, int s, int fwd, int mate_fwd, int tl, const std::string& sq, const std::string& ql, bool is_rev) {
-        if (s > 0) fprintf(fsam, "r%lld\t%d\tt%d\t%d\t255\t%dM\t%s\t%d\t%d\t", id, flag, s, fwd + 1, L, pe ? "=" : "*", pe ? mate_fwd + 1 : 0, tl);
-        else fprintf(fsam, "r%lld\t%d\t*\t0\t0\t*\t*\t0\t0\t", id, flag);
-        const std::string a = is_rev ? revcomp(sq) : sq, b = is_rev ? rev(ql) : ql;
-        fwrite(a.data(), 1, a.size(), fsam); fputc('\t', fsam);
-        fwrite(b.data(), 1, b.size(), fsam); fputc('\n', fsam);
-    };
     fprintf(fdat, "%-99s\n", "");  // header is patched at the end (parseIt.cpp:195-199)
-    long long nHits = 0;
-    std::string seq(L, 'A'), qual(L, 'I'), seq2(L, 'A'), qual2(L, 'I'), line;
-    auto emit_read = [&](FILE* f, long long id, const std::string& s, const std::string& q) {
-        fprintf(f, "@r%lld\n", id);
-        fwrite(s.data(), 1, s.size(), f); fputs("\n+\n", f);
-        fwrite(q.data(), 1, q.size(), f); fputc('\n', f);
-    };
-    // read sequence of `len` bases starting at strand position spos of transcript t on strand dir, with errors
-    auto make_read = [&](int t, int dir, int spos, std::string& s, std::string& q) {
-        const std::string& g = gseq[tx[t].gene];
-        const int tl = tlen(t);
-        int qv = irand(25, 40);
-        for (int i = 0; i < L; i++) {
-            char c = dir == 0 ? g[tx[t].a + spos + i] : comp(g[tx[t].a + (tl - 1 - (spos + i))]);
-            if (uni(0, 1) < pow(10.0, -qv / 10.0)) c = BASES[rng() & 3];
-            s[i] = c;
-            q[i] = (char)(qv + 33);
-            qv = next_q(qv);
-        }
-    };
-    for (long long r = 0; r < N1; r++) {
-        double u = uni(0, cdf[M]);
-        int t = (int)(std::upper_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
-        t = std::min(std::max(t, 1), M);
-        const int tl = tlen(t);
-        const int dir = (rng() & 1);
-        int frag = L;
-        if (pe) { frag = (int)std::lround(std::normal_distribution<double>(200, 30)(rng)); frag = std::min(std::max(frag, L), std::min(tl, 400)); }
-        const int fpos = irand(0, tl - frag);              // forward coordinate of the fragment in t
-        const int gpos = tx[t].a + fpos;                   // gene coordinate
-        const int spos = dir == 0 ? fpos : tl - fpos - frag;  // position on the strand of alignment
-        make_read(t, dir, spos, seq, qual);
-        if (pe) make_read(t, !dir, tl - spos - frag, seq2, qual2);
-        emit_read(fq1, r, seq, qual);
-        if (pe) emit_read(fq2, r, seq2, qual2);
-        // alignments: every isoform of the gene that contains [gpos, gpos+frag)
-        line.clear();
-        int k = 0;
-        const int g = tx[t].gene;
-        for (int s = gstart[g]; s < gstart[g + 1]; s++) {
-            if (tx[s].a <= gpos && gpos + frag <= tx[s].b) {
-                const int sl = tlen(s), f2 = gpos - tx[s].a;
-                const int p = dir == 0 ? f2 : sl - f2 - frag;
-                char tmp[64];
-                if (pe) snprintf(tmp, sizeof(tmp), " %d %d %d", dir == 0 ? s : -s, p, frag);
-                else snprintf(tmp, sizeof(tmp), " %d %d", dir == 0 ? s : -s, p);
-                line += tmp;
-                ++k;
-                if (fsam) {
-                    if (!pe) sam_rec(r, dir == 0 ? 0 : 16, s, f2, 0, 0, seq, qual, dir != 0);
-                    else if (dir == 0) {
-                        sam_rec(r, 99, s, f2, f2 + frag - L, frag, seq, qual, false);
-                        sam_rec(r, 147, s, f2 + frag - L, f2, -frag, seq2, qual2, true);
-                    } else {
-                        sam_rec(r, 83, s, f2 + frag - L, f2, -frag, seq, qual, true);
-                        sam_rec(r, 163, s, f2, f2 + frag - L, frag, seq2, qual2, false);
+    // Reads are generated in tasks of kTask reads, each from its own generator seeded by (seed, task), on all host
+    // threads; the tasks' text is written in task order, so the files do not depend on the number of threads.
+    constexpr long long kTask = 16384;
+    struct TaskOut { std::string dat, q1, q2, sam; long long hits = 0; };
+    auto gen_task = [&](long long task, TaskOut& O) {
+        std::mt19937_64 rg(((uint64_t)seed << 20) ^ (uint64_t)(task + 1) * 0x9e3779b97f4a7c15ull);
+        auto tuni = [&](double a, double b) { return std::uniform_real_distribution<double>(a, b)(rg); };
+        auto tirand = [&](int a, int b) { return std::uniform_int_distribution<int>(a, b)(rg); };
+        auto tnext_q = [&](int q) { int d = tirand(-5, 3); int v = q + d; if (v > 40) v = 40 - tirand(0, 3); if (v < 2) v = 2 + tirand(0, 3); return v; };
+        std::string seq(L, 'A'), qual(L, 'I'), seq2(L, 'A'), qual2(L, 'I');
+        char tmp[160];
+        auto revcomp = [&](const std::string& x) { std::string r(x.rbegin(), x.rend()); for (char& c : r) c = comp(c); return r; };
+        auto rev = [&](const std::string& x) { return std::string(x.rbegin(), x.rend()); };
+        auto sam_rec = [&](long long id, int flag, int sv, int fwd, int mate_fwd, int tl, const std::string& sq, const std::string& ql, bool is_rev) {
+            if (sv > 0) snprintf(tmp, sizeof(tmp), "r%lld\t%d\tt%d\t%d\t255\t%dM\t%s\t%d\t%d\t", id, flag, sv, fwd + 1, L, pe ? "=" : "*", pe ? mate_fwd + 1 : 0, tl);
+            else snprintf(tmp, sizeof(tmp), "r%lld\t%d\t*\t0\t0\t*\t*\t0\t0\t", id, flag);
+            O.sam += tmp;
+            O.sam += is_rev ? revcomp(sq) : sq; O.sam += '\t';
+            O.sam += is_rev ? rev(ql) : ql; O.sam += '\n';
+        };
+        auto emit_read = [&](std::string& f, long long id, const std::string& sq, const std::string& q) {
+            snprintf(tmp, sizeof(tmp), "@r%lld\n", id);
+            f += tmp; f += sq; f += "\n+\n"; f += q; f += '\n';
+        };
+        auto make_read = [&](int t, int dir, int spos, std::string& sq, std::string& q) {
+            const std::string& g = gseq[tx[t].gene];
+            const int tl = tlen(t);
+            int qv = tirand(25, 40);
+            for (int i = 0; i < L; i++) {
+                char c = dir == 0 ? g[tx[t].a + spos + i] : comp(g[tx[t].a + (tl - 1 - (spos + i))]);
+                if (tuni(0, 1) < pow(10.0, -qv / 10.0)) c = BASES[rg() & 3];
+                sq[i] = c;
+                q[i] = (char)(qv + 33);
+                qv = tnext_q(qv);
+            }
+        };
+        const long long r0 = task * kTask, r1 = std::min(N1, r0 + kTask);
+        O.dat.reserve((size_t)(r1 - r0) * 80);
+        O.q1.reserve((size_t)(r1 - r0) * (2 * L + 20));
+        if (pe) O.q2.reserve((size_t)(r1 - r0) * (2 * L + 20));
+        std::string line;
+        for (long long r = r0; r < r1; r++) {
+            double u = tuni(0, cdf[M]);
+            int t = (int)(std::upper_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
+            t = std::min(std::max(t, 1), M);
+            const int tl = tlen(t);
+            const int dir = (rg() & 1);
+            int frag = L;
+            if (pe) { frag = (int)std::lround(std::normal_distribution<double>(200, 30)(rg)); frag = std::min(std::max(frag, L), std::min(tl, 400)); }
+            const int fpos = tirand(0, tl - frag);             // forward coordinate of the fragment in t
+            const int gpos = tx[t].a + fpos;                   // gene coordinate
+            const int spos = dir == 0 ? fpos : tl - fpos - frag;  // position on the strand of alignment
+            make_read(t, dir, spos, seq, qual);
+            if (pe) make_read(t, !dir, tl - spos - frag, seq2, qual2);
+            emit_read(O.q1, r, seq, qual);
+            if (pe) emit_read(O.q2, r, seq2, qual2);
+            // alignments: every isoform of the gene that contains [gpos, gpos+frag)
+            line.clear();
+            int k = 0;
+            const int g = tx[t].gene;
+            for (int sv = gstart[g]; sv < gstart[g + 1]; sv++) {
+                if (tx[sv].a <= gpos && gpos + frag <= tx[sv].b) {
+                    const int sl = tlen(sv), f2 = gpos - tx[sv].a;
+                    const int p = dir == 0 ? f2 : sl - f2 - frag;
+                    if (pe) snprintf(tmp, sizeof(tmp), " %d %d %d", dir == 0 ? sv : -sv, p, frag);
+                    else snprintf(tmp, sizeof(tmp), " %d %d", dir == 0 ? sv : -sv, p);
+                    line += tmp;
+                    ++k;
+                    if (want_sam) {
+                        if (!pe) sam_rec(r, dir == 0 ? 0 : 16, sv, f2, 0, 0, seq, qual, dir != 0);
+                        else if (dir == 0) {
+                            sam_rec(r, 99, sv, f2, f2 + frag - L, frag, seq, qual, false);
+                            sam_rec(r, 147, sv, f2 + frag - L, f2, -frag, seq2, qual2, true);
+                        } else {
+                            sam_rec(r, 83, sv, f2 + frag - L, f2, -frag, seq, qual, true);
+                            sam_rec(r, 163, sv, f2, f2 + frag - L, frag, seq2, qual2, false);
+                        }
                     }
                 }
             }
+            snprintf(tmp, sizeof(tmp), "%d", k);
+            O.dat += tmp; O.dat += line; O.dat += '\n';
+            O.hits += k;
         }
-        fprintf(fdat, "%d%s\n", k, line.c_str());
-        nHits += k;
+    };
+    long long nHits = 0;
+    {
+        const long long ntasks = (N1 + kTask - 1) / kTask;
+        const int nthr = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 256u));
+        for (long long w0 = 0; w0 < ntasks; w0 += nthr) {
+            const int nw = (int)std::min<long long>(nthr, ntasks - w0);
+            std::vector<TaskOut> outs(nw);
+            std::vector<std::thread> th;
+            for (int i = 0; i < nw; i++) th.emplace_back([&, i]() { gen_task(w0 + i, outs[i]); });
+            for (auto& x : th) x.join();
+            for (int i = 0; i < nw; i++) {
+                fwrite(outs[i].dat.data(), 1, outs[i].dat.size(), fdat);
+                fwrite(outs[i].q1.data(), 1, outs[i].q1.size(), fq1);
+                if (fq2) fwrite(outs[i].q2.data(), 1, outs[i].q2.size(), fq2);
+                if (fsam) fwrite(outs[i].sam.data(), 1, outs[i].sam.size(), fsam);
+                nHits += outs[i].hits;
+            }
+        }
     }
     fseek(fdat, 0, SEEK_SET);
     fprintf(fdat, "%lld %lld %d", N1, nHits, read_type);
     fclose(fdat); fclose(fq1); if (fq2) fclose(fq2);
+    std::string seq(L, 'A'), qual(L, 'I');
+    auto revcomp = [&](const std::string& x) { std::string r(x.rbegin(), x.rend()); for (char& c : r) c = comp(c); return r; };
+    auto rev = [&](const std::string& x) { return std::string(x.rbegin(), x.rend()); };
+    auto sam_rec = [&](long long id, int flag, int sv, int fwd, int mate_fwd, int tl, const std::string& sq, const std::string& ql, bool is_rev) {
+        (void)sv; (void)fwd; (void)mate_fwd; (void)tl;
+        fprintf(fsam, "r%lld\t%d\t*\t0\t0\t*\t*\t0\t0\t", id, flag);
+        const std::string a2 = is_rev ? revcomp(sq) : sq, b2 = is_rev ? rev(ql) : ql;
+        fwrite(a2.data(), 1, a2.size(), fsam); fputc('\t', fsam);
+        fwrite(b2.data(), 1, b2.size(), fsam); fputc('\n', fsam);
+    };
+    auto emit_read = [&](FILE* f, long long id, const std::string& sq, const std::string& q) {
+        fprintf(f, "@r%lld\n", id);
+        fwrite(sq.data(), 1, sq.size(), f); fputs("\n+\n", f);
+        fwrite(q.data(), 1, q.size(), f); fputc('\n', f);
+    };
     {   // unalignable reads
         FILE* fu1 = fopen((out + (pe ? "/temp/s_un_1.fq" : "/temp/s_un.fq")).c_str(), "w");
         FILE* fu2 = pe ? fopen((out + "/temp/s_un_2.fq").c_str(), "w") : nullptr;
