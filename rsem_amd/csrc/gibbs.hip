@@ -334,12 +334,15 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
                                                           int32_t* counts_base, int32_t* z_base,
                                                           const double* __restrict__ alpha, double pseudoC, MtState* mt_base,
                                                           const int32_t* __restrict__ last_round, int round, uint64_t stride_c,
-                                                          uint64_t stride_z) {
+                                                          uint64_t stride_z, int dbg, unsigned long long* dbg_out) {
+    // dbg (tools/gibbs_exact_profile.py only; results are wrong when set): 1 = no commit loop, 2 = no draw either,
+    // 4 = count the commit loop's iterations / redraws into dbg_out[0..3]
     const int chain = blockIdx.x;
     if (round > last_round[chain]) return;
     int32_t* counts = counts_base + (uint64_t)chain * stride_c;
     int32_t* z = z_base + (uint64_t)chain * stride_z;
     MtState* mt_state = mt_base + chain;
+    unsigned long long n_changed = 0, n_iter = 0, n_redraw_events = 0, n_redraw_lanes = 0;
     __shared__ uint32_t mt[624];
     __shared__ uint64_t t_rp[kTileRows + 1];
     __shared__ int32_t t_sid[kTileItems];
@@ -509,10 +512,13 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
             else { lo = min(lo, s); hi = max(hi, s); }
             if (!kInit && s == z_old) t_c[fr + k] -= 1;  // the read leaves its current transcript (Gibbs.cpp:298)
         }
-        int z_new = mine ? draw(fr, len, rnd) : 0;
+        int z_new = (mine && !(dbg & 2)) ? draw(fr, len, rnd) : z_old;
         if (!kInit) {
             unsigned long long changed = __ballot(mine && z_new != z_old);
+            if (dbg & 4) n_changed += __popcll(changed);
+            if (dbg & 1) changed = 0;
             while (changed) {
+                if (dbg & 4) ++n_iter;
                 const int r1 = __ffsll((long long)changed) - 1;
                 const int zo = __builtin_amdgcn_readlane(z_old, r1), zn = __builtin_amdgcn_readlane(z_new, r1);
                 changed &= ~(1ull << r1);
@@ -530,6 +536,7 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
                     }
                 }
                 if (__ballot(hit)) {
+                    if (dbg & 4) { ++n_redraw_events; n_redraw_lanes += __popcll(__ballot(hit)); }
                     if (hit) z_new = draw(fr, len, rnd);
                     const unsigned long long later = (r1 >= 63) ? 0ull : (~0ull << (r1 + 1));
                     changed = __ballot(mine && z_new != z_old) & later;
@@ -550,6 +557,10 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
     __syncthreads();
     for (int i = lane; i < 624; i += 64) mt_state->mt[i] = mt[i];
     if (lane == 0) mt_state->idx = idx;
+    if ((dbg & 4) && dbg_out && lane == 0) {
+        atomicAdd(&dbg_out[0], n_changed); atomicAdd(&dbg_out[1], n_iter);
+        atomicAdd(&dbg_out[2], n_redraw_events); atomicAdd(&dbg_out[3], n_redraw_lanes);
+    }
 }
 
 constexpr int kSerialTileItems = 3072;
@@ -1167,6 +1178,10 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         for (int k = 0; k < nchains; k++) host_mt_seed(h[k], seeds[k]);
         RSEM_HIP_TRY(hipMemcpyAsync(mts.p, h.data(), sizeof(MtState) * nchains, hipMemcpyHostToDevice, st));
         const bool serial = exact_serial_requested();
+        const int dbg = getenv("RSEM_GIBBS_EXACT_DEBUG") ? atoi(getenv("RSEM_GIBBS_EXACT_DEBUG")) : 0;
+        DevBuf dbg_buf;
+        RSEM_HIP_TRY(dbg_buf.alloc(4 * sizeof(unsigned long long)));
+        RSEM_HIP_TRY(hipMemsetAsync(dbg_buf.p, 0, 4 * sizeof(unsigned long long), st));
         auto sweep = [&](bool init, int round) {
 #define EXACT_ARGS c->N1, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->d_alpha, c->pseudoC, \
                    mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z
@@ -1174,8 +1189,8 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                 if (init) hipLaunchKernelGGL(k_gibbs_exact_serial<true>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
                 else hipLaunchKernelGGL(k_gibbs_exact_serial<false>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
             } else {
-                if (init) hipLaunchKernelGGL(k_gibbs_exact_coop<true>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
-                else hipLaunchKernelGGL(k_gibbs_exact_coop<false>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
+                if (init) hipLaunchKernelGGL(k_gibbs_exact_coop<true>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS, dbg, dbg_buf.as<unsigned long long>());
+                else hipLaunchKernelGGL(k_gibbs_exact_coop<false>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS, dbg, dbg_buf.as<unsigned long long>());
             }
 #undef EXACT_ARGS
         };
@@ -1191,6 +1206,14 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                 int rc = keep_sample((round - burnin - 1) / gap, 0, nchains);
                 if (rc != RSEM_OK) return rc;
             }
+        }
+        if (dbg & 4) {
+            unsigned long long h4[4] = {0, 0, 0, 0};
+            RSEM_HIP_TRY(hipMemcpyAsync(h4, dbg_buf.p, sizeof(h4), hipMemcpyDeviceToHost, st));
+            RSEM_HIP_TRY(hipStreamSynchronize(st));
+            const double visits = (double)c->N1 * rounds * nchains;
+            fprintf(stderr, "[gibbs exact] per read visit: changed %.3f, commit iterations %.3f, redraw events %.4f, lanes redrawn %.4f\n",
+                    h4[0] / visits, h4[1] / visits, h4[2] / visits, h4[3] / visits);
         }
     } else {
         // one chain after the other: a sweep of this sampler fills the GPU by itself

@@ -57,7 +57,7 @@ def test_sharded_em_run_equals_single_context(world):
     # one line per round, in order, SUM = N0 + reads with a non-zero normaliser over ALL shards
     assert [l[0] for l in lines] == list(range(1, ref["rounds"] + 1))
     assert abs(lines[-1][1] - (wl["N0"] + len(wl["row_ptr"]) - 1)) < 1e-6
-    assert lines[-1][3] == 0 and lines[-1][2] == out[0]["bChange"]
+    assert lines[-1][3] == out[0]["totNum"] and lines[-1][2] == out[0]["bChange"]
 
 
 def test_rccl_calls_with_a_one_rank_communicator(monkeypatch):
@@ -76,4 +76,5 @@ def test_rccl_calls_with_a_one_rank_communicator(monkeypatch):
     viarccl = ctx.run(wl["theta0"], wl["N0"], max_round=60)
     ctx.close()
     comm.close()
-    assert viarccl["rounds"] == plain["rounds"] and np.array_equal(viarccl["theta"], plain["theta"])
+    # (floating-point atomics: two runs of the same ctx agree to the last few bits, not bit for bit)
+    assert viarccl["rounds"] == plain["rounds"] and np.allclose(viarccl["theta"], plain["theta"], rtol=1e-12, atol=0)
