@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -57,6 +58,22 @@ struct MappedFile {
         if (data && size) munmap((void*)data, size);
         if (fd >= 0) ::close(fd);
     }
+};
+
+// A typed array that either owns its storage (uninitialised on allocation: the parsers fill it from many threads, which
+// also spreads the first-touch page faults) or views memory owned elsewhere (a mapped file).
+template <typename T>
+struct Arr {
+    std::unique_ptr<T[]> own;
+    std::shared_ptr<MappedFile> keep;
+    const T* p = nullptr;
+    size_t n = 0;
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    const T& operator[](size_t i) const { return p[i]; }
+    T* alloc(size_t m) { own.reset(new T[m ? m : 1]); p = own.get(); n = m; return own.get(); }
+    void view(const T* q, size_t m, std::shared_ptr<MappedFile> k) { own.reset(); keep = std::move(k); p = q; n = m; }
 };
 
 inline int hardware_threads() {

@@ -2,11 +2,17 @@
 // SAM/BAM in, the EM stage's input files out, byte-identical to the reference's:
 //
 //   rsem-parse-alignments refName imdName statName alignF read_type [-t fai_file] [-tag tagName] [-q] [-p threads]
+//                         [--binary [--text]]        (not in the reference; also RSEM_HIP_BINARY=1 / =both in the environment)
 //
 //   imdName.dat                        N1 nHits read_type / one line of hits per alignable read
 //   imdName_{un,alignable,max}[_1|_2].{fa,fq}   reads by category (empty categories are removed)
 //   imdName.omit                       transcripts the alignment header does not declare
 //   statName.cnt                       N0 N1 N2 / nUnique nMulti nIsoMulti / nHits read_type / hits-per-read histogram
+//
+// --binary writes imdName.rsb/ INSTEAD of imdName.dat and the read files: the same alignments and reads as the arrays
+// rsem-run-em uploads (host/rsb.hpp), so that the EM stage maps them instead of parsing decimal text (the reference's
+// text round trip: parseIt.cpp:139-147 -> HitContainer.h:63-79, SingleReadQ.h:38-60); --text keeps the text files as
+// well.  .cnt and .omit are always written.
 //
 // Host-only stage (byte shuffling, no GPU work); it feeds the EM hot path.  The reference
 // walks the file on one thread through htslib.  Here the decoded stream is cut into waves; inside a wave the records
@@ -24,6 +30,7 @@
 
 #include "files.hpp"
 #include "reads.hpp"
+#include "rsb.hpp"
 
 using namespace rsemh;
 
@@ -56,6 +63,7 @@ struct Config {
     std::unordered_map<std::string, int> tid_of;  // SAM RNAME -> header index
     std::vector<int32_t> e2i, target_len, gid_of;
     int n_targets = 0;
+    bool want_text = true, want_bin = false;
 };
 
 struct ParseError { std::string msg; };
@@ -230,6 +238,10 @@ inline void append_int(std::string& s, long long v) {
 
 struct ChunkOut {
     std::string dat, reads[3][2];
+    // --binary: the same content as arrays (host/rsb.hpp)
+    std::vector<uint32_t> b_rowlen, b_len[3][2];
+    std::vector<int32_t> b_sid, b_pos, b_ins;
+    std::vector<uint8_t> b_seq[3][2], b_qual[3][2];
     long long N[3] = {0, 0, 0}, nHits = 0, nMulti = 0, nIsoMulti = 0, units = 0;
     std::map<long long, long long> counter;
     std::vector<std::string> warns;
@@ -269,17 +281,34 @@ void run_chunk(const Wave& w, size_t u0, size_t u1, const Config& cfg, ChunkOut&
     struct Mate { std::string name, seq, qual; int len = 0; } cur[2];
     int cur_val = -2;
     std::string hits;
-    std::vector<int32_t> gids;
+    std::vector<int32_t> gids, h_sid, h_pos, h_ins;
     const int n_os = cfg.paired ? 2 : 1;
 
     auto flush = [&]() {  // parseIt.cpp:92-118
         if (cur_val >= 0) {
             for (int j = 0; j < n_os; j++) {  // SingleRead.h:52-55, SingleReadQ.h:57-60
-                std::string& o = out.reads[cur_val][j];
-                o.push_back(cfg.has_q ? '@' : '>');
-                o += cur[j].name; o.push_back('\n');
-                o += cur[j].seq; o.push_back('\n');
-                if (cfg.has_q) { o += "+\n"; o += cur[j].qual; o.push_back('\n'); }
+                if (cfg.want_text) {
+                    std::string& o = out.reads[cur_val][j];
+                    o.push_back(cfg.has_q ? '@' : '>');
+                    o += cur[j].name; o.push_back('\n');
+                    o += cur[j].seq; o.push_back('\n');
+                    if (cfg.has_q) { o += "+\n"; o += cur[j].qual; o.push_back('\n'); }
+                }
+                if (cfg.want_bin) {  // what rsem-run-em would decode from the text: get_base_id (utils.h:36-50), c2q (QProfile.h:44)
+                    const int8_t* tbl = base_table();
+                    const std::string& sq = cur[j].seq;
+                    std::vector<uint8_t>& bs = out.b_seq[cur_val][j];
+                    const size_t o0 = bs.size();
+                    bs.resize(o0 + sq.size());
+                    for (size_t i = 0; i < sq.size(); i++) { const int8_t id = tbl[(unsigned char)sq[i]]; bs[o0 + i] = id < 0 ? 255 : (uint8_t)id; }
+                    if (cfg.has_q) {
+                        const std::string& ql = cur[j].qual;
+                        std::vector<uint8_t>& bq = out.b_qual[cur_val][j];
+                        bq.resize(o0 + sq.size());
+                        for (size_t i = 0; i < sq.size(); i++) bq[o0 + i] = i < ql.size() ? (uint8_t)((unsigned char)ql[i] - 33) : 255;
+                    }
+                    out.b_len[cur_val][j].push_back((uint32_t)sq.size());
+                }
             }
             ++out.N[cur_val];
         }
@@ -290,11 +319,18 @@ void run_chunk(const Wave& w, size_t u0, size_t u1, const Config& cfg, ChunkOut&
             std::sort(gids.begin(), gids.end());
             if (std::unique(gids.begin(), gids.end()) - gids.begin() > 1) ++out.nMulti;  // HitContainer.h:94-108
             if (k > 1) ++out.nIsoMulti;
-            if (k > 0) { append_int(out.dat, k); out.dat += hits; out.dat.push_back('\n'); }
+            if (k > 0 && cfg.want_text) { append_int(out.dat, k); out.dat += hits; out.dat.push_back('\n'); }
+            if (k > 0 && cfg.want_bin) {
+                out.b_rowlen.push_back((uint32_t)k);
+                out.b_sid.insert(out.b_sid.end(), h_sid.begin(), h_sid.end());
+                out.b_pos.insert(out.b_pos.end(), h_pos.begin(), h_pos.end());
+                if (cfg.paired) out.b_ins.insert(out.b_ins.end(), h_ins.begin(), h_ins.end());
+            }
             ++out.counter[k];
         }
         hits.clear();
         gids.clear();
+        h_sid.clear(); h_pos.clear(); h_ins.clear();
     };
 
     Unit U;
@@ -339,14 +375,16 @@ void run_chunk(const Wave& w, size_t u0, size_t u1, const Config& cfg, ChunkOut&
                 if (a.tid < 0 || a.tid >= cfg.n_targets) fail("Read " + nm + ": aligned to a reference sequence the header does not declare!");
                 const int sid = cfg.e2i[a.tid];
                 const int tlen = cfg.target_len[a.tid];
-                hits.push_back(' ');
-                if (a.rev()) {  // SamParser.h:136-141, 218-223
-                    append_int(hits, -sid); hits.push_back(' '); append_int(hits, tlen - a.pos - a.l_seq);
-                    if (cfg.paired) { hits.push_back(' '); append_int(hits, a.pos + a.l_seq - b.pos); }
-                } else {
-                    append_int(hits, sid); hits.push_back(' '); append_int(hits, a.pos);
-                    if (cfg.paired) { hits.push_back(' '); append_int(hits, b.pos + b.l_seq - a.pos); }
+                // SamParser.h:136-141, 218-223
+                const int h_s = a.rev() ? -sid : sid;
+                const int h_p = a.rev() ? tlen - a.pos - a.l_seq : a.pos;
+                const int h_i = !cfg.paired ? 0 : (a.rev() ? a.pos + a.l_seq - b.pos : b.pos + b.l_seq - a.pos);
+                if (cfg.want_text) {
+                    hits.push_back(' ');
+                    append_int(hits, h_s); hits.push_back(' '); append_int(hits, h_p);
+                    if (cfg.paired) { hits.push_back(' '); append_int(hits, h_i); }
                 }
+                if (cfg.want_bin) { h_sid.push_back(h_s); h_pos.push_back(h_p); if (cfg.paired) h_ins.push_back(h_i); }
                 gids.push_back(cfg.gid_of[sid]);
             }
             ++out.units;
@@ -462,6 +500,16 @@ int main(int argc, char* argv[]) {
         if (!strcmp(argv[i], "-q")) verbose = false;
         if (!strcmp(argv[i], "-p") && i + 1 < argc) threads = std::max(1, atoi(argv[i + 1]));
         if (!strcmp(argv[i], "--wave-bytes") && i + 1 < argc) wave_bytes = (size_t)atoll(argv[i + 1]);  // testing knob
+    }
+    {   // binary hand-off to rsem-run-em (host/rsb.hpp): a flag, or the environment when the Perl driver builds the command line
+        bool bin = false, text = false;
+        for (int i = 6; i < argc; i++) { bin = bin || !strcmp(argv[i], "--binary"); text = text || !strcmp(argv[i], "--text"); }
+        if (const char* e = getenv("RSEM_HIP_BINARY")) {
+            if (!strcmp(e, "both")) { bin = true; text = true; }
+            else if (*e && strcmp(e, "0")) bin = true;
+        }
+        cfg.want_bin = bin;
+        cfg.want_text = !bin || text;
     }
     if (!cfg.rt_tag.empty() && cfg.rt_tag.size() != 2) die("-tag expects a two-character SAM tag!");
     if (!wave_bytes) wave_bytes = std::max<size_t>((size_t)threads << 23, (size_t)64 << 20);
@@ -585,7 +633,7 @@ int main(int argc, char* argv[]) {
     const int n_os = cfg.paired ? 2 : 1;
     FILE* cat[3][2] = {{nullptr}};
     std::string cat_path[3][2];
-    for (int c = 0; c < 3; c++) {
+    for (int c = 0; c < 3 && cfg.want_text; c++) {
         const std::vector<std::string> names = read_file_names(imdName, c, cfg.read_type);
         for (int j = 0; j < n_os; j++) {
             cat_path[c][j] = names[j];
@@ -593,9 +641,14 @@ int main(int argc, char* argv[]) {
             if (!cat[c][j]) die("Cannot open %s for writing!", names[j].c_str());
         }
     }
-    FILE* fdat = fopen((imdName + ".dat").c_str(), "w");
-    if (!fdat) die("Cannot open %s.dat for writing!", imdName.c_str());
-    fprintf(fdat, "%-99s\n", "");  // patched once the totals are known (parseIt.cpp:195-204)
+    FILE* fdat = nullptr;
+    if (cfg.want_text) {
+        fdat = fopen((imdName + ".dat").c_str(), "w");
+        if (!fdat) die("Cannot open %s.dat for writing!", imdName.c_str());
+        fprintf(fdat, "%-99s\n", "");  // patched once the totals are known (parseIt.cpp:195-204)
+    }
+    std::unique_ptr<RsbWriter> rsb;
+    if (cfg.want_bin) rsb.reset(new RsbWriter(imdName, cfg.read_type));
 
     long long N[3] = {0, 0, 0}, nHits = 0, nMulti = 0, nIsoMulti = 0, cnt = 0, n_warns = 0, next_report = 1000000;
     std::map<long long, long long> counter;
@@ -710,9 +763,17 @@ int main(int argc, char* argv[]) {
             for (auto& m : o.warns)
                 if (++n_warns <= 50) fprintf(stderr, "%s\n", m.c_str());
             n_warns += o.n_warns - (long long)o.warns.size();
-            fwrite(o.dat.data(), 1, o.dat.size(), fdat);
-            for (int k = 0; k < 3; k++)
-                for (int j = 0; j < n_os; j++) fwrite(o.reads[k][j].data(), 1, o.reads[k][j].size(), cat[k][j]);
+            if (cfg.want_text) {
+                fwrite(o.dat.data(), 1, o.dat.size(), fdat);
+                for (int k = 0; k < 3; k++)
+                    for (int j = 0; j < n_os; j++) fwrite(o.reads[k][j].data(), 1, o.reads[k][j].size(), cat[k][j]);
+            }
+            if (rsb && o.error.empty()) {
+                rsb->append_hits(o.b_rowlen.data(), o.b_rowlen.size(), o.b_sid.data(), o.b_pos.data(), o.b_ins.data());
+                for (int k = 0; k < 3; k++)
+                    for (int j = 0; j < n_os; j++)
+                        rsb->append_reads(k, j, o.b_len[k][j].data(), o.b_len[k][j].size(), o.b_seq[k][j].data(), o.b_qual[k][j].data());
+            }
             for (int k = 0; k < 3; k++) N[k] += o.N[k];
             nHits += o.nHits; nMulti += o.nMulti; nIsoMulti += o.nIsoMulti;
             for (auto& kv : o.counter) counter[kv.first] += kv.second;
@@ -726,10 +787,19 @@ int main(int argc, char* argv[]) {
     if (n_warns > 0) fprintf(stderr, "Warning: Detected %lld lines containing read pairs whose two mates have different names.\n", n_warns);
     const long long nUnique = N[1] - nMulti;
 
-    fflush(fdat);
-    fseek(fdat, 0, SEEK_SET);
-    fprintf(fdat, "%lld %lld %d", N[1], nHits, cfg.read_type);
-    fclose(fdat);
+    if (fdat) {
+        fflush(fdat);
+        fseek(fdat, 0, SEEK_SET);
+        fprintf(fdat, "%lld %lld %d", N[1], nHits, cfg.read_type);
+        fclose(fdat);
+    }
+    if (rsb) {
+        rsb->finish();
+        const RsbHeader& h = rsb->header();
+        if ((long long)h.N[0] != N[0] || (long long)h.N[1] != N[1] || (long long)h.N[2] != N[2] || (long long)h.nHits != nHits)
+            die("rsem-parse-alignments: the binary hand-off does not add up (%llu %llu %llu reads, %llu alignments)!", (unsigned long long)h.N[0],
+                (unsigned long long)h.N[1], (unsigned long long)h.N[2], (unsigned long long)h.nHits);
+    }
 
     FILE* fc = fopen((statName + ".cnt").c_str(), "w");
     if (!fc) die("Cannot open %s.cnt for writing!", statName.c_str());
@@ -741,7 +811,7 @@ int main(int argc, char* argv[]) {
     fprintf(fc, "Inf\t%lld\n", N[2]);
     fclose(fc);
 
-    for (int c = 0; c < 3; c++)
+    for (int c = 0; c < 3 && cfg.want_text; c++)
         for (int j = 0; j < n_os; j++) {
             fclose(cat[c][j]);
             if (N[c] == 0) remove(cat_path[c][j].c_str());

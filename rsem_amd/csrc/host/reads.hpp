@@ -21,10 +21,10 @@ inline const int8_t* base_table() {
 
 struct ReadFile {
     uint64_t n = 0;
-    std::vector<uint64_t> off;  // [n+1]
-    std::vector<uint8_t> seq;   // base ids
-    std::vector<uint8_t> qual;  // quality - 33 (FASTQ only)
-    std::vector<uint8_t> lq1;   // Single*Read::calc_lq of this mate alone
+    Arr<uint64_t> off;         // [n+1]
+    Arr<uint8_t> seq;          // base ids
+    Arr<uint8_t> qual;         // quality - 33 (FASTQ only)
+    std::vector<uint8_t> lq1;  // Single*Read::calc_lq of this mate alone
     int len(uint64_t i) const { return (int)(off[i + 1] - off[i]); }
 };
 
@@ -38,6 +38,22 @@ inline bool calc_lq_single(const char* s, int len, bool hasPolyA, int seedLen) {
     for (int i = 0; i < len; i++) {
         if (s[i] == 'A') { ++numA; if (i < kOLen) ++numAO; }
         if (s[i] == 'T') { ++numT; if (i >= len - kOLen) ++numTO; }
+    }
+    if (numA >= threshold_1) return numAO >= threshold_2;
+    if (numT >= threshold_1) return numTO >= threshold_2;
+    return false;
+}
+
+// the same on base ids (A = 0, T = 3): reads that arrive already decoded (host/rsb.hpp)
+inline bool calc_lq_single_ids(const uint8_t* s, int len, bool hasPolyA, int seedLen) {
+    if (len < seedLen) return true;
+    if (!hasPolyA) return false;
+    int numA = 0, numT = 0, numAO = 0, numTO = 0;
+    const int threshold_1 = int(0.9 * len - 1.5 * sqrt(len * 1.0) + 0.5);
+    const int threshold_2 = (kOLen - 1) / 2 + 1;
+    for (int i = 0; i < len; i++) {
+        if (s[i] == 0) { ++numA; if (i < kOLen) ++numAO; }
+        if (s[i] == 3) { ++numT; if (i >= len - kOLen) ++numTO; }
     }
     if (numA >= threshold_1) return numAO >= threshold_2;
     if (numT >= threshold_1) return numTO >= threshold_2;
@@ -117,20 +133,25 @@ inline ReadFile parse_read_file(const std::string& path, bool fastq, bool hasPol
             }
         }
     });
+    // the chunks' pieces go to their final places in parallel
     ReadFile R;
-    R.off.push_back(0);
-    size_t tot = 0;
-    for (auto& P : parts) tot += P.seq.size();
-    R.seq.reserve(tot);
-    if (fastq) R.qual.reserve(tot);
-    for (auto& P : parts) {
-        for (uint32_t l : P.lens) R.off.push_back(R.off.back() + l);
-        R.seq.insert(R.seq.end(), P.seq.begin(), P.seq.end());
-        if (fastq) R.qual.insert(R.qual.end(), P.qual.begin(), P.qual.end());
-        R.lq1.insert(R.lq1.end(), P.lq.begin(), P.lq.end());
+    std::vector<uint64_t> r0(nc + 1, 0), b0(nc + 1, 0);
+    for (int c = 0; c < nc; c++) { r0[c + 1] = r0[c] + parts[c].lens.size(); b0[c + 1] = b0[c] + parts[c].seq.size(); }
+    R.n = r0[nc];
+    uint64_t* off = R.off.alloc(R.n + 1);
+    uint8_t* seq = R.seq.alloc(b0[nc]);
+    uint8_t* qual = fastq ? R.qual.alloc(b0[nc]) : nullptr;
+    R.lq1.resize(R.n);
+    off[R.n] = b0[nc];
+    parallel_for(nc, [&](int c) {
+        Part& P = parts[c];
+        uint64_t o = b0[c];
+        for (size_t i = 0; i < P.lens.size(); i++) { off[r0[c] + i] = o; o += P.lens[i]; }
+        if (!P.seq.empty()) memcpy(seq + b0[c], P.seq.data(), P.seq.size());
+        if (fastq && !P.qual.empty()) memcpy(qual + b0[c], P.qual.data(), P.qual.size());
+        if (!P.lq.empty()) memcpy(R.lq1.data() + r0[c], P.lq.data(), P.lq.size());
         P = Part();
-    }
-    R.n = R.off.size() - 1;
+    });
     return R;
 }
 
@@ -150,8 +171,8 @@ inline std::vector<std::string> read_file_names(const std::string& imdName, int 
 struct DatData {  // imd.dat (HitContainer.h:63-91, SingleHit.h:44-51, PairedEndHit.h:27-34)
     uint64_t N1 = 0, nHits = 0;
     int read_type = 0;
-    std::vector<uint64_t> row_ptr;
-    std::vector<int32_t> sid_signed, pos, insertL;
+    Arr<uint64_t> row_ptr;
+    Arr<int32_t> sid_signed, pos, insertL;
 };
 
 inline DatData load_dat(const std::string& path, int expect_read_type) {
@@ -195,14 +216,24 @@ inline DatData load_dat(const std::string& path, int expect_read_type) {
             q = le + 1;
         }
     });
-    D.row_ptr.push_back(0);
-    for (auto& P : parts) {
-        for (uint32_t l : P.lens) D.row_ptr.push_back(D.row_ptr.back() + l);
-        D.sid_signed.insert(D.sid_signed.end(), P.sid.begin(), P.sid.end());
-        D.pos.insert(D.pos.end(), P.pos.begin(), P.pos.end());
-        if (pe) D.insertL.insert(D.insertL.end(), P.ins.begin(), P.ins.end());
+    std::vector<uint64_t> r0(nc + 1, 0), h0(nc + 1, 0);
+    for (int c = 0; c < nc; c++) { r0[c + 1] = r0[c] + parts[c].lens.size(); h0[c + 1] = h0[c] + parts[c].sid.size(); }
+    uint64_t* rp = D.row_ptr.alloc(r0[nc] + 1);
+    int32_t* sidp = D.sid_signed.alloc(h0[nc]);
+    int32_t* posp = D.pos.alloc(h0[nc]);
+    int32_t* insp = pe ? D.insertL.alloc(h0[nc]) : nullptr;
+    rp[r0[nc]] = h0[nc];
+    parallel_for(nc, [&](int c) {
+        Part& P = parts[c];
+        uint64_t o = h0[c];
+        for (size_t i = 0; i < P.lens.size(); i++) { rp[r0[c] + i] = o; o += P.lens[i]; }
+        if (!P.sid.empty()) {
+            memcpy(sidp + h0[c], P.sid.data(), sizeof(int32_t) * P.sid.size());
+            memcpy(posp + h0[c], P.pos.data(), sizeof(int32_t) * P.pos.size());
+            if (pe) memcpy(insp + h0[c], P.ins.data(), sizeof(int32_t) * P.ins.size());
+        }
         P = Part();
-    }
+    });
     if (D.row_ptr.size() - 1 != D.N1) die("Number of alignable reads does not match!");
     return D;
 }

@@ -30,6 +30,7 @@
 #include "model_host.hpp"
 #include "reads.hpp"
 #include "results.hpp"
+#include "rsb.hpp"
 
 using namespace rsemh;
 
@@ -74,11 +75,6 @@ static void set_as_normal(LenDist& d, double mean, double sd, int minL, int maxL
     for (int i = 1; i <= d.span; i++) { d.pdf[i] /= sum; d.cdf[i] = d.cdf[i - 1] + d.pdf[i]; }
     d.trim();
 }
-
-struct ReadSetFiles {  // the three categories of reads (utils.h:129-149): un, alignable, max
-    ReadFile mate[3][2];
-    bool present[3] = {false, false, false};
-};
 
 // *Model::estimateFromReads (SingleQModel.h:283-327, PairedEndQModel.h:241-290 and the no-Q twins)
 static void estimate_from_reads(Model& model, const ReadSetFiles& rs, const RefInfo& refs, std::vector<uint8_t>& lq_alignable) {
@@ -348,9 +344,15 @@ int main(int argc, char* argv[]) {
     const bool pe = read_type >= 2, hasQ = (read_type == 1 || read_type == 3);
 
     // ---- inputs, parsed once --------------------------------------------------------------------------
-    DatData dat = load_dat(imdName + ".dat", read_type);
+    // imdName.rsb/ (rsem-parse-alignments --binary, host/rsb.hpp): the arrays themselves, mapped; otherwise the
+    // reference's text files
+    const bool binary_in = rsb_present(imdName);
+    DatData dat;
+    ReadSetFiles rs;
+    if (binary_in) load_rsb(imdName, read_type, refs.has_polyA, P.seedLen, dat, rs);
+    else dat = load_dat(imdName + ".dat", read_type);
     if (dat.N1 != N1) die("Number of alignable reads does not match!");
-    lap("parse .dat");
+    lap(binary_in ? "map .rsb" : "parse .dat");
     // the EM context (CSR upload, device-side sort into the sliced layout) only needs the hits: build it while the
     // read files are parsed
     int ndev = 0;
@@ -419,10 +421,15 @@ int main(int argc, char* argv[]) {
         });
     });
     Joiner em_joiner{em_builder};
-    ReadSetFiles rs;
     const uint64_t Ncat[3] = {N0, N1, N2};
     for (int tag = 0; tag < 3; tag++) {
         if (Ncat[tag] == 0) continue;
+        if (binary_in) {
+            if (rs.mate[tag][0].n != Ncat[tag]) die("%s.rsb holds %llu reads of category %d, %s.cnt says %llu!", imdName.c_str(),
+                                                    (unsigned long long)rs.mate[tag][0].n, tag, statName.c_str(), (unsigned long long)Ncat[tag]);
+            if (verbose) printf("estimateFromReads, N%d finished.\n", tag);
+            continue;
+        }
         std::vector<std::string> names = read_file_names(imdName, tag, read_type);
         for (size_t m = 0; m < names.size(); m++) rs.mate[tag][m] = parse_read_file(names[m], hasQ, refs.has_polyA, P.seedLen);
         rs.present[tag] = true;

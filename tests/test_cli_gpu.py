@@ -180,6 +180,37 @@ def test_generated_dataset_vs_reference_binary(read_type, n_reads, tmp_path):
     assert np.allclose(np.array(res[5], float), np.array(gres[5], float), atol=0.011, rtol=1e-6)  # TPM
 
 
+@pytest.mark.parametrize("name", ["se_q", "se_noq_rev_rspd_omit", "pe_q", "pe_noq", "se_q_polya_rspd"])
+def test_rsem_run_em_binary_input_equals_text_input(name, tmp_path):
+    """imdName.rsb/ (rsem-parse-alignments --binary, host/rsb.hpp) instead of .dat + read files: same rounds, same theta
+    bits-for-tolerance, same model, same .ofg -- and the text files are really not read (they are deleted)."""
+    conv = os.path.join(ROOT, "tools", "bin", "temp_to_rsb")
+    if not os.path.exists(conv):
+        pytest.skip("tools/bin/temp_to_rsb not built")
+    fx, dst = _stage(name, tmp_path)
+    meta = rf.read_meta(fx)
+    rt = str(meta["model_type"])
+    args = [os.path.join(dst, "ref"), rt, os.path.join(dst, "s"), os.path.join(dst, "temp", "s"), os.path.join(dst, "stat", "s"), "--gibbs-out"]
+    out_t = _run([os.path.join(BIN, "rsem-run-em")] + args)
+    keep = {}
+    for f in ("stat/s.theta", "stat/s.model", "temp/s.ofg", "temp/s.iso_res"):
+        keep[f] = open(os.path.join(dst, f)).read()
+    _run([conv, os.path.join(dst, "temp", "s"), os.path.join(dst, "stat", "s"), rt])
+    for f in os.listdir(os.path.join(dst, "temp")):
+        if f == "s.dat" or f.endswith((".fq", ".fa")):
+            os.remove(os.path.join(dst, "temp", f))
+    out_b = _run([os.path.join(BIN, "rsem-run-em")] + args)
+    lt = [l for l in out_t.split("\n") if l.startswith("ROUND")]
+    lb = [l for l in out_b.split("\n") if l.startswith("ROUND")]
+    assert len(lt) == len(lb) and lt[:11] == lb[:11]
+    ta, tb = rf.read_theta(os.path.join(dst, "stat", "s.theta")), None
+    open(os.path.join(dst, "stat", "t.theta"), "w").write(keep["stat/s.theta"])
+    tb = rf.read_theta(os.path.join(dst, "stat", "t.theta"))
+    assert np.allclose(ta[0], tb[0], rtol=1e-9, atol=1e-15) and np.allclose(ta[1], tb[1], rtol=1e-9, atol=1e-15)
+    assert open(os.path.join(dst, "stat", "s.model")).read().split() [:50] == keep["stat/s.model"].split()[:50]
+    assert len(open(os.path.join(dst, "temp", "s.ofg")).read()) == len(keep["temp/s.ofg"])
+
+
 def _bam_records(path):
     """Decompress a BAM (BGZF = concatenated gzip members) and split it into (header bytes, [record bytes])."""
     import gzip

@@ -252,3 +252,56 @@ def test_parse_more_error_paths(tmp_path):
     r = subprocess.run([NEW, "x"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode != 0 and "Usage" in r.stdout
     assert body0 > 0
+
+
+BIN_VARIANTS = [("se_q", 1, "aln.sam", ()), ("se_q", 0, "aln.sam", ()), ("pe_q", 3, "aln.sam", ("--wave-bytes", "5000", "-p", "7")),
+                ("pe_q", 2, "golden.transcript.bam", ()), ("pe_q", 3, "tagged", ("-tag", "ZT"))]
+
+
+@pytest.mark.parametrize("name,read_type,aln,extra", BIN_VARIANTS)
+def test_binary_handoff_equals_the_text_files(name, read_type, aln, extra, tmp_path):
+    """--binary: imdName.rsb/ holds, as arrays, exactly what the text files hold.  Checked by
+    converting the parser's own text output with tools/temp_to_rsb (which goes through the text READERS of rsem-run-em):
+    every file of the two directories must be byte-identical.  --binary alone writes no .dat / read files, --binary
+    --text writes both, .cnt / .omit are always there and identical."""
+    _need_new()
+    conv = os.path.join(ROOT, "tools", "bin", "temp_to_rsb")
+    if not os.path.exists(conv):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", conv, os.path.join(ROOT, "tools", "temp_to_rsb.cpp")])
+    fx = os.path.join(GOLD, name)
+    src = os.path.join(fx, aln)
+    if aln == "tagged":
+        src = str(tmp_path / "tagged.sam")
+        _tagged_sam(os.path.join(fx, "aln.sam"), src, read_type >= 2)
+    t, b, both = str(tmp_path / "text"), str(tmp_path / "bin"), str(tmp_path / "both")
+    for d, fl in ((t, ()), (b, ("--binary",)), (both, ("--binary", "--text"))):
+        r = _run(NEW, os.path.join(fx, "ref"), d, src, read_type, tuple(extra) + fl)
+        assert r.returncode == 0, r.stderr
+    assert not os.path.exists(os.path.join(t, "temp", "s.rsb"))
+    assert sorted(os.listdir(os.path.join(b, "temp"))) == ["s.omit", "s.rsb"]  # no .dat, no read files
+    for f in ("temp/s.omit", "stat/s.cnt"):
+        assert filecmp.cmp(os.path.join(t, f), os.path.join(b, f), shallow=False), f
+    # --text keeps the reference's files next to the binary ones
+    for f in _files(t):
+        assert filecmp.cmp(os.path.join(t, f), os.path.join(both, f), shallow=False), f
+    # the conversion of the text output = the binary output
+    subprocess.check_call([conv, os.path.join(t, "temp", "s"), os.path.join(t, "stat", "s"), str(read_type)], stdout=subprocess.DEVNULL)
+    ra, rb = os.path.join(t, "temp", "s.rsb"), os.path.join(b, "temp", "s.rsb")
+    assert sorted(os.listdir(ra)) == sorted(os.listdir(rb)) and "hdr" in os.listdir(rb)
+    for f in os.listdir(ra):
+        assert filecmp.cmp(os.path.join(ra, f), os.path.join(rb, f), shallow=False), f
+    for f in os.listdir(ra):
+        assert filecmp.cmp(os.path.join(ra, f), os.path.join(both, "temp", "s.rsb", f), shallow=False), f
+
+
+def test_binary_handoff_via_environment(tmp_path):
+    """The Perl driver builds the parser's command line; RSEM_HIP_BINARY switches the hand-off without touching it."""
+    _need_new()
+    fx = os.path.join(GOLD, "se_q")
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "temp")); os.makedirs(os.path.join(d, "stat"))
+    cmd = [NEW, os.path.join(fx, "ref"), os.path.join(d, "temp", "s"), os.path.join(d, "stat", "s"), os.path.join(fx, "aln.sam"), "1", "-q"]
+    subprocess.check_call(cmd, env=dict(os.environ, RSEM_HIP_BINARY="1"))
+    assert os.path.exists(os.path.join(d, "temp", "s.rsb", "hdr")) and not os.path.exists(os.path.join(d, "temp", "s.dat"))
+    subprocess.check_call(cmd, env=dict(os.environ, RSEM_HIP_BINARY="both"))
+    assert os.path.exists(os.path.join(d, "temp", "s.rsb", "hdr")) and os.path.exists(os.path.join(d, "temp", "s.dat"))
