@@ -27,7 +27,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MIN_TIMED_S = 0.5
-WORKLOADS = {"C2": "BASELINE configs[1] (SingleQModel-shaped)", "C3": "BASELINE configs[2] (PairedEndQModel-shaped, the north-star target config)",
+WORKLOADS = {"C2R": "configs[1]'s size with NO gene structure (every read hits random transcripts: worst case for tuple re-use and the LDS window)",
+             "C2": "BASELINE configs[1] (SingleQModel-shaped)", "C3": "BASELINE configs[2] (PairedEndQModel-shaped, the north-star target config)",
              "C5": "BASELINE configs[4] (multi-mapping stress)"}
 
 
@@ -200,7 +201,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--legs", default="C2", help="extra single-GPU E-step legs on other configs (comma list, '' for none)")
+    ap.add_argument("--legs", default="C2,C2R", help="extra single-GPU E-step legs on other configs (comma list, '' for none)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

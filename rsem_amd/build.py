@@ -60,7 +60,7 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError("compile failed: " + " ".join(cmd))
     if force or _stale(LIB, objs):
-        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

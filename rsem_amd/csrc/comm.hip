@@ -4,17 +4,56 @@
 // (EM.cpp:385-389) and the sum of the per-chain Gibbs accumulators in release() (Gibbs.cpp:372-388).  Here the
 // shards / chains live on different GPUs, so the sums are RCCL collectives over xGMI, enqueued on the stream the
 // kernels run on (no host round trip inside the EM loop).
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <condition_variable>
 #include <cstdlib>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "comm_internal.hpp"
 
 namespace {
+
+// librccl.so is half a gigabyte of code objects: it is loaded when the first communicator is asked for, not with
+// librsem_hip.so (single-GPU runs never pay for it).  Inside a process that already holds RCCL (bench.py: torch) the
+// same library instance is found by its soname.
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+Rccl* rccl() {
+    static std::mutex mu;
+    static Rccl R;
+    std::lock_guard<std::mutex> lk(mu);
+    if (R.lib || !R.error.empty()) return &R;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        R.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (R.lib) break;
+    }
+    if (!R.lib) { R.error = std::string("cannot load librccl.so: ") + dlerror(); return &R; }
+#define SYM(field, sym)                                                        \
+    R.field = reinterpret_cast<decltype(R.field)>(dlsym(R.lib, sym));            \
+    if (!R.field) { R.error = std::string("librccl.so lacks ") + sym; R.lib = nullptr; return &R; }
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(Reduce, "ncclReduce")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    return &R;
+}
 
 struct LocalGroup {  // ranks of one process, possibly on the same device
     int world = 0;
@@ -59,13 +98,20 @@ struct rsem_comm {
     double** d_ptrs = nullptr;    // LOCAL: device copy of the peers' buffer pointers
 };
 
-#define RSEM_NCCL_TRY(expr)                                                                              \
-    do {                                                                                                 \
-        ncclResult_t _r = (expr);                                                                        \
-        if (_r != ncclSuccess) {                                                                         \
-            rsem::set_last_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r));  \
-            return RSEM_ERR_HIP;                                                                         \
-        }                                                                                                \
+#define RSEM_NCCL_TRY(expr)                                                                                  \
+    do {                                                                                                     \
+        ncclResult_t _r = (expr);                                                                            \
+        if (_r != ncclSuccess) {                                                                             \
+            rsem::set_last_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, rccl()->GetErrorString(_r));  \
+            return RSEM_ERR_HIP;                                                                             \
+        }                                                                                                    \
+    } while (0)
+#define RSEM_NEED_RCCL()                                                       \
+    do {                                                                       \
+        if (!rccl()->lib) {                                                    \
+            rsem::set_last_error("%s", rccl()->error.c_str());                 \
+            return RSEM_ERR_HIP;                                               \
+        }                                                                      \
     } while (0)
 
 namespace rsem {
@@ -114,14 +160,14 @@ bool comm_active(const rsem_comm* c) { return !skip_single(c); }
 int comm_allreduce_sum_f64(rsem_comm* c, double* d_buf, size_t n, hipStream_t st) {
     if (skip_single(c)) return RSEM_OK;
     if (c->kind == 1) return local_exchange(c, d_buf, n, st, true, 0);
-    RSEM_NCCL_TRY(ncclAllReduce(d_buf, d_buf, n, ncclDouble, ncclSum, c->nccl, st));
+    RSEM_NCCL_TRY(rccl()->AllReduce(d_buf, d_buf, n, ncclDouble, ncclSum, c->nccl, st));
     return RSEM_OK;
 }
 
 int comm_reduce_sum_f64(rsem_comm* c, double* d_buf, size_t n, int root, hipStream_t st) {
     if (skip_single(c)) return RSEM_OK;
     if (c->kind == 1) return local_exchange(c, d_buf, n, st, false, root);
-    RSEM_NCCL_TRY(ncclReduce(d_buf, d_buf, n, ncclDouble, ncclSum, root, c->nccl, st));
+    RSEM_NCCL_TRY(rccl()->Reduce(d_buf, d_buf, n, ncclDouble, ncclSum, root, c->nccl, st));
     return RSEM_OK;
 }
 
@@ -132,8 +178,9 @@ extern "C" {
 int rsem_comm_unique_id(char* id) {
     RSEM_REQUIRE(id != nullptr, "id is NULL");
     static_assert(sizeof(ncclUniqueId) <= RSEM_COMM_ID_BYTES, "RSEM_COMM_ID_BYTES too small for ncclUniqueId");
+    RSEM_NEED_RCCL();
     ncclUniqueId u;
-    RSEM_NCCL_TRY(ncclGetUniqueId(&u));
+    RSEM_NCCL_TRY(rccl()->GetUniqueId(&u));
     memset(id, 0, RSEM_COMM_ID_BYTES);
     memcpy(id, &u, sizeof(u));
     return RSEM_OK;
@@ -149,6 +196,7 @@ int rsem_comm_create(rsem_comm** out, int device, int rank, int world, const cha
         rsem::set_last_error("no HIP device %d (have %d)", device, ndev);
         return RSEM_ERR_NODEVICE;
     }
+    RSEM_NEED_RCCL();
     RSEM_HIP_TRY(hipSetDevice(device));
     rsem_comm* c = new (std::nothrow) rsem_comm();
     if (!c) return RSEM_ERR_NOMEM;
@@ -158,9 +206,9 @@ int rsem_comm_create(rsem_comm** out, int device, int rank, int world, const cha
     c->device = device;
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
-    ncclResult_t r = ncclCommInitRank(&c->nccl, world, u, rank);
+    ncclResult_t r = rccl()->CommInitRank(&c->nccl, world, u, rank);
     if (r != ncclSuccess) {
-        rsem::set_last_error("ncclCommInitRank(rank %d of %d, device %d): %s", rank, world, device, ncclGetErrorString(r));
+        rsem::set_last_error("ncclCommInitRank(rank %d of %d, device %d): %s", rank, world, device, rccl()->GetErrorString(r));
         delete c;
         return RSEM_ERR_HIP;
     }
@@ -224,7 +272,7 @@ int rsem_comm_destroy(rsem_comm* c) {
     if (!c) return RSEM_OK;
     (void)hipSetDevice(c->device);
     if (c->kind == 0) {
-        if (c->nccl) (void)ncclCommDestroy(c->nccl);
+        if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
     } else {
         (void)hipFree(c->d_scratch);
         (void)hipFree(c->d_ptrs);

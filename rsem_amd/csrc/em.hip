@@ -31,6 +31,7 @@
 
 #include "comm_internal.hpp"
 #include "em_internal.hpp"
+#include "upload.hpp"
 #include "sell_layout.hpp"
 
 namespace {
@@ -933,11 +934,12 @@ int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64
     TRY_OR_FAIL(dmalloc(&c->d_sid, nnz));
     TRY_OR_FAIL(dmalloc(&c->d_cp, nnz));
     TRY_OR_FAIL(dmalloc(&c->d_ncp, N1));
-    TRY_OR_FAIL(hipMemcpyAsync(c->d_row_ptr, row_ptr, sizeof(uint64_t) * (N1 + 1), hipMemcpyHostToDevice, c->stream));
-    if (nnz) TRY_OR_FAIL(hipMemcpyAsync(c->d_sid, sid, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, c->stream));
+    // the big arrays go through pinned staging (upload.hpp)
+    if ((rc = rsem::staged_h2d(c->d_row_ptr, row_ptr, sizeof(uint64_t) * (N1 + 1), c->stream)) != RSEM_OK) return fail(rc);
+    if ((rc = rsem::staged_h2d(c->d_sid, sid, sizeof(int32_t) * nnz, c->stream)) != RSEM_OK) return fail(rc);
     if (conprb) {
-        if (nnz) TRY_OR_FAIL(hipMemcpyAsync(c->d_cp, conprb, sizeof(double) * nnz, hipMemcpyHostToDevice, c->stream));
-        if (N1) TRY_OR_FAIL(hipMemcpyAsync(c->d_ncp, ncp, sizeof(double) * N1, hipMemcpyHostToDevice, c->stream));
+        if ((rc = rsem::staged_h2d(c->d_cp, conprb, sizeof(double) * nnz, c->stream)) != RSEM_OK) return fail(rc);
+        if ((rc = rsem::staged_h2d(c->d_ncp, ncp, sizeof(double) * N1, c->stream)) != RSEM_OK) return fail(rc);
         c->have_values = true;
     }
     for (int i = 0; i < 2; i++) TRY_OR_FAIL(dmalloc(&c->d_theta[i], (size_t)M + 1));
@@ -960,6 +962,7 @@ int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64
     rc = build_layout(c);
     if (rc != RSEM_OK) return fail(rc);
     set_grid_for_kernel(c);
+    rsem::thread_stager().release();
 #undef TRY_OR_FAIL
     *out = c;
     return RSEM_OK;

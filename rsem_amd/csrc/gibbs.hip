@@ -408,6 +408,7 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
         const int nr = __popcll(__ballot(fits));
         if (nr == 0) {
             // one read with more items than the tile holds: lane 0 walks it over global memory (two passes)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // earlier tiles' count updates
             if (lane == 0) {
                 const uint64_t fr = base, to = t_rp[1];
                 const uint64_t len = to - fr;
@@ -464,6 +465,9 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
                 p8[u] = j < T ? cp[base + j] : 0.0;
             }
             if (!kInit) {
+                // the previous tile's count updates (device atomics, not waited for there) are in L2 before these loads
+                // are issued; their latency overlapped this tile's row-pointer / item loads
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const uint32_t j = j0 + u * 64 + lane;
@@ -503,15 +507,31 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
         __syncthreads();  // tile staged
         const uint32_t fr = mine ? (uint32_t)(t_rp[lane] - base) : 0;
         const int len = mine ? (int)(t_rp[lane + 1] - t_rp[lane]) : 0;
-        // smallest / largest transcript id of the read (noise, id 0, apart): the commit loop's membership filter
-        int lo = 0x7fffffff, hi = -1;
-        bool has_noise = false;
+        // Which transcripts does this read hold?  The commit loop asks that for every committed (z_old, z_new) pair, so the
+        // answer must not cost a walk over the items: a 64-bit set of the ids relative to the read's first one (isoforms
+        // of a gene are neighbours in id space), exact; reads spanning more than that fall back to their id range
+        // (conservative: a false hit only costs a redraw).  Noise (id 0) apart.
+        int lo = 0x7fffffff, hi = -1, ref = -1;
+        unsigned long long present = 0;
+        bool has_noise = false, wide = false;
         for (int k = 0; k < len; k++) {
             const int s = t_sid[fr + k];
             if (s == 0) has_noise = true;
-            else { lo = min(lo, s); hi = max(hi, s); }
+            else {
+                lo = min(lo, s); hi = max(hi, s);
+                if (ref < 0) ref = s - 32;
+                const unsigned b = (unsigned)(s - ref);
+                if (b < 64u) present |= 1ull << b;
+                else wide = true;
+            }
             if (!kInit && s == z_old) t_c[fr + k] -= 1;  // the read leaves its current transcript (Gibbs.cpp:298)
         }
+        auto holds = [&](int zz) -> bool {
+            if (zz == 0) return has_noise;
+            if (wide) return zz >= lo && zz <= hi;
+            const unsigned b = (unsigned)(zz - ref);
+            return b < 64u && ((present >> b) & 1ull);
+        };
         int z_new = (mine && !(dbg & 2)) ? draw(fr, len, rnd) : z_old;
         if (!kInit) {
             unsigned long long changed = __ballot(mine && z_new != z_old);
@@ -525,9 +545,7 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
                 // later reads see counts[zo] - 1 and counts[zn] + 1
                 bool hit = false;
                 if (mine && lane > r1) {
-                    const bool in_o = (zo == 0) ? has_noise : (zo >= lo && zo <= hi);
-                    const bool in_n = (zn == 0) ? has_noise : (zn >= lo && zn <= hi);
-                    if (in_o || in_n) {
+                    if (holds(zo) || holds(zn)) {
                         for (int k = 0; k < len; k++) {
                             const int s = t_sid[fr + k];
                             const int d = (s == zn ? 1 : 0) - (s == zo ? 1 : 0);
@@ -551,8 +569,7 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
             __hip_atomic_fetch_add(&counts[z_new], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             z[i0 + lane] = z_new;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the updates are in L2 before the next tile reads the counts
-        i0 += (uint64_t)nr;
+        i0 += (uint64_t)nr;  // (the count updates are waited for where the next tile reads the counts)
     }
     __syncthreads();
     for (int i = lane; i < 624; i += 64) mt_state->mt[i] = mt[i];

@@ -18,7 +18,10 @@
 #include <thread>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "em_internal.hpp"
+#include "upload.hpp"
 
 namespace {
 
@@ -369,8 +372,34 @@ hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, (n ? n : 1) * 
 template <typename T>
 int upload(T** d, const T* h, size_t n, hipStream_t st) {
     RSEM_HIP_TRY(dmalloc(d, n));
-    if (n) RSEM_HIP_TRY(hipMemcpyAsync(*d, h, sizeof(T) * n, hipMemcpyHostToDevice, st));
+    if (n) return rsem::staged_h2d(*d, h, sizeof(T) * n, st);
     return RSEM_OK;
+}
+
+// reads arrive as one byte per base, back to back (offsets `off`, relative to off[0]); the kernels want every read on a
+// 64-bit word boundary, 8 codes per word.  Lengths, word offsets (scan) and the repacking are done here on the device.
+__global__ void k_read_words(uint64_t N1, const uint64_t* __restrict__ off, uint64_t* nwords, int32_t* len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N1) return;
+    if (i == N1) { nwords[i] = 0; return; }
+    const uint64_t l = off[i + 1] - off[i];
+    len[i] = (int32_t)l;
+    nwords[i] = (l + 7) / 8;
+}
+
+__global__ void k_pack_reads(uint64_t N1, const uint64_t* __restrict__ off, const uint64_t* __restrict__ off8,
+                             const uint8_t* __restrict__ raw, uint64_t* words) {
+    // one wave per 64 reads would waste lanes on the short copy loops: thread per output word instead
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N1) return;
+    const uint64_t b0 = off[i] - off[0], l = off[i + 1] - off[i];
+    uint64_t* o = words + off8[i];
+    for (uint64_t w = 0; w * 8 < l; w++) {
+        uint64_t v = 0;
+        const uint64_t n = l - w * 8 < 8 ? l - w * 8 : 8;
+        for (uint64_t k = 0; k < n; k++) v |= (uint64_t)raw[b0 + w * 8 + k] << (8 * k);  // little-endian: byte k of the word
+        o[w] = v;
+    }
 }
 
 }  // namespace
@@ -480,33 +509,43 @@ int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_da
     UP(sid_signed, d->sid_signed, d->nnz);
     UP(pos, d->pos, d->nnz);
     if (pe) UP(insertL, d->insertL, d->nnz);
-    // reads: 8 codes per 64-bit word, every read on a word boundary (the kernels fetch 8 bases per load)
+    // reads: 8 codes per 64-bit word, every read on a word boundary (the kernels fetch 8 bases per load).  The bytes go
+    // up as they are (pinned staging, upload.hpp) and are repacked on the device.
     for (int m = 0; m < (pe ? 2 : 1); m++) {
-        std::vector<uint64_t> off8(d->N1 + 1, 0);
-        std::vector<int32_t> len(d->N1);
-        for (uint64_t i = 0; i < d->N1; i++) {
-            const uint64_t l = d->read_off[m][i + 1] - d->read_off[m][i];
-            len[i] = (int32_t)l;
-            off8[i + 1] = off8[i] + (l + 7) / 8;
+        const uint64_t b_lo = d->read_off[m][0], nbytes = d->read_off[m][d->N1] - b_lo;
+        uint64_t *d_off = nullptr, *d_nw = nullptr, *d_off8 = nullptr, *d_ws = nullptr, *d_wq = nullptr;
+        int32_t* d_len = nullptr;
+        uint8_t* d_raw = nullptr;
+        void* d_tmp = nullptr;
+        auto drop = [&]() { hipFree(d_off); hipFree(d_nw); hipFree(d_raw); hipFree(d_tmp); };
+        auto bail = [&](int code) { drop(); hipFree(d_off8); hipFree(d_len); hipFree(d_ws); hipFree(d_wq); rsem_model_destroy(c); return code; };
+        if ((rc = upload(&d_off, d->read_off[m], (size_t)d->N1 + 1, st)) != RSEM_OK) return bail(rc);
+        if (dmalloc(&d_nw, (size_t)d->N1 + 1) != hipSuccess || dmalloc(&d_off8, (size_t)d->N1 + 1) != hipSuccess ||
+            dmalloc(&d_len, (size_t)d->N1) != hipSuccess || dmalloc(&d_raw, (size_t)nbytes) != hipSuccess)
+            return bail(RSEM_ERR_NOMEM);
+        hipLaunchKernelGGL(k_read_words, dim3(rsem::ceil_div(d->N1 + 1, kBlk)), dim3(kBlk), 0, st, d->N1, d_off, d_nw, d_len);
+        size_t tb = 0;
+        if (hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_nw, d_off8, d->N1 + 1, st) != hipSuccess || hipMalloc(&d_tmp, tb ? tb : 1) != hipSuccess ||
+            hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_nw, d_off8, d->N1 + 1, st) != hipSuccess)
+            return bail(RSEM_ERR_HIP);
+        uint64_t nw = 0;
+        if (hipMemcpyAsync(&nw, d_off8 + d->N1, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return bail(RSEM_ERR_HIP);
+        nw += 1;  // one spare word: the last read's 8-byte fetches may look one word ahead
+        for (int what = 0; what < (q ? 2 : 1); what++) {
+            uint64_t*& d_w = what ? d_wq : d_ws;
+            if (dmalloc(&d_w, (size_t)nw) != hipSuccess) return bail(RSEM_ERR_NOMEM);
+            if (hipMemsetAsync(d_w + (nw - 1), 0, sizeof(uint64_t), st) != hipSuccess) return bail(RSEM_ERR_HIP);
+            if ((rc = rsem::staged_h2d(d_raw, (what ? d->read_qual[m] : d->read_seq[m]) + b_lo, (size_t)nbytes, st)) != RSEM_OK) return bail(rc);
+            if (d->N1) hipLaunchKernelGGL(k_pack_reads, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, d->N1, d_off, d_off8, d_raw, d_w);
+            if (hipGetLastError() != hipSuccess) return bail(RSEM_ERR_HIP);
         }
-        const uint64_t nw = off8[d->N1] + 1;
-        std::vector<uint64_t> ws(nw, 0), wq(q ? nw : 0, 0);
-        const int nt = d->N1 > 100000 ? 32 : 1;
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; t++)
-            th.emplace_back([&, t]() {
-                const uint64_t lo = d->N1 * t / nt, hi = d->N1 * (t + 1) / nt;
-                for (uint64_t i = lo; i < hi; i++) {  // little-endian: packing 8 byte codes into a word is a memcpy
-                    memcpy(ws.data() + off8[i], d->read_seq[m] + d->read_off[m][i], (size_t)len[i]);
-                    if (q) memcpy(wq.data() + off8[i], d->read_qual[m] + d->read_off[m][i], (size_t)len[i]);
-                }
-            });
-        for (auto& x : th) x.join();
-        UP(roff8[m], off8.data(), d->N1 + 1);
-        UP(rlen[m], len.data(), d->N1);
-        UP(rseq_w[m], ws.data(), nw);
-        if (q) UP(rqual_w[m], wq.data(), nw);
-        if (hipStreamSynchronize(st) != hipSuccess) { rsem_model_destroy(c); return RSEM_ERR_HIP; }  // the vectors die here
+        if (hipStreamSynchronize(st) != hipSuccess) return bail(RSEM_ERR_HIP);
+        drop();
+        c->owned.push_back(d_off8); D.roff8[m] = d_off8;
+        c->owned.push_back(d_len); D.rlen[m] = d_len;
+        c->owned.push_back(d_ws); D.rseq_w[m] = d_ws;
+        if (q) { c->owned.push_back(d_wq); D.rqual_w[m] = d_wq; }
     }
     UP(lq, d->low_quality, d->N1);
     {   // both strands of every transcript (RefSeq::get_id, RefSeq.h:84-87), word-aligned starts, one spare word at the end
@@ -555,6 +594,7 @@ int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_da
     D.hit_row = hr;
     if (d->N1) hipLaunchKernelGGL(k_hit_rows, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, d->N1, D.row_ptr, hr);
     if (hipStreamSynchronize(st) != hipSuccess) { rsem_model_destroy(c); return RSEM_ERR_HIP; }
+    rsem::thread_stager().release();
     *out = c;
     return RSEM_OK;
 }

@@ -152,21 +152,23 @@ def test_rsem_run_gibbs_parallel_runs_and_is_close(tmp_path):
     assert np.all(np.abs(pme[big] - em_counts[big]) < 0.25 * em_counts[big] + 3)
 
 
-@pytest.mark.parametrize("read_type,n_reads", [(1, 40000), (3, 30000)])
-def test_generated_dataset_vs_reference_binary(read_type, n_reads, tmp_path):
+@pytest.mark.parametrize("read_type,n_reads,M,threads", [(1, 40000, 2000, 4), (3, 30000, 2000, 4), (3, 1_060_000, 20000, 64)])
+def test_generated_dataset_vs_reference_binary(read_type, n_reads, M, threads, tmp_path):
     """A fresh, larger synthetic .temp directory (tools/gen_temp.cpp): run the reference binary (oracle/_ref, shipped
-    to the GPU box) and the drop-in on the same files; same ROUND count, theta within 1e-6 relative."""
+    to the GPU box) and the drop-in on the same files; same ROUND count, theta within 1e-6 relative.  The last case is
+    paired-end at > 1 M pairs over 20 k transcripts: more transcripts than one LDS window holds (2048), several
+    workgroup units per shape -- the out-of-window and multi-unit paths against the REFERENCE, not only the oracle."""
     gen = os.path.join(ROOT, "tools", "bin", "gen_temp")
     ref_em = os.path.join(ROOT, "oracle", "_ref", "rsem-run-em")
     ref_idx = os.path.join(ROOT, "oracle", "_ref", "rsem-build-read-index")
     if not (os.path.exists(gen) and os.path.exists(ref_em) and os.path.exists(ref_idx)):
         pytest.skip("generator or reference binaries not built")
     d = str(tmp_path)
-    _run([gen, d, str(n_reads), "2000", str(read_type), "7", "75"])
+    _run([gen, d, str(n_reads), str(M), str(read_type), "7", "75"])
     reads = ["s_alignable.fq"] if read_type == 1 else ["s_alignable_1.fq", "s_alignable_2.fq"]
     _run([ref_idx, "32", "1", "1"] + [os.path.join(d, "temp", r) for r in reads])
     args = [os.path.join(d, "ref"), str(read_type), os.path.join(d, "s"), os.path.join(d, "temp", "s"), os.path.join(d, "stat", "s")]
-    out_ref = _run([ref_em] + args + ["-p", "4"])
+    out_ref = _run([ref_em] + args + ["-p", str(threads)])
     graw, gpol = rf.read_theta(os.path.join(d, "stat", "s.theta"))
     gres = rf.read_res(os.path.join(d, "temp", "s.iso_res"))
     os.rename(os.path.join(d, "stat", "s.theta"), os.path.join(d, "stat", "ref.theta"))

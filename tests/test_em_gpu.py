@@ -184,3 +184,67 @@ def test_full_size_c2_properties():
     out2 = ctx.run(wl["theta0"], wl["N0"], min_round=30, max_round=30)
     assert np.allclose(out["theta"], out2["theta"], rtol=1e-9, atol=1e-18)
     ctx.close()
+
+
+def test_full_size_c3_step_vs_oracle():
+    """BASELINE configs[2] (the north-star config: 50 M reads, 200 k transcripts, 570 M alignments) at full size: one E + M
+    step against the oracle's single-thread restatement (EM.cpp:199-236, 385-413), 1e-9 per count."""
+    wl = make_em_workload("C3")
+    N1 = len(wl["row_ptr"]) - 1
+    ctx = capi().EmContext(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
+    counts, theta_new, s, b, t = ctx.step(wl["theta0"], wl["N0"])
+    oraw = orc.em_estep(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["theta0"])
+    oc, ot, os_, ob, otn = orc.em_mstep(wl["M"], wl["N0"], oraw, wl["theta0"])  # oc = counts incl. +N0 (EM.cpp:392)
+    assert np.allclose(counts, oc, rtol=1e-9, atol=1e-6)
+    assert abs(s - (wl["N0"] + N1)) < 1e-6 * N1 and abs(theta_new.sum() - 1.0) < 1e-12
+    assert np.allclose(theta_new, ot, rtol=1e-9, atol=1e-18) and t == otn
+    c2, _, _ = ctx.expected_weights(wl["theta0"], wl["N0"], want_weights=False)  # K5 counts = the E step's counts
+    assert np.allclose(c2, oc, rtol=1e-9, atol=1e-6)
+    ctx.close()
+
+
+def test_unstructured_tuples_all_variants():
+    """No gene structure at all (every read hits random transcripts): the lane kernel's tuple runs and LDS window give
+    nothing, every count goes through the out-of-window path -- results must not depend on that."""
+    wl = make_em_workload("tinyR", seed=4)
+    M = wl["M"]
+    oc = orc.em_estep(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["theta0"])
+    oc[0] += wl["N0"]
+    for v in VARIANTS:
+        ctx = capi().EmContext(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
+        ctx.set_option("kernel", v)
+        counts, *_ = ctx.step(wl["theta0"], wl["N0"])
+        assert np.allclose(counts, oc, rtol=1e-9, atol=1e-9), v
+        ctx.close()
+    wl = make_em_workload("C2R", scale=0.05)  # 500 k reads over 50 k transcripts: windows of 2048 ids cover 4 % of a unit's hits
+    ctx = capi().EmContext(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
+    out = ctx.run(wl["theta0"], wl["N0"], max_round=200)
+    oth, orounds, _, _ = orc.em_run(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["N0"], wl["theta0"], max_round=200)
+    assert out["rounds"] == orounds and np.allclose(out["theta"], oth, rtol=1e-6, atol=1e-12)
+    ctx.close()
+
+
+@pytest.mark.skipif(not os.environ.get("RSEM_TEST_XL"), reason="needs ~110 GB of host memory and 60 GB of HBM: set RSEM_TEST_XL=1")
+def test_more_than_2_to_32_alignments():
+    """4.4 G alignments in ONE shard (BASELINE configs[4] scale): every index past 2^32 (plane offsets of the sliced layout,
+    CSR offsets of the weights pass) must be 64-bit.  108 M reads x 41 alignments over 500 k transcripts with a cheap
+    closed-form structure; one step against the oracle."""
+    N1, L, M = 108_000_000, 41, 500_000
+    rp = (np.arange(N1 + 1, dtype=np.uint64) * np.uint64(L))
+    nnz = N1 * L
+    assert nnz > 2 ** 32
+    base = (np.arange(N1, dtype=np.int64) * 7919) % (M - L)
+    sid = (np.repeat(base, L) + np.tile(np.arange(L, dtype=np.int64), N1) + 1).astype(np.int32)
+    del base
+    rng = np.random.default_rng(1)
+    cp = rng.random(nnz) * 1e-20
+    ncp = np.full(N1, 1e-60)
+    theta = np.full(M + 1, 0.95 / M)
+    theta[0] = 0.05
+    ctx = capi().EmContext(M, rp, sid, cp, ncp)
+    counts, theta_new, s, b, t = ctx.step(theta, 1000.0)
+    ctx.close()
+    oc = orc.em_estep(M, rp, sid, cp, ncp, theta)
+    oc[0] += 1000.0
+    assert np.allclose(counts, oc, rtol=1e-9, atol=1e-6)
+    assert abs(s - (1000.0 + N1)) < 1.0

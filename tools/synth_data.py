@@ -15,6 +15,10 @@ CONFIGS = {
     "C2": (10_000_000, 50_000, 5.0, (4, 12)),
     "C3": (50_000_000, 200_000, 10.0, (8, 24)),
     "C5": (100_000_000, 500_000, 40.0, (32, 64)),
+    # worst case for the sliced layout: every read hits its own random transcripts all over the id space (no gene
+    # structure), so lanes almost never see the same tuple twice and a workgroup's LDS window covers nothing
+    "C2R": (10_000_000, 50_000, 5.0, None),
+    "tinyR": (20_000, 400, 5.0, None),
     "tiny": (20_000, 400, 5.0, (4, 12)),
     "small": (400_000, 5_000, 5.0, (4, 12)),
 }
@@ -23,9 +27,12 @@ CONFIGS = {
 def make_em_workload(config="C2", seed=20250925, scale=1.0, long_row_every=0, shard=0):
     """Returns dict(M, N0, row_ptr u64, sid i32, conprb f64, ncp f64, theta0 f64).
     `shard` re-draws the reads (not the transcriptome): shard r of a weak-scaling job."""
-    N1, M, mean_hits, (kmin, kmax) = CONFIGS[config]
+    N1, M, mean_hits, ksz = CONFIGS[config]
     N1 = max(1, int(N1 * scale))
     rng = np.random.default_rng(seed)
+    if ksz is None:
+        return _make_unstructured(config, seed, N1, M, mean_hits, shard)
+    kmin, kmax = ksz
     # genes
     sizes = []
     tot = 0
@@ -111,6 +118,23 @@ def make_em_workload(config="C2", seed=20250925, scale=1.0, long_row_every=0, sh
     theta0[0] = 0.05
     return dict(M=M, N0=N0, row_ptr=row_ptr, sid=np.ascontiguousarray(sid, np.int32),
                 conprb=np.ascontiguousarray(conprb), ncp=ncp, theta0=theta0, config=config, seed=seed)
+
+
+def _make_unstructured(config, seed, N1, M, mean_hits, shard):
+    rng = np.random.default_rng([seed, 77, shard])
+    lens = np.clip(1 + rng.poisson(mean_hits - 1.0, N1), 1, 16).astype(np.int64)
+    row_ptr = np.zeros(N1 + 1, np.uint64)
+    row_ptr[1:] = np.cumsum(lens)
+    nnz = int(row_ptr[-1])
+    sid = rng.integers(1, M + 1, nnz, dtype=np.int32)
+    rows = np.repeat(np.arange(N1), lens)
+    e_row = rng.uniform(-60.0, -3.0, N1)
+    conprb = np.power(10.0, e_row[rows] + rng.normal(0.0, 0.5, nnz))
+    ncp = np.power(10.0, rng.uniform(-130.0, -40.0, N1))
+    N0 = int(round(0.05 * N1 / 0.95))
+    theta0 = np.full(M + 1, (1.0 - 0.05) / M)
+    theta0[0] = 0.05
+    return dict(M=M, N0=N0, row_ptr=row_ptr, sid=sid, conprb=np.ascontiguousarray(conprb), ncp=ncp, theta0=theta0, config=config, seed=seed)
 
 
 def to_gibbs_items(wl):
