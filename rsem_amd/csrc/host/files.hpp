@@ -332,9 +332,9 @@ inline void calc_expression(int M, const std::vector<double>& theta, const std::
 struct OfgData {  // imd.ofg (EM.cpp:435-457): items CSR incl. the noise column
     int M = 0;
     uint64_t N0 = 0;
-    std::vector<uint64_t> row_ptr;
-    std::vector<int32_t> sid;
-    std::vector<double> conprb;
+    Arr<uint64_t> row_ptr;
+    Arr<int32_t> sid;
+    Arr<double> conprb;
 };
 
 inline OfgData load_ofg(const std::string& path) {
@@ -377,12 +377,22 @@ inline OfgData load_ofg(const std::string& path) {
             q = le + 1;
         }
     });
-    D.row_ptr.push_back(0);
-    for (auto& P : parts) {
-        for (uint32_t n : P.lens) D.row_ptr.push_back(D.row_ptr.back() + n);
-        D.sid.insert(D.sid.end(), P.sid.begin(), P.sid.end());
-        D.conprb.insert(D.conprb.end(), P.val.begin(), P.val.end());
-    }
+    std::vector<uint64_t> r0(nc + 1, 0), h0(nc + 1, 0);
+    for (int c = 0; c < nc; c++) { r0[c + 1] = r0[c] + parts[c].lens.size(); h0[c + 1] = h0[c] + parts[c].sid.size(); }
+    uint64_t* rp = D.row_ptr.alloc(r0[nc] + 1);
+    int32_t* sp = D.sid.alloc(h0[nc]);
+    double* vp = D.conprb.alloc(h0[nc]);
+    rp[r0[nc]] = h0[nc];
+    parallel_for(nc, [&](int c) {  // the chunks' pieces go to their final places in parallel
+        Part& P = parts[c];
+        uint64_t o = h0[c];
+        for (size_t i = 0; i < P.lens.size(); i++) { rp[r0[c] + i] = o; o += P.lens[i]; }
+        if (!P.sid.empty()) {
+            memcpy(sp + h0[c], P.sid.data(), sizeof(int32_t) * P.sid.size());
+            memcpy(vp + h0[c], P.val.data(), sizeof(double) * P.val.size());
+        }
+        P = Part();
+    });
     return D;
 }
 

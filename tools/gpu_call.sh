@@ -14,6 +14,7 @@ for step in "$@"; do
     bench) timeout 1500 python bench.py $arg > $out/bench.json 2> $out/bench.err; tail -5 $out/bench.err; cut -c1-3000 $out/bench.json ;;
     prof)  IFS=: read -r ptag pcfgs <<< "$arg"; timeout 1500 tools/profile_round.sh ${ptag:-rXX} "${pcfgs:-C3 C2}" > $out/profile.log 2>&1; tail -60 $out/profile.log ;;
     e2e)   IFS=: read -r n m sub <<< "$arg"; timeout 2400 tools/e2e_c3.sh ${n:-50000000} ${m:-200000} ${sub:-10} > $out/e2e_c3.log 2>&1; cat $out/e2e_c3.log ;;
+    c4)    IFS=: read -r n m pp <<< "$arg"; timeout 2400 tools/e2e_c4.sh ${n:-50000000} ${m:-200000} ${pp:-8} > $out/e2e_c4.log 2>&1; cat $out/e2e_c4.log ;;
     cmd)   timeout 1500 bash -c "$arg" > $out/cmd.log 2>&1; tail -40 $out/cmd.log ;;
   esac
   echo "== step $step: $(( $(date +%s) - t0 )) s"
