@@ -442,16 +442,6 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
             i0 += 1;
             continue;
         }
-        {   // prefetch for the tile that starts at i0 + nr
-            const uint64_t nxt = i0 + (uint64_t)nr;
-            pf_i0 = nxt;
-            if (nxt < N1) {
-                const int nrn = (int)min((uint64_t)kTileRows, N1 - nxt);
-                pf_rp = row_ptr[nxt + min(lane, nrn)];
-                pf_rp_last = row_ptr[nxt + nrn];
-                if (!kInit) pf_z = (lane < nrn) ? z[nxt + lane] : 0;
-            }
-        }
         const uint32_t T = (uint32_t)(t_rp[nr] - base);
         // items of the tile: coalesced loads, eight in flight per lane; the counts as they are now (L2 copy: the
         // updates below are device atomics)
@@ -488,6 +478,16 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
                 }
             }
         }
+        {   // prefetch for the tile that starts at i0 + nr (issued after the count loads: their wait must not cover it)
+            const uint64_t nxt = i0 + (uint64_t)nr;
+            pf_i0 = nxt;
+            if (nxt < N1) {
+                const int nrn = (int)min((uint64_t)kTileRows, N1 - nxt);
+                pf_rp = row_ptr[nxt + min(lane, nrn)];
+                pf_rp_last = row_ptr[nxt + nrn];
+                if (!kInit) pf_z = (lane < nrn) ? z[nxt + lane] : 0;
+            }
+        }
         const bool mine = lane < nr;
         // the next nr MT19937 outputs, read r of the tile takes the r-th (= the order the sequential chain draws them)
         uint32_t rnd = 0;
@@ -511,15 +511,15 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
         // answer must not cost a walk over the items: a 64-bit set of the ids relative to the read's first one (isoforms
         // of a gene are neighbours in id space), exact; reads spanning more than that fall back to their id range
         // (conservative: a false hit only costs a redraw).  Noise (id 0) apart.
-        int lo = 0x7fffffff, hi = -1, ref = -1;
+        int lo = 0x7fffffff, hi = -1, ref = 0;
         unsigned long long present = 0;
-        bool has_noise = false, wide = false;
+        bool has_noise = false, wide = false, have_ref = false;
         for (int k = 0; k < len; k++) {
             const int s = t_sid[fr + k];
             if (s == 0) has_noise = true;
             else {
                 lo = min(lo, s); hi = max(hi, s);
-                if (ref < 0) ref = s - 32;
+                if (!have_ref) { ref = s - 32; have_ref = true; }
                 const unsigned b = (unsigned)(s - ref);
                 if (b < 64u) present |= 1ull << b;
                 else wide = true;

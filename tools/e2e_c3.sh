@@ -27,6 +27,19 @@ grep -E "^\[timing\]" $DF/new.log; grep ROUND $DF/new.log | tail -1
 python - <<PY
 print("theta_sum_full %.12f" % sum(float(x) for x in open("$DF/stat/s.theta").read().split("\n")[1].split()))
 PY
+cp $DF/stat/s.theta $DS/full_text.theta
+echo "== drop-in, full size, binary hand-off (imdName.rsb/ = what rsem-parse-alignments --binary writes; conversion not timed)"
+t=$(now); tools/bin/temp_to_rsb $DF/temp/s $DF/stat/s 3; echo "to_rsb_s $(el $t)"
+rm -f $DF/temp/s.dat $DF/temp/*.fq
+t=$(now)
+rsem_amd/bin/rsem-run-em $DF/ref 3 $DF/s $DF/temp/s $DF/stat/s -p $P > $DF/new_rsb.log 2>&1; echo "new_full_rsb_rc $? new_full_rsb_s $(el $t)"
+grep -E "^\[timing\]" $DF/new_rsb.log; grep ROUND $DF/new_rsb.log | tail -1
+python - <<PY
+import numpy as np
+a=np.array(open("$DF/stat/s.theta").read().split("\n")[1].split(),float); b=np.array(open("$DS/full_text.theta").read().split("\n")[1].split(),float)
+m=b>=1e-7
+print("theta_max_rel_diff_rsb_vs_text_full %.3g" % np.max(np.abs(a[m]-b[m])/b[m]))
+PY
 rm -rf $DF
 echo "== reference -p $P, 1/$SUB size (alone on the host)"
 ( t=$(now); oracle/_ref/rsem-run-em $DS/ref 3 $DS/s $DS/temp/s $DS/stat/s -p $P > $DS/ref.log 2>&1; echo "ref_sub_rc $? ref_sub_s $(el $t)" > $DS/ref.time ) &
