@@ -285,6 +285,7 @@ __global__ void k_sample_z_long(uint32_t n_rows, const uint32_t* __restrict__ ro
 
 constexpr int kTileRows = 64;
 constexpr int kTileItems = 2048;
+constexpr int kHeldSlots = 1024;
 
 struct MtState { uint32_t mt[624]; int idx; };
 
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
     __shared__ double t_p[kTileItems];
     __shared__ int32_t t_c[kTileItems];
     __shared__ double t_al[kTileItems];
+    __shared__ int32_t t_held[kHeldSlots];  // how many items of the tile carry a transcript id (hashed): the commit filter
     const int lane = threadIdx.x;
     for (int i = lane; i < 624; i += 64) mt[i] = mt_state->mt[i];
     int idx = mt_state->idx;  // wave-uniform
@@ -443,6 +445,10 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
             continue;
         }
         const uint32_t T = (uint32_t)(t_rp[nr] - base);
+        if (!kInit) {
+#pragma unroll
+            for (int u = 0; u < kHeldSlots / 64; u++) t_held[u * 64 + lane] = 0;
+        }
         // items of the tile: coalesced loads, eight in flight per lane; the counts as they are now (L2 copy: the
         // updates below are device atomics)
         for (uint32_t j0 = 0; j0 < T; j0 += 64 * 8) {
@@ -524,18 +530,30 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
                 if (b < 64u) present |= 1ull << b;
                 else wide = true;
             }
-            if (!kInit && s == z_old) t_c[fr + k] -= 1;  // the read leaves its current transcript (Gibbs.cpp:298)
+            if (!kInit) {
+                if (s == z_old) t_c[fr + k] -= 1;  // the read leaves its current transcript (Gibbs.cpp:298)
+                atomicAdd(&t_held[s & (kHeldSlots - 1)], 1);
+            }
         }
-        auto holds = [&](int zz) -> bool {
-            if (zz == 0) return has_noise;
-            if (wide) return zz >= lo && zz <= hi;
+        auto holds = [&](int zz) -> bool {  // branch-free: this sits in the commit loop
             const unsigned b = (unsigned)(zz - ref);
-            return b < 64u && ((present >> b) & 1ull);
+            const bool bit = (b < 64u) & (((present >> (b & 63u)) & 1ull) != 0ull);
+            const bool rng = (zz >= lo) & (zz <= hi);
+            const bool tr = wide ? rng : bit;
+            return zz == 0 ? has_noise : tr;
         };
         int z_new = (mine && !(dbg & 2)) ? draw(fr, len, rnd) : z_old;
         if (!kInit) {
-            unsigned long long changed = __ballot(mine && z_new != z_old);
-            if (dbg & 4) n_changed += __popcll(changed);
+            __syncthreads();  // t_held complete
+            // a changed read needs a turn in the commit loop only if some OTHER item of the tile carries its old or its
+            // new transcript (the table counts the read's own items too, hence >= 2; hash collisions only add turns);
+            // everybody else's move concerns nobody in this tile
+            auto concerns_others = [&](int zo, int zn) -> bool {
+                return (t_held[zo & (kHeldSlots - 1)] >= 2) | (t_held[zn & (kHeldSlots - 1)] >= 2);
+            };
+            bool turn = mine && z_new != z_old && concerns_others(z_old, z_new);
+            unsigned long long changed = __ballot(turn);
+            if (dbg & 4) n_changed += __popcll(__ballot(mine && z_new != z_old));
             if (dbg & 1) changed = 0;
             while (changed) {
                 if (dbg & 4) ++n_iter;
@@ -543,21 +561,25 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
                 const int zo = __builtin_amdgcn_readlane(z_old, r1), zn = __builtin_amdgcn_readlane(z_new, r1);
                 changed &= ~(1ull << r1);
                 // later reads see counts[zo] - 1 and counts[zn] + 1
-                bool hit = false;
-                if (mine && lane > r1) {
-                    if (holds(zo) || holds(zn)) {
+                const bool cand = mine & (lane > r1) & (holds(zo) | holds(zn));
+                if (__ballot(cand)) {
+                    bool hit = false;
+                    if (cand) {
                         for (int k = 0; k < len; k++) {
                             const int s = t_sid[fr + k];
                             const int d = (s == zn ? 1 : 0) - (s == zo ? 1 : 0);
                             if (d != 0) { t_c[fr + k] += d; hit = true; }
                         }
                     }
-                }
-                if (__ballot(hit)) {
-                    if (dbg & 4) { ++n_redraw_events; n_redraw_lanes += __popcll(__ballot(hit)); }
-                    if (hit) z_new = draw(fr, len, rnd);
-                    const unsigned long long later = (r1 >= 63) ? 0ull : (~0ull << (r1 + 1));
-                    changed = __ballot(mine && z_new != z_old) & later;
+                    if (__ballot(hit)) {
+                        if (dbg & 4) { ++n_redraw_events; n_redraw_lanes += __popcll(__ballot(hit)); }
+                        if (hit) {
+                            z_new = draw(fr, len, rnd);
+                            turn = z_new != z_old && concerns_others(z_old, z_new);
+                        }
+                        const unsigned long long later = (r1 >= 63) ? 0ull : (~0ull << (r1 + 1));
+                        changed = __ballot(turn) & later;
+                    }
                 }
             }
             if (mine && z_new != z_old) {

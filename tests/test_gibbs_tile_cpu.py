@@ -29,7 +29,7 @@ class Mt:
         return int(self.L.orc_mt_next(self.buf))
 
 
-def tile_chain(M, rp, sid, cp, init, pseudoC, N0, seed, burnin, nsamples, gap, tile_rows=64, tile_items=2048):
+def tile_chain(M, rp, sid, cp, init, pseudoC, N0, seed, burnin, nsamples, gap, tile_rows=64, tile_items=2048, held_slots=1024):
     rp = rp.astype(np.int64)
     N1 = len(rp) - 1
     counts = init.astype(np.int64).copy()
@@ -79,7 +79,16 @@ def tile_chain(M, rp, sid, cp, init, pseudoC, N0, seed, burnin, nsamples, gap, t
                     counts[R["zn"]] += 1
                     z[i0 + r] = R["zn"]
             else:
-                changed = [r for r, R in enumerate(rows) if R["zn"] != R["zo"]]
+                # the kernel's commit filter: a changed read only takes a turn if another item of the tile carries its old
+                # or new transcript (hashed counts, the read's own items included, hence >= 2)
+                held = np.zeros(held_slots, np.int64)
+                for R in rows:
+                    np.add.at(held, R["s"] % held_slots, 1)
+
+                def turn(R):
+                    return R["zn"] != R["zo"] and (held[R["zo"] % held_slots] >= 2 or held[R["zn"] % held_slots] >= 2)
+
+                changed = [r for r, R in enumerate(rows) if turn(R)]
                 while changed:
                     r1 = changed.pop(0)
                     zo, zn = rows[r1]["zo"], rows[r1]["zn"]
@@ -89,7 +98,7 @@ def tile_chain(M, rp, sid, cp, init, pseudoC, N0, seed, burnin, nsamples, gap, t
                         if np.any(d != 0):
                             R["c"] += d
                             R["zn"] = draw(R["s"], R["p"], R["c"], R["rnd"], False)
-                    changed = [r for r in range(r1 + 1, nr) if rows[r]["zn"] != rows[r]["zo"]]
+                    changed = [r for r in range(r1 + 1, nr) if turn(rows[r])]
                 for r, R in enumerate(rows):
                     if R["zn"] != R["zo"]:
                         counts[R["zo"]] -= 1
@@ -119,9 +128,9 @@ def _items(n_reads, seed, long_row_every=0, dup=False):
     return wl["M"], to_gibbs_items(sub)
 
 
-@pytest.mark.parametrize("tile_rows,tile_items,long_every,dup", [(64, 2048, 0, False), (64, 40, 0, True), (5, 2048, 0, False),
-                                                                 (64, 300, 150, True)])
-def test_tile_schedule_is_the_sequential_chain(tile_rows, tile_items, long_every, dup):
+@pytest.mark.parametrize("tile_rows,tile_items,long_every,dup,held_slots", [(64, 2048, 0, False, 1024), (64, 40, 0, True, 1024), (5, 2048, 0, False, 16),
+                                                                            (64, 300, 150, True, 7), (64, 2048, 0, True, 1)])
+def test_tile_schedule_is_the_sequential_chain(tile_rows, tile_items, long_every, dup, held_slots):
     n = 700
     M, (irp, isid, icp) = _items(n, 11, long_row_every=long_every, dup=dup)
     init = np.zeros(M + 1, np.int32)
@@ -130,5 +139,5 @@ def test_tile_schedule_is_the_sequential_chain(tile_rows, tile_items, long_every
     totc = (M + 1) * pseudoC + N0 + n
     burnin, nsamples, gap = 2, 3, 2
     ocv, _ = orc.gibbs_chain(M, irp, isid, icp, init, None, pseudoC, totc, N0, eel, mw, grp, 4242, burnin, nsamples, gap)
-    tcv = tile_chain(M, irp, isid, icp, init, pseudoC, N0, 4242, burnin, nsamples, gap, tile_rows, tile_items)
+    tcv = tile_chain(M, irp, isid, icp, init, pseudoC, N0, 4242, burnin, nsamples, gap, tile_rows, tile_items, held_slots)
     assert np.array_equal(tcv, ocv)
