@@ -204,6 +204,41 @@ def test_parallel_posterior_means_within_sampling_tolerance(name):
     ctx.close()
 
 
+def test_parallel_sampler_is_no_further_from_long_chains_than_the_reference_setup():
+    """200 k reads x 5 k transcripts (tests/golden/make_gibbs_truth.py).  "Truth" = long collapsed chains (8 x (2000 + 500)
+    sweeps of the oracle's restatement of Gibbs.cpp, bit-identical to the reference).  The reference's own configuration
+    (BURNIN 200, 1000 samples over 64 chains) sits at a certain distance from them; the data-augmentation sampler with the
+    program's default of 8 sweeps per round, same BURNIN / NSAMPLES / chains, must not sit further away.  And the exact
+    mode, given the reference configuration's seeds, must reproduce its posterior mean counts EXACTLY (64 concurrent
+    chains x 216 rounds x 200 k reads of the tile kernel against the sequential chain)."""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_gibbs_truth", os.path.join(here, "golden", "make_gibbs_truth.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    T = np.load(os.path.join(here, "golden", "gibbs_truth", "truth.npz"))
+    assert int(T["n_reads"]) == mk.N_READS and int(T["seed"]) == mk.SEED
+    d = mk.items()
+    ctx = capi().GibbsContext(d["M"], d["irp"], d["isid"], d["icp"], d["init"], None, d["pseudoC"], d["totc"], d["N0"], d["eel"], d["mw"], d["grp"])
+    ns = [1000 // 64 + (1 if k < 1000 % 64 else 0) for k in range(64)]
+
+    def dist(x):
+        q = np.abs(x - T["long_mean"]) / (T["long_sd"] + 0.5)
+        return float(np.sqrt((q ** 2).mean())), float(q.max())
+
+    _, acc, _, prof = ctx.run_chains(capi().GIBBS_EXACT, orc.chain_seeds(5, 64), 200, ns, 1, want_vectors=False)
+    assert np.array_equal(acc[0] / 1000.0, T["ref_mean"])  # the reference configuration, chain for chain
+    _, accp, _, _ = ctx.run_chains(capi().GIBBS_PARALLEL, capi().gibbs_chain_seeds(5, 64), 200, ns, 1, thin=8, want_vectors=False)
+    ctx.close()
+    rms_ref, max_ref = dist(T["ref_mean"])
+    rms_l2, max_l2 = dist(T["long2_mean"])
+    rms_p, max_p = dist(accp[0] / 1000.0)
+    print("distance to the long chains, |diff| / (sd + 0.5): second long set rms %.4f max %.3f | reference setup rms %.4f max %.3f | "
+          "parallel sampler rms %.4f max %.3f | exact mode %.1f ms per round (64 chains)" % (rms_l2, max_l2, rms_ref, max_ref, rms_p, max_p, prof.sweep_ms))
+    assert rms_p <= 1.10 * rms_ref and max_p <= 1.5 * max(max_ref, max_l2)
+    assert abs(accp[0].sum() / 1000.0 - (d["N0"] + mk.N_READS)) < 1e-6
+
+
 def test_exact_chain_with_prior_file_semantics():
     """--prior: per-transcript pseudo counts (Gibbs.cpp:171-194, 300-303): same integer draws as the oracle."""
     d = _load("pe_q")
