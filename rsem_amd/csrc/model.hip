@@ -122,6 +122,113 @@ __device__ inline double profile_prob(const double* __restrict__ prof, const uin
     return prob;
 }
 
+// Do two strand windows of `len` bases hold the same bases?  The alignments of a read mostly do: isoforms of a gene share
+// the exon the read came from, which is WHY the read is multi-mapped.  Then the profile product of the read against the
+// window (the expensive part of getConPrb) and the profile counts it feeds (update) are the same for both alignments.
+__device__ inline bool same_window(const uint64_t* __restrict__ refw, uint64_t a, uint64_t b, int len) {
+    if (a == b) return true;
+    const uint64_t* ra = refw + (a >> 3);
+    const uint64_t* rb = refw + (b >> 3);
+    const int sa = (int)(a & 7) * 8, sb = (int)(b & 7) * 8;
+    uint64_t a0 = ra[0], b0 = rb[0];
+    for (int i = 0; i < len; i += 8) {
+        const uint64_t a1 = ra[(i >> 3) + 1], b1 = rb[(i >> 3) + 1];
+        uint64_t x = funnel8(a0, a1, sa) ^ funnel8(b0, b1, sb);
+        a0 = a1; b0 = b1;
+        const int n = len - i;
+        if (n < 8) x &= (1ull << (8 * n)) - 1ull;
+        if (x) return false;
+    }
+    return true;
+}
+
+// One thread per READ: its alignments are walked in file order and the profile product of a mate is taken over from the
+// previous alignment when the reference window is the same (same bases, same read, same multiplication order: the value
+// is bit-identical to recomputing it).  Everything else of getConPrb is per alignment as in the reference
+// (SingleQModel.h:101-151, PairedEndQModel.h:94-138 and the no-quality twins).
+template <bool kQ, bool kPE>
+__global__ __launch_bounds__(kBlk) void k_conprb_read(DevData D, DevTables T, double* cp) {
+    __shared__ double s_prof[kQ ? 2500 : 1];
+    if (kQ) {
+        for (int i = threadIdx.x; i < 2500; i += blockDim.x) s_prof[i] = T.prof[i];
+        __syncthreads();
+    }
+    const double* prof = kQ ? s_prof : T.prof;
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= D.N1) return;
+    const uint64_t fr = D.row_ptr[row], to = D.row_ptr[row + 1];
+    if (D.lq[row]) {
+        for (uint64_t j = fr; j < to; j++) cp[j] = 0.0;
+        return;
+    }
+    const uint64_t r0 = D.roff8[0][row];
+    const int len1 = D.rlen[0][row];
+    const uint64_t q0 = kPE ? D.roff8[1][row] : 0;
+    const int len2 = kPE ? D.rlen[1][row] : 0;
+    bool have1 = false, have2 = false;
+    uint64_t w1 = 0, w2 = 0;     // windows the cached products belong to
+    double p1 = 0.0, p2 = 0.0;
+    auto product1 = [&](uint64_t a) -> double {
+        if (!(have1 && same_window(D.refw, a, w1, len1))) {
+            p1 = profile_prob<kQ>(prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, a);
+            w1 = a; have1 = true;
+        }
+        return p1;
+    };
+    auto product2 = [&](uint64_t a) -> double {
+        if (!(have2 && same_window(D.refw, a, w2, len2))) {
+            p2 = profile_prob<kQ>(prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2, D.refw, a);
+            w2 = a; have2 = true;
+        }
+        return p2;
+    };
+    for (uint64_t j = fr; j < to; j++) {
+        double prob = 0.0;
+        const int s = D.sid_signed[j];
+        const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
+        const int pos = D.pos[j];
+        const int fullLen = D.fullLen[sid], totLen = D.totLen[sid];
+        if (!kPE) {
+            const int fpos = dir == 0 ? pos : totLen - pos - len1;
+            const int seedPos = dir == 0 ? pos : totLen - pos - T.seedLen;
+            if (!(seedPos >= fullLen || ref_mask(D, sid, seedPos))) {
+                double value;
+                if (T.has_mld) {  // SingleQModel.h:127-136
+                    const int minL = max(len1, T.gld_lb + 1), maxL = min(totLen - pos, T.gld_ub);
+                    value = 0.0;
+                    for (int fragLen = minL; fragLen <= maxL; fragLen++) {
+                        const int pfpos = dir == 0 ? pos : totLen - pos - fragLen;
+                        const int effL = min(fullLen, totLen - fragLen + 1);
+                        value += ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, fragLen, totLen) * rspd_adj(T, pfpos, effL, fullLen) *
+                                 ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len1, fragLen);
+                    }
+                } else {
+                    const int effL = min(fullLen, totLen - len1 + 1);
+                    value = ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, len1, totLen) * rspd_adj(T, fpos, effL, fullLen);
+                }
+                const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
+                prob = ori * value * product1(D.soff[2 * sid + dir] + pos);
+                if (prob < kEpsilon) prob = 0.0;
+                prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
+            }
+        } else {  // PairedEndQModel.h:94-138
+            const int insertLen = D.insertL[j];
+            const int fpos = dir == 0 ? pos : totLen - pos - insertLen;
+            const int effL = min(fullLen, totLen - insertLen + 1);
+            if (!(fpos >= fullLen || ref_mask(D, sid, fpos))) {
+                const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
+                prob = ori * ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, insertLen, totLen) * rspd_adj(T, fpos, effL, fullLen);
+                prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len1, insertLen) * product1(D.soff[2 * sid + dir] + pos);
+                const int m2pos = totLen - pos - insertLen, m2dir = !dir;
+                prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len2, insertLen) * product2(D.soff[2 * sid + m2dir] + m2pos);
+                if (prob < kEpsilon) prob = 0.0;
+                prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
+            }
+        }
+        cp[j] = prob;
+    }
+}
+
 template <bool kQ, bool kPE>
 __global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double* cp) {
     // QProfile (100 x 5 x 5 doubles = 20 KB) is staged in LDS; the position-indexed Profile stays in global memory
@@ -360,6 +467,104 @@ __global__ __launch_bounds__(kBlk) void k_update(DevData D, DevTables T, const d
             if (s_gld[i] != 0.0) unsafeAtomicAdd(&A.gld[i], s_gld[i]);
 }
 
+// One thread per READ.  Consecutive alignments whose reference windows hold the same bases put the SAME (quality, reference
+// base, read base) triples into the profile counts (QProfile::update, QProfile.h:88-93), so their posterior weights are
+// added up first and the read is walked once per group instead of once per alignment: one LDS atomic per base and group
+// instead of per base and alignment (the kernel is bound by those atomics).  RSPD / fragment-length counts stay per
+// alignment; the noise profile is per read anyway (SingleQModel.h:168-221, PairedEndQModel.h:161-188).
+template <bool kQ, bool kPE>
+__global__ __launch_bounds__(kBlk) void k_update_read(DevData D, DevTables T, const double* __restrict__ w,
+                                                       const double* __restrict__ wn, AccumPtrs A) {
+    __shared__ double s_prof[kProfLds];
+    __shared__ double s_noise[kNoiseLds];
+    __shared__ double s_rspd[kRspdLds];
+    __shared__ double s_gld[kGldLds];
+    for (int i = threadIdx.x; i < kProfLds; i += blockDim.x) s_prof[i] = 0.0;
+    for (int i = threadIdx.x; i < kNoiseLds; i += blockDim.x) s_noise[i] = 0.0;
+    for (int i = threadIdx.x; i < kRspdLds; i += blockDim.x) s_rspd[i] = 0.0;
+    for (int i = threadIdx.x; i < kGldLds; i += blockDim.x) s_gld[i] = 0.0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; row < D.N1; row += stride) {
+        if (D.lq[row]) continue;
+        const uint64_t r0 = D.roff8[0][row];
+        const int len1 = D.rlen[0][row];
+        const uint64_t q0 = kPE ? D.roff8[1][row] : 0;
+        const int len2 = kPE ? D.rlen[1][row] : 0;
+        // the open group: windows of its first alignment and the weight collected so far
+        bool open = false;
+        uint64_t g1 = 0, g2 = 0;
+        double gw = 0.0;
+        auto flush = [&]() {
+            if (!open) return;
+            profile_update<kQ>(s_prof, A.prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, g1, gw);
+            if (kPE) profile_update<kQ>(s_prof, A.prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2, D.refw, g2, gw);
+            open = false;
+        };
+        for (uint64_t j = D.row_ptr[row]; j < D.row_ptr[row + 1]; j++) {
+            const double frac = w[j];
+            if (frac < kEpsilon) continue;
+            const int s = D.sid_signed[j];
+            const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
+            const int pos = D.pos[j];
+            const int fullLen = D.fullLen[sid], totLen = D.totLen[sid];
+            uint64_t a1, a2 = 0;
+            if (!kPE) {
+                if (T.estRSPD) {  // only one strand estimates the RSPD; helper models have no mld (SingleQModel.h:176-213)
+                    if (T.probF >= 0.1 && dir == 0) rspd_update(s_rspd, A.rspd, T.B, pos, fullLen, frac);
+                    if (T.probF < 0.1 && dir == 1) rspd_update(s_rspd, A.rspd, T.B, totLen - pos - len1, fullLen, frac);
+                }
+                a1 = D.soff[2 * sid + dir] + pos;
+            } else {
+                const int insertL = D.insertL[j];
+                add_tbl(s_gld, kGldLds, A.gld, insertL - A.gld0_lb, frac);  // LenDist::update (LenDist.h:46-49)
+                if (T.estRSPD) {
+                    const int fpos = dir == 0 ? pos : totLen - pos - insertL;
+                    rspd_update(s_rspd, A.rspd, T.B, fpos, fullLen, frac);
+                }
+                a1 = D.soff[2 * sid + dir] + pos;
+                a2 = D.soff[2 * sid + (!dir)] + (totLen - pos - insertL);
+            }
+            if (open && same_window(D.refw, a1, g1, len1) && (!kPE || same_window(D.refw, a2, g2, len2))) {
+                gw += frac;
+            } else {
+                flush();
+                open = true; g1 = a1; g2 = a2; gw = frac;
+            }
+        }
+        flush();
+        // noise profile (SingleQModel.h:217-221, PairedEndQModel.h:182-188)
+        const double nfrac = wn[row];
+        if (nfrac < kEpsilon) continue;
+        for (int m = 0; m < (kPE ? 2 : 1); m++) {
+            const uint64_t* sq = D.rseq_w[m] + D.roff8[m][row];
+            const uint64_t* ql = kQ ? D.rqual_w[m] + D.roff8[m][row] : nullptr;
+            const int len = D.rlen[m][row];
+            for (int k = 0; k < len; k += 8) {
+                const uint64_t sb = sq[k >> 3], qb = kQ ? ql[k >> 3] : 0;
+                const int n = min(8, len - k);
+                for (int u = 0; u < n; u++) {
+                    const int b = (int)((sb >> (8 * u)) & 0xff);
+                    unsafeAtomicAdd(&s_noise[kQ ? (int)((qb >> (8 * u)) & 0xff) * 5 + b : b], nfrac);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nprof = min(kProfLds, T.prof_rows * 25);
+    for (int i = threadIdx.x; i < nprof; i += blockDim.x)
+        if (s_prof[i] != 0.0) unsafeAtomicAdd(&A.prof[i], s_prof[i]);
+    const int nnoise = kQ ? 500 : 5;
+    for (int i = threadIdx.x; i < nnoise; i += blockDim.x)
+        if (s_noise[i] != 0.0) unsafeAtomicAdd(&A.noise[i], s_noise[i]);
+    if (A.rspd)
+        for (int i = threadIdx.x; i < min(kRspdLds, T.B + 2); i += blockDim.x)
+            if (s_rspd[i] != 0.0) unsafeAtomicAdd(&A.rspd[i], s_rspd[i]);
+    if (A.gld)
+        for (int i = threadIdx.x; i < min(kGldLds, A.gld0_ub - A.gld0_lb + 1); i += blockDim.x)
+            if (s_gld[i] != 0.0) unsafeAtomicAdd(&A.gld[i], s_gld[i]);
+}
+
 __global__ void k_hit_rows(uint64_t N1, const uint64_t* __restrict__ row_ptr, uint32_t* hit_row) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N1) return;
@@ -432,11 +637,19 @@ int up_field(rsem_model_ctx* c, const T*& field, const T* src, size_t n, hipStre
     return RSEM_OK;
 }
 
+// RSEM_MODEL_KERNELS=alignment selects the thread-per-alignment kernels of round 1 (cross-check of the per-read ones)
+bool per_alignment_kernels() {
+    const char* e = getenv("RSEM_MODEL_KERNELS");
+    return e && !strcmp(e, "alignment");
+}
+
 template <bool kQ, bool kPE>
 int launch_conprb(rsem_model_ctx* c) {
     hipStream_t st = c->v.stream;
-    if (c->D.nnz)
+    if (c->D.nnz && per_alignment_kernels())
         hipLaunchKernelGGL((k_conprb<kQ, kPE>), dim3(rsem::ceil_div(c->D.nnz, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_cp);
+    else if (c->D.N1)
+        hipLaunchKernelGGL((k_conprb_read<kQ, kPE>), dim3(rsem::ceil_div(c->D.N1, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_cp);
     if (c->D.N1)
         hipLaunchKernelGGL((k_noise<kQ, kPE>), dim3(rsem::ceil_div(c->D.N1, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_ncp);
     RSEM_HIP_TRY(hipGetLastError());
@@ -445,9 +658,15 @@ int launch_conprb(rsem_model_ctx* c) {
 
 template <bool kQ, bool kPE>
 int launch_update(rsem_model_ctx* c, const AccumPtrs& A) {
-    int grid = std::max(1, std::min(1024, rsem::ceil_div(std::max<uint64_t>(c->D.nnz, c->D.N1), kBlk * 4)));
-    hipLaunchKernelGGL((k_update<kQ, kPE>), dim3(grid), dim3(kBlk), 0, c->v.stream, c->D, c->T, (const double*)c->v.d_w,
-                       (const double*)c->v.d_wn, A);
+    if (per_alignment_kernels()) {
+        int grid = std::max(1, std::min(1024, rsem::ceil_div(std::max<uint64_t>(c->D.nnz, c->D.N1), kBlk * 4)));
+        hipLaunchKernelGGL((k_update<kQ, kPE>), dim3(grid), dim3(kBlk), 0, c->v.stream, c->D, c->T, (const double*)c->v.d_w,
+                           (const double*)c->v.d_wn, A);
+    } else {
+        int grid = std::max(1, std::min(1024, rsem::ceil_div(c->D.N1, kBlk)));
+        hipLaunchKernelGGL((k_update_read<kQ, kPE>), dim3(grid), dim3(kBlk), 0, c->v.stream, c->D, c->T, (const double*)c->v.d_w,
+                           (const double*)c->v.d_wn, A);
+    }
     RSEM_HIP_TRY(hipGetLastError());
     return RSEM_OK;
 }

@@ -213,6 +213,27 @@ def test_rsem_run_em_binary_input_equals_text_input(name, tmp_path):
     assert len(open(os.path.join(dst, "temp", "s.ofg")).read()) == len(keep["temp/s.ofg"])
 
 
+@pytest.mark.parametrize("name", ["pe_q", "se_noq_rev_rspd_omit", "se_q_fragmean"])
+def test_per_read_model_kernels_equal_per_alignment_kernels(name, tmp_path):
+    """k_conprb_read / k_update_read (one thread per read, profile products and profile counts shared by alignments whose
+    reference windows hold the same bases) against the thread-per-alignment kernels (RSEM_MODEL_KERNELS=alignment): same
+    rounds, theta and .ofg values to 1e-9 (the products are bit-identical; the count sums differ in summation order)."""
+    fx, dst = _stage(name, tmp_path)
+    meta = rf.read_meta(fx)
+    args = [os.path.join(dst, "ref"), str(meta["model_type"]), os.path.join(dst, "s"), os.path.join(dst, "temp", "s"), os.path.join(dst, "stat", "s"), "--gibbs-out"]
+    out_r = _run([os.path.join(BIN, "rsem-run-em")] + args)
+    th_r = rf.read_theta(os.path.join(dst, "stat", "s.theta"))
+    ofg_r = rf.read_ofg(os.path.join(dst, "temp", "s.ofg"))
+    r = subprocess.run([os.path.join(BIN, "rsem-run-em")] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       env=dict(os.environ, RSEM_MODEL_KERNELS="alignment"))
+    assert r.returncode == 0, r.stdout[-2000:]
+    th_a = rf.read_theta(os.path.join(dst, "stat", "s.theta"))
+    ofg_a = rf.read_ofg(os.path.join(dst, "temp", "s.ofg"))
+    assert [l for l in out_r.split("\n") if l.startswith("ROUND")][-1].split(",")[0] == [l for l in r.stdout.split("\n") if l.startswith("ROUND")][-1].split(",")[0]
+    assert np.allclose(th_r[0], th_a[0], rtol=1e-9, atol=1e-15)
+    assert np.array_equal(ofg_r[2], ofg_a[2]) and np.array_equal(ofg_r[3], ofg_a[3]) and np.allclose(ofg_r[4], ofg_a[4], rtol=1e-9, atol=0)
+
+
 def _bam_records(path):
     """Decompress a BAM (BGZF = concatenated gzip members) and split it into (header bytes, [record bytes])."""
     import gzip
