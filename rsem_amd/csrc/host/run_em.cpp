@@ -18,7 +18,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <fcntl.h>
 #include <functional>
+#include <memory>
 #include <string>
 #include <unistd.h>
 #include <thread>
@@ -616,16 +618,17 @@ int main(int argc, char* argv[]) {
 
     // ---- imd.ofg for the Gibbs sampler (EM.cpp:421-458) ---------------------------------------------------
     if (genGibbsOut) {
-        std::vector<double> cp(nnz), ncp(N1);
+        std::unique_ptr<double[]> cp(new double[nnz ? nnz : 1]), ncp(new double[N1 ? N1 : 1]);  // filled by the copies below
         each_shard([&](Shard& X, int) {
-            X.rc = rsem_model_get_values(X.mc, cp.data() + X.a, ncp.data() + X.lo);
+            X.rc = rsem_model_get_values(X.mc, cp.get() + X.a, ncp.get() + X.lo);
             if (X.rc != RSEM_OK) X.err = rsem_hip_last_error();
         });
         check_shards("rsem_model_get_values");
-        FILE* fo = fopen((imdName + ".ofg").c_str(), "w");
-        if (!fo) die("Cannot open %s.ofg for writing!", imdName.c_str());
-        fprintf(fo, "%d %llu\n", M, (unsigned long long)N0);
-        // rows are formatted by all host threads into per-chunk buffers, then written in order
+        const std::string ofg_path = imdName + ".ofg";
+        char head[64];
+        const int head_n = snprintf(head, sizeof(head), "%d %llu\n", M, (unsigned long long)N0);
+        // rows are formatted by all host threads into per-chunk buffers; every thread then writes its chunk at its own
+        // offset of the file (the text is tens of GB at BASELINE sizes: one writer is page-cache bound)
         const int nt = N1 > 100000 ? hardware_threads() : 1;
         std::vector<std::string> bufs(nt);
         parallel_for(nt, [&](int t) {
@@ -648,8 +651,24 @@ int main(int argc, char* argv[]) {
                 if (n > 0) b.push_back('\n');
             }
         });
-        for (auto& b : bufs) fwrite(b.data(), 1, b.size(), fo);
-        fclose(fo);
+        std::vector<uint64_t> at(nt + 1, (uint64_t)head_n);
+        for (int t = 0; t < nt; t++) at[t + 1] = at[t] + bufs[t].size();
+        const int fd = ::open(ofg_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) die("Cannot open %s.ofg for writing!", imdName.c_str());
+        bool wr_ok = ::pwrite(fd, head, head_n, 0) == head_n;
+        std::vector<char> okv(nt, 1);
+        parallel_for(nt, [&](int t) {
+            const char* q = bufs[t].data();
+            uint64_t left = bufs[t].size(), off = at[t];
+            while (left > 0) {
+                const ssize_t k = ::pwrite(fd, q, (size_t)std::min<uint64_t>(left, (uint64_t)1 << 30), (off_t)off);
+                if (k <= 0) { okv[t] = 0; return; }
+                q += k; off += (uint64_t)k; left -= (uint64_t)k;
+            }
+            bufs[t] = std::string();
+        });
+        for (char o : okv) wr_ok = wr_ok && o;
+        if (::close(fd) != 0 || !wr_ok) die("Cannot write %s.ofg!", imdName.c_str());
     }
     lap("write .ofg");
     // ---- expected counts with the learned theta (EM.cpp:460-478) -------------------------------------------
