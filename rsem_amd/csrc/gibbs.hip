@@ -520,13 +520,8 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
         int lo = 0x7fffffff, hi = -1, ref = 0;
         unsigned long long present = 0;
         bool has_noise = false, wide = false, have_ref = false;
-        int sreg[8];  // the read's first ids in registers: the commit loop's patch step compares without touching LDS
-#pragma unroll
-        for (int k = 0; k < 8; k++) sreg[k] = -1;
         for (int k = 0; k < len; k++) {
             const int s = t_sid[fr + k];
-#pragma unroll
-            for (int u = 0; u < 8; u++) sreg[u] = (u == k) ? s : sreg[u];
             if (s == 0) has_noise = true;
             else {
                 lo = min(lo, s); hi = max(hi, s);
@@ -570,12 +565,7 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
                 if (__ballot(cand)) {
                     bool hit = false;
                     if (cand) {
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {  // ids >= 0, the empty slots hold -1: they match nothing
-                            const int d = (sreg[k] == zn ? 1 : 0) - (sreg[k] == zo ? 1 : 0);
-                            if (d != 0) { t_c[fr + k] += d; hit = true; }
-                        }
-                        for (int k = 8; k < len; k++) {
+                        for (int k = 0; k < len; k++) {
                             const int s = t_sid[fr + k];
                             const int d = (s == zn ? 1 : 0) - (s == zo ? 1 : 0);
                             if (d != 0) { t_c[fr + k] += d; hit = true; }

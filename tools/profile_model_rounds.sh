@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf $D; tools/bin/gen_temp $D $N $M 3 20250925 100 nosam 5-16 | tail -1
 tools/bin/temp_to_rsb $D/temp/s $D/stat/s 3 > /dev/null
 for mode in read alignment; do
-  export RSEM_MODEL_KERNELS=$mode
+  export RSEM_MODEL_KERNELS=$mode RSEM_HIP_NORMAL_EXIT=1
   rm -rf gpurun_out/pmr_$mode
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmr_$mode -o p -- rsem_amd/bin/rsem-run-em $D/ref 3 $D/s $D/temp/s $D/stat/s -q > /dev/null 2>&1
   echo "== RSEM_MODEL_KERNELS=$mode"
