@@ -637,16 +637,21 @@ int up_field(rsem_model_ctx* c, const T*& field, const T* src, size_t n, hipStre
     return RSEM_OK;
 }
 
-// RSEM_MODEL_KERNELS=alignment selects the thread-per-alignment kernels of round 1 (cross-check of the per-read ones)
-bool per_alignment_kernels() {
+// Which variant runs.  Measured on 5 M read pairs / 56 M alignments (tools/profile_model_rounds.sh, profiles/r02_model_rounds.log):
+// update: per read 23.6 ms vs per alignment 38.1 ms (the LDS atomics are what the per-alignment kernel waits for);
+// conprb: per alignment 13.8 ms vs per read 49.7 ms (the product is cheap next to walking a read's alignments serially).
+// Default = the faster of each; RSEM_MODEL_KERNELS=alignment | read forces one family (cross-checks in tests/).
+bool per_alignment_kernels(bool for_update) {
     const char* e = getenv("RSEM_MODEL_KERNELS");
-    return e && !strcmp(e, "alignment");
+    if (e && !strcmp(e, "alignment")) return true;
+    if (e && !strcmp(e, "read")) return false;
+    return !for_update;
 }
 
 template <bool kQ, bool kPE>
 int launch_conprb(rsem_model_ctx* c) {
     hipStream_t st = c->v.stream;
-    if (c->D.nnz && per_alignment_kernels())
+    if (c->D.nnz && per_alignment_kernels(false))
         hipLaunchKernelGGL((k_conprb<kQ, kPE>), dim3(rsem::ceil_div(c->D.nnz, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_cp);
     else if (c->D.N1)
         hipLaunchKernelGGL((k_conprb_read<kQ, kPE>), dim3(rsem::ceil_div(c->D.N1, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_cp);
@@ -658,7 +663,7 @@ int launch_conprb(rsem_model_ctx* c) {
 
 template <bool kQ, bool kPE>
 int launch_update(rsem_model_ctx* c, const AccumPtrs& A) {
-    if (per_alignment_kernels()) {
+    if (per_alignment_kernels(true)) {
         int grid = std::max(1, std::min(1024, rsem::ceil_div(std::max<uint64_t>(c->D.nnz, c->D.N1), kBlk * 4)));
         hipLaunchKernelGGL((k_update<kQ, kPE>), dim3(grid), dim3(kBlk), 0, c->v.stream, c->D, c->T, (const double*)c->v.d_w,
                            (const double*)c->v.d_wn, A);

@@ -226,14 +226,15 @@ def test_per_read_model_kernels_equal_per_alignment_kernels(name, tmp_path):
     out_r = _run([os.path.join(BIN, "rsem-run-em")] + args)
     th_r = rf.read_theta(os.path.join(dst, "stat", "s.theta"))
     ofg_r = rf.read_ofg(os.path.join(dst, "temp", "s.ofg"))
-    r = subprocess.run([os.path.join(BIN, "rsem-run-em")] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                       env=dict(os.environ, RSEM_MODEL_KERNELS="alignment"))
-    assert r.returncode == 0, r.stdout[-2000:]
-    th_a = rf.read_theta(os.path.join(dst, "stat", "s.theta"))
-    ofg_a = rf.read_ofg(os.path.join(dst, "temp", "s.ofg"))
-    assert [l for l in out_r.split("\n") if l.startswith("ROUND")][-1].split(",")[0] == [l for l in r.stdout.split("\n") if l.startswith("ROUND")][-1].split(",")[0]
-    assert np.allclose(th_r[0], th_a[0], rtol=1e-9, atol=1e-15)
-    assert np.array_equal(ofg_r[2], ofg_a[2]) and np.array_equal(ofg_r[3], ofg_a[3]) and np.allclose(ofg_r[4], ofg_a[4], rtol=1e-9, atol=0)
+    for family in ("alignment", "read"):  # the default mixes them (per-alignment conprb, per-read update)
+        r = subprocess.run([os.path.join(BIN, "rsem-run-em")] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           env=dict(os.environ, RSEM_MODEL_KERNELS=family))
+        assert r.returncode == 0, r.stdout[-2000:]
+        th_a = rf.read_theta(os.path.join(dst, "stat", "s.theta"))
+        ofg_a = rf.read_ofg(os.path.join(dst, "temp", "s.ofg"))
+        assert [l for l in out_r.split("\n") if l.startswith("ROUND")][-1].split(",")[0] == [l for l in r.stdout.split("\n") if l.startswith("ROUND")][-1].split(",")[0]
+        assert np.allclose(th_r[0], th_a[0], rtol=1e-9, atol=1e-15)
+        assert np.array_equal(ofg_r[2], ofg_a[2]) and np.array_equal(ofg_r[3], ofg_a[3]) and np.allclose(ofg_r[4], ofg_a[4], rtol=1e-9, atol=0)
 
 
 def _bam_records(path):
