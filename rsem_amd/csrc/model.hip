@@ -67,6 +67,9 @@ struct DevData {
     const int32_t* totLen;
     const uint64_t* mask_off;
     const uint32_t* mask_words;
+    // per alignment: bit 0 / bit 1 = the reference window of mate 1 / mate 2 holds the same bases as the window of the
+    // read's PREVIOUS alignment (computed once at create: the windows never change); 0 for a read's first alignment
+    const uint8_t* same_prev;
 };
 
 // LenDist::getAdjustedProb (LenDist.h:63-68)
@@ -350,8 +353,13 @@ struct AccumPtrs {
     int gld0_lb, gld0_ub;
 };
 
+// The LDS side is spelled as an LDS operation: left as a generic pointer, the two branches can be merged into one flat
+// atomic on a selected address, which this compiler then fails to encode (and which would be slower anyway).
+__device__ inline void lds_add_f64(double* p, double v) {
+    (void)__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)p, v);
+}
 __device__ inline void add_tbl(double* lds, int cap, double* glob, int idx, double v) {
-    if (idx < cap) unsafeAtomicAdd(&lds[idx], v);
+    if (idx < cap) lds_add_f64(&lds[idx], v);
     else unsafeAtomicAdd(&glob[idx], v);
 }
 
@@ -467,6 +475,36 @@ __global__ __launch_bounds__(kBlk) void k_update(DevData D, DevTables T, const d
             if (s_gld[i] != 0.0) unsafeAtomicAdd(&A.gld[i], s_gld[i]);
 }
 
+// same_prev flags (DevData): one thread per read, once per model context
+template <bool kPE>
+__global__ __launch_bounds__(kBlk) void k_window_flags(DevData D, uint8_t* flags) {
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= D.N1) return;
+    const uint64_t fr = D.row_ptr[row], to = D.row_ptr[row + 1];
+    if (D.lq[row]) {  // never walked by the update kernel (and its coordinates were not range-checked)
+        for (uint64_t j = fr; j < to; j++) flags[j] = 0;
+        return;
+    }
+    const int len1 = D.rlen[0][row];
+    const int len2 = kPE ? D.rlen[1][row] : 0;
+    uint64_t p1 = 0, p2 = 0;
+    for (uint64_t j = fr; j < to; j++) {
+        const int s = D.sid_signed[j];
+        const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
+        const int pos = D.pos[j];
+        const uint64_t a1 = D.soff[2 * sid + dir] + pos;
+        uint64_t a2 = 0;
+        if (kPE) a2 = D.soff[2 * sid + (!dir)] + (D.totLen[sid] - pos - D.insertL[j]);
+        uint8_t f = 0;
+        if (j > fr) {
+            if (same_window(D.refw, a1, p1, len1)) f |= 1;
+            if (kPE && same_window(D.refw, a2, p2, len2)) f |= 2;
+        }
+        flags[j] = f;
+        p1 = a1; p2 = a2;
+    }
+}
+
 // One thread per READ.  Consecutive alignments whose reference windows hold the same bases put the SAME (quality, reference
 // base, read base) triples into the profile counts (QProfile::update, QProfile.h:88-93), so their posterior weights are
 // added up first and the read is walked once per group instead of once per alignment: one LDS atomic per base and group
@@ -491,30 +529,35 @@ __global__ __launch_bounds__(kBlk) void k_update_read(DevData D, DevTables T, co
         const int len1 = D.rlen[0][row];
         const uint64_t q0 = kPE ? D.roff8[1][row] : 0;
         const int len2 = kPE ? D.rlen[1][row] : 0;
-        // the open group: windows of its first alignment and the weight collected so far
+        // the open group: windows of its first alignment, the weight collected so far, and the "window generation" it
+        // belongs to (the generation advances whenever an alignment's windows differ from its predecessor's, skipped
+        // alignments included, so equal generations mean equal bases)
         bool open = false;
         uint64_t g1 = 0, g2 = 0;
         double gw = 0.0;
-        auto flush = [&]() {
-            if (!open) return;
-            profile_update<kQ>(s_prof, A.prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, g1, gw);
-            if (kPE) profile_update<kQ>(s_prof, A.prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2, D.refw, g2, gw);
-            open = false;
-        };
+        int gen = 0, ggen = -1;
+        // (a macro, not a lambda: the LDS tables must reach the atomics as LDS pointers, not through a captured reference)
+#define RSEM_FLUSH_GROUP()                                                                                                              \
+    do {                                                                                                                                \
+        if (open) {                                                                                                                     \
+            profile_update<kQ>(s_prof, A.prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, g1, gw);               \
+            if (kPE) profile_update<kQ>(s_prof, A.prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2, D.refw, g2, gw);     \
+            open = false;                                                                                                               \
+        }                                                                                                                               \
+    } while (0)
         for (uint64_t j = D.row_ptr[row]; j < D.row_ptr[row + 1]; j++) {
+            if (D.same_prev[j] != (kPE ? 3 : 1)) ++gen;
             const double frac = w[j];
             if (frac < kEpsilon) continue;
             const int s = D.sid_signed[j];
             const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
             const int pos = D.pos[j];
             const int fullLen = D.fullLen[sid], totLen = D.totLen[sid];
-            uint64_t a1, a2 = 0;
             if (!kPE) {
                 if (T.estRSPD) {  // only one strand estimates the RSPD; helper models have no mld (SingleQModel.h:176-213)
                     if (T.probF >= 0.1 && dir == 0) rspd_update(s_rspd, A.rspd, T.B, pos, fullLen, frac);
                     if (T.probF < 0.1 && dir == 1) rspd_update(s_rspd, A.rspd, T.B, totLen - pos - len1, fullLen, frac);
                 }
-                a1 = D.soff[2 * sid + dir] + pos;
             } else {
                 const int insertL = D.insertL[j];
                 add_tbl(s_gld, kGldLds, A.gld, insertL - A.gld0_lb, frac);  // LenDist::update (LenDist.h:46-49)
@@ -522,17 +565,18 @@ __global__ __launch_bounds__(kBlk) void k_update_read(DevData D, DevTables T, co
                     const int fpos = dir == 0 ? pos : totLen - pos - insertL;
                     rspd_update(s_rspd, A.rspd, T.B, fpos, fullLen, frac);
                 }
-                a1 = D.soff[2 * sid + dir] + pos;
-                a2 = D.soff[2 * sid + (!dir)] + (totLen - pos - insertL);
             }
-            if (open && same_window(D.refw, a1, g1, len1) && (!kPE || same_window(D.refw, a2, g2, len2))) {
+            if (open && ggen == gen) {
                 gw += frac;
             } else {
-                flush();
-                open = true; g1 = a1; g2 = a2; gw = frac;
+                RSEM_FLUSH_GROUP();
+                open = true; ggen = gen; gw = frac;
+                g1 = D.soff[2 * sid + dir] + pos;
+                g2 = kPE ? D.soff[2 * sid + (!dir)] + (totLen - pos - D.insertL[j]) : 0;
             }
         }
-        flush();
+        RSEM_FLUSH_GROUP();
+#undef RSEM_FLUSH_GROUP
         // noise profile (SingleQModel.h:217-221, PairedEndQModel.h:182-188)
         const double nfrac = wn[row];
         if (nfrac < kEpsilon) continue;
@@ -817,6 +861,14 @@ int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_da
     c->owned.push_back(hr);
     D.hit_row = hr;
     if (d->N1) hipLaunchKernelGGL(k_hit_rows, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, d->N1, D.row_ptr, hr);
+    uint8_t* fl = nullptr;
+    if (dmalloc(&fl, d->nnz) != hipSuccess) { rsem_model_destroy(c); return RSEM_ERR_NOMEM; }
+    c->owned.push_back(fl);
+    D.same_prev = fl;
+    if (d->N1) {
+        if (pe) hipLaunchKernelGGL(k_window_flags<true>, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, D, fl);
+        else hipLaunchKernelGGL(k_window_flags<false>, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, D, fl);
+    }
     if (hipStreamSynchronize(st) != hipSuccess) { rsem_model_destroy(c); return RSEM_ERR_HIP; }
     rsem::thread_stager().release();
     *out = c;
