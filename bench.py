@@ -223,19 +223,28 @@ def main():
         raise SystemExit("bench.py needs a GPU: librsem_hip has no CPU path")
     torch.cuda.set_device(local)
     comm = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1: take the N > 1 code path with a single rank (process group, communicator id broadcast, RCCL
+    # collectives issued although there is one rank) -- the only way to execute that path on a one-GPU box
+    distributed = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
+    if distributed and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ["RSEM_COMM_FORCE"] = "1"
+    if distributed:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # "nccl" is RCCL on ROCm
     if rank == 0:
         build.build()
-    if world > 1:
+    if distributed:
         dist.barrier()
         # the product's own communicator (RCCL from C++, collectives on the EM stream); only its id goes through torch
         ids = [capi.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         comm = capi.Comm.create(local, rank, world, ids[0])
     sync = torch.cuda.synchronize
-    barrier = dist.barrier if world > 1 else (lambda: None)
+    barrier = dist.barrier if distributed else (lambda: None)
 
     t0 = time.perf_counter()
     wl = make_em_workload(args.config, shard=rank, scale=args.scale)
@@ -252,7 +261,7 @@ def main():
         ctx.set_comm(comm)
     N0g = float(wl["N0"] * world)  # every rank passes the GLOBAL N0 (rsem_em_set_comm)
     def agree(x):
-        if world == 1:
+        if not distributed:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=torch.device("cuda", local))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -261,7 +270,7 @@ def main():
     elapsed, rounds, reps, estep_ms, theta_sum = timed_rounds(ctx, wl, N0g, K, W, sync, barrier, agree)
     total_nnz = nnz
     dist_info = None
-    if world > 1:
+    if distributed:
         dev = torch.device("cuda", local)
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -377,7 +386,7 @@ def main():
     if comm is not None:
         barrier()
         comm.close()
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
