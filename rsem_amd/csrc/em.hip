@@ -261,11 +261,29 @@ __global__ __launch_bounds__(kBlock) void k_estep_sell(
 // and adds the normalised fractions into registers; on a change it spills its registers to the
 // LDS window and reloads sid / theta for the new tuple.  The loads of slice s+1 are issued before
 // slice s is reduced (software pipeline, static instruction stream per K).
+// Where theta comes from.  Plain: the array the M-step kernel wrote.  kFC ("from counts", the fused loop of rsem_em_run):
+// the PREVIOUS round's raw counts and its two totals -- theta_i = (counts_i + (i == 0 ? noise + N0 : 0)) / (N0 + reads with
+// a non-zero normaliser), the very expression the M step evaluates (EM.cpp:392-398), so the E step does not wait for an
+// M-step kernel at all; convergence statistics run beside it on a second stream (k_mstep_fast<true>).
+struct ThetaSrc {
+    const double* v;
+    double extra0, sum;
+};
+template <bool kFC>
+__device__ inline double theta_at(const ThetaSrc& t, int i) {
+    if (!kFC) return t.v[i];
+    return (t.v[i] + (i == 0 ? t.extra0 : 0.0)) / t.sum;
+}
+// the two totals of the source round: every wave sums the slots itself (fixed order: identical in all waves)
+template <bool kFC>
+__device__ inline ThetaSrc theta_src(const double* __restrict__ v, const double* __restrict__ tsrc, double N0, int lane);
+
 // theta[base, base+span) -> LDS, count window zeroed; every wave of the workgroup calls this exactly once
-__device__ inline void stage_windows(int base, int span, int M, const double* __restrict__ theta, double* th_win, double* cnt_win) {
+template <bool kFC>
+__device__ inline void stage_windows(int base, int span, int M, const ThetaSrc& th, double* th_win, double* cnt_win) {
     for (int i = threadIdx.x; i < span; i += blockDim.x) {
         const int sidv = base + i;
-        th_win[i] = (sidv >= 0 && sidv <= M) ? theta[sidv] : 0.0;
+        th_win[i] = (sidv >= 0 && sidv <= M) ? theta_at<kFC>(th, sidv) : 0.0;
         cnt_win[i] = 0.0;
     }
     __syncthreads();
@@ -278,9 +296,9 @@ struct SliceRegs {
     double nc;
 };
 
-template <int K>
+template <int K, bool kFC>
 __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
-                                   const double* __restrict__ theta, double th0, double* th_win, double* cnt_win,
+                                   const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, double* th_win, double* cnt_win,
                                    const double* __restrict__ scp, const int32_t* __restrict__ ssid,
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
                                    double* counts, double& noise, double& neff, int M) {
@@ -327,6 +345,8 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
     double rth[K], acc[K];
 #pragma unroll
     for (int k = 0; k < K; k++) { rsid[k] = 0; rth[k] = 0.0; acc[k] = 0.0; }
+    ThetaSrc th{theta, 0.0, 1.0};
+    double th0 = 0.0;
     auto reduce = [&](const SliceRegs<K>& cur, unsigned long long cur_m) {
         if (cur_m != 0ull) {                 // wave-uniform
             if ((cur_m >> lane) & 1ull) {    // lanes whose read starts a new sid tuple
@@ -336,7 +356,7 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
                     const int sidv = cur.id[k];
                     rsid[k] = sidv;
                     const unsigned off = (unsigned)(sidv - base);
-                    rth[k] = (off < (unsigned)span) ? th_win[off] : theta[sidv];
+                    rth[k] = (off < (unsigned)span) ? th_win[off] : theta_at<kFC>(th, sidv);
                 }
             }
         }
@@ -362,7 +382,9 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
     SliceRegs<K> A, B;
     unsigned long long mA = ~0ull, mB = 0;  // a block always starts fresh
     issue(s_begin, mA, A);
-    stage_windows(base, span, M, theta, th_win, cnt_win);  // the first slice's loads fly while the windows are staged
+    th = theta_src<kFC>(theta, tsrc, N0, lane);  // (after the first slice's loads were issued: they fly meanwhile)
+    th0 = theta_at<kFC>(th, 0);
+    stage_windows<kFC>(base, span, M, th, th_win, cnt_win);  // ... and while the windows are staged
     for (uint32_t s = s_begin; s < s_end; s += 2) {
         if (s + 1 < s_end) {
             mB = mask_of(s + 1);
@@ -379,11 +401,25 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
     spill(rsid, acc);
 }
 
+template <bool kFC>
+__device__ inline ThetaSrc theta_src(const double* __restrict__ v, const double* __restrict__ tsrc, double N0, int lane) {
+    ThetaSrc t{v, 0.0, 1.0};
+    if (kFC) {
+        const double a = wave_sum(tsrc[lane]);
+        const double b = wave_sum(tsrc[kTotSlots + lane]);
+        t.extra0 = a + N0;  // counts[0] += noise + N0 (EM.cpp:392)
+        t.sum = b + N0;     // = sum(counts) (EM.cpp:395): every read with a non-zero normaliser carries mass one
+    }
+    return t;
+}
+
+// kFC: `theta` holds the previous round's raw counts, tsrc its totals (see ThetaSrc)
+template <bool kFC>
 __global__ __launch_bounds__(kBlock) void k_estep_lane(
     const Shape* __restrict__ shapes, const Unit* __restrict__ units, uint32_t T, int M,
-    const double* __restrict__ theta, const double* __restrict__ scp, const int32_t* __restrict__ ssid,
-    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks, double* counts,
-    double* noise_partial, double* totals, const Ctrl* ctrl, unsigned long long* trace) {
+    const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, const double* __restrict__ scp,
+    const int32_t* __restrict__ ssid, const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
+    double* counts, double* noise_partial, double* totals, const Ctrl* ctrl, unsigned long long* trace) {
     if (ctrl->done) return;
     if (trace && threadIdx.x == 0) trace[2 * blockIdx.x] = wall_clock64();  // rsem_em_debug_trace only
     __shared__ double th_win[kWindow];
@@ -405,13 +441,15 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
         const uint32_t u_end = S.slice_base + U.slice_begin + U.n_slices;
         const uint32_t s_begin = S.slice_base + U.slice_begin + (uint32_t)w * U.per_wave;
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
-        const double th0 = theta[0];
         if (s_begin < u_end) switch (S.K) {
-            case 1: estep_block<1>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
-            case 2: estep_block<2>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
-            case 3: estep_block<3>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
-            default: estep_block<4>(S, s_begin, s_end, lane, U.base, U.span, theta, th0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
-        } else stage_windows(U.base, U.span, M, theta, th_win, cnt_win);
+            case 1: estep_block<1, kFC>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
+            case 2: estep_block<2, kFC>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
+            case 3: estep_block<3, kFC>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
+            default: estep_block<4, kFC>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
+        } else {
+            const ThetaSrc th = theta_src<kFC>(theta, tsrc, N0, lane);
+            stage_windows<kFC>(U.base, U.span, M, th, th_win, cnt_win);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < U.span; i += blockDim.x) {
@@ -621,10 +659,14 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fused(int32_t M, double N0, do
 // one, so sum(counts) (EM.cpp:395) = N0 + (number of such reads), which the E-step workgroups count on the side
 // (one atomic per E-step workgroup into one of kTotSlots slots; exact, the addends are integers), like the noise
 // fraction (a second set of slots).  No reduction, no barrier before theta = counts / sum.
+// kFused (the fused loop of rsem_em_run): counts / totals of this round are LEFT IN PLACE -- the next E step reads theta
+// out of them (ThetaSrc) and is already running beside this kernel -- and the buffer that round r-1 left (`spent`,
+// counts then totals, read for the last time by this round's E step) is cleared for round r+2 instead.
+template <bool kFused>
 __global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, double* counts, double* totals,
                                                         const double* __restrict__ theta_old, double* theta_new,
                                                         double* counts_last, Ctrl* ctrl, int round, int min_round, int max_round,
-                                                        HostMirror* mirror) {
+                                                        HostMirror* mirror, double* spent) {
     if (ctrl->done) return;
     const int n = M + 1;
     const int nb = gridDim.x;
@@ -661,13 +703,15 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, dou
         const double th = c / sum;
         theta_new[i] = th;
         counts_last[i] = c;
-        counts[i] = 0.0;
+        if (kFused) spent[i] = 0.0;
+        else counts[i] = 0.0;
         if (old >= 1e-7) {
             const double change = fabs(th - old) / old;
             if (change >= 0.001) ++tot;
             bmax = fmax(bmax, change);
         }
     };
+    if (kFused && blockIdx.x == 0 && threadIdx.x < 2 * kTotSlots) spent[n + threadIdx.x] = 0.0;
     if (pre) {
 #pragma unroll
         for (int k = 0; k < kPre; k++) {
@@ -723,7 +767,7 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, dou
     }
     __syncthreads();
     // the last workgroup to arrive clears the totals for the next round: every workgroup has read them by now
-    if (s_last && threadIdx.x < 2 * kTotSlots) __hip_atomic_store(&totals[threadIdx.x], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!kFused && s_last && threadIdx.x < 2 * kTotSlots) __hip_atomic_store(&totals[threadIdx.x], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
@@ -756,7 +800,8 @@ struct rsem_em_ctx {
     size_t noise_cap = 0;
     // EM state
     double* d_theta[2] = {nullptr, nullptr};
-    double* d_red = nullptr;      // [counts (M+1) | totals (2 * kTotSlots)]: one buffer, so that one all-reduce covers both
+    double* d_red3 = nullptr;     // three buffers of [counts (M+1) | totals (2 * kTotSlots)] (the fused loop rotates them)
+    double* d_red = nullptr;      // = d_red3: [counts | totals] in one buffer, so that one all-reduce covers both
     double* d_counts = nullptr;   // = d_red
     double* d_counts_last = nullptr;
     double* d_noise_a = nullptr;  // per-workgroup noise partials of the main E-step launch
@@ -775,6 +820,8 @@ struct rsem_em_ctx {
     std::vector<hipEvent_t> events;
     HostMirror* mirror = nullptr;  // pinned host memory, written by the M-step kernel
     hipEvent_t lag_ev[2] = {nullptr, nullptr};
+    hipStream_t stream2 = nullptr;  // fused loop: the statistics kernel of round r runs here, beside the E step of round r+1
+    hipEvent_t ev_e[4] = {nullptr, nullptr, nullptr, nullptr}, ev_s[4] = {nullptr, nullptr, nullptr, nullptr};
     rsem_comm* comm = nullptr;     // not owned; rows sharded over its ranks when set
     rsem_em_progress_fn progress = nullptr;
     void* progress_user = nullptr;
@@ -800,8 +847,9 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
     }
     if (kern == RSEM_EM_KERNEL_LANE) {
         if (c->n_units)
-            hipLaunchKernelGGL(k_estep_lane, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
-                               d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace);
+            hipLaunchKernelGGL(k_estep_lane<false>, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
+                               d_theta, (const double*)nullptr, 0.0, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a,
+                               c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace);
     } else {
         hipLaunchKernelGGL(k_estep_sell, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
                            c->L.n_slices, d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, d_counts, c->d_noise_a, ctrl);
@@ -834,8 +882,8 @@ int launch_mstep(rsem_em_ctx* c, double N0, double* d_counts, const double* d_th
     const int grid = std::max(1, std::min(kMstepBlocks, rsem::ceil_div((uint64_t)c->M + 1, kBlock * 4)));
     if (c->use_totals) {
         const int gridf = std::max(1, std::min(2 * kMstepBlocks, rsem::ceil_div((uint64_t)c->M + 1, kBlock * 2)));
-        hipLaunchKernelGGL(k_mstep_fast, dim3(gridf), dim3(kBlock), 0, st, c->M, N0, d_counts, c->d_totals, d_theta_old, d_theta_new,
-                           c->d_counts_last, c->d_ctrl, round, min_round, max_round, mirror);
+        hipLaunchKernelGGL(k_mstep_fast<false>, dim3(gridf), dim3(kBlock), 0, st, c->M, N0, d_counts, c->d_totals, d_theta_old, d_theta_new,
+                           c->d_counts_last, c->d_ctrl, round, min_round, max_round, mirror, (double*)nullptr);
         RSEM_HIP_TRY(hipGetLastError());
         return RSEM_OK;
     }
@@ -943,7 +991,8 @@ int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64
         c->have_values = true;
     }
     for (int i = 0; i < 2; i++) TRY_OR_FAIL(dmalloc(&c->d_theta[i], (size_t)M + 1));
-    TRY_OR_FAIL(dmalloc(&c->d_red, (size_t)M + 1 + 2 * kTotSlots));
+    TRY_OR_FAIL(dmalloc(&c->d_red3, 3 * ((size_t)M + 1 + 2 * kTotSlots)));
+    c->d_red = c->d_red3;
     c->d_counts = c->d_red;
     c->d_totals = c->d_red + (size_t)M + 1;
     TRY_OR_FAIL(dmalloc(&c->d_counts_last, (size_t)M + 1));
@@ -952,6 +1001,11 @@ int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64
     TRY_OR_FAIL(hipHostMalloc((void**)&c->mirror, sizeof(HostMirror), hipHostMallocDefault));
     memset(c->mirror, 0, sizeof(HostMirror));
     for (int i = 0; i < 2; i++) TRY_OR_FAIL(hipEventCreateWithFlags(&c->lag_ev[i], hipEventDisableTiming));
+    TRY_OR_FAIL(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) {
+        TRY_OR_FAIL(hipEventCreateWithFlags(&c->ev_e[i], hipEventDisableTiming));
+        TRY_OR_FAIL(hipEventCreateWithFlags(&c->ev_s[i], hipEventDisableTiming));
+    }
     TRY_OR_FAIL(dmalloc(&c->d_partials, 2 * kReduceBlocks));
     TRY_OR_FAIL(dmalloc(&c->d_ctrl, 1));
     TRY_OR_FAIL(hipMemsetAsync(c->d_counts, 0, sizeof(double) * ((size_t)M + 1), c->stream));
@@ -1065,7 +1119,9 @@ int rsem_em_destroy(rsem_em_ctx* c) {
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     hipFree(c->d_row_ptr); hipFree(c->d_sid); hipFree(c->d_cp); hipFree(c->d_ncp);
     sell_free(c->L); hipFree(c->d_scp); hipFree(c->d_sncp);
-    hipFree(c->d_theta[0]); hipFree(c->d_theta[1]); hipFree(c->d_red);
+    hipFree(c->d_theta[0]); hipFree(c->d_theta[1]); hipFree(c->d_red3);
+    for (int i = 0; i < 4; i++) { if (c->ev_e[i]) (void)hipEventDestroy(c->ev_e[i]); if (c->ev_s[i]) (void)hipEventDestroy(c->ev_s[i]); }
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     hipFree(c->d_counts_last); hipFree(c->d_noise_a); hipFree(c->d_noise_b); hipFree(c->d_partials);
     if (c->mirror) (void)hipHostFree(c->mirror);
     for (int i = 0; i < 2; i++) if (c->lag_ev[i]) (void)hipEventDestroy(c->lag_ev[i]);
@@ -1109,6 +1165,24 @@ static int tune_unit_order(rsem_em_ctx* c, const double* d_theta) {
     }
     return RSEM_OK;
 }
+
+namespace {
+// The fused loop's first round reads theta out of a [counts | totals] buffer like every other round: the caller's theta
+// goes in as the counts, with totals chosen so that the round's formula returns it unchanged -- noise + N0 = 0 and
+// normaliser total + N0 = 1 (N0 is an integer below 2^31: both sums are exact; x + 0 and x / 1 are exact).
+__global__ void k_seed_theta_source(int32_t M, const double* __restrict__ theta, double N0, double* buf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = M + 1;
+    if (i < n) buf[i] = theta[i];
+    if (i < 2 * kTotSlots) buf[n + i] = (i == 0) ? -N0 : (i == kTotSlots ? 1.0 - N0 : 0.0);
+}
+
+bool fused_loop_wanted(const rsem_em_ctx* c) {
+    const char* e = getenv("RSEM_EM_FUSED");
+    if (e && !strcmp(e, "0")) return false;
+    return resolved_kernel(c) == RSEM_EM_KERNEL_LANE && c->L.n_long_rows == 0 && c->n_units > 0;
+}
+}  // namespace
 
 int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_round, int max_round, int* rounds_done,
                 double* counts, double* bChange, int32_t* totNum, rsem_em_profile* prof) {
@@ -1162,34 +1236,75 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
         }
         printed = std::max(printed, upto);
     };
+    // FUSED loop (LANE kernel, no long rows): the E step of round r+1 reads theta straight out of round r's counts and
+    // totals (ThetaSrc), so it follows the E step of round r with nothing in between; the statistics / stop-rule kernel of
+    // round r (k_mstep_fast<true>) runs beside it on a second stream.  Three [counts | totals] buffers rotate: round r
+    // reads buffer (r-1) % 3, accumulates into r % 3; the statistics kernel of round r clears (r-1) % 3 for round r+2,
+    // which therefore waits for it (and so also sees its stop flag; the one E step launched past the stopping round only
+    // accumulates into a buffer nobody reads).  theta, counts_last and the ROUND lines come from the statistics kernels.
+    const bool fused = mir && fused_loop_wanted(c);
+    const size_t R = (size_t)c->M + 1 + 2 * kTotSlots;
+    hipStream_t st2 = c->stream2;
+    if (fused) {
+        RSEM_HIP_TRY(hipMemsetAsync(c->d_red3, 0, sizeof(double) * 3 * R, st));
+        hipLaunchKernelGGL(k_seed_theta_source, dim3(rsem::ceil_div((uint64_t)c->M + 1 + 2 * kTotSlots, kBlock)), dim3(kBlock), 0, st, c->M,
+                           (const double*)c->d_theta[round0 & 1], N0, c->d_red3 + (size_t)(round0 % 3) * R);
+        RSEM_HIP_TRY(hipGetLastError());
+    }
     int r = round0;
     while (r < max_round) {
         ++r;
         const double* th_old = c->d_theta[(r - 1) & 1];
         double* th_new = c->d_theta[r & 1];
         const int ti = r - round0 - 1;
-        if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[2 + 2 * ti], st));
-        int rc = launch_estep(c, th_old, c->d_counts, st, true);
-        if (rc != RSEM_OK) return rc;
-        if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));
-        if (sharded) {  // EM.cpp:385-389 across shards: counts and the two totals in one all-reduce
-            rc = rsem::comm_allreduce_sum_f64(c->comm, c->d_red, (size_t)c->M + 1 + 2 * kTotSlots, st);
+        int rc = RSEM_OK;
+        hipStream_t st_stats = st;  // the stream the round's statistics (and with them the stop flag) are produced on
+        if (fused) {
+            double* src = c->d_red3 + (size_t)((r - 1) % 3) * R;
+            double* dst = c->d_red3 + (size_t)(r % 3) * R;
+            if (r - round0 >= 3) RSEM_HIP_TRY(hipStreamWaitEvent(st, c->ev_s[(r - 2) & 3], 0));  // dst was cleared by round r-2's statistics
+            if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[2 + 2 * ti], st));
+            hipLaunchKernelGGL(k_estep_lane<true>, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
+                               (const double*)src, (const double*)(src + c->M + 1), N0, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
+                               c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr);
+            RSEM_HIP_TRY(hipGetLastError());
+            if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));
+            if (sharded) {  // EM.cpp:385-389 across shards
+                rc = rsem::comm_allreduce_sum_f64(c->comm, dst, R, st);
+                if (rc != RSEM_OK) return rc;
+            }
+            RSEM_HIP_TRY(hipEventRecord(c->ev_e[r & 3], st));
+            RSEM_HIP_TRY(hipStreamWaitEvent(st2, c->ev_e[r & 3], 0));
+            const int gridf = std::max(1, std::min(2 * kMstepBlocks, rsem::ceil_div((uint64_t)c->M + 1, kBlock * 2)));
+            hipLaunchKernelGGL(k_mstep_fast<true>, dim3(gridf), dim3(kBlock), 0, st2, c->M, N0, dst, dst + c->M + 1, th_old, th_new,
+                               c->d_counts_last, c->d_ctrl, r, min_round, max_round, mir, src);
+            RSEM_HIP_TRY(hipGetLastError());
+            RSEM_HIP_TRY(hipEventRecord(c->ev_s[r & 3], st2));
+            st_stats = st2;
+        } else {
+            if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[2 + 2 * ti], st));
+            rc = launch_estep(c, th_old, c->d_counts, st, true);
+            if (rc != RSEM_OK) return rc;
+            if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));
+            if (sharded) {  // EM.cpp:385-389 across shards: counts and the two totals in one all-reduce
+                rc = rsem::comm_allreduce_sum_f64(c->comm, c->d_red, R, st);
+                if (rc != RSEM_OK) return rc;
+            }
+            rc = launch_mstep(c, N0, c->d_counts, th_old, th_new, r, min_round, max_round, st, mir);
             if (rc != RSEM_OK) return rc;
         }
-        rc = launch_mstep(c, N0, c->d_counts, th_old, th_new, r, min_round, max_round, st, mir);
-        if (rc != RSEM_OK) return rc;
         const bool checkpoint = ((r - round0) % c->check_every == 0) || r == max_round;
         if (sharded || !mir) {
             if (r >= min_round && checkpoint) {
-                RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
-                RSEM_HIP_TRY(hipStreamSynchronize(st));
+                RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st_stats));
+                RSEM_HIP_TRY(hipStreamSynchronize(st_stats));
                 if (mir) report(h.done ? h.final_round : r);
                 if (h.done) break;
             }
             continue;
         }
         if (checkpoint) {
-            RSEM_HIP_TRY(hipEventRecord(c->lag_ev[lag & 1], st));
+            RSEM_HIP_TRY(hipEventRecord(c->lag_ev[lag & 1], st_stats));
             if (lag > 0) RSEM_HIP_TRY(hipEventSynchronize(c->lag_ev[(lag - 1) & 1]));
             ++lag;
         }
@@ -1197,9 +1312,14 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
         if (c->progress && seen > printed) report(seen);
         if (__atomic_load_n(&mir->done, __ATOMIC_ACQUIRE)) break;
     }
+    if (fused) {  // the statistics stream joins the main one
+        RSEM_HIP_TRY(hipEventRecord(c->lag_ev[0], st2));
+        RSEM_HIP_TRY(hipStreamWaitEvent(st, c->lag_ev[0], 0));
+    }
     if (prof) RSEM_HIP_TRY(hipEventRecord(c->events[1], st));
     RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
     RSEM_HIP_TRY(hipStreamSynchronize(st));
+    if (fused) RSEM_HIP_TRY(hipMemsetAsync(c->d_red3, 0, sizeof(double) * 3 * R, st));  // leave the shared scratch as the other entry points expect it
     if (!h.done) { rsem::set_last_error("EM loop ended without the device stop flag"); return RSEM_ERR_STATE; }
     const int fr = h.final_round;
     report(fr);

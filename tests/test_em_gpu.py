@@ -248,3 +248,31 @@ def test_more_than_2_to_32_alignments():
     oc[0] += 1000.0
     assert np.allclose(counts, oc, rtol=1e-9, atol=1e-6)
     assert abs(s - (1000.0 + N1)) < 1.0
+
+
+def test_fused_loop_equals_kernel_per_step_loop(monkeypatch):
+    """rsem_em_run's fused loop (the E step reads theta out of the previous round's counts; statistics / stop rule on a
+    second stream) against the E-step -> M-step kernel sequence (RSEM_EM_FUSED=0): theta_i is the same expression
+    evaluated in another kernel, so the runs agree to the noise of the floating-point atomics; same ROUND count, same
+    final statistics, every ROUND line present."""
+    wl = make_em_workload("small", seed=21)
+    M = wl["M"]
+    ctx = capi().EmContext(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
+    lines = []
+    ctx.set_progress(lambda r, s, b, t: lines.append((r, s, b, t)))
+    fused = ctx.run(wl["theta0"], wl["N0"], max_round=3000)
+    assert [l[0] for l in lines] == list(range(1, fused["rounds"] + 1))
+    assert abs(lines[-1][1] - (wl["N0"] + len(wl["row_ptr"]) - 1)) < 1e-6 and lines[-1][3] == fused["totNum"]
+    monkeypatch.setenv("RSEM_EM_FUSED", "0")
+    ctx.set_progress(None)
+    plain = ctx.run(wl["theta0"], wl["N0"], max_round=3000)
+    monkeypatch.delenv("RSEM_EM_FUSED")
+    assert fused["rounds"] == plain["rounds"] and fused["totNum"] == plain["totNum"]
+    assert np.allclose(fused["theta"], plain["theta"], rtol=1e-10, atol=1e-18)
+    assert np.allclose(fused["counts"], plain["counts"], rtol=1e-10, atol=1e-9)
+    oth, orounds, _, _ = orc.em_run(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["N0"], wl["theta0"], max_round=3000)
+    assert fused["rounds"] == orounds and np.allclose(fused["theta"], oth, rtol=1e-6, atol=1e-12)
+    # a start in the middle (round0 > 0, as rsem-run-em does after its model rounds) and a hard stop at max_round
+    part = ctx.run(wl["theta0"], wl["N0"], round0=11, min_round=20, max_round=37)
+    assert part["rounds"] == 37
+    ctx.close()
