@@ -210,6 +210,12 @@ def main():
     ap.add_argument("--gibbs-sweeps", type=int, default=30)
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: libraries that print to the C-level stdout (RCCL's version banner) are sent to
+    # stderr for the whole run, the line itself goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from rsem_amd import build, capi
     from tools.synth_data import make_em_workload, to_gibbs_items
@@ -382,7 +388,7 @@ def main():
                     line["cpu_baseline_port_1core"] = cpu_baseline_port(wl, budget_s=5.0)
                 line["cpu_baseline"] = cb
                 line["speedup_vs_cpu_baseline_rounds"] = line["value"] / cb["value"]
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if comm is not None:
         barrier()
         comm.close()

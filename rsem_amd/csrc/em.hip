@@ -1001,7 +1001,12 @@ int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64
     TRY_OR_FAIL(hipHostMalloc((void**)&c->mirror, sizeof(HostMirror), hipHostMallocDefault));
     memset(c->mirror, 0, sizeof(HostMirror));
     for (int i = 0; i < 2; i++) TRY_OR_FAIL(hipEventCreateWithFlags(&c->lag_ev[i], hipEventDisableTiming));
-    TRY_OR_FAIL(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    {   // the statistics kernels are tiny and sit on the next round's critical path: highest priority, so that they are
+        // dispatched as soon as workgroup slots free up instead of behind the E step's thousands of workgroups
+        int least = 0, greatest = 0;
+        TRY_OR_FAIL(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        TRY_OR_FAIL(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, greatest));
+    }
     for (int i = 0; i < 4; i++) {
         TRY_OR_FAIL(hipEventCreateWithFlags(&c->ev_e[i], hipEventDisableTiming));
         TRY_OR_FAIL(hipEventCreateWithFlags(&c->ev_s[i], hipEventDisableTiming));
@@ -1177,10 +1182,16 @@ __global__ void k_seed_theta_source(int32_t M, const double* __restrict__ theta,
     if (i < 2 * kTotSlots) buf[n + i] = (i == 0) ? -N0 : (i == kTotSlots ? 1.0 - N0 : 0.0);
 }
 
+// Measured (profiles/r02_fused_loop.log, same box, back to back): BASELINE configs[2] 1.0567 ms per round fused vs 1.0912
+// (the E step itself 1.030 vs 1.065 ms: it no longer starts behind the M-step kernel); configs[1] 0.1546 ms fused vs 0.1500:
+// the two stream hand-offs per round cost more than the 8 us M-step kernel they replace once a round is that short.
+// Hence: fused from ~2.5 GB of matrix per round on; RSEM_EM_FUSED=0 / 1 forces either loop (tests run both).
 bool fused_loop_wanted(const rsem_em_ctx* c) {
+    const bool possible = resolved_kernel(c) == RSEM_EM_KERNEL_LANE && c->L.n_long_rows == 0 && c->n_units > 0;
     const char* e = getenv("RSEM_EM_FUSED");
     if (e && !strcmp(e, "0")) return false;
-    return resolved_kernel(c) == RSEM_EM_KERNEL_LANE && c->L.n_long_rows == 0 && c->n_units > 0;
+    if (e && !strcmp(e, "1")) return possible;
+    return possible && 12ull * c->nnz + 16ull * c->N1 >= 2500000000ull;
 }
 }  // namespace
 

@@ -260,6 +260,7 @@ def test_fused_loop_equals_kernel_per_step_loop(monkeypatch):
     ctx = capi().EmContext(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
     lines = []
     ctx.set_progress(lambda r, s, b, t: lines.append((r, s, b, t)))
+    monkeypatch.setenv("RSEM_EM_FUSED", "1")  # (by default only matrices of BASELINE configs[2] size and up take the fused loop)
     fused = ctx.run(wl["theta0"], wl["N0"], max_round=3000)
     assert [l[0] for l in lines] == list(range(1, fused["rounds"] + 1))
     assert abs(lines[-1][1] - (wl["N0"] + len(wl["row_ptr"]) - 1)) < 1e-6 and lines[-1][3] == fused["totNum"]
@@ -273,6 +274,7 @@ def test_fused_loop_equals_kernel_per_step_loop(monkeypatch):
     oth, orounds, _, _ = orc.em_run(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["N0"], wl["theta0"], max_round=3000)
     assert fused["rounds"] == orounds and np.allclose(fused["theta"], oth, rtol=1e-6, atol=1e-12)
     # a start in the middle (round0 > 0, as rsem-run-em does after its model rounds) and a hard stop at max_round
+    monkeypatch.setenv("RSEM_EM_FUSED", "1")
     part = ctx.run(wl["theta0"], wl["N0"], round0=11, min_round=20, max_round=37)
     assert part["rounds"] == 37
     ctx.close()
