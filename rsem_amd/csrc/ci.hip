@@ -44,6 +44,17 @@ struct DevMem {  // frees what it owns on scope exit
     }
 };
 
+struct EventGuard {  // events / streams released on every exit path
+    hipEvent_t e = nullptr;
+    ~EventGuard() { if (e) (void)hipEventDestroy(e); }
+    hipError_t create() { return hipEventCreate(&e); }
+};
+struct StreamGuard {
+    hipStream_t s = nullptr;
+    ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
+    hipError_t create() { return hipStreamCreate(&s); }
+};
+
 // y[j][s] for transcripts j in this block's chunk, samples s = lane
 __global__ void __launch_bounds__(64) k_ci_draw(int32_t M, int32_t nS, int32_t nSpC, int32_t chunk, const int32_t* __restrict__ cvecs,
                                                   const double* __restrict__ w, const double* __restrict__ eel, double pseudoC,
@@ -67,10 +78,13 @@ __global__ void __launch_bounds__(64) k_ci_draw(int32_t M, int32_t nS, int32_t n
 }
 
 // sc[s] = 1e6 / T_s ; lbar[s] = (float)(L_s / T_s)   (calcCI.cpp:143-148)
-__global__ void k_ci_scales(int32_t nS, const double* __restrict__ T, const double* __restrict__ L, double* sc, float* lbar) {
+// A draw whose normaliser is below EPSILON (every transcript with weight drew zero) has no TPM: the reference stops at
+// assert(sum >= EPSILON) (calcCI.cpp:143); here the flag makes the call fail instead of letting 1e3 / 0 * 0 = NaN rows through.
+__global__ void k_ci_scales(int32_t nS, const double* __restrict__ T, const double* __restrict__ L, double* sc, float* lbar, int* bad) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nS) return;
     const double t = T[s];
+    if (!(t >= kEpsilon)) *bad = 1;
     sc[s] = t >= kEpsilon ? 1e6 / t : 0.0;
     lbar[s] = t >= kEpsilon ? (float)(L[s] / t) : 0.0f;
 }
@@ -259,6 +273,9 @@ struct Sampler {  // Y (M x nS, unnormalised), scale and l_bar per sample, on th
         for (int j = 1; j <= M; j++)
             if (eel[j] >= kEpsilon && mw[j] >= kEpsilon) w[j] = 1.0 / (mw[j] * eel[j]);  // calcCI.cpp:131,137-141
         int32_t* d_cv; double *d_w, *d_eel, *d_T, *d_L;
+        int* d_bad;
+        RSEM_HIP_TRY(mem.alloc(&d_bad, 1));
+        RSEM_HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(int), st));
         RSEM_HIP_TRY(mem.alloc(&d_Y, (size_t)M * nS));
         RSEM_HIP_TRY(mem.alloc(&d_sc, (size_t)nS));
         RSEM_HIP_TRY(mem.alloc(&d_lbar, (size_t)nS));
@@ -272,8 +289,9 @@ struct Sampler {  // Y (M x nS, unnormalised), scale and l_bar per sample, on th
         RSEM_HIP_TRY(hipMemcpyAsync(d_eel, eel, sizeof(double) * ((size_t)M + 1), hipMemcpyHostToDevice, st));
         RSEM_HIP_TRY(hipMemsetAsync(d_T, 0, sizeof(double) * nS, st));
         RSEM_HIP_TRY(hipMemsetAsync(d_L, 0, sizeof(double) * nS, st));
-        hipEvent_t e0, e1;
-        RSEM_HIP_TRY(hipEventCreate(&e0)); RSEM_HIP_TRY(hipEventCreate(&e1));
+        EventGuard g0, g1;
+        RSEM_HIP_TRY(g0.create()); RSEM_HIP_TRY(g1.create());
+        hipEvent_t e0 = g0.e, e1 = g1.e;
         RSEM_HIP_TRY(hipEventRecord(e0, st));
         // enough (sample block, transcript chunk) waves to fill 256 CUs several times over
         const int sblocks = rsem::ceil_div(nS, 64);
@@ -283,14 +301,19 @@ struct Sampler {  // Y (M x nS, unnormalised), scale and l_bar per sample, on th
         Philox ph{(uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x52534349u};  // 'RSCI'
         hipLaunchKernelGGL(k_ci_draw, dim3(sblocks, nchunks), dim3(64), 0, st, M, nS, nSpC, chunk, d_cv, d_w, d_eel, pseudoC, ph, d_Y,
                            d_T, d_L);
-        hipLaunchKernelGGL(k_ci_scales, dim3(rsem::ceil_div(nS, kBlock)), dim3(kBlock), 0, st, nS, d_T, d_L, d_sc, d_lbar);
+        hipLaunchKernelGGL(k_ci_scales, dim3(rsem::ceil_div(nS, kBlock)), dim3(kBlock), 0, st, nS, d_T, d_L, d_sc, d_lbar, d_bad);
         RSEM_HIP_TRY(hipEventRecord(e1, st));
+        int h_bad = 0;
+        RSEM_HIP_TRY(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
         RSEM_HIP_TRY(hipStreamSynchronize(st));
         RSEM_HIP_TRY(hipGetLastError());
         float ms = 0;
         RSEM_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
         sample_ms = ms;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (h_bad) {
+            rsem::set_last_error("a sampled expression vector sums to less than EPSILON (no transcript with weight and effective length): no TPM can be formed");
+            return RSEM_ERR_INVALID;
+        }
         return RSEM_OK;
     }
 };
@@ -308,8 +331,9 @@ extern "C" int rsem_ci_intervals(int device, int64_t nrows, int32_t nSamples, co
     RSEM_REQUIRE(nrows >= 0 && nSamples > 0 && rows && lb && ub && cqv, "bad arguments");
     RSEM_REQUIRE(confidence > 0.0 && confidence <= 1.0, "confidence must be in (0, 1]");
     RSEM_HIP_TRY(hipSetDevice(device));
-    hipStream_t st;
-    RSEM_HIP_TRY(hipStreamCreate(&st));
+    StreamGuard sg;
+    RSEM_HIP_TRY(sg.create());
+    hipStream_t st = sg.s;
     int rc = RSEM_OK;
     {
         const int64_t R = batch_rows(nSamples, std::max<int64_t>(nrows, 1));
@@ -326,7 +350,6 @@ extern "C" int rsem_ci_intervals(int device, int64_t nrows, int32_t nSamples, co
             rc = sorter.run(d_keys, n, confidence, lb + r0, ub + r0, cqv + r0);
         }
     }
-    (void)hipStreamDestroy(st);
     return rc;
 }
 
@@ -336,8 +359,9 @@ extern "C" int rsem_ci_sample(int device, int32_t M, int32_t nCV, int32_t nSpC, 
     if (rc != RSEM_OK) return rc;
     RSEM_REQUIRE(cvecs && eel && mw && tpm_samples && l_bars, "null argument");
     RSEM_HIP_TRY(hipSetDevice(device));
-    hipStream_t st;
-    RSEM_HIP_TRY(hipStreamCreate(&st));
+    StreamGuard sg;
+    RSEM_HIP_TRY(sg.create());
+    hipStream_t st = sg.s;
     const int32_t nS = nCV * nSpC;
     {
         Sampler S;
@@ -351,7 +375,6 @@ extern "C" int rsem_ci_sample(int device, int32_t M, int32_t nCV, int32_t nSpC, 
             }
         }
     }
-    (void)hipStreamDestroy(st);
     return rc;
 }
 
@@ -368,11 +391,13 @@ extern "C" int rsem_ci_calculate(int device, int32_t M, int32_t nCV, int32_t nSp
     const bool allele = trans_starts != nullptr;
     if (allele) RSEM_REQUIRE(m_trans > 0 && iso_tpm_ci && iso_fpkm_ci && trans_starts[0] == 1 && trans_starts[m_trans] == M + 1, "bad trans_starts");
     RSEM_HIP_TRY(hipSetDevice(device));
-    hipStream_t st;
-    RSEM_HIP_TRY(hipStreamCreate(&st));
+    StreamGuard sg;
+    RSEM_HIP_TRY(sg.create());
+    hipStream_t st = sg.s;
     const int32_t nS = nCV * nSpC;
-    hipEvent_t t0, t1;
-    RSEM_HIP_TRY(hipEventCreate(&t0)); RSEM_HIP_TRY(hipEventCreate(&t1));
+    EventGuard gt0, gt1;
+    RSEM_HIP_TRY(gt0.create()); RSEM_HIP_TRY(gt1.create());
+    hipEvent_t t0 = gt0.e, t1 = gt1.e;
     RSEM_HIP_TRY(hipEventRecord(t0, st));
     {
         Sampler S;
@@ -448,7 +473,5 @@ extern "C" int rsem_ci_calculate(int device, int32_t M, int32_t nCV, int32_t nSp
             }
         }
     }
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
-    (void)hipStreamDestroy(st);
     return rc;
 }

@@ -163,3 +163,15 @@ def test_calculate_consistent_with_own_samples():
 def test_bad_arguments():
     with pytest.raises(capi.RsemHipError):
         capi.ci_intervals(np.zeros((2, 5), np.float32), 1.5)
+
+
+def test_zero_normaliser_is_an_error_not_nan_rows():
+    """The reference stops at assert(sum >= EPSILON) (calcCI.cpp:143) when a sampled theta vector has no mass on any
+    transcript with an effective length; the drop-in reports RSEM_ERR_INVALID instead of writing NaN intervals."""
+    from rsem_amd import capi
+    M = 6
+    cv = np.full((4, M + 1), 3, np.int32)
+    eel = np.zeros(M + 1)  # no transcript has an effective length
+    with pytest.raises(capi.RsemHipError) as e:
+        capi.ci_calculate(cv, 5, eel, np.ones(M + 1), np.array([1, 4, M + 1], np.int32), 0.95, 1.0, seed=1)
+    assert e.value.status == -1 and "EPSILON" in str(e.value)
