@@ -232,9 +232,11 @@ __global__ __launch_bounds__(kBlk) void k_conprb_read(DevData D, DevTables T, do
     }
 }
 
+// Profile products shared between alignments (same_prev flags): pass 1 computes the product of a mate only for the HEAD of
+// every run of alignments whose window of that mate holds the same bases; pass 2 (k_conprb<.., true>) takes the head's value.
+// Same bases, same read, same multiplication order: the value is the one every alignment of the run would compute itself.
 template <bool kQ, bool kPE>
-__global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double* cp) {
-    // QProfile (100 x 5 x 5 doubles = 20 KB) is staged in LDS; the position-indexed Profile stays in global memory
+__global__ __launch_bounds__(kBlk) void k_profile_heads(DevData D, DevTables T, double* P1, double* P2) {
     __shared__ double s_prof[kQ ? 2500 : 1];
     if (kQ) {
         for (int i = threadIdx.x; i < 2500; i += blockDim.x) s_prof[i] = T.prof[i];
@@ -244,6 +246,42 @@ __global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double*
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= D.nnz) return;
     const uint32_t row = D.hit_row[j];
+    if (D.lq[row]) return;
+    const uint8_t f = D.same_prev[j];
+    if ((f & 1) && (!kPE || (f & 2))) return;
+    const int s = D.sid_signed[j];
+    const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
+    const int pos = D.pos[j];
+    if (!(f & 1)) {
+        const uint64_t r0 = D.roff8[0][row];
+        P1[j] = profile_prob<kQ>(prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, D.rlen[0][row], D.refw, D.soff[2 * sid + dir] + pos);
+    }
+    if (kPE && !(f & 2)) {
+        const uint64_t q0 = D.roff8[1][row];
+        P2[j] = profile_prob<kQ>(prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, D.rlen[1][row], D.refw,
+                                 D.soff[2 * sid + (!dir)] + (D.totLen[sid] - pos - D.insertL[j]));
+    }
+}
+
+template <bool kQ, bool kPE, bool kShared = false>
+__global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double* cp, const double* __restrict__ P1 = nullptr,
+                                                  const double* __restrict__ P2 = nullptr) {
+    // QProfile (100 x 5 x 5 doubles = 20 KB) is staged in LDS; the position-indexed Profile stays in global memory
+    __shared__ double s_prof[(kQ && !kShared) ? 2500 : 1];
+    if (kQ && !kShared) {
+        for (int i = threadIdx.x; i < 2500; i += blockDim.x) s_prof[i] = T.prof[i];
+        __syncthreads();
+    }
+    const double* prof = (kQ && !kShared) ? s_prof : T.prof;
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D.nnz) return;
+    const uint32_t row = D.hit_row[j];
+    // kShared: the product of mate m comes from the head of this alignment's run (walk back while the flag says "same")
+    auto shared_product = [&](const double* __restrict__ P, int bit) -> double {
+        uint64_t h = j;
+        while (D.same_prev[h] & bit) --h;
+        return P[h];
+    };
     double prob = 0.0;
     if (!D.lq[row]) {
         const int s = D.sid_signed[j];
@@ -271,7 +309,9 @@ __global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double*
                     value = ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, len1, totLen) * rspd_adj(T, fpos, effL, fullLen);
                 }
                 const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
-                prob = ori * value * profile_prob<kQ>(prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, D.soff[2 * sid + dir] + pos);
+                const double pp1 = kShared ? shared_product(P1, 1)
+                                           : profile_prob<kQ>(prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, D.soff[2 * sid + dir] + pos);
+                prob = ori * value * pp1;
                 if (prob < kEpsilon) prob = 0.0;
                 prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
             }
@@ -282,13 +322,15 @@ __global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double*
             if (!(fpos >= fullLen || ref_mask(D, sid, fpos))) {
                 const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
                 prob = ori * ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, insertLen, totLen) * rspd_adj(T, fpos, effL, fullLen);
-                prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len1, insertLen) *
-                        profile_prob<kQ>(prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, D.soff[2 * sid + dir] + pos);
+                const double pp1 = kShared ? shared_product(P1, 1)
+                                           : profile_prob<kQ>(prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, D.soff[2 * sid + dir] + pos);
+                prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len1, insertLen) * pp1;
                 const uint64_t q0 = D.roff8[1][row];
                 const int len2 = D.rlen[1][row];
                 const int m2pos = totLen - pos - insertLen, m2dir = !dir;
-                prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len2, insertLen) *
-                        profile_prob<kQ>(prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2, D.refw, D.soff[2 * sid + m2dir] + m2pos);
+                const double pp2 = kShared ? shared_product(P2, 2)
+                                           : profile_prob<kQ>(prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2, D.refw, D.soff[2 * sid + m2dir] + m2pos);
+                prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len2, insertLen) * pp2;
                 if (prob < kEpsilon) prob = 0.0;
                 prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
             }
@@ -475,34 +517,29 @@ __global__ __launch_bounds__(kBlk) void k_update(DevData D, DevTables T, const d
             if (s_gld[i] != 0.0) unsafeAtomicAdd(&A.gld[i], s_gld[i]);
 }
 
-// same_prev flags (DevData): one thread per read, once per model context
+// same_prev flags (DevData): one thread per alignment, once per model context
 template <bool kPE>
 __global__ __launch_bounds__(kBlk) void k_window_flags(DevData D, uint8_t* flags) {
-    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= D.N1) return;
-    const uint64_t fr = D.row_ptr[row], to = D.row_ptr[row + 1];
-    if (D.lq[row]) {  // never walked by the update kernel (and its coordinates were not range-checked)
-        for (uint64_t j = fr; j < to; j++) flags[j] = 0;
-        return;
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D.nnz) return;
+    const uint32_t row = D.hit_row[j];
+    uint8_t f = 0;
+    // low-quality reads are never walked (and their coordinates were not range-checked); a read's first alignment has no predecessor
+    if (!D.lq[row] && j > D.row_ptr[row]) {
+        auto windows = [&](uint64_t k, uint64_t& a1, uint64_t& a2) {
+            const int s = D.sid_signed[k];
+            const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
+            const int pos = D.pos[k];
+            a1 = D.soff[2 * sid + dir] + pos;
+            a2 = kPE ? D.soff[2 * sid + (!dir)] + (D.totLen[sid] - pos - D.insertL[k]) : 0;
+        };
+        uint64_t a1, a2, p1, p2;
+        windows(j, a1, a2);
+        windows(j - 1, p1, p2);
+        if (same_window(D.refw, a1, p1, D.rlen[0][row])) f |= 1;
+        if (kPE && same_window(D.refw, a2, p2, D.rlen[1][row])) f |= 2;
     }
-    const int len1 = D.rlen[0][row];
-    const int len2 = kPE ? D.rlen[1][row] : 0;
-    uint64_t p1 = 0, p2 = 0;
-    for (uint64_t j = fr; j < to; j++) {
-        const int s = D.sid_signed[j];
-        const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
-        const int pos = D.pos[j];
-        const uint64_t a1 = D.soff[2 * sid + dir] + pos;
-        uint64_t a2 = 0;
-        if (kPE) a2 = D.soff[2 * sid + (!dir)] + (D.totLen[sid] - pos - D.insertL[j]);
-        uint8_t f = 0;
-        if (j > fr) {
-            if (same_window(D.refw, a1, p1, len1)) f |= 1;
-            if (kPE && same_window(D.refw, a2, p2, len2)) f |= 2;
-        }
-        flags[j] = f;
-        p1 = a1; p2 = a2;
-    }
+    flags[j] = f;
 }
 
 // One thread per READ.  Consecutive alignments whose reference windows hold the same bases put the SAME (quality, reference
@@ -661,6 +698,7 @@ struct rsem_model_ctx {
     bool have_tables = false;
     int B_alloc = 0, gld_n = 0, mld_n = 0, prof_n = 0, noise_n = 0;
     std::vector<void*> owned;       // device allocations of the immutable data
+    double *d_P1 = nullptr, *d_P2 = nullptr;  // profile products of the run heads (k_profile_heads), [nnz] each
     // table buffers (re-uploaded every round)
     double *t_rspd_pdf = nullptr, *t_rspd_cdf = nullptr, *t_gld_pdf = nullptr, *t_gld_cdf = nullptr, *t_mld_pdf = nullptr,
            *t_mld_cdf = nullptr, *t_prof = nullptr, *t_noise = nullptr, *t_mw = nullptr;
@@ -683,8 +721,11 @@ int up_field(rsem_model_ctx* c, const T*& field, const T* src, size_t n, hipStre
 
 // Which variant runs.  Measured on 5 M read pairs / 56 M alignments (tools/profile_model_rounds.sh, profiles/r02_model_rounds.log):
 // update: per read 23.6 ms vs per alignment 38.1 ms (the LDS atomics are what the per-alignment kernel waits for);
-// conprb: per alignment 13.8 ms vs per read 49.7 ms (the product is cheap next to walking a read's alignments serially).
-// Default = the faster of each; RSEM_MODEL_KERNELS=alignment | read forces one family (cross-checks in tests/).
+// conprb: per alignment 13.8 ms vs per read 49.7 ms (the product is cheap next to walking a read's alignments serially);
+//         products shared between identical windows: 3.6 + 2.1 ms (profiles/r02c_model_rounds.log).
+// Default = the per-read update and, for conprb, the two-pass variant that shares the products between alignments with
+// identical windows (k_profile_heads + k_conprb<.., true>); RSEM_MODEL_KERNELS=alignment | read forces one family
+// (cross-checks in tests/).
 bool per_alignment_kernels(bool for_update) {
     const char* e = getenv("RSEM_MODEL_KERNELS");
     if (e && !strcmp(e, "alignment")) return true;
@@ -695,10 +736,19 @@ bool per_alignment_kernels(bool for_update) {
 template <bool kQ, bool kPE>
 int launch_conprb(rsem_model_ctx* c) {
     hipStream_t st = c->v.stream;
-    if (c->D.nnz && per_alignment_kernels(false))
-        hipLaunchKernelGGL((k_conprb<kQ, kPE>), dim3(rsem::ceil_div(c->D.nnz, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_cp);
-    else if (c->D.N1)
+    const char* fam = getenv("RSEM_MODEL_KERNELS");
+    if (c->D.nnz && fam && !strcmp(fam, "alignment"))
+        hipLaunchKernelGGL((k_conprb<kQ, kPE, false>), dim3(rsem::ceil_div(c->D.nnz, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_cp,
+                           (const double*)nullptr, (const double*)nullptr);
+    else if (c->D.N1 && fam && !strcmp(fam, "read"))
         hipLaunchKernelGGL((k_conprb_read<kQ, kPE>), dim3(rsem::ceil_div(c->D.N1, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_cp);
+    else if (c->D.nnz) {  // default: products once per run of identical windows, then one thread per alignment
+        if (!c->d_P1) RSEM_HIP_TRY(dmalloc(&c->d_P1, (size_t)c->D.nnz));
+        if (kPE && !c->d_P2) RSEM_HIP_TRY(dmalloc(&c->d_P2, (size_t)c->D.nnz));
+        hipLaunchKernelGGL((k_profile_heads<kQ, kPE>), dim3(rsem::ceil_div(c->D.nnz, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->d_P1, c->d_P2);
+        hipLaunchKernelGGL((k_conprb<kQ, kPE, true>), dim3(rsem::ceil_div(c->D.nnz, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_cp,
+                           (const double*)c->d_P1, (const double*)c->d_P2);
+    }
     if (c->D.N1)
         hipLaunchKernelGGL((k_noise<kQ, kPE>), dim3(rsem::ceil_div(c->D.N1, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_ncp);
     RSEM_HIP_TRY(hipGetLastError());
@@ -740,6 +790,7 @@ int rsem_model_destroy(rsem_model_ctx* c) {
     hipFree(c->t_rspd_pdf); hipFree(c->t_rspd_cdf); hipFree(c->t_gld_pdf); hipFree(c->t_gld_cdf); hipFree(c->t_mld_pdf);
     hipFree(c->t_mld_cdf); hipFree(c->t_prof); hipFree(c->t_noise); hipFree(c->t_mw);
     hipFree(c->a_prof); hipFree(c->a_noise); hipFree(c->a_rspd); hipFree(c->a_gld);
+    hipFree(c->d_P1); hipFree(c->d_P2);
     delete c;
     return RSEM_OK;
 }
@@ -865,9 +916,9 @@ int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_da
     if (dmalloc(&fl, d->nnz) != hipSuccess) { rsem_model_destroy(c); return RSEM_ERR_NOMEM; }
     c->owned.push_back(fl);
     D.same_prev = fl;
-    if (d->N1) {
-        if (pe) hipLaunchKernelGGL(k_window_flags<true>, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, D, fl);
-        else hipLaunchKernelGGL(k_window_flags<false>, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, D, fl);
+    if (d->nnz) {
+        if (pe) hipLaunchKernelGGL(k_window_flags<true>, dim3(rsem::ceil_div(d->nnz, kBlk)), dim3(kBlk), 0, st, D, fl);
+        else hipLaunchKernelGGL(k_window_flags<false>, dim3(rsem::ceil_div(d->nnz, kBlk)), dim3(kBlk), 0, st, D, fl);
     }
     if (hipStreamSynchronize(st) != hipSuccess) { rsem_model_destroy(c); return RSEM_ERR_HIP; }
     rsem::thread_stager().release();

@@ -226,7 +226,7 @@ def test_per_read_model_kernels_equal_per_alignment_kernels(name, tmp_path):
     out_r = _run([os.path.join(BIN, "rsem-run-em")] + args)
     th_r = rf.read_theta(os.path.join(dst, "stat", "s.theta"))
     ofg_r = rf.read_ofg(os.path.join(dst, "temp", "s.ofg"))
-    for family in ("alignment", "read"):  # the default mixes them (per-alignment conprb, per-read update)
+    for family in ("alignment", "read"):  # the default: two-pass conprb sharing the products, per-read update
         r = subprocess.run([os.path.join(BIN, "rsem-run-em")] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                            env=dict(os.environ, RSEM_MODEL_KERNELS=family))
         assert r.returncode == 0, r.stdout[-2000:]

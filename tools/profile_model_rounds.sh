@@ -1,19 +1,20 @@
 #!/bin/bash
 # Per-kernel times of the model rounds (1-11) of rsem-run-em on a generated PairedEndQModel input, for the per-read model
-# kernels (default) and the thread-per-alignment ones (RSEM_MODEL_KERNELS=alignment).   tools/profile_model_rounds.sh [n_reads] [M]
+# kernels of the default path and the thread-per-alignment ones (RSEM_MODEL_KERNELS=alignment; MODES="default alignment read").   tools/profile_model_rounds.sh [n_reads] [M]
 N=${1:-5263157}; M=${2:-200000}; D=/tmp/pmr
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf $D; tools/bin/gen_temp $D $N $M 3 20250925 100 nosam 5-16 | tail -1
 tools/bin/temp_to_rsb $D/temp/s $D/stat/s 3 > /dev/null
-for mode in read alignment; do
-  export RSEM_MODEL_KERNELS=$mode RSEM_HIP_NORMAL_EXIT=1
+for mode in ${MODES:-default alignment}; do
+  export RSEM_HIP_NORMAL_EXIT=1
+  if [ $mode = default ]; then unset RSEM_MODEL_KERNELS; else export RSEM_MODEL_KERNELS=$mode; fi
   rm -rf gpurun_out/pmr_$mode
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmr_$mode -o p -- rsem_amd/bin/rsem-run-em $D/ref 3 $D/s $D/temp/s $D/stat/s -q > /dev/null 2>&1
   echo "== RSEM_MODEL_KERNELS=$mode"
   python - <<PY
 import csv, glob
 f = glob.glob("gpurun_out/pmr_$mode/**/*kernel_stats.csv", recursive=True)
-for r in list(csv.DictReader(open(f[0])))[:9]:
+for r in list(csv.DictReader(open(f[0])))[:10]:
     n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
     print("%-44s calls %5s avg %10.1f us total %8.1f ms" % (n[:44], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 PY
