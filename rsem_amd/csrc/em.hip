@@ -413,19 +413,148 @@ __device__ inline ThetaSrc theta_src(const double* __restrict__ v, const double*
     return t;
 }
 
+// The one-kernel round (kSolo, rsem_em_run's default loop): besides their E-step work for round r, some workgroups close
+// a slice of round r-1 -- convergence statistics of theta_{r-1} (buffer `theta`) against theta_{r-2} (buffer `prev`),
+// EM.cpp:400-416 -- and clears that slice of `prev`, which is the buffer round r+1 accumulates into.  The last closer
+// to arrive applies the stop rule, writes the round's line to the host mirror and clears prev's totals (every other
+// closer has read them by then).  No M-step kernel, no second stream: a round IS this launch.
+struct SoloArgs {
+    double* prev = nullptr;     // [counts | totals] of round r-2
+    Ctrl* ctrl = nullptr;
+    HostMirror* mirror = nullptr;
+    int stat_round = 0;         // r-1, or 0 when there is no finished round to close yet
+    int min_round = 0, max_round = 0;
+};
+
+// Closing is latency (dependent trips to memory, one returning atomic on a word every closer hits), not bandwidth.
+// Measured: done at the END of every workgroup it kept the workgroup's LDS and wave slots idle for that long and cost
+// 18 % (configs[2]) to 90 % (configs[1]) of the E step; done by 1024 neighbouring workgroups their ~2000 same-line
+// atomics queued up behind each other (+40 us on either config).  So: kCloseMax workgroups spread evenly over the
+// launch order close a slice each in their PROLOGUE, the whole workgroup taking part, one pair of atomics per closer.
+constexpr int kCloseMax = 128;
+__device__ inline void solo_close_round(const SoloArgs& A, int M, double N0, const double* __restrict__ cur) {
+    const int n_close = min((int)gridDim.x, kCloseMax);
+    const int stride = (int)gridDim.x / n_close;
+    const int rel = (int)blockIdx.x - stride / 2;
+    if (rel < 0 || rel % stride != 0 || rel / stride >= n_close) return;  // (uniform over the workgroup)
+    const int me = rel / stride;
+    const int lane = threadIdx.x & 63;
+    const int n = M + 1;
+    const int per = (n + n_close - 1) / n_close;
+    const int lo = me * per, hi = min(n, lo + per);
+    constexpr int kPre = 8;
+    double pc[kPre], pp[kPre];
+    const bool pre = per <= kPre * kBlock;
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < kPre; k++) {
+            const int i = lo + (int)threadIdx.x + kBlock * k;
+            pc[k] = i < hi ? cur[i] : 0.0;
+            pp[k] = i < hi ? A.prev[i] : 0.0;
+        }
+    }
+    const double extra_c = wave_sum(cur[n + lane]) + N0, sum_c = wave_sum(cur[n + kTotSlots + lane]) + N0;
+    const double extra_p = wave_sum(A.prev[n + lane]) + N0, sum_p = wave_sum(A.prev[n + kTotSlots + lane]) + N0;
+    int tot = 0;
+    double bmax = 0.0;
+    auto one = [&](int i, double craw, double praw) {
+        const double th = (craw + (i == 0 ? extra_c : 0.0)) / sum_c;
+        const double old = (praw + (i == 0 ? extra_p : 0.0)) / sum_p;
+        A.prev[i] = 0.0;
+        if (old >= 1e-7) {
+            const double change = fabs(th - old) / old;
+            if (change >= 0.001) ++tot;
+            bmax = fmax(bmax, change);
+        }
+    };
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < kPre; k++) {
+            const int i = lo + (int)threadIdx.x + kBlock * k;
+            if (i < hi) one(i, pc[k], pp[k]);
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += kBlock) one(i, cur[i], A.prev[i]);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        tot += __shfl_xor(tot, d);
+        bmax = fmax(bmax, __shfl_xor(bmax, d));
+    }
+    __shared__ int s_tot[kBlock / 64];
+    __shared__ double s_b[kBlock / 64];
+    if (lane == 0) { s_tot[threadIdx.x >> 6] = tot; s_b[threadIdx.x >> 6] = bmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kBlock / 64; i++) { tot += s_tot[i]; bmax = fmax(bmax, s_b[i]); }
+        Ctrl* ctrl = A.ctrl;
+        // The arrival must not overtake the maximum.  No fence: an agent-scope fence in the middle of this kernel writes
+        // back and invalidates the XCD's L2 under everybody else's feet.  The arrival's operand is made to depend on the
+        // RETURN of the max instead (one more trip for this thread only).
+        unsigned int zero = 0;
+        if (bmax > 0.0) {
+            const unsigned long long was = __hip_atomic_fetch_max(&ctrl->bbits, (unsigned long long)__double_as_longlong(bmax),
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"((unsigned int)was));
+        }
+        const unsigned long long old = __hip_atomic_fetch_add(&ctrl->tick2, (((unsigned long long)(unsigned)tot << 32) | 1ull) + zero,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(old & 0xffffffffull) == n_close - 1) {  // last closer: stop rule (EM.cpp:416) for round stat_round
+            const int round = A.stat_round;
+            const int totNum = (int)(old >> 32) + tot;
+            const unsigned long long bb = __hip_atomic_load(&ctrl->bbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctrl->last_sum = sum_c;
+            ctrl->last_bchange = __longlong_as_double((long long)bb);
+            ctrl->last_totNum = totNum;
+            ctrl->last_round = round;
+            const bool stop = !(round < A.min_round || (totNum > 0 && round < A.max_round));
+            if (stop) {
+                ctrl->done = 1;
+                ctrl->final_round = round;
+            }
+            if (A.mirror) {
+                RoundStat* h = &A.mirror->hist[(round - 1) % kHistCap];
+                h->sum = sum_c;
+                h->bchange = __longlong_as_double((long long)bb);
+                h->totNum = totNum;
+                h->round = round;
+                if (stop) A.mirror->final_round = round;
+                __hip_atomic_store(&A.mirror->last_round, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (stop) __hip_atomic_store(&A.mirror->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __hip_atomic_store(&ctrl->bbits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctrl->tick2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < 2 * kTotSlots; k++) A.prev[n + k] = 0.0;  // every other closer has read them
+        }
+    }
+}
+
+// theta and counts of the round the one-kernel loop stopped at, from the buffer that round accumulated (EM.cpp:392-398)
+__global__ __launch_bounds__(kBlock) void k_solo_finish(int32_t M, double N0, const double* __restrict__ buf, double* theta, double* counts_last) {
+    const int n = M + 1;
+    const int lane = threadIdx.x & 63;
+    const double extra0 = wave_sum(buf[n + lane]) + N0, sum = wave_sum(buf[n + kTotSlots + lane]) + N0;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double c = buf[i] + (i == 0 ? extra0 : 0.0);
+        counts_last[i] = c;
+        theta[i] = c / sum;
+    }
+}
+
 // kFC: `theta` holds the previous round's raw counts, tsrc its totals (see ThetaSrc)
-template <bool kFC>
+template <bool kFC, bool kSolo = false>
 __global__ __launch_bounds__(kBlock) void k_estep_lane(
     const Shape* __restrict__ shapes, const Unit* __restrict__ units, uint32_t T, int M,
     const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, const double* __restrict__ scp,
     const int32_t* __restrict__ ssid, const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
-    double* counts, double* noise_partial, double* totals, const Ctrl* ctrl, unsigned long long* trace) {
+    double* counts, double* noise_partial, double* totals, const Ctrl* ctrl, unsigned long long* trace, SoloArgs solo = SoloArgs()) {
     if (ctrl->done) return;
     if (trace && threadIdx.x == 0) trace[2 * blockIdx.x] = wall_clock64();  // rsem_em_debug_trace only
     __shared__ double th_win[kWindow];
     __shared__ double cnt_win[kWindow];
     const Unit U = units[blockIdx.x];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (kSolo && solo.stat_round > 0) solo_close_round(solo, M, N0, theta);
     double noise = 0.0, neff = 0.0;
     {
         const Shape& G = U.S;
@@ -733,10 +862,15 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, dou
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int i = 1; i < kBlock / 64; i++) { tot += s_tot[i]; bmax = fmax(bmax, s_b[i]); }
-        // one fire-and-forget max, one returning add that carries both this workgroup's count and its arrival
-        (void)__hip_atomic_fetch_max(&ctrl->bbits, (unsigned long long)__double_as_longlong(bmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        const unsigned long long old = __hip_atomic_fetch_add(&ctrl->tick2, ((unsigned long long)(unsigned)tot << 32) | 1ull,
+        // one max, one returning add that carries both this workgroup's count and its arrival; the add follows the max by a
+        // data dependency instead of a fence (see solo_close_round: this kernel runs beside an E step in the fused loop)
+        unsigned int zero = 0;
+        if (bmax > 0.0) {
+            const unsigned long long was = __hip_atomic_fetch_max(&ctrl->bbits, (unsigned long long)__double_as_longlong(bmax),
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"((unsigned int)was));
+        }
+        const unsigned long long old = __hip_atomic_fetch_add(&ctrl->tick2, (((unsigned long long)(unsigned)tot << 32) | 1ull) + zero,
                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(old & 0xffffffffull) == gridDim.x - 1) {  // last workgroup: stop rule (EM.cpp:416)
             const int totNum = (int)(old >> 32) + tot;
@@ -847,9 +981,9 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
     }
     if (kern == RSEM_EM_KERNEL_LANE) {
         if (c->n_units)
-            hipLaunchKernelGGL(k_estep_lane<false>, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
+            hipLaunchKernelGGL((k_estep_lane<false, false>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
                                d_theta, (const double*)nullptr, 0.0, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a,
-                               c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace);
+                               c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs());
     } else {
         hipLaunchKernelGGL(k_estep_sell, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
                            c->L.n_slices, d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, d_counts, c->d_noise_a, ctrl);
@@ -1182,16 +1316,24 @@ __global__ void k_seed_theta_source(int32_t M, const double* __restrict__ theta,
     if (i < 2 * kTotSlots) buf[n + i] = (i == 0) ? -N0 : (i == kTotSlots ? 1.0 - N0 : 0.0);
 }
 
-// Measured (profiles/r02_fused_loop.log, same box, back to back): BASELINE configs[2] 1.0567 ms per round fused vs 1.0912
-// (the E step itself 1.030 vs 1.065 ms: it no longer starts behind the M-step kernel); configs[1] 0.1546 ms fused vs 0.1500:
-// the two stream hand-offs per round cost more than the 8 us M-step kernel they replace once a round is that short.
-// Hence: fused from ~2.5 GB of matrix per round on; RSEM_EM_FUSED=0 / 1 forces either loop (tests run both).
-bool fused_loop_wanted(const rsem_em_ctx* c) {
+// Measured (profiles/r02c_em_loops.log, same box, back to back), ms per round on BASELINE configs[2] / configs[1]:
+//   plain (E-step kernel, M-step kernel)          1.102 / 0.1393
+//   fused (statistics kernel on a second stream)  1.042 / 0.1468   (two stream hand-offs per round)
+//   solo  (one launch per round)                  1.051 / 0.1333   (E-step launch itself 1.038 / 0.1322)
+// On configs[2] the E step gains 5 % from not starting behind an M-step kernel; on configs[1] the round is so short that
+// only the one-launch round wins.  RSEM_EM_FUSED=0 / 1 / 2 forces plain / fused / solo (tests run all three).
+// The one-kernel round (SOLO, k_estep_lane<true, true>) needs neither stream hand-off nor M-step kernel and is the default
+// whenever the counts need not cross devices between the E step and theta; RSEM_EM_FUSED=2 asks for it explicitly.
+enum class Loop { PLAIN, FUSED, SOLO };
+Loop loop_wanted(const rsem_em_ctx* c, bool sharded) {
     const bool possible = resolved_kernel(c) == RSEM_EM_KERNEL_LANE && c->L.n_long_rows == 0 && c->n_units > 0;
+    if (!possible) return Loop::PLAIN;
     const char* e = getenv("RSEM_EM_FUSED");
-    if (e && !strcmp(e, "0")) return false;
-    if (e && !strcmp(e, "1")) return possible;
-    return possible && 12ull * c->nnz + 16ull * c->N1 >= 2500000000ull;
+    if (e && !strcmp(e, "0")) return Loop::PLAIN;
+    if (e && !strcmp(e, "1")) return Loop::FUSED;
+    if (e && !strcmp(e, "2") && !sharded) return Loop::SOLO;
+    if (!sharded) return Loop::SOLO;
+    return 12ull * c->nnz + 16ull * c->N1 >= 2500000000ull ? Loop::FUSED : Loop::PLAIN;
 }
 }  // namespace
 
@@ -1253,31 +1395,52 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
     // reads buffer (r-1) % 3, accumulates into r % 3; the statistics kernel of round r clears (r-1) % 3 for round r+2,
     // which therefore waits for it (and so also sees its stop flag; the one E step launched past the stopping round only
     // accumulates into a buffer nobody reads).  theta, counts_last and the ROUND lines come from the statistics kernels.
-    const bool fused = mir && fused_loop_wanted(c);
+    const Loop loop = mir ? loop_wanted(c, sharded) : Loop::PLAIN;
+    const bool fused = loop == Loop::FUSED, solo = loop == Loop::SOLO;
     const size_t R = (size_t)c->M + 1 + 2 * kTotSlots;
     hipStream_t st2 = c->stream2;
-    if (fused) {
+    // SOLO: round r is ONE launch (see SoloArgs); the same three rotating buffers, seeded the same way.  Round q's line and
+    // stop decision come out of launch q+1, so the loop issues one launch past max_round (whose own E-step work is unused,
+    // like the one launch the device makes past any stopping round).
+    const int last_launch = solo ? max_round + 1 : max_round;
+    if (fused || solo) {
         RSEM_HIP_TRY(hipMemsetAsync(c->d_red3, 0, sizeof(double) * 3 * R, st));
         hipLaunchKernelGGL(k_seed_theta_source, dim3(rsem::ceil_div((uint64_t)c->M + 1 + 2 * kTotSlots, kBlock)), dim3(kBlock), 0, st, c->M,
                            (const double*)c->d_theta[round0 & 1], N0, c->d_red3 + (size_t)(round0 % 3) * R);
         RSEM_HIP_TRY(hipGetLastError());
     }
     int r = round0;
-    while (r < max_round) {
+    while (r < last_launch) {
         ++r;
         const double* th_old = c->d_theta[(r - 1) & 1];
         double* th_new = c->d_theta[r & 1];
         const int ti = r - round0 - 1;
         int rc = RSEM_OK;
         hipStream_t st_stats = st;  // the stream the round's statistics (and with them the stop flag) are produced on
-        if (fused) {
+        if (solo) {
+            double* src = c->d_red3 + (size_t)((r - 1) % 3) * R;
+            double* dst = c->d_red3 + (size_t)(r % 3) * R;
+            SoloArgs sa;
+            sa.prev = c->d_red3 + (size_t)((r + 1) % 3) * R;  // = (r - 2) % 3
+            sa.ctrl = c->d_ctrl;
+            sa.mirror = mir;
+            sa.stat_round = r - 1 > round0 ? r - 1 : 0;
+            sa.min_round = min_round;
+            sa.max_round = max_round;
+            if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[2 + 2 * ti], st));
+            hipLaunchKernelGGL((k_estep_lane<true, true>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
+                               (const double*)src, (const double*)(src + c->M + 1), N0, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
+                               c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, sa);
+            RSEM_HIP_TRY(hipGetLastError());
+            if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));
+        } else if (fused) {
             double* src = c->d_red3 + (size_t)((r - 1) % 3) * R;
             double* dst = c->d_red3 + (size_t)(r % 3) * R;
             if (r - round0 >= 3) RSEM_HIP_TRY(hipStreamWaitEvent(st, c->ev_s[(r - 2) & 3], 0));  // dst was cleared by round r-2's statistics
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[2 + 2 * ti], st));
-            hipLaunchKernelGGL(k_estep_lane<true>, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
+            hipLaunchKernelGGL((k_estep_lane<true, false>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
                                (const double*)src, (const double*)(src + c->M + 1), N0, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
-                               c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr);
+                               c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, SoloArgs());
             RSEM_HIP_TRY(hipGetLastError());
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));
             if (sharded) {  // EM.cpp:385-389 across shards
@@ -1304,7 +1467,7 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
             rc = launch_mstep(c, N0, c->d_counts, th_old, th_new, r, min_round, max_round, st, mir);
             if (rc != RSEM_OK) return rc;
         }
-        const bool checkpoint = ((r - round0) % c->check_every == 0) || r == max_round;
+        const bool checkpoint = ((r - round0) % c->check_every == 0) || r == last_launch;
         if (sharded || !mir) {
             if (r >= min_round && checkpoint) {
                 RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st_stats));
@@ -1330,9 +1493,14 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
     if (prof) RSEM_HIP_TRY(hipEventRecord(c->events[1], st));
     RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
     RSEM_HIP_TRY(hipStreamSynchronize(st));
-    if (fused) RSEM_HIP_TRY(hipMemsetAsync(c->d_red3, 0, sizeof(double) * 3 * R, st));  // leave the shared scratch as the other entry points expect it
     if (!h.done) { rsem::set_last_error("EM loop ended without the device stop flag"); return RSEM_ERR_STATE; }
     const int fr = h.final_round;
+    if (solo) {  // nothing wrote theta or the final counts on the way: they are in the buffer the stopping round accumulated
+        hipLaunchKernelGGL(k_solo_finish, dim3(rsem::ceil_div((uint64_t)c->M + 1, kBlock)), dim3(kBlock), 0, st, c->M, N0,
+                           (const double*)(c->d_red3 + (size_t)(fr % 3) * R), c->d_theta[fr & 1], c->d_counts_last);
+        RSEM_HIP_TRY(hipGetLastError());
+    }
+    if (fused || solo) RSEM_HIP_TRY(hipMemsetAsync(c->d_red3, 0, sizeof(double) * 3 * R, st));  // leave the shared scratch as the other entry points expect it
     report(fr);
     RSEM_HIP_TRY(hipMemcpyAsync(theta, c->d_theta[fr & 1], nb, hipMemcpyDeviceToHost, st));
     if (counts) RSEM_HIP_TRY(hipMemcpyAsync(counts, c->d_counts_last, nb, hipMemcpyDeviceToHost, st));

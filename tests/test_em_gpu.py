@@ -250,31 +250,51 @@ def test_more_than_2_to_32_alignments():
     assert abs(s - (1000.0 + N1)) < 1.0
 
 
-def test_fused_loop_equals_kernel_per_step_loop(monkeypatch):
-    """rsem_em_run's fused loop (the E step reads theta out of the previous round's counts; statistics / stop rule on a
-    second stream) against the E-step -> M-step kernel sequence (RSEM_EM_FUSED=0): theta_i is the same expression
-    evaluated in another kernel, so the runs agree to the noise of the floating-point atomics; same ROUND count, same
-    final statistics, every ROUND line present."""
+@pytest.mark.parametrize("loop", ["solo", "fused"])
+def test_device_loops_equal_kernel_per_step_loop(loop, monkeypatch):
+    """rsem_em_run's loops that never materialise theta between rounds -- the E step reads theta out of the previous
+    round's counts -- against the E-step -> M-step kernel sequence (RSEM_EM_FUSED=0).  "solo" (the default): a round is
+    ONE launch, whose workgroups also close the previous round (statistics, stop rule, ROUND line); "fused" (sharded
+    runs on large matrices): statistics on a second stream.  theta_i is the same expression evaluated in another kernel,
+    so the runs agree to the noise of the floating-point atomics; same ROUND count, same final statistics, every ROUND
+    line present."""
     wl = make_em_workload("small", seed=21)
     M = wl["M"]
     ctx = capi().EmContext(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
     lines = []
     ctx.set_progress(lambda r, s, b, t: lines.append((r, s, b, t)))
-    monkeypatch.setenv("RSEM_EM_FUSED", "1")  # (by default only matrices of BASELINE configs[2] size and up take the fused loop)
-    fused = ctx.run(wl["theta0"], wl["N0"], max_round=3000)
-    assert [l[0] for l in lines] == list(range(1, fused["rounds"] + 1))
-    assert abs(lines[-1][1] - (wl["N0"] + len(wl["row_ptr"]) - 1)) < 1e-6 and lines[-1][3] == fused["totNum"]
+    if loop == "fused":
+        monkeypatch.setenv("RSEM_EM_FUSED", "1")
+    else:
+        monkeypatch.delenv("RSEM_EM_FUSED", raising=False)
+    dev = ctx.run(wl["theta0"], wl["N0"], max_round=3000)
+    assert [l[0] for l in lines] == list(range(1, dev["rounds"] + 1))
+    assert abs(lines[-1][1] - (wl["N0"] + len(wl["row_ptr"]) - 1)) < 1e-6 and lines[-1][3] == dev["totNum"]
     monkeypatch.setenv("RSEM_EM_FUSED", "0")
     ctx.set_progress(None)
     plain = ctx.run(wl["theta0"], wl["N0"], max_round=3000)
-    monkeypatch.delenv("RSEM_EM_FUSED")
-    assert fused["rounds"] == plain["rounds"] and fused["totNum"] == plain["totNum"]
-    assert np.allclose(fused["theta"], plain["theta"], rtol=1e-10, atol=1e-18)
-    assert np.allclose(fused["counts"], plain["counts"], rtol=1e-10, atol=1e-9)
+    assert dev["rounds"] == plain["rounds"] and dev["totNum"] == plain["totNum"]
+    assert np.allclose(dev["theta"], plain["theta"], rtol=1e-10, atol=1e-18)
+    assert np.allclose(dev["counts"], plain["counts"], rtol=1e-10, atol=1e-9)
+    assert abs(dev["bChange"] - plain["bChange"]) <= 1e-6 * max(1e-30, abs(plain["bChange"]))
     oth, orounds, _, _ = orc.em_run(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["N0"], wl["theta0"], max_round=3000)
-    assert fused["rounds"] == orounds and np.allclose(fused["theta"], oth, rtol=1e-6, atol=1e-12)
-    # a start in the middle (round0 > 0, as rsem-run-em does after its model rounds) and a hard stop at max_round
-    monkeypatch.setenv("RSEM_EM_FUSED", "1")
+    assert dev["rounds"] == orounds and np.allclose(dev["theta"], oth, rtol=1e-6, atol=1e-12)
+    # a start in the middle (round0 > 0, as rsem-run-em does after its model rounds), a hard stop at max_round, one round only
+    if loop == "fused":
+        monkeypatch.setenv("RSEM_EM_FUSED", "1")
+    else:
+        monkeypatch.delenv("RSEM_EM_FUSED")
     part = ctx.run(wl["theta0"], wl["N0"], round0=11, min_round=20, max_round=37)
     assert part["rounds"] == 37
+    monkeypatch.setenv("RSEM_EM_FUSED", "0")
+    part0 = ctx.run(wl["theta0"], wl["N0"], round0=11, min_round=20, max_round=37)
+    assert part0["rounds"] == 37 and part["totNum"] == part0["totNum"] and np.allclose(part["theta"], part0["theta"], rtol=1e-10, atol=1e-18)
+    one0 = ctx.run(wl["theta0"], wl["N0"], round0=0, min_round=1, max_round=1)
+    if loop == "fused":
+        monkeypatch.setenv("RSEM_EM_FUSED", "1")
+    else:
+        monkeypatch.delenv("RSEM_EM_FUSED")
+    one = ctx.run(wl["theta0"], wl["N0"], round0=0, min_round=1, max_round=1)
+    assert one["rounds"] == one0["rounds"] == 1 and one["totNum"] == one0["totNum"]
+    assert np.allclose(one["theta"], one0["theta"], rtol=1e-12, atol=1e-18) and np.allclose(one["counts"], one0["counts"], rtol=1e-12, atol=1e-9)
     ctx.close()
