@@ -174,7 +174,38 @@ def timed_rounds(ctx, wl, N0, K, W, sync, barrier, agree=lambda x: x):
     return elapsed, reps * K, reps, estep_ms, float(out["theta"].sum())
 
 
-def em_leg(capi, make_em_workload, config, K, W, kernel, sync, device):
+def q32_leg(ctx, wl, N0, K, W, sync, alg_bytes, f64_ms_per_step, f64_estep_ms):
+    """The same context with Q32 value planes (rsem_em_set_option "value_bits" 32: 32-bit mantissas + one exponent per
+    read for the reads that qualify, include/rsem_hip.h) -- same rounds, same procedure, reported BESIDE the headline,
+    which stays on the doubles.  Also: theta after K rounds in both formats."""
+    try:
+        N1, nnz, M = len(wl["row_ptr"]) - 1, len(wl["sid"]), wl["M"]
+        ref = ctx.run(wl["theta0"], N0, min_round=K, max_round=K)["theta"]
+        bytes64 = ctx.info("value_plane_bytes")
+        t0 = time.perf_counter()
+        ctx.set_option("value_bits", 32)
+        relayout_s = time.perf_counter() - t0
+        bytes32, n_q32 = ctx.info("value_plane_bytes"), ctx.info("reads_q32")
+        el, rounds, reps, estep_ms, ts = timed_rounds(ctx, wl, N0, K, W, sync, lambda: None)
+        th = ctx.run(wl["theta0"], N0, min_round=K, max_round=K)["theta"]
+        ctx.set_option("value_bits", 64)
+        big = ref >= 1e-7
+        own = alg_bytes - (bytes64 - bytes32) + 2 * n_q32  # what this layout stores per round instead of the doubles
+        return {"value_bits": 32, "value_range_bits": ctx.info("value_range_bits"), "reads_q32_fraction": n_q32 / max(N1, 1),
+                "value_plane_bytes_f64": bytes64, "value_plane_bytes_q32": bytes32, "relayout_s": relayout_s,
+                "ms_per_step": el * 1e3 / rounds, "timed_rounds": rounds, "timed_region_s": el, "value": nnz * rounds / el,
+                "estep_avg_launch_ms": estep_ms, "speedup_step_vs_f64": f64_ms_per_step / (el * 1e3 / rounds),
+                "speedup_launch_vs_f64": f64_estep_ms / estep_ms,
+                "bytes_per_launch_this_format": own, "achieved_GBps_this_format": own / (estep_ms * 1e-3) / 1e9,
+                "frac_this_format": own / (estep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "frac_by_the_f64_formula": alg_bytes / (estep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "theta_max_rel_diff_vs_f64_after_%d_rounds" % K: float(np.max(np.abs(th - ref)[big] / ref[big])) if big.any() else 0.0,
+                "theta_sum": ts}
+    except Exception as e:
+        return {"error": str(e)}
+
+
+def em_leg(capi, make_em_workload, config, K, W, kernel, sync, device, q32=False):
     """One extra single-GPU E-step measurement on another BASELINE config (same procedure as the headline)."""
     try:
         t0 = time.perf_counter()
@@ -184,13 +215,16 @@ def em_leg(capi, make_em_workload, config, K, W, kernel, sync, device):
         ctx = capi.EmContext(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], device=device)
         ctx.set_option("kernel", kernel)
         el, rounds, reps, estep_ms, ts = timed_rounds(ctx, wl, wl["N0"], K, W, sync, lambda: None)
-        ctx.close()
         alg = 12 * nnz + 16 * N1 + 16 * (M + 1)
         ach = alg / (estep_ms * 1e-3) / 1e9
-        return {"workload": "%s: %d reads x %d transcripts, %d alignments" % (WORKLOADS.get(config, config), N1, M, nnz),
-                "ms_per_step": el * 1e3 / rounds, "timed_rounds": rounds, "timed_region_s": el, "value": nnz * rounds / el,
-                "estep_avg_launch_ms": estep_ms, "algorithmic_bytes_per_launch": alg, "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS,
-                "theta_sum": ts, "generate_s": gen_s}
+        out = {"workload": "%s: %d reads x %d transcripts, %d alignments" % (WORKLOADS.get(config, config), N1, M, nnz),
+               "ms_per_step": el * 1e3 / rounds, "timed_rounds": rounds, "timed_region_s": el, "value": nnz * rounds / el,
+               "estep_avg_launch_ms": estep_ms, "algorithmic_bytes_per_launch": alg, "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS,
+               "theta_sum": ts, "generate_s": gen_s}
+        if q32 and kernel in (0, 3):
+            out["q32_value_planes"] = q32_leg(ctx, wl, wl["N0"], K, W, sync, alg, el * 1e3 / rounds, estep_ms)
+        ctx.close()
+        return out
     except Exception as e:
         return {"error": str(e)}
 
@@ -204,6 +238,9 @@ def main():
     ap.add_argument("--legs", default="C2,C2R", help="extra single-GPU E-step legs on other configs (comma list, '' for none)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--no-q32", action="store_true", help="skip the Q32 value-plane measurement beside the headline")
+    ap.add_argument("--value-bits", type=int, default=64, choices=(64, 32),
+                    help="32: the HEADLINE context itself streams Q32 value planes (profiling runs; the default line stays on the doubles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gibbs", action="store_true")
     ap.add_argument("--no-ci", action="store_true")
@@ -259,6 +296,8 @@ def main():
     t0 = time.perf_counter()
     ctx = capi.EmContext(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], device=local)
     ctx.set_option("kernel", args.kernel)
+    if args.value_bits == 32:
+        ctx.set_option("value_bits", 32)
     upload_s = time.perf_counter() - t0
     log("[rank %d] upload + device layout: %.2f s" % (rank, upload_s))
     alg_bytes = 12 * nnz + 16 * N1 + 16 * (M + 1)
@@ -332,6 +371,9 @@ def main():
         except Exception as e:  # the EM line must still be printed
             gibbs = {"error": str(e)}
 
+    q32 = None
+    if world == 1 and not distributed and not args.no_q32 and args.value_bits == 64 and args.kernel in (0, 3):
+        q32 = q32_leg(ctx, wl, N0g, K, W, sync, alg_bytes, elapsed * 1e3 / rounds, estep_ms)
     ctx.close()
     if rank == 0:
         achieved = alg_bytes / (estep_ms * 1e-3) / 1e9
@@ -351,7 +393,7 @@ def main():
             "em_iterations_per_s": rounds / elapsed, "timed_rounds": rounds, "timed_region_s": elapsed, "timed_repeats_of_steps": reps,
             "config": {"workload": "%s: EM matrix of %d reads x %d transcripts, %d alignments (%.2f/read) per GPU, frozen conprb "
                                    "(rounds >= 12)" % (WORKLOADS.get(args.config, args.config), N1, M, nnz, nnz / max(N1, 1)),
-                       "synthetic_config": args.config, "kernel": args.kernel,
+                       "synthetic_config": args.config, "kernel": args.kernel, "value_bits": args.value_bits,
                        "parallelism": "1 GPU" if world == 1 else "read-sharded x%d + RCCL all-reduce(M+1 f64)/round from C++ on the EM stream" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -361,12 +403,14 @@ def main():
             "upload_and_layout_s": upload_s,
             "gibbs": gibbs,
         }
+        if q32 is not None:
+            line["q32_value_planes"] = q32
         if dist_info:
             line["distributed"] = dist_info
         if world == 1:
             legs = {}
             for cfg in [c for c in args.legs.split(",") if c and c != args.config]:
-                legs[cfg] = em_leg(capi, make_em_workload, cfg, K, W, args.kernel, sync, local)
+                legs[cfg] = em_leg(capi, make_em_workload, cfg, K, W, args.kernel, sync, local, q32=not args.no_q32 and cfg == "C2")
             if legs:
                 line["other_configs"] = legs
             if not args.no_ci:

@@ -87,7 +87,19 @@ int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64
                    const double* ncp);
 /* Replace the CSR values (hit.setConPrb / ncpv[i], EM.cpp:210,216) in the caller's (file) order. */
 int rsem_em_set_values(rsem_em_ctx* ctx, const double* conprb, const double* ncp);
+/* Options (none of them is part of the reference's surface):
+ *   "kernel"            RSEM_EM_KERNEL_*;
+ *   "check_every"       rounds between the host's looks at the loop;
+ *   "value_bits"        64 (default): the theta-only E step streams the conprb doubles as given; 32: reads whose
+ *                       non-zero conprb values span less than 2^value_range_bits are streamed as 32-bit mantissas with
+ *                       one exponent per read (value = m * 2^e, rounded to nearest: relative error <= 2^-33 of the
+ *                       read's largest value), all other reads stay doubles.  Affects the counts of rsem_em_step /
+ *                       rsem_em_run / rsem_em_expected_weights; the weights w[] always come from the doubles.
+ *   "value_range_bits"  0..24, default 8. */
 int rsem_em_set_option(rsem_em_ctx* ctx, const char* key, int64_t value);
+/* Layout facts: "value_bits", "value_range_bits", "reads_q32", "reads_sliced", "reads_long", "value_plane_bytes",
+ * "sid_plane_bytes", "slots", "units". */
+int rsem_em_get_info(const rsem_em_ctx* ctx, const char* key, int64_t* value);
 /* Tuning aid (not part of the reference's surface): one E-step launch of the LANE kernel with per-workgroup start/end
  * timestamps (100 MHz clock), out[2u], out[2u+1] in dispatch order; *n_units_io = capacity in, units written out. */
 int rsem_em_debug_trace(rsem_em_ctx* ctx, const double* theta, unsigned long long* out, uint32_t* n_units_io);

@@ -58,6 +58,7 @@ def lib():
         L.rsem_em_create.argtypes = [C.POINTER(vp), ci, i32, u64, u64, _u64p, vp, vp, vp]
         L.rsem_em_set_values.argtypes = [vp, _f64p, _f64p]
         L.rsem_em_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+        L.rsem_em_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
         L.rsem_em_destroy.argtypes = [vp]
         L.rsem_em_set_comm.argtypes = [vp, vp]
         L.rsem_em_set_progress.argtypes = [vp, vp, vp]
@@ -140,6 +141,11 @@ class EmContext:
 
     def set_option(self, key, value):
         _check(lib().rsem_em_set_option(self._h, key.encode(), int(value)))
+
+    def info(self, key):
+        v = C.c_int64()
+        _check(lib().rsem_em_get_info(self._h, key.encode(), C.byref(v)))
+        return v.value
 
     def set_comm(self, comm):
         _check(lib().rsem_em_set_comm(self._h, comm._h if comm is not None else None))

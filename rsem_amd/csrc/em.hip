@@ -14,13 +14,14 @@
 //     read l / G.  Every global load of the hot loop is therefore a fully coalesced 256 B (sid) or
 //     512 B (conprb) wave access, whatever the row length (1..256 alignments per read).
 //   * per-read normaliser: xor-shuffle reduction over the G lanes of a read;
-//   * per-transcript counts: wave-level *segmented* shuffle reduction keyed by sid along the
-//     lanes (neighbouring reads share sids after the sort), only run tails issue an fp64 atomic;
-//     with RSEM_EM_KERNEL_SELLRUN, runs of consecutive slices whose reads all have the identical
-//     sid tuple keep their partial counts in registers across slices, skip the sid planes
-//     entirely (8 B/alignment of HBM traffic instead of 12) and flush once per run;
-//   * the noise bin (touched by every read) never sees an atomic: per-lane register, block
-//     reduction, one partial per workgroup summed deterministically by the M-step kernel;
+//   * per-transcript counts (LANE kernel, the default): inside a block of slices a lane follows consecutive
+//     sorted reads; while their sid tuple does not change it keeps the partial counts in registers and
+//     skips the sid planes; on a change it spills into a 2048-entry LDS count window, which leaves the
+//     workgroup as one device atomic per touched sid;
+//   * optional Q32 value planes (rsem_em_set_option "value_bits" 32): 4 B per alignment instead of 8 for
+//     the reads that qualify (sell_layout.hpp), the rest stay F64 in shapes of their own;
+//   * the noise bin (touched by every read) never sees a per-read atomic: per-lane register, block
+//     reduction, one partial per workgroup;
 //   * M step + convergence statistics run on the device; a `done` word set by the last
 //     workgroup of the M step freezes theta at exactly the reference's stopping round while the
 //     host only polls it every few rounds (no per-round host sync).
@@ -28,6 +29,7 @@
 #include <climits>
 #include <cstdlib>
 #include <cmath>
+#include <type_traits>
 
 #include "comm_internal.hpp"
 #include "em_internal.hpp"
@@ -289,19 +291,26 @@ __device__ inline void stage_windows(int base, int span, int M, const ThetaSrc& 
     __syncthreads();
 }
 
-template <int K>
+// one slice's loads: sids (only where a tuple starts), values (doubles, or Q32 mantissas + the read's exponent), noise
+template <int K, bool kQ>
 struct SliceRegs {
     int id[K];
-    double c[K];
+    typename std::conditional<kQ, uint32_t, double>::type c[K];
     double nc;
+    int e;
 };
 
-template <int K, bool kFC>
+// 2^e for the exponents q32_scale_of admits (always a normal double)
+__device__ inline double pow2_of(int e) { return __longlong_as_double((long long)(1023 + e) << 52); }
+
+template <int K, bool kFC, bool kQ>
 __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
                                    const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, double* th_win, double* cnt_win,
-                                   const double* __restrict__ scp, const int32_t* __restrict__ ssid,
+                                   const unsigned char* __restrict__ sval, const int16_t* __restrict__ sexp, const int32_t* __restrict__ ssid,
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
                                    double* counts, double& noise, double& neff, int M) {
+    using ValT = typename std::conditional<kQ, uint32_t, double>::type;
+    const ValT* __restrict__ scp = (const ValT*)(sval + S.val_base);  // this shape's value planes
     const int lg = S.lg;
     const int g = lane & ((1 << lg) - 1);
     const bool g0 = (g == 0);
@@ -319,15 +328,18 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
         const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), src);
         return ((unsigned long long)hi << 32) | lo;
     };
-    auto issue = [&](uint32_t t, unsigned long long m, SliceRegs<K>& b) {
+    auto issue = [&](uint32_t t, unsigned long long m, SliceRegs<K, kQ>& b) {
         const uint32_t sl = t - S.slice_base;
-        const uint64_t pl = (S.plane_base + (uint64_t)sl * K) * 64 + lane;
+        const uint64_t vl = (uint64_t)sl * K * 64 + lane;      // within the shape's value planes
+        const uint64_t pl = S.plane_base * 64 + vl;             // within the sid planes of the whole layout
         const bool want = (m >> lane) & 1ull;
 #pragma unroll
         for (int k = 0; k < K; k++) b.id[k] = ssid[want ? pl + (uint64_t)k * 64 : 0];
 #pragma unroll
-        for (int k = 0; k < K; k++) b.c[k] = scp[pl + (uint64_t)k * 64];
-        b.nc = g0 ? sncp[S.slot_base + sl * R + (lane >> lg)] : 0.0;
+        for (int k = 0; k < K; k++) b.c[k] = scp[vl + (uint64_t)k * 64];
+        const uint32_t slot = S.slot_base + sl * R + (lane >> lg);
+        b.nc = g0 ? sncp[slot] : 0.0;
+        b.e = kQ ? (int)sexp[slot] : 0;
     };
     auto spill = [&](const int* rsid, double* acc) {  // lane-private partial counts -> LDS window
 #pragma unroll
@@ -347,7 +359,7 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
     for (int k = 0; k < K; k++) { rsid[k] = 0; rth[k] = 0.0; acc[k] = 0.0; }
     ThetaSrc th{theta, 0.0, 1.0};
     double th0 = 0.0;
-    auto reduce = [&](const SliceRegs<K>& cur, unsigned long long cur_m) {
+    auto reduce = [&](const SliceRegs<K, kQ>& cur, unsigned long long cur_m) {
         if (cur_m != 0ull) {                 // wave-uniform
             if ((cur_m >> lane) & 1ull) {    // lanes whose read starts a new sid tuple
                 spill(rsid, acc);
@@ -364,9 +376,12 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
         if (f0 < kEpsilon) f0 = 0.0;
         double f[K];
         double part = f0;
+        const double scale = kQ ? pow2_of(cur.e) : 1.0;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            double v = rth[k] * cur.c[k];
+            // Q32: mantissa * 2^e is exact, so this is the F64 expression on the rounded value
+            const double cv = kQ ? (double)cur.c[k] * scale : (double)cur.c[k];
+            double v = rth[k] * cv;
             if (v < kEpsilon) v = 0.0;
             f[k] = v;
             part += v;
@@ -379,7 +394,7 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
         for (int k = 0; k < K; k++) acc[k] += f[k] * inv;
     };
     // ping-pong register sets A / B: the loads of the next slice are in flight while this one is reduced
-    SliceRegs<K> A, B;
+    SliceRegs<K, kQ> A, B;
     unsigned long long mA = ~0ull, mB = 0;  // a block always starts fresh
     issue(s_begin, mA, A);
     th = theta_src<kFC>(theta, tsrc, N0, lane);  // (after the first slice's loads were issued: they fly meanwhile)
@@ -545,9 +560,10 @@ __global__ __launch_bounds__(kBlock) void k_solo_finish(int32_t M, double N0, co
 template <bool kFC, bool kSolo = false>
 __global__ __launch_bounds__(kBlock) void k_estep_lane(
     const Shape* __restrict__ shapes, const Unit* __restrict__ units, uint32_t T, int M,
-    const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, const double* __restrict__ scp,
-    const int32_t* __restrict__ ssid, const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
-    double* counts, double* noise_partial, double* totals, const Ctrl* ctrl, unsigned long long* trace, SoloArgs solo = SoloArgs()) {
+    const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, const unsigned char* __restrict__ sval,
+    const int16_t* __restrict__ sexp, const int32_t* __restrict__ ssid, const double* __restrict__ sncp,
+    const unsigned long long* __restrict__ masks, double* counts, double* noise_partial, double* totals, const Ctrl* ctrl,
+    unsigned long long* trace, SoloArgs solo = SoloArgs()) {
     if (ctrl->done) return;
     if (trace && threadIdx.x == 0) trace[2 * blockIdx.x] = wall_clock64();  // rsem_em_debug_trace only
     __shared__ double th_win[kWindow];
@@ -567,14 +583,23 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
         S.slot_base = G.slot_base;
         S.K = G.K;
         S.lg = G.lg;
+        S.fmt = G.fmt;
+        S.val_base = G.val_base;
         const uint32_t u_end = S.slice_base + U.slice_begin + U.n_slices;
         const uint32_t s_begin = S.slice_base + U.slice_begin + (uint32_t)w * U.per_wave;
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
-        if (s_begin < u_end) switch (S.K) {
-            case 1: estep_block<1, kFC>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
-            case 2: estep_block<2, kFC>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
-            case 3: estep_block<3, kFC>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
-            default: estep_block<4, kFC>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, scp, ssid, sncp, masks, counts, noise, neff, M); break;
+#define RSEM_ESTEP_BLOCK(KK, QQ) \
+    estep_block<KK, kFC, QQ>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M)
+        if (s_begin < u_end) switch (S.K + 4 * S.fmt) {  // (uniform over the workgroup)
+            case 1: RSEM_ESTEP_BLOCK(1, false); break;
+            case 2: RSEM_ESTEP_BLOCK(2, false); break;
+            case 3: RSEM_ESTEP_BLOCK(3, false); break;
+            case 4: RSEM_ESTEP_BLOCK(4, false); break;
+            case 5: RSEM_ESTEP_BLOCK(1, true); break;
+            case 6: RSEM_ESTEP_BLOCK(2, true); break;
+            case 7: RSEM_ESTEP_BLOCK(3, true); break;
+            default: RSEM_ESTEP_BLOCK(4, true); break;
+#undef RSEM_ESTEP_BLOCK
         } else {
             const ThetaSrc th = theta_src<kFC>(theta, tsrc, N0, lane);
             stage_windows<kFC>(U.base, U.span, M, th, th_win, cnt_win);
@@ -922,8 +947,13 @@ struct rsem_em_ctx {
     bool have_values = false;
     // sliced layout
     SellLayout L;
-    double* d_scp = nullptr;
+    unsigned char* d_sval = nullptr;  // value planes: F64 or Q32 per shape (sell_layout.hpp)
     double* d_sncp = nullptr;
+    int16_t* d_sexp = nullptr;        // per-slot exponents of the Q32 reads (only with value_bits = 32)
+    int* d_fill_err = nullptr;
+    int value_bits = 64;              // 64: every read F64; 32: Q32 where a read qualifies
+    int value_range_bits = 8;         // a read qualifies when its non-zero values span less than 2^this
+    bool layout_has_q32 = false;      // the current layout was built with Q32 shapes (from the then-current values)
     // LANE variant work list
     Unit* d_units = nullptr;
     unsigned long long* d_trace = nullptr;  // per-workgroup timestamps (tune_unit_order, rsem_em_debug_trace)
@@ -982,11 +1012,12 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
     if (kern == RSEM_EM_KERNEL_LANE) {
         if (c->n_units)
             hipLaunchKernelGGL((k_estep_lane<false, false>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
-                               d_theta, (const double*)nullptr, 0.0, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a,
-                               c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs());
+                               d_theta, (const double*)nullptr, 0.0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid,
+                               c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs());
     } else {
+        if (c->layout_has_q32) { rsem::set_last_error("the SELL kernel reads F64 planes only (value_bits = 32 needs the LANE kernel)"); return RSEM_ERR_STATE; }
         hipLaunchKernelGGL(k_estep_sell, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
-                           c->L.n_slices, d_theta, c->d_scp, c->L.d_ssid, c->d_sncp, d_counts, c->d_noise_a, ctrl);
+                           c->L.n_slices, d_theta, (const double*)c->d_sval, c->L.d_ssid, c->d_sncp, d_counts, c->d_noise_a, ctrl);
     }
     RSEM_HIP_TRY(hipGetLastError());
     if (c->L.n_long_rows) {
@@ -1028,21 +1059,60 @@ int launch_mstep(rsem_em_ctx* c, double N0, double* d_counts, const double* d_th
     return RSEM_OK;
 }
 
+int build_layout(rsem_em_ctx* c);
+void free_layout(rsem_em_ctx* c);
+
+int write_values(rsem_em_ctx* c) {
+    if (c->d_fill_err) RSEM_HIP_TRY(hipMemsetAsync(c->d_fill_err, 0, sizeof(int), c->stream));
+    int rc = sell_fill_values(c->L, c->stream, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_sval, c->d_sncp, c->d_sexp, c->d_fill_err);
+    if (rc != RSEM_OK) return rc;
+    if (c->layout_has_q32) {  // a Q32 shape was handed a read that no longer qualifies: cannot happen after a rebuild
+        int h = 0;
+        RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_fill_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h) { rsem::set_last_error("Q32 planes: a read's values left the range its format was chosen for"); return RSEM_ERR_STATE; }
+    }
+    return RSEM_OK;
+}
+
+// The caller-order values changed.  F64 layout: rewrite the planes.  With value_bits = 32 the format of a read depends
+// on its values, so the layout is rebuilt from them (the rounds that change the values every time -- rounds 1-11 of
+// rsem-run-em -- run with value_bits = 64 and switch afterwards).
 int fill_values(rsem_em_ctx* c) {
-    return sell_fill_values(c->L, c->stream, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_scp, c->d_sncp);
+    if (c->value_bits == 32 || c->layout_has_q32) {
+        free_layout(c);
+        return build_layout(c);
+    }
+    return write_values(c);
+}
+
+void free_layout(rsem_em_ctx* c) {
+    sell_free(c->L);
+    hipFree(c->d_sval); hipFree(c->d_sncp); hipFree(c->d_sexp); hipFree(c->d_fill_err); hipFree(c->d_units); hipFree(c->d_noise_a);
+    c->d_sval = nullptr; c->d_sncp = nullptr; c->d_sexp = nullptr; c->d_fill_err = nullptr; c->d_units = nullptr; c->d_noise_a = nullptr;
+    c->h_units.clear();
+    c->n_units = 0;
+    c->layout_has_q32 = false;
 }
 
 int build_layout(rsem_em_ctx* c) {
     // one block per wave, ~2.5 blocks per wave slot (6 waves/SIMD) for load balance
     const uint32_t target_waves = (uint32_t)c->n_cus * 4 * 6 * 5 / 2;
-    int rc = sell_build(c->L, c->stream, c->N1, c->M, c->d_row_ptr, c->d_sid, target_waves, c->forced_T);
+    const bool q32 = c->value_bits == 32 && c->have_values;
+    int rc = sell_build(c->L, c->stream, c->N1, c->M, c->d_row_ptr, c->d_sid, target_waves, c->forced_T,
+                        q32 ? c->d_cp : nullptr, c->value_range_bits);
     if (rc != RSEM_OK) return rc;
-    RSEM_HIP_TRY(dmalloc(&c->d_scp, c->L.n_planes * 64));
+    c->layout_has_q32 = q32;
+    RSEM_HIP_TRY(hipMalloc((void**)&c->d_sval, std::max<uint64_t>(c->L.val_bytes, 1)));
     RSEM_HIP_TRY(dmalloc(&c->d_sncp, (size_t)c->L.n_slots));
-    RSEM_HIP_TRY(hipMemsetAsync(c->d_scp, 0, sizeof(double) * c->L.n_planes * 64, c->stream));
+    if (q32) {
+        RSEM_HIP_TRY(dmalloc(&c->d_sexp, (size_t)c->L.n_slots));
+        RSEM_HIP_TRY(dmalloc(&c->d_fill_err, 1));
+    }
+    RSEM_HIP_TRY(hipMemsetAsync(c->d_sval, 0, c->L.val_bytes, c->stream));
     RSEM_HIP_TRY(hipMemsetAsync(c->d_sncp, 0, sizeof(double) * c->L.n_slots, c->stream));
     if (c->have_values) {
-        rc = fill_values(c);
+        rc = write_values(c);
         if (rc != RSEM_OK) return rc;
     }
     RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1051,6 +1121,7 @@ int build_layout(rsem_em_ctx* c) {
     if (rc != RSEM_OK) return rc;
     c->n_units = (uint32_t)units.size();
     c->h_units = units;
+    c->tune_passes_left = 1;
     if (const char* e = getenv("RSEM_HIP_TUNE")) c->tune_passes_left = atoi(e);  // tuning knob: 0 disables
     RSEM_HIP_TRY(dmalloc(&c->d_units, units.size()));
     if (!units.empty())
@@ -1216,6 +1287,24 @@ int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
         set_grid_for_kernel(c);
         return RSEM_OK;
     }
+    if (!strcmp(key, "value_bits") || !strcmp(key, "value_range_bits")) {
+        // Format of the value planes the theta-only E step streams (sell_layout.hpp): 64 = the caller's doubles; 32 = a
+        // 32-bit mantissa + per-read exponent for the reads whose non-zero values span < 2^value_range_bits.  Changing it
+        // rebuilds the device layout from the current values.
+        const bool bits = !strcmp(key, "value_bits");
+        if (bits) RSEM_REQUIRE(value == 64 || value == 32, "value_bits must be 64 or 32");
+        else RSEM_REQUIRE(value >= 0 && value <= 24, "value_range_bits must be in 0..24");
+        int& field = bits ? c->value_bits : c->value_range_bits;
+        if (field == (int)value) return RSEM_OK;
+        field = (int)value;
+        if (c->value_bits == 64 && !c->layout_has_q32) return RSEM_OK;  // nothing built depends on it
+        RSEM_HIP_TRY(hipSetDevice(c->device));
+        free_layout(c);
+        int rc = build_layout(c);
+        if (rc != RSEM_OK) return rc;
+        set_grid_for_kernel(c);
+        return RSEM_OK;
+    }
     if (!strcmp(key, "check_every")) {
         RSEM_REQUIRE(value >= 1 && value <= kHistCap / 4, "check_every out of range");
         c->check_every = (int)value;
@@ -1223,6 +1312,21 @@ int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
     }
     rsem::set_last_error("unknown option '%s'", key);
     return RSEM_ERR_INVALID;
+}
+
+int rsem_em_get_info(const rsem_em_ctx* c, const char* key, int64_t* value) {
+    RSEM_REQUIRE(c && key && value, "NULL argument");
+    if (!strcmp(key, "value_bits")) *value = c->value_bits;
+    else if (!strcmp(key, "value_range_bits")) *value = c->value_range_bits;
+    else if (!strcmp(key, "reads_q32")) *value = c->L.n_q32_rows;                       // reads held in Q32 planes
+    else if (!strcmp(key, "reads_sliced")) *value = c->L.n_sell_rows;                   // reads in the sliced layout
+    else if (!strcmp(key, "reads_long")) *value = c->L.n_long_rows;                     // reads left in the CSR
+    else if (!strcmp(key, "value_plane_bytes")) *value = (int64_t)c->L.val_bytes;       // incl. padding
+    else if (!strcmp(key, "sid_plane_bytes")) *value = (int64_t)(c->L.n_planes * 256);
+    else if (!strcmp(key, "slots")) *value = c->L.n_slots;
+    else if (!strcmp(key, "units")) *value = c->n_units;
+    else { rsem::set_last_error("unknown info key '%s'", key); return RSEM_ERR_INVALID; }
+    return RSEM_OK;
 }
 
 // Tuning aid: one E-step launch with per-workgroup start / end timestamps (100 MHz wall clock): out[2u], out[2u+1] for
@@ -1257,7 +1361,7 @@ int rsem_em_destroy(rsem_em_ctx* c) {
     (void)hipSetDevice(c->device);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     hipFree(c->d_row_ptr); hipFree(c->d_sid); hipFree(c->d_cp); hipFree(c->d_ncp);
-    sell_free(c->L); hipFree(c->d_scp); hipFree(c->d_sncp);
+    sell_free(c->L); hipFree(c->d_sval); hipFree(c->d_sncp); hipFree(c->d_sexp); hipFree(c->d_fill_err);
     hipFree(c->d_theta[0]); hipFree(c->d_theta[1]); hipFree(c->d_red3);
     for (int i = 0; i < 4; i++) { if (c->ev_e[i]) (void)hipEventDestroy(c->ev_e[i]); if (c->ev_s[i]) (void)hipEventDestroy(c->ev_s[i]); }
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -1429,7 +1533,7 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
             sa.max_round = max_round;
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[2 + 2 * ti], st));
             hipLaunchKernelGGL((k_estep_lane<true, true>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
-                               (const double*)src, (const double*)(src + c->M + 1), N0, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
+                               (const double*)src, (const double*)(src + c->M + 1), N0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
                                c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, sa);
             RSEM_HIP_TRY(hipGetLastError());
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));
@@ -1439,7 +1543,7 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
             if (r - round0 >= 3) RSEM_HIP_TRY(hipStreamWaitEvent(st, c->ev_s[(r - 2) & 3], 0));  // dst was cleared by round r-2's statistics
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[2 + 2 * ti], st));
             hipLaunchKernelGGL((k_estep_lane<true, false>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
-                               (const double*)src, (const double*)(src + c->M + 1), N0, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
+                               (const double*)src, (const double*)(src + c->M + 1), N0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
                                c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, SoloArgs());
             RSEM_HIP_TRY(hipGetLastError());
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));

@@ -2,7 +2,7 @@
 //
 //   rsem-run-em refName read_type sampleName imdName statName [-p N] [-b samInpF has_fai [fai]] [-q]
 //               [--gibbs-out] [--sampling] [--seed u32] [--append-names]
-//               + ignored-by-the-reference: [--device d] [--ngpus N] [--devices d0,d1,..]
+//               + ignored-by-the-reference: [--device d] [--ngpus N] [--devices d0,d1,..] [--value-bits 32 [--value-range-bits D]]
 //
 // Structure (EM<>() of EM.cpp:313-539): text inputs are parsed ONCE into packed arrays and uploaded;
 // rounds 1-11 recompute the alignment probabilities with the current read model on the GPU
@@ -285,7 +285,7 @@ int main(int argc, char* argv[]) {
     bool verbose = true, genBamF = false, genGibbsOut = false, appendNames = false, bamSampling = false, hasSeed = false;
     uint32_t seed = 0;
     std::string inpSamF, devices_s;
-    int device = 0, ngpus = 1;
+    int device = 0, ngpus = 1, value_bits = 64, value_range_bits = -1;
     for (int i = 6; i < argc; i++) {  // EM.cpp:578-595; -p is accepted and irrelevant (the GPU is the parallelism)
         if (!strcmp(argv[i], "-b") && i + 1 < argc) { genBamF = true; inpSamF = argv[i + 1]; }
         if (!strcmp(argv[i], "--sampling")) bamSampling = true;
@@ -300,7 +300,10 @@ int main(int argc, char* argv[]) {
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--ngpus") && i + 1 < argc) ngpus = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices_s = argv[i + 1];
+        if (!strcmp(argv[i], "--value-bits") && i + 1 < argc) value_bits = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--value-range-bits") && i + 1 < argc) value_range_bits = atoi(argv[i + 1]);
     }
+    if (value_bits != 64 && value_bits != 32) die("--value-bits must be 64 or 32");
     std::vector<int> devs;  // one entry per shard; a device named twice shares it between two shards (single-GPU testing)
     if (!devices_s.empty()) {
         for (size_t p = 0; p < devices_s.size();) {
@@ -600,6 +603,15 @@ int main(int argc, char* argv[]) {
             hip_check(rsem_em_set_progress(sh[0].em, [](int r, double sm, double bc, int tn, void*) {
                 printf("ROUND = %d, SUM = %.15g, bChange = %g, totNum = %d\n", r, sm, bc, tn);
             }, nullptr), "rsem_em_set_progress");
+        if (value_bits == 32) {  // the values are frozen now: the theta-only rounds may stream them as Q32 planes (rsem_hip.h)
+            each_shard([&](Shard& X, int) {
+                X.rc = value_range_bits >= 0 ? rsem_em_set_option(X.em, "value_range_bits", value_range_bits) : RSEM_OK;
+                if (X.rc == RSEM_OK) X.rc = rsem_em_set_option(X.em, "value_bits", 32);
+                if (X.rc != RSEM_OK) X.err = rsem_hip_last_error();
+            });
+            check_shards("rsem_em_set_option(value_bits)");
+            lap("Q32 value planes");
+        }
         each_shard([&](Shard& X, int k) {
             X.rc = rsem_em_run(X.em, s_theta[k].data(), (double)N0, round0, MIN_ROUND, MAX_ROUND, &s_rounds[k], k == 0 ? counts.data() : nullptr,
                                &s_bc[k], &s_tn[k], nullptr);

@@ -10,6 +10,15 @@
 // can keep their partial counts in registers, while every global load stays a fully coalesced
 // 256 B (sid) / 512 B (conprb) wave access.  A 64-bit mask per slice tells which lanes start a new
 // tuple there.  Reads with > 256 alignments stay in the caller's CSR ("long rows").
+//
+// Value planes come in two formats, chosen per read and therefore per shape (a shape = (format, G, K)):
+//   F64  the caller's doubles, 512 B per plane;
+//   Q32  block floating point: a 32-bit unsigned mantissa per alignment (256 B per plane) and one int16 exponent e per
+//        read, value = m * 2^e with 2^e chosen so that the read's largest value lands in [2^31, 2^32), m rounded to
+//        nearest.  Only reads whose non-zero values all lie within a factor 2^range_bits of their largest one take
+//        this format (every value keeps >= 32 - range_bits significant bits); the rest stay F64 in shapes of their
+//        own.  m * 2^e is exact in a double, so a kernel reading Q32 planes computes bit for bit what the F64 kernel
+//        computes on the rounded values (tests pin that; quantize_q32 in tests/ is the numpy statement of the rule).
 // Included by em.hip and gibbs.hip (each TU gets its own copy of the kernels).
 #pragma once
 #include <hipcub/hipcub.hpp>
@@ -21,8 +30,10 @@
 
 namespace {
 
-constexpr int kMaxShapes = 28;
+constexpr int kShapesPerFmt = 28;   // (lg 0..6) x (K 1..4)
+constexpr int kMaxShapes = 2 * kShapesPerFmt;  // F64 shapes, then Q32 shapes
 constexpr int kLongShape = 63;      // rows with more than 256 alignments: CSR kernel
+constexpr int kFmtF64 = 0, kFmtQ32 = 1;
 constexpr int kMaxK = 4;
 constexpr int kBlock = 256;         // 4 waves
 
@@ -35,8 +46,28 @@ struct Shape {
     uint32_t slot_base;   // first row slot (slot = slice * rows_per_slice + r)
     int32_t K;            // planes per slice
     int32_t lg;           // log2(lanes per read)
-    int32_t pad;
+    int32_t fmt;          // kFmtF64 / kFmtQ32
+    uint64_t val_base;    // byte offset of this shape's value planes (512 B per F64 plane, 256 B per Q32 plane)
 };
+
+__host__ __device__ inline uint32_t plane_bytes(int fmt) { return fmt == kFmtQ32 ? 256u : 512u; }
+
+// ---- Q32 quantisation rule (one read) ----------------------------------------------------------
+// mx = the read's largest value.  Returns false when the read must stay F64: no positive value, a non-zero value
+// below mx * 2^-range_bits, or an exponent for which 2^e / value * 2^-e would leave the normal doubles.
+struct Q32Scale { int e; };
+__device__ inline bool q32_scale_of(double mx, double mn_nonzero, int range_bits, Q32Scale& q) {
+    if (!(mx > 0.0) || !(mx < 1e300)) return false;
+    int ex;
+    (void)frexp(mx, &ex);              // mx = f * 2^ex, f in [0.5, 1)
+    q.e = ex - 32;                     // mx / 2^e in [2^31, 2^32)
+    if (q.e < -1000 || q.e > 900) return false;
+    return mn_nonzero >= ldexp(mx, -range_bits);
+}
+__device__ inline uint32_t q32_mantissa(double v, int e) {
+    const double m = rint(ldexp(v, -e));      // exact scaling, round to nearest even
+    return m >= 4294967295.0 ? 0xffffffffu : (uint32_t)m;
+}
 
 __host__ __device__ inline int shape_id_of(uint64_t L) {
     if (L <= 4) return (int)(L == 0 ? 0 : L - 1);  // lg = 0, K = L
@@ -66,21 +97,33 @@ __device__ inline uint32_t mix32(uint32_t h, uint32_t v) {
 
 // ---- layout construction ---------------------------------------------------------------------
 
+// cp != nullptr: reads that qualify (q32_scale_of) go to the Q32 twin of their shape
 __global__ void k_row_keys(uint64_t N1, int32_t M, const uint64_t* __restrict__ row_ptr,
-                           const int32_t* __restrict__ sid, uint64_t* keys, uint32_t* vals, int* err) {
+                           const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits,
+                           uint64_t* keys, uint32_t* vals, int* err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N1) return;
     uint64_t fr = row_ptr[i], to = row_ptr[i + 1];
     if (to < fr) { *err = 1; return; }
     uint32_t h = 0x811c9dc5u, mn = 0xffffffffu;
+    double vmx = 0.0, vmn = 1.79e308;
     for (uint64_t j = fr; j < to; j++) {
         int32_t s = sid[j];
         if (s < 1 || s > M) { *err = 2; s = 1; }
         h = mix32(h, (uint32_t)s);
         mn = min(mn, (uint32_t)s);
+        if (cp) {
+            const double v = cp[j];
+            if (!(v >= 0.0)) vmx = 1e308;  // negative / NaN: never compressed
+            vmx = fmax(vmx, v);
+            if (v > 0.0) vmn = fmin(vmn, v);
+        }
     }
     if (mn > 0x3ffffffu) mn = 0x3ffffffu;
-    keys[i] = ((uint64_t)shape_id_of(to - fr) << 58) | ((uint64_t)mn << 32) | h;
+    int shape = shape_id_of(to - fr);
+    Q32Scale q;
+    if (cp && shape != kLongShape && q32_scale_of(vmx, vmn, range_bits, q)) shape += kShapesPerFmt;
+    keys[i] = ((uint64_t)shape << 58) | ((uint64_t)mn << 32) | h;
     vals[i] = (uint32_t)i;
 }
 
@@ -97,12 +140,14 @@ __device__ inline int find_shape_by_row(const Shape* shapes, int n, uint32_t p) 
     return sh;
 }
 
-// one thread per sorted row: scatter its alignments into the planes (values optional)
+// one thread per sorted row: scatter its alignments into the planes (values optional; sval = the value planes of all
+// shapes, F64 or Q32 per shape; sexp = per-slot exponents of the Q32 reads)
 template <bool kIds>
 __global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_sell_rows,
                             const uint32_t* __restrict__ order, const uint64_t* __restrict__ row_ptr,
                             const int32_t* __restrict__ sid, const double* __restrict__ cp,
-                            const double* __restrict__ ncp, int32_t* ssid, double* scp, double* sncp) {
+                            const double* __restrict__ ncp, int32_t* ssid, unsigned char* sval, double* sncp,
+                            int16_t* sexp, int* err) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_sell_rows) return;
     int sh = find_shape_by_row(shapes, n_shapes, p);
@@ -113,13 +158,26 @@ __global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint
     uint32_t orig = order[p];
     uint64_t fr = row_ptr[orig];
     int L = (int)(row_ptr[orig + 1] - fr);
-    uint64_t pl0 = (S.plane_base + (uint64_t)slice_local * S.K) * 64;
-    for (int c = 0; c < L; c++) {
-        uint64_t idx = pl0 + (uint64_t)(c >> S.lg) * 64 + r * G + (c & (G - 1));
-        if (kIds) ssid[idx] = sid[fr + c];
-        if (cp) scp[idx] = cp[fr + c];
+    const uint64_t pl_local = (uint64_t)slice_local * S.K * 64;   // first entry of the slice, within the shape
+    const uint64_t pl0 = S.plane_base * 64 + pl_local;
+    const uint32_t slot = S.slot_base + slice_local * (64u >> S.lg) + r;
+    Q32Scale q{0};
+    if (cp && S.fmt == kFmtQ32) {
+        double vmx = 0.0;
+        for (int c = 0; c < L; c++) vmx = fmax(vmx, cp[fr + c]);
+        // the format was decided from these very values (k_row_keys); anything else means the caller changed them
+        if (!q32_scale_of(vmx, vmx, 0, q)) { if (err) *err = 3; q.e = 0; }
+        if (sexp) sexp[slot] = (int16_t)q.e;
     }
-    if (ncp) sncp[S.slot_base + slice_local * (64u >> S.lg) + r] = ncp[orig];
+    for (int c = 0; c < L; c++) {
+        const uint64_t off = (uint64_t)(c >> S.lg) * 64 + r * G + (c & (G - 1));
+        if (kIds) ssid[pl0 + off] = sid[fr + c];
+        if (cp) {
+            if (S.fmt == kFmtQ32) ((uint32_t*)(sval + S.val_base))[pl_local + off] = q32_mantissa(cp[fr + c], q.e);
+            else ((double*)(sval + S.val_base))[pl_local + off] = cp[fr + c];
+        }
+    }
+    if (ncp) sncp[slot] = ncp[orig];
 }
 
 // per slice: bit l set when lane l's read has a different sid tuple than the same lane's read in
@@ -200,6 +258,9 @@ struct SellLayout {
     uint32_t n_slices = 0;
     uint32_t n_slots = 0;
     uint64_t n_planes = 0;
+    uint64_t val_bytes = 0;       // value planes of all shapes (Shape::val_base points into them)
+    uint32_t n_q32_rows = 0;      // sorted rows held in Q32 shapes
+    uint64_t n_q32_planes = 0;
     int32_t* d_ssid = nullptr;
     unsigned long long* d_masks = nullptr;
     uint32_t* d_slice_minsid = nullptr;
@@ -211,24 +272,29 @@ inline void sell_free(SellLayout& L) {
     L = SellLayout();
 }
 
-// (re)write the value planes / per-slot noise values from the caller-order arrays
+// (re)write the value planes / per-slot noise values (and exponents of the Q32 reads) from the caller-order arrays.
+// d_sval: L.val_bytes bytes (= n_planes * 512 for a layout without Q32 shapes); d_sexp / d_err only with Q32 shapes.
 inline int sell_fill_values(const SellLayout& L, hipStream_t st, const uint64_t* d_row_ptr, const double* d_cp,
-                            const double* d_ncp, double* d_scp, double* d_sncp) {
-    RSEM_HIP_TRY(hipMemsetAsync(d_scp, 0, sizeof(double) * L.n_planes * 64, st));
+                            const double* d_ncp, void* d_sval, double* d_sncp, int16_t* d_sexp = nullptr,
+                            int* d_err = nullptr) {
+    RSEM_HIP_TRY(hipMemsetAsync(d_sval, 0, L.val_bytes, st));
     RSEM_HIP_TRY(hipMemsetAsync(d_sncp, 0, sizeof(double) * L.n_slots, st));
+    if (d_sexp) RSEM_HIP_TRY(hipMemsetAsync(d_sexp, 0, sizeof(int16_t) * L.n_slots, st));
     if (L.n_sell_rows) {
         hipLaunchKernelGGL(k_fill_sell<false>, dim3(rsem::ceil_div(L.n_sell_rows, kBlock)), dim3(kBlock), 0, st,
                            L.d_shapes, L.n_shapes, L.T, L.n_sell_rows, L.d_order, d_row_ptr, (const int32_t*)nullptr,
-                           d_cp, d_ncp, (int32_t*)nullptr, d_scp, d_sncp);
+                           d_cp, d_ncp, (int32_t*)nullptr, (unsigned char*)d_sval, d_sncp, d_sexp, d_err);
         RSEM_HIP_TRY(hipGetLastError());
     }
     return RSEM_OK;
 }
 
 // sort the rows, derive the shape table, scatter the sid planes and compute the per-slice masks.
-// target_waves: how many wave-sized blocks the caller wants (sets T).
+// target_waves: how many wave-sized blocks the caller wants (sets T).  d_cp_for_q32 != nullptr: reads whose values
+// qualify (q32_scale_of with range_bits) are placed in Q32 shapes.
 inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, const uint64_t* d_row_ptr,
-                      const int32_t* d_sid, uint32_t target_waves, uint32_t forced_T = 0) {
+                      const int32_t* d_sid, uint32_t target_waves, uint32_t forced_T = 0,
+                      const double* d_cp_for_q32 = nullptr, int range_bits = 0) {
     L.N1 = N1;
     uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
     uint32_t *d_vals = nullptr, *d_first = nullptr;
@@ -247,7 +313,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     RSEM_HIP_TRY(hipMemsetAsync(d_first, 0xff, 64 * sizeof(uint32_t), st));
     if (N1) {
         hipLaunchKernelGGL(k_row_keys, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, M, d_row_ptr, d_sid,
-                           d_keys, d_vals, d_err);
+                           d_cp_for_q32, range_bits, d_keys, d_vals, d_err);
         RSEM_HIP_TRY(hipGetLastError());
         size_t tb = 0;
         RSEM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_keys, d_keys2, d_vals, L.d_order, N1, 0, 64, st));
@@ -270,6 +336,9 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     L.n_slices = 0;
     L.n_planes = 0;
     L.n_slots = 0;
+    L.val_bytes = 0;
+    L.n_q32_rows = 0;
+    L.n_q32_planes = 0;
     uint32_t long_first = (h_first[kLongShape] == 0xffffffffu) ? (uint32_t)N1 : h_first[kLongShape];
     L.n_sell_rows = long_first;
     L.n_long_rows = (uint32_t)N1 - long_first;
@@ -279,9 +348,9 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
         for (int j = id + 1; j < kMaxShapes; j++)
             if (h_first[j] != 0xffffffffu) { next = h_first[j]; break; }
         Shape& S = L.h_shapes[L.n_shapes++];
-        S.lg = id / 4;
+        S.fmt = id / kShapesPerFmt;
+        S.lg = (id % kShapesPerFmt) / 4;
         S.K = id % 4 + 1;
-        S.pad = 0;
         S.row_base = h_first[id];
         S.n_rows = next - h_first[id];
         uint32_t rps = 64u >> S.lg;
@@ -289,9 +358,12 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
         S.slice_base = L.n_slices;
         S.plane_base = L.n_planes;
         S.slot_base = L.n_slots;
+        S.val_base = L.val_bytes;
         L.n_slices += S.n_slices;
         L.n_planes += (uint64_t)S.n_slices * S.K;
         L.n_slots += S.n_slices * rps;
+        L.val_bytes += (uint64_t)S.n_slices * S.K * plane_bytes(S.fmt);
+        if (S.fmt == kFmtQ32) { L.n_q32_rows += S.n_rows; L.n_q32_planes += (uint64_t)S.n_slices * S.K; }
     }
     // slices per block: enough blocks to fill the chip a few times over, long enough lane runs
     uint32_t T = forced_T ? forced_T : L.n_slices / std::max(1u, target_waves);
@@ -306,7 +378,8 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     if (L.n_sell_rows) {
         hipLaunchKernelGGL(k_fill_sell<true>, dim3(rsem::ceil_div(L.n_sell_rows, kBlock)), dim3(kBlock), 0, st,
                            L.d_shapes, L.n_shapes, L.T, L.n_sell_rows, L.d_order, d_row_ptr, d_sid, (const double*)nullptr,
-                           (const double*)nullptr, L.d_ssid, (double*)nullptr, (double*)nullptr);
+                           (const double*)nullptr, L.d_ssid, (unsigned char*)nullptr, (double*)nullptr, (int16_t*)nullptr,
+                           (int*)nullptr);
         RSEM_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_slice_minsid, dim3(rsem::ceil_div(L.n_slices, kBlock)), dim3(kBlock), 0, st, L.d_shapes,
                            L.n_shapes, L.T, L.n_slices, d_keys2, L.d_slice_minsid);
