@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsem_hip.so")
+# RSEM_HIP_LIB: another build of the same library (tuning experiments build variants next to it: tools/build_variants.sh)
+LIB_PATH = os.environ.get("RSEM_HIP_LIB") or os.path.join(_HERE, "librsem_hip.so")
 
 KERNEL_AUTO, KERNEL_CSR, KERNEL_SELL, KERNEL_LANE = 0, 1, 2, 3
 GIBBS_EXACT, GIBBS_PARALLEL = 0, 1

@@ -303,7 +303,22 @@ struct SliceRegs {
 // 2^e for the exponents q32_scale_of admits (always a normal double)
 __device__ inline double pow2_of(int e) { return __longlong_as_double((long long)(1023 + e) << 52); }
 
-template <int K, bool kFC, bool kQ>
+// How many slices a wave keeps in flight (register sets).  The loads of a slice are K wave loads of 512 B (F64) or 256 B
+// (Q32): with two sets in flight a Q32 wave has half the bytes outstanding of an F64 wave, and the kernel -- which is
+// bound by memory-level parallelism, not by arithmetic -- then runs no faster on half the traffic (measured:
+// profiles/r02d_bench_with_q32_depth2.json: 3.54 GB instead of 5.83 GB per launch, 1.08 ms instead of 1.05 ms).  Q32 sets
+// are smaller, so the same registers hold more of them; the depths below are what fits in 128 VGPRs (4 waves per SIMD,
+// which the 32 KB of LDS windows allow).  Per K = 1..4.
+#ifndef RSEM_F64_DEPTHS
+#define RSEM_F64_DEPTHS 2, 2, 2, 2
+#endif
+#ifndef RSEM_Q32_DEPTHS
+#define RSEM_Q32_DEPTHS 8, 6, 4, 3
+#endif
+constexpr int kF64Depth[4] = {RSEM_F64_DEPTHS};
+constexpr int kQ32Depth[4] = {RSEM_Q32_DEPTHS};
+
+template <int K, bool kFC, bool kQ, int NBUF>
 __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
                                    const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, double* th_win, double* cnt_win,
                                    const unsigned char* __restrict__ sval, const int16_t* __restrict__ sexp, const int32_t* __restrict__ ssid,
@@ -393,25 +408,57 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
 #pragma unroll
         for (int k = 0; k < K; k++) acc[k] += f[k] * inv;
     };
-    // ping-pong register sets A / B: the loads of the next slice are in flight while this one is reduced
-    SliceRegs<K, kQ> A, B;
-    unsigned long long mA = ~0ull, mB = 0;  // a block always starts fresh
-    issue(s_begin, mA, A);
-    th = theta_src<kFC>(theta, tsrc, N0, lane);  // (after the first slice's loads were issued: they fly meanwhile)
-    th0 = theta_at<kFC>(th, 0);
-    stage_windows<kFC>(base, span, M, th, th_win, cnt_win);  // ... and while the windows are staged
-    for (uint32_t s = s_begin; s < s_end; s += 2) {
-        if (s + 1 < s_end) {
-            mB = mask_of(s + 1);
-            issue(s + 1, mB, B);
+    if constexpr (NBUF == 2) {
+        // ping-pong register sets A / B: the loads of the next slice are in flight while this one is reduced
+        SliceRegs<K, kQ> A, B;
+        unsigned long long mA = ~0ull, mB = 0;  // a block always starts fresh
+        issue(s_begin, mA, A);
+        th = theta_src<kFC>(theta, tsrc, N0, lane);  // (after the first slice's loads were issued: they fly meanwhile)
+        th0 = theta_at<kFC>(th, 0);
+        stage_windows<kFC>(base, span, M, th, th_win, cnt_win);  // ... and while the windows are staged
+        for (uint32_t s = s_begin; s < s_end; s += 2) {
+            if (s + 1 < s_end) {
+                mB = mask_of(s + 1);
+                issue(s + 1, mB, B);
+            }
+            reduce(A, mA);
+            if (s + 1 >= s_end) break;
+            if (s + 2 < s_end) {
+                mA = mask_of(s + 2);
+                issue(s + 2, mA, A);
+            }
+            reduce(B, mB);
         }
-        reduce(A, mA);
-        if (s + 1 >= s_end) break;
-        if (s + 2 < s_end) {
-            mA = mask_of(s + 2);
-            issue(s + 2, mA, A);
+    } else {
+        // ring of NBUF register sets (fully unrolled: every index is static): NBUF - 1 slices in flight while one is reduced
+        SliceRegs<K, kQ> buf[NBUF];
+        unsigned long long mk[NBUF];
+        mk[0] = ~0ull;  // a block always starts fresh
+        issue(s_begin, mk[0], buf[0]);
+        th = theta_src<kFC>(theta, tsrc, N0, lane);
+        th0 = theta_at<kFC>(th, 0);
+        stage_windows<kFC>(base, span, M, th, th_win, cnt_win);
+#pragma unroll
+        for (int j = 1; j < NBUF - 1; j++)
+            if (s_begin + j < s_end) {
+                mk[j] = mask_of(s_begin + j);
+                issue(s_begin + j, mk[j], buf[j]);
+            }
+        for (uint32_t s = s_begin; s < s_end; s += NBUF) {
+#pragma unroll
+            for (int j = 0; j < NBUF; j++) {
+                const uint32_t t = s + j;
+                if (t < s_end) {  // (uniform over the wave)
+                    constexpr int ahead = NBUF - 1;
+                    const int nj = (j + ahead) % NBUF;  // static after unrolling
+                    if (t + ahead < s_end) {
+                        mk[nj] = mask_of(t + ahead);
+                        issue(t + ahead, mk[nj], buf[nj]);
+                    }
+                    reduce(buf[j], mk[j]);
+                }
+            }
         }
-        reduce(B, mB);
     }
     spill(rsid, acc);
 }
@@ -589,7 +636,7 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
         const uint32_t s_begin = S.slice_base + U.slice_begin + (uint32_t)w * U.per_wave;
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
 #define RSEM_ESTEP_BLOCK(KK, QQ) \
-    estep_block<KK, kFC, QQ>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M)
+    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1])>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M)
         if (s_begin < u_end) switch (S.K + 4 * S.fmt) {  // (uniform over the workgroup)
             case 1: RSEM_ESTEP_BLOCK(1, false); break;
             case 2: RSEM_ESTEP_BLOCK(2, false); break;

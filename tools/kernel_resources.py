@@ -4,9 +4,9 @@ import re
 import subprocess
 import sys
 
-src = sys.argv[1]
+src = sys.argv[1]  # further arguments go to hipcc (e.g. -DRSEM_Q32_DEPTHS=4,4,3,3)
 cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-ffp-contract=off", "-w",
-       "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
+       "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"] + sys.argv[2:]
 out = subprocess.run(cmd, stderr=subprocess.PIPE, text=True).stderr
 cur = None
 rows = {}
