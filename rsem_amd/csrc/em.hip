@@ -315,6 +315,13 @@ __device__ inline double pow2_of(int e) { return __longlong_as_double((long long
 #ifndef RSEM_Q32_DEPTHS
 #define RSEM_Q32_DEPTHS 8, 6, 4, 3
 #endif
+// Tuning by elimination (tools/build_variants.sh; NEVER set in the product build): each bit removes one component of the
+// E step so that its share of the launch time can be read off a bench run whose results are meaningless.
+//   1 no count spills (LDS / global atomics)   2 no division   4 no cross-lane reduction   8 no value loads
+//   16 no sid loads   32 no noise / exponent loads
+#ifndef RSEM_DIAG
+#define RSEM_DIAG 0
+#endif
 constexpr int kF64Depth[4] = {RSEM_F64_DEPTHS};
 constexpr int kQ32Depth[4] = {RSEM_Q32_DEPTHS};
 
@@ -349,17 +356,17 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
         const uint64_t pl = S.plane_base * 64 + vl;             // within the sid planes of the whole layout
         const bool want = (m >> lane) & 1ull;
 #pragma unroll
-        for (int k = 0; k < K; k++) b.id[k] = ssid[want ? pl + (uint64_t)k * 64 : 0];
+        for (int k = 0; k < K; k++) b.id[k] = (RSEM_DIAG & 16) ? (int)(t & 1023) + k : ssid[want ? pl + (uint64_t)k * 64 : 0];
 #pragma unroll
-        for (int k = 0; k < K; k++) b.c[k] = scp[vl + (uint64_t)k * 64];
+        for (int k = 0; k < K; k++) b.c[k] = (RSEM_DIAG & 8) ? (ValT)(t + k) : scp[vl + (uint64_t)k * 64];
         const uint32_t slot = S.slot_base + sl * R + (lane >> lg);
-        b.nc = g0 ? sncp[slot] : 0.0;
-        b.e = kQ ? (int)sexp[slot] : 0;
+        b.nc = (RSEM_DIAG & 32) ? 1e-30 : (g0 ? sncp[slot] : 0.0);
+        b.e = (RSEM_DIAG & 32) ? -40 : (kQ ? (int)sexp[slot] : 0);
     };
     auto spill = [&](const int* rsid, double* acc) {  // lane-private partial counts -> LDS window
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            if (acc[k] != 0.0) {
+            if (acc[k] != 0.0 && !(RSEM_DIAG & 1)) {
                 const unsigned off = (unsigned)(rsid[k] - base);
                 if (off < (unsigned)span) unsafeAtomicAdd(&cnt_win[off], acc[k]);
                 else unsafeAtomicAdd(&counts[rsid[k]], acc[k]);
@@ -401,8 +408,9 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
             f[k] = v;
             part += v;
         }
-        for (int d = 1; d < (1 << lg); d <<= 1) part += __shfl_xor(part, d);
-        const double inv = (part >= kEpsilon) ? 1.0 / part : 0.0;
+        if (!(RSEM_DIAG & 4))
+            for (int d = 1; d < (1 << lg); d <<= 1) part += __shfl_xor(part, d);
+        const double inv = (RSEM_DIAG & 2) ? part : ((part >= kEpsilon) ? 1.0 / part : 0.0);
         noise += f0 * inv;
         neff += (g0 && part >= kEpsilon) ? 1.0 : 0.0;  // reads whose fractions sum to one: sum(counts) without a reduction
 #pragma unroll
