@@ -350,18 +350,30 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
         const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), src);
         return ((unsigned long long)hi << 32) | lo;
     };
+    // Everything about a slice except the lane is uniform over the wave (s_begin / s_end come from the wave index, which
+    // the caller hands over through readfirstlane): the slice's base addresses are scalar, a lane adds its own constant
+    // offset -- no per-lane 64-bit address arithmetic.  The sids of a slice are loaded by all lanes or (mask 0, a scalar
+    // branch) by none: lanes that do not start a tuple ignore theirs.
+    const unsigned ulane = (unsigned)lane, uslot = ulane >> lg;
     auto issue = [&](uint32_t t, unsigned long long m, SliceRegs<K, kQ>& b) {
         const uint32_t sl = t - S.slice_base;
-        const uint64_t vl = (uint64_t)sl * K * 64 + lane;      // within the shape's value planes
-        const uint64_t pl = S.plane_base * 64 + vl;             // within the sid planes of the whole layout
-        const bool want = (m >> lane) & 1ull;
+        const uint64_t v0 = (uint64_t)sl * (K * 64);              // first entry of the slice within the shape's planes
+        const ValT* __restrict__ vp = scp + v0;
+        if ((RSEM_DIAG & 16) == 0) {
+            if (m != 0ull) {
+                const int32_t* __restrict__ ip = ssid + (S.plane_base * 64 + v0);
 #pragma unroll
-        for (int k = 0; k < K; k++) b.id[k] = (RSEM_DIAG & 16) ? (int)(t & 1023) + k : ssid[want ? pl + (uint64_t)k * 64 : 0];
+                for (int k = 0; k < K; k++) b.id[k] = ip[k * 64 + ulane];
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < K; k++) b.c[k] = (RSEM_DIAG & 8) ? (ValT)(t + k) : scp[vl + (uint64_t)k * 64];
-        const uint32_t slot = S.slot_base + sl * R + (lane >> lg);
-        b.nc = (RSEM_DIAG & 32) ? 1e-30 : (g0 ? sncp[slot] : 0.0);
-        b.e = (RSEM_DIAG & 32) ? -40 : (kQ ? (int)sexp[slot] : 0);
+            for (int k = 0; k < K; k++) b.id[k] = (int)(t & 1023) + k;
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) b.c[k] = (RSEM_DIAG & 8) ? (ValT)(t + k) : vp[k * 64 + ulane];
+        const uint32_t slot0 = S.slot_base + sl * R;
+        b.nc = (RSEM_DIAG & 32) ? 1e-30 : (g0 ? (sncp + slot0)[uslot] : 0.0);
+        b.e = (RSEM_DIAG & 32) ? -40 : (kQ ? (int)(sexp + slot0)[uslot] : 0);
     };
     auto spill = [&](const int* rsid, double* acc) {  // lane-private partial counts -> LDS window
 #pragma unroll
@@ -624,7 +636,8 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
     __shared__ double th_win[kWindow];
     __shared__ double cnt_win[kWindow];
     const Unit U = units[blockIdx.x];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // the wave index, as a scalar
     if (kSolo && solo.stat_round > 0) solo_close_round(solo, M, N0, theta);
     double noise = 0.0, neff = 0.0;
     {
