@@ -174,7 +174,7 @@ def timed_rounds(ctx, wl, N0, K, W, sync, barrier, agree=lambda x: x):
     return elapsed, reps * K, reps, estep_ms, float(out["theta"].sum())
 
 
-def q32_leg(ctx, wl, N0, K, W, sync, alg_bytes, f64_ms_per_step, f64_estep_ms):
+def q32_leg(ctx, wl, N0, K, W, sync, alg_bytes, f64_ms_per_step, f64_estep_ms, traffic=None):
     """The same context with Q32 value planes (rsem_em_set_option "value_bits" 32: 32-bit mantissas + one exponent per
     read for the reads that qualify, include/rsem_hip.h) -- same rounds, same procedure, reported BESIDE the headline,
     which stays on the doubles.  Also: theta after K rounds in both formats."""
@@ -200,7 +200,7 @@ def q32_leg(ctx, wl, N0, K, W, sync, alg_bytes, f64_ms_per_step, f64_estep_ms):
                 "frac_this_format": own / (estep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "frac_by_the_f64_formula": alg_bytes / (estep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "theta_max_rel_diff_vs_f64_after_%d_rounds" % K: float(np.max(np.abs(th - ref)[big] / ref[big])) if big.any() else 0.0,
-                "theta_sum": ts}
+                "theta_sum": ts, "traffic": traffic}
     except Exception as e:
         return {"error": str(e)}
 
@@ -373,7 +373,15 @@ def main():
 
     q32 = None
     if world == 1 and not distributed and not args.no_q32 and args.value_bits == 64 and args.kernel in (0, 3):
-        q32 = q32_leg(ctx, wl, N0g, K, W, sync, alg_bytes, elapsed * 1e3 / rounds, estep_ms)
+        q32_traffic = None  # the committed PMC measurement of this layout (profiles/pmc_traffic.json), as for the headline
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pm = json.load(f).get(args.config + "_q32")
+            if pm and args.scale == 1.0:
+                q32_traffic = pm["traffic_bytes_per_launch"]
+        except Exception:
+            pass
+        q32 = q32_leg(ctx, wl, N0g, K, W, sync, alg_bytes, elapsed * 1e3 / rounds, estep_ms, q32_traffic)
     ctx.close()
     if rank == 0:
         achieved = alg_bytes / (estep_ms * 1e-3) / 1e9
