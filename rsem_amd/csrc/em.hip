@@ -322,6 +322,38 @@ __device__ inline double pow2_of(int e) { return __longlong_as_double((long long
 #ifndef RSEM_DIAG
 #define RSEM_DIAG 0
 #endif
+// Candidates for the next measurement (tools/build_variants.sh; off in the product build until measured and tested on a GPU):
+//   RSEM_FAST_RCP    1 / normaliser as v_rcp_f64 + two Newton steps (<= 2 ulp) instead of the IEEE division sequence
+//   RSEM_DPP_REDUCE  the per-read normaliser's butterfly over 2..16 lanes with DPP moves instead of ds_bpermute
+//                    (same additions in the same order: bit-identical)
+#ifndef RSEM_FAST_RCP
+#define RSEM_FAST_RCP 0
+#endif
+#ifndef RSEM_DPP_REDUCE
+#define RSEM_DPP_REDUCE 0
+#endif
+__device__ inline double recip_newton(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+template <int kCtrl>
+__device__ inline double dpp_take(double v) {  // the value of the lane the DPP control selects (all lanes active here)
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, kCtrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), kCtrl, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// sum over the 2^lg lanes of a read, every lane ends with the total.  Steps 1, 2: quad permutes; 4: row_half_mirror (the
+// other quad of the 8-group: all its lanes hold the same quad sum); 8: row_mirror; 16, 32: ds_bpermute as before.
+__device__ inline double read_sum_dpp(double part, int lg) {
+    if (lg >= 1) part += dpp_take<0xB1>(part);   // quad_perm [1,0,3,2]
+    if (lg >= 2) part += dpp_take<0x4E>(part);   // quad_perm [2,3,0,1]
+    if (lg >= 3) part += dpp_take<0x141>(part);  // row_half_mirror
+    if (lg >= 4) part += dpp_take<0x140>(part);  // row_mirror
+    for (int d = 16; d < (1 << lg); d <<= 1) part += __shfl_xor(part, d);
+    return part;
+}
 constexpr int kF64Depth[4] = {RSEM_F64_DEPTHS};
 constexpr int kQ32Depth[4] = {RSEM_Q32_DEPTHS};
 
@@ -420,9 +452,11 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
             f[k] = v;
             part += v;
         }
-        if (!(RSEM_DIAG & 4))
-            for (int d = 1; d < (1 << lg); d <<= 1) part += __shfl_xor(part, d);
-        const double inv = (RSEM_DIAG & 2) ? part : ((part >= kEpsilon) ? 1.0 / part : 0.0);
+        if (!(RSEM_DIAG & 4)) {
+            if (RSEM_DPP_REDUCE) part = read_sum_dpp(part, lg);
+            else for (int d = 1; d < (1 << lg); d <<= 1) part += __shfl_xor(part, d);
+        }
+        const double inv = (RSEM_DIAG & 2) ? part : ((part >= kEpsilon) ? (RSEM_FAST_RCP ? recip_newton(part) : 1.0 / part) : 0.0);
         noise += f0 * inv;
         neff += (g0 && part >= kEpsilon) ? 1.0 : 0.0;  // reads whose fractions sum to one: sum(counts) without a reduction
 #pragma unroll

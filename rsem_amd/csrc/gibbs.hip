@@ -57,6 +57,11 @@ __global__ void k_fill_double(int32_t n, double v, double* g) {
     if (i < n) g[i] = v;
 }
 
+// Candidate for the next measurement (tools/build_variants.sh; off until measured and tested on a GPU): the E step's scalar
+// slice addressing (which took 10 % off its Q32 launch) in the sweep kernel.
+#ifndef RSEM_GIBBS_SCALAR_ADDR
+#define RSEM_GIBBS_SCALAR_ADDR 0
+#endif
 constexpr int kGWindow = 2048;  // sids per workgroup window (g values: 16 KB, int counts: 8 KB of LDS)
 
 // g[base, base+span) -> LDS, count window zeroed; every wave of the workgroup calls this exactly once
@@ -105,6 +110,21 @@ __device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin,
     };
     auto issue = [&](uint32_t t, unsigned long long m, SliceRegs<K>& b) {
         const uint32_t sl = t - S.slice_base;
+#if RSEM_GIBBS_SCALAR_ADDR
+        // as in the E step (em.hip, estep_block): scalar slice bases + a constant lane offset; the sids of a slice are
+        // loaded by all lanes or (mask 0) by none
+        const uint64_t p0 = (S.plane_base + (uint64_t)sl * K) * 64;
+        const unsigned ulane = (unsigned)lane;
+        if (m != 0ull) {
+            const int32_t* __restrict__ ip = ssid + p0;
+#pragma unroll
+            for (int k = 0; k < K; k++) b.id[k] = ip[k * 64 + ulane];
+        }
+        const double* __restrict__ vp = scp + p0;
+#pragma unroll
+        for (int k = 0; k < K; k++) b.c[k] = vp[k * 64 + ulane];
+        b.nc = g0lane ? (sncp + (S.slot_base + sl * R))[ulane >> lg] : 0.0;
+#else
         const uint64_t pl = (S.plane_base + (uint64_t)sl * K) * 64 + lane;
         const bool want = (m >> lane) & 1ull;
 #pragma unroll
@@ -112,6 +132,7 @@ __device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin,
 #pragma unroll
         for (int k = 0; k < K; k++) b.c[k] = scp[pl + (uint64_t)k * 64];
         b.nc = g0lane ? sncp[S.slot_base + sl * R + (lane >> lg)] : 0.0;
+#endif
     };
     int rsid[K], acc[K];
     double rg[K];
@@ -213,7 +234,12 @@ __global__ __launch_bounds__(kBlock) void k_sample_z_lane(
     __shared__ int s_noise;
     const Unit U = units[blockIdx.x];
     if (threadIdx.x == 0) s_noise = 0;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+#if RSEM_GIBBS_SCALAR_ADDR
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+    const int w = threadIdx.x >> 6;
+#endif
     int noise = 0;
     {
         const Shape S = U.S;
