@@ -1056,6 +1056,7 @@ struct rsem_em_ctx {
     int value_bits = 64;              // 64: every read F64; 32: Q32 where a read qualifies
     int value_range_bits = 8;         // a read qualifies when its non-zero values span less than 2^this
     bool layout_has_q32 = false;      // the current layout was built with Q32 shapes (from the then-current values)
+    bool layout_ok = false;           // false between free_layout and a build_layout that went through (a failed rebuild)
     // LANE variant work list
     Unit* d_units = nullptr;
     unsigned long long* d_trace = nullptr;  // per-workgroup timestamps (tune_unit_order, rsem_em_debug_trace)
@@ -1195,6 +1196,7 @@ void free_layout(rsem_em_ctx* c) {
     c->h_units.clear();
     c->n_units = 0;
     c->layout_has_q32 = false;
+    c->layout_ok = false;
 }
 
 int build_layout(rsem_em_ctx* c) {
@@ -1234,6 +1236,7 @@ int build_layout(rsem_em_ctx* c) {
     RSEM_HIP_TRY(hipMemsetAsync(c->d_noise_a, 0, sizeof(double) * c->noise_cap, c->stream));
 
     c->grid_long = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_long_rows, kBlock)));
+    c->layout_ok = true;
     return RSEM_OK;
 }
 
@@ -1435,7 +1438,7 @@ int rsem_em_get_info(const rsem_em_ctx* c, const char* key, int64_t* value) {
 // unit u in dispatch order; *n_units_io in: capacity (units), out: units written.
 int rsem_em_debug_trace(rsem_em_ctx* c, const double* theta, unsigned long long* out, uint32_t* n_units_io) {
     RSEM_REQUIRE(c && theta && out && n_units_io, "NULL argument");
-    RSEM_REQUIRE(resolved_kernel(c) == RSEM_EM_KERNEL_LANE && c->have_values, "needs the LANE kernel with values set");
+    RSEM_REQUIRE(resolved_kernel(c) == RSEM_EM_KERNEL_LANE && c->have_values && c->layout_ok, "needs the LANE kernel with values set");
     RSEM_REQUIRE(*n_units_io >= c->n_units, "trace buffer too small");
     RSEM_HIP_TRY(hipSetDevice(c->device));
     unsigned long long* d = nullptr;
@@ -1548,6 +1551,7 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
     RSEM_REQUIRE(c && theta, "NULL argument");
     RSEM_REQUIRE(max_round > round0, "max_round must exceed round0");
     if (!c->have_values) { rsem::set_last_error("CSR values were never set"); return RSEM_ERR_STATE; }
+    if (!c->layout_ok) { rsem::set_last_error("the device layout could not be rebuilt after the last change of values / options"); return RSEM_ERR_STATE; }
     RSEM_HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const size_t nb = sizeof(double) * ((size_t)c->M + 1);
@@ -1736,6 +1740,7 @@ int rsem_em_step(rsem_em_ctx* c, const double* theta, double N0, double* counts,
                  double* bChange, int32_t* totNum) {
     RSEM_REQUIRE(c && theta, "NULL argument");
     if (!c->have_values) { rsem::set_last_error("CSR values were never set"); return RSEM_ERR_STATE; }
+    if (!c->layout_ok) { rsem::set_last_error("the device layout could not be rebuilt after the last change of values / options"); return RSEM_ERR_STATE; }
     RSEM_HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const size_t nb = sizeof(double) * ((size_t)c->M + 1);
@@ -1760,6 +1765,7 @@ int rsem_em_step(rsem_em_ctx* c, const double* theta, double N0, double* counts,
 int rsem_em_expected_weights(rsem_em_ctx* c, const double* theta, double N0, double* counts, double* w, double* w_noise) {
     RSEM_REQUIRE(c && theta, "NULL argument");
     if (!c->have_values) { rsem::set_last_error("CSR values were never set"); return RSEM_ERR_STATE; }
+    if (!c->layout_ok) { rsem::set_last_error("the device layout could not be rebuilt after the last change of values / options"); return RSEM_ERR_STATE; }
     RSEM_HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const size_t nb = sizeof(double) * ((size_t)c->M + 1);
@@ -1822,6 +1828,7 @@ int em_step_with_weights(rsem_em_ctx* c, const double* theta, double N0, double*
                          double* bChange, int32_t* totNum) {
     RSEM_REQUIRE(c && theta, "NULL argument");
     if (!c->have_values) { set_last_error("CSR values were never set"); return RSEM_ERR_STATE; }
+    if (!c->layout_ok) { set_last_error("the device layout could not be rebuilt after the last change of values / options"); return RSEM_ERR_STATE; }
     RSEM_HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const size_t nb = sizeof(double) * ((size_t)c->M + 1);
