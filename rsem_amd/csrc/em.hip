@@ -366,9 +366,19 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
     using ValT = typename std::conditional<kQ, uint32_t, double>::type;
     const ValT* __restrict__ scp = (const ValT*)(sval + S.val_base);  // this shape's value planes
     const int lg = S.lg;
+#if RSEM_GENERAL_G
+    // lanes per read need not be a power of two (sell_layout.hpp): read r of the slice sits in lanes [r * G, r * G + G), the
+    // lanes past the last read idle on zero planes
+    const int G = shape_G(S);
+    const uint32_t R = shape_R(S);
+    const int rr = lg >= 0 ? (lane >> lg) : lane / G;
+    const int g = lane - rr * G;
+    const bool g0 = (g == 0) && (uint32_t)rr < R;
+#else
     const int g = lane & ((1 << lg) - 1);
     const bool g0 = (g == 0);
     const uint32_t R = 64u >> lg;
+#endif
     // 64 slices' masks at a time, one per lane
     uint32_t m_base = s_begin;
     unsigned long long mv = (s_begin + lane < s_end) ? masks[s_begin + lane] : ~0ull;
@@ -386,7 +396,11 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
     // the caller hands over through readfirstlane): the slice's base addresses are scalar, a lane adds its own constant
     // offset -- no per-lane 64-bit address arithmetic.  The sids of a slice are loaded by all lanes or (mask 0, a scalar
     // branch) by none: lanes that do not start a tuple ignore theirs.
+#if RSEM_GENERAL_G
+    const unsigned ulane = (unsigned)lane, uslot = (unsigned)rr < R ? (unsigned)rr : R - 1;  // (idle lanes: any slot of the slice)
+#else
     const unsigned ulane = (unsigned)lane, uslot = ulane >> lg;
+#endif
     auto issue = [&](uint32_t t, unsigned long long m, SliceRegs<K, kQ>& b) {
         const uint32_t sl = t - S.slice_base;
         const uint64_t v0 = (uint64_t)sl * (K * 64);              // first entry of the slice within the shape's planes
@@ -453,6 +467,15 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
             part += v;
         }
         if (!(RSEM_DIAG & 4)) {
+#if RSEM_GENERAL_G
+            if (lg < 0) {  // (uniform over the workgroup) any G: fold towards the read's first lane, then hand the total back
+                for (int d = 1; d < G; d <<= 1) {
+                    const double o = __shfl_down(part, d);
+                    if (g + d < G) part += o;
+                }
+                part = __shfl(part, lane - g);
+            } else
+#endif
             if (RSEM_DPP_REDUCE) part = read_sum_dpp(part, lg);
             else for (int d = 1; d < (1 << lg); d <<= 1) part += __shfl_xor(part, d);
         }
@@ -1056,6 +1079,7 @@ struct rsem_em_ctx {
     int value_bits = 64;              // 64: every read F64; 32: Q32 where a read qualifies
     int value_range_bits = 8;         // a read qualifies when its non-zero values span less than 2^this
     bool layout_has_q32 = false;      // the current layout was built with Q32 shapes (from the then-current values)
+    int lane_policy = 0;              // RSEM_GENERAL_G builds: 1 = lanes per read chosen for the fewest plane bytes
     bool layout_ok = false;           // false between free_layout and a build_layout that went through (a failed rebuild)
     // LANE variant work list
     Unit* d_units = nullptr;
@@ -1119,6 +1143,7 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
                                c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs());
     } else {
         if (c->layout_has_q32) { rsem::set_last_error("the SELL kernel reads F64 planes only (value_bits = 32 needs the LANE kernel)"); return RSEM_ERR_STATE; }
+        if (c->L.has_general_g) { rsem::set_last_error("the SELL kernel needs power-of-two lane groups (lane_policy = 1 needs the LANE kernel)"); return RSEM_ERR_STATE; }
         hipLaunchKernelGGL(k_estep_sell, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
                            c->L.n_slices, d_theta, (const double*)c->d_sval, c->L.d_ssid, c->d_sncp, d_counts, c->d_noise_a, ctrl);
     }
@@ -1203,6 +1228,7 @@ int build_layout(rsem_em_ctx* c) {
     // one block per wave, ~2.5 blocks per wave slot (6 waves/SIMD) for load balance
     const uint32_t target_waves = (uint32_t)c->n_cus * 4 * 6 * 5 / 2;
     const bool q32 = c->value_bits == 32 && c->have_values;
+    c->L.g_policy = c->lane_policy;
     int rc = sell_build(c->L, c->stream, c->N1, c->M, c->d_row_ptr, c->d_sid, target_waves, c->forced_T,
                         q32 ? c->d_cp : nullptr, c->value_range_bits);
     if (rc != RSEM_OK) return rc;
@@ -1410,6 +1436,22 @@ int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
         set_grid_for_kernel(c);
         return RSEM_OK;
     }
+    if (!strcmp(key, "lane_policy")) {  // experimental (RSEM_GENERAL_G builds only): see sell_layout.hpp
+#if RSEM_GENERAL_G
+        RSEM_REQUIRE(value == 0 || value == 1, "lane_policy must be 0 or 1");
+        if (c->lane_policy == (int)value) return RSEM_OK;
+        c->lane_policy = (int)value;
+        RSEM_HIP_TRY(hipSetDevice(c->device));
+        free_layout(c);
+        int rc = build_layout(c);
+        if (rc != RSEM_OK) return rc;
+        set_grid_for_kernel(c);
+        return RSEM_OK;
+#else
+        rsem::set_last_error("lane_policy: this build has power-of-two lane groups only");
+        return value == 0 ? RSEM_OK : RSEM_ERR_INVALID;
+#endif
+    }
     if (!strcmp(key, "check_every")) {
         RSEM_REQUIRE(value >= 1 && value <= kHistCap / 4, "check_every out of range");
         c->check_every = (int)value;
@@ -1430,6 +1472,8 @@ int rsem_em_get_info(const rsem_em_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "sid_plane_bytes")) *value = (int64_t)(c->L.n_planes * 256);
     else if (!strcmp(key, "slots")) *value = c->L.n_slots;
     else if (!strcmp(key, "units")) *value = c->n_units;
+    else if (!strcmp(key, "lane_policy")) *value = c->lane_policy;
+    else if (!strcmp(key, "general_g")) *value = RSEM_GENERAL_G;
     else { rsem::set_last_error("unknown info key '%s'", key); return RSEM_ERR_INVALID; }
     return RSEM_OK;
 }

@@ -30,9 +30,27 @@
 
 namespace {
 
+// RSEM_GENERAL_G (compile-time, off in the product build until measured and tested on a GPU; tools/build_variants.sh):
+// the lanes a read occupies need not be a power of two.  With G = 2^lg a read of L alignments occupies K * 2^lg >= L
+// entries -- on BASELINE configs[2] 14 % of the value planes are padding, and the F64 E step sits on the HBM ceiling for
+// the bytes it moves.  With any G in 1..64 (R = floor(64 / G) reads per slice, the last 64 - R * G lanes idle) the shape of a
+// read length is the (G, K) that minimises K * 64 / R bytes per read: L = 9 -> (3, 3) instead of (4, 3), L = 10 -> (5, 2),
+// L = 14 -> (7, 2), ...  Planes stay 64 entries wide and aligned; only the lane -> (read, position) mapping and the
+// reduction over a read's lanes change.  Shape::lg then holds log2(G) for a power of two and -G otherwise.
+#ifndef RSEM_GENERAL_G
+#define RSEM_GENERAL_G 0
+#endif
+#if RSEM_GENERAL_G
+constexpr int kShapesPerFmt = 256;  // (G 1..64) x (K 1..4): id = (G - 1) * 4 + (K - 1)
+constexpr int kShapeBits = 10;
+#else
 constexpr int kShapesPerFmt = 28;   // (lg 0..6) x (K 1..4)
+constexpr int kShapeBits = 6;
+#endif
 constexpr int kMaxShapes = 2 * kShapesPerFmt;  // F64 shapes, then Q32 shapes
-constexpr int kLongShape = 63;      // rows with more than 256 alignments: CSR kernel
+constexpr int kShapeIds = 1 << kShapeBits;
+constexpr int kLongShape = kShapeIds - 1;      // rows with more than 256 alignments: CSR kernel
+constexpr uint32_t kKeyMinSidCap = (1u << (32 - kShapeBits)) - 1;  // sort key: shape | min sid (capped) | hash of the tuple
 constexpr int kFmtF64 = 0, kFmtQ32 = 1;
 constexpr int kMaxK = 4;
 constexpr int kBlock = 256;         // 4 waves
@@ -45,7 +63,7 @@ struct Shape {
     uint32_t n_rows;
     uint32_t slot_base;   // first row slot (slot = slice * rows_per_slice + r)
     int32_t K;            // planes per slice
-    int32_t lg;           // log2(lanes per read)
+    int32_t lg;           // log2(lanes per read)  [RSEM_GENERAL_G: -G when G is not a power of two]
     int32_t fmt;          // kFmtF64 / kFmtQ32
     uint64_t val_base;    // byte offset of this shape's value planes (512 B per F64 plane, 256 B per Q32 plane)
 };
@@ -69,6 +87,52 @@ __device__ inline uint32_t q32_mantissa(double v, int e) {
     return m >= 4294967295.0 ? 0xffffffffu : (uint32_t)m;
 }
 
+__host__ __device__ inline int shape_G(const Shape& S) {  // lanes per read
+#if RSEM_GENERAL_G
+    return S.lg >= 0 ? (1 << S.lg) : -S.lg;
+#else
+    return 1 << S.lg;
+#endif
+}
+__host__ __device__ inline uint32_t shape_R(const Shape& S) {  // reads per slice
+#if RSEM_GENERAL_G
+    return S.lg >= 0 ? (64u >> S.lg) : 64u / (uint32_t)(-S.lg);
+#else
+    return 64u >> S.lg;
+#endif
+}
+
+#if RSEM_GENERAL_G
+// read length -> shape id, for L = 0..256 (longer: kLongShape).  policy 0: G a power of two (the layout of the default
+// build); policy 1: the (G, K) with the fewest plane bytes per read, kept only where it saves >= 3 % over policy 0
+// (the power-of-two butterfly is the cheaper reduction); ties: power-of-two G first, then more planes (more reads per slice).
+inline void shape_policy_table(int policy, uint16_t* tab) {
+    for (int L = 0; L <= 256; L++) {
+        int G0 = 1, K0 = L < 1 ? 1 : L;
+        if (L > 4) {
+            int lg = 1, cap = 8;
+            while (L > cap) { cap <<= 1; ++lg; }
+            G0 = 1 << lg;
+            K0 = (L + G0 - 1) / G0;
+        }
+        int G = G0, K = K0;
+        if (policy == 1 && L > 4) {
+            const double c0 = K0 * 64.0 / (64 / G0);
+            double best = c0;
+            for (int k = 1; k <= 4; k++) {
+                const int g = (L + k - 1) / k;
+                if (g > 64) continue;
+                const double c = k * 64.0 / (64 / g);
+                const bool p2 = (g & (g - 1)) == 0, bp2 = (G & (G - 1)) == 0;
+                if (c < best - 1e-9 || (c < best + 1e-9 && ((p2 && !bp2) || (p2 == bp2 && k > K)))) { best = c; G = g; K = k; }
+            }
+            if (!(best < 0.97 * c0)) { G = G0; K = K0; }
+        }
+        tab[L] = (uint16_t)((G - 1) * 4 + (K - 1));
+    }
+}
+#endif
+
 __host__ __device__ inline int shape_id_of(uint64_t L) {
     if (L <= 4) return (int)(L == 0 ? 0 : L - 1);  // lg = 0, K = L
     int lg = 1;
@@ -81,7 +145,7 @@ __host__ __device__ inline int shape_id_of(uint64_t L) {
 
 // sorted read q of a shape  ->  (slice within the shape, row slot within the slice)
 __host__ __device__ inline void row_to_slot(const Shape& S, uint32_t T, uint32_t q, uint32_t& slice_local, uint32_t& r) {
-    const uint32_t R = 64u >> S.lg, rpb = R * T;
+    const uint32_t R = shape_R(S), rpb = R * T;
     const uint32_t b = q / rpb, qb = q % rpb;
     const uint32_t left = S.n_rows - b * rpb;
     const uint32_t nb = left < rpb ? left : rpb;
@@ -100,6 +164,9 @@ __device__ inline uint32_t mix32(uint32_t h, uint32_t v) {
 // cp != nullptr: reads that qualify (q32_scale_of) go to the Q32 twin of their shape
 __global__ void k_row_keys(uint64_t N1, int32_t M, const uint64_t* __restrict__ row_ptr,
                            const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits,
+#if RSEM_GENERAL_G
+                           const uint16_t* __restrict__ shape_of_len,
+#endif
                            uint64_t* keys, uint32_t* vals, int* err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N1) return;
@@ -119,19 +186,23 @@ __global__ void k_row_keys(uint64_t N1, int32_t M, const uint64_t* __restrict__ 
             if (v > 0.0) vmn = fmin(vmn, v);
         }
     }
-    if (mn > 0x3ffffffu) mn = 0x3ffffffu;
+    if (mn > kKeyMinSidCap) mn = kKeyMinSidCap;
+#if RSEM_GENERAL_G
+    int shape = (to - fr) <= 256 ? (int)shape_of_len[to - fr] : kLongShape;
+#else
     int shape = shape_id_of(to - fr);
+#endif
     Q32Scale q;
     if (cp && shape != kLongShape && q32_scale_of(vmx, vmn, range_bits, q)) shape += kShapesPerFmt;
-    keys[i] = ((uint64_t)shape << 58) | ((uint64_t)mn << 32) | h;
+    keys[i] = ((uint64_t)shape << (64 - kShapeBits)) | ((uint64_t)mn << 32) | h;
     vals[i] = (uint32_t)i;
 }
 
 __global__ void k_shape_bounds(uint64_t N1, const uint64_t* __restrict__ keys, uint32_t* first) {
     uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N1) return;
-    int sh = (int)(keys[p] >> 58);
-    if (p == 0 || sh != (int)(keys[p - 1] >> 58)) first[sh] = (uint32_t)p;
+    int sh = (int)(keys[p] >> (64 - kShapeBits));
+    if (p == 0 || sh != (int)(keys[p - 1] >> (64 - kShapeBits))) first[sh] = (uint32_t)p;
 }
 
 __device__ inline int find_shape_by_row(const Shape* shapes, int n, uint32_t p) {
@@ -152,7 +223,7 @@ __global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint
     if (p >= n_sell_rows) return;
     int sh = find_shape_by_row(shapes, n_shapes, p);
     const Shape S = shapes[sh];
-    const int G = 1 << S.lg;
+    const int G = shape_G(S);
     uint32_t slice_local, r;
     row_to_slot(S, T, p - S.row_base, slice_local, r);
     uint32_t orig = order[p];
@@ -160,7 +231,7 @@ __global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint
     int L = (int)(row_ptr[orig + 1] - fr);
     const uint64_t pl_local = (uint64_t)slice_local * S.K * 64;   // first entry of the slice, within the shape
     const uint64_t pl0 = S.plane_base * 64 + pl_local;
-    const uint32_t slot = S.slot_base + slice_local * (64u >> S.lg) + r;
+    const uint32_t slot = S.slot_base + slice_local * shape_R(S) + r;
     Q32Scale q{0};
     if (cp && S.fmt == kFmtQ32) {
         double vmx = 0.0;
@@ -170,7 +241,11 @@ __global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint
         if (sexp) sexp[slot] = (int16_t)q.e;
     }
     for (int c = 0; c < L; c++) {
+#if RSEM_GENERAL_G
+        const uint64_t off = (uint64_t)(c / G) * 64 + r * G + (c % G);
+#else
         const uint64_t off = (uint64_t)(c >> S.lg) * 64 + r * G + (c & (G - 1));
+#endif
         if (kIds) ssid[pl0 + off] = sid[fr + c];
         if (cp) {
             if (S.fmt == kFmtQ32) ((uint32_t*)(sval + S.val_base))[pl_local + off] = q32_mantissa(cp[fr + c], q.e);
@@ -203,9 +278,13 @@ __global__ void k_slice_masks(const Shape* __restrict__ shapes, int n_shapes, ui
             changed = changed || (pv != v);
         }
     // a read occupies G lanes: all of them restart together
-    const int G = 1 << S.lg;
+    const int G = shape_G(S);
     unsigned long long m = __ballot(changed);
+#if RSEM_GENERAL_G
+    const int gb = (lane / G) * G;  // (the idle lanes past the last read of the slice form a partial group of their own)
+#else
     const int gb = lane & ~(G - 1);
+#endif
     const unsigned long long grp = (G == 64) ? ~0ull : (((1ull << G) - 1) << gb);
     m = __ballot((m & grp) != 0);
     if (lane == 0) masks[s] = m;
@@ -219,9 +298,9 @@ __global__ void k_slice_minsid(const Shape* __restrict__ shapes, int n_shapes, u
     int sh = 0;
     while (sh + 1 < n_shapes && s >= shapes[sh + 1].slice_base) ++sh;
     const Shape S = shapes[sh];
-    const uint32_t sl = s - S.slice_base, R = 64u >> S.lg;
+    const uint32_t sl = s - S.slice_base, R = shape_R(S);
     uint32_t q = (sl / T) * R * T + sl % T;  // row slot 0 of this slice
-    slice_minsid[s] = (uint32_t)((keys_sorted[S.row_base + q] >> 32) & 0x3ffffffu);
+    slice_minsid[s] = (uint32_t)((keys_sorted[S.row_base + q] >> 32) & kKeyMinSidCap);
 }
 
 // largest sid of every slice (for the extent of a unit's LDS windows)
@@ -259,6 +338,8 @@ struct SellLayout {
     uint32_t n_slots = 0;
     uint64_t n_planes = 0;
     uint64_t val_bytes = 0;       // value planes of all shapes (Shape::val_base points into them)
+    int g_policy = 0;             // RSEM_GENERAL_G builds: 0 = lanes per read a power of two, 1 = fewest plane bytes (set before sell_build)
+    bool has_general_g = false;   // some shape's G is not a power of two
     uint32_t n_q32_rows = 0;      // sorted rows held in Q32 shapes
     uint64_t n_q32_planes = 0;
     int32_t* d_ssid = nullptr;
@@ -307,13 +388,25 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     RSEM_HIP_TRY(dmalloc(&d_keys2, N1));
     RSEM_HIP_TRY(dmalloc(&d_vals, N1));
     RSEM_HIP_TRY(dmalloc(&L.d_order, N1));
-    RSEM_HIP_TRY(dmalloc(&d_first, 64));
+    RSEM_HIP_TRY(dmalloc(&d_first, kShapeIds));
     RSEM_HIP_TRY(dmalloc(&d_err, 1));
     RSEM_HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), st));
-    RSEM_HIP_TRY(hipMemsetAsync(d_first, 0xff, 64 * sizeof(uint32_t), st));
+    RSEM_HIP_TRY(hipMemsetAsync(d_first, 0xff, kShapeIds * sizeof(uint32_t), st));
+#if RSEM_GENERAL_G
+    uint16_t h_tab[257];
+    shape_policy_table(L.g_policy, h_tab);
+    uint16_t* d_tab = nullptr;
+    RSEM_HIP_TRY(dmalloc(&d_tab, 257));
+    struct TabFree { uint16_t* p; ~TabFree() { hipFree(p); } } tab_free{d_tab};
+    RSEM_HIP_TRY(hipMemcpyAsync(d_tab, h_tab, sizeof(h_tab), hipMemcpyHostToDevice, st));
+#endif
     if (N1) {
         hipLaunchKernelGGL(k_row_keys, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, M, d_row_ptr, d_sid,
-                           d_cp_for_q32, range_bits, d_keys, d_vals, d_err);
+                           d_cp_for_q32, range_bits,
+#if RSEM_GENERAL_G
+                           (const uint16_t*)d_tab,
+#endif
+                           d_keys, d_vals, d_err);
         RSEM_HIP_TRY(hipGetLastError());
         size_t tb = 0;
         RSEM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_keys, d_keys2, d_vals, L.d_order, N1, 0, 64, st));
@@ -322,7 +415,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
         hipLaunchKernelGGL(k_shape_bounds, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, d_keys2, d_first);
         RSEM_HIP_TRY(hipGetLastError());
     }
-    uint32_t h_first[64];
+    uint32_t h_first[kShapeIds];
     int h_err = 0;
     RSEM_HIP_TRY(hipMemcpyAsync(h_first, d_first, sizeof(h_first), hipMemcpyDeviceToHost, st));
     RSEM_HIP_TRY(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -339,6 +432,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     L.val_bytes = 0;
     L.n_q32_rows = 0;
     L.n_q32_planes = 0;
+    L.has_general_g = false;
     uint32_t long_first = (h_first[kLongShape] == 0xffffffffu) ? (uint32_t)N1 : h_first[kLongShape];
     L.n_sell_rows = long_first;
     L.n_long_rows = (uint32_t)N1 - long_first;
@@ -349,11 +443,21 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
             if (h_first[j] != 0xffffffffu) { next = h_first[j]; break; }
         Shape& S = L.h_shapes[L.n_shapes++];
         S.fmt = id / kShapesPerFmt;
+#if RSEM_GENERAL_G
+        {
+            const int G = (id % kShapesPerFmt) / 4 + 1;
+            int lg = 0;
+            while ((1 << lg) < G) ++lg;
+            S.lg = ((1 << lg) == G) ? lg : -G;
+            if (S.lg < 0) L.has_general_g = true;
+        }
+#else
         S.lg = (id % kShapesPerFmt) / 4;
+#endif
         S.K = id % 4 + 1;
         S.row_base = h_first[id];
         S.n_rows = next - h_first[id];
-        uint32_t rps = 64u >> S.lg;
+        uint32_t rps = shape_R(S);
         S.n_slices = (S.n_rows + rps - 1) / rps;
         S.slice_base = L.n_slices;
         S.plane_base = L.n_planes;
