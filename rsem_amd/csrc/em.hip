@@ -332,6 +332,16 @@ __device__ inline double pow2_of(int e) { return __longlong_as_double((long long
 #ifndef RSEM_DPP_REDUCE
 #define RSEM_DPP_REDUCE 0
 #endif
+//   RSEM_CLAMP_FAST  the 1e-300 clamps of a slice's terms (EM.cpp:212,219: one compare + two selects per alignment) are
+//                    applied only when some lane of the wave has a term under the threshold (one ballot per slice);
+//                    otherwise the products are used as they are -- the same values, since nothing was to be clamped
+//   RSEM_FMA_ACC     acc += f * inv as one fused multiply-add (one rounding instead of two: last-bit differences)
+#ifndef RSEM_CLAMP_FAST
+#define RSEM_CLAMP_FAST 0
+#endif
+#ifndef RSEM_FMA_ACC
+#define RSEM_FMA_ACC 0
+#endif
 __device__ inline double recip_newton(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
@@ -462,9 +472,21 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
             // Q32: mantissa * 2^e is exact, so this is the F64 expression on the rounded value
             const double cv = kQ ? (double)cur.c[k] * scale : (double)cur.c[k];
             double v = rth[k] * cv;
-            if (v < kEpsilon) v = 0.0;
+            if (!RSEM_CLAMP_FAST && v < kEpsilon) v = 0.0;
             f[k] = v;
-            part += v;
+            if (!RSEM_CLAMP_FAST) part += v;
+        }
+        if (RSEM_CLAMP_FAST) {
+            bool small = false;
+#pragma unroll
+            for (int k = 0; k < K; k++) small = small || (f[k] < kEpsilon);
+            if (__ballot(small) != 0ull) {  // (uniform) rare: some theta * conprb of this slice is under 1e-300
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    if (f[k] < kEpsilon) f[k] = 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) part += f[k];
         }
         if (!(RSEM_DIAG & 4)) {
 #if RSEM_GENERAL_G
@@ -483,7 +505,7 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
         noise += f0 * inv;
         neff += (g0 && part >= kEpsilon) ? 1.0 : 0.0;  // reads whose fractions sum to one: sum(counts) without a reduction
 #pragma unroll
-        for (int k = 0; k < K; k++) acc[k] += f[k] * inv;
+        for (int k = 0; k < K; k++) acc[k] = RSEM_FMA_ACC ? fma(f[k], inv, acc[k]) : acc[k] + f[k] * inv;
     };
     if constexpr (NBUF == 2) {
         // ping-pong register sets A / B: the loads of the next slice are in flight while this one is reduced
