@@ -336,6 +336,11 @@ __device__ inline double pow2_of(int e) { return __longlong_as_double((long long
 //                    applied only when some lane of the wave has a term under the threshold (one ballot per slice);
 //                    otherwise the products are used as they are -- the same values, since nothing was to be clamped
 //   RSEM_FMA_ACC     acc += f * inv as one fused multiply-add (one rounding instead of two: last-bit differences)
+//   RSEM_SPILL_DS    the count spill spelled as an LDS atomic (ds_add_f64) or a global one; left to the compiler the two
+//                    branches become ONE flat_atomic_add_f64 on a selected address (seen in the ISA)
+#ifndef RSEM_SPILL_DS
+#define RSEM_SPILL_DS 0
+#endif
 #ifndef RSEM_CLAMP_FAST
 #define RSEM_CLAMP_FAST 0
 #endif
@@ -436,8 +441,13 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
         for (int k = 0; k < K; k++) {
             if (acc[k] != 0.0 && !(RSEM_DIAG & 1)) {
                 const unsigned off = (unsigned)(rsid[k] - base);
+#if RSEM_SPILL_DS
+                if (off < (unsigned)span) (void)__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)&cnt_win[off], acc[k]);
+                else unsafeAtomicAdd(&counts[rsid[k]], acc[k]);
+#else
                 if (off < (unsigned)span) unsafeAtomicAdd(&cnt_win[off], acc[k]);
                 else unsafeAtomicAdd(&counts[rsid[k]], acc[k]);
+#endif
             }
             acc[k] = 0.0;
         }
