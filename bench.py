@@ -241,6 +241,8 @@ def main():
     ap.add_argument("--no-q32", action="store_true", help="skip the Q32 value-plane measurement beside the headline")
     ap.add_argument("--value-bits", type=int, default=64, choices=(64, 32),
                     help="32: the HEADLINE context itself streams Q32 value planes (profiling runs; the default line stays on the doubles)")
+    ap.add_argument("--lane-policy", type=int, default=0, choices=(0, 1),
+                    help="1: lanes per read chosen for the fewest plane bytes (needs a library built with -DRSEM_GENERAL_G=1; experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gibbs", action="store_true")
     ap.add_argument("--no-ci", action="store_true")
@@ -298,6 +300,8 @@ def main():
     ctx.set_option("kernel", args.kernel)
     if args.value_bits == 32:
         ctx.set_option("value_bits", 32)
+    if args.lane_policy:
+        ctx.set_option("lane_policy", args.lane_policy)
     upload_s = time.perf_counter() - t0
     log("[rank %d] upload + device layout: %.2f s" % (rank, upload_s))
     alg_bytes = 12 * nnz + 16 * N1 + 16 * (M + 1)
@@ -371,6 +375,7 @@ def main():
         except Exception as e:  # the EM line must still be printed
             gibbs = {"error": str(e)}
 
+    value_plane_bytes = ctx.info("value_plane_bytes")
     q32 = None
     if world == 1 and not distributed and not args.no_q32 and args.value_bits == 64 and args.kernel in (0, 3):
         q32_traffic = None  # the committed PMC measurement of this layout (profiles/pmc_traffic.json), as for the headline
@@ -401,7 +406,8 @@ def main():
             "em_iterations_per_s": rounds / elapsed, "timed_rounds": rounds, "timed_region_s": elapsed, "timed_repeats_of_steps": reps,
             "config": {"workload": "%s: EM matrix of %d reads x %d transcripts, %d alignments (%.2f/read) per GPU, frozen conprb "
                                    "(rounds >= 12)" % (WORKLOADS.get(args.config, args.config), N1, M, nnz, nnz / max(N1, 1)),
-                       "synthetic_config": args.config, "kernel": args.kernel, "value_bits": args.value_bits,
+                       "synthetic_config": args.config, "kernel": args.kernel, "value_bits": args.value_bits, "lane_policy": args.lane_policy,
+                       "value_plane_bytes": value_plane_bytes,
                        "parallelism": "1 GPU" if world == 1 else "read-sharded x%d + RCCL all-reduce(M+1 f64)/round from C++ on the EM stream" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
