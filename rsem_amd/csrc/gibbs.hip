@@ -81,6 +81,23 @@ struct SliceRegs {
     double nc;
 };
 
+#if RSEM_GIBBS_SCALAR_ADDR
+// per slice: the sorted position of the read in row slot 0 and the slot stride of its block, so that the position of
+// the read in slot r (the key of its random number) is x + r * y without the divisions by T and R per slice
+__global__ void k_slice_ptab(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_slices, uint2* ptab) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slices) return;
+    int sh = 0;
+    while (sh + 1 < n_shapes && s >= shapes[sh + 1].slice_base) ++sh;
+    const Shape S = shapes[sh];
+    const uint32_t sl = s - S.slice_base, R = shape_R(S);
+    const uint32_t b = sl / T, t = sl % T;
+    const uint32_t left = S.n_rows - b * R * T;
+    const uint32_t nb = left < R * T ? left : R * T;
+    ptab[s] = make_uint2(S.row_base + b * R * T + t, (nb + R - 1) / R);
+}
+#endif
+
 // z_i | g for the reads of one block (T slices, one wave), lane-major runs as in the E step: a lane
 // keeps the g values and integer pick counters of its current sid tuple in registers and spills
 // them to the workgroup's LDS window when the tuple changes.  Weight order inside a read: noise,
@@ -90,6 +107,9 @@ __device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin,
                                    const double* __restrict__ g, double g0, double* g_win, int* cnt_win,
                                    const double* __restrict__ scp, const int32_t* __restrict__ ssid,
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
+#if RSEM_GIBBS_SCALAR_ADDR
+                                   const uint2* __restrict__ ptab,
+#endif
                                    const Philox& ph, uint32_t sweep, int32_t* counts, int& noise, int M) {
     const int lg = S.lg, G = 1 << lg;
     const int gl = lane & (G - 1);
@@ -179,12 +199,17 @@ __device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin,
         if (gl == 0) excl = 0.0;
         const double total = __shfl(incl, gbase + G - 1);
         // one uniform per read, keyed by the read's position in the sorted order (layout independent)
+#if RSEM_GIBBS_SCALAR_ADDR
+        const uint2 pt = ptab[s];  // (s is uniform over the wave: a scalar load)
+        const uint32_t p = pt.x + ((uint32_t)lane >> lg) * pt.y;
+#else
         const uint32_t sl = s - S.slice_base;
         const uint32_t b = sl / T, t = sl % T, r = (uint32_t)lane >> lg;
         const uint32_t left = S.n_rows - b * R * T;
         const uint32_t nb = left < R * T ? left : R * T;
         const uint32_t Tb = (nb + R - 1) / R;
         const uint32_t p = S.row_base + b * R * T + r * Tb + t;
+#endif
         uint32_t rnd[4] = {0, 0, 0, 0};
         if (g0lane) ph.gen(p, sweep, 0x5a5a5a5au, 0u, rnd);
         const double u = __shfl(u53(rnd[0], rnd[1]), gbase);
@@ -224,11 +249,20 @@ __device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin,
     spill();
 }
 
+#if RSEM_GIBBS_SCALAR_ADDR
+#define GIBBS_PTAB_ARG ptab,
+#else
+#define GIBBS_PTAB_ARG
+#endif
 __global__ __launch_bounds__(kBlock) void k_sample_z_lane(
     const Shape* __restrict__ shapes, const Unit* __restrict__ units, uint32_t T, int M,
     const double* __restrict__ g, const double* __restrict__ scp, const int32_t* __restrict__ ssid,
     const double* __restrict__ sncp, const unsigned long long* __restrict__ masks, Philox ph, uint32_t sweep,
-    int32_t* counts) {
+    int32_t* counts
+#if RSEM_GIBBS_SCALAR_ADDR
+    , const uint2* __restrict__ ptab
+#endif
+    ) {
     __shared__ double g_win[kGWindow];
     __shared__ int cnt_win[kGWindow];
     __shared__ int s_noise;
@@ -248,10 +282,10 @@ __global__ __launch_bounds__(kBlock) void k_sample_z_lane(
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
         const double g0 = g[0];
         if (s_begin < u_end) switch (S.K) {
-            case 1: gibbs_block<1>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise, M); break;
-            case 2: gibbs_block<2>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise, M); break;
-            case 3: gibbs_block<3>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise, M); break;
-            default: gibbs_block<4>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise, M); break;
+            case 1: gibbs_block<1>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, GIBBS_PTAB_ARG ph, sweep, counts, noise, M); break;
+            case 2: gibbs_block<2>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, GIBBS_PTAB_ARG ph, sweep, counts, noise, M); break;
+            case 3: gibbs_block<3>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, GIBBS_PTAB_ARG ph, sweep, counts, noise, M); break;
+            default: gibbs_block<4>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, GIBBS_PTAB_ARG ph, sweep, counts, noise, M); break;
         } else stage_gwindows(U.base, U.span, M, g, g_win, cnt_win);
     }
     for (int d = 32; d >= 1; d >>= 1) noise += __shfl_xor(noise, d);
@@ -892,6 +926,9 @@ struct rsem_gibbs_ctx {
     SellLayout L;
     double* d_scp = nullptr;
     double* d_sncp = nullptr;
+#if RSEM_GIBBS_SCALAR_ADDR
+    uint2* d_ptab = nullptr;      // k_slice_ptab
+#endif
     Unit* d_units = nullptr;
     uint32_t n_units = 0;
     double* d_g = nullptr;
@@ -1008,6 +1045,14 @@ int ensure_parallel_layout(rsem_gibbs_ctx* c) {
     RSEM_HIP_TRY(dmalloc(&c->d_sncp, (size_t)c->L.n_slots));
     rc = sell_fill_values(c->L, st, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_scp, c->d_sncp);
     if (rc != RSEM_OK) return rc;
+#if RSEM_GIBBS_SCALAR_ADDR
+    RSEM_HIP_TRY(dmalloc(&c->d_ptab, (size_t)c->L.n_slices));
+    if (c->L.n_slices) {
+        hipLaunchKernelGGL(k_slice_ptab, dim3(rsem::ceil_div(c->L.n_slices, kBlock)), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
+                           c->L.T, c->L.n_slices, c->d_ptab);
+        RSEM_HIP_TRY(hipGetLastError());
+    }
+#endif
     RSEM_HIP_TRY(hipStreamSynchronize(st));
     std::vector<Unit> units;
     rc = sell_build_units(c->L, units, kGWindow);
@@ -1051,6 +1096,9 @@ int rsem_gibbs_destroy(rsem_gibbs_ctx* c) {
     if (!c) return RSEM_OK;
     (void)hipSetDevice(c->device);
     hipFree(c->d_irp); hipFree(c->d_isid); hipFree(c->d_icp); hipFree(c->d_row_ptr); hipFree(c->d_sid);
+#if RSEM_GIBBS_SCALAR_ADDR
+    hipFree(c->d_ptab);
+#endif
     hipFree(c->d_cp); hipFree(c->d_ncp); sell_free(c->L); hipFree(c->d_scp); hipFree(c->d_sncp);
     hipFree(c->d_init_counts); hipFree(c->d_g); hipFree(c->d_alpha);
     hipFree(c->d_eel); hipFree(c->d_mw); hipFree(c->d_grp);
@@ -1289,7 +1337,11 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             auto parallel_z = [&](uint32_t sw) -> int {
                 if (c->n_units)
                     hipLaunchKernelGGL(k_sample_z_lane, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
-                                       c->d_g, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, ph, sw, ck);
+                                       c->d_g, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, ph, sw, ck
+#if RSEM_GIBBS_SCALAR_ADDR
+                                       , (const uint2*)c->d_ptab
+#endif
+                                       );
                 if (c->L.n_long_rows)
                     hipLaunchKernelGGL(k_sample_z_long, dim3(rsem::ceil_div(c->L.n_long_rows, kBlock)), dim3(kBlock), 0, st,
                                        c->L.n_long_rows, c->L.d_order + c->L.n_sell_rows, c->L.n_sell_rows, c->d_row_ptr, c->d_sid,
