@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call: the Gibbs GPU tests and the sweep time (tools/gibbs_profile.py on the C3 matrix) per library variant.
+# One gpurun call: the Gibbs GPU tests and the sweep time (tools/gibbs_profile.py, C2-shaped matrix) per library variant.
 #   tools/gpu_gibbs_variants.sh <budget seconds> default gsa ...
 budget=${1:-400}; shift
 start=$(date +%s)
