@@ -3,6 +3,7 @@ and refuses to run without a GPU (there is no CPU fallback).  No compute calls h
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -159,3 +160,20 @@ def test_run_em_rejects_inconsistent_alignment_coordinates(tmp_path):
     shutil.copytree(os.path.join(root, "tests", "golden", "se_q"), d)
     r = subprocess.run([exe, d + "/ref", "1", d + "/s", d + "/temp/s", d + "/stat/s", "-q"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert "hung over" not in r.stderr and "starts at" not in r.stderr
+
+
+def test_run_em_rejects_unknown_value_format():
+    """--value-bits takes 64 (default: the doubles as given) or 32 (Q32 planes); anything else ends the program with the
+    reference's error convention (message, status -1) before any file or device is touched."""
+    exe = os.path.join(ROOT, "rsem_amd", "bin", "rsem-run-em")
+    if not os.path.exists(exe):
+        pytest.skip("programs not built")
+    r = subprocess.run([exe, "ref", "1", "s", "imd", "stat", "--value-bits", "16"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 255 and "--value-bits must be 64 or 32" in r.stdout
+
+
+def test_null_arguments_of_the_info_and_option_calls(lib):
+    import ctypes as C
+    v = C.c_int64()
+    assert lib.rsem_em_get_info(None, b"units", C.byref(v)) == -1
+    assert lib.rsem_em_set_option(None, b"value_bits", 32) == -1
