@@ -74,7 +74,7 @@ __host__ __device__ inline uint32_t plane_bytes(int fmt) { return fmt == kFmtQ32
 // mx = the read's largest value.  Returns false when the read must stay F64: no positive value, a non-zero value
 // below mx * 2^-range_bits, or an exponent for which 2^e / value * 2^-e would leave the normal doubles.
 struct Q32Scale { int e; };
-__device__ inline bool q32_scale_of(double mx, double mn_nonzero, int range_bits, Q32Scale& q) {
+__host__ __device__ inline bool q32_scale_of(double mx, double mn_nonzero, int range_bits, Q32Scale& q) {
     if (!(mx > 0.0) || !(mx < 1e300)) return false;
     int ex;
     (void)frexp(mx, &ex);              // mx = f * 2^ex, f in [0.5, 1)
@@ -82,7 +82,7 @@ __device__ inline bool q32_scale_of(double mx, double mn_nonzero, int range_bits
     if (q.e < -1000 || q.e > 900) return false;
     return mn_nonzero >= ldexp(mx, -range_bits);
 }
-__device__ inline uint32_t q32_mantissa(double v, int e) {
+__host__ __device__ inline uint32_t q32_mantissa(double v, int e) {
     const double m = rint(ldexp(v, -e));      // exact scaling, round to nearest even
     return m >= 4294967295.0 ? 0xffffffffu : (uint32_t)m;
 }

@@ -60,3 +60,42 @@ def test_oracle_run_on_rounded_values_meets_the_bar():
             big = th >= 1e-7
             assert r2 == r and tn2 == tn
             assert np.max(np.abs(th2 - th)[big] / th[big]) < 1e-6
+
+
+def test_numpy_rule_is_the_rule_of_the_device_code(tmp_path):
+    """tools/q32_ref.quantize_q32 against sell_layout.hpp's own q32_scale_of / q32_mantissa (host-callable; the kernels
+    call the same functions): which reads qualify, exponents, every mantissa -- on values spread over the whole exponent
+    range, with zeros, ties, negatives and NaN mixed in."""
+    import os
+    import shutil
+    import subprocess
+    cc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(cc):
+        import pytest
+        pytest.skip("needs hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(tmp_path), "q32_rule_check")
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value",
+                           os.path.join(root, "tests", "q32_rule_check.cpp"), "-o", exe], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    rng = np.random.default_rng(11)
+    n, L = 20000, 6
+    base = np.power(2.0, rng.uniform(-1060, 1000, n))[:, None]           # from subnormal to huge
+    vals = base * np.power(2.0, rng.uniform(-14, 0, (n, L)))             # spans below and above 2^-8
+    vals[rng.random((n, L)) < 0.05] = 0.0
+    vals[::97, 0] = -1.0
+    vals[::101, 1] = np.nan
+    vals[::7] = np.ldexp(rng.integers(1, 2 ** 33, (len(vals[::7]), L)).astype(np.float64) + 0.5, -40)  # exact .5 ties after scaling
+    vals = np.ascontiguousarray(vals)
+    inp, outp = os.path.join(str(tmp_path), "in.bin"), os.path.join(str(tmp_path), "out.bin")
+    vals.tofile(inp)
+    rp = (np.arange(n + 1) * L).astype(np.uint64)
+    for D in (0, 8, 24):
+        subprocess.check_call([exe, inp, outp, str(n), str(L), str(D)])
+        out = np.fromfile(outp, np.int64).reshape(n, 2 + L)
+        with np.errstate(invalid="ignore"):
+            q, ok = quantize_q32(rp, vals.reshape(-1), D)
+        assert np.array_equal(out[:, 0].astype(bool), ok)
+        assert 0.02 < ok.mean() < 0.98 or D == 0
+        e = out[:, 1][ok]
+        m = out[:, 2:][ok].astype(np.float64)
+        assert np.array_equal(np.ldexp(m, e[:, None]), q.reshape(n, L)[ok])   # every mantissa, every exponent
