@@ -62,6 +62,10 @@ __global__ void k_fill_double(int32_t n, double v, double* g) {
 #ifndef RSEM_GIBBS_SCALAR_ADDR
 #define RSEM_GIBBS_SCALAR_ADDR 0
 #endif
+// ... and: the read's uniform from Philox2x32-10 (64 bits per call) instead of Philox4x32-10 (128 bits, half of them unused)
+#ifndef RSEM_GIBBS_PHILOX2
+#define RSEM_GIBBS_PHILOX2 0
+#endif
 constexpr int kGWindow = 2048;  // sids per workgroup window (g values: 16 KB, int counts: 8 KB of LDS)
 
 // g[base, base+span) -> LDS, count window zeroed; every wave of the workgroup calls this exactly once
@@ -211,7 +215,11 @@ __device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin,
         const uint32_t p = S.row_base + b * R * T + r * Tb + t;
 #endif
         uint32_t rnd[4] = {0, 0, 0, 0};
+#if RSEM_GIBBS_PHILOX2
+        if (g0lane) rsem::philox2x32_10(ph.k0 ^ ((ph.k1 << 13) | (ph.k1 >> 19)) ^ 0x5a5a5a5au, p, sweep, rnd);
+#else
         if (g0lane) ph.gen(p, sweep, 0x5a5a5a5au, 0u, rnd);
+#endif
         const double u = __shfl(u53(rnd[0], rnd[1]), gbase);
         double target = u * total;
         if (target >= total) target = total * (1.0 - 1.1102230246251565e-16);

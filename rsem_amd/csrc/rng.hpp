@@ -8,16 +8,25 @@
 
 namespace rsem {
 
+// (host-callable as well: tests/rng_kat_check.cpp runs the known-answer vectors of Random123 through these very functions)
+__host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
 struct Philox {
     uint32_t k0, k1;
-    __device__ inline void round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t a, uint32_t b) const {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    __host__ __device__ inline void round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t a, uint32_t b) const {
+        uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
         uint32_t n0 = hi1 ^ c1 ^ a, n1 = lo1, n2 = hi0 ^ c3 ^ b, n3 = lo0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     }
     // Philox4x32-10 (Salmon et al., SC'11)
-    __device__ inline void gen(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* out) const {
+    __host__ __device__ inline void gen(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* out) const {
         uint32_t a = k0, b = k1;
 #pragma unroll
         for (int i = 0; i < 10; i++) {
@@ -28,6 +37,19 @@ struct Philox {
         out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
     }
 };
+
+// Philox2x32-10 (same paper): 64 bits per call for half the multiplications -- one 53-bit uniform per read is all the
+// Gibbs sweep needs (RSEM_GIBBS_PHILOX2, a prepared variant of gibbs.hip).
+__host__ __device__ inline void philox2x32_10(uint32_t key, uint32_t c0, uint32_t c1, uint32_t* out) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const uint32_t hi = mulhi32(0xD256D193u, c0), lo = 0xD256D193u * c0;
+        c0 = hi ^ key ^ c1;
+        c1 = lo;
+        key += 0x9E3779B9u;
+    }
+    out[0] = c0; out[1] = c1;
+}
 
 __device__ inline double u53(uint32_t hi, uint32_t lo) {  // uniform in [0,1)
     return (double)(((uint64_t)(hi >> 5) << 26) | (lo >> 6)) * (1.0 / 9007199254740992.0);

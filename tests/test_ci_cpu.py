@@ -133,3 +133,19 @@ def test_calc_ci_edge_cases():
         else:
             q1, q3 = y[q], y[3 * q]
         assert abs(orc.calc_ci(y, 0.95)[2] - (q3 - q1) / (q3 + q1)) < 1e-6
+
+
+def test_philox_known_answers(tmp_path):
+    """rsem_amd/csrc/rng.hpp's Philox4x32-10 (Gibbs PARALLEL sampler, credibility intervals) and Philox2x32-10 against the
+    known-answer vectors of Random123, through the header's own (host-callable) functions: tests/rng_kat_check.cpp."""
+    import shutil
+    import subprocess
+    cc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(cc):
+        pytest.skip("needs hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(tmp_path), "rng_kat_check")
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-O1", "-std=c++17", os.path.join(root, "tests", "rng_kat_check.cpp"), "-o", exe],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and "bad=0" in r.stdout, r.stdout

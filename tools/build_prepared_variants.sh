@@ -7,4 +7,4 @@ cd "$(dirname "$0")/.."
 exec tools/build_variants.sh \
   rcp "-DRSEM_FAST_RCP=1" dpp "-DRSEM_DPP_REDUCE=1" ds "-DRSEM_SPILL_DS=1" clamp "-DRSEM_CLAMP_FAST=1" fma "-DRSEM_FMA_ACC=1" \
   all "-DRSEM_FAST_RCP=1 -DRSEM_DPP_REDUCE=1 -DRSEM_SPILL_DS=1 -DRSEM_CLAMP_FAST=1 -DRSEM_FMA_ACC=1" \
-  g1 "-DRSEM_GENERAL_G=1" gsa "-DRSEM_GIBBS_SCALAR_ADDR=1"
+  g1 "-DRSEM_GENERAL_G=1" gsa "-DRSEM_GIBBS_SCALAR_ADDR=1" gsap "-DRSEM_GIBBS_SCALAR_ADDR=1 -DRSEM_GIBBS_PHILOX2=1"
