@@ -20,6 +20,7 @@
 #include "../../../include/rsem_hip.h"
 #include "files.hpp"
 #include "model_host.hpp"
+#include "posterior_moments.hpp"
 #include "results.hpp"
 
 using namespace rsemh;
@@ -251,28 +252,12 @@ int main(int argc, char* argv[]) {
     for (auto& e : errors)
         if (!e.empty()) die("rsem-run-gibbs: %s", e.c_str());
 
-    // release() part 2 (Gibbs.cpp:389-423): means and variances from the sums
-    for (int i = 0; i <= M; i++) {
-        pme_c[i] /= NSAMPLES;
-        pve_c[i] = (pve_c[i] - double(NSAMPLES) * pme_c[i] * pme_c[i]) / double(NSAMPLES - 1);
-        if (pve_c[i] < 0.0) pve_c[i] = 0.0;
-        pme_tpm[i] /= NSAMPLES;
-        pme_fpkm[i] /= NSAMPLES;
-    }
-    for (int i = 0; i < gi.m; i++) {
-        double pme_c_gene = 0.0;
-        for (int j = gi.starts[i]; j < gi.starts[i + 1]; j++) pme_c_gene += pme_c[j];
-        pve_c_genes[i] = (pve_c_genes[i] - double(NSAMPLES) * pme_c_gene * pme_c_gene) / double(NSAMPLES - 1);
-        if (pve_c_genes[i] < 0.0) pve_c_genes[i] = 0.0;
-    }
-    if (alleleS) {
-        for (int i = 0; i < m_trans; i++) {
-            double pme_c_tran = 0.0;
-            for (int j = ta.starts[i]; j < ta.starts[i + 1]; j++) pme_c_tran += pme_c[j];
-            pve_c_trans[i] = (pve_c_trans[i] - double(NSAMPLES) * pme_c_tran * pme_c_tran) / double(NSAMPLES - 1);
-            if (pve_c_trans[i] < 0.0) pve_c_trans[i] = 0.0;
-        }
-    }
+    // the accumulators hold sums over all kept samples: means and variances (posterior_moments.hpp; Gibbs.cpp:389-423)
+    rsem_host::finish_per_transcript(NSAMPLES, pme_c, pve_c);
+    rsem_host::finish_means(NSAMPLES, pme_tpm);
+    rsem_host::finish_means(NSAMPLES, pme_fpkm);
+    rsem_host::finish_per_group(NSAMPLES, pme_c, gi.starts, pve_c_genes);
+    if (alleleS) rsem_host::finish_per_group(NSAMPLES, pme_c, ta.starts, pve_c_trans);
     if (verbose) printf("Gibbs finished!\n");
     write_results_gibbs(M, gi, imdName, pme_c, pme_fpkm, pme_tpm, pve_c, pve_c_genes, alleleS, &gt, &ta, &pve_c_trans);
     if (verbose) printf("Gibbs based expression values are written!\n");

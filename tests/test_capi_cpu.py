@@ -177,3 +177,27 @@ def test_null_arguments_of_the_info_and_option_calls(lib):
     v = C.c_int64()
     assert lib.rsem_em_get_info(None, b"units", C.byref(v)) == -1
     assert lib.rsem_em_set_option(None, b"value_bits", 32) == -1
+
+
+def test_posterior_moments_from_sums(tmp_path):
+    """host/posterior_moments.hpp (the end of rsem-run-gibbs: means and unbiased variances from the device's sums) against
+    the formulas of Gibbs.cpp:389-423 in numpy, bit for bit, incl. the floor at zero."""
+    exe = os.path.join(str(tmp_path), "pm_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "posterior_moments_check.cpp"), "-o", exe])
+    rng = np.random.default_rng(3)
+    n, M1, m = 1000, 41, 9
+    samples = rng.poisson(rng.gamma(0.7, 30.0, M1), size=(n, M1)).astype(np.float64)
+    samples[:, 5] = 7.0          # a constant column: variance exactly 0 or a negative rounding residue -> floored
+    samples[:, 6] = 1e8 + 0.1    # cancellation
+    starts = np.sort(np.concatenate([[1, M1], rng.choice(np.arange(2, M1), m - 1, replace=False)])).astype(np.int64)
+    s1, s2 = samples.sum(0), (samples ** 2).sum(0)
+    g2 = np.array([(samples[:, a:b].sum(1) ** 2).sum() for a, b in zip(starts[:-1], starts[1:])])
+    text = "%d %d %d\n" % (n, M1, m) + "\n".join("%.17g" % v for v in np.concatenate([s1, s2])) + "\n" + " ".join(map(str, starts)) + "\n" + "\n".join("%.17g" % v for v in g2) + "\n"
+    out = np.array(subprocess.run([exe], input=text, stdout=subprocess.PIPE, text=True, check=True).stdout.split(), np.float64)
+    mean = s1 / n
+    var = np.maximum((s2 - float(n) * mean * mean) / float(n - 1), 0.0)
+    gmean = np.array([mean[a:b].sum() for a, b in zip(starts[:-1], starts[1:])])
+    # (the group mean is summed left to right in the header; numpy's pairwise sum may differ in the last bit for long groups)
+    gvar = np.maximum((g2 - float(n) * gmean * gmean) / float(n - 1), 0.0)
+    assert np.array_equal(out[:M1], mean) and np.array_equal(out[M1:2 * M1], var)
+    assert np.allclose(out[2 * M1:], gvar, rtol=1e-12, atol=1e-9) and out[M1 + 5] == 0.0 and np.all(out[M1:] >= 0.0)
