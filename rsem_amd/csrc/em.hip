@@ -342,6 +342,11 @@ __device__ inline double pow2_of(int e) { return __longlong_as_double((long long
 #ifndef RSEM_SPILL_DS
 #define RSEM_SPILL_DS 0
 #endif
+//   RSEM_NT_LOADS    the value planes (read once per launch) with the non-temporal hint, so that they do not push theta /
+//                    counts / sid planes out of L2 and the Infinity Cache
+#ifndef RSEM_NT_LOADS
+#define RSEM_NT_LOADS 0
+#endif
 #ifndef RSEM_CLAMP_FAST
 #define RSEM_CLAMP_FAST 0
 #endif
@@ -432,7 +437,8 @@ __device__ inline void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_
             for (int k = 0; k < K; k++) b.id[k] = (int)(t & 1023) + k;
         }
 #pragma unroll
-        for (int k = 0; k < K; k++) b.c[k] = (RSEM_DIAG & 8) ? (ValT)(t + k) : vp[k * 64 + ulane];
+        for (int k = 0; k < K; k++)
+            b.c[k] = (RSEM_DIAG & 8) ? (ValT)(t + k) : (RSEM_NT_LOADS ? __builtin_nontemporal_load(&vp[k * 64 + ulane]) : vp[k * 64 + ulane]);
         const uint32_t slot0 = S.slot_base + sl * R;
         b.nc = (RSEM_DIAG & 32) ? 1e-30 : (g0 ? (sncp + slot0)[uslot] : 0.0);
         b.e = (RSEM_DIAG & 32) ? -40 : (kQ ? (int)(sexp + slot0)[uslot] : 0);
