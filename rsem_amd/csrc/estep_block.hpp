@@ -1,0 +1,371 @@
+// estep_block.hpp -- the per-wave body of the LANE E-step kernel (k_estep_lane of em.hip).
+//
+// Included by em.hip INSIDE its anonymous namespace (after kEpsilon / kTotSlots / sell_layout.hpp are in scope), and by
+// tests/estep_emu.cpp, which runs this very code on the CPU -- one OS thread per lane, the cross-lane intrinsics replaced by
+// exchanges through memory -- to check the lane mapping, the prefetch rings, the Q32 arithmetic and the prepared variants
+// against the oracle without a GPU.  The product build uses the GPU intrinsics directly: everything that differs between
+// the two goes through the macros below, which expand to the intrinsic in the product (same tokens, same code).
+#pragma once
+#include <type_traits>
+
+#ifndef RSEM_EMU
+#define RSEM_DEVFN __device__ inline
+#define RSEM_TIDX ((int)threadIdx.x)
+#define RSEM_BDIM ((int)blockDim.x)
+#define RSEM_SYNC() __syncthreads()
+#define RSEM_SHFL_XOR(v, d) __shfl_xor(v, d)
+#define RSEM_SHFL_DOWN(v, d) __shfl_down(v, d)
+#define RSEM_SHFL(v, src) __shfl(v, src)
+#define RSEM_BALLOT(p) __ballot(p)
+#define RSEM_READLANE(v, src) __builtin_amdgcn_readlane(v, src)
+#define RSEM_ATOMIC_ADD(p, v) unsafeAtomicAdd(p, v)
+#define RSEM_LDS_ADD(p, v) (void)__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(p), v)
+#define RSEM_RCP(x) __builtin_amdgcn_rcp(x)
+#define RSEM_DPP_MOV(v, ctrl) __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false)
+#define RSEM_LL_AS_DOUBLE(x) __longlong_as_double(x)
+#define RSEM_DOUBLE_AS_LL(x) __double_as_longlong(x)
+#endif
+
+RSEM_DEVFN double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += RSEM_SHFL_XOR(v, d);
+    return v;
+}
+
+
+// Variant LANE (default).  One workgroup = one Unit (sell_layout.hpp): each of its 4 waves walks one
+// block of T slices.  theta[base .. base+kWindow) is staged in LDS once, counts for the same sid
+// window accumulate in LDS (ds_add_f64) and leave the workgroup as ONE device atomic per touched
+// sid.  Inside a block every lane follows consecutive sorted reads: while the sid tuple does not
+// change (slice mask bit clear) the lane multiplies cached theta values with the streamed conprb
+// and adds the normalised fractions into registers; on a change it spills its registers to the
+// LDS window and takes sid / theta of the new tuple (the sid planes of a slice are loaded only when its mask is not zero,
+// then by all lanes).  The loads of the next slices are issued before slice s is reduced (software pipeline of 2 register
+// sets for doubles, up to 8 for Q32 mantissas; static instruction stream per K and format).
+// Where theta comes from.  Plain: the array the M-step kernel wrote.  kFC ("from counts", the fused loop of rsem_em_run):
+// the PREVIOUS round's raw counts and its two totals -- theta_i = (counts_i + (i == 0 ? noise + N0 : 0)) / (N0 + reads with
+// a non-zero normaliser), the very expression the M step evaluates (EM.cpp:392-398), so the E step does not wait for an
+// M-step kernel at all; convergence statistics run beside it on a second stream (k_mstep_fast<true>).
+struct ThetaSrc {
+    const double* v;
+    double extra0, sum;
+};
+template <bool kFC>
+RSEM_DEVFN double theta_at(const ThetaSrc& t, int i) {
+    if (!kFC) return t.v[i];
+    return (t.v[i] + (i == 0 ? t.extra0 : 0.0)) / t.sum;
+}
+// the two totals of the source round: every wave sums the slots itself (fixed order: identical in all waves)
+template <bool kFC>
+RSEM_DEVFN ThetaSrc theta_src(const double* __restrict__ v, const double* __restrict__ tsrc, double N0, int lane);
+
+// theta[base, base+span) -> LDS, count window zeroed; every wave of the workgroup calls this exactly once
+template <bool kFC>
+RSEM_DEVFN void stage_windows(int base, int span, int M, const ThetaSrc& th, double* th_win, double* cnt_win) {
+    for (int i = RSEM_TIDX; i < span; i += RSEM_BDIM) {
+        const int sidv = base + i;
+        th_win[i] = (sidv >= 0 && sidv <= M) ? theta_at<kFC>(th, sidv) : 0.0;
+        cnt_win[i] = 0.0;
+    }
+    RSEM_SYNC();
+}
+
+// one slice's loads: sids (only where a tuple starts), values (doubles, or Q32 mantissas + the read's exponent), noise
+template <int K, bool kQ>
+struct SliceRegs {
+    int id[K];
+    typename std::conditional<kQ, uint32_t, double>::type c[K];
+    double nc;
+    int e;
+};
+
+// 2^e for the exponents q32_scale_of admits (always a normal double)
+RSEM_DEVFN double pow2_of(int e) { return RSEM_LL_AS_DOUBLE((long long)(1023 + e) << 52); }
+
+// How many slices a wave keeps in flight (register sets).  The loads of a slice are K wave loads of 512 B (F64) or 256 B
+// (Q32): with two sets in flight a Q32 wave has half the bytes outstanding of an F64 wave, and the kernel -- which is
+// bound by memory-level parallelism, not by arithmetic -- then runs no faster on half the traffic (measured:
+// profiles/r02d_bench_with_q32_depth2.json: 3.54 GB instead of 5.83 GB per launch, 1.08 ms instead of 1.05 ms).  Q32 sets
+// are smaller, so the same registers hold more of them; the depths below are what fits in 128 VGPRs (4 waves per SIMD,
+// which the 32 KB of LDS windows allow).  Per K = 1..4.
+#ifndef RSEM_F64_DEPTHS
+#define RSEM_F64_DEPTHS 2, 2, 2, 2
+#endif
+#ifndef RSEM_Q32_DEPTHS
+#define RSEM_Q32_DEPTHS 8, 6, 4, 3
+#endif
+// Tuning by elimination (tools/build_variants.sh; NEVER set in the product build): each bit removes one component of the
+// E step so that its share of the launch time can be read off a bench run whose results are meaningless.
+//   1 no count spills (LDS / global atomics)   2 no division   4 no cross-lane reduction   8 no value loads
+//   16 no sid loads   32 no noise / exponent loads
+#ifndef RSEM_DIAG
+#define RSEM_DIAG 0
+#endif
+// Candidates for the next measurement (tools/build_variants.sh; off in the product build until measured and tested on a GPU):
+//   RSEM_FAST_RCP    1 / normaliser as v_rcp_f64 + two Newton steps (<= 2 ulp) instead of the IEEE division sequence
+//   RSEM_DPP_REDUCE  the per-read normaliser's butterfly over 2..16 lanes with DPP moves instead of ds_bpermute
+//                    (same additions in the same order: bit-identical)
+#ifndef RSEM_FAST_RCP
+#define RSEM_FAST_RCP 0
+#endif
+#ifndef RSEM_DPP_REDUCE
+#define RSEM_DPP_REDUCE 0
+#endif
+//   RSEM_CLAMP_FAST  the 1e-300 clamps of a slice's terms (EM.cpp:212,219: one compare + two selects per alignment) are
+//                    applied only when some lane of the wave has a term under the threshold (one ballot per slice);
+//                    otherwise the products are used as they are -- the same values, since nothing was to be clamped
+//   RSEM_FMA_ACC     acc += f * inv as one fused multiply-add (one rounding instead of two: last-bit differences)
+//   RSEM_SPILL_DS    the count spill spelled as an LDS atomic (ds_add_f64) or a global one; left to the compiler the two
+//                    branches become ONE flat_atomic_add_f64 on a selected address (seen in the ISA)
+#ifndef RSEM_SPILL_DS
+#define RSEM_SPILL_DS 0
+#endif
+//   RSEM_NT_LOADS    the value planes (read once per launch) with the non-temporal hint, so that they do not push theta /
+//                    counts / sid planes out of L2 and the Infinity Cache
+#ifndef RSEM_NT_LOADS
+#define RSEM_NT_LOADS 0
+#endif
+#ifndef RSEM_CLAMP_FAST
+#define RSEM_CLAMP_FAST 0
+#endif
+#ifndef RSEM_FMA_ACC
+#define RSEM_FMA_ACC 0
+#endif
+RSEM_DEVFN double recip_newton(double x) {
+    double r = RSEM_RCP(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+template <int kCtrl>
+RSEM_DEVFN double dpp_take(double v) {  // the value of the lane the DPP control selects (all lanes active here)
+    const long long b = RSEM_DOUBLE_AS_LL(v);
+    const int lo = RSEM_DPP_MOV((int)(unsigned)b, kCtrl);
+    const int hi = RSEM_DPP_MOV((int)(unsigned)(b >> 32), kCtrl);
+    return RSEM_LL_AS_DOUBLE(((long long)hi << 32) | (unsigned)lo);
+}
+// sum over the 2^lg lanes of a read, every lane ends with the total.  Steps 1, 2: quad permutes; 4: row_half_mirror (the
+// other quad of the 8-group: all its lanes hold the same quad sum); 8: row_mirror; 16, 32: ds_bpermute as before.
+RSEM_DEVFN double read_sum_dpp(double part, int lg) {
+    if (lg >= 1) part += dpp_take<0xB1>(part);   // quad_perm [1,0,3,2]
+    if (lg >= 2) part += dpp_take<0x4E>(part);   // quad_perm [2,3,0,1]
+    if (lg >= 3) part += dpp_take<0x141>(part);  // row_half_mirror
+    if (lg >= 4) part += dpp_take<0x140>(part);  // row_mirror
+    for (int d = 16; d < (1 << lg); d <<= 1) part += RSEM_SHFL_XOR(part, d);
+    return part;
+}
+constexpr int kF64Depth[4] = {RSEM_F64_DEPTHS};
+constexpr int kQ32Depth[4] = {RSEM_Q32_DEPTHS};
+
+template <int K, bool kFC, bool kQ, int NBUF>
+RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
+                                   const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, double* th_win, double* cnt_win,
+                                   const unsigned char* __restrict__ sval, const int16_t* __restrict__ sexp, const int32_t* __restrict__ ssid,
+                                   const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
+                                   double* counts, double& noise, double& neff, int M) {
+    using ValT = typename std::conditional<kQ, uint32_t, double>::type;
+    const ValT* __restrict__ scp = (const ValT*)(sval + S.val_base);  // this shape's value planes
+    const int lg = S.lg;
+#if RSEM_GENERAL_G
+    // lanes per read need not be a power of two (sell_layout.hpp): read r of the slice sits in lanes [r * G, r * G + G), the
+    // lanes past the last read idle on zero planes
+    const int G = shape_G(S);
+    const uint32_t R = shape_R(S);
+    const int rr = lg >= 0 ? (lane >> lg) : lane / G;
+    const int g = lane - rr * G;
+    const bool g0 = (g == 0) && (uint32_t)rr < R;
+#else
+    const int g = lane & ((1 << lg) - 1);
+    const bool g0 = (g == 0);
+    const uint32_t R = 64u >> lg;
+#endif
+    // 64 slices' masks at a time, one per lane
+    uint32_t m_base = s_begin;
+    unsigned long long mv = (s_begin + lane < s_end) ? masks[s_begin + lane] : ~0ull;
+    auto mask_of = [&](uint32_t t) -> unsigned long long {
+        if (t - m_base >= 64u) {
+            m_base = t;
+            mv = (t + lane < s_end) ? masks[t + lane] : ~0ull;
+        }
+        const int src = (int)(t - m_base);
+        const uint32_t lo = RSEM_READLANE((int)(uint32_t)mv, src);
+        const uint32_t hi = RSEM_READLANE((int)(uint32_t)(mv >> 32), src);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    // Everything about a slice except the lane is uniform over the wave (s_begin / s_end come from the wave index, which
+    // the caller hands over through readfirstlane): the slice's base addresses are scalar, a lane adds its own constant
+    // offset -- no per-lane 64-bit address arithmetic.  The sids of a slice are loaded by all lanes or (mask 0, a scalar
+    // branch) by none: lanes that do not start a tuple ignore theirs.
+#if RSEM_GENERAL_G
+    const unsigned ulane = (unsigned)lane, uslot = (unsigned)rr < R ? (unsigned)rr : R - 1;  // (idle lanes: any slot of the slice)
+#else
+    const unsigned ulane = (unsigned)lane, uslot = ulane >> lg;
+#endif
+    auto issue = [&](uint32_t t, unsigned long long m, SliceRegs<K, kQ>& b) {
+        const uint32_t sl = t - S.slice_base;
+        const uint64_t v0 = (uint64_t)sl * (K * 64);              // first entry of the slice within the shape's planes
+        const ValT* __restrict__ vp = scp + v0;
+        if ((RSEM_DIAG & 16) == 0) {
+            if (m != 0ull) {
+                const int32_t* __restrict__ ip = ssid + (S.plane_base * 64 + v0);
+#pragma unroll
+                for (int k = 0; k < K; k++) b.id[k] = ip[k * 64 + ulane];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) b.id[k] = (int)(t & 1023) + k;
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            b.c[k] = (RSEM_DIAG & 8) ? (ValT)(t + k) : (RSEM_NT_LOADS ? __builtin_nontemporal_load(&vp[k * 64 + ulane]) : vp[k * 64 + ulane]);
+        const uint32_t slot0 = S.slot_base + sl * R;
+        b.nc = (RSEM_DIAG & 32) ? 1e-30 : (g0 ? (sncp + slot0)[uslot] : 0.0);
+        b.e = (RSEM_DIAG & 32) ? -40 : (kQ ? (int)(sexp + slot0)[uslot] : 0);
+    };
+    auto spill = [&](const int* rsid, double* acc) {  // lane-private partial counts -> LDS window
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (acc[k] != 0.0 && !(RSEM_DIAG & 1)) {
+                const unsigned off = (unsigned)(rsid[k] - base);
+#if RSEM_SPILL_DS
+                if (off < (unsigned)span) RSEM_LDS_ADD(&cnt_win[off], acc[k]);
+                else RSEM_ATOMIC_ADD(&counts[rsid[k]], acc[k]);
+#else
+                if (off < (unsigned)span) RSEM_ATOMIC_ADD(&cnt_win[off], acc[k]);
+                else RSEM_ATOMIC_ADD(&counts[rsid[k]], acc[k]);
+#endif
+            }
+            acc[k] = 0.0;
+        }
+    };
+
+    int rsid[K];
+    double rth[K], acc[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { rsid[k] = 0; rth[k] = 0.0; acc[k] = 0.0; }
+    ThetaSrc th{theta, 0.0, 1.0};
+    double th0 = 0.0;
+    auto reduce = [&](const SliceRegs<K, kQ>& cur, unsigned long long cur_m) {
+        if (cur_m != 0ull) {                 // wave-uniform
+            if ((cur_m >> lane) & 1ull) {    // lanes whose read starts a new sid tuple
+                spill(rsid, acc);
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const int sidv = cur.id[k];
+                    rsid[k] = sidv;
+                    const unsigned off = (unsigned)(sidv - base);
+                    rth[k] = (off < (unsigned)span) ? th_win[off] : theta_at<kFC>(th, sidv);
+                }
+            }
+        }
+        double f0 = th0 * cur.nc;
+        if (f0 < kEpsilon) f0 = 0.0;
+        double f[K];
+        double part = f0;
+        const double scale = kQ ? pow2_of(cur.e) : 1.0;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            // Q32: mantissa * 2^e is exact, so this is the F64 expression on the rounded value
+            const double cv = kQ ? (double)cur.c[k] * scale : (double)cur.c[k];
+            double v = rth[k] * cv;
+            if (!RSEM_CLAMP_FAST && v < kEpsilon) v = 0.0;
+            f[k] = v;
+            if (!RSEM_CLAMP_FAST) part += v;
+        }
+        if (RSEM_CLAMP_FAST) {
+            bool small = false;
+#pragma unroll
+            for (int k = 0; k < K; k++) small = small || (f[k] < kEpsilon);
+            if (RSEM_BALLOT(small) != 0ull) {  // (uniform) rare: some theta * conprb of this slice is under 1e-300
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    if (f[k] < kEpsilon) f[k] = 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) part += f[k];
+        }
+        if (!(RSEM_DIAG & 4)) {
+#if RSEM_GENERAL_G
+            if (lg < 0) {  // (uniform over the workgroup) any G: fold towards the read's first lane, then hand the total back
+                for (int d = 1; d < G; d <<= 1) {
+                    const double o = RSEM_SHFL_DOWN(part, d);
+                    if (g + d < G) part += o;
+                }
+                part = RSEM_SHFL(part, lane - g);
+            } else
+#endif
+            if (RSEM_DPP_REDUCE) part = read_sum_dpp(part, lg);
+            else for (int d = 1; d < (1 << lg); d <<= 1) part += RSEM_SHFL_XOR(part, d);
+        }
+        const double inv = (RSEM_DIAG & 2) ? part : ((part >= kEpsilon) ? (RSEM_FAST_RCP ? recip_newton(part) : 1.0 / part) : 0.0);
+        noise += f0 * inv;
+        neff += (g0 && part >= kEpsilon) ? 1.0 : 0.0;  // reads whose fractions sum to one: sum(counts) without a reduction
+#pragma unroll
+        for (int k = 0; k < K; k++) acc[k] = RSEM_FMA_ACC ? fma(f[k], inv, acc[k]) : acc[k] + f[k] * inv;
+    };
+    if constexpr (NBUF == 2) {
+        // ping-pong register sets A / B: the loads of the next slice are in flight while this one is reduced
+        SliceRegs<K, kQ> A, B;
+        unsigned long long mA = ~0ull, mB = 0;  // a block always starts fresh
+        issue(s_begin, mA, A);
+        th = theta_src<kFC>(theta, tsrc, N0, lane);  // (after the first slice's loads were issued: they fly meanwhile)
+        th0 = theta_at<kFC>(th, 0);
+        stage_windows<kFC>(base, span, M, th, th_win, cnt_win);  // ... and while the windows are staged
+        for (uint32_t s = s_begin; s < s_end; s += 2) {
+            if (s + 1 < s_end) {
+                mB = mask_of(s + 1);
+                issue(s + 1, mB, B);
+            }
+            reduce(A, mA);
+            if (s + 1 >= s_end) break;
+            if (s + 2 < s_end) {
+                mA = mask_of(s + 2);
+                issue(s + 2, mA, A);
+            }
+            reduce(B, mB);
+        }
+    } else {
+        // ring of NBUF register sets (fully unrolled: every index is static): NBUF - 1 slices in flight while one is reduced
+        SliceRegs<K, kQ> buf[NBUF];
+        unsigned long long mk[NBUF];
+        mk[0] = ~0ull;  // a block always starts fresh
+        issue(s_begin, mk[0], buf[0]);
+        th = theta_src<kFC>(theta, tsrc, N0, lane);
+        th0 = theta_at<kFC>(th, 0);
+        stage_windows<kFC>(base, span, M, th, th_win, cnt_win);
+#pragma unroll
+        for (int j = 1; j < NBUF - 1; j++)
+            if (s_begin + j < s_end) {
+                mk[j] = mask_of(s_begin + j);
+                issue(s_begin + j, mk[j], buf[j]);
+            }
+        for (uint32_t s = s_begin; s < s_end; s += NBUF) {
+#pragma unroll
+            for (int j = 0; j < NBUF; j++) {
+                const uint32_t t = s + j;
+                if (t < s_end) {  // (uniform over the wave)
+                    constexpr int ahead = NBUF - 1;
+                    const int nj = (j + ahead) % NBUF;  // static after unrolling
+                    if (t + ahead < s_end) {
+                        mk[nj] = mask_of(t + ahead);
+                        issue(t + ahead, mk[nj], buf[nj]);
+                    }
+                    reduce(buf[j], mk[j]);
+                }
+            }
+        }
+    }
+    spill(rsid, acc);
+}
+
+template <bool kFC>
+RSEM_DEVFN ThetaSrc theta_src(const double* __restrict__ v, const double* __restrict__ tsrc, double N0, int lane) {
+    ThetaSrc t{v, 0.0, 1.0};
+    if (kFC) {
+        const double a = wave_sum(tsrc[lane]);
+        const double b = wave_sum(tsrc[kTotSlots + lane]);
+        t.extra0 = a + N0;  // counts[0] += noise + N0 (EM.cpp:392)
+        t.sum = b + N0;     // = sum(counts) (EM.cpp:395): every read with a non-zero normaliser carries mass one
+    }
+    return t;
+}
+
