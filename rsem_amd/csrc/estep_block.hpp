@@ -8,23 +8,7 @@
 #pragma once
 #include <type_traits>
 
-#ifndef RSEM_EMU
-#define RSEM_DEVFN __device__ inline
-#define RSEM_TIDX ((int)threadIdx.x)
-#define RSEM_BDIM ((int)blockDim.x)
-#define RSEM_SYNC() __syncthreads()
-#define RSEM_SHFL_XOR(v, d) __shfl_xor(v, d)
-#define RSEM_SHFL_DOWN(v, d) __shfl_down(v, d)
-#define RSEM_SHFL(v, src) __shfl(v, src)
-#define RSEM_BALLOT(p) __ballot(p)
-#define RSEM_READLANE(v, src) __builtin_amdgcn_readlane(v, src)
-#define RSEM_ATOMIC_ADD(p, v) unsafeAtomicAdd(p, v)
-#define RSEM_LDS_ADD(p, v) (void)__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(p), v)
-#define RSEM_RCP(x) __builtin_amdgcn_rcp(x)
-#define RSEM_DPP_MOV(v, ctrl) __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false)
-#define RSEM_LL_AS_DOUBLE(x) __longlong_as_double(x)
-#define RSEM_DOUBLE_AS_LL(x) __double_as_longlong(x)
-#endif
+#include "simt_macros.hpp"
 
 RSEM_DEVFN double wave_sum(double v) {
 #pragma unroll

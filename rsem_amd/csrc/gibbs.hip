@@ -68,194 +68,18 @@ __global__ void k_fill_double(int32_t n, double v, double* g) {
 #endif
 constexpr int kGWindow = 2048;  // sids per workgroup window (g values: 16 KB, int counts: 8 KB of LDS)
 
-// g[base, base+span) -> LDS, count window zeroed; every wave of the workgroup calls this exactly once
-__device__ inline void stage_gwindows(int base, int span, int M, const double* __restrict__ g, double* g_win, int* cnt_win) {
-    for (int i = threadIdx.x; i < span; i += blockDim.x) {
-        const int sidv = base + i;
-        g_win[i] = (sidv >= 0 && sidv <= M) ? g[sidv] : 0.0;
-        cnt_win[i] = 0;
-    }
-    __syncthreads();
-}
-
-template <int K>
-struct SliceRegs {
-    int id[K];
-    double c[K];
-    double nc;
-};
+// the per-wave body of the sweep kernel (also run on the CPU by tests/gibbs_emu.cpp)
+#include "gibbs_block.hpp"
 
 #if RSEM_GIBBS_SCALAR_ADDR
-// per slice: the sorted position of the read in row slot 0 and the slot stride of its block, so that the position of
-// the read in slot r (the key of its random number) is x + r * y without the divisions by T and R per slice
-__global__ void k_slice_ptab(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_slices, uint2* ptab) {
+__global__ void k_slice_ptab(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_slices, PtabEntry* ptab) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slices) return;
     int sh = 0;
     while (sh + 1 < n_shapes && s >= shapes[sh + 1].slice_base) ++sh;
-    const Shape S = shapes[sh];
-    const uint32_t sl = s - S.slice_base, R = shape_R(S);
-    const uint32_t b = sl / T, t = sl % T;
-    const uint32_t left = S.n_rows - b * R * T;
-    const uint32_t nb = left < R * T ? left : R * T;
-    ptab[s] = make_uint2(S.row_base + b * R * T + t, (nb + R - 1) / R);
+    ptab[s] = slice_ptab_entry(shapes[sh], T, s - shapes[sh].slice_base);
 }
 #endif
-
-// z_i | g for the reads of one block (T slices, one wave), lane-major runs as in the E step: a lane
-// keeps the g values and integer pick counters of its current sid tuple in registers and spills
-// them to the workgroup's LDS window when the tuple changes.  Weight order inside a read: noise,
-// then the G lanes of the read in order, each lane's K planes in order.
-template <int K>
-__device__ inline void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
-                                   const double* __restrict__ g, double g0, double* g_win, int* cnt_win,
-                                   const double* __restrict__ scp, const int32_t* __restrict__ ssid,
-                                   const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
-#if RSEM_GIBBS_SCALAR_ADDR
-                                   const uint2* __restrict__ ptab,
-#endif
-                                   const Philox& ph, uint32_t sweep, int32_t* counts, int& noise, int M) {
-    const int lg = S.lg, G = 1 << lg;
-    const int gl = lane & (G - 1);
-    const bool g0lane = (gl == 0);
-    const uint32_t R = 64u >> lg;
-    const int gbase = lane & ~(G - 1);
-    uint32_t m_base = s_begin;
-    unsigned long long mv = (s_begin + lane < s_end) ? masks[s_begin + lane] : ~0ull;
-    auto mask_of = [&](uint32_t t) -> unsigned long long {
-        if (t - m_base >= 64u) {
-            m_base = t;
-            mv = (t + lane < s_end) ? masks[t + lane] : ~0ull;
-        }
-        const int src = (int)(t - m_base);
-        const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)mv, src);
-        const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), src);
-        return ((unsigned long long)hi << 32) | lo;
-    };
-    auto issue = [&](uint32_t t, unsigned long long m, SliceRegs<K>& b) {
-        const uint32_t sl = t - S.slice_base;
-#if RSEM_GIBBS_SCALAR_ADDR
-        // as in the E step (em.hip, estep_block): scalar slice bases + a constant lane offset; the sids of a slice are
-        // loaded by all lanes or (mask 0) by none
-        const uint64_t p0 = (S.plane_base + (uint64_t)sl * K) * 64;
-        const unsigned ulane = (unsigned)lane;
-        if (m != 0ull) {
-            const int32_t* __restrict__ ip = ssid + p0;
-#pragma unroll
-            for (int k = 0; k < K; k++) b.id[k] = ip[k * 64 + ulane];
-        }
-        const double* __restrict__ vp = scp + p0;
-#pragma unroll
-        for (int k = 0; k < K; k++) b.c[k] = vp[k * 64 + ulane];
-        b.nc = g0lane ? (sncp + (S.slot_base + sl * R))[ulane >> lg] : 0.0;
-#else
-        const uint64_t pl = (S.plane_base + (uint64_t)sl * K) * 64 + lane;
-        const bool want = (m >> lane) & 1ull;
-#pragma unroll
-        for (int k = 0; k < K; k++) b.id[k] = ssid[want ? pl + (uint64_t)k * 64 : 0];
-#pragma unroll
-        for (int k = 0; k < K; k++) b.c[k] = scp[pl + (uint64_t)k * 64];
-        b.nc = g0lane ? sncp[S.slot_base + sl * R + (lane >> lg)] : 0.0;
-#endif
-    };
-    int rsid[K], acc[K];
-    double rg[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) { rsid[k] = 0; acc[k] = 0; rg[k] = 0.0; }
-    auto spill = [&]() {
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            if (acc[k] != 0) {
-                const unsigned off = (unsigned)(rsid[k] - base);
-                if (off < (unsigned)span) atomicAdd(&cnt_win[off], acc[k]);
-                else atomicAdd(&counts[rsid[k]], acc[k]);
-            }
-            acc[k] = 0;
-        }
-    };
-    auto sample = [&](const SliceRegs<K>& cur, unsigned long long cur_m, uint32_t s) {
-        if (cur_m != 0ull) {
-            if ((cur_m >> lane) & 1ull) {
-                spill();
-#pragma unroll
-                for (int k = 0; k < K; k++) {
-                    const int sidv = cur.id[k];
-                    rsid[k] = sidv;
-                    const unsigned off = (unsigned)(sidv - base);
-                    rg[k] = (off < (unsigned)span) ? g_win[off] : g[sidv];
-                }
-            }
-        }
-        const double f0 = g0 * cur.nc;
-        double f[K];
-        double part = f0;
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            f[k] = rg[k] * cur.c[k];
-            part += f[k];
-        }
-        double incl = part;  // inclusive scan over the G lanes of the read
-        for (int d = 1; d < G; d <<= 1) {
-            double o = __shfl_up(incl, d);
-            if (gl >= d) incl += o;
-        }
-        double excl = __shfl_up(incl, 1);
-        if (gl == 0) excl = 0.0;
-        const double total = __shfl(incl, gbase + G - 1);
-        // one uniform per read, keyed by the read's position in the sorted order (layout independent)
-#if RSEM_GIBBS_SCALAR_ADDR
-        const uint2 pt = ptab[s];  // (s is uniform over the wave: a scalar load)
-        const uint32_t p = pt.x + ((uint32_t)lane >> lg) * pt.y;
-#else
-        const uint32_t sl = s - S.slice_base;
-        const uint32_t b = sl / T, t = sl % T, r = (uint32_t)lane >> lg;
-        const uint32_t left = S.n_rows - b * R * T;
-        const uint32_t nb = left < R * T ? left : R * T;
-        const uint32_t Tb = (nb + R - 1) / R;
-        const uint32_t p = S.row_base + b * R * T + r * Tb + t;
-#endif
-        uint32_t rnd[4] = {0, 0, 0, 0};
-#if RSEM_GIBBS_PHILOX2
-        if (g0lane) rsem::philox2x32_10(ph.k0 ^ ((ph.k1 << 13) | (ph.k1 >> 19)) ^ 0x5a5a5a5au, p, sweep, rnd);
-#else
-        if (g0lane) ph.gen(p, sweep, 0x5a5a5a5au, 0u, rnd);
-#endif
-        const double u = __shfl(u53(rnd[0], rnd[1]), gbase);
-        double target = u * total;
-        if (target >= total) target = total * (1.0 - 1.1102230246251565e-16);
-        int pick = -2;  // -2: not mine, -1: noise, k >= 0: my plane k
-        if (total > 0.0 && target >= excl && target < incl) {
-            double run = excl;
-            if (g0lane) { run += f0; if (target < run) pick = -1; }
-            if (pick == -2) {
-                int last = -2;
-#pragma unroll
-                for (int k = 0; k < K; k++)
-                    if (pick == -2) {
-                        run += f[k];
-                        if (f[k] > 0.0) last = k;
-                        if (target < run) pick = k;
-                    }
-                if (pick == -2) pick = (last >= 0) ? last : ((g0lane && f0 > 0.0) ? -1 : -2);
-            }
-        }
-        noise += (pick == -1);
-#pragma unroll
-        for (int k = 0; k < K; k++) acc[k] += (pick == k);
-    };
-    SliceRegs<K> A, B;
-    unsigned long long mA = ~0ull, mB = 0;
-    issue(s_begin, mA, A);
-    stage_gwindows(base, span, M, g, g_win, cnt_win);  // the first slice's loads fly while the windows are staged
-    for (uint32_t s = s_begin; s < s_end; s += 2) {
-        if (s + 1 < s_end) { mB = mask_of(s + 1); issue(s + 1, mB, B); }
-        sample(A, mA, s);
-        if (s + 1 >= s_end) break;
-        if (s + 2 < s_end) { mA = mask_of(s + 2); issue(s + 2, mA, A); }
-        sample(B, mB, s + 1);
-    }
-    spill();
-}
 
 #if RSEM_GIBBS_SCALAR_ADDR
 #define GIBBS_PTAB_ARG ptab,
@@ -268,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void k_sample_z_lane(
     const double* __restrict__ sncp, const unsigned long long* __restrict__ masks, Philox ph, uint32_t sweep,
     int32_t* counts
 #if RSEM_GIBBS_SCALAR_ADDR
-    , const uint2* __restrict__ ptab
+    , const PtabEntry* __restrict__ ptab
 #endif
     ) {
     __shared__ double g_win[kGWindow];
@@ -935,7 +759,7 @@ struct rsem_gibbs_ctx {
     double* d_scp = nullptr;
     double* d_sncp = nullptr;
 #if RSEM_GIBBS_SCALAR_ADDR
-    uint2* d_ptab = nullptr;      // k_slice_ptab
+    PtabEntry* d_ptab = nullptr;      // k_slice_ptab
 #endif
     Unit* d_units = nullptr;
     uint32_t n_units = 0;
@@ -1347,7 +1171,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                     hipLaunchKernelGGL(k_sample_z_lane, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
                                        c->d_g, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, ph, sw, ck
 #if RSEM_GIBBS_SCALAR_ADDR
-                                       , (const uint2*)c->d_ptab
+                                       , (const PtabEntry*)c->d_ptab
 #endif
                                        );
                 if (c->L.n_long_rows)

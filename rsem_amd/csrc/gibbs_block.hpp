@@ -1,0 +1,191 @@
+// gibbs_block.hpp -- the per-wave body of the Gibbs PARALLEL sweep kernel (k_sample_z_lane of gibbs.hip).
+//
+// Included by gibbs.hip INSIDE its anonymous namespace (after kEpsilon / Philox / sell_layout.hpp are in scope) and by
+// tests/gibbs_emu.cpp, which runs this very code on the CPU (tests/simt_emu.hpp).  Intrinsics go through simt_macros.hpp.
+#pragma once
+#include "simt_macros.hpp"
+
+// g[base, base+span) -> LDS, count window zeroed; every wave of the workgroup calls this exactly once
+RSEM_DEVFN void stage_gwindows(int base, int span, int M, const double* __restrict__ g, double* g_win, int* cnt_win) {
+    for (int i = RSEM_TIDX; i < span; i += RSEM_BDIM) {
+        const int sidv = base + i;
+        g_win[i] = (sidv >= 0 && sidv <= M) ? g[sidv] : 0.0;
+        cnt_win[i] = 0;
+    }
+    RSEM_SYNC();
+}
+
+template <int K>
+struct SliceRegs {
+    int id[K];
+    double c[K];
+    double nc;
+};
+
+// per slice: the sorted position of the read in row slot 0 and the slot stride of its block, so that the position of the
+// read in slot r (the key of its random number) is x + r * y without the divisions by T and R in every slice
+// (RSEM_GIBBS_SCALAR_ADDR; k_slice_ptab in gibbs.hip tabulates it)
+struct PtabEntry { uint32_t x, y; };
+__host__ RSEM_DEVFN PtabEntry slice_ptab_entry(const Shape& S, uint32_t T, uint32_t sl) {
+    const uint32_t R = shape_R(S);
+    const uint32_t b = sl / T, t = sl % T;
+    const uint32_t left = S.n_rows - b * R * T;
+    const uint32_t nb = left < R * T ? left : R * T;
+    return PtabEntry{S.row_base + b * R * T + t, (nb + R - 1) / R};
+}
+
+// z_i | g for the reads of one block (T slices, one wave), lane-major runs as in the E step: a lane
+// keeps the g values and integer pick counters of its current sid tuple in registers and spills
+// them to the workgroup's LDS window when the tuple changes.  Weight order inside a read: noise,
+// then the G lanes of the read in order, each lane's K planes in order.
+template <int K>
+RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
+                                   const double* __restrict__ g, double g0, double* g_win, int* cnt_win,
+                                   const double* __restrict__ scp, const int32_t* __restrict__ ssid,
+                                   const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
+#if RSEM_GIBBS_SCALAR_ADDR
+                                   const PtabEntry* __restrict__ ptab,
+#endif
+                                   const Philox& ph, uint32_t sweep, int32_t* counts, int& noise, int M) {
+    const int lg = S.lg, G = 1 << lg;
+    const int gl = lane & (G - 1);
+    const bool g0lane = (gl == 0);
+    const uint32_t R = 64u >> lg;
+    const int gbase = lane & ~(G - 1);
+    uint32_t m_base = s_begin;
+    unsigned long long mv = (s_begin + lane < s_end) ? masks[s_begin + lane] : ~0ull;
+    auto mask_of = [&](uint32_t t) -> unsigned long long {
+        if (t - m_base >= 64u) {
+            m_base = t;
+            mv = (t + lane < s_end) ? masks[t + lane] : ~0ull;
+        }
+        const int src = (int)(t - m_base);
+        const uint32_t lo = RSEM_READLANE((int)(uint32_t)mv, src);
+        const uint32_t hi = RSEM_READLANE((int)(uint32_t)(mv >> 32), src);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    auto issue = [&](uint32_t t, unsigned long long m, SliceRegs<K>& b) {
+        const uint32_t sl = t - S.slice_base;
+#if RSEM_GIBBS_SCALAR_ADDR
+        // as in the E step (em.hip, estep_block): scalar slice bases + a constant lane offset; the sids of a slice are
+        // loaded by all lanes or (mask 0) by none
+        const uint64_t p0 = (S.plane_base + (uint64_t)sl * K) * 64;
+        const unsigned ulane = (unsigned)lane;
+        if (m != 0ull) {
+            const int32_t* __restrict__ ip = ssid + p0;
+#pragma unroll
+            for (int k = 0; k < K; k++) b.id[k] = ip[k * 64 + ulane];
+        }
+        const double* __restrict__ vp = scp + p0;
+#pragma unroll
+        for (int k = 0; k < K; k++) b.c[k] = vp[k * 64 + ulane];
+        b.nc = g0lane ? (sncp + (S.slot_base + sl * R))[ulane >> lg] : 0.0;
+#else
+        const uint64_t pl = (S.plane_base + (uint64_t)sl * K) * 64 + lane;
+        const bool want = (m >> lane) & 1ull;
+#pragma unroll
+        for (int k = 0; k < K; k++) b.id[k] = ssid[want ? pl + (uint64_t)k * 64 : 0];
+#pragma unroll
+        for (int k = 0; k < K; k++) b.c[k] = scp[pl + (uint64_t)k * 64];
+        b.nc = g0lane ? sncp[S.slot_base + sl * R + (lane >> lg)] : 0.0;
+#endif
+    };
+    int rsid[K], acc[K];
+    double rg[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { rsid[k] = 0; acc[k] = 0; rg[k] = 0.0; }
+    auto spill = [&]() {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (acc[k] != 0) {
+                const unsigned off = (unsigned)(rsid[k] - base);
+                if (off < (unsigned)span) RSEM_ATOMIC_ADD_I32(&cnt_win[off], acc[k]);
+                else RSEM_ATOMIC_ADD_I32(&counts[rsid[k]], acc[k]);
+            }
+            acc[k] = 0;
+        }
+    };
+    auto sample = [&](const SliceRegs<K>& cur, unsigned long long cur_m, uint32_t s) {
+        if (cur_m != 0ull) {
+            if ((cur_m >> lane) & 1ull) {
+                spill();
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const int sidv = cur.id[k];
+                    rsid[k] = sidv;
+                    const unsigned off = (unsigned)(sidv - base);
+                    rg[k] = (off < (unsigned)span) ? g_win[off] : g[sidv];
+                }
+            }
+        }
+        const double f0 = g0 * cur.nc;
+        double f[K];
+        double part = f0;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            f[k] = rg[k] * cur.c[k];
+            part += f[k];
+        }
+        double incl = part;  // inclusive scan over the G lanes of the read
+        for (int d = 1; d < G; d <<= 1) {
+            double o = RSEM_SHFL_UP(incl, d);
+            if (gl >= d) incl += o;
+        }
+        double excl = RSEM_SHFL_UP(incl, 1);
+        if (gl == 0) excl = 0.0;
+        const double total = RSEM_SHFL(incl, gbase + G - 1);
+        // one uniform per read, keyed by the read's position in the sorted order (layout independent)
+#if RSEM_GIBBS_SCALAR_ADDR
+        const PtabEntry pt = ptab[s];  // (s is uniform over the wave: a scalar load)
+        const uint32_t p = pt.x + ((uint32_t)lane >> lg) * pt.y;
+#else
+        const uint32_t sl = s - S.slice_base;
+        const uint32_t b = sl / T, t = sl % T, r = (uint32_t)lane >> lg;
+        const uint32_t left = S.n_rows - b * R * T;
+        const uint32_t nb = left < R * T ? left : R * T;
+        const uint32_t Tb = (nb + R - 1) / R;
+        const uint32_t p = S.row_base + b * R * T + r * Tb + t;
+#endif
+        uint32_t rnd[4] = {0, 0, 0, 0};
+#if RSEM_GIBBS_PHILOX2
+        if (g0lane) rsem::philox2x32_10(ph.k0 ^ ((ph.k1 << 13) | (ph.k1 >> 19)) ^ 0x5a5a5a5au, p, sweep, rnd);
+#else
+        if (g0lane) ph.gen(p, sweep, 0x5a5a5a5au, 0u, rnd);
+#endif
+        const double u = RSEM_SHFL(u53(rnd[0], rnd[1]), gbase);
+        double target = u * total;
+        if (target >= total) target = total * (1.0 - 1.1102230246251565e-16);
+        int pick = -2;  // -2: not mine, -1: noise, k >= 0: my plane k
+        if (total > 0.0 && target >= excl && target < incl) {
+            double run = excl;
+            if (g0lane) { run += f0; if (target < run) pick = -1; }
+            if (pick == -2) {
+                int last = -2;
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    if (pick == -2) {
+                        run += f[k];
+                        if (f[k] > 0.0) last = k;
+                        if (target < run) pick = k;
+                    }
+                if (pick == -2) pick = (last >= 0) ? last : ((g0lane && f0 > 0.0) ? -1 : -2);
+            }
+        }
+        noise += (pick == -1);
+#pragma unroll
+        for (int k = 0; k < K; k++) acc[k] += (pick == k);
+    };
+    SliceRegs<K> A, B;
+    unsigned long long mA = ~0ull, mB = 0;
+    issue(s_begin, mA, A);
+    stage_gwindows(base, span, M, g, g_win, cnt_win);  // the first slice's loads fly while the windows are staged
+    for (uint32_t s = s_begin; s < s_end; s += 2) {
+        if (s + 1 < s_end) { mB = mask_of(s + 1); issue(s + 1, mB, B); }
+        sample(A, mA, s);
+        if (s + 1 >= s_end) break;
+        if (s + 2 < s_end) { mA = mask_of(s + 2); issue(s + 2, mA, A); }
+        sample(B, mB, s + 1);
+    }
+    spill();
+}
+

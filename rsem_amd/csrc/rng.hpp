@@ -51,7 +51,7 @@ __host__ __device__ inline void philox2x32_10(uint32_t key, uint32_t c0, uint32_
     out[0] = c0; out[1] = c1;
 }
 
-__device__ inline double u53(uint32_t hi, uint32_t lo) {  // uniform in [0,1)
+__host__ __device__ inline double u53(uint32_t hi, uint32_t lo) {  // uniform in [0,1)
     return (double)(((uint64_t)(hi >> 5) << 26) | (lo >> 6)) * (1.0 / 9007199254740992.0);
 }
 

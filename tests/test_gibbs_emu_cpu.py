@@ -1,0 +1,78 @@
+"""The per-wave body of the Gibbs PARALLEL sweep kernel (rsem_amd/csrc/gibbs_block.hpp -- the file gibbs.hip compiles for the
+GPU) run on the CPU by tests/gibbs_emu.cpp (thread per lane, tests/simt_emu.hpp).  z_i | g must pick alignment j of read i
+with probability g_j * conprb_j / (g_0 * ncp_i + sum_k g_k * conprb_k): every sweep assigns every read once, and the picks
+per transcript over a few sweeps sit where the binomial says (z-scores: rms ~1).  The prepared variant with scalar slice
+addressing and the per-slice position table must draw the SAME picks (it only locates the read's random-number key
+differently); the Philox2x32 variant draws different ones from the same distribution.  No GPU involved."""
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import test_estep_emu_cpu as te
+
+ROOT = te.ROOT
+pytestmark = pytest.mark.skipif(not os.path.exists(te.CC), reason="needs hipcc (host compilation of the HIP headers)")
+
+BUILDS = {"product": [], "scalar_addr": ["-DRSEM_GIBBS_SCALAR_ADDR=1"], "philox2": ["-DRSEM_GIBBS_SCALAR_ADDR=1", "-DRSEM_GIBBS_PHILOX2=1"]}
+
+
+@pytest.fixture(scope="module")
+def emulators(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("gibbs_emu"))
+    procs = {}
+    for name, defs in BUILDS.items():
+        exe = os.path.join(d, "gibbs_emu_" + name)
+        procs[name] = (exe, subprocess.Popen([te.CC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-DRSEM_EMU", "-Wno-unused-result", "-Wno-unused-value"] + defs +
+                                             [os.path.join(ROOT, "tests", "gibbs_emu.cpp"), "-o", exe, "-lpthread"],
+                                             stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+    out = {}
+    for name, (exe, p) in procs.items():
+        err = p.communicate()[1]
+        assert p.returncode == 0, err[-3000:]
+        out[name] = exe
+    return out
+
+
+def _run(exe, M, rp, sid, cp, ncp, g, T, sweeps, seed, window=0):
+    d = tempfile.mkdtemp()
+    try:
+        inp, outp = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(inp, "wb") as f:
+            f.write(np.array([M, len(rp) - 1, T, sweeps, seed, window, 0, 0], np.int32).tobytes())
+            for a, t in ((rp, np.uint64), (sid, np.int32), (cp, np.float64), (ncp, np.float64), (g, np.float64)):
+                f.write(np.ascontiguousarray(a, t).tobytes())
+        subprocess.check_call([exe, inp, outp], timeout=900)
+        return np.fromfile(outp, np.int32).reshape(sweeps, M + 1)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_sweep_body_distribution_and_variants(emulators):
+    M, rp, sid, cp, ncp, _ = te._data(1, n=300)   # every read length 1..256 once, then 300 short reads
+    rng = np.random.default_rng(9)
+    g = rng.gamma(0.5, 1.0, M + 1) + 1e-3
+    g[0] = 0.02
+    N1 = len(rp) - 1
+    rows = np.repeat(np.arange(N1), np.diff(rp.astype(np.int64)))
+    w = g[sid] * cp
+    tot = np.bincount(rows, weights=w, minlength=N1) + g[0] * ncp
+    p = w / tot[rows]
+    p0 = g[0] * ncp / tot
+    exp = np.bincount(sid, weights=p, minlength=M + 1)
+    var = np.bincount(sid, weights=p * (1 - p), minlength=M + 1)
+    exp[0], var[0] = p0.sum(), (p0 * (1 - p0)).sum()
+    S = 8
+    res = {name: _run(exe, M, rp, sid, cp, ncp, g, T=4, sweeps=S, seed=5, window=(64 if name == "philox2" else 0)) for name, exe in emulators.items()}
+    for name, c in res.items():
+        assert np.all(c.sum(1) == N1), name                      # every read picks exactly one of its items in every sweep
+        big = S * var > 5
+        z = (c.sum(0) - S * exp)[big] / np.sqrt(S * var[big])
+        assert big.sum() > 50 and np.abs(z).max() < 5.0 and 0.7 < np.sqrt((z ** 2).mean()) < 1.3, (name, np.abs(z).max(), np.sqrt((z ** 2).mean()))
+        assert np.all(c[:, exp == 0] == 0)                        # nothing lands where no alignment points
+    assert np.array_equal(res["product"], res["scalar_addr"])     # same keys, same draws
+    assert not np.array_equal(res["product"], res["philox2"])
+    assert not np.array_equal(res["product"][0], res["product"][1])  # sweeps differ from one another
