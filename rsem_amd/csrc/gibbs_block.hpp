@@ -5,6 +5,12 @@
 #pragma once
 #include "simt_macros.hpp"
 
+// Tuning by elimination, as RSEM_DIAG in estep_block.hpp (never set in the product build; results meaningless, times
+// comparable):  1 no random numbers (u = 0.5)   2 no scan over the read's lanes   4 no count spills
+#ifndef RSEM_GDIAG
+#define RSEM_GDIAG 0
+#endif
+
 // g[base, base+span) -> LDS, count window zeroed; every wave of the workgroup calls this exactly once
 RSEM_DEVFN void stage_gwindows(int base, int span, int M, const double* __restrict__ g, double* g_win, int* cnt_win) {
     for (int i = RSEM_TIDX; i < span; i += RSEM_BDIM) {
@@ -97,7 +103,7 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
     auto spill = [&]() {
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            if (acc[k] != 0) {
+            if (acc[k] != 0 && !(RSEM_GDIAG & 4)) {
                 const unsigned off = (unsigned)(rsid[k] - base);
                 if (off < (unsigned)span) RSEM_ATOMIC_ADD_I32(&cnt_win[off], acc[k]);
                 else RSEM_ATOMIC_ADD_I32(&counts[rsid[k]], acc[k]);
@@ -127,7 +133,7 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
             part += f[k];
         }
         double incl = part;  // inclusive scan over the G lanes of the read
-        for (int d = 1; d < G; d <<= 1) {
+        for (int d = 1; d < G && !(RSEM_GDIAG & 2); d <<= 1) {
             double o = RSEM_SHFL_UP(incl, d);
             if (gl >= d) incl += o;
         }
@@ -150,8 +156,9 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
 #if RSEM_GIBBS_PHILOX2
         if (g0lane) rsem::philox2x32_10(ph.k0 ^ ((ph.k1 << 13) | (ph.k1 >> 19)) ^ 0x5a5a5a5au, p, sweep, rnd);
 #else
-        if (g0lane) ph.gen(p, sweep, 0x5a5a5a5au, 0u, rnd);
+        if (g0lane && !(RSEM_GDIAG & 1)) ph.gen(p, sweep, 0x5a5a5a5au, 0u, rnd);
 #endif
+        if (RSEM_GDIAG & 1) rnd[0] = 0x80000000u;
         const double u = RSEM_SHFL(u53(rnd[0], rnd[1]), gbase);
         double target = u * total;
         if (target >= total) target = total * (1.0 - 1.1102230246251565e-16);
