@@ -109,6 +109,11 @@ RSEM_DEVFN double pow2_of(int e) { return RSEM_LL_AS_DOUBLE((long long)(1023 + e
 #ifndef RSEM_NT_LOADS
 #define RSEM_NT_LOADS 0
 #endif
+//   RSEM_Q32_MAGIC   Q32 mantissa -> double by an exponent word and one subtraction (see the reduce step) instead of
+//                    v_cvt_f64_u32 + v_mul_f64
+#ifndef RSEM_Q32_MAGIC
+#define RSEM_Q32_MAGIC 0
+#endif
 #ifndef RSEM_CLAMP_FAST
 #define RSEM_CLAMP_FAST 0
 #endif
@@ -246,10 +251,16 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         double f[K];
         double part = f0;
         const double scale = kQ ? pow2_of(cur.e) : 1.0;
+        // RSEM_Q32_MAGIC: the bits {exponent of 2^(52+e), mantissa m} ARE the double 2^(52+e) + m * 2^e (m < 2^32 fits the low
+        // mantissa bits), so m * 2^e = that double - 2^(52+e), exactly: one full-rate add instead of a conversion and a multiply
+        const long long magic_hi = kQ ? (long long)(1075 + cur.e) << 52 : 0;
+        const double magic_base = RSEM_LL_AS_DOUBLE(magic_hi);
 #pragma unroll
         for (int k = 0; k < K; k++) {
             // Q32: mantissa * 2^e is exact, so this is the F64 expression on the rounded value
-            const double cv = kQ ? (double)cur.c[k] * scale : (double)cur.c[k];
+            const double cv = !kQ ? (double)cur.c[k]
+                            : RSEM_Q32_MAGIC ? RSEM_LL_AS_DOUBLE(magic_hi | (long long)(unsigned long long)cur.c[k]) - magic_base
+                                             : (double)cur.c[k] * scale;
             double v = rth[k] * cv;
             if (!RSEM_CLAMP_FAST && v < kEpsilon) v = 0.0;
             f[k] = v;

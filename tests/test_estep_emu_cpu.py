@@ -4,7 +4,8 @@ rebuilt on the host with sell_layout.hpp's own index helpers.  Checked against t
 of EVERY length 1..256, with clamped terms (theta * conprb < 1e-300), a noise term that matters, tiny LDS windows (the
 out-of-window path), theta taken from raw counts (the one-launch round), Q32 planes (against the oracle on the rounded
 values: the format is exact), and for the prepared compile-time variants: lanes per read that are no power of two, the
-Newton reciprocal on top of an inexact rcp, DPP reductions, the clamp fast path, fused accumulation, deeper F64 rings.
+Newton reciprocal on top of an inexact rcp, DPP reductions, the clamp fast path, fused accumulation, deeper F64 rings,
+the exponent-word conversion of Q32 mantissas.
 No GPU involved: this is how kernel edits are checked before GPU minutes are spent on them."""
 import os
 import shutil
@@ -25,7 +26,7 @@ BUILDS = {
     "product": [],
     "general_g": ["-DRSEM_GENERAL_G=1"],
     "variants": ["-DRSEM_FAST_RCP=1", "-DRSEM_DPP_REDUCE=1", "-DRSEM_CLAMP_FAST=1", "-DRSEM_FMA_ACC=1", "-DRSEM_SPILL_DS=1", "-DRSEM_NT_LOADS=1",
-                 "-DRSEM_F64_DEPTHS=4,3,3,2", "-DRSEM_Q32_DEPTHS=5,4,3,2"],
+                 "-DRSEM_F64_DEPTHS=4,3,3,2", "-DRSEM_Q32_DEPTHS=5,4,3,2", "-DRSEM_Q32_MAGIC=1"],
 }
 
 
