@@ -137,9 +137,19 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
             double o = RSEM_SHFL_UP(incl, d);
             if (gl >= d) incl += o;
         }
+#if RSEM_GIBBS_SCALAR_ADDR
+        // (one lane per read: nothing to exchange -- a uniform branch, lg comes from the unit descriptor)
+        double excl = 0.0, total = incl;
+        if (lg > 0) {
+            excl = RSEM_SHFL_UP(incl, 1);
+            if (gl == 0) excl = 0.0;
+            total = RSEM_SHFL(incl, gbase + G - 1);
+        }
+#else
         double excl = RSEM_SHFL_UP(incl, 1);
         if (gl == 0) excl = 0.0;
         const double total = RSEM_SHFL(incl, gbase + G - 1);
+#endif
         // one uniform per read, keyed by the read's position in the sorted order (layout independent)
 #if RSEM_GIBBS_SCALAR_ADDR
         const PtabEntry pt = ptab[s];  // (s is uniform over the wave: a scalar load)
@@ -159,7 +169,12 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
         if (g0lane && !(RSEM_GDIAG & 1)) ph.gen(p, sweep, 0x5a5a5a5au, 0u, rnd);
 #endif
         if (RSEM_GDIAG & 1) rnd[0] = 0x80000000u;
+#if RSEM_GIBBS_SCALAR_ADDR
+        double u = u53(rnd[0], rnd[1]);
+        if (lg > 0) u = RSEM_SHFL(u, gbase);
+#else
         const double u = RSEM_SHFL(u53(rnd[0], rnd[1]), gbase);
+#endif
         double target = u * total;
         if (target >= total) target = total * (1.0 - 1.1102230246251565e-16);
         int pick = -2;  // -2: not mine, -1: noise, k >= 0: my plane k
