@@ -104,8 +104,16 @@ __host__ __device__ inline uint32_t shape_R(const Shape& S) {  // reads per slic
 
 #if RSEM_GENERAL_G
 // read length -> shape id, for L = 0..256 (longer: kLongShape).  policy 0: G a power of two (the layout of the default
-// build); policy 1: the (G, K) with the fewest plane bytes per read, kept only where it saves >= 3 % over policy 0
-// (the power-of-two butterfly is the cheaper reduction); ties: power-of-two G first, then more planes (more reads per slice).
+// build).  policy 1: the (G, K) of least cost per read, where a slice of K planes costs max(its plane bytes, the byte
+// equivalent of its arithmetic): a slice's instruction stream has a part that does not depend on K (mask, noise term,
+// division, reduction) -- about what 550 B of streaming cost, plus ~100 B per plane, estimated from the SQ counters of
+// DESIGN.md section 4 -- so one-plane shapes with few reads per slice ((5, 1), (7, 1)) lose although they save bytes, while
+// (3, 3) for L = 9, (5, 2) for 10, (7, 2) for 13-14, (9, 2) for 17-18 ... win 10-25 %.  Kept only where it saves >= 3 %
+// over policy 0; ties: power-of-two G first (the cheaper reduction), then more planes.
+inline double shape_cost_per_read(int G, int K) {
+    const double bytes = 512.0 * K, arith = 550.0 + 100.0 * K;
+    return (bytes > arith ? bytes : arith) / (64 / G);
+}
 inline void shape_policy_table(int policy, uint16_t* tab) {
     for (int L = 0; L <= 256; L++) {
         int G0 = 1, K0 = L < 1 ? 1 : L;
@@ -117,12 +125,12 @@ inline void shape_policy_table(int policy, uint16_t* tab) {
         }
         int G = G0, K = K0;
         if (policy == 1 && L > 4) {
-            const double c0 = K0 * 64.0 / (64 / G0);
+            const double c0 = shape_cost_per_read(G0, K0);
             double best = c0;
             for (int k = 1; k <= 4; k++) {
                 const int g = (L + k - 1) / k;
                 if (g > 64) continue;
-                const double c = k * 64.0 / (64 / g);
+                const double c = shape_cost_per_read(g, k);
                 const bool p2 = (g & (g - 1)) == 0, bp2 = (G & (G - 1)) == 0;
                 if (c < best - 1e-9 || (c < best + 1e-9 && ((p2 && !bp2) || (p2 == bp2 && k > K)))) { best = c; G = g; K = k; }
             }
