@@ -201,3 +201,15 @@ def test_posterior_moments_from_sums(tmp_path):
     gvar = np.maximum((g2 - float(n) * gmean * gmean) / float(n - 1), 0.0)
     assert np.array_equal(out[:M1], mean) and np.array_equal(out[M1:2 * M1], var)
     assert np.allclose(out[2 * M1:], gvar, rtol=1e-12, atol=1e-9) and out[M1 + 5] == 0.0 and np.all(out[M1:] >= 0.0)
+
+
+def test_integration_binding_compiles_against_the_reference_headers():
+    """INTEGRATION.md section B as code (tests/integration_sketch.cpp): HitContainer<SingleHit / PairedEndHit> flattened into
+    the CSR of rsem_em_create, rsem_em_run, rsem_em_expected_weights -- compiled (syntax only) against the reference's own
+    headers in the reference's own dialect (its Makefile: gnu++98), with include/rsem_hip.h as the only thing from here."""
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "HitContainer.h")):
+        pytest.skip("the reference sources are not on this machine")
+    r = subprocess.run(["g++", "-std=gnu++98", "-fsyntax-only", "-w", "-I" + ref, "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "integration_sketch.cpp")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
