@@ -213,3 +213,22 @@ def test_integration_binding_compiles_against_the_reference_headers():
     r = subprocess.run(["g++", "-std=gnu++98", "-fsyntax-only", "-w", "-I" + ref, "-I" + os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "tests", "integration_sketch.cpp")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_model_file_reader_and_writer_reproduce_the_reference_files(tmp_path):
+    """host/model_host.hpp: read each golden s.model (written by the reference: SingleModel / SingleQModel / PairedEndModel /
+    PairedEndQModel ::write with their parts) and write it again -> the same bytes (layout of every table, %.10g / %.15g)."""
+    import filecmp
+    exe = os.path.join(str(tmp_path), "model_rt")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "model_roundtrip.cpp"), "-o", exe, "-lz", "-lpthread"])
+    gold = os.path.join(ROOT, "tests", "golden")
+    n = 0
+    for name in sorted(os.listdir(gold)):
+        src = os.path.join(gold, name, "stat", "s.model")
+        if not os.path.exists(src):
+            continue
+        out = os.path.join(str(tmp_path), name + ".model")
+        subprocess.check_call([exe, src, out])
+        assert filecmp.cmp(src, out, shallow=False), name
+        n += 1
+    assert n >= 9
