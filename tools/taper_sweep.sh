@@ -1,3 +1,5 @@
+#!/bin/bash
+# Round-1 experiment: unit tapering (RSEM_HIP_TAPER = fraction of full-size, half-size units) vs E-step time.  Did not pay.
 for tp in "1.0,0.0" "0.95,0.05" "0.9,0.1" "0.9,0.05" "0.85,0.1" "0.8,0.2"; do
   export RSEM_HIP_TAPER=$tp
   for i in 1 2; do
