@@ -162,31 +162,33 @@ __host__ __device__ inline void row_to_slot(const Shape& S, uint32_t T, uint32_t
     slice_local = b * T + qb % Tb;
 }
 
-__device__ inline uint32_t mix32(uint32_t h, uint32_t v) {
+__host__ __device__ inline uint32_t mix32(uint32_t h, uint32_t v) {
     h ^= v + 0x9e3779b9u + (h << 6) + (h >> 2);
     return h;
 }
 
 // ---- layout construction ---------------------------------------------------------------------
 
-// cp != nullptr: reads that qualify (q32_scale_of) go to the Q32 twin of their shape
-__global__ void k_row_keys(uint64_t N1, int32_t M, const uint64_t* __restrict__ row_ptr,
-                           const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits,
+// The per-thread bodies of the construction kernels are host-callable functions: tests/simt_emu.hpp builds the layout on
+// the CPU with these very functions.
+//
+// sort key of read i = shape | smallest sid (capped) | hash of the sid tuple.  cp != nullptr: reads that qualify
+// (q32_scale_of) go to the Q32 twin of their shape.  *err: 1 row_ptr not monotone, 2 sid outside 1..M.
+__host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint64_t* __restrict__ row_ptr,
+                                               const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits,
 #if RSEM_GENERAL_G
-                           const uint16_t* __restrict__ shape_of_len,
+                                               const uint16_t* __restrict__ shape_of_len,
 #endif
-                           uint64_t* keys, uint32_t* vals, int* err) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N1) return;
+                                               int* err) {
     uint64_t fr = row_ptr[i], to = row_ptr[i + 1];
-    if (to < fr) { *err = 1; return; }
+    if (to < fr) { *err = 1; return 0; }
     uint32_t h = 0x811c9dc5u, mn = 0xffffffffu;
     double vmx = 0.0, vmn = 1.79e308;
     for (uint64_t j = fr; j < to; j++) {
         int32_t s = sid[j];
         if (s < 1 || s > M) { *err = 2; s = 1; }
         h = mix32(h, (uint32_t)s);
-        mn = min(mn, (uint32_t)s);
+        mn = (uint32_t)s < mn ? (uint32_t)s : mn;
         if (cp) {
             const double v = cp[j];
             if (!(v >= 0.0)) vmx = 1e308;  // negative / NaN: never compressed
@@ -202,7 +204,26 @@ __global__ void k_row_keys(uint64_t N1, int32_t M, const uint64_t* __restrict__ 
 #endif
     Q32Scale q;
     if (cp && shape != kLongShape && q32_scale_of(vmx, vmn, range_bits, q)) shape += kShapesPerFmt;
-    keys[i] = ((uint64_t)shape << (64 - kShapeBits)) | ((uint64_t)mn << 32) | h;
+    return ((uint64_t)shape << (64 - kShapeBits)) | ((uint64_t)mn << 32) | h;
+}
+
+__global__ void k_row_keys(uint64_t N1, int32_t M, const uint64_t* __restrict__ row_ptr,
+                           const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits,
+#if RSEM_GENERAL_G
+                           const uint16_t* __restrict__ shape_of_len,
+#endif
+                           uint64_t* keys, uint32_t* vals, int* err) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N1) return;
+    int e = 0;
+    const uint64_t key = row_key_of(i, M, row_ptr, sid, cp, range_bits,
+#if RSEM_GENERAL_G
+                                    shape_of_len,
+#endif
+                                    &e);
+    if (e) *err = e;
+    if (e == 1) return;
+    keys[i] = key;
     vals[i] = (uint32_t)i;
 }
 
@@ -219,18 +240,13 @@ __device__ inline int find_shape_by_row(const Shape* shapes, int n, uint32_t p) 
     return sh;
 }
 
-// one thread per sorted row: scatter its alignments into the planes (values optional; sval = the value planes of all
-// shapes, F64 or Q32 per shape; sexp = per-slot exponents of the Q32 reads)
+// sorted row p of shape S: scatter its alignments into the planes (values optional; sval = the value planes of all shapes,
+// F64 or Q32 per shape; sexp = per-slot exponents of the Q32 reads)
 template <bool kIds>
-__global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_sell_rows,
-                            const uint32_t* __restrict__ order, const uint64_t* __restrict__ row_ptr,
-                            const int32_t* __restrict__ sid, const double* __restrict__ cp,
-                            const double* __restrict__ ncp, int32_t* ssid, unsigned char* sval, double* sncp,
-                            int16_t* sexp, int* err) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_sell_rows) return;
-    int sh = find_shape_by_row(shapes, n_shapes, p);
-    const Shape S = shapes[sh];
+__host__ __device__ inline void sell_fill_row(const Shape& S, uint32_t T, uint32_t p, const uint32_t* __restrict__ order,
+                                              const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
+                                              const double* __restrict__ cp, const double* __restrict__ ncp, int32_t* ssid,
+                                              unsigned char* sval, double* sncp, int16_t* sexp, int* err) {
     const int G = shape_G(S);
     uint32_t slice_local, r;
     row_to_slot(S, T, p - S.row_base, slice_local, r);
@@ -263,8 +279,43 @@ __global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint
     if (ncp) sncp[slot] = ncp[orig];
 }
 
+template <bool kIds>
+__global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_sell_rows,
+                            const uint32_t* __restrict__ order, const uint64_t* __restrict__ row_ptr,
+                            const int32_t* __restrict__ sid, const double* __restrict__ cp,
+                            const double* __restrict__ ncp, int32_t* ssid, unsigned char* sval, double* sncp,
+                            int16_t* sexp, int* err) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_sell_rows) return;
+    const Shape S = shapes[find_shape_by_row(shapes, n_shapes, p)];
+    sell_fill_row<kIds>(S, T, p, order, row_ptr, sid, cp, ncp, ssid, sval, sncp, sexp, err);
+}
+
 // per slice: bit l set when lane l's read has a different sid tuple than the same lane's read in
 // the previous slice of its block (= the previous read in sorted order), or starts a block
+// lane of slice sl (within shape S): does its read's sid tuple differ from the same lane's in the previous slice of the block?
+__host__ __device__ inline bool slice_lane_changed(const Shape& S, uint32_t T, uint32_t sl, int lane, const int32_t* __restrict__ ssid) {
+    if (sl % T == 0) return true;
+    const uint64_t pl0 = (S.plane_base + (uint64_t)sl * S.K) * 64;
+    bool changed = false;
+    for (int k = 0; k < S.K; k++) {
+        int v = ssid[pl0 + (uint64_t)k * 64 + lane];
+        int pv = ssid[pl0 - (uint64_t)S.K * 64 + (uint64_t)k * 64 + lane];
+        changed = changed || (pv != v);
+    }
+    return changed;
+}
+// the lanes of a read restart together: the bits of `lane`'s read in a 64-lane mask
+__host__ __device__ inline unsigned long long read_lanes_of(const Shape& S, int lane) {
+    const int G = shape_G(S);
+#if RSEM_GENERAL_G
+    const int gb = (lane / G) * G;  // (the idle lanes past the last read of the slice form a partial group of their own)
+#else
+    const int gb = lane & ~(G - 1);
+#endif
+    return (G == 64) ? ~0ull : (((1ull << G) - 1) << gb);
+}
+
 __global__ void k_slice_masks(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_slices,
                               const int32_t* __restrict__ ssid, unsigned long long* masks) {
     __shared__ Shape sh_shapes[kMaxShapes];
@@ -276,25 +327,9 @@ __global__ void k_slice_masks(const Shape* __restrict__ shapes, int n_shapes, ui
     int sh = 0;
     while (sh + 1 < n_shapes && s >= sh_shapes[sh + 1].slice_base) ++sh;
     const Shape S = sh_shapes[sh];
-    const uint32_t sl = s - S.slice_base;
-    uint64_t pl0 = (S.plane_base + (uint64_t)sl * S.K) * 64;
-    bool changed = (sl % T == 0);
-    if (!changed)
-        for (int k = 0; k < S.K; k++) {
-            int v = ssid[pl0 + (uint64_t)k * 64 + lane];
-            int pv = ssid[pl0 - (uint64_t)S.K * 64 + (uint64_t)k * 64 + lane];
-            changed = changed || (pv != v);
-        }
-    // a read occupies G lanes: all of them restart together
-    const int G = shape_G(S);
+    const bool changed = slice_lane_changed(S, T, s - S.slice_base, lane, ssid);
     unsigned long long m = __ballot(changed);
-#if RSEM_GENERAL_G
-    const int gb = (lane / G) * G;  // (the idle lanes past the last read of the slice form a partial group of their own)
-#else
-    const int gb = lane & ~(G - 1);
-#endif
-    const unsigned long long grp = (G == 64) ? ~0ull : (((1ull << G) - 1) << gb);
-    m = __ballot((m & grp) != 0);
+    m = __ballot((m & read_lanes_of(S, lane)) != 0);
     if (lane == 0) masks[s] = m;
 }
 

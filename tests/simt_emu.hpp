@@ -110,40 +110,26 @@ struct HostLayout {
     uint32_t n_slices = 0;
 };
 
-static uint32_t host_mix32(uint32_t h, uint32_t v) { return h ^ (v + 0x9e3779b9u + (h << 6) + (h >> 2)); }
-
-static int shape_of_len(uint64_t L, int policy) {
-#if RSEM_GENERAL_G
-    static uint16_t tab[2][257];
-    static bool init = false;
-    if (!init) { shape_policy_table(0, tab[0]); shape_policy_table(1, tab[1]); init = true; }
-    return L <= 256 ? tab[policy][L] : kLongShape;
-#else
-    (void)policy;
-    return shape_id_of(L);
-#endif
-}
-
 static void build_layout(HostLayout& H, int M, uint64_t N1, const uint64_t* rp, const int32_t* sid, const double* cp, const double* ncp,
                          int policy, bool q32, int range_bits) {
-    // keys (k_row_keys), sorted rows, shapes (the host loop of sell_build)
+    // keys: sell_layout.hpp's row_key_of (the body of k_row_keys); sorted rows; shapes (the host loop of sell_build)
     std::vector<std::pair<uint64_t, uint32_t>> keyed(N1);
+#if RSEM_GENERAL_G
+    uint16_t tab[257];
+    shape_policy_table(policy, tab);
+#else
+    (void)policy;
+#endif
     for (uint64_t i = 0; i < N1; i++) {
-        uint32_t h = 0x811c9dc5u, mn = 0xffffffffu;
-        double vmx = 0.0, vmn = 1.79e308;
-        for (uint64_t j = rp[i]; j < rp[i + 1]; j++) {
-            h = host_mix32(h, (uint32_t)sid[j]);
-            mn = std::min(mn, (uint32_t)sid[j]);
-            if (!(cp[j] >= 0.0)) vmx = 1e308;
-            vmx = fmax(vmx, cp[j]);
-            if (cp[j] > 0.0) vmn = fmin(vmn, cp[j]);
-        }
-        if (mn > kKeyMinSidCap) mn = kKeyMinSidCap;
-        int shape = shape_of_len(rp[i + 1] - rp[i], policy);
-        if (shape == kLongShape) { fprintf(stderr, "estep_emu: rows with more than 256 alignments are not modelled\n"); exit(2); }
-        Q32Scale q;
-        if (q32 && q32_scale_of(vmx, vmn, range_bits, q)) shape += kShapesPerFmt;
-        keyed[i] = {((uint64_t)shape << (64 - kShapeBits)) | ((uint64_t)mn << 32) | h, (uint32_t)i};
+        int err = 0;
+        const uint64_t key = row_key_of(i, M, rp, sid, q32 ? cp : nullptr, range_bits,
+#if RSEM_GENERAL_G
+                                        tab,
+#endif
+                                        &err);
+        if (err) { fprintf(stderr, "simt_emu: bad CSR (%d)\n", err); exit(2); }
+        if ((int)(key >> (64 - kShapeBits)) == kLongShape) { fprintf(stderr, "simt_emu: rows with more than 256 alignments are not modelled\n"); exit(2); }
+        keyed[i] = {key, (uint32_t)i};
     }
     std::stable_sort(keyed.begin(), keyed.end());
     H.order.resize(N1);
@@ -186,55 +172,24 @@ static void build_layout(HostLayout& H, int M, uint64_t N1, const uint64_t* rp, 
     H.sval.assign(val_bytes + 8, 0);
     H.sncp.assign(n_slots + 1, 0.0);
     H.sexp.assign(n_slots + 1, 0);
-    // planes (k_fill_sell)
-    for (const Shape& S : H.shapes) {
-        const int G = shape_G(S);
+    // planes: sell_fill_row (the body of k_fill_sell)
+    for (const Shape& S : H.shapes)
         for (uint32_t q = 0; q < S.n_rows; q++) {
-            uint32_t sl, r;
-            row_to_slot(S, H.T, q, sl, r);
-            const uint32_t orig = H.order[S.row_base + q];
-            const uint64_t fr = rp[orig];
-            const int L = (int)(rp[orig + 1] - fr);
-            const uint64_t pl_local = (uint64_t)sl * S.K * 64, pl0 = S.plane_base * 64 + pl_local;
-            const uint32_t slot = S.slot_base + sl * shape_R(S) + r;
-            Q32Scale qs{0};
-            if (S.fmt == kFmtQ32) {
-                double vmx = 0.0;
-                for (int c = 0; c < L; c++) vmx = fmax(vmx, cp[fr + c]);
-                if (!q32_scale_of(vmx, vmx, 0, qs)) { fprintf(stderr, "estep_emu: inconsistent Q32 decision\n"); exit(2); }
-                H.sexp[slot] = (int16_t)qs.e;
-            }
-            for (int c = 0; c < L; c++) {
-                const uint64_t off = (uint64_t)(c / G) * 64 + r * G + (c % G);
-                H.ssid[pl0 + off] = sid[fr + c];
-                if (S.fmt == kFmtQ32) ((uint32_t*)(H.sval.data() + S.val_base))[pl_local + off] = q32_mantissa(cp[fr + c], qs.e);
-                else ((double*)(H.sval.data() + S.val_base))[pl_local + off] = cp[fr + c];
-            }
-            H.sncp[slot] = ncp[orig];
+            int err = 0;
+            sell_fill_row<true>(S, H.T, S.row_base + q, H.order.data(), rp, sid, cp, ncp, H.ssid.data(), H.sval.data(), H.sncp.data(), H.sexp.data(), &err);
+            if (err) { fprintf(stderr, "simt_emu: inconsistent Q32 decision\n"); exit(2); }
         }
-    }
-    // masks (k_slice_masks)
+    // masks: slice_lane_changed / read_lanes_of (the body of k_slice_masks; its two ballots are the loops over l)
     H.masks.assign(H.n_slices, 0);
-    for (const Shape& S : H.shapes) {
-        const int G = shape_G(S);
+    for (const Shape& S : H.shapes)
         for (uint32_t sl = 0; sl < S.n_slices; sl++) {
-            const uint64_t pl0 = (S.plane_base + (uint64_t)sl * S.K) * 64;
-            unsigned long long m = 0;
-            for (int l = 0; l < 64; l++) {
-                bool changed = (sl % H.T == 0);
-                for (int k = 0; k < S.K && !changed; k++)
-                    changed = H.ssid[pl0 + (uint64_t)k * 64 + l] != H.ssid[pl0 - (uint64_t)S.K * 64 + (uint64_t)k * 64 + l];
-                if (changed) m |= 1ull << l;
-            }
-            unsigned long long full = 0;
-            for (int l = 0; l < 64; l++) {
-                const int gb = (l / G) * G;
-                const unsigned long long grp = (G == 64) ? ~0ull : (((1ull << G) - 1) << gb);
-                if (m & grp) full |= 1ull << l;
-            }
+            unsigned long long m = 0, full = 0;
+            for (int l = 0; l < 64; l++)
+                if (slice_lane_changed(S, H.T, sl, l, H.ssid.data())) m |= 1ull << l;
+            for (int l = 0; l < 64; l++)
+                if (m & read_lanes_of(S, l)) full |= 1ull << l;
             H.masks[S.slice_base + sl] = full;
         }
-    }
     (void)M;
 }
 
