@@ -206,10 +206,15 @@ def q32_leg(ctx, wl, N0, K, W, sync, alg_bytes, f64_ms_per_step, f64_estep_ms, t
 
 
 def em_leg(capi, make_em_workload, config, K, W, kernel, sync, device, q32=False):
-    """One extra single-GPU E-step measurement on another BASELINE config (same procedure as the headline)."""
+    """One extra single-GPU E-step measurement on another BASELINE config (same procedure as the headline).
+    "C5@0.1" = configs[4] at a tenth of its reads (the full size takes minutes to generate with numpy)."""
     try:
         t0 = time.perf_counter()
-        wl = make_em_workload(config)
+        scale = 1.0
+        if "@" in config:
+            config, sc = config.split("@", 1)
+            scale = float(sc)
+        wl = make_em_workload(config, scale=scale)
         gen_s = time.perf_counter() - t0
         N1, nnz, M = len(wl["row_ptr"]) - 1, len(wl["sid"]), wl["M"]
         ctx = capi.EmContext(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], device=device)
@@ -217,7 +222,7 @@ def em_leg(capi, make_em_workload, config, K, W, kernel, sync, device, q32=False
         el, rounds, reps, estep_ms, ts = timed_rounds(ctx, wl, wl["N0"], K, W, sync, lambda: None)
         alg = 12 * nnz + 16 * N1 + 16 * (M + 1)
         ach = alg / (estep_ms * 1e-3) / 1e9
-        out = {"workload": "%s: %d reads x %d transcripts, %d alignments" % (WORKLOADS.get(config, config), N1, M, nnz),
+        out = {"workload": "%s%s: %d reads x %d transcripts, %d alignments" % (WORKLOADS.get(config, config), "" if scale == 1.0 else " at %g of its reads" % scale, N1, M, nnz),
                "ms_per_step": el * 1e3 / rounds, "timed_rounds": rounds, "timed_region_s": el, "value": nnz * rounds / el,
                "estep_avg_launch_ms": estep_ms, "algorithmic_bytes_per_launch": alg, "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS,
                "theta_sum": ts, "generate_s": gen_s}
@@ -235,7 +240,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--legs", default="C2,C2R", help="extra single-GPU E-step legs on other configs (comma list, '' for none)")
+    ap.add_argument("--legs", default="C2,C2R", help="extra single-GPU E-step legs on other configs (comma list, '' for none; NAME@scale for a fraction of the reads, e.g. C5@0.1)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--no-q32", action="store_true", help="skip the Q32 value-plane measurement beside the headline")
