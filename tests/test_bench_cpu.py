@@ -37,7 +37,7 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(%(root)r, "bench.py"))
 b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 b.MIN_TIMED_S = 0.0
-sys.argv = ["bench.py", "--config", "tiny", "--legs", "tinyR", "--no-cpu-baseline", "--steps", "3", "--warmup", "1"]
+sys.argv = ["bench.py", "--config", "tiny", "--legs", "tinyR,tiny@0.5", "--no-cpu-baseline", "--steps", "3", "--warmup", "1"]
 b.main()
 '''
 
@@ -56,5 +56,5 @@ def test_bench_main_prints_one_contract_line():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in d["roofline"], key
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
-    assert d["q32_value_planes"]["value_bits"] == 32 and "tinyR" in d["other_configs"]
+    assert d["q32_value_planes"]["value_bits"] == 32 and "tinyR" in d["other_configs"] and "10000 reads" in d["other_configs"]["tiny@0.5"]["workload"]
     assert "error" in d["gibbs"] and "error" in d["credibility_intervals"]  # the EM line survives a failing side leg
