@@ -114,6 +114,11 @@ RSEM_DEVFN double pow2_of(int e) { return RSEM_LL_AS_DOUBLE((long long)(1023 + e
 #ifndef RSEM_Q32_MAGIC
 #define RSEM_Q32_MAGIC 0
 #endif
+//   RSEM_NEFF_BALLOT the count of reads with a non-zero normaliser as popcount(ballot) into a scalar per wave instead of a
+//                    compare / select / f64 add per lane and slice
+#ifndef RSEM_NEFF_BALLOT
+#define RSEM_NEFF_BALLOT 0
+#endif
 #ifndef RSEM_CLAMP_FAST
 #define RSEM_CLAMP_FAST 0
 #endif
@@ -233,6 +238,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
     for (int k = 0; k < K; k++) { rsid[k] = 0; rth[k] = 0.0; acc[k] = 0.0; }
     ThetaSrc th{theta, 0.0, 1.0};
     double th0 = 0.0;
+    unsigned neff_wave = 0;  // RSEM_NEFF_BALLOT: the wave's count, uniform (a scalar register), handed to lane 0 at the end
     auto reduce = [&](const SliceRegs<K, kQ>& cur, unsigned long long cur_m) {
         if (cur_m != 0ull) {                 // wave-uniform
             if ((cur_m >> lane) & 1ull) {    // lanes whose read starts a new sid tuple
@@ -293,7 +299,9 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         }
         const double inv = (RSEM_DIAG & 2) ? part : ((part >= kEpsilon) ? (RSEM_FAST_RCP ? recip_newton(part) : 1.0 / part) : 0.0);
         noise += f0 * inv;
-        neff += (g0 && part >= kEpsilon) ? 1.0 : 0.0;  // reads whose fractions sum to one: sum(counts) without a reduction
+        // reads whose fractions sum to one: sum(counts) without a reduction
+        if (RSEM_NEFF_BALLOT) neff_wave += (unsigned)__builtin_popcountll(RSEM_BALLOT(g0 && part >= kEpsilon));
+        else neff += (g0 && part >= kEpsilon) ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < K; k++) acc[k] = RSEM_FMA_ACC ? fma(f[k], inv, acc[k]) : acc[k] + f[k] * inv;
     };
@@ -350,6 +358,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         }
     }
     spill(rsid, acc);
+    if (RSEM_NEFF_BALLOT && lane == 0) neff += (double)neff_wave;
 }
 
 template <bool kFC>

@@ -26,7 +26,7 @@ BUILDS = {
     "product": [],
     "general_g": ["-DRSEM_GENERAL_G=1"],
     "variants": ["-DRSEM_FAST_RCP=1", "-DRSEM_DPP_REDUCE=1", "-DRSEM_CLAMP_FAST=1", "-DRSEM_FMA_ACC=1", "-DRSEM_SPILL_DS=1", "-DRSEM_NT_LOADS=1",
-                 "-DRSEM_F64_DEPTHS=4,3,3,2", "-DRSEM_Q32_DEPTHS=5,4,3,2", "-DRSEM_Q32_MAGIC=1"],
+                 "-DRSEM_F64_DEPTHS=4,3,3,2", "-DRSEM_Q32_DEPTHS=5,4,3,2", "-DRSEM_Q32_MAGIC=1", "-DRSEM_NEFF_BALLOT=1"],
 }
 
 
