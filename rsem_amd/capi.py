@@ -56,6 +56,7 @@ def lib():
         L.rsem_hip_last_error.restype = C.c_char_p
         L.rsem_hip_device_count.argtypes = [C.POINTER(ci)]
         L.rsem_hip_abi_version.restype = ci
+        L.rsem_hip_stream_probe.argtypes = [ci, u64, ci, C.POINTER(dbl), C.POINTER(dbl)]
         L.rsem_em_create.argtypes = [C.POINTER(vp), ci, i32, u64, u64, _u64p, vp, vp, vp]
         L.rsem_em_set_values.argtypes = [vp, _f64p, _f64p]
         L.rsem_em_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
@@ -107,6 +108,13 @@ def device_count():
     n = C.c_int(0)
     _check(lib().rsem_hip_device_count(C.byref(n)))
     return n.value
+
+
+def stream_probe(device=0, nbytes=4 << 30, reps=5):
+    """Measured device STREAM rates in GB/s: (read-only, copy with read + write bytes counted)."""
+    r, c = C.c_double(), C.c_double()
+    _check(lib().rsem_hip_stream_probe(device, int(nbytes), int(reps), C.byref(r), C.byref(c)))
+    return r.value, c.value
 
 
 class EmContext:

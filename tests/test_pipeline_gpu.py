@@ -1,8 +1,7 @@
 """The four drop-ins inside the reference's own pipeline on a GPU box: rsem-calculate-expression (Perl, unmodified) --calc-pme
 with rsem-parse-alignments, rsem-run-em, rsem-run-gibbs (exact mode = the reference's chains) from this repo, against the
 untouched pipeline on the same SAM file: expected counts / TPM / FPKM to the printed 0.01, posterior mean counts likewise
-(the exact sampler draws the reference's chains).  Written at the end of round 2 without GPU time left to run it once:
-enabled with RSEM_TEST_PIPELINE_GPU=1 until it has been seen passing."""
+(the exact sampler draws the reference's chains)."""
 import os
 
 import numpy as np
@@ -10,9 +9,7 @@ import pytest
 
 import pipeline_util as pu
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not pu.available(), reason="needs perl and oracle/_ref"),
-              pytest.mark.skipif(not os.environ.get("RSEM_TEST_PIPELINE_GPU"), reason="set RSEM_TEST_PIPELINE_GPU=1 (not yet run on a GPU)")]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not pu.available(), reason="needs perl and oracle/_ref")]
 
 
 @pytest.mark.parametrize("fixture", sorted(pu.FIXTURES_WITH_SAM))

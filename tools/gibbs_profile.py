@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time / profile the PARALLEL Gibbs sweep on a synthetic C2-shaped matrix: python tools/gibbs_profile.py [scale] [sweeps]"""
+"""Time / profile the PARALLEL Gibbs sweep on a synthetic matrix: python tools/gibbs_profile.py [scale] [sweeps] [config=C2]"""
 import os
 import sys
 import time
@@ -12,9 +12,20 @@ from tools.synth_data import make_em_workload, to_gibbs_items  # noqa: E402
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 sweeps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-wl = make_em_workload("C2", scale=scale)
+config = sys.argv[3] if len(sys.argv) > 3 else "C2"
+wl = make_em_workload(config, scale=scale)
 M = wl["M"]
-irp, isid, icp = to_gibbs_items(wl)
+cache = os.environ.get("RSEM_WL_CACHE")
+cdir = os.path.join(cache, "gibbs_%s_%g" % (config, scale)) if cache else None
+if cdir and os.path.exists(os.path.join(cdir, "icp.npy")):
+    irp, isid, icp = (np.load(os.path.join(cdir, k + ".npy")) for k in ("irp", "isid", "icp"))
+else:
+    irp, isid, icp = to_gibbs_items(wl)
+    if cdir:
+        os.makedirs(cdir + ".tmp", exist_ok=True)
+        for k, a in (("irp", irp), ("isid", isid), ("icp", icp)):
+            np.save(os.path.join(cdir + ".tmp", k + ".npy"), a)
+        os.rename(cdir + ".tmp", cdir)
 N1 = len(irp) - 1
 t0 = time.time()
 g = capi.GibbsContext(M, irp, isid, icp, np.zeros(M + 1, np.int32), None, 1.0, (M + 1) + wl["N0"] + N1, wl["N0"],

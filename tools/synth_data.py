@@ -7,6 +7,9 @@ one of the segments containing it, and aligns to exactly that segment's isoform 
 lognormal(0, 2) with 30 % zeros, 5 % noise reads.  conprb = 10^U(-60,-3) per read with a per-hit
 jitter 10^N(0,0.5); ncp = 10^U(-130,-40).  Everything is a pure function of (config, seed).
 """
+import json
+import os
+
 import numpy as np
 
 CONFIGS = {
@@ -24,9 +27,41 @@ CONFIGS = {
 }
 
 
+_ARRAYS = ("row_ptr", "sid", "conprb", "ncp", "theta0")
+
+
 def make_em_workload(config="C2", seed=20250925, scale=1.0, long_row_every=0, shard=0):
     """Returns dict(M, N0, row_ptr u64, sid i32, conprb f64, ncp f64, theta0 f64).
-    `shard` re-draws the reads (not the transcriptome): shard r of a weak-scaling job."""
+    `shard` re-draws the reads (not the transcriptome): shard r of a weak-scaling job.
+    RSEM_WL_CACHE=<dir> (e.g. on /dev/shm): the arrays are kept there as .npy files, so that GPU calls which start
+    many processes on the same workload (profiling passes, library variants) generate it once."""
+    cache = os.environ.get("RSEM_WL_CACHE")
+    if not cache:
+        return _make_em_workload(config, seed, scale, long_row_every, shard)
+    d = os.path.join(cache, "%s_%d_%g_%d_%d" % (config, seed, scale, long_row_every, shard))
+    meta = os.path.join(d, "meta.json")
+    if os.path.exists(meta):
+        with open(meta) as f:
+            wl = json.load(f)
+        for k in _ARRAYS:
+            wl[k] = np.load(os.path.join(d, k + ".npy"))
+        return wl
+    wl = _make_em_workload(config, seed, scale, long_row_every, shard)
+    tmp = d + ".tmp%d" % os.getpid()
+    os.makedirs(tmp, exist_ok=True)
+    for k in _ARRAYS:
+        np.save(os.path.join(tmp, k + ".npy"), wl[k])
+    with open(os.path.join(tmp, "meta.json"), "w") as f:
+        json.dump({k: v for k, v in wl.items() if k not in _ARRAYS}, f)
+    try:
+        os.rename(tmp, d)
+    except OSError:  # another process was faster
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return wl
+
+
+def _make_em_workload(config, seed, scale, long_row_every, shard):
     N1, M, mean_hits, ksz = CONFIGS[config]
     N1 = max(1, int(N1 * scale))
     rng = np.random.default_rng(seed)
