@@ -494,6 +494,35 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
     }
 }
 
+// ---- EXACT mode, the default implementation: one WORKGROUP per chain (gibbs_exact_wg.hpp) ------------------------------
+#include "gibbs_exact_wg.hpp"
+
+template <bool kInit>
+__global__ __launch_bounds__(64 * kXW) void k_gibbs_exact_wg(uint32_t n_tiles, const uint32_t* __restrict__ tile_start,
+                                                            const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
+                                                            const double* __restrict__ cp, int32_t* counts_base, int32_t* z_base,
+                                                            double pseudoC, MtState* mt_base, const int32_t* __restrict__ last_round,
+                                                            int round, uint64_t stride_c, uint64_t stride_z) {
+    __shared__ XShared sh;
+    __shared__ XWaveLds wl[kXW];
+    const int chain = blockIdx.x;
+    if (round > last_round[chain]) return;  // (uniform over the workgroup)
+    MtState* mt_state = mt_base + chain;
+    for (int i = threadIdx.x; i < 624; i += blockDim.x) sh.mt[i] = mt_state->mt[i];
+    if (threadIdx.x == 0) {
+        sh.idx = mt_state->idx;
+        sh.next_tile = 0u;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    gibbs_exact_wg_body<kInit>(lane, w, &sh, &wl[w], n_tiles, tile_start, row_ptr, sid, cp, counts_base + (uint64_t)chain * stride_c,
+                               z_base + (uint64_t)chain * stride_z, pseudoC);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 624; i += blockDim.x) mt_state->mt[i] = sh.mt[i];
+    if (threadIdx.x == 0) mt_state->idx = sh.idx;
+}
+
 constexpr int kSerialTileItems = 3072;
 
 // The previous implementation: lane 0 walks the chain, the other 63 lanes stage the next tile of reads into LDS.
@@ -749,6 +778,8 @@ struct rsem_gibbs_ctx {
     uint64_t* d_irp = nullptr;
     int32_t* d_isid = nullptr;
     double* d_icp = nullptr;
+    uint32_t* d_tiles = nullptr;  // k_gibbs_exact_wg: first read of every tile (+ N1), build_exact_tiles
+    uint32_t n_tiles = 0;
     // PARALLEL mode, built on the device at its first use: noise split out + the sliced layout
     bool have_parallel = false;
     uint64_t* d_row_ptr = nullptr;
@@ -901,9 +932,30 @@ int ensure_parallel_layout(rsem_gibbs_ctx* c) {
     return RSEM_OK;
 }
 
-bool exact_serial_requested() {
+// RSEM_GIBBS_EXACT_IMPL = wg (default) | coop | serial: the three implementations of the same chain (cross-checks)
+enum ExactImpl { kExactWg, kExactCoop, kExactSerial };
+ExactImpl exact_impl_requested(bool have_alpha) {
     const char* e = getenv("RSEM_GIBBS_EXACT_IMPL");
-    return e && !strcmp(e, "serial");
+    if (e && !strcmp(e, "serial")) return kExactSerial;
+    if (e && !strcmp(e, "coop")) return kExactCoop;
+    return have_alpha ? kExactCoop : kExactWg;  // a per-transcript alpha (not in the reference) runs on the one-wave kernel
+}
+
+// Tiles of the workgroup kernel: greedy cut of the reads into runs of <= 64 reads and <= kXItems items; a read with more
+// items than that is a tile of its own (walked over global memory).  Depends on the row pointers only.
+void build_exact_tiles(uint64_t N1, const uint64_t* row_ptr, std::vector<uint32_t>& tiles) {
+    tiles.clear();
+    tiles.reserve(N1 / 48 + 2);
+    uint64_t i = 0;
+    while (i < N1) {
+        tiles.push_back((uint32_t)i);
+        const uint64_t b = row_ptr[i];
+        uint64_t e = i + 1;  // the first read always belongs to the tile
+        while (e < N1 && e - i < 64 && row_ptr[e + 1] - b <= (uint64_t)kXItems) ++e;
+        if (row_ptr[i + 1] - b > (uint64_t)kXItems) e = i + 1;
+        i = e;
+    }
+    tiles.push_back((uint32_t)N1);
 }
 
 }  // namespace
@@ -927,7 +979,7 @@ int rsem_gibbs_chain_seeds(uint32_t seed, int nchains, uint32_t* out) {
 int rsem_gibbs_destroy(rsem_gibbs_ctx* c) {
     if (!c) return RSEM_OK;
     (void)hipSetDevice(c->device);
-    hipFree(c->d_irp); hipFree(c->d_isid); hipFree(c->d_icp); hipFree(c->d_row_ptr); hipFree(c->d_sid);
+    hipFree(c->d_irp); hipFree(c->d_isid); hipFree(c->d_icp); hipFree(c->d_tiles); hipFree(c->d_row_ptr); hipFree(c->d_sid);
 #if RSEM_GIBBS_SCALAR_ADDR
     hipFree(c->d_ptab);
 #endif
@@ -1021,6 +1073,17 @@ int rsem_gibbs_create(rsem_gibbs_ctx** out, int device, int32_t M, uint64_t N1, 
         G_TRY(dmalloc(&c->d_alpha, nM));
         G_TRY(hipMemcpyAsync(c->d_alpha, alpha, sizeof(double) * nM, hipMemcpyHostToDevice, st));
     }
+    std::vector<uint32_t> tiles;  // (outlives the asynchronous copy: the stream is synchronised below)
+    for (uint64_t i = 0; i < N1; i++)
+        if (row_ptr[i + 1] < row_ptr[i]) {
+            rsem::set_last_error("row_ptr decreases at read %llu", (unsigned long long)i);
+            rsem_gibbs_destroy(c);
+            return RSEM_ERR_INVALID;
+        }
+    build_exact_tiles(N1, row_ptr, tiles);
+    c->n_tiles = (uint32_t)tiles.size() - 1;
+    G_TRY(dmalloc(&c->d_tiles, tiles.size()));
+    G_TRY(hipMemcpyAsync(c->d_tiles, tiles.data(), sizeof(uint32_t) * tiles.size(), hipMemcpyHostToDevice, st));
     // the ids index counts[] on the device: check them there (the host copy is not walked)
     int* d_err = nullptr;
     int h_err = 0;
@@ -1122,7 +1185,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         std::vector<MtState> h(nchains);
         for (int k = 0; k < nchains; k++) host_mt_seed(h[k], seeds[k]);
         RSEM_HIP_TRY(hipMemcpyAsync(mts.p, h.data(), sizeof(MtState) * nchains, hipMemcpyHostToDevice, st));
-        const bool serial = exact_serial_requested();
+        const ExactImpl impl = exact_impl_requested(c->d_alpha != nullptr);
         const int dbg = getenv("RSEM_GIBBS_EXACT_DEBUG") ? atoi(getenv("RSEM_GIBBS_EXACT_DEBUG")) : 0;
         DevBuf dbg_buf;
         RSEM_HIP_TRY(dbg_buf.alloc(4 * sizeof(unsigned long long)));
@@ -1130,7 +1193,13 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         auto sweep = [&](bool init, int round) {
 #define EXACT_ARGS c->N1, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->d_alpha, c->pseudoC, \
                    mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z
-            if (serial) {
+            if (impl == kExactWg) {
+#define EXACT_WG_ARGS c->n_tiles, c->d_tiles, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->pseudoC, \
+                      mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z
+                if (init) hipLaunchKernelGGL(k_gibbs_exact_wg<true>, dim3(nchains), dim3(64 * kXW), 0, st, EXACT_WG_ARGS);
+                else hipLaunchKernelGGL(k_gibbs_exact_wg<false>, dim3(nchains), dim3(64 * kXW), 0, st, EXACT_WG_ARGS);
+#undef EXACT_WG_ARGS
+            } else if (impl == kExactSerial) {
                 if (init) hipLaunchKernelGGL(k_gibbs_exact_serial<true>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
                 else hipLaunchKernelGGL(k_gibbs_exact_serial<false>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
             } else {

@@ -10,8 +10,8 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export RSEM_WL_CACHE=/dev/shm/rsem_wl
 tag=r03a
 out=gpurun_out/$tag; mkdir -p $out
-step() { name=$1; lim=$2; shift 2; l=$(left); [ $l -lt 15 ] && { echo "== $name: skipped, $l s left"; return; }; [ $lim -gt $l ] && lim=$l
-  t0=$(date +%s); timeout $lim "$@"; echo "== $name: rc=$? $(( $(date +%s) - t0 )) s"; }
+step() { local sname=$1 lim=$2; shift 2; local l=$(left); [ $l -lt 15 ] && { echo "== $sname: skipped, $l s left"; return; }; [ $lim -gt $l ] && lim=$l
+  local t0=$(date +%s); timeout $lim "$@"; echo "== $sname: rc=$? $(( $(date +%s) - t0 )) s"; }
 
 step tests_all 420 bash -c "python -m pytest tests -q -m gpu > $out/tests_all.log 2>&1; grep -E 'passed|failed|rror' $out/tests_all.log | tail -8"
 
@@ -20,7 +20,7 @@ step stream 40 bash -c "python -c \"
 from rsem_amd import capi
 print('stream probe read/copy GB/s: %.0f %.0f' % capi.stream_probe(0, 8 << 30, 5))\" | tee $out/stream.log"
 prof() {  # name, command
-  name=$1; shift
+  local name=$1; shift
   step stats_$name 120 bash -c "rocprofv3 --kernel-trace --stats --output-format csv -d $out/${name}_stats -o s -- $* > $out/${name}_stats.out 2> $out/${name}_stats.err"
   for c in FETCH_SIZE WRITE_SIZE; do
     step pmc_${name}_$c 120 bash -c "rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${name}_pmc_$c -o p -- $* > /dev/null 2> $out/${name}_pmc_$c.err"
