@@ -246,8 +246,6 @@ def main():
     ap.add_argument("--no-q32", action="store_true", help="skip the Q32 value-plane measurement beside the headline")
     ap.add_argument("--value-bits", type=int, default=64, choices=(64, 32),
                     help="32: the HEADLINE context itself streams Q32 value planes (profiling runs; the default line stays on the doubles)")
-    ap.add_argument("--lane-policy", type=int, default=0, choices=(0, 1),
-                    help="1: lanes per read chosen for the fewest plane bytes (needs a library built with -DRSEM_GENERAL_G=1; experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gibbs", action="store_true")
     ap.add_argument("--no-ci", action="store_true")
@@ -306,8 +304,6 @@ def main():
     ctx.set_option("kernel", args.kernel)
     if args.value_bits == 32:
         ctx.set_option("value_bits", 32)
-    if args.lane_policy:
-        ctx.set_option("lane_policy", args.lane_policy)
     upload_s = time.perf_counter() - t0
     log("[rank %d] upload + device layout: %.2f s" % (rank, upload_s))
     alg_bytes = 12 * nnz + 16 * N1 + 16 * (M + 1)
@@ -420,7 +416,7 @@ def main():
             "em_iterations_per_s": rounds / elapsed, "timed_rounds": rounds, "timed_region_s": elapsed, "timed_repeats_of_steps": reps,
             "config": {"workload": "%s: EM matrix of %d reads x %d transcripts, %d alignments (%.2f/read) per GPU, frozen conprb "
                                    "(rounds >= 12)" % (WORKLOADS.get(args.config, args.config), N1, M, nnz, nnz / max(N1, 1)),
-                       "synthetic_config": args.config, "kernel": args.kernel, "value_bits": args.value_bits, "lane_policy": args.lane_policy,
+                       "synthetic_config": args.config, "kernel": args.kernel, "value_bits": args.value_bits,
                        "value_plane_bytes": value_plane_bytes,
                        "parallelism": "1 GPU" if world == 1 else "read-sharded x%d + RCCL all-reduce(M+1 f64)/round from C++ on the EM stream" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

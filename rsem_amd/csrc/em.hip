@@ -780,7 +780,6 @@ struct rsem_em_ctx {
     int value_bits = 64;              // 64: every read F64; 32: Q32 where a read qualifies
     int value_range_bits = 8;         // a read qualifies when its non-zero values span less than 2^this
     bool layout_has_q32 = false;      // the current layout was built with Q32 shapes (from the then-current values)
-    int lane_policy = 0;              // RSEM_GENERAL_G builds: 1 = lanes per read chosen for the fewest plane bytes
     bool layout_ok = false;           // false between free_layout and a build_layout that went through (a failed rebuild)
     // LANE variant work list
     Unit* d_units = nullptr;
@@ -844,7 +843,6 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
                                c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs());
     } else {
         if (c->layout_has_q32) { rsem::set_last_error("the SELL kernel reads F64 planes only (value_bits = 32 needs the LANE kernel)"); return RSEM_ERR_STATE; }
-        if (c->L.has_general_g) { rsem::set_last_error("the SELL kernel needs power-of-two lane groups (lane_policy = 1 needs the LANE kernel)"); return RSEM_ERR_STATE; }
         hipLaunchKernelGGL(k_estep_sell, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
                            c->L.n_slices, d_theta, (const double*)c->d_sval, c->L.d_ssid, c->d_sncp, d_counts, c->d_noise_a, ctrl);
     }
@@ -929,7 +927,6 @@ int build_layout(rsem_em_ctx* c) {
     // one block per wave, ~2.5 blocks per wave slot (6 waves/SIMD) for load balance
     const uint32_t target_waves = (uint32_t)c->n_cus * 4 * 6 * 5 / 2;
     const bool q32 = c->value_bits == 32 && c->have_values;
-    c->L.g_policy = c->lane_policy;
     int rc = sell_build(c->L, c->stream, c->N1, c->M, c->d_row_ptr, c->d_sid, target_waves, c->forced_T,
                         q32 ? c->d_cp : nullptr, c->value_range_bits);
     if (rc != RSEM_OK) return rc;
@@ -1137,22 +1134,6 @@ int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
         set_grid_for_kernel(c);
         return RSEM_OK;
     }
-    if (!strcmp(key, "lane_policy")) {  // experimental (RSEM_GENERAL_G builds only): see sell_layout.hpp
-#if RSEM_GENERAL_G
-        RSEM_REQUIRE(value == 0 || value == 1, "lane_policy must be 0 or 1");
-        if (c->lane_policy == (int)value) return RSEM_OK;
-        c->lane_policy = (int)value;
-        RSEM_HIP_TRY(hipSetDevice(c->device));
-        free_layout(c);
-        int rc = build_layout(c);
-        if (rc != RSEM_OK) return rc;
-        set_grid_for_kernel(c);
-        return RSEM_OK;
-#else
-        rsem::set_last_error("lane_policy: this build has power-of-two lane groups only");
-        return value == 0 ? RSEM_OK : RSEM_ERR_INVALID;
-#endif
-    }
     if (!strcmp(key, "check_every")) {
         RSEM_REQUIRE(value >= 1 && value <= kHistCap / 4, "check_every out of range");
         c->check_every = (int)value;
@@ -1173,8 +1154,6 @@ int rsem_em_get_info(const rsem_em_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "sid_plane_bytes")) *value = (int64_t)(c->L.n_planes * 256);
     else if (!strcmp(key, "slots")) *value = c->L.n_slots;
     else if (!strcmp(key, "units")) *value = c->n_units;
-    else if (!strcmp(key, "lane_policy")) *value = c->lane_policy;
-    else if (!strcmp(key, "general_g")) *value = RSEM_GENERAL_G;
     else { rsem::set_last_error("unknown info key '%s'", key); return RSEM_ERR_INVALID; }
     return RSEM_OK;
 }

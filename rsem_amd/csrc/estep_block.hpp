@@ -78,58 +78,23 @@ RSEM_DEVFN double pow2_of(int e) { return RSEM_LL_AS_DOUBLE((long long)(1023 + e
 #ifndef RSEM_Q32_DEPTHS
 #define RSEM_Q32_DEPTHS 8, 6, 4, 3
 #endif
-// Tuning by elimination (tools/build_variants.sh; NEVER set in the product build): each bit removes one component of the
-// E step so that its share of the launch time can be read off a bench run whose results are meaningless.
-//   1 no count spills (LDS / global atomics)   2 no division   4 no cross-lane reduction   8 no value loads
-//   16 no sid loads   32 no noise / exponent loads
-#ifndef RSEM_DIAG
-#define RSEM_DIAG 0
+// Measured in round 3 (profiles/r03a_variants_and_steps.log, C3 / C2, F64 / Q32 launch) and adopted: the per-read normaliser's
+// butterfly over 2..16 lanes with DPP moves instead of ds_bpermute (same additions in the same order: bit-identical; Q32
+// -4.6 %), the count spill spelled as an LDS atomic (ds_add_f64) or a global one instead of ONE flat atomic on a selected
+// address (Q32 -4 %), and the non-temporal hint on the value planes (read once per launch: they no longer push theta /
+// counts / sid planes out of L2 and the Infinity Cache; F64 -4 % at C3, -12 % at C2).  Measured and dropped (within +-1 %):
+// reciprocal by Newton steps, clamp fast path, fused multiply-add accumulation, mantissa conversion by an exponent word,
+// ballot-counted normalisers, lane groups that are not a power of two (+5 %: the cheaper planes lost to the dearer
+// lane arithmetic).
+//   RSEM_NT_LEVEL  1: value planes non-temporal (the product).  2 (candidate for the next measurement): also the sid planes,
+//                  the per-read noise / exponent slots and the slice masks -- everything that is read once per launch.
+#ifndef RSEM_NT_LEVEL
+#define RSEM_NT_LEVEL 1
 #endif
-// Candidates for the next measurement (tools/build_variants.sh; off in the product build until measured and tested on a GPU):
-//   RSEM_FAST_RCP    1 / normaliser as v_rcp_f64 + two Newton steps (<= 2 ulp) instead of the IEEE division sequence
-//   RSEM_DPP_REDUCE  the per-read normaliser's butterfly over 2..16 lanes with DPP moves instead of ds_bpermute
-//                    (same additions in the same order: bit-identical)
-#ifndef RSEM_FAST_RCP
-#define RSEM_FAST_RCP 0
-#endif
-#ifndef RSEM_DPP_REDUCE
-#define RSEM_DPP_REDUCE 0
-#endif
-//   RSEM_CLAMP_FAST  the 1e-300 clamps of a slice's terms (EM.cpp:212,219: one compare + two selects per alignment) are
-//                    applied only when some lane of the wave has a term under the threshold (one ballot per slice);
-//                    otherwise the products are used as they are -- the same values, since nothing was to be clamped
-//   RSEM_FMA_ACC     acc += f * inv as one fused multiply-add (one rounding instead of two: last-bit differences)
-//   RSEM_SPILL_DS    the count spill spelled as an LDS atomic (ds_add_f64) or a global one; left to the compiler the two
-//                    branches become ONE flat_atomic_add_f64 on a selected address (seen in the ISA)
-#ifndef RSEM_SPILL_DS
-#define RSEM_SPILL_DS 0
-#endif
-//   RSEM_NT_LOADS    the value planes (read once per launch) with the non-temporal hint, so that they do not push theta /
-//                    counts / sid planes out of L2 and the Infinity Cache
-#ifndef RSEM_NT_LOADS
-#define RSEM_NT_LOADS 0
-#endif
-//   RSEM_Q32_MAGIC   Q32 mantissa -> double by an exponent word and one subtraction (see the reduce step) instead of
-//                    v_cvt_f64_u32 + v_mul_f64
-#ifndef RSEM_Q32_MAGIC
-#define RSEM_Q32_MAGIC 0
-#endif
-//   RSEM_NEFF_BALLOT the count of reads with a non-zero normaliser as popcount(ballot) into a scalar per wave instead of a
-//                    compare / select / f64 add per lane and slice
-#ifndef RSEM_NEFF_BALLOT
-#define RSEM_NEFF_BALLOT 0
-#endif
-#ifndef RSEM_CLAMP_FAST
-#define RSEM_CLAMP_FAST 0
-#endif
-#ifndef RSEM_FMA_ACC
-#define RSEM_FMA_ACC 0
-#endif
-RSEM_DEVFN double recip_newton(double x) {
-    double r = RSEM_RCP(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return fma(fma(-x, r, 1.0), r, r);
-}
+template <typename T>
+RSEM_DEVFN T stream_load(const T* p) { return RSEM_NT_LOAD(p); }
+template <typename T>
+RSEM_DEVFN T stream_load2(const T* p) { return RSEM_NT_LEVEL >= 2 ? RSEM_NT_LOAD(p) : *p; }  // the level-2 streams
 template <int kCtrl>
 RSEM_DEVFN double dpp_take(double v) {  // the value of the lane the DPP control selects (all lanes active here)
     const long long b = RSEM_DOUBLE_AS_LL(v);
@@ -159,26 +124,16 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
     using ValT = typename std::conditional<kQ, uint32_t, double>::type;
     const ValT* __restrict__ scp = (const ValT*)(sval + S.val_base);  // this shape's value planes
     const int lg = S.lg;
-#if RSEM_GENERAL_G
-    // lanes per read need not be a power of two (sell_layout.hpp): read r of the slice sits in lanes [r * G, r * G + G), the
-    // lanes past the last read idle on zero planes
-    const int G = shape_G(S);
-    const uint32_t R = shape_R(S);
-    const int rr = lg >= 0 ? (lane >> lg) : lane / G;
-    const int g = lane - rr * G;
-    const bool g0 = (g == 0) && (uint32_t)rr < R;
-#else
     const int g = lane & ((1 << lg) - 1);
     const bool g0 = (g == 0);
     const uint32_t R = 64u >> lg;
-#endif
     // 64 slices' masks at a time, one per lane
     uint32_t m_base = s_begin;
-    unsigned long long mv = (s_begin + lane < s_end) ? masks[s_begin + lane] : ~0ull;
+    unsigned long long mv = (s_begin + lane < s_end) ? stream_load2(&masks[s_begin + lane]) : ~0ull;
     auto mask_of = [&](uint32_t t) -> unsigned long long {
         if (t - m_base >= 64u) {
             m_base = t;
-            mv = (t + lane < s_end) ? masks[t + lane] : ~0ull;
+            mv = (t + lane < s_end) ? stream_load2(&masks[t + lane]) : ~0ull;
         }
         const int src = (int)(t - m_base);
         const uint32_t lo = RSEM_READLANE((int)(uint32_t)mv, src);
@@ -189,44 +144,29 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
     // the caller hands over through readfirstlane): the slice's base addresses are scalar, a lane adds its own constant
     // offset -- no per-lane 64-bit address arithmetic.  The sids of a slice are loaded by all lanes or (mask 0, a scalar
     // branch) by none: lanes that do not start a tuple ignore theirs.
-#if RSEM_GENERAL_G
-    const unsigned ulane = (unsigned)lane, uslot = (unsigned)rr < R ? (unsigned)rr : R - 1;  // (idle lanes: any slot of the slice)
-#else
     const unsigned ulane = (unsigned)lane, uslot = ulane >> lg;
-#endif
     auto issue = [&](uint32_t t, unsigned long long m, SliceRegs<K, kQ>& b) {
         const uint32_t sl = t - S.slice_base;
         const uint64_t v0 = (uint64_t)sl * (K * 64);              // first entry of the slice within the shape's planes
         const ValT* __restrict__ vp = scp + v0;
-        if ((RSEM_DIAG & 16) == 0) {
-            if (m != 0ull) {
-                const int32_t* __restrict__ ip = ssid + (S.plane_base * 64 + v0);
+        if (m != 0ull) {
+            const int32_t* __restrict__ ip = ssid + (S.plane_base * 64 + v0);
 #pragma unroll
-                for (int k = 0; k < K; k++) b.id[k] = ip[k * 64 + ulane];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < K; k++) b.id[k] = (int)(t & 1023) + k;
+            for (int k = 0; k < K; k++) b.id[k] = stream_load2(&ip[k * 64 + ulane]);
         }
 #pragma unroll
-        for (int k = 0; k < K; k++)
-            b.c[k] = (RSEM_DIAG & 8) ? (ValT)(t + k) : (RSEM_NT_LOADS ? __builtin_nontemporal_load(&vp[k * 64 + ulane]) : vp[k * 64 + ulane]);
+        for (int k = 0; k < K; k++) b.c[k] = stream_load(&vp[k * 64 + ulane]);
         const uint32_t slot0 = S.slot_base + sl * R;
-        b.nc = (RSEM_DIAG & 32) ? 1e-30 : (g0 ? (sncp + slot0)[uslot] : 0.0);
-        b.e = (RSEM_DIAG & 32) ? -40 : (kQ ? (int)(sexp + slot0)[uslot] : 0);
+        b.nc = g0 ? stream_load2(&(sncp + slot0)[uslot]) : 0.0;
+        b.e = kQ ? (int)stream_load2(&(sexp + slot0)[uslot]) : 0;
     };
     auto spill = [&](const int* rsid, double* acc) {  // lane-private partial counts -> LDS window
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            if (acc[k] != 0.0 && !(RSEM_DIAG & 1)) {
+            if (acc[k] != 0.0) {
                 const unsigned off = (unsigned)(rsid[k] - base);
-#if RSEM_SPILL_DS
                 if (off < (unsigned)span) RSEM_LDS_ADD(&cnt_win[off], acc[k]);
                 else RSEM_ATOMIC_ADD(&counts[rsid[k]], acc[k]);
-#else
-                if (off < (unsigned)span) RSEM_ATOMIC_ADD(&cnt_win[off], acc[k]);
-                else RSEM_ATOMIC_ADD(&counts[rsid[k]], acc[k]);
-#endif
             }
             acc[k] = 0.0;
         }
@@ -238,7 +178,6 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
     for (int k = 0; k < K; k++) { rsid[k] = 0; rth[k] = 0.0; acc[k] = 0.0; }
     ThetaSrc th{theta, 0.0, 1.0};
     double th0 = 0.0;
-    unsigned neff_wave = 0;  // RSEM_NEFF_BALLOT: the wave's count, uniform (a scalar register), handed to lane 0 at the end
     auto reduce = [&](const SliceRegs<K, kQ>& cur, unsigned long long cur_m) {
         if (cur_m != 0ull) {                 // wave-uniform
             if ((cur_m >> lane) & 1ull) {    // lanes whose read starts a new sid tuple
@@ -257,53 +196,22 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         double f[K];
         double part = f0;
         const double scale = kQ ? pow2_of(cur.e) : 1.0;
-        // RSEM_Q32_MAGIC: the bits {exponent of 2^(52+e), mantissa m} ARE the double 2^(52+e) + m * 2^e (m < 2^32 fits the low
-        // mantissa bits), so m * 2^e = that double - 2^(52+e), exactly: one full-rate add instead of a conversion and a multiply
-        const long long magic_hi = kQ ? (long long)(1075 + cur.e) << 52 : 0;
-        const double magic_base = RSEM_LL_AS_DOUBLE(magic_hi);
 #pragma unroll
         for (int k = 0; k < K; k++) {
             // Q32: mantissa * 2^e is exact, so this is the F64 expression on the rounded value
-            const double cv = !kQ ? (double)cur.c[k]
-                            : RSEM_Q32_MAGIC ? RSEM_LL_AS_DOUBLE(magic_hi | (long long)(unsigned long long)cur.c[k]) - magic_base
-                                             : (double)cur.c[k] * scale;
+            const double cv = kQ ? (double)cur.c[k] * scale : (double)cur.c[k];
             double v = rth[k] * cv;
-            if (!RSEM_CLAMP_FAST && v < kEpsilon) v = 0.0;
+            if (v < kEpsilon) v = 0.0;
             f[k] = v;
-            if (!RSEM_CLAMP_FAST) part += v;
+            part += v;
         }
-        if (RSEM_CLAMP_FAST) {
-            bool small = false;
-#pragma unroll
-            for (int k = 0; k < K; k++) small = small || (f[k] < kEpsilon);
-            if (RSEM_BALLOT(small) != 0ull) {  // (uniform) rare: some theta * conprb of this slice is under 1e-300
-#pragma unroll
-                for (int k = 0; k < K; k++)
-                    if (f[k] < kEpsilon) f[k] = 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < K; k++) part += f[k];
-        }
-        if (!(RSEM_DIAG & 4)) {
-#if RSEM_GENERAL_G
-            if (lg < 0) {  // (uniform over the workgroup) any G: fold towards the read's first lane, then hand the total back
-                for (int d = 1; d < G; d <<= 1) {
-                    const double o = RSEM_SHFL_DOWN(part, d);
-                    if (g + d < G) part += o;
-                }
-                part = RSEM_SHFL(part, lane - g);
-            } else
-#endif
-            if (RSEM_DPP_REDUCE) part = read_sum_dpp(part, lg);
-            else for (int d = 1; d < (1 << lg); d <<= 1) part += RSEM_SHFL_XOR(part, d);
-        }
-        const double inv = (RSEM_DIAG & 2) ? part : ((part >= kEpsilon) ? (RSEM_FAST_RCP ? recip_newton(part) : 1.0 / part) : 0.0);
+        part = read_sum_dpp(part, lg);
+        const double inv = (part >= kEpsilon) ? 1.0 / part : 0.0;
         noise += f0 * inv;
         // reads whose fractions sum to one: sum(counts) without a reduction
-        if (RSEM_NEFF_BALLOT) neff_wave += (unsigned)__builtin_popcountll(RSEM_BALLOT(g0 && part >= kEpsilon));
-        else neff += (g0 && part >= kEpsilon) ? 1.0 : 0.0;
+        neff += (g0 && part >= kEpsilon) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < K; k++) acc[k] = RSEM_FMA_ACC ? fma(f[k], inv, acc[k]) : acc[k] + f[k] * inv;
+        for (int k = 0; k < K; k++) acc[k] = acc[k] + f[k] * inv;
     };
     if constexpr (NBUF == 2) {
         // ping-pong register sets A / B: the loads of the next slice are in flight while this one is reduced
@@ -358,7 +266,6 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         }
     }
     spill(rsid, acc);
-    if (RSEM_NEFF_BALLOT && lane == 0) neff += (double)neff_wave;
 }
 
 template <bool kFC>

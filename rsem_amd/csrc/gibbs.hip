@@ -57,21 +57,11 @@ __global__ void k_fill_double(int32_t n, double v, double* g) {
     if (i < n) g[i] = v;
 }
 
-// Candidate for the next measurement (tools/build_variants.sh; off until measured and tested on a GPU): the E step's scalar
-// slice addressing (which took 10 % off its Q32 launch) in the sweep kernel.
-#ifndef RSEM_GIBBS_SCALAR_ADDR
-#define RSEM_GIBBS_SCALAR_ADDR 0
-#endif
-// ... and: the read's uniform from Philox2x32-10 (64 bits per call) instead of Philox4x32-10 (128 bits, half of them unused)
-#ifndef RSEM_GIBBS_PHILOX2
-#define RSEM_GIBBS_PHILOX2 0
-#endif
 constexpr int kGWindow = 2048;  // sids per workgroup window (g values: 16 KB, int counts: 8 KB of LDS)
 
 // the per-wave body of the sweep kernel (also run on the CPU by tests/gibbs_emu.cpp)
 #include "gibbs_block.hpp"
 
-#if RSEM_GIBBS_SCALAR_ADDR
 __global__ void k_slice_ptab(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_slices, PtabEntry* ptab) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slices) return;
@@ -79,21 +69,13 @@ __global__ void k_slice_ptab(const Shape* __restrict__ shapes, int n_shapes, uin
     while (sh + 1 < n_shapes && s >= shapes[sh + 1].slice_base) ++sh;
     ptab[s] = slice_ptab_entry(shapes[sh], T, s - shapes[sh].slice_base);
 }
-#endif
 
-#if RSEM_GIBBS_SCALAR_ADDR
-#define GIBBS_PTAB_ARG ptab,
-#else
-#define GIBBS_PTAB_ARG
-#endif
 __global__ __launch_bounds__(kBlock) void k_sample_z_lane(
     const Shape* __restrict__ shapes, const Unit* __restrict__ units, uint32_t T, int M,
     const double* __restrict__ g, const double* __restrict__ scp, const int32_t* __restrict__ ssid,
     const double* __restrict__ sncp, const unsigned long long* __restrict__ masks, Philox ph, uint32_t sweep,
     int32_t* counts
-#if RSEM_GIBBS_SCALAR_ADDR
     , const PtabEntry* __restrict__ ptab
-#endif
     ) {
     __shared__ double g_win[kGWindow];
     __shared__ int cnt_win[kGWindow];
@@ -101,11 +83,7 @@ __global__ __launch_bounds__(kBlock) void k_sample_z_lane(
     const Unit U = units[blockIdx.x];
     if (threadIdx.x == 0) s_noise = 0;
     const int lane = threadIdx.x & 63;
-#if RSEM_GIBBS_SCALAR_ADDR
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#else
-    const int w = threadIdx.x >> 6;
-#endif
     int noise = 0;
     {
         const Shape S = U.S;
@@ -114,10 +92,10 @@ __global__ __launch_bounds__(kBlock) void k_sample_z_lane(
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
         const double g0 = g[0];
         if (s_begin < u_end) switch (S.K) {
-            case 1: gibbs_block<1>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, GIBBS_PTAB_ARG ph, sweep, counts, noise, M); break;
-            case 2: gibbs_block<2>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, GIBBS_PTAB_ARG ph, sweep, counts, noise, M); break;
-            case 3: gibbs_block<3>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, GIBBS_PTAB_ARG ph, sweep, counts, noise, M); break;
-            default: gibbs_block<4>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, GIBBS_PTAB_ARG ph, sweep, counts, noise, M); break;
+            case 1: gibbs_block<1>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ptab, ph, sweep, counts, noise, M); break;
+            case 2: gibbs_block<2>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ptab, ph, sweep, counts, noise, M); break;
+            case 3: gibbs_block<3>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ptab, ph, sweep, counts, noise, M); break;
+            default: gibbs_block<4>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ptab, ph, sweep, counts, noise, M); break;
         } else stage_gwindows(U.base, U.span, M, g, g_win, cnt_win);
     }
     for (int d = 32; d >= 1; d >>= 1) noise += __shfl_xor(noise, d);
@@ -789,9 +767,7 @@ struct rsem_gibbs_ctx {
     SellLayout L;
     double* d_scp = nullptr;
     double* d_sncp = nullptr;
-#if RSEM_GIBBS_SCALAR_ADDR
     PtabEntry* d_ptab = nullptr;      // k_slice_ptab
-#endif
     Unit* d_units = nullptr;
     uint32_t n_units = 0;
     double* d_g = nullptr;
@@ -908,14 +884,12 @@ int ensure_parallel_layout(rsem_gibbs_ctx* c) {
     RSEM_HIP_TRY(dmalloc(&c->d_sncp, (size_t)c->L.n_slots));
     rc = sell_fill_values(c->L, st, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_scp, c->d_sncp);
     if (rc != RSEM_OK) return rc;
-#if RSEM_GIBBS_SCALAR_ADDR
     RSEM_HIP_TRY(dmalloc(&c->d_ptab, (size_t)c->L.n_slices));
     if (c->L.n_slices) {
         hipLaunchKernelGGL(k_slice_ptab, dim3(rsem::ceil_div(c->L.n_slices, kBlock)), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
                            c->L.T, c->L.n_slices, c->d_ptab);
         RSEM_HIP_TRY(hipGetLastError());
     }
-#endif
     RSEM_HIP_TRY(hipStreamSynchronize(st));
     std::vector<Unit> units;
     rc = sell_build_units(c->L, units, kGWindow);
@@ -980,9 +954,7 @@ int rsem_gibbs_destroy(rsem_gibbs_ctx* c) {
     if (!c) return RSEM_OK;
     (void)hipSetDevice(c->device);
     hipFree(c->d_irp); hipFree(c->d_isid); hipFree(c->d_icp); hipFree(c->d_tiles); hipFree(c->d_row_ptr); hipFree(c->d_sid);
-#if RSEM_GIBBS_SCALAR_ADDR
     hipFree(c->d_ptab);
-#endif
     hipFree(c->d_cp); hipFree(c->d_ncp); sell_free(c->L); hipFree(c->d_scp); hipFree(c->d_sncp);
     hipFree(c->d_init_counts); hipFree(c->d_g); hipFree(c->d_alpha);
     hipFree(c->d_eel); hipFree(c->d_mw); hipFree(c->d_grp);
@@ -1239,9 +1211,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                 if (c->n_units)
                     hipLaunchKernelGGL(k_sample_z_lane, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
                                        c->d_g, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, ph, sw, ck
-#if RSEM_GIBBS_SCALAR_ADDR
                                        , (const PtabEntry*)c->d_ptab
-#endif
                                        );
                 if (c->L.n_long_rows)
                     hipLaunchKernelGGL(k_sample_z_long, dim3(rsem::ceil_div(c->L.n_long_rows, kBlock)), dim3(kBlock), 0, st,

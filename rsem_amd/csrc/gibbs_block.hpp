@@ -5,10 +5,18 @@
 #pragma once
 #include "simt_macros.hpp"
 
-// Tuning by elimination, as RSEM_DIAG in estep_block.hpp (never set in the product build; results meaningless, times
-// comparable):  1 no random numbers (u = 0.5)   2 no scan over the read's lanes   4 no count spills
-#ifndef RSEM_GDIAG
-#define RSEM_GDIAG 0
+// Measured in round 3 and adopted (profiles/r03a_variants_and_steps.log: 1.538 -> 1.396 ms per sweep at C3): scalar slice
+// addressing with a per-slice table of sorted positions (no divisions by T and R in every slice), the read's uniform from
+// Philox2x32-10 (64 bits per call) instead of Philox4x32-10.  Candidates for the next measurement:
+//   RSEM_GIBBS_NT          the value planes (read once per sweep) with the non-temporal hint, as in the E step
+//   RSEM_GIBBS_RNG_SPREAD  a read that occupies G lanes computes ONE uniform per slice in its first lane while the other
+//                          G - 1 lanes wait: instead lane j of the read computes the uniform of slice s + j once every G
+//                          slices and each slice fetches its own with one cross-lane move (same keys, same numbers)
+#ifndef RSEM_GIBBS_NT
+#define RSEM_GIBBS_NT 0
+#endif
+#ifndef RSEM_GIBBS_RNG_SPREAD
+#define RSEM_GIBBS_RNG_SPREAD 0
 #endif
 
 // g[base, base+span) -> LDS, count window zeroed; every wave of the workgroup calls this exactly once
@@ -49,9 +57,7 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
                                    const double* __restrict__ g, double g0, double* g_win, int* cnt_win,
                                    const double* __restrict__ scp, const int32_t* __restrict__ ssid,
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
-#if RSEM_GIBBS_SCALAR_ADDR
                                    const PtabEntry* __restrict__ ptab,
-#endif
                                    const Philox& ph, uint32_t sweep, int32_t* counts, int& noise, int M) {
     const int lg = S.lg, G = 1 << lg;
     const int gl = lane & (G - 1);
@@ -72,7 +78,6 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
     };
     auto issue = [&](uint32_t t, unsigned long long m, SliceRegs<K>& b) {
         const uint32_t sl = t - S.slice_base;
-#if RSEM_GIBBS_SCALAR_ADDR
         // as in the E step (em.hip, estep_block): scalar slice bases + a constant lane offset; the sids of a slice are
         // loaded by all lanes or (mask 0) by none
         const uint64_t p0 = (S.plane_base + (uint64_t)sl * K) * 64;
@@ -84,17 +89,8 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
         }
         const double* __restrict__ vp = scp + p0;
 #pragma unroll
-        for (int k = 0; k < K; k++) b.c[k] = vp[k * 64 + ulane];
+        for (int k = 0; k < K; k++) b.c[k] = RSEM_GIBBS_NT ? RSEM_NT_LOAD(&vp[k * 64 + ulane]) : vp[k * 64 + ulane];
         b.nc = g0lane ? (sncp + (S.slot_base + sl * R))[ulane >> lg] : 0.0;
-#else
-        const uint64_t pl = (S.plane_base + (uint64_t)sl * K) * 64 + lane;
-        const bool want = (m >> lane) & 1ull;
-#pragma unroll
-        for (int k = 0; k < K; k++) b.id[k] = ssid[want ? pl + (uint64_t)k * 64 : 0];
-#pragma unroll
-        for (int k = 0; k < K; k++) b.c[k] = scp[pl + (uint64_t)k * 64];
-        b.nc = g0lane ? sncp[S.slot_base + sl * R + (lane >> lg)] : 0.0;
-#endif
     };
     int rsid[K], acc[K];
     double rg[K];
@@ -103,7 +99,7 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
     auto spill = [&]() {
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            if (acc[k] != 0 && !(RSEM_GDIAG & 4)) {
+            if (acc[k] != 0) {
                 const unsigned off = (unsigned)(rsid[k] - base);
                 if (off < (unsigned)span) RSEM_ATOMIC_ADD_I32(&cnt_win[off], acc[k]);
                 else RSEM_ATOMIC_ADD_I32(&counts[rsid[k]], acc[k]);
@@ -111,6 +107,7 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
             acc[k] = 0;
         }
     };
+    double u_batch = 0.0;  // RSEM_GIBBS_RNG_SPREAD: this lane's share of the read's next G uniforms
     auto sample = [&](const SliceRegs<K>& cur, unsigned long long cur_m, uint32_t s) {
         if (cur_m != 0ull) {
             if ((cur_m >> lane) & 1ull) {
@@ -133,11 +130,10 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
             part += f[k];
         }
         double incl = part;  // inclusive scan over the G lanes of the read
-        for (int d = 1; d < G && !(RSEM_GDIAG & 2); d <<= 1) {
+        for (int d = 1; d < G; d <<= 1) {
             double o = RSEM_SHFL_UP(incl, d);
             if (gl >= d) incl += o;
         }
-#if RSEM_GIBBS_SCALAR_ADDR
         // (one lane per read: nothing to exchange -- a uniform branch, lg comes from the unit descriptor)
         double excl = 0.0, total = incl;
         if (lg > 0) {
@@ -145,36 +141,31 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
             if (gl == 0) excl = 0.0;
             total = RSEM_SHFL(incl, gbase + G - 1);
         }
-#else
-        double excl = RSEM_SHFL_UP(incl, 1);
-        if (gl == 0) excl = 0.0;
-        const double total = RSEM_SHFL(incl, gbase + G - 1);
-#endif
         // one uniform per read, keyed by the read's position in the sorted order (layout independent)
-#if RSEM_GIBBS_SCALAR_ADDR
-        const PtabEntry pt = ptab[s];  // (s is uniform over the wave: a scalar load)
-        const uint32_t p = pt.x + ((uint32_t)lane >> lg) * pt.y;
-#else
-        const uint32_t sl = s - S.slice_base;
-        const uint32_t b = sl / T, t = sl % T, r = (uint32_t)lane >> lg;
-        const uint32_t left = S.n_rows - b * R * T;
-        const uint32_t nb = left < R * T ? left : R * T;
-        const uint32_t Tb = (nb + R - 1) / R;
-        const uint32_t p = S.row_base + b * R * T + r * Tb + t;
-#endif
-        uint32_t rnd[4] = {0, 0, 0, 0};
-#if RSEM_GIBBS_PHILOX2
-        if (g0lane) rsem::philox2x32_10(ph.k0 ^ ((ph.k1 << 13) | (ph.k1 >> 19)) ^ 0x5a5a5a5au, p, sweep, rnd);
-#else
-        if (g0lane && !(RSEM_GDIAG & 1)) ph.gen(p, sweep, 0x5a5a5a5au, 0u, rnd);
-#endif
-        if (RSEM_GDIAG & 1) rnd[0] = 0x80000000u;
-#if RSEM_GIBBS_SCALAR_ADDR
-        double u = u53(rnd[0], rnd[1]);
-        if (lg > 0) u = RSEM_SHFL(u, gbase);
-#else
-        const double u = RSEM_SHFL(u53(rnd[0], rnd[1]), gbase);
-#endif
+        const uint32_t key = ph.k0 ^ ((ph.k1 << 13) | (ph.k1 >> 19)) ^ 0x5a5a5a5au;
+        double u;
+        if (RSEM_GIBBS_RNG_SPREAD && lg > 0) {
+            const uint32_t off = (s - s_begin) & (uint32_t)(G - 1);  // (uniform over the wave)
+            if (off == 0) {
+                const uint32_t sj = s + (uint32_t)gl;  // lane gl of the read: the uniform of slice s + gl
+                double ub = 0.0;
+                if (sj < s_end) {
+                    const PtabEntry pj = ptab[sj];
+                    uint32_t r2[2];
+                    rsem::philox2x32_10(key, pj.x + ((uint32_t)lane >> lg) * pj.y, sweep, r2);
+                    ub = u53(r2[0], r2[1]);
+                }
+                u_batch = ub;
+            }
+            u = RSEM_SHFL(u_batch, gbase + (int)off);
+        } else {
+            const PtabEntry pt = ptab[s];  // (s is uniform over the wave: a scalar load)
+            const uint32_t p = pt.x + ((uint32_t)lane >> lg) * pt.y;
+            uint32_t rnd[2] = {0, 0};
+            if (g0lane) rsem::philox2x32_10(key, p, sweep, rnd);
+            u = u53(rnd[0], rnd[1]);
+            if (lg > 0) u = RSEM_SHFL(u, gbase);
+        }
         double target = u * total;
         if (target >= total) target = total * (1.0 - 1.1102230246251565e-16);
         int pick = -2;  // -2: not mine, -1: noise, k >= 0: my plane k

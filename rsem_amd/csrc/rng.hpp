@@ -39,7 +39,7 @@ struct Philox {
 };
 
 // Philox2x32-10 (same paper): 64 bits per call for half the multiplications -- one 53-bit uniform per read is all the
-// Gibbs sweep needs (RSEM_GIBBS_PHILOX2, a prepared variant of gibbs.hip).
+// Gibbs sweep needs (gibbs_block.hpp).
 __host__ __device__ inline void philox2x32_10(uint32_t key, uint32_t c0, uint32_t c1, uint32_t* out) {
 #pragma unroll
     for (int i = 0; i < 10; i++) {

@@ -30,23 +30,8 @@
 
 namespace {
 
-// RSEM_GENERAL_G (compile-time, off in the product build until measured and tested on a GPU; tools/build_variants.sh):
-// the lanes a read occupies need not be a power of two.  With G = 2^lg a read of L alignments occupies K * 2^lg >= L
-// entries -- on BASELINE configs[2] 14 % of the value planes are padding, and the F64 E step sits on the HBM ceiling for
-// the bytes it moves.  With any G in 1..64 (R = floor(64 / G) reads per slice, the last 64 - R * G lanes idle) the shape of a
-// read length is the (G, K) that minimises K * 64 / R bytes per read: L = 9 -> (3, 3) instead of (4, 3), L = 10 -> (5, 2),
-// L = 14 -> (7, 2), ...  Planes stay 64 entries wide and aligned; only the lane -> (read, position) mapping and the
-// reduction over a read's lanes change.  Shape::lg then holds log2(G) for a power of two and -G otherwise.
-#ifndef RSEM_GENERAL_G
-#define RSEM_GENERAL_G 0
-#endif
-#if RSEM_GENERAL_G
-constexpr int kShapesPerFmt = 256;  // (G 1..64) x (K 1..4): id = (G - 1) * 4 + (K - 1)
-constexpr int kShapeBits = 10;
-#else
 constexpr int kShapesPerFmt = 28;   // (lg 0..6) x (K 1..4)
 constexpr int kShapeBits = 6;
-#endif
 constexpr int kMaxShapes = 2 * kShapesPerFmt;  // F64 shapes, then Q32 shapes
 constexpr int kShapeIds = 1 << kShapeBits;
 constexpr int kLongShape = kShapeIds - 1;      // rows with more than 256 alignments: CSR kernel
@@ -63,7 +48,7 @@ struct Shape {
     uint32_t n_rows;
     uint32_t slot_base;   // first row slot (slot = slice * rows_per_slice + r)
     int32_t K;            // planes per slice
-    int32_t lg;           // log2(lanes per read)  [RSEM_GENERAL_G: -G when G is not a power of two]
+    int32_t lg;           // log2(lanes per read)
     int32_t fmt;          // kFmtF64 / kFmtQ32
     uint64_t val_base;    // byte offset of this shape's value planes (512 B per F64 plane, 256 B per Q32 plane)
 };
@@ -88,58 +73,12 @@ __host__ __device__ inline uint32_t q32_mantissa(double v, int e) {
 }
 
 __host__ __device__ inline int shape_G(const Shape& S) {  // lanes per read
-#if RSEM_GENERAL_G
-    return S.lg >= 0 ? (1 << S.lg) : -S.lg;
-#else
     return 1 << S.lg;
-#endif
 }
 __host__ __device__ inline uint32_t shape_R(const Shape& S) {  // reads per slice
-#if RSEM_GENERAL_G
-    return S.lg >= 0 ? (64u >> S.lg) : 64u / (uint32_t)(-S.lg);
-#else
     return 64u >> S.lg;
-#endif
 }
 
-#if RSEM_GENERAL_G
-// read length -> shape id, for L = 0..256 (longer: kLongShape).  policy 0: G a power of two (the layout of the default
-// build).  policy 1: the (G, K) of least cost per read, where a slice of K planes costs max(its plane bytes, the byte
-// equivalent of its arithmetic): a slice's instruction stream has a part that does not depend on K (mask, noise term,
-// division, reduction) -- about what 550 B of streaming cost, plus ~100 B per plane, estimated from the SQ counters of
-// DESIGN.md section 4 -- so one-plane shapes with few reads per slice ((5, 1), (7, 1)) lose although they save bytes, while
-// (3, 3) for L = 9, (5, 2) for 10, (7, 2) for 13-14, (9, 2) for 17-18 ... win 10-25 %.  Kept only where it saves >= 3 %
-// over policy 0; ties: power-of-two G first (the cheaper reduction), then more planes.
-inline double shape_cost_per_read(int G, int K) {
-    const double bytes = 512.0 * K, arith = 550.0 + 100.0 * K;
-    return (bytes > arith ? bytes : arith) / (64 / G);
-}
-inline void shape_policy_table(int policy, uint16_t* tab) {
-    for (int L = 0; L <= 256; L++) {
-        int G0 = 1, K0 = L < 1 ? 1 : L;
-        if (L > 4) {
-            int lg = 1, cap = 8;
-            while (L > cap) { cap <<= 1; ++lg; }
-            G0 = 1 << lg;
-            K0 = (L + G0 - 1) / G0;
-        }
-        int G = G0, K = K0;
-        if (policy == 1 && L > 4) {
-            const double c0 = shape_cost_per_read(G0, K0);
-            double best = c0;
-            for (int k = 1; k <= 4; k++) {
-                const int g = (L + k - 1) / k;
-                if (g > 64) continue;
-                const double c = shape_cost_per_read(g, k);
-                const bool p2 = (g & (g - 1)) == 0, bp2 = (G & (G - 1)) == 0;
-                if (c < best - 1e-9 || (c < best + 1e-9 && ((p2 && !bp2) || (p2 == bp2 && k > K)))) { best = c; G = g; K = k; }
-            }
-            if (!(best < 0.97 * c0)) { G = G0; K = K0; }
-        }
-        tab[L] = (uint16_t)((G - 1) * 4 + (K - 1));
-    }
-}
-#endif
 
 __host__ __device__ inline int shape_id_of(uint64_t L) {
     if (L <= 4) return (int)(L == 0 ? 0 : L - 1);  // lg = 0, K = L
@@ -176,9 +115,6 @@ __host__ __device__ inline uint32_t mix32(uint32_t h, uint32_t v) {
 // (q32_scale_of) go to the Q32 twin of their shape.  *err: 1 row_ptr not monotone, 2 sid outside 1..M.
 __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint64_t* __restrict__ row_ptr,
                                                const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits,
-#if RSEM_GENERAL_G
-                                               const uint16_t* __restrict__ shape_of_len,
-#endif
                                                int* err) {
     uint64_t fr = row_ptr[i], to = row_ptr[i + 1];
     if (to < fr) { *err = 1; return 0; }
@@ -197,11 +133,7 @@ __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint
         }
     }
     if (mn > kKeyMinSidCap) mn = kKeyMinSidCap;
-#if RSEM_GENERAL_G
-    int shape = (to - fr) <= 256 ? (int)shape_of_len[to - fr] : kLongShape;
-#else
     int shape = shape_id_of(to - fr);
-#endif
     Q32Scale q;
     if (cp && shape != kLongShape && q32_scale_of(vmx, vmn, range_bits, q)) shape += kShapesPerFmt;
     return ((uint64_t)shape << (64 - kShapeBits)) | ((uint64_t)mn << 32) | h;
@@ -209,17 +141,11 @@ __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint
 
 __global__ void k_row_keys(uint64_t N1, int32_t M, const uint64_t* __restrict__ row_ptr,
                            const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits,
-#if RSEM_GENERAL_G
-                           const uint16_t* __restrict__ shape_of_len,
-#endif
                            uint64_t* keys, uint32_t* vals, int* err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N1) return;
     int e = 0;
     const uint64_t key = row_key_of(i, M, row_ptr, sid, cp, range_bits,
-#if RSEM_GENERAL_G
-                                    shape_of_len,
-#endif
                                     &e);
     if (e) *err = e;
     if (e == 1) return;
@@ -265,11 +191,7 @@ __host__ __device__ inline void sell_fill_row(const Shape& S, uint32_t T, uint32
         if (sexp) sexp[slot] = (int16_t)q.e;
     }
     for (int c = 0; c < L; c++) {
-#if RSEM_GENERAL_G
-        const uint64_t off = (uint64_t)(c / G) * 64 + r * G + (c % G);
-#else
         const uint64_t off = (uint64_t)(c >> S.lg) * 64 + r * G + (c & (G - 1));
-#endif
         if (kIds) ssid[pl0 + off] = sid[fr + c];
         if (cp) {
             if (S.fmt == kFmtQ32) ((uint32_t*)(sval + S.val_base))[pl_local + off] = q32_mantissa(cp[fr + c], q.e);
@@ -308,11 +230,7 @@ __host__ __device__ inline bool slice_lane_changed(const Shape& S, uint32_t T, u
 // the lanes of a read restart together: the bits of `lane`'s read in a 64-lane mask
 __host__ __device__ inline unsigned long long read_lanes_of(const Shape& S, int lane) {
     const int G = shape_G(S);
-#if RSEM_GENERAL_G
-    const int gb = (lane / G) * G;  // (the idle lanes past the last read of the slice form a partial group of their own)
-#else
     const int gb = lane & ~(G - 1);
-#endif
     return (G == 64) ? ~0ull : (((1ull << G) - 1) << gb);
 }
 
@@ -381,8 +299,6 @@ struct SellLayout {
     uint32_t n_slots = 0;
     uint64_t n_planes = 0;
     uint64_t val_bytes = 0;       // value planes of all shapes (Shape::val_base points into them)
-    int g_policy = 0;             // RSEM_GENERAL_G builds: 0 = lanes per read a power of two, 1 = fewest plane bytes (set before sell_build)
-    bool has_general_g = false;   // some shape's G is not a power of two
     uint32_t n_q32_rows = 0;      // sorted rows held in Q32 shapes
     uint64_t n_q32_planes = 0;
     int32_t* d_ssid = nullptr;
@@ -435,20 +351,9 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     RSEM_HIP_TRY(dmalloc(&d_err, 1));
     RSEM_HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), st));
     RSEM_HIP_TRY(hipMemsetAsync(d_first, 0xff, kShapeIds * sizeof(uint32_t), st));
-#if RSEM_GENERAL_G
-    uint16_t h_tab[257];
-    shape_policy_table(L.g_policy, h_tab);
-    uint16_t* d_tab = nullptr;
-    RSEM_HIP_TRY(dmalloc(&d_tab, 257));
-    struct TabFree { uint16_t* p; ~TabFree() { hipFree(p); } } tab_free{d_tab};
-    RSEM_HIP_TRY(hipMemcpyAsync(d_tab, h_tab, sizeof(h_tab), hipMemcpyHostToDevice, st));
-#endif
     if (N1) {
         hipLaunchKernelGGL(k_row_keys, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, M, d_row_ptr, d_sid,
                            d_cp_for_q32, range_bits,
-#if RSEM_GENERAL_G
-                           (const uint16_t*)d_tab,
-#endif
                            d_keys, d_vals, d_err);
         RSEM_HIP_TRY(hipGetLastError());
         size_t tb = 0;
@@ -475,7 +380,6 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     L.val_bytes = 0;
     L.n_q32_rows = 0;
     L.n_q32_planes = 0;
-    L.has_general_g = false;
     uint32_t long_first = (h_first[kLongShape] == 0xffffffffu) ? (uint32_t)N1 : h_first[kLongShape];
     L.n_sell_rows = long_first;
     L.n_long_rows = (uint32_t)N1 - long_first;
@@ -486,17 +390,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
             if (h_first[j] != 0xffffffffu) { next = h_first[j]; break; }
         Shape& S = L.h_shapes[L.n_shapes++];
         S.fmt = id / kShapesPerFmt;
-#if RSEM_GENERAL_G
-        {
-            const int G = (id % kShapesPerFmt) / 4 + 1;
-            int lg = 0;
-            while ((1 << lg) < G) ++lg;
-            S.lg = ((1 << lg) == G) ? lg : -G;
-            if (S.lg < 0) L.has_general_g = true;
-        }
-#else
         S.lg = (id % kShapesPerFmt) / 4;
-#endif
         S.K = id % 4 + 1;
         S.row_base = h_first[id];
         S.n_rows = next - h_first[id];

@@ -20,4 +20,5 @@
 #define RSEM_DPP_MOV(v, ctrl) __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false)
 #define RSEM_LL_AS_DOUBLE(x) __longlong_as_double(x)
 #define RSEM_DOUBLE_AS_LL(x) __double_as_longlong(x)
+#define RSEM_NT_LOAD(p) __builtin_nontemporal_load(p)  /* read-once streams: kept out of the way of theta / counts in L2 and MALL */
 #endif

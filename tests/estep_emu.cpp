@@ -8,7 +8,7 @@
 //   estep_emu in.bin out.bin        in:  i32 M, N1, T, policy, q32 (0/1), range_bits, from_counts (0/1), pad; f64 N0
 //                                        u64 row_ptr[N1+1]; i32 sid[nnz]; f64 cp[nnz]; f64 ncp[N1]; f64 theta[M+1]
 //                                   out: f64 counts[M+1] (without N0), f64 noise total, f64 reads with a non-zero normaliser
-// Build (tests/test_estep_emu_cpu.py): hipcc -DRSEM_EMU [-DRSEM_GENERAL_G=1 -DRSEM_FAST_RCP=1 ...] tests/estep_emu.cpp -lpthread
+// Build (tests/test_estep_emu_cpu.py): hipcc -DRSEM_EMU [-DRSEM_F64_DEPTHS=... -DRSEM_Q32_DEPTHS=...] tests/estep_emu.cpp -lpthread
 #include "simt_emu.hpp"
 
 namespace {

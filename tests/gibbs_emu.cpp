@@ -12,12 +12,6 @@ namespace {
 using rsem::kEpsilon;
 using rsem::Philox;
 using rsem::u53;
-#ifndef RSEM_GIBBS_SCALAR_ADDR
-#define RSEM_GIBBS_SCALAR_ADDR 0
-#endif
-#ifndef RSEM_GIBBS_PHILOX2
-#define RSEM_GIBBS_PHILOX2 0
-#endif
 constexpr int kGWindow = 2048;
 #include "../rsem_amd/csrc/gibbs_block.hpp"
 }  // namespace
@@ -51,12 +45,7 @@ static void lane_body(Job* J, int tid) {
     const double* scp = (const double*)H.sval.data();  // F64 layout: plane p at scp + p * 64
     int noise = 0;
     const double g0 = J->g[0];
-#if RSEM_GIBBS_SCALAR_ADDR
-#define PTAB_ARG J->ptab,
-#else
-#define PTAB_ARG
-#endif
-#define EMU_BLOCK(KK) gibbs_block<KK>(S, T, s_begin, s_end, lane, J->base, J->span, J->g, g0, J->g_win, J->cnt_win, scp, H.ssid.data(), H.sncp.data(), H.masks.data(), PTAB_ARG J->ph, J->sweep, J->counts, noise, J->M)
+#define EMU_BLOCK(KK) gibbs_block<KK>(S, T, s_begin, s_end, lane, J->base, J->span, J->g, g0, J->g_win, J->cnt_win, scp, H.ssid.data(), H.sncp.data(), H.masks.data(), J->ptab, J->ph, J->sweep, J->counts, noise, J->M)
     if (s_begin < u_end) switch (S.K) {
         case 1: EMU_BLOCK(1); break;
         case 2: EMU_BLOCK(2); break;

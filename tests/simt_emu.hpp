@@ -96,6 +96,7 @@ inline long long double_as_ll(double d) { long long x; memcpy(&x, &d, 8); return
 #define RSEM_DPP_MOV(v, ctrl) emu::exchange(v, emu::dpp_src(ctrl))
 #define RSEM_LL_AS_DOUBLE(x) emu::ll_as_double(x)
 #define RSEM_DOUBLE_AS_LL(x) emu::double_as_ll(x)
+#define RSEM_NT_LOAD(p) (*(p))
 
 // ---- the layout, on the host -----------------------------------------------------------------------------------------
 struct HostLayout {
@@ -114,18 +115,10 @@ static void build_layout(HostLayout& H, int M, uint64_t N1, const uint64_t* rp, 
                          int policy, bool q32, int range_bits) {
     // keys: sell_layout.hpp's row_key_of (the body of k_row_keys); sorted rows; shapes (the host loop of sell_build)
     std::vector<std::pair<uint64_t, uint32_t>> keyed(N1);
-#if RSEM_GENERAL_G
-    uint16_t tab[257];
-    shape_policy_table(policy, tab);
-#else
     (void)policy;
-#endif
     for (uint64_t i = 0; i < N1; i++) {
         int err = 0;
         const uint64_t key = row_key_of(i, M, rp, sid, q32 ? cp : nullptr, range_bits,
-#if RSEM_GENERAL_G
-                                        tab,
-#endif
                                         &err);
         if (err) { fprintf(stderr, "simt_emu: bad CSR (%d)\n", err); exit(2); }
         if ((int)(key >> (64 - kShapeBits)) == kLongShape) { fprintf(stderr, "simt_emu: rows with more than 256 alignments are not modelled\n"); exit(2); }
@@ -142,16 +135,7 @@ static void build_layout(HostLayout& H, int M, uint64_t N1, const uint64_t* rp, 
         while (e < N1 && (int)(keyed[e].first >> (64 - kShapeBits)) == id) ++e;
         Shape S{};
         S.fmt = id / kShapesPerFmt;
-#if RSEM_GENERAL_G
-        {
-            const int G = (id % kShapesPerFmt) / 4 + 1;
-            int lg = 0;
-            while ((1 << lg) < G) ++lg;
-            S.lg = ((1 << lg) == G) ? lg : -G;
-        }
-#else
         S.lg = (id % kShapesPerFmt) / 4;
-#endif
         S.K = id % 4 + 1;
         S.row_base = (uint32_t)p;
         S.n_rows = (uint32_t)(e - p);

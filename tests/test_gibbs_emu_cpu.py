@@ -1,9 +1,8 @@
 """The per-wave body of the Gibbs PARALLEL sweep kernel (rsem_amd/csrc/gibbs_block.hpp -- the file gibbs.hip compiles for the
 GPU) run on the CPU by tests/gibbs_emu.cpp (thread per lane, tests/simt_emu.hpp).  z_i | g must pick alignment j of read i
 with probability g_j * conprb_j / (g_0 * ncp_i + sum_k g_k * conprb_k): every sweep assigns every read once, and the picks
-per transcript over a few sweeps sit where the binomial says (z-scores: rms ~1).  The prepared variant with scalar slice
-addressing and the per-slice position table must draw the SAME picks (it only locates the read's random-number key
-differently); the Philox2x32 variant draws different ones from the same distribution.  No GPU involved."""
+per transcript over a few sweeps sit where the binomial says (z-scores: rms ~1).  The candidate build (a read's lanes share
+the work of its next G uniforms; non-temporal value loads) must draw the SAME picks: same keys, same numbers.  No GPU involved."""
 import os
 import shutil
 import subprocess
@@ -17,7 +16,7 @@ import test_estep_emu_cpu as te
 ROOT = te.ROOT
 pytestmark = pytest.mark.skipif(not os.path.exists(te.CC), reason="needs hipcc (host compilation of the HIP headers)")
 
-BUILDS = {"product": [], "scalar_addr": ["-DRSEM_GIBBS_SCALAR_ADDR=1"], "philox2": ["-DRSEM_GIBBS_SCALAR_ADDR=1", "-DRSEM_GIBBS_PHILOX2=1"]}
+BUILDS = {"product": [], "candidates": ["-DRSEM_GIBBS_RNG_SPREAD=1", "-DRSEM_GIBBS_NT=1"]}
 
 
 @pytest.fixture(scope="module")
@@ -66,13 +65,15 @@ def test_sweep_body_distribution_and_variants(emulators):
     var = np.bincount(sid, weights=p * (1 - p), minlength=M + 1)
     exp[0], var[0] = p0.sum(), (p0 * (1 - p0)).sum()
     S = 8
-    res = {name: _run(exe, M, rp, sid, cp, ncp, g, T=4, sweeps=S, seed=5, window=(64 if name == "philox2" else 0)) for name, exe in emulators.items()}
+    res = {name: _run(exe, M, rp, sid, cp, ncp, g, T=4, sweeps=S, seed=5, window=0) for name, exe in emulators.items()}
     for name, c in res.items():
         assert np.all(c.sum(1) == N1), name                      # every read picks exactly one of its items in every sweep
         big = S * var > 5
         z = (c.sum(0) - S * exp)[big] / np.sqrt(S * var[big])
         assert big.sum() > 50 and np.abs(z).max() < 5.0 and 0.7 < np.sqrt((z ** 2).mean()) < 1.3, (name, np.abs(z).max(), np.sqrt((z ** 2).mean()))
         assert np.all(c[:, exp == 0] == 0)                        # nothing lands where no alignment points
-    assert np.array_equal(res["product"], res["scalar_addr"])     # same keys, same draws
-    assert not np.array_equal(res["product"], res["philox2"])
+    assert np.array_equal(res["product"], res["candidates"])      # same keys, same draws
+    small = _run(emulators["candidates"], M, rp, sid, cp, ncp, g, T=3, sweeps=2, seed=5, window=64)  # odd block length, tiny LDS window
+    ref = _run(emulators["product"], M, rp, sid, cp, ncp, g, T=3, sweeps=2, seed=5, window=64)
+    assert np.array_equal(small, ref)
     assert not np.array_equal(res["product"][0], res["product"][1])  # sweeps differ from one another
