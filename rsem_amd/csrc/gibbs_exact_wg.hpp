@@ -19,8 +19,9 @@
 //      induction over the lane index is the sequential chain's state (lane 0 never depends on anybody),
 //   4. commits the moves (counts[z_old]--, counts[z_new]++, z[]), waits for them and passes the token on.
 // Same visiting order, same left-to-right cumulative sums (one lane sums one read), same MT19937 stream as the reference:
-// the integer count vectors are the reference's, bit for bit.  alpha == uniform pseudo count only (the reference has no
-// other; a per-transcript alpha runs on the one-wave kernel k_gibbs_exact_coop).
+// the integer count vectors are the reference's, bit for bit.  Uniform pseudo count only: with --prior (per-transcript
+// pseudo counts, Gibbs.cpp:171-194) a tile would need 8 more bytes of LDS per item; those runs use the one-wave kernel
+// k_gibbs_exact_coop.
 #pragma once
 
 #ifndef GX_EMU
@@ -35,15 +36,22 @@
     } while (0)
 #define GX_BALLOT(p) __ballot(p)
 #define GX_LDS_OR64(p, v) (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define GX_CNT_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define GX_CNT_ADD(p, v) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// candidate for a measurement: a chain's counts are touched by ONE workgroup per launch, so workgroup scope is enough
+#ifndef RSEM_GX_SCOPE
+#define RSEM_GX_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+#define GX_CNT_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, RSEM_GX_SCOPE)
+#define GX_CNT_ADD(p, v) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, RSEM_GX_SCOPE)
 #define GX_TOKEN_LOAD(p) __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define GX_TOKEN_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define GX_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define GX_SLEEP() __builtin_amdgcn_s_sleep(1)
 #endif
 
-constexpr int kXW = 8;         // waves per chain
+#ifndef RSEM_GX_W
+#define RSEM_GX_W 8
+#endif
+constexpr int kXW = RSEM_GX_W;  // waves per chain
 constexpr int kXItems = 896;   // items per tile: 64 reads of 12.4 items (BASELINE configs[2]) = 794 on average
 constexpr int kXSlots = 256;   // hashed transcript ids; slot kXSlots = the noise transcript (id 0: every read carries it)
 

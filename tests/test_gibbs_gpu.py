@@ -98,9 +98,10 @@ def _synthetic_items(n_reads, config="small", long_row_every=0):
 
 @pytest.mark.parametrize("n_reads,long_every", [(200_000, 0), (30_000, 4000)])
 def test_exact_tile_kernel_at_scale_vs_oracle_and_serial_kernel(n_reads, long_every, monkeypatch):
-    """200 k reads x 5000 transcripts, 5 concurrent chains with unequal lengths: the cooperative tile kernel, the
-    previous lane-0 kernel (RSEM_GIBBS_EXACT_IMPL=serial) and the oracle's sequential chain give the same count
-    vectors; the second case carries reads with more items than an LDS tile (walked alone)."""
+    """200 k reads x 5000 transcripts, 5 concurrent chains with unequal lengths: the workgroup-per-chain kernel (the
+    default), the one-wave tile kernel (RSEM_GIBBS_EXACT_IMPL=coop), the lane-0 kernel (=serial) and the oracle's
+    sequential chain give the same count vectors; the second case carries reads with more items than an LDS tile
+    (walked alone)."""
     M, (irp, isid, icp) = _synthetic_items(n_reads, long_row_every=long_every)
     init = np.zeros(M + 1, np.int32)
     N0, pseudoC = 12345, 1.0
@@ -116,16 +117,19 @@ def test_exact_tile_kernel_at_scale_vs_oracle_and_serial_kernel(n_reads, long_ev
     cvs, acc, _, prof = ctx.run_chains(capi().GIBBS_EXACT, seeds, burnin, ns, gap)
     monkeypatch.setenv("RSEM_GIBBS_EXACT_IMPL", "serial")
     cvs_s, acc_s, _, prof_s = ctx.run_chains(capi().GIBBS_EXACT, seeds, burnin, ns, gap)
+    monkeypatch.setenv("RSEM_GIBBS_EXACT_IMPL", "coop")
+    cvs_c, acc_c, _, prof_c = ctx.run_chains(capi().GIBBS_EXACT, seeds, burnin, ns, gap)
     monkeypatch.delenv("RSEM_GIBBS_EXACT_IMPL")
     for k in range(5):
-        assert np.array_equal(cvs[k], cvs_s[k])
-    for a, b in zip(acc, acc_s):
-        assert np.array_equal(a, b)
+        assert np.array_equal(cvs[k], cvs_s[k]) and np.array_equal(cvs[k], cvs_c[k])
+    for a, b, c2 in zip(acc, acc_s, acc_c):
+        assert np.array_equal(a, b) and np.array_equal(a, c2)
     for k in (0, 4):
         ocv, _ = orc.gibbs_chain(M, irp, isid, icp, init, None, pseudoC, totc, N0, eel, mw, grp, seeds[k], burnin, ns[k], gap)
         assert np.array_equal(cvs[k], ocv)
     assert np.all(cvs[0].sum(1) == N0 + n_reads)
-    print("exact sweeps: tile kernel %.3f ms, lane-0 kernel %.3f ms per round (5 chains, %d reads)" % (prof.sweep_ms, prof_s.sweep_ms, n_reads))
+    print("exact sweeps: workgroup kernel %.3f ms, one-wave tile kernel %.3f ms, lane-0 kernel %.3f ms per round (5 chains, %d reads)"
+          % (prof.sweep_ms, prof_c.sweep_ms, prof_s.sweep_ms, n_reads))
     ctx.close()
 
 
