@@ -254,6 +254,7 @@ typedef struct {
     double sweep_ms;   /* total_ms / sweeps */
     int64_t sweeps;    /* EXACT: rounds (every chain advances in each); PARALLEL: z passes summed over the chains */
     int32_t chains;
+    double reduce_ms;  /* the ONE collective of the multi-GPU split (reduce of the chain sums to rank 0), 0 without a communicator */
 } rsem_gibbs_profile;
 
 /* Run nchains independent chains on this GPU -- the reference's worker threads (Gibbs.cpp:207-254): chain k starts

@@ -1251,9 +1251,15 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         hipLaunchKernelGGL(k_sum_chains, dim3(rsem::ceil_div(mt, kBlock)), dim3(kBlock), 0, st, (uint64_t)mt, nchains, (uint64_t)mt,
                            acc_t.as<double>(), o + 4 * nM + m);
     RSEM_HIP_TRY(hipGetLastError());
-    if (rsem::comm_active(c->comm)) {
+    EventPair evr;
+    const bool reduce = rsem::comm_active(c->comm);
+    if (reduce) {
+        RSEM_HIP_TRY(hipEventCreate(&evr.a));
+        RSEM_HIP_TRY(hipEventCreate(&evr.b));
+        RSEM_HIP_TRY(hipEventRecord(evr.a, st));
         int rc = rsem::comm_reduce_sum_f64(c->comm, o, n_out, 0, st);
         if (rc != RSEM_OK) return rc;
+        RSEM_HIP_TRY(hipEventRecord(evr.b, st));
     }
     RSEM_HIP_TRY(hipMemcpyAsync(pme_c, o, sizeof(double) * nM, hipMemcpyDeviceToHost, st));
     RSEM_HIP_TRY(hipMemcpyAsync(pve_c, o + nM, sizeof(double) * nM, hipMemcpyDeviceToHost, st));
@@ -1276,6 +1282,12 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         prof->sweeps = sweeps;
         prof->sweep_ms = sweeps ? ms / (double)sweeps : 0.0;
         prof->chains = nchains;
+        prof->reduce_ms = 0.0;
+        if (reduce) {
+            float rms = 0.f;
+            RSEM_HIP_TRY(hipEventElapsedTime(&rms, evr.a, evr.b));
+            prof->reduce_ms = rms;
+        }
     }
     return RSEM_OK;
 }

@@ -58,7 +58,7 @@ const char* rsem_hip_strerror(int status) {
 
 const char* rsem_hip_last_error(void) { return rsem::g_last_error; }
 
-int rsem_hip_abi_version(void) { return 2; }
+int rsem_hip_abi_version(void) { return 3; }
 
 int rsem_hip_device_count(int* n) {
     if (!n) return RSEM_ERR_INVALID;

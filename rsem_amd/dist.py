@@ -43,3 +43,9 @@ def gibbs_chain_plan(nsamples, world):
     """Gibbs.cpp:215-223: samples per chain."""
     q, left = divmod(nsamples, world)
     return [q + (1 if r < left else 0) for r in range(world)]
+
+
+def gibbs_rank_chains(nchains, world, rank):
+    """Chains are dealt round-robin to the GPUs (rsem-run-gibbs: chain k runs on group k % world, which also writes
+    imdName.countvectors<k>, Gibbs.cpp:225-226,257-262)."""
+    return list(range(rank, nchains, world))

@@ -102,3 +102,78 @@ def test_gibbs_chain_plan():
     assert rd.gibbs_chain_plan(1000, 8) == [125] * 8
     assert rd.gibbs_chain_plan(10, 4) == [3, 3, 2, 2]
     assert sum(rd.gibbs_chain_plan(1001, 8)) == 1001
+
+
+def _gibbs_worker(rank, world, port, fxname, nchains, nsamples, tmp, q):
+    """Rank r runs the chains k = r, r + world, ... (the product's deal), sums their accumulators in chain order, writes
+    their count-vector files; ONE reduce to rank 0 at the end (release(), Gibbs.cpp:372-388)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import pyoracle as orc
+    from rsem_amd import dist as rd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = _gibbs_inputs(fxname)
+    plan = rd.gibbs_chain_plan(nsamples, nchains)
+    seeds = _chain_seeds(orc, 7, nchains)
+    acc = None
+    for k in rd.gibbs_rank_chains(nchains, world, rank):
+        cv, a = orc.gibbs_chain(d["M"], d["rp"], d["sid"], d["val"], d["init"], None, 1.0, d["totc"], d["N0"], d["eel"], d["mw"], d["grp"],
+                                seeds[k], 5, plan[k], 2)
+        np.savetxt(os.path.join(tmp, "s.countvectors%d" % k), cv, fmt="%d")
+        acc = a if acc is None else [x + y for x, y in zip(acc, a)]
+    flat = torch.from_numpy(np.concatenate(acc))
+    dist.reduce(flat, dst=0)
+    if rank == 0:
+        q.put(flat.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _gibbs_inputs(fxname):
+    fx = rf.fixture(fxname)
+    M, N0, rp, sid, val = rf.read_ofg(os.path.join(fx, "temp", "s.ofg"))
+    N1 = len(rp) - 1
+    return dict(M=M, N0=N0, rp=rp, sid=sid, val=val, init=np.zeros(M + 1, np.int32), totc=float((M + 1) + N0 + N1),
+                eel=np.full(M + 1, 300.0), mw=np.ones(M + 1), grp=np.array([1, M + 1], np.int32))
+
+
+def _chain_seeds(orc, seed, n):
+    from rsem_amd import capi
+    return capi.gibbs_chain_seeds(seed, n)
+
+
+def test_gibbs_chain_sharding_gloo(tmp_path):
+    """The split north_star names: independent chains per GPU, one reduce at the end.  world_size 2, 5 chains with unequal
+    numbers of samples: the reduced accumulators and the count-vector files equal the one-process run."""
+    from oracle import pyoracle as orc
+    from rsem_amd import dist as rd
+    world, nchains, nsamples = 2, 5, 13
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gibbs_worker, args=(r, world, port, "se_q", nchains, nsamples, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    d = _gibbs_inputs("se_q")
+    plan = rd.gibbs_chain_plan(nsamples, nchains)
+    assert plan == [3, 3, 3, 2, 2]
+    seeds = _chain_seeds(orc, 7, nchains)
+    assert sorted(k for r in range(world) for k in rd.gibbs_rank_chains(nchains, world, r)) == list(range(nchains))
+    acc = None
+    for k in range(nchains):
+        cv, a = orc.gibbs_chain(d["M"], d["rp"], d["sid"], d["val"], d["init"], None, 1.0, d["totc"], d["N0"], d["eel"], d["mw"], d["grp"],
+                                seeds[k], 5, plan[k], 2)
+        acc = a if acc is None else [x + y for x, y in zip(acc, a)]
+        own = np.loadtxt(os.path.join(str(tmp_path), "s.countvectors%d" % k), dtype=np.int64, ndmin=2)
+        assert np.array_equal(own, cv)  # every chain's file exists exactly once, written by the rank that ran it
+    want = np.concatenate(acc)
+    nM = d["M"] + 1
+    assert np.array_equal(got[:2 * nM], want[:2 * nM])          # counts and squared counts: integers in doubles, exact
+    assert np.allclose(got[2 * nM:], want[2 * nM:], rtol=1e-12, atol=0)  # tpm / fpkm / group sums: summation order differs
+    assert abs(got[:nM].sum() - nsamples * (d["N0"] + len(d["rp"]) - 1)) < 1e-6
