@@ -12,7 +12,9 @@ second = nnz * rounds / wall.  The timed region is repeated (K rounds each time,
 synchronisation on both sides) until at least 0.5 s have been measured, whatever K is; ms_per_step is the mean.
 N > 1: weak scaling -- every rank holds its own config-sized shard of reads over the same transcriptome, theta
 replicated, one RCCL all-reduce of the M+1 fractional counts per round, issued from C++ on the kernel stream
-(rsem_em_set_comm; the communicator id travels through torch.distributed).  Rank 0 prints ONE JSON line.
+(rsem_em_set_comm; the communicator id travels through torch.distributed); the Gibbs leg deals independent chains to the
+ranks and ends in ONE reduce (the split BASELINE.json's north_star names).  `python bench.py --gpus N` without a launcher
+starts its own ranks (torch.distributed.run, 127.0.0.1).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -29,7 +31,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MIN_TIMED_S = 0.5
 WORKLOADS = {"C2R": "configs[1]'s size with NO gene structure (every read hits random transcripts: worst case for tuple re-use and the LDS window)",
              "C2": "BASELINE configs[1] (SingleQModel-shaped)", "C3": "BASELINE configs[2] (PairedEndQModel-shaped, the north-star target config)",
-             "C5": "BASELINE configs[4] (multi-mapping stress)"}
+             "C5": "BASELINE configs[4] (multi-mapping stress: > 2^32 alignments in one context)",
+             "C3X": "configs[2] with cross-gene multi-mappers: 10 % of the reads also hit 1-3 transcripts of another gene (between C3, where no read "
+                    "leaves its gene, and C2R)"}
 
 
 def log(*a):
@@ -63,68 +67,122 @@ def cpu_baseline_port(wl, budget_s=8.0):
 # the reference binary's input: a complete .temp directory, same shape as the bench workload at a stated fraction of
 # its reads (tools/gen_temp.cpp: genes of kmin..kmax overlapping isoforms)
 CPU_SAMPLE = {"C2": dict(read_type=1, frac=0.1, M=50_000, iso="4-12"), "C3": dict(read_type=3, frac=0.05, M=200_000, iso="5-16"),
-              "C5": dict(read_type=1, frac=0.01, M=500_000, iso="32-64")}
+              "C5": dict(read_type=1, frac=0.01, M=500_000, iso="32-64"), "tiny": dict(read_type=1, frac=1.0, M=400, iso="4-12")}
 
 
-def cpu_baseline_reference(config, n_full, timed_s=10.0, limit_s=240.0):
-    """The UNMODIFIED reference binary (oracle/_ref/rsem-run-em, built from /root/reference) on this host's cores, on
-    a generated row-subsample-sized input of the SAME shape as the bench workload (model type, transcripts, isoforms
-    per gene; `frac` of its reads).  Per-round time of the rounds with frozen alignment probabilities (ROUND >= 12,
-    the rounds the GPU line times) from the arrival times of its 'ROUND =' lines (EM.cpp:415); the process is stopped
-    once `timed_s` seconds of such rounds have been seen.  The E step is O(alignments) (EM.cpp:199-236), so the rate
-    in read-alignments/s carries over to the full size; run with -p 64 and with -p <all cores>, best one reported."""
+def _theta_line(path):
+    with open(path) as f:
+        return np.array(f.read().split("\n")[1].split(), float)
+
+
+def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True):
+    """The UNMODIFIED reference binary (oracle/_ref/rsem-run-em, built from /root/reference) and the drop-in
+    (rsem_amd/bin/rsem-run-em) on the SAME generated .temp files of the bench workload's shape (tools/gen_temp.cpp: model
+    type, transcripts, isoforms per gene; `frac` of its reads), each run to convergence, wall clock of the whole program.
+    -> (cpu_baseline, e2e).  cpu_baseline = the reference's rate in the rounds the GPU line times (ROUND >= 12, frozen
+    alignment probabilities; from the arrival times of its 'ROUND =' lines, EM.cpp:415): the E step is O(alignments)
+    (EM.cpp:199-236), so the rate per alignment carries over to the full size.  e2e.measured = both programs' wall clock at
+    that size, ROUND counts and theta compared; e2e.full_size = the drop-in alone on the full-size files (50 M read pairs,
+    30 GB of text) and the reference's time EXTRAPOLATED to them (every phase of EM.cpp is linear in reads / alignments;
+    the ROUND count is the drop-in's: the two programs stop at the same ROUND on the same input, checked at the small size)."""
     import shutil
     import subprocess
     import tempfile
     gen = os.path.join(ROOT, "tools", "bin", "gen_temp")
     ref_em = os.path.join(ROOT, "oracle", "_ref", "rsem-run-em")
     ref_idx = os.path.join(ROOT, "oracle", "_ref", "rsem-build-read-index")
-    if not all(os.path.exists(p) for p in (gen, ref_em, ref_idx)):
-        return None
+    new_em = os.path.join(ROOT, "rsem_amd", "bin", "rsem-run-em")
+    if not all(os.path.exists(p) for p in (gen, ref_em, ref_idx, new_em)):
+        return None, None
     cs = CPU_SAMPLE[config]
     rt = cs["read_type"]
-    n_reads = max(100_000, int(n_full * cs["frac"] / 0.95))  # gen_temp: 95 % of the reads are alignable
+    ncpu = os.cpu_count() or 1
+    cores = min(64, ncpu)  # -p 64 beat -p 256 in every run of rounds 1-2 (13.0 vs 25.4 ms per round, profiles/r02b_bench_default_driver_args.json)
     d = tempfile.mkdtemp(prefix="rsem_bench_", dir="/tmp")
-    try:
+
+    def generate(root, n_reads):
         t0 = time.perf_counter()
-        out = subprocess.run([gen, d, str(n_reads), str(cs["M"]), str(rt), "20250925", "100", "nosam", cs["iso"]],
+        out = subprocess.run([gen, root, str(n_reads), str(cs["M"]), str(rt), "20250925", "100", "nosam", cs["iso"]],
                              stdout=subprocess.PIPE, text=True, check=True).stdout
-        nhits = int(out.split("nHits=")[1].split()[0])
-        n1 = int(out.split("N1=")[1].split()[0])
         reads = ["s_alignable.fq"] if rt == 1 else ["s_alignable_1.fq", "s_alignable_2.fq"]
-        subprocess.run([ref_idx, "32", "1", "1"] + [os.path.join(d, "temp", r) for r in reads], stdout=subprocess.DEVNULL, check=True)
-        gen_s = time.perf_counter() - t0
-        args = [os.path.join(d, "ref"), str(rt), os.path.join(d, "s"), os.path.join(d, "temp", "s"), os.path.join(d, "stat", "s")]
-        ncpu = os.cpu_count() or 1
-        runs = []
-        for cores in sorted({min(64, ncpu), ncpu}):
-            t0 = time.perf_counter()
-            p = subprocess.Popen([ref_em] + args + ["-p", str(cores)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-            late = []
-            for line in p.stdout:
-                now = time.perf_counter()
-                if line.startswith("ROUND ="):
-                    r = int(line.split(",")[0].split("=")[1])
-                    if r >= 12:
-                        late.append((r, now))
-                if (len(late) >= 3 and late[-1][1] - late[0][1] >= timed_s) or now - t0 > limit_s:
-                    break
+        subprocess.run([ref_idx, "32", "1", "1"] + [os.path.join(root, "temp", r) for r in reads], stdout=subprocess.DEVNULL, check=True)
+        return int(out.split("nHits=")[1].split()[0]), int(out.split("N1=")[1].split()[0]), time.perf_counter() - t0
+
+    def em_args(root):
+        return [os.path.join(root, "ref"), str(rt), os.path.join(root, "s"), os.path.join(root, "temp", "s"), os.path.join(root, "stat", "s"), "-p", str(cores)]
+
+    def run_dropin(root):
+        t0 = time.perf_counter()
+        r = subprocess.run([new_em] + em_args(root), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        wall = time.perf_counter() - t0
+        rounds = [int(l.split(",")[0].split("=")[1]) for l in r.stdout.split("\n") if l.startswith("ROUND =")]
+        if r.returncode != 0 or not rounds:
+            raise RuntimeError("drop-in rsem-run-em failed: " + r.stdout[-500:])
+        return wall, rounds[-1], _theta_line(os.path.join(root, "stat", "s.theta"))
+
+    try:
+        small = os.path.join(d, "small")
+        n_reads = max(100_000, int(n_full * cs["frac"] / 0.95))  # gen_temp: 95 % of the reads are alignable
+        nhits, n1, gen_s = generate(small, n_reads)
+        # --- the reference, to convergence (or to the limit: then only its per-round rate is known)
+        t0 = time.perf_counter()
+        p = subprocess.Popen([ref_em] + em_args(small), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        marks = []  # (ROUND, arrival time)
+        finished = False
+        for line in p.stdout:
+            now = time.perf_counter()
+            if line.startswith("ROUND ="):
+                marks.append((int(line.split(",")[0].split("=")[1]), now))
+            if now - t0 > ref_limit_s:
+                break
+        else:
+            finished = True
+        if not finished:
             p.kill()
-            p.wait()
-            if len(late) >= 3:
-                per_round = (late[-1][1] - late[0][1]) / (late[-1][0] - late[0][0])
-                runs.append({"cores": cores, "ms_per_round": per_round * 1e3, "rounds_timed": late[-1][0] - late[0][0],
-                             "value": nhits / per_round, "startup_s": late[0][1] - t0})
-        if not runs:
-            return None
-        best = max(runs, key=lambda r: r["value"])
-        return {"value": best["value"], "unit": "read-alignments/s", "cores": best["cores"], "kind": "reference",
-                "sample": "oracle/_ref/rsem-run-em on a generated %s input of the bench workload's shape at %.0f %% of its reads: %d "
-                          "alignable reads, %d alignments (%.2f/read), %d transcripts; rounds >= 12 timed from its ROUND lines (%d rounds, "
-                          "%.2f ms/round at -p %d); rate per alignment, so it carries over to the full size (E step is O(alignments))"
-                          % ({1: "SingleQModel", 3: "PairedEndQModel"}[rt], cs["frac"] * 100, n1, nhits, nhits / n1, cs["M"],
-                             best["rounds_timed"], best["ms_per_round"], best["cores"]),
-                "runs": runs, "host_cores_available": ncpu, "generate_s": gen_s}
+        p.wait()
+        ref_wall = time.perf_counter() - t0
+        finished = finished and p.returncode == 0
+        late = [m for m in marks if m[0] >= 12]
+        if len(late) < 3:
+            return None, None
+        per_round = (late[-1][1] - late[0][1]) / (late[-1][0] - late[0][0])
+        startup_s = marks[0][1] - t0
+        early_s = late[0][1] - marks[0][1]
+        cpu = {"value": nhits / per_round, "unit": "read-alignments/s", "cores": cores, "kind": "reference",
+               "sample": "oracle/_ref/rsem-run-em -p %d on a generated %s input of the bench workload's shape at %.0f %% of its reads: %d alignable "
+                         "reads, %d alignments (%.2f/read), %d transcripts; rounds >= 12 timed from its ROUND lines (%d rounds, %.2f ms/round); rate "
+                         "per alignment, so it carries over to the full size (E step is O(alignments))"
+                         % (cores, {1: "SingleQModel", 3: "PairedEndQModel"}[rt], cs["frac"] * 100, n1, nhits, nhits / n1, cs["M"],
+                            late[-1][0] - late[0][0], per_round * 1e3),
+               "ms_per_round": per_round * 1e3, "rounds_timed": late[-1][0] - late[0][0], "startup_s": startup_s,
+               "host_cores_available": ncpu, "generate_s": gen_s}
+        e2e = {"what": "whole programs on the same files, wall clock: parse the .temp files, rounds 1-11 with the model, rounds >= 12 to convergence, "
+                       "expected counts, results",
+               "measured": {"size": "%d alignable reads, %d alignments, %d transcripts (%.0f %% of the bench workload's reads)" % (n1, nhits, cs["M"], cs["frac"] * 100),
+                            "reference_s": ref_wall if finished else None, "reference_finished": finished, "reference_rounds": marks[-1][0],
+                            "reference_breakdown_s": {"startup": startup_s, "rounds_1_11": early_s, "rounds_12_on": late[-1][1] - late[0][1]},
+                            "reference_threads": cores}}
+        if finished:
+            ref_theta = _theta_line(os.path.join(small, "stat", "s.theta"))
+            new_wall, new_rounds, new_theta = run_dropin(small)
+            big = ref_theta >= 1e-7
+            e2e["measured"].update({"dropin_s": new_wall, "dropin_rounds": new_rounds, "speedup": ref_wall / new_wall,
+                                    "same_round_count": new_rounds == marks[-1][0],
+                                    "theta_max_rel_diff": float(np.max(np.abs(new_theta - ref_theta)[big] / ref_theta[big])) if big.any() else 0.0})
+        shutil.rmtree(small, ignore_errors=True)
+        if full_size:
+            full = os.path.join(d, "full")
+            fh, f1, fgen_s = generate(full, int(n_full / 0.95))
+            new_wall, new_rounds, new_theta = run_dropin(full)
+            scale = fh / nhits
+            ref_full = scale * (startup_s + early_s) + (new_rounds - 11) * scale * per_round
+            e2e["full_size"] = {"size": "%d alignable reads, %d alignments, %d transcripts" % (f1, fh, cs["M"]), "generate_s": fgen_s,
+                                "dropin_s": new_wall, "dropin_rounds": new_rounds, "theta_sum": float(new_theta.sum()),
+                                "reference_s_extrapolated": ref_full,
+                                "extrapolation": "reference(full) = %.2f x (startup + rounds 1-11 measured above) + (%d - 11) rounds x %.2f x %.2f ms"
+                                                 % (scale, new_rounds, scale, per_round * 1e3),
+                                "speedup_extrapolated": ref_full / new_wall}
+        return cpu, e2e
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -240,18 +298,26 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--legs", default="C2,C2R", help="extra single-GPU E-step legs on other configs (comma list, '' for none; NAME@scale for a fraction of the reads, e.g. C5@0.1)")
+    ap.add_argument("--legs", default="C2,C2R,C3X,C5", help="extra single-GPU E-step legs on other configs (comma list, '' for none; NAME@scale for a fraction of the reads, e.g. C5@0.1)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--no-q32", action="store_true", help="skip the Q32 value-plane measurement beside the headline")
     ap.add_argument("--value-bits", type=int, default=64, choices=(64, 32),
                     help="32: the HEADLINE context itself streams Q32 value planes (profiling runs; the default line stays on the doubles)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference binary (CPU baseline + whole-program wall clock)")
+    ap.add_argument("--no-e2e-full", action="store_true", help="skip the drop-in's full-size whole-program run (30 GB of generated text inputs)")
     ap.add_argument("--no-gibbs", action="store_true")
     ap.add_argument("--no-ci", action="store_true")
     ap.add_argument("--no-stream", action="store_true", help="skip the device STREAM probe beside the roofline")
     ap.add_argument("--gibbs-sweeps", type=int, default=30)
+    ap.add_argument("--gibbs-exact-rounds", type=int, default=3, help="rounds of the exact (reference) chain timed in the Gibbs leg (>= 2)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called without a launcher: start one rank per GPU ourselves (the contract's launch line)
+        port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:])
 
     # stdout carries exactly one JSON line: libraries that print to the C-level stdout (RCCL's version banner) are sent to
     # stderr for the whole run, the line itself goes to the saved descriptor at the end
@@ -267,7 +333,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or under torch.distributed.run "
+                         "with --nproc-per-node equal to --gpus)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: librsem_hip has no CPU path")
     torch.cuda.set_device(local)
@@ -349,9 +416,13 @@ def main():
 
     gibbs = None
     if not args.no_gibbs:
-        # Gibbs on the same matrix, one context per GPU: data-augmentation sweeps (one chain fills the GPU) and the exact
-        # (reference) chain, 8 chains advancing together; across GPUs the chains are independent (one reduce at the end)
+        # Gibbs on the same matrix, one context per GPU.  Chains are independent: global chain k runs on rank k % world
+        # (rsem_amd.dist.gibbs_rank_chains = rsem-run-gibbs's deal), every rank's chain sums meet in ONE reduce to rank 0 at
+        # the end of rsem_gibbs_run_chains (RCCL from C++ on the chain stream; release(), Gibbs.cpp:372-388).  Two samplers:
+        # the data-augmentation sweeps (one chain fills a GPU) and the reference's own chain (8 chains per GPU advancing
+        # together, one workgroup each).
         try:
+            from rsem_amd.dist import gibbs_rank_chains
             irp, isid, icp = to_gibbs_items(wl)
             grp = np.arange(1, M + 2, 50, dtype=np.int32)
             if grp[-1] != M + 1:
@@ -360,20 +431,39 @@ def main():
                                   np.full(M + 1, 1000.0), np.ones(M + 1), grp, device=local)
             if comm is not None:
                 g.set_comm(comm)
-            _, _, _, pp = g.run_chains(capi.GIBBS_PARALLEL, [1 + rank], args.gibbs_sweeps - 2, [2], 1, thin=1, want_vectors=False)
+            par_seeds = capi.gibbs_chain_seeds(1, world)
+            _, _, _, pp = g.run_chains(capi.GIBBS_PARALLEL, [par_seeds[k] for k in gibbs_rank_chains(world, world, rank)],
+                                       args.gibbs_sweeps - 2, [2], 1, thin=1, want_vectors=False)
             n_exact = 8
-            _, _, _, pe = g.run_chains(capi.GIBBS_EXACT, capi.gibbs_chain_seeds(7 + rank, n_exact), 1, [2] * n_exact, 1, want_vectors=False)
+            ex_seeds = capi.gibbs_chain_seeds(7, n_exact * world)
+            _, acc_e, _, pe = g.run_chains(capi.GIBBS_EXACT, [ex_seeds[k] for k in gibbs_rank_chains(n_exact * world, world, rank)],
+                                           args.gibbs_exact_rounds - 1, [2] * n_exact, 1, want_vectors=False)
             g.close()
             b_g = 12 * (len(isid) - N1) + 16 * N1  # conprb + sid per alignment, noise conprb + row slot per read
-            gibbs = {"items_per_chain": int(len(isid)), "gpus": world,
-                     "parallel": {"mode": "data-augmentation sampler, 1 chain per GPU", "ms_per_sweep": pp.sweep_ms,
-                                  "algorithmic_GBps_per_gpu": b_g / pp.sweep_ms / 1e6 if pp.sweep_ms > 0 else None,
-                                  "sweeps_per_s_all_gpus": world * 1e3 / pp.sweep_ms if pp.sweep_ms > 0 else None,
-                                  "items_per_s_all_gpus": world * len(isid) * 1e3 / pp.sweep_ms if pp.sweep_ms > 0 else None},
-                     "exact": {"mode": "reference chain (bit-identical draws), %d chains per GPU advancing together" % n_exact,
-                               "ms_per_round": pe.sweep_ms, "chains_per_gpu": n_exact,
-                               "read_visits_per_s_all_gpus": world * n_exact * N1 * 1e3 / pe.sweep_ms if pe.sweep_ms > 0 else None,
-                               "items_per_s_all_gpus": world * n_exact * len(isid) * 1e3 / pe.sweep_ms if pe.sweep_ms > 0 else None}}
+            per_rank = [[pp.sweep_ms, pp.reduce_ms, pe.sweep_ms, pe.reduce_ms]]
+            if distributed:
+                t = torch.zeros(world, 4, dtype=torch.float64, device=torch.device("cuda", local))
+                t[rank] = torch.tensor(per_rank[0], dtype=torch.float64)
+                dist.all_reduce(t)
+                per_rank = t.cpu().tolist()
+            sw = max(r[0] for r in per_rank)      # the slowest GPU sets the job's rate (all finish before the reduce)
+            ex = max(r[2] for r in per_rank)
+            gibbs = {"items_per_chain": int(len(isid)), "gpus": world, "chains_to_ranks": "chain k on rank k % world, one reduce to rank 0 at the end",
+                     "parallel": {"mode": "data-augmentation sampler, 1 chain per GPU", "ms_per_sweep": sw,
+                                  "ms_per_sweep_per_rank": [r[0] for r in per_rank],
+                                  "algorithmic_GBps_per_gpu": b_g / sw / 1e6 if sw > 0 else None,
+                                  "frac_of_hbm_peak_per_gpu": b_g / sw / 1e6 / HBM_PEAK_GBPS if sw > 0 else None,
+                                  "sweeps_per_s_all_gpus": world * 1e3 / sw if sw > 0 else None,
+                                  "items_per_s_all_gpus": world * len(isid) * 1e3 / sw if sw > 0 else None,
+                                  "final_reduce_ms": max(r[1] for r in per_rank) if distributed else None},
+                     "exact": {"mode": "reference chain (bit-identical draws), %d chains per GPU advancing together, one workgroup of 8 waves per chain" % n_exact,
+                               "ms_per_round": ex, "ms_per_round_per_rank": [r[2] for r in per_rank], "chains_per_gpu": n_exact,
+                               "rounds_timed": args.gibbs_exact_rounds,
+                               "us_per_read_visit_and_chain": ex * 1e3 / N1 if N1 else None,
+                               "read_visits_per_s_all_gpus": world * n_exact * N1 * 1e3 / ex if ex > 0 else None,
+                               "items_per_s_all_gpus": world * n_exact * len(isid) * 1e3 / ex if ex > 0 else None,
+                               "final_reduce_ms": max(r[3] for r in per_rank) if distributed else None,
+                               "sum_of_pme_c_over_samples": float(acc_e[0].sum())}}
         except Exception as e:  # the EM line must still be printed
             gibbs = {"error": str(e)}
 
@@ -446,23 +536,25 @@ def main():
                 line["other_configs"] = legs
             if not args.no_ci:
                 line["credibility_intervals"] = ci_leg(capi, min(M, 50_000))
-            try:  # end-to-end wall clock of the drop-in programs vs the reference on the same files: measured by tools/e2e_c3.sh
-                with open(os.path.join(ROOT, "profiles", "e2e_wall_clock.json")) as f:
-                    line["e2e_wall_clock"] = json.load(f)
-            except Exception:
-                pass
-            if not args.no_cpu_baseline:  # reported baseline: rank 0 at N=1 only
-                cb = None
+            if not args.no_cpu_baseline:  # reported baseline + whole-program wall clock: rank 0 at N=1 only
+                cb, e2e = None, None
                 try:
-                    cb = cpu_baseline_reference(args.config, N1)
+                    cb, e2e = reference_e2e(args.config, N1, full_size=not args.no_e2e_full)
                 except Exception as e:
-                    log("cpu_baseline_reference failed: %s" % e)
+                    log("reference_e2e failed: %s" % e)
                 if cb is None:
                     cb = cpu_baseline_port(wl)
                 else:
                     line["cpu_baseline_port_1core"] = cpu_baseline_port(wl, budget_s=5.0)
                 line["cpu_baseline"] = cb
                 line["speedup_vs_cpu_baseline_rounds"] = line["value"] / cb["value"]
+                if e2e is not None:
+                    line["e2e_wall_clock"] = e2e
+            try:  # an earlier round's builder-run record of the same comparison (tools/e2e_c3.sh), for reference only
+                with open(os.path.join(ROOT, "profiles", "e2e_wall_clock.json")) as f:
+                    line["e2e_wall_clock_recorded_round2"] = json.load(f)
+            except Exception:
+                pass
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if comm is not None:
         barrier()

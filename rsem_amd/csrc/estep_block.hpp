@@ -85,16 +85,10 @@ RSEM_DEVFN double pow2_of(int e) { return RSEM_LL_AS_DOUBLE((long long)(1023 + e
 // counts / sid planes out of L2 and the Infinity Cache; F64 -4 % at C3, -12 % at C2).  Measured and dropped (within +-1 %):
 // reciprocal by Newton steps, clamp fast path, fused multiply-add accumulation, mantissa conversion by an exponent word,
 // ballot-counted normalisers, lane groups that are not a power of two (+5 %: the cheaper planes lost to the dearer
-// lane arithmetic).
-//   RSEM_NT_LEVEL  1: value planes non-temporal (the product).  2 (candidate for the next measurement): also the sid planes,
-//                  the per-read noise / exponent slots and the slice masks -- everything that is read once per launch.
-#ifndef RSEM_NT_LEVEL
-#define RSEM_NT_LEVEL 1
-#endif
+// lane arithmetic); the non-temporal hint on the sid planes, noise / exponent slots and slice masks as well (profiles/
+// r03b_variants.log: F64 at C3 -0.5 %, everything else +3..+8 %: those lines are re-used across neighbouring workgroups).
 template <typename T>
 RSEM_DEVFN T stream_load(const T* p) { return RSEM_NT_LOAD(p); }
-template <typename T>
-RSEM_DEVFN T stream_load2(const T* p) { return RSEM_NT_LEVEL >= 2 ? RSEM_NT_LOAD(p) : *p; }  // the level-2 streams
 template <int kCtrl>
 RSEM_DEVFN double dpp_take(double v) {  // the value of the lane the DPP control selects (all lanes active here)
     const long long b = RSEM_DOUBLE_AS_LL(v);
@@ -129,11 +123,11 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
     const uint32_t R = 64u >> lg;
     // 64 slices' masks at a time, one per lane
     uint32_t m_base = s_begin;
-    unsigned long long mv = (s_begin + lane < s_end) ? stream_load2(&masks[s_begin + lane]) : ~0ull;
+    unsigned long long mv = (s_begin + lane < s_end) ? masks[s_begin + lane] : ~0ull;
     auto mask_of = [&](uint32_t t) -> unsigned long long {
         if (t - m_base >= 64u) {
             m_base = t;
-            mv = (t + lane < s_end) ? stream_load2(&masks[t + lane]) : ~0ull;
+            mv = (t + lane < s_end) ? masks[t + lane] : ~0ull;
         }
         const int src = (int)(t - m_base);
         const uint32_t lo = RSEM_READLANE((int)(uint32_t)mv, src);
@@ -152,13 +146,13 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         if (m != 0ull) {
             const int32_t* __restrict__ ip = ssid + (S.plane_base * 64 + v0);
 #pragma unroll
-            for (int k = 0; k < K; k++) b.id[k] = stream_load2(&ip[k * 64 + ulane]);
+            for (int k = 0; k < K; k++) b.id[k] = ip[k * 64 + ulane];
         }
 #pragma unroll
         for (int k = 0; k < K; k++) b.c[k] = stream_load(&vp[k * 64 + ulane]);
         const uint32_t slot0 = S.slot_base + sl * R;
-        b.nc = g0 ? stream_load2(&(sncp + slot0)[uslot]) : 0.0;
-        b.e = kQ ? (int)stream_load2(&(sexp + slot0)[uslot]) : 0;
+        b.nc = g0 ? (sncp + slot0)[uslot] : 0.0;
+        b.e = kQ ? (int)(sexp + slot0)[uslot] : 0;
     };
     auto spill = [&](const int* rsid, double* acc) {  // lane-private partial counts -> LDS window
 #pragma unroll

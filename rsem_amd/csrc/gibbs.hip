@@ -480,7 +480,7 @@ __global__ __launch_bounds__(64 * kXW) void k_gibbs_exact_wg(uint32_t n_tiles, c
                                                             const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
                                                             const double* __restrict__ cp, int32_t* counts_base, int32_t* z_base,
                                                             double pseudoC, MtState* mt_base, const int32_t* __restrict__ last_round,
-                                                            int round, uint64_t stride_c, uint64_t stride_z) {
+                                                            int round, uint64_t stride_c, uint64_t stride_z, unsigned long long* prof) {
     __shared__ XShared sh;
     __shared__ XWaveLds wl[kXW];
     const int chain = blockIdx.x;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(64 * kXW) void k_gibbs_exact_wg(uint32_t n_tiles, c
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     gibbs_exact_wg_body<kInit>(lane, w, &sh, &wl[w], n_tiles, tile_start, row_ptr, sid, cp, counts_base + (uint64_t)chain * stride_c,
-                               z_base + (uint64_t)chain * stride_z, pseudoC);
+                               z_base + (uint64_t)chain * stride_z, pseudoC, prof);
     __syncthreads();
     for (int i = threadIdx.x; i < 624; i += blockDim.x) mt_state->mt[i] = sh.mt[i];
     if (threadIdx.x == 0) mt_state->idx = sh.idx;
@@ -1162,12 +1162,16 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         DevBuf dbg_buf;
         RSEM_HIP_TRY(dbg_buf.alloc(4 * sizeof(unsigned long long)));
         RSEM_HIP_TRY(hipMemsetAsync(dbg_buf.p, 0, 4 * sizeof(unsigned long long), st));
+        DevBuf prof_buf;  // RSEM_GX_PROFILE builds: the workgroup kernel's phase cycles
+        RSEM_HIP_TRY(prof_buf.alloc(16 * sizeof(unsigned long long)));
+        RSEM_HIP_TRY(hipMemsetAsync(prof_buf.p, 0, 16 * sizeof(unsigned long long), st));
         auto sweep = [&](bool init, int round) {
 #define EXACT_ARGS c->N1, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->d_alpha, c->pseudoC, \
                    mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z
             if (impl == kExactWg) {
 #define EXACT_WG_ARGS c->n_tiles, c->d_tiles, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->pseudoC, \
-                      mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z
+                      mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z, \
+                      ((RSEM_GX_PROFILE && !init) ? prof_buf.as<unsigned long long>() : (unsigned long long*)nullptr)
                 if (init) hipLaunchKernelGGL(k_gibbs_exact_wg<true>, dim3(nchains), dim3(64 * kXW), 0, st, EXACT_WG_ARGS);
                 else hipLaunchKernelGGL(k_gibbs_exact_wg<false>, dim3(nchains), dim3(64 * kXW), 0, st, EXACT_WG_ARGS);
 #undef EXACT_WG_ARGS
@@ -1192,6 +1196,15 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                 int rc = keep_sample((round - burnin - 1) / gap, 0, nchains);
                 if (rc != RSEM_OK) return rc;
             }
+        }
+        if (RSEM_GX_PROFILE && impl == kExactWg) {
+            unsigned long long h[16];
+            RSEM_HIP_TRY(hipMemcpyAsync(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost, st));
+            RSEM_HIP_TRY(hipStreamSynchronize(st));
+            const double tiles = h[7] ? (double)h[7] : 1.0;
+            fprintf(stderr, "[gibbs exact wg] shader-clock cycles per tile: prepare %.0f | wait for token %.0f | rng %.0f | gather %.0f | first draw %.0f | "
+                            "resolve %.0f (%.2f rounds) | commit + pass %.0f ; tiles %.0f\n",
+                    h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[5] / tiles, h[8] / tiles, h[6] / tiles, tiles);
         }
         if (dbg & 4) {
             unsigned long long h4[4] = {0, 0, 0, 0};

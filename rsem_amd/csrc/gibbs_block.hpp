@@ -18,6 +18,19 @@
 #ifndef RSEM_GIBBS_RNG_SPREAD
 #define RSEM_GIBBS_RNG_SPREAD 0
 #endif
+//   RSEM_GIBBS_DPP         the scan over a read's lanes and the two broadcasts with DPP moves (row_shr / quad_perm) instead of
+//                          ds_bpermute wherever a read occupies <= 16 (scan) / <= 4 (broadcasts) lanes: the same values move,
+//                          the picks are bit-identical
+#ifndef RSEM_GIBBS_DPP
+#define RSEM_GIBBS_DPP 0
+#endif
+template <int kCtrl>
+RSEM_DEVFN double gdpp(double v) {  // the value of the lane the DPP control selects (0 where it selects none)
+    const long long b = RSEM_DOUBLE_AS_LL(v);
+    const int lo = RSEM_DPP_MOV((int)(unsigned)b, kCtrl);
+    const int hi = RSEM_DPP_MOV((int)(unsigned)(b >> 32), kCtrl);
+    return RSEM_LL_AS_DOUBLE(((long long)hi << 32) | (unsigned)lo);
+}
 
 // g[base, base+span) -> LDS, count window zeroed; every wave of the workgroup calls this exactly once
 RSEM_DEVFN void stage_gwindows(int base, int span, int M, const double* __restrict__ g, double* g_win, int* cnt_win) {
@@ -130,16 +143,27 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
             part += f[k];
         }
         double incl = part;  // inclusive scan over the G lanes of the read
-        for (int d = 1; d < G; d <<= 1) {
-            double o = RSEM_SHFL_UP(incl, d);
-            if (gl >= d) incl += o;
+        const bool dpp_scan = RSEM_GIBBS_DPP && lg >= 1 && lg <= 4;  // (uniform; row_shr moves within rows of 16 lanes: a read's lanes never straddle one)
+        if (dpp_scan) {
+            double o = gdpp<0x111>(incl);
+            if (gl >= 1) incl += o;
+            if (lg >= 2) { o = gdpp<0x112>(incl); if (gl >= 2) incl += o; }
+            if (lg >= 3) { o = gdpp<0x114>(incl); if (gl >= 4) incl += o; }
+            if (lg >= 4) { o = gdpp<0x118>(incl); if (gl >= 8) incl += o; }
+        } else {
+            for (int d = 1; d < G; d <<= 1) {
+                double o = RSEM_SHFL_UP(incl, d);
+                if (gl >= d) incl += o;
+            }
         }
         // (one lane per read: nothing to exchange -- a uniform branch, lg comes from the unit descriptor)
         double excl = 0.0, total = incl;
         if (lg > 0) {
-            excl = RSEM_SHFL_UP(incl, 1);
+            excl = dpp_scan ? gdpp<0x111>(incl) : RSEM_SHFL_UP(incl, 1);
             if (gl == 0) excl = 0.0;
-            total = RSEM_SHFL(incl, gbase + G - 1);
+            if (RSEM_GIBBS_DPP && lg == 1) total = gdpp<0xF5>(incl);       // quad_perm [1,1,3,3]
+            else if (RSEM_GIBBS_DPP && lg == 2) total = gdpp<0xFF>(incl);  // quad_perm [3,3,3,3]
+            else total = RSEM_SHFL(incl, gbase + G - 1);
         }
         // one uniform per read, keyed by the read's position in the sorted order (layout independent)
         const uint32_t key = ph.k0 ^ ((ph.k1 << 13) | (ph.k1 >> 19)) ^ 0x5a5a5a5au;
@@ -164,7 +188,9 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
             uint32_t rnd[2] = {0, 0};
             if (g0lane) rsem::philox2x32_10(key, p, sweep, rnd);
             u = u53(rnd[0], rnd[1]);
-            if (lg > 0) u = RSEM_SHFL(u, gbase);
+            if (RSEM_GIBBS_DPP && lg == 1) u = gdpp<0xA0>(u);       // quad_perm [0,0,2,2]
+            else if (RSEM_GIBBS_DPP && lg == 2) u = gdpp<0x00>(u);  // quad_perm [0,0,0,0]
+            else if (lg > 0) u = RSEM_SHFL(u, gbase);
         }
         double target = u * total;
         if (target >= total) target = total * (1.0 - 1.1102230246251565e-16);

@@ -7,22 +7,25 @@
 //
 // The chain is sequential from read to read only through `counts`.  Reads are cut into TILES of <= 64 consecutive reads
 // and <= kXItems items (a table built once per context: the cut depends on the row pointers only).  Wave w of the workgroup
-// owns tiles w, w + kXW, ...: it stages its tile's items into its own LDS region at any time (coalesced loads, HBM latency
-// hidden behind the other waves' turns) and then waits for the TOKEN (`next_tile` in LDS).  Holding the token it
+// owns tiles w, w + kXW, ...: at any time it stages its tile's items into its own LDS region (coalesced loads, HBM latency
+// hidden behind the other waves' turns) and prepares everything that does not depend on the counts -- which item is the
+// read's current transcript, per hashed id the lanes whose read carries it (`hold`), per lane the EARLIER lanes that share
+// an id with it (`pred`) -- and then waits for the TOKEN (`next_tile` in LDS).  Holding the token it
 //   1. takes the tile's MT19937 outputs (read r of the tile takes the r-th next output: the sequential order),
 //   2. gathers counts[sid] for the tile's items -- exact: every earlier tile has been committed with device atomics,
 //   3. evaluates all reads of the tile at once, one read per lane, and resolves the dependencies INSIDE the tile by
 //      fixed-point rounds: a lane's draw depends on the moves (z_old -> z_new) of EARLIER lanes that touch one of its
-//      transcripts; every round each lane recomputes the deltas those moves apply to its items (a 64-bit lane mask per
-//      hashed transcript id finds the candidates, zo[] / zn[] decide exactly) and redraws with the SAME random number if a
-//      delta changed; a round in which no draw changes leaves every lane consistent with all earlier lanes, which by
-//      induction over the lane index is the sequential chain's state (lane 0 never depends on anybody),
+//      transcripts; every round the lanes with a moved predecessor (one AND of the moved-lanes ballot with `pred`) recompute
+//      the deltas those moves apply to their items (`hold` finds the candidates, zo[] / zn[] decide exactly) and redraw with
+//      the SAME random number if a delta changed; a round in which no draw changes leaves every lane consistent with all
+//      earlier lanes, which by induction over the lane index is the sequential chain's state (lane 0 depends on nobody),
 //   4. commits the moves (counts[z_old]--, counts[z_new]++, z[]), waits for them and passes the token on.
 // Same visiting order, same left-to-right cumulative sums (one lane sums one read), same MT19937 stream as the reference:
 // the integer count vectors are the reference's, bit for bit.  Uniform pseudo count only: with --prior (per-transcript
 // pseudo counts, Gibbs.cpp:171-194) a tile would need 8 more bytes of LDS per item; those runs use the one-wave kernel
 // k_gibbs_exact_coop.
 #pragma once
+#include <type_traits>
 
 #ifndef GX_EMU
 #define GX_DEVFN __device__ inline
@@ -53,22 +56,37 @@
 #endif
 constexpr int kXW = RSEM_GX_W;  // waves per chain
 constexpr int kXItems = 896;   // items per tile: 64 reads of 12.4 items (BASELINE configs[2]) = 794 on average
-constexpr int kXSlots = 256;   // hashed transcript ids; slot kXSlots = the noise transcript (id 0: every read carries it)
+constexpr int kXSlots = 256;   // hashed transcript ids (the noise transcript, id 0, which every read carries, is kept apart)
+constexpr int kXChunk = 16;    // items of a read handled per step with independent (pipelined) LDS reads
+constexpr int kXPlanes = (kXItems + 63) / 64;
 
-struct XWaveLds {  // one per wave: 18.4 KB, kXW of them + XShared = 150 KB of the CU's 160 KB
+struct XWaveLds {  // one per wave: 19.2 KB, kXW of them + XShared = 156.2 KB of the CU's 163.8 KB
     unsigned long long rp[65];
-    unsigned long long mask[kXSlots + 64];
+    unsigned long long hold[kXSlots];       // per hashed id (not the noise id 0): the lanes whose read carries such an item
     double p[kXItems];
     int32_t sid[kXItems];
-    int32_t c[kXItems];
+    int32_t c[kXItems];        // counts[sid] after every earlier tile, minus 1 where the read itself sits
     int32_t zo[64], zn[64];
-    signed char d[kXItems];
+    signed char own[kXItems];  // 1: this item is its read's current transcript
+    signed char dl[kXItems];   // what the moves of EARLIER reads of the tile add to this item's count
 };
 struct XShared {
     uint32_t mt[624];
     int idx;
     unsigned next_tile;
 };
+
+// Phase profile (variant builds only, -DRSEM_GX_PROFILE=1; the product's kernel reads no timer): shader-clock cycles per
+// wave summed into prof[0..6] = stage + prepare | wait for the token | random numbers | gather | first draw | resolve
+// rounds | commit + wait + pass the token; prof[7] = tiles, prof[8] = resolve rounds
+#ifndef RSEM_GX_PROFILE
+#define RSEM_GX_PROFILE 0
+#endif
+#if RSEM_GX_PROFILE && !defined(GX_EMU)
+#define GX_CLOCK() ((unsigned long long)clock64())
+#else
+#define GX_CLOCK() 0ull
+#endif
 
 GX_DEVFN uint32_t gx_temper(uint32_t y) {
     y ^= (y >> 11);
@@ -94,51 +112,98 @@ GX_DEVFN void gx_mt_regen(uint32_t* mt, int lane) {
     }
 }
 
-GX_DEVFN int gx_slot(int s) { return s == 0 ? kXSlots : (s & (kXSlots - 1)); }
+GX_DEVFN int gx_slot(int s) { return s & (kXSlots - 1); }
 
 // One sweep over all reads in file order (Gibbs.cpp:297-311), or the initial assignment (Gibbs.cpp:281-291) when kInit.
 // Called by every lane of every wave of the chain's workgroup; sh->mt / sh->idx / sh->next_tile (= 0) are set up before.
 template <bool kInit>
 GX_DEVFN void gibbs_exact_wg_body(int lane, int w, XShared* sh, XWaveLds* my, uint32_t n_tiles, const uint32_t* __restrict__ tile_start,
                                   const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid, const double* __restrict__ cp,
-                                  int32_t* counts, int32_t* z, double pseudoC) {
+                                  int32_t* counts, int32_t* z, double pseudoC, unsigned long long* prof) {
+    unsigned long long pa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long below = (1ull << lane) - 1ull;
     for (uint32_t t = (uint32_t)w; t < n_tiles; t += kXW) {
+        unsigned long long tk = GX_CLOCK();
+        auto lap = [&](int i) {
+            if (RSEM_GX_PROFILE) {
+                const unsigned long long n = GX_CLOCK();
+                pa[i] += n - tk;
+                tk = n;
+            }
+        };
         const uint64_t r0 = tile_start[t];
         const int nr = (int)(tile_start[t + 1] - tile_start[t]);  // 1 .. 64
-        // ---- before the token: everything that does not depend on the counts
+        // ---- before the token: everything that does not depend on the counts ------------------------------------------------
         my->rp[lane] = row_ptr[r0 + (uint64_t)(lane < nr ? lane : nr)];
         if (lane == 0) my->rp[64] = row_ptr[r0 + (uint64_t)nr];
         const bool mine = lane < nr;
         int z_old = 0;
         if (!kInit && mine) z_old = z[r0 + lane];
+        if (!kInit) {
+#pragma unroll
+            for (int u = 0; u < kXSlots / 64; u++) my->hold[u * 64 + lane] = 0ull;
+        }
         GX_WAVE_SYNC();
         const uint64_t base = my->rp[0];
         const uint64_t T64 = my->rp[nr] - base;
         const bool long_tile = T64 > (uint64_t)kXItems;  // one read with more items than a tile holds (then nr == 1)
         const uint32_t T = long_tile ? 0u : (uint32_t)T64;
-        for (uint32_t j0 = 0; j0 < T; j0 += 64 * 8) {  // coalesced, eight loads in flight per lane
-            int s8[8];
-            double p8[8];
+        int sj[kXPlanes];  // the tile's ids item-major (item u * 64 + lane): kept in registers for the gather
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t j = j0 + u * 64 + lane;
-                s8[u] = j < T ? sid[base + j] : 0;
-                p8[u] = j < T ? cp[base + j] : 0.0;
+        for (int u0 = 0; u0 < kXPlanes; u0 += 7) {  // coalesced, seven (sid, conprb) pairs in flight per lane
+            double p7[7];
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                const uint32_t j = (uint32_t)(u0 + u) * 64 + lane;
+                sj[u0 + u] = j < T ? sid[base + j] : 0;
+                p7[u] = j < T ? cp[base + j] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t j = j0 + u * 64 + lane;
+            for (int u = 0; u < 7; u++) {
+                const uint32_t j = (uint32_t)(u0 + u) * 64 + lane;
                 if (j < T) {
-                    my->sid[j] = s8[u];
-                    my->p[j] = p8[u];
+                    my->sid[j] = sj[u0 + u];
+                    my->p[j] = p7[u];
+                    if (!kInit) my->dl[j] = 0;
                 }
             }
         }
         const uint32_t fr = mine ? (uint32_t)(my->rp[lane] - base) : 0;
         const int len = (mine && !long_tile) ? (int)(my->rp[lane + 1] - my->rp[lane]) : 0;
         GX_WAVE_SYNC();
-        // ---- the token: tiles commit in file order
+        unsigned long long pred = 0ull;  // the earlier lanes of the tile whose read shares a (hashed) id with this one
+        bool has0 = false;               // the read carries the noise transcript (every read of an .ofg file does)
+        if (!kInit) {
+            // which item is the read's current transcript (Gibbs.cpp:298: the read leaves it before it is weighed), and the
+            // holders of every hashed id
+            for (int k0 = 0; k0 < len; k0 += kXChunk) {
+                int s[kXChunk];
+#pragma unroll
+                for (int j = 0; j < kXChunk; j++) s[j] = (k0 + j < len) ? my->sid[fr + k0 + j] : -1;
+#pragma unroll
+                for (int j = 0; j < kXChunk; j++)
+                    if (k0 + j < len) {
+                        my->own[fr + k0 + j] = (signed char)(s[j] == z_old ? 1 : 0);
+                        if (s[j] != 0) GX_LDS_OR64(&my->hold[gx_slot(s[j])], 1ull << lane);
+                        else has0 = true;
+                    }
+            }
+            GX_WAVE_SYNC();
+            for (int k0 = 0; k0 < len; k0 += kXChunk) {
+                int s[kXChunk];
+#pragma unroll
+                for (int j = 0; j < kXChunk; j++) s[j] = (k0 + j < len) ? my->sid[fr + k0 + j] : -1;
+#pragma unroll
+                for (int j = 0; j < kXChunk; j++)
+                    if (k0 + j < len && s[j] != 0) pred |= my->hold[gx_slot(s[j])];
+            }
+            pred &= below;
+        }
+        GX_WAVE_SYNC();
+        lap(0);
+        // ---- the token: tiles commit in file order ------------------------------------------------------------------------------
         while (GX_TOKEN_LOAD(&sh->next_tile) != t) GX_SLEEP();
+        lap(1);
         int idx = sh->idx;
         GX_WAVE_SYNC();
         uint32_t* mt = sh->mt;
@@ -189,96 +254,129 @@ GX_DEVFN void gibbs_exact_wg_body(int lane, int w, XShared* sh, XWaveLds* my, ui
                     idx += nr;
                 }
             }
+            lap(2);
             if (!kInit) {
-                // counts of the tile's items as they are after every earlier tile
-                for (uint32_t j0 = 0; j0 < T; j0 += 64 * 8) {
-                    int c8[8];
+                // counts of the tile's items as they are after every earlier tile (item-major: neighbouring lanes fetch
+                // neighbouring ids), the read's own unit taken off where it sits
+                int cj[kXPlanes];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const uint32_t j = j0 + u * 64 + lane;
-                        c8[u] = j < T ? GX_CNT_LOAD(&counts[my->sid[j]]) : 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const uint32_t j = j0 + u * 64 + lane;
-                        if (j < T) my->c[j] = c8[u];
-                    }
+                for (int u = 0; u < kXPlanes; u++) {
+                    const uint32_t j = (uint32_t)u * 64 + lane;
+                    cj[u] = j < T ? GX_CNT_LOAD(&counts[sj[u]]) : 0;
                 }
-                // the read leaves its current transcript (Gibbs.cpp:298): delta -1 on that item (own items: no other lane
-                // reads or writes them)
-                for (int k = 0; k < len; k++) my->d[fr + k] = (signed char)(my->sid[fr + k] == z_old ? -1 : 0);
+#pragma unroll
+                for (int u = 0; u < kXPlanes; u++) {
+                    const uint32_t j = (uint32_t)u * 64 + lane;
+                    if (j < T) my->c[j] = cj[u] - (int)my->own[j];
+                }
             }
             GX_WAVE_SYNC();
-            auto weight = [&](uint32_t j) -> double {
-                if (kInit) return my->p[j];
-                return ((double)(my->c[j] + (int)my->d[j]) + pseudoC) * my->p[j];
-            };
+            lap(3);
             // sample() of sampling.h:50-65 on arr[k] = arr[k-1] + weight_k: the index of the first partial sum > prb, which for
             // a non-decreasing array is the number of partial sums <= prb (what the binary search there finds), capped at
             // len-1.  0.0 + a == a and x + 0.0 == x exactly, so the padded positions leave the left-to-right sums bit-identical.
-            constexpr int kChunk = 16;
-            auto draw = [&]() -> int {
-                double part[kChunk];
-                double run = 0.0;
+            // kDelta: the items' counts carry the deltas of earlier reads' moves (a redraw).
+            auto draw = [&](auto with_delta) -> int {
+                constexpr bool kDelta = decltype(with_delta)::value;
+                auto load = [&](int k0, double* a) {  // the weights of items k0 .. k0 + kXChunk - 1 (0.0 past the read's end)
+                    int cc[kXChunk];
+                    double pp[kXChunk];
 #pragma unroll
-                for (int j = 0; j < kChunk; j++) {
-                    const double a = (j < len) ? weight(fr + j) : 0.0;
-                    run += a;
+                    for (int j = 0; j < kXChunk; j++) {
+                        const bool in = k0 + j < len;
+                        pp[j] = in ? my->p[fr + k0 + j] : 0.0;
+                        cc[j] = (in && !kInit) ? my->c[fr + k0 + j] : 0;
+                        if (kDelta && in) cc[j] += (int)my->dl[fr + k0 + j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kXChunk; j++) a[j] = kInit ? pp[j] : ((double)cc[j] + pseudoC) * pp[j];
+                };
+                double part[kXChunk], a[kXChunk];
+                double run = 0.0;
+                load(0, a);
+#pragma unroll
+                for (int j = 0; j < kXChunk; j++) {
+                    run += (j < len) ? a[j] : 0.0;
                     part[j] = run;
                 }
-                for (int k = kChunk; k < len; k++) run += weight(fr + k);
+                for (int k0 = kXChunk; k0 < len; k0 += kXChunk) {
+                    load(k0, a);
+#pragma unroll
+                    for (int j = 0; j < kXChunk; j++) run += (k0 + j < len) ? a[j] : 0.0;
+                }
                 const double prb = ((double)rnd * (1.0 / 4294967296.0)) * run;
                 int cnt = 0;
 #pragma unroll
-                for (int j = 0; j < kChunk; j++) cnt += (j < len && part[j] <= prb) ? 1 : 0;
-                if (len > kChunk) {
-                    double r2 = part[kChunk - 1];
-                    for (int k = kChunk; k < len; k++) {
-                        r2 += weight(fr + k);
-                        cnt += (r2 <= prb) ? 1 : 0;
+                for (int j = 0; j < kXChunk; j++) cnt += (j < len && part[j] <= prb) ? 1 : 0;
+                double r2 = part[kXChunk - 1];
+                for (int k0 = kXChunk; k0 < len; k0 += kXChunk) {
+                    load(k0, a);
+#pragma unroll
+                    for (int j = 0; j < kXChunk; j++) {
+                        r2 += (k0 + j < len) ? a[j] : 0.0;
+                        cnt += (k0 + j < len && r2 <= prb) ? 1 : 0;
                     }
                 }
                 const int l = cnt < len ? cnt : len - 1;
                 return my->sid[fr + l];
             };
-            int z_new = mine ? draw() : z_old;
+            int z_new = mine ? draw(std::false_type{}) : z_old;
+            lap(4);
             if (!kInit) {
-                const unsigned long long below = (1ull << lane) - 1ull;
-                for (;;) {
-                    const bool moved = mine && z_new != z_old;
-                    if (GX_BALLOT(moved) == 0ull) break;  // nobody moves: nothing to resolve, nothing to commit
+                unsigned long long mm = GX_BALLOT(mine && z_new != z_old);  // the lanes whose read moves
+                bool hasd = false;                                          // some dl of this lane's items is not zero
+                while (mm != 0ull) {
+                    // only a lane with a moved predecessor (or with deltas left from a predecessor that moved back) has work;
+                    // the noise transcript is everybody's: moves to or from it concern every later read that carries it
+                    const unsigned long long nmov = GX_BALLOT(mine && z_new != z_old && (z_old == 0 || z_new == 0));
+                    const bool affected = mine && (((mm & pred) != 0ull) || (has0 && (nmov & below) != 0ull) || hasd);
+                    if (GX_BALLOT(affected) == 0ull) break;
+                    if (RSEM_GX_PROFILE) pa[8] += 1;
                     my->zo[lane] = z_old;
-                    my->zn[lane] = z_new;  // (lanes that did not move: zn == zo, they contribute nothing below)
-#pragma unroll
-                    for (int u = 0; u < (kXSlots + 64) / 64; u++) my->mask[u * 64 + lane] = 0ull;
-                    GX_WAVE_SYNC();
-                    if (moved) {
-                        GX_LDS_OR64(&my->mask[gx_slot(z_old)], 1ull << lane);
-                        GX_LDS_OR64(&my->mask[gx_slot(z_new)], 1ull << lane);
-                    }
+                    my->zn[lane] = z_new;
                     GX_WAVE_SYNC();
                     bool dirty = false;
-                    for (int k = 0; k < len; k++) {
-                        const int s = my->sid[fr + k];
-                        unsigned long long m = my->mask[gx_slot(s)] & below;
-                        int dd = (s == z_old) ? -1 : 0;
-                        while (m) {
-                            const int r1 = __builtin_ctzll(m);
-                            m &= m - 1ull;
-                            dd += (my->zn[r1] == s ? 1 : 0) - (my->zo[r1] == s ? 1 : 0);
+                    if (affected) {
+                        bool nz = false;
+                        for (int k0 = 0; k0 < len; k0 += kXChunk) {
+                            int s[kXChunk], od[kXChunk];
+                            unsigned long long cand[kXChunk];
+#pragma unroll
+                            for (int j = 0; j < kXChunk; j++) {
+                                const bool in = k0 + j < len;
+                                s[j] = in ? my->sid[fr + k0 + j] : -1;
+                                od[j] = in ? (int)my->dl[fr + k0 + j] : 0;
+                            }
+#pragma unroll
+                            for (int j = 0; j < kXChunk; j++)
+                                cand[j] = (k0 + j >= len) ? 0ull : (s[j] == 0 ? (nmov & below) : (my->hold[gx_slot(s[j])] & mm & below));
+#pragma unroll
+                            for (int j = 0; j < kXChunk; j++) {
+                                int dd = 0;
+                                unsigned long long m = cand[j];
+                                while (m) {  // (rare: an earlier lane that moved AND carries this hashed id)
+                                    const int r1 = __builtin_ctzll(m);
+                                    m &= m - 1ull;
+                                    dd += (my->zn[r1] == s[j] ? 1 : 0) - (my->zo[r1] == s[j] ? 1 : 0);
+                                }
+                                if (dd != od[j]) {
+                                    my->dl[fr + k0 + j] = (signed char)dd;
+                                    dirty = true;
+                                }
+                                nz = nz || dd != 0;
+                            }
                         }
-                        if (dd != (int)my->d[fr + k]) {
-                            my->d[fr + k] = (signed char)dd;
-                            dirty = true;
-                        }
+                        hasd = nz;
                     }
                     int z2 = z_new;
-                    if (dirty) z2 = draw();
+                    if (dirty) z2 = draw(std::true_type{});
                     const bool changed = mine && z2 != z_new;
                     z_new = z2;
                     if (GX_BALLOT(changed) == 0ull) break;  // every lane is consistent with all earlier lanes
-                    GX_WAVE_SYNC();  // (zo / zn / mask are rewritten)
+                    mm = GX_BALLOT(mine && z_new != z_old);
+                    GX_WAVE_SYNC();  // (zo / zn are rewritten)
                 }
+                lap(5);
                 if (mine && z_new != z_old) {
                     GX_CNT_ADD(&counts[z_old], -1);
                     GX_CNT_ADD(&counts[z_new], 1);
@@ -294,5 +392,14 @@ GX_DEVFN void gibbs_exact_wg_body(int lane, int w, XShared* sh, XWaveLds* my, ui
         GX_WAIT_VM();  // this tile's count updates are performed before the next tile gathers
         GX_WAVE_SYNC();
         if (lane == 0) GX_TOKEN_STORE(&sh->next_tile, t + 1);
+        lap(6);
+        if (RSEM_GX_PROFILE) pa[7] += 1;
     }
+#if RSEM_GX_PROFILE && !defined(GX_EMU)
+    if (prof && lane == 0)
+        for (int i = 0; i < 9; i++) (void)__hip_atomic_fetch_add(&prof[i], pa[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    (void)prof;
+    (void)pa;
+#endif
 }

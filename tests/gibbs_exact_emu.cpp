@@ -120,9 +120,9 @@ int main(int argc, char** argv) {
             if (tid == 0) mc.sh.next_tile = 0u;
             pthread_barrier_wait(&mc.block_bar);
             if (round == 0)
-                gibbs_exact_wg_body<true>(lane, w, &mc.sh, &mc.wl[w], n_tiles, tiles.data(), rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC);
+                gibbs_exact_wg_body<true>(lane, w, &mc.sh, &mc.wl[w], n_tiles, tiles.data(), rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, nullptr);
             else
-                gibbs_exact_wg_body<false>(lane, w, &mc.sh, &mc.wl[w], n_tiles, tiles.data(), rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC);
+                gibbs_exact_wg_body<false>(lane, w, &mc.sh, &mc.wl[w], n_tiles, tiles.data(), rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, nullptr);
             pthread_barrier_wait(&mc.block_bar);
             if (tid == 0 && round >= 1) memcpy(&out[(size_t)(round - 1) * (M + 1)], counts.data(), sizeof(int32_t) * (M + 1));
             pthread_barrier_wait(&mc.block_bar);

@@ -56,6 +56,8 @@ inline unsigned long long ballot(bool p) {
 inline int dpp_src(int ctrl) {
     const int l = lane();
     static const int p1[4] = {1, 0, 3, 2}, p2[4] = {2, 3, 0, 1};
+    if (ctrl >= 0 && ctrl < 0x100) return (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);  // quad_perm
+    if (ctrl > 0x110 && ctrl < 0x120) return ((l & 15) >= (ctrl & 15)) ? l - (ctrl & 15) : -1;  // row_shr (no source: own value here, 0 on the GPU; callers mask it)
     switch (ctrl) {
         case 0xB1: return (l & ~3) | p1[l & 3];
         case 0x4E: return (l & ~3) | p2[l & 3];

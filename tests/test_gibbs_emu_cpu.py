@@ -16,7 +16,7 @@ import test_estep_emu_cpu as te
 ROOT = te.ROOT
 pytestmark = pytest.mark.skipif(not os.path.exists(te.CC), reason="needs hipcc (host compilation of the HIP headers)")
 
-BUILDS = {"product": [], "candidates": ["-DRSEM_GIBBS_RNG_SPREAD=1", "-DRSEM_GIBBS_NT=1"]}
+BUILDS = {"product": [], "candidates": ["-DRSEM_GIBBS_RNG_SPREAD=1", "-DRSEM_GIBBS_NT=1", "-DRSEM_GIBBS_DPP=1"]}
 
 
 @pytest.fixture(scope="module")

@@ -91,3 +91,17 @@ def test_workgroup_chain_is_the_reference_chain(emulator, case):
     want = _oracle(c["M"], rp, sid, cp, init, c["rounds"], 1000 + c["seed"], c["N0"], c["pseudoC"])
     assert got.sum(1).tolist() == [c["N0"] + c["N1"]] * c["rounds"]
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 4, 5, 6])
+def test_a_predecessor_that_moves_back(emulator, seed):
+    """Three reads A {1,2}, B {2,3}, C {3,4} in one tile, counts of 0 / 1 so that one unit flips draws: B's speculative move
+    is undone by A's move while C has already taken B's move into account -- C must drop that delta although none of ITS
+    predecessors moves any more.  (With that rule removed from the kernel body these seeds give wrong chains.)"""
+    M = 4
+    rp = np.array([0, 3, 6, 9], np.uint64)
+    sid = np.array([0, 1, 2, 0, 2, 3, 0, 3, 4], np.int32)
+    cp = np.array([1e-9, 1.0, 1.0, 1e-9, 1.0, 1.0, 1e-9, 1.0, 1.0])
+    init = np.zeros(M + 1, np.int32)
+    got = _run(emulator, M, rp, sid, cp, init, 40, seed, 0, 0.05)
+    assert np.array_equal(got, _oracle(M, rp, sid, cp, init, 40, seed, 0, 0.05))

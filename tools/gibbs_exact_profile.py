@@ -35,4 +35,4 @@ impls = (sys.argv[5] if len(sys.argv) > 5 else "wg,coop").split(",")
 for impl in impls:
     env = dict(os.environ, RSEM_GIBBS_EXACT_IMPL=impl)
     r = subprocess.run([sys.executable, __file__, scale, chains, rounds, config, impl, "child"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    print("%-7s %s" % (impl, r.stdout.strip().split("\n")[-1] if r.stdout.strip() else "(no output) " + r.stderr[-400:]))
+    print("%-7s %s %s" % (impl, r.stdout.strip().split("\n")[-1] if r.stdout.strip() else "(no output) " + r.stderr[-400:], " | ".join(l for l in r.stderr.split("\n") if "gibbs exact" in l)))

@@ -34,5 +34,5 @@ print("create %.2f s" % (time.time() - t0))
 cv, acc, ms = g.run(capi.GIBBS_PARALLEL, 1, sweeps - 2, 2, 1, thin=1, want_vectors=False)
 nitems = len(isid)
 bytes_sweep = 12 * (nitems - N1) + 16 * N1  # conprb + sid per alignment, noise conprb + (unused) row pointer per read
-print("N1=%d items=%d: %.3f ms/sweep, %.1f G items/s, algorithmic %.2f GB/sweep -> %.2f TB/s" % (
-    N1, nitems, ms, nitems / ms / 1e6, bytes_sweep / 1e9, bytes_sweep / ms / 1e9))
+print("N1=%d items=%d: %.3f ms/sweep, %.1f G items/s, algorithmic %.2f GB/sweep -> %.2f TB/s, checksum %.3f" % (
+    N1, nitems, ms, nitems / ms / 1e6, bytes_sweep / 1e9, bytes_sweep / ms / 1e9, float(np.dot(acc[0], np.arange(M + 1) % 97))))

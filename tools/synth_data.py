@@ -30,6 +30,54 @@ CONFIGS = {
 _ARRAYS = ("row_ptr", "sid", "conprb", "ncp", "theta0")
 
 
+# configs built by the threaded C++ generator (tools/gen_workload.cpp -> tools/bin/libgenwl.so): name: (N1, M, mean alignments
+# per read, gene size range, fraction of reads that also hit 1..3 transcripts of ANOTHER gene)
+FAST_CONFIGS = {
+    "C5": (100_000_000, 500_000, 40.0, (32, 64), 0.0),
+    # configs[2] with cross-gene multi-mappers (paralogs): between C3 (no read leaves its gene) and C2R (no genes at all)
+    "C3X": (50_000_000, 200_000, 10.0, (8, 24), 0.10),
+    "tinyX": (20_000, 400, 5.0, (4, 12), 0.25),
+}
+_genwl = None
+
+
+def _genwl_lib():
+    global _genwl
+    if _genwl is None:
+        import ctypes as C
+        here = os.path.dirname(os.path.abspath(__file__))
+        so, src = os.path.join(here, "bin", "libgenwl.so"), os.path.join(here, "gen_workload.cpp")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            import subprocess
+            os.makedirs(os.path.dirname(so), exist_ok=True)
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", so, src])
+        L = C.CDLL(so)
+        L.wl_plan.restype = C.c_void_p
+        L.wl_plan.argtypes = [C.c_int64, C.c_int32, C.c_double, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)]
+        L.wl_fill.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.wl_free.argtypes = [C.c_void_p]
+        _genwl = L
+    return _genwl
+
+
+def _make_fast(config, seed, scale, shard):
+    import ctypes as C
+    N1, M, mean_hits, (kmin, kmax), cross = FAST_CONFIGS[config]
+    N1 = max(1, int(N1 * scale))
+    L = _genwl_lib()
+    nnz = C.c_uint64(0)
+    h = L.wl_plan(N1, M, mean_hits, kmin, kmax, cross, seed, shard, 0, C.byref(nnz))
+    if not h:
+        raise ValueError("gen_workload: bad parameters")
+    row_ptr, sid = np.empty(N1 + 1, np.uint64), np.empty(nnz.value, np.int32)
+    conprb, ncp = np.empty(nnz.value, np.float64), np.empty(N1, np.float64)
+    L.wl_fill(h, row_ptr.ctypes.data, sid.ctypes.data, conprb.ctypes.data, ncp.ctypes.data)
+    L.wl_free(h)
+    theta0 = np.full(M + 1, (1.0 - 0.05) / M)
+    theta0[0] = 0.05
+    return dict(M=M, N0=int(round(0.05 * N1 / 0.95)), row_ptr=row_ptr, sid=sid, conprb=conprb, ncp=ncp, theta0=theta0, config=config, seed=seed)
+
+
 def make_em_workload(config="C2", seed=20250925, scale=1.0, long_row_every=0, shard=0):
     """Returns dict(M, N0, row_ptr u64, sid i32, conprb f64, ncp f64, theta0 f64).
     `shard` re-draws the reads (not the transcriptome): shard r of a weak-scaling job.
@@ -62,6 +110,8 @@ def make_em_workload(config="C2", seed=20250925, scale=1.0, long_row_every=0, sh
 
 
 def _make_em_workload(config, seed, scale, long_row_every, shard):
+    if config in FAST_CONFIGS:
+        return _make_fast(config, seed, scale, shard)
     N1, M, mean_hits, ksz = CONFIGS[config]
     N1 = max(1, int(N1 * scale))
     rng = np.random.default_rng(seed)
