@@ -263,9 +263,27 @@ def q32_leg(ctx, wl, N0, K, W, sync, alg_bytes, f64_ms_per_step, f64_estep_ms, t
         return {"error": str(e)}
 
 
+def one_step_parity(ctx, wl):
+    """One E + M step of the context against the CPU restatement (oracle/, EM.cpp:199-236,391-398) on the WHOLE matrix --
+    the checker beside the measurement, not part of it (for configs[4] this is also the > 2^32-alignments index check:
+    the oracle walks 4 G alignments in a few seconds)."""
+    try:
+        from oracle import pyoracle as orc
+        t0 = time.perf_counter()
+        counts, *_ = ctx.step(wl["theta0"], wl["N0"])
+        oc = orc.em_estep(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["theta0"])
+        oc[0] += wl["N0"]
+        denom = np.maximum(np.abs(oc), 1e-6)
+        err = float(np.max(np.abs(counts - oc) / denom))
+        return {"max_rel_diff_counts_vs_oracle": err, "ok": bool(err < 1e-9), "tolerance": 1e-9, "alignments_checked": int(len(wl["sid"])),
+                "seconds": time.perf_counter() - t0}
+    except Exception as e:
+        return {"error": str(e)}
+
+
 def em_leg(capi, make_em_workload, config, K, W, kernel, sync, device, q32=False):
     """One extra single-GPU E-step measurement on another BASELINE config (same procedure as the headline).
-    "C5@0.1" = configs[4] at a tenth of its reads (the full size takes minutes to generate with numpy)."""
+    "C5@0.1" = configs[4] at a tenth of its reads."""
     try:
         t0 = time.perf_counter()
         scale = 1.0
@@ -283,7 +301,7 @@ def em_leg(capi, make_em_workload, config, K, W, kernel, sync, device, q32=False
         out = {"workload": "%s%s: %d reads x %d transcripts, %d alignments" % (WORKLOADS.get(config, config), "" if scale == 1.0 else " at %g of its reads" % scale, N1, M, nnz),
                "ms_per_step": el * 1e3 / rounds, "timed_rounds": rounds, "timed_region_s": el, "value": nnz * rounds / el,
                "estep_avg_launch_ms": estep_ms, "algorithmic_bytes_per_launch": alg, "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS,
-               "theta_sum": ts, "generate_s": gen_s}
+               "theta_sum": ts, "generate_s": gen_s, "parity_one_step": one_step_parity(ctx, wl)}
         if q32 and kernel in (0, 3):
             out["q32_value_planes"] = q32_leg(ctx, wl, wl["N0"], K, W, sync, alg, el * 1e3 / rounds, estep_ms)
         ctx.close()
@@ -467,6 +485,7 @@ def main():
         except Exception as e:  # the EM line must still be printed
             gibbs = {"error": str(e)}
 
+    parity = one_step_parity(ctx, wl) if (rank == 0 and world == 1) else None
     value_plane_bytes = ctx.info("value_plane_bytes")
     q32 = None
     if world == 1 and not distributed and not args.no_q32 and args.value_bits == 64 and args.kernel in (0, 3):
@@ -520,7 +539,7 @@ def main():
                          "achieved_over_stream_read": (achieved / stream["read_GBps"]) if stream and stream.get("read_GBps") else None,
                          "traffic_rate_over_stream_read": (traffic / (estep_ms * 1e-3) / 1e9 / stream["read_GBps"])
                          if traffic and stream and stream.get("read_GBps") else None},
-            "checks": {"theta_sum": theta_sum},
+            "checks": {"theta_sum": theta_sum, "parity_one_step": parity},
             "upload_and_layout_s": upload_s,
             "gibbs": gibbs,
         }

@@ -57,6 +57,10 @@ __global__ void k_fill_double(int32_t n, double v, double* g) {
     if (i < n) g[i] = v;
 }
 
+// waves per SIMD the sweep kernel is compiled for (its register budget): 4 = what it needs unconstrained (100 VGPRs)
+#ifndef RSEM_GIBBS_MIN_WAVES
+#define RSEM_GIBBS_MIN_WAVES 4
+#endif
 constexpr int kGWindow = 2048;  // sids per workgroup window (g values: 16 KB, int counts: 8 KB of LDS)
 
 // the per-wave body of the sweep kernel (also run on the CPU by tests/gibbs_emu.cpp)
@@ -70,7 +74,7 @@ __global__ void k_slice_ptab(const Shape* __restrict__ shapes, int n_shapes, uin
     ptab[s] = slice_ptab_entry(shapes[sh], T, s - shapes[sh].slice_base);
 }
 
-__global__ __launch_bounds__(kBlock) void k_sample_z_lane(
+__global__ __launch_bounds__(kBlock, RSEM_GIBBS_MIN_WAVES) void k_sample_z_lane(
     const Shape* __restrict__ shapes, const Unit* __restrict__ units, uint32_t T, int M,
     const double* __restrict__ g, const double* __restrict__ scp, const int32_t* __restrict__ ssid,
     const double* __restrict__ sncp, const unsigned long long* __restrict__ masks, Philox ph, uint32_t sweep,
@@ -756,7 +760,7 @@ struct rsem_gibbs_ctx {
     uint64_t* d_irp = nullptr;
     int32_t* d_isid = nullptr;
     double* d_icp = nullptr;
-    uint32_t* d_tiles = nullptr;  // k_gibbs_exact_wg: first read of every tile (+ N1), build_exact_tiles
+    uint32_t* d_tiles = nullptr;  // k_gibbs_exact_wg: first read of every tile (+ N1), gx_build_tiles
     uint32_t n_tiles = 0;
     // PARALLEL mode, built on the device at its first use: noise split out + the sliced layout
     bool have_parallel = false;
@@ -915,23 +919,6 @@ ExactImpl exact_impl_requested(bool have_alpha) {
     return have_alpha ? kExactCoop : kExactWg;  // a per-transcript alpha (not in the reference) runs on the one-wave kernel
 }
 
-// Tiles of the workgroup kernel: greedy cut of the reads into runs of <= 64 reads and <= kXItems items; a read with more
-// items than that is a tile of its own (walked over global memory).  Depends on the row pointers only.
-void build_exact_tiles(uint64_t N1, const uint64_t* row_ptr, std::vector<uint32_t>& tiles) {
-    tiles.clear();
-    tiles.reserve(N1 / 48 + 2);
-    uint64_t i = 0;
-    while (i < N1) {
-        tiles.push_back((uint32_t)i);
-        const uint64_t b = row_ptr[i];
-        uint64_t e = i + 1;  // the first read always belongs to the tile
-        while (e < N1 && e - i < 64 && row_ptr[e + 1] - b <= (uint64_t)kXItems) ++e;
-        if (row_ptr[i + 1] - b > (uint64_t)kXItems) e = i + 1;
-        i = e;
-    }
-    tiles.push_back((uint32_t)N1);
-}
-
 }  // namespace
 
 extern "C" {
@@ -1052,7 +1039,7 @@ int rsem_gibbs_create(rsem_gibbs_ctx** out, int device, int32_t M, uint64_t N1, 
             rsem_gibbs_destroy(c);
             return RSEM_ERR_INVALID;
         }
-    build_exact_tiles(N1, row_ptr, tiles);
+    gx_build_tiles(N1, row_ptr, tiles);
     c->n_tiles = (uint32_t)tiles.size() - 1;
     G_TRY(dmalloc(&c->d_tiles, tiles.size()));
     G_TRY(hipMemcpyAsync(c->d_tiles, tiles.data(), sizeof(uint32_t) * tiles.size(), hipMemcpyHostToDevice, st));

@@ -5,33 +5,11 @@
 #pragma once
 #include "simt_macros.hpp"
 
-// Measured in round 3 and adopted (profiles/r03a_variants_and_steps.log: 1.538 -> 1.396 ms per sweep at C3): scalar slice
-// addressing with a per-slice table of sorted positions (no divisions by T and R in every slice), the read's uniform from
-// Philox2x32-10 (64 bits per call) instead of Philox4x32-10.  Candidates for the next measurement:
-//   RSEM_GIBBS_NT          the value planes (read once per sweep) with the non-temporal hint, as in the E step
-//   RSEM_GIBBS_RNG_SPREAD  a read that occupies G lanes computes ONE uniform per slice in its first lane while the other
-//                          G - 1 lanes wait: instead lane j of the read computes the uniform of slice s + j once every G
-//                          slices and each slice fetches its own with one cross-lane move (same keys, same numbers)
-#ifndef RSEM_GIBBS_NT
-#define RSEM_GIBBS_NT 0
-#endif
-#ifndef RSEM_GIBBS_RNG_SPREAD
-#define RSEM_GIBBS_RNG_SPREAD 0
-#endif
-//   RSEM_GIBBS_DPP         the scan over a read's lanes and the two broadcasts with DPP moves (row_shr / quad_perm) instead of
-//                          ds_bpermute wherever a read occupies <= 16 (scan) / <= 4 (broadcasts) lanes: the same values move,
-//                          the picks are bit-identical
-#ifndef RSEM_GIBBS_DPP
-#define RSEM_GIBBS_DPP 0
-#endif
-template <int kCtrl>
-RSEM_DEVFN double gdpp(double v) {  // the value of the lane the DPP control selects (0 where it selects none)
-    const long long b = RSEM_DOUBLE_AS_LL(v);
-    const int lo = RSEM_DPP_MOV((int)(unsigned)b, kCtrl);
-    const int hi = RSEM_DPP_MOV((int)(unsigned)(b >> 32), kCtrl);
-    return RSEM_LL_AS_DOUBLE(((long long)hi << 32) | (unsigned)lo);
-}
-
+// Measured in round 3 and adopted (profiles/r03a_variants_and_steps.log, r03b_variants.log, r03c_exact_and_sweep.log:
+// 1.538 -> 1.35 ms per sweep at C3): scalar slice addressing with a per-slice table of sorted positions (no divisions by T
+// and R in every slice), the read's uniform from Philox2x32-10 (64 bits per call) instead of Philox4x32-10, the non-temporal
+// hint on the value planes.  Measured and dropped (within the +-3 % run-to-run noise of this kernel, identical picks): the
+// scan over a read's lanes with DPP moves, the read's lanes sharing the work of its next G uniforms.
 // g[base, base+span) -> LDS, count window zeroed; every wave of the workgroup calls this exactly once
 RSEM_DEVFN void stage_gwindows(int base, int span, int M, const double* __restrict__ g, double* g_win, int* cnt_win) {
     for (int i = RSEM_TIDX; i < span; i += RSEM_BDIM) {
@@ -51,7 +29,7 @@ struct SliceRegs {
 
 // per slice: the sorted position of the read in row slot 0 and the slot stride of its block, so that the position of the
 // read in slot r (the key of its random number) is x + r * y without the divisions by T and R in every slice
-// (RSEM_GIBBS_SCALAR_ADDR; k_slice_ptab in gibbs.hip tabulates it)
+// (k_slice_ptab in gibbs.hip tabulates it)
 struct PtabEntry { uint32_t x, y; };
 __host__ RSEM_DEVFN PtabEntry slice_ptab_entry(const Shape& S, uint32_t T, uint32_t sl) {
     const uint32_t R = shape_R(S);
@@ -102,7 +80,7 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
         }
         const double* __restrict__ vp = scp + p0;
 #pragma unroll
-        for (int k = 0; k < K; k++) b.c[k] = RSEM_GIBBS_NT ? RSEM_NT_LOAD(&vp[k * 64 + ulane]) : vp[k * 64 + ulane];
+        for (int k = 0; k < K; k++) b.c[k] = RSEM_NT_LOAD(&vp[k * 64 + ulane]);
         b.nc = g0lane ? (sncp + (S.slot_base + sl * R))[ulane >> lg] : 0.0;
     };
     int rsid[K], acc[K];
@@ -120,7 +98,6 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
             acc[k] = 0;
         }
     };
-    double u_batch = 0.0;  // RSEM_GIBBS_RNG_SPREAD: this lane's share of the read's next G uniforms
     auto sample = [&](const SliceRegs<K>& cur, unsigned long long cur_m, uint32_t s) {
         if (cur_m != 0ull) {
             if ((cur_m >> lane) & 1ull) {
@@ -143,55 +120,25 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
             part += f[k];
         }
         double incl = part;  // inclusive scan over the G lanes of the read
-        const bool dpp_scan = RSEM_GIBBS_DPP && lg >= 1 && lg <= 4;  // (uniform; row_shr moves within rows of 16 lanes: a read's lanes never straddle one)
-        if (dpp_scan) {
-            double o = gdpp<0x111>(incl);
-            if (gl >= 1) incl += o;
-            if (lg >= 2) { o = gdpp<0x112>(incl); if (gl >= 2) incl += o; }
-            if (lg >= 3) { o = gdpp<0x114>(incl); if (gl >= 4) incl += o; }
-            if (lg >= 4) { o = gdpp<0x118>(incl); if (gl >= 8) incl += o; }
-        } else {
-            for (int d = 1; d < G; d <<= 1) {
-                double o = RSEM_SHFL_UP(incl, d);
-                if (gl >= d) incl += o;
-            }
+        for (int d = 1; d < G; d <<= 1) {
+            double o = RSEM_SHFL_UP(incl, d);
+            if (gl >= d) incl += o;
         }
         // (one lane per read: nothing to exchange -- a uniform branch, lg comes from the unit descriptor)
         double excl = 0.0, total = incl;
         if (lg > 0) {
-            excl = dpp_scan ? gdpp<0x111>(incl) : RSEM_SHFL_UP(incl, 1);
+            excl = RSEM_SHFL_UP(incl, 1);
             if (gl == 0) excl = 0.0;
-            if (RSEM_GIBBS_DPP && lg == 1) total = gdpp<0xF5>(incl);       // quad_perm [1,1,3,3]
-            else if (RSEM_GIBBS_DPP && lg == 2) total = gdpp<0xFF>(incl);  // quad_perm [3,3,3,3]
-            else total = RSEM_SHFL(incl, gbase + G - 1);
+            total = RSEM_SHFL(incl, gbase + G - 1);
         }
         // one uniform per read, keyed by the read's position in the sorted order (layout independent)
         const uint32_t key = ph.k0 ^ ((ph.k1 << 13) | (ph.k1 >> 19)) ^ 0x5a5a5a5au;
-        double u;
-        if (RSEM_GIBBS_RNG_SPREAD && lg > 0) {
-            const uint32_t off = (s - s_begin) & (uint32_t)(G - 1);  // (uniform over the wave)
-            if (off == 0) {
-                const uint32_t sj = s + (uint32_t)gl;  // lane gl of the read: the uniform of slice s + gl
-                double ub = 0.0;
-                if (sj < s_end) {
-                    const PtabEntry pj = ptab[sj];
-                    uint32_t r2[2];
-                    rsem::philox2x32_10(key, pj.x + ((uint32_t)lane >> lg) * pj.y, sweep, r2);
-                    ub = u53(r2[0], r2[1]);
-                }
-                u_batch = ub;
-            }
-            u = RSEM_SHFL(u_batch, gbase + (int)off);
-        } else {
-            const PtabEntry pt = ptab[s];  // (s is uniform over the wave: a scalar load)
-            const uint32_t p = pt.x + ((uint32_t)lane >> lg) * pt.y;
-            uint32_t rnd[2] = {0, 0};
-            if (g0lane) rsem::philox2x32_10(key, p, sweep, rnd);
-            u = u53(rnd[0], rnd[1]);
-            if (RSEM_GIBBS_DPP && lg == 1) u = gdpp<0xA0>(u);       // quad_perm [0,0,2,2]
-            else if (RSEM_GIBBS_DPP && lg == 2) u = gdpp<0x00>(u);  // quad_perm [0,0,0,0]
-            else if (lg > 0) u = RSEM_SHFL(u, gbase);
-        }
+        const PtabEntry pt = ptab[s];  // (s is uniform over the wave: a scalar load)
+        const uint32_t p = pt.x + ((uint32_t)lane >> lg) * pt.y;
+        uint32_t rnd[2] = {0, 0};
+        if (g0lane) rsem::philox2x32_10(key, p, sweep, rnd);
+        double u = u53(rnd[0], rnd[1]);
+        if (lg > 0) u = RSEM_SHFL(u, gbase);
         double target = u * total;
         if (target >= total) target = total * (1.0 - 1.1102230246251565e-16);
         int pick = -2;  // -2: not mine, -1: noise, k >= 0: my plane k

@@ -5,14 +5,17 @@
 // CPU (one OS thread per lane, kXW waves) against the oracle's chain.  Everything that differs between the two goes through
 // the GX_* macros below, which expand to the GPU intrinsic in the product.
 //
-// The chain is sequential from read to read only through `counts`.  Reads are cut into TILES of <= 64 consecutive reads
-// and <= kXItems items (a table built once per context: the cut depends on the row pointers only).  Wave w of the workgroup
-// owns tiles w, w + kXW, ...: at any time it stages its tile's items into its own LDS region (coalesced loads, HBM latency
-// hidden behind the other waves' turns) and prepares everything that does not depend on the counts -- which item is the
-// read's current transcript, per hashed id the lanes whose read carries it (`hold`), per lane the EARLIER lanes that share
-// an id with it (`pred`) -- and then waits for the TOKEN (`next_tile` in LDS).  Holding the token it
+// The chain is sequential from read to read only through `counts`.  Reads are cut into TILES of consecutive reads, one read
+// per lane (gx_build_tiles: a table built once per context, the cut depends on the row pointers only).  A tile lives in LDS
+// TRANSPOSED: item k of the read in lane r sits at [k * S + r] (S = 64, 32, 16 or 8 lanes by the tile's longest read), so a
+// lane walking its own read touches consecutive banks -- no bank conflicts, and no lane ever touches another lane's items
+// (the first version kept the items in file order: 36 k cycles per tile inside the token, LDS-bound; profiles/r03c).
+// Wave w of the workgroup owns tiles w, w + kXW, ...: at any time it stages its tile (every lane loads its own read; HBM
+// latency hidden behind the other waves' turns) and prepares what does not depend on the counts -- per hashed id the lanes
+// whose read carries it (`hold`), per lane the EARLIER lanes that share an id with it (`pred`) -- and then waits for the
+// TOKEN (`next_tile` in LDS).  Holding the token it
 //   1. takes the tile's MT19937 outputs (read r of the tile takes the r-th next output: the sequential order),
-//   2. gathers counts[sid] for the tile's items -- exact: every earlier tile has been committed with device atomics,
+//   2. gathers counts[sid] for its read's items -- exact: every earlier tile has been committed with device atomics,
 //   3. evaluates all reads of the tile at once, one read per lane, and resolves the dependencies INSIDE the tile by
 //      fixed-point rounds: a lane's draw depends on the moves (z_old -> z_new) of EARLIER lanes that touch one of its
 //      transcripts; every round the lanes with a moved predecessor (one AND of the moved-lanes ballot with `pred`) recompute
@@ -26,9 +29,11 @@
 // k_gibbs_exact_coop.
 #pragma once
 #include <type_traits>
+#include <vector>
 
 #ifndef GX_EMU
 #define GX_DEVFN __device__ inline
+#define GX_HOSTDEVFN __host__ __device__ inline
 // LDS operations of one wave execute in order, so lanes of a wave that exchange data through LDS only need the COMPILER
 // to keep the order: wavefront-scope fences, no instruction
 #define GX_WAVE_SYNC()                                        \
@@ -52,29 +57,55 @@
 #endif
 
 #ifndef RSEM_GX_W
-#define RSEM_GX_W 8
+#define RSEM_GX_W 4
 #endif
-constexpr int kXW = RSEM_GX_W;  // waves per chain
-constexpr int kXItems = 896;   // items per tile: 64 reads of 12.4 items (BASELINE configs[2]) = 794 on average
-constexpr int kXSlots = 256;   // hashed transcript ids (the noise transcript, id 0, which every read carries, is kept apart)
-constexpr int kXChunk = 16;    // items of a read handled per step with independent (pipelined) LDS reads
-constexpr int kXPlanes = (kXItems + 63) / 64;
+constexpr int kXW = RSEM_GX_W;  // waves per chain (the token section sets the pace: 4, 6 and 8 waves measured the same)
+constexpr int kXCap = 2048;     // LDS entries per wave: S lanes x up to kXCap / S items per read
+constexpr int kXMaxLen = kXCap / 8;  // 256: a longer read is a tile of its own, walked over global memory
+constexpr int kXSlots = 256;    // hashed transcript ids (the noise transcript, id 0, which every read carries, is kept apart)
+constexpr int kXChunk = 16;     // items of a read handled per step with independent (pipelined) LDS reads
 
-struct XWaveLds {  // one per wave: 19.2 KB, kXW of them + XShared = 156.2 KB of the CU's 163.8 KB
+struct XWaveLds {  // one per wave: 37.4 KB, kXW of them + XShared = 152 KB of the CU's 163.8 KB
     unsigned long long rp[65];
-    unsigned long long hold[kXSlots];       // per hashed id (not the noise id 0): the lanes whose read carries such an item
-    double p[kXItems];
-    int32_t sid[kXItems];
-    int32_t c[kXItems];        // counts[sid] after every earlier tile, minus 1 where the read itself sits
+    unsigned long long hold[kXSlots];  // per hashed id (not the noise id 0): the lanes whose read carries such an item
+    double p[kXCap];
+    int32_t sid[kXCap];
+    int32_t c[kXCap];          // counts[sid] after every earlier tile, minus 1 where the read itself sits
     int32_t zo[64], zn[64];
-    signed char own[kXItems];  // 1: this item is its read's current transcript
-    signed char dl[kXItems];   // what the moves of EARLIER reads of the tile add to this item's count
+    signed char dl[kXCap];     // what the moves of EARLIER reads of the tile add to this item's count
 };
 struct XShared {
     uint32_t mt[624];
     int idx;
     unsigned next_tile;
 };
+
+// lanes per tile for a longest read of m items (m <= kXMaxLen)
+GX_HOSTDEVFN int gx_lanes_for(int m) { return m <= kXCap / 64 ? 64 : m <= kXCap / 32 ? 32 : m <= kXCap / 16 ? 16 : 8; }
+
+// Tiles: greedy cut into runs of consecutive reads such that the run has at most gx_lanes_for(its longest read) reads; a read
+// with more than kXMaxLen items is a tile of its own.  Depends on the row pointers only.  (Host; also tests/gibbs_exact_emu.cpp.)
+inline void gx_build_tiles(uint64_t N1, const uint64_t* row_ptr, std::vector<uint32_t>& tiles) {
+    tiles.clear();
+    tiles.reserve(N1 / 48 + 2);
+    uint64_t i = 0;
+    while (i < N1) {
+        tiles.push_back((uint32_t)i);
+        uint64_t m = row_ptr[i + 1] - row_ptr[i];
+        uint64_t e = i + 1;
+        if (m <= (uint64_t)kXMaxLen) {
+            while (e < N1) {
+                const uint64_t l = row_ptr[e + 1] - row_ptr[e];
+                const uint64_t m2 = l > m ? l : m;
+                if (m2 > (uint64_t)kXMaxLen || e + 1 - i > (uint64_t)gx_lanes_for((int)m2)) break;
+                m = m2;
+                ++e;
+            }
+        }
+        i = e;
+    }
+    tiles.push_back((uint32_t)N1);
+}
 
 // Phase profile (variant builds only, -DRSEM_GX_PROFILE=1; the product's kernel reads no timer): shader-clock cycles per
 // wave summed into prof[0..6] = stage + prepare | wait for the token | random numbers | gather | first draw | resolve
@@ -144,46 +175,43 @@ GX_DEVFN void gibbs_exact_wg_body(int lane, int w, XShared* sh, XWaveLds* my, ui
             for (int u = 0; u < kXSlots / 64; u++) my->hold[u * 64 + lane] = 0ull;
         }
         GX_WAVE_SYNC();
-        const uint64_t base = my->rp[0];
-        const uint64_t T64 = my->rp[nr] - base;
-        const bool long_tile = T64 > (uint64_t)kXItems;  // one read with more items than a tile holds (then nr == 1)
-        const uint32_t T = long_tile ? 0u : (uint32_t)T64;
-        int sj[kXPlanes];  // the tile's ids item-major (item u * 64 + lane): kept in registers for the gather
+        const uint64_t base = my->rp[lane];  // this lane's read
+        const uint64_t len64 = mine ? my->rp[lane + 1] - base : 0ull;
+        const bool long_tile = GX_BALLOT(len64 > (uint64_t)kXMaxLen) != 0ull;  // (uniform; then nr == 1)
+        const int len = long_tile ? 0 : (int)len64;
+        int maxlen = 0;  // (uniform) the tile's longest read, bit by bit from the top
 #pragma unroll
-        for (int u0 = 0; u0 < kXPlanes; u0 += 7) {  // coalesced, seven (sid, conprb) pairs in flight per lane
-            double p7[7];
+        for (int b = 8; b >= 0; b--)
+            if (GX_BALLOT(len >= (maxlen | (1 << b))) != 0ull) maxlen |= 1 << b;
+        const int S = gx_lanes_for(maxlen);  // the tile table guarantees nr <= S
+        auto at = [&](int k) -> int { return k * S + lane; };
+        for (int k0 = 0; k0 < maxlen; k0 += 8) {  // every lane loads its own read: eight (sid, conprb) pairs in flight
+            int s8[8];
+            double p8[8];
 #pragma unroll
-            for (int u = 0; u < 7; u++) {
-                const uint32_t j = (uint32_t)(u0 + u) * 64 + lane;
-                sj[u0 + u] = j < T ? sid[base + j] : 0;
-                p7[u] = j < T ? cp[base + j] : 0.0;
+            for (int u = 0; u < 8; u++) {
+                const bool in = k0 + u < len;
+                s8[u] = in ? sid[base + (uint64_t)(k0 + u)] : 0;
+                p8[u] = in ? cp[base + (uint64_t)(k0 + u)] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 7; u++) {
-                const uint32_t j = (uint32_t)(u0 + u) * 64 + lane;
-                if (j < T) {
-                    my->sid[j] = sj[u0 + u];
-                    my->p[j] = p7[u];
-                    if (!kInit) my->dl[j] = 0;
+            for (int u = 0; u < 8; u++)
+                if (k0 + u < len) {
+                    my->sid[at(k0 + u)] = s8[u];
+                    my->p[at(k0 + u)] = p8[u];
+                    if (!kInit) my->dl[at(k0 + u)] = 0;
                 }
-            }
         }
-        const uint32_t fr = mine ? (uint32_t)(my->rp[lane] - base) : 0;
-        const int len = (mine && !long_tile) ? (int)(my->rp[lane + 1] - my->rp[lane]) : 0;
-        GX_WAVE_SYNC();
         unsigned long long pred = 0ull;  // the earlier lanes of the tile whose read shares a (hashed) id with this one
         bool has0 = false;               // the read carries the noise transcript (every read of an .ofg file does)
         if (!kInit) {
-            // which item is the read's current transcript (Gibbs.cpp:298: the read leaves it before it is weighed), and the
-            // holders of every hashed id
             for (int k0 = 0; k0 < len; k0 += kXChunk) {
                 int s[kXChunk];
 #pragma unroll
-                for (int j = 0; j < kXChunk; j++) s[j] = (k0 + j < len) ? my->sid[fr + k0 + j] : -1;
+                for (int j = 0; j < kXChunk; j++) s[j] = (k0 + j < len) ? my->sid[at(k0 + j)] : -1;
 #pragma unroll
                 for (int j = 0; j < kXChunk; j++)
                     if (k0 + j < len) {
-                        my->own[fr + k0 + j] = (signed char)(s[j] == z_old ? 1 : 0);
                         if (s[j] != 0) GX_LDS_OR64(&my->hold[gx_slot(s[j])], 1ull << lane);
                         else has0 = true;
                     }
@@ -192,14 +220,13 @@ GX_DEVFN void gibbs_exact_wg_body(int lane, int w, XShared* sh, XWaveLds* my, ui
             for (int k0 = 0; k0 < len; k0 += kXChunk) {
                 int s[kXChunk];
 #pragma unroll
-                for (int j = 0; j < kXChunk; j++) s[j] = (k0 + j < len) ? my->sid[fr + k0 + j] : -1;
+                for (int j = 0; j < kXChunk; j++) s[j] = (k0 + j < len) ? my->sid[at(k0 + j)] : -1;
 #pragma unroll
                 for (int j = 0; j < kXChunk; j++)
                     if (k0 + j < len && s[j] != 0) pred |= my->hold[gx_slot(s[j])];
             }
             pred &= below;
         }
-        GX_WAVE_SYNC();
         lap(0);
         // ---- the token: tiles commit in file order ------------------------------------------------------------------------------
         while (GX_TOKEN_LOAD(&sh->next_tile) != t) GX_SLEEP();
@@ -213,7 +240,7 @@ GX_DEVFN void gibbs_exact_wg_body(int lane, int w, XShared* sh, XWaveLds* my, ui
             const uint32_t rnd = gx_temper(mt[idx]);
             idx += 1;
             if (lane == 0) {
-                const uint64_t fr64 = base, n = T64;
+                const uint64_t fr64 = base, n = len64;
                 if (!kInit) {
                     GX_CNT_ADD(&counts[z_old], -1);
                     GX_WAIT_VM();
@@ -256,21 +283,19 @@ GX_DEVFN void gibbs_exact_wg_body(int lane, int w, XShared* sh, XWaveLds* my, ui
             }
             lap(2);
             if (!kInit) {
-                // counts of the tile's items as they are after every earlier tile (item-major: neighbouring lanes fetch
-                // neighbouring ids), the read's own unit taken off where it sits
-                int cj[kXPlanes];
+                // counts of this read's items as they are after every earlier tile; the read itself leaves its current
+                // transcript before it is weighed (Gibbs.cpp:298)
+                for (int k0 = 0; k0 < len; k0 += 8) {
+                    int s8[8], c8[8];
 #pragma unroll
-                for (int u = 0; u < kXPlanes; u++) {
-                    const uint32_t j = (uint32_t)u * 64 + lane;
-                    cj[u] = j < T ? GX_CNT_LOAD(&counts[sj[u]]) : 0;
-                }
+                    for (int u = 0; u < 8; u++) s8[u] = (k0 + u < len) ? my->sid[at(k0 + u)] : 0;
 #pragma unroll
-                for (int u = 0; u < kXPlanes; u++) {
-                    const uint32_t j = (uint32_t)u * 64 + lane;
-                    if (j < T) my->c[j] = cj[u] - (int)my->own[j];
+                    for (int u = 0; u < 8; u++) c8[u] = (k0 + u < len) ? GX_CNT_LOAD(&counts[s8[u]]) : 0;
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (k0 + u < len) my->c[at(k0 + u)] = c8[u] - (s8[u] == z_old ? 1 : 0);
                 }
             }
-            GX_WAVE_SYNC();
             lap(3);
             // sample() of sampling.h:50-65 on arr[k] = arr[k-1] + weight_k: the index of the first partial sum > prb, which for
             // a non-decreasing array is the number of partial sums <= prb (what the binary search there finds), capped at
@@ -284,9 +309,9 @@ GX_DEVFN void gibbs_exact_wg_body(int lane, int w, XShared* sh, XWaveLds* my, ui
 #pragma unroll
                     for (int j = 0; j < kXChunk; j++) {
                         const bool in = k0 + j < len;
-                        pp[j] = in ? my->p[fr + k0 + j] : 0.0;
-                        cc[j] = (in && !kInit) ? my->c[fr + k0 + j] : 0;
-                        if (kDelta && in) cc[j] += (int)my->dl[fr + k0 + j];
+                        pp[j] = in ? my->p[at(k0 + j)] : 0.0;
+                        cc[j] = (in && !kInit) ? my->c[at(k0 + j)] : 0;
+                        if (kDelta && in) cc[j] += (int)my->dl[at(k0 + j)];
                     }
 #pragma unroll
                     for (int j = 0; j < kXChunk; j++) a[j] = kInit ? pp[j] : ((double)cc[j] + pseudoC) * pp[j];
@@ -318,7 +343,7 @@ GX_DEVFN void gibbs_exact_wg_body(int lane, int w, XShared* sh, XWaveLds* my, ui
                     }
                 }
                 const int l = cnt < len ? cnt : len - 1;
-                return my->sid[fr + l];
+                return my->sid[at(l)];
             };
             int z_new = mine ? draw(std::false_type{}) : z_old;
             lap(4);
@@ -344,8 +369,8 @@ GX_DEVFN void gibbs_exact_wg_body(int lane, int w, XShared* sh, XWaveLds* my, ui
 #pragma unroll
                             for (int j = 0; j < kXChunk; j++) {
                                 const bool in = k0 + j < len;
-                                s[j] = in ? my->sid[fr + k0 + j] : -1;
-                                od[j] = in ? (int)my->dl[fr + k0 + j] : 0;
+                                s[j] = in ? my->sid[at(k0 + j)] : -1;
+                                od[j] = in ? (int)my->dl[at(k0 + j)] : 0;
                             }
 #pragma unroll
                             for (int j = 0; j < kXChunk; j++)
@@ -360,7 +385,7 @@ GX_DEVFN void gibbs_exact_wg_body(int lane, int w, XShared* sh, XWaveLds* my, ui
                                     dd += (my->zn[r1] == s[j] ? 1 : 0) - (my->zo[r1] == s[j] ? 1 : 0);
                                 }
                                 if (dd != od[j]) {
-                                    my->dl[fr + k0 + j] = (signed char)dd;
+                                    my->dl[at(k0 + j)] = (signed char)dd;
                                     dirty = true;
                                 }
                                 nz = nz || dd != 0;

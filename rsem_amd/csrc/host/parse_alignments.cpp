@@ -2,7 +2,9 @@
 // SAM/BAM in, the EM stage's input files out, byte-identical to the reference's:
 //
 //   rsem-parse-alignments refName imdName statName alignF read_type [-t fai_file] [-tag tagName] [-q] [-p threads]
-//                         [--binary [--text]]        (not in the reference; also RSEM_HIP_BINARY=1 / =both in the environment)
+//                         [--binary [--text]]        (not in the reference; also RSEM_HIP_BINARY=1 / =both in the environment;
+//                                                     =1 there keeps the alignable read files as text for the driver's
+//                                                     rsem-build-read-index step, --binary alone writes no text at all)
 //
 //   imdName.dat                        N1 nHits read_type / one line of hits per alignable read
 //   imdName_{un,alignable,max}[_1|_2].{fa,fq}   reads by category (empty categories are removed)
@@ -64,6 +66,11 @@ struct Config {
     std::vector<int32_t> e2i, target_len, gid_of;
     int n_targets = 0;
     bool want_text = true, want_bin = false;
+    // RSEM_HIP_BINARY=1 in the ENVIRONMENT (the unmodified Perl driver built the command line): binary hand-off, but the
+    // alignable read files are still written as text -- the driver's next command is the reference's rsem-build-read-index
+    // on exactly those files (rsem-calculate-expression:597-604), which would end the run without them
+    bool keep_alignable = false;
+    bool reads_text(int category) const { return want_text || (keep_alignable && category == 1); }
 };
 
 struct ParseError { std::string msg; };
@@ -287,7 +294,7 @@ void run_chunk(const Wave& w, size_t u0, size_t u1, const Config& cfg, ChunkOut&
     auto flush = [&]() {  // parseIt.cpp:92-118
         if (cur_val >= 0) {
             for (int j = 0; j < n_os; j++) {  // SingleRead.h:52-55, SingleReadQ.h:57-60
-                if (cfg.want_text) {
+                if (cfg.reads_text(cur_val)) {
                     std::string& o = out.reads[cur_val][j];
                     o.push_back(cfg.has_q ? '@' : '>');
                     o += cur[j].name; o.push_back('\n');
@@ -504,12 +511,14 @@ int main(int argc, char* argv[]) {
     {   // binary hand-off to rsem-run-em (host/rsb.hpp): a flag, or the environment when the Perl driver builds the command line
         bool bin = false, text = false;
         for (int i = 6; i < argc; i++) { bin = bin || !strcmp(argv[i], "--binary"); text = text || !strcmp(argv[i], "--text"); }
+        bool from_env = false;
         if (const char* e = getenv("RSEM_HIP_BINARY")) {
             if (!strcmp(e, "both")) { bin = true; text = true; }
-            else if (*e && strcmp(e, "0")) bin = true;
+            else if (*e && strcmp(e, "0")) { from_env = !bin; bin = true; }
         }
         cfg.want_bin = bin;
         cfg.want_text = !bin || text;
+        cfg.keep_alignable = from_env && !cfg.want_text;
     }
     if (!cfg.rt_tag.empty() && cfg.rt_tag.size() != 2) die("-tag expects a two-character SAM tag!");
     if (!wave_bytes) wave_bytes = std::max<size_t>((size_t)threads << 23, (size_t)64 << 20);
@@ -633,7 +642,8 @@ int main(int argc, char* argv[]) {
     const int n_os = cfg.paired ? 2 : 1;
     FILE* cat[3][2] = {{nullptr}};
     std::string cat_path[3][2];
-    for (int c = 0; c < 3 && cfg.want_text; c++) {
+    for (int c = 0; c < 3; c++) {
+        if (!cfg.reads_text(c)) continue;
         const std::vector<std::string> names = read_file_names(imdName, c, cfg.read_type);
         for (int j = 0; j < n_os; j++) {
             cat_path[c][j] = names[j];
@@ -649,6 +659,7 @@ int main(int argc, char* argv[]) {
     }
     std::unique_ptr<RsbWriter> rsb;
     if (cfg.want_bin) rsb.reset(new RsbWriter(imdName, cfg.read_type));
+    else remove_rsb(imdName);  // a text-only run must not leave an OLDER binary hand-off behind: rsem-run-em would prefer it
 
     long long N[3] = {0, 0, 0}, nHits = 0, nMulti = 0, nIsoMulti = 0, cnt = 0, n_warns = 0, next_report = 1000000;
     std::map<long long, long long> counter;
@@ -763,11 +774,9 @@ int main(int argc, char* argv[]) {
             for (auto& m : o.warns)
                 if (++n_warns <= 50) fprintf(stderr, "%s\n", m.c_str());
             n_warns += o.n_warns - (long long)o.warns.size();
-            if (cfg.want_text) {
-                fwrite(o.dat.data(), 1, o.dat.size(), fdat);
-                for (int k = 0; k < 3; k++)
-                    for (int j = 0; j < n_os; j++) fwrite(o.reads[k][j].data(), 1, o.reads[k][j].size(), cat[k][j]);
-            }
+            if (cfg.want_text) fwrite(o.dat.data(), 1, o.dat.size(), fdat);
+            for (int k = 0; k < 3; k++)
+                for (int j = 0; j < n_os && cfg.reads_text(k); j++) fwrite(o.reads[k][j].data(), 1, o.reads[k][j].size(), cat[k][j]);
             if (rsb && o.error.empty()) {
                 rsb->append_hits(o.b_rowlen.data(), o.b_rowlen.size(), o.b_sid.data(), o.b_pos.data(), o.b_ins.data());
                 for (int k = 0; k < 3; k++)
@@ -811,8 +820,8 @@ int main(int argc, char* argv[]) {
     fprintf(fc, "Inf\t%lld\n", N[2]);
     fclose(fc);
 
-    for (int c = 0; c < 3 && cfg.want_text; c++)
-        for (int j = 0; j < n_os; j++) {
+    for (int c = 0; c < 3; c++)
+        for (int j = 0; j < n_os && cfg.reads_text(c); j++) {
             fclose(cat[c][j]);
             if (N[c] == 0) remove(cat_path[c][j].c_str());
         }

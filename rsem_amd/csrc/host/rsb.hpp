@@ -19,6 +19,10 @@
 // All files are plain little-endian arrays; everything is appended in read order, so the writer needs no seeking.
 // Read names are not stored: the EM stage never uses them (error messages fall back to the read's index).
 #pragma once
+#include <dirent.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "reads.hpp"
 
 namespace rsemh {
@@ -34,12 +38,25 @@ struct RsbHeader {
 
 inline std::string rsb_dir(const std::string& imdName) { return imdName + ".rsb"; }
 
+// remove imdName.rsb/ and the plain files in it (the writer creates nothing else there); no shell involved
+inline void remove_rsb(const std::string& imdName) {
+    const std::string dir = rsb_dir(imdName);
+    if (DIR* d = opendir(dir.c_str())) {
+        while (dirent* e = readdir(d)) {
+            if (!strcmp(e->d_name, ".") || !strcmp(e->d_name, "..")) continue;
+            unlink((dir + "/" + e->d_name).c_str());
+        }
+        closedir(d);
+        rmdir(dir.c_str());
+    }
+}
+
 class RsbWriter {
   public:
     RsbWriter(const std::string& imdName, int read_type) : dir_(rsb_dir(imdName)), read_type_(read_type) {
         const bool pe = read_type >= 2, q = (read_type == 1 || read_type == 3);
-        std::string cmd = "rm -rf '" + dir_ + "' && mkdir -p '" + dir_ + "'";
-        if (system(cmd.c_str()) != 0) die("Cannot create %s!", dir_.c_str());
+        remove_rsb(imdName);
+        if (mkdir(dir_.c_str(), 0777) != 0) die("Cannot create %s!", dir_.c_str());
         memset(&h_, 0, sizeof(h_));
         f_rp_ = open_("row_ptr"); f_sid_ = open_("sid"); f_pos_ = open_("pos");
         if (pe) f_ins_ = open_("ins");
@@ -50,10 +67,10 @@ class RsbWriter {
                 f_seq_[c][m] = open_("seq" + t);
                 if (q) f_qual_[c][m] = open_("qual" + t);
                 const uint64_t zero = 0;
-                fwrite(&zero, sizeof(zero), 1, f_off_[c][m]);
+                put_(&zero, sizeof(zero), 1, f_off_[c][m]);
             }
         const uint64_t zero = 0;
-        fwrite(&zero, sizeof(zero), 1, f_rp_);
+        put_(&zero, sizeof(zero), 1, f_rp_);
     }
     // alignments of consecutive alignable reads: lens[n] alignments each
     void append_hits(const uint32_t* lens, size_t n, const int32_t* sid, const int32_t* pos, const int32_t* ins) {
@@ -61,19 +78,19 @@ class RsbWriter {
         const uint64_t before = h_.nHits;
         for (size_t i = 0; i < n; i++) { h_.nHits += lens[i]; tmp_[i] = h_.nHits; }
         const size_t k = (size_t)(h_.nHits - before);
-        fwrite(tmp_.data(), sizeof(uint64_t), n, f_rp_);
-        fwrite(sid, sizeof(int32_t), k, f_sid_);
-        fwrite(pos, sizeof(int32_t), k, f_pos_);
-        if (f_ins_) fwrite(ins, sizeof(int32_t), k, f_ins_);
+        put_(tmp_.data(), sizeof(uint64_t), n, f_rp_);
+        put_(sid, sizeof(int32_t), k, f_sid_);
+        put_(pos, sizeof(int32_t), k, f_pos_);
+        if (f_ins_) put_(ins, sizeof(int32_t), k, f_ins_);
     }
     // consecutive reads of category c, mate m: lens[n] bases each, packed back to back
     void append_reads(int c, int m, const uint32_t* lens, size_t n, const uint8_t* seq, const uint8_t* qual) {
         tmp_.resize(n);
         uint64_t tot = 0;
         for (size_t i = 0; i < n; i++) { tot += lens[i]; tmp_[i] = h_.nBases[c][m] + tot; }
-        fwrite(tmp_.data(), sizeof(uint64_t), n, f_off_[c][m]);
-        fwrite(seq, 1, tot, f_seq_[c][m]);
-        if (f_qual_[c][m]) fwrite(qual, 1, tot, f_qual_[c][m]);
+        put_(tmp_.data(), sizeof(uint64_t), n, f_off_[c][m]);
+        put_(seq, 1, tot, f_seq_[c][m]);
+        if (f_qual_[c][m]) put_(qual, 1, tot, f_qual_[c][m]);
         h_.nBases[c][m] += tot;
         if (m == 0) h_.N[c] += n;
     }
@@ -88,12 +105,15 @@ class RsbWriter {
         h_.version = 1;
         h_.read_type = (uint32_t)read_type_;
         FILE* f = open_("hdr");
-        fwrite(&h_, sizeof(h_), 1, f);
+        put_(&h_, sizeof(h_), 1, f);
         if (fclose(f) != 0) die("Cannot write %s/hdr!", dir_.c_str());
     }
     const RsbHeader& header() const { return h_; }
 
   private:
+    void put_(const void* p, size_t size, size_t n, FILE* f) {  // a full disk is an error here, not a surprise at load time
+        if (n && fwrite(p, size, n, f) != n) die("Cannot write %s (disk full?)!", dir_.c_str());
+    }
     FILE* open_(const std::string& name) {
         FILE* f = fopen((dir_ + "/" + name).c_str(), "wb");
         if (!f) die("Cannot open %s/%s for writing!", dir_.c_str(), name.c_str());
@@ -110,7 +130,17 @@ class RsbWriter {
     FILE* f_qual_[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
 };
 
-inline bool rsb_present(const std::string& imdName) { return file_exists(rsb_dir(imdName) + "/hdr"); }
+// The binary hand-off is used when its header exists AND it is not older than a text hand-off lying next to it: a kept
+// sample.temp directory may hold arrays of an earlier --binary run beside the .dat of a later text run of another parser
+// (this repo's parser removes the stale directory itself; the reference's does not know about it).
+inline bool rsb_present(const std::string& imdName) {
+    struct stat hb, db;
+    if (stat((rsb_dir(imdName) + "/hdr").c_str(), &hb) != 0) return false;
+    if (stat((imdName + ".dat").c_str(), &db) != 0) return true;
+    const bool newer_dat = db.st_mtim.tv_sec > hb.st_mtim.tv_sec || (db.st_mtim.tv_sec == hb.st_mtim.tv_sec && db.st_mtim.tv_nsec > hb.st_mtim.tv_nsec);
+    if (newer_dat) fprintf(stderr, "Warning: %s.dat is newer than %s: the text files are used.\n", imdName.c_str(), rsb_dir(imdName).c_str());
+    return !newer_dat;
+}
 
 struct ReadSetFiles {  // the three categories of reads (utils.h:129-149): un, alignable, max
     ReadFile mate[3][2];
@@ -145,6 +175,8 @@ inline void load_rsb(const std::string& imdName, int read_type, bool hasPolyA, i
     rsb_map(dir + "/pos", (size_t)h.nHits, D.pos);
     if (pe) rsb_map(dir + "/ins", (size_t)h.nHits, D.insertL);
     if (D.row_ptr[0] != 0 || D.row_ptr[h.N[1]] != h.nHits) die("%s/row_ptr does not match the header!", dir.c_str());
+    for (uint64_t i = 0; i < h.N[1]; i++)
+        if (D.row_ptr[i + 1] < D.row_ptr[i]) die("%s/row_ptr is damaged (not increasing at read %llu)!", dir.c_str(), (unsigned long long)i);
     for (int c = 0; c < 3; c++) {
         if (h.N[c] == 0) continue;
         rs.present[c] = true;
@@ -162,6 +194,7 @@ inline void load_rsb(const std::string& imdName, int read_type, bool hasPolyA, i
             parallel_for(nt, [&](int th) {
                 const uint64_t lo = R.n * th / nt, hi = R.n * (th + 1) / nt;
                 for (uint64_t i = lo; i < hi; i++) {
+                    if (R.off[i + 1] < R.off[i] || R.off[i + 1] > h.nBases[c][m] || R.off[i + 1] - R.off[i] > 0x7fffffffull) { bad[th] = 3; break; }
                     const uint8_t* s = R.seq.data() + R.off[i];
                     const int len = R.len(i);
                     for (int k = 0; k < len; k++)
@@ -177,6 +210,7 @@ inline void load_rsb(const std::string& imdName, int read_type, bool hasPolyA, i
             for (int b : bad) {
                 if (b == 1) die("Found unknown sequence letter at function get_base_id! (%s/seq%s)", dir.c_str(), t.c_str());
                 if (b == 2) die("%s/qual%s: quality character out of range", dir.c_str(), t.c_str());
+                if (b == 3) die("%s/off%s is damaged (offsets not increasing or past the end)!", dir.c_str(), t.c_str());
             }
         }
     }

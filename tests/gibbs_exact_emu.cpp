@@ -3,7 +3,7 @@
 // synchronisation points as real barriers between the 64 threads of a wave, LDS / count atomics as CPU atomics, the token
 // as an atomic word.  Never part of the product.
 //
-//   gibbs_exact_emu in.bin out.bin     in:  i32 M, N1, rounds, seed, N0, tile_items (0 = kXItems), pad, pad; f64 pseudoC
+//   gibbs_exact_emu in.bin out.bin     in:  i32 M, N1, rounds, seed, N0, pad, pad, pad; f64 pseudoC
 //                                           u64 row_ptr[N1+1]; i32 sid[n]; f64 cp[n]; i32 init_counts[M+1]
 //                                      out: i32 counts[rounds][M+1]  (after every sweep; the initial assignment is not dumped)
 #include <pthread.h>
@@ -37,6 +37,7 @@ inline unsigned long long ballot(bool p) {
 
 #define GX_EMU 1
 #define GX_DEVFN inline
+#define GX_HOSTDEVFN inline
 #define GX_WAVE_SYNC() emu::wave_sync()
 #define GX_BALLOT(p) emu::ballot(p)
 #define GX_LDS_OR64(p, v) (void)__atomic_fetch_or(p, v, __ATOMIC_RELAXED)
@@ -49,19 +50,6 @@ inline unsigned long long ballot(bool p) {
 #define __restrict__
 
 #include "../rsem_amd/csrc/gibbs_exact_wg.hpp"
-
-static void build_tiles(uint64_t N1, const uint64_t* row_ptr, int tile_items, std::vector<uint32_t>& tiles) {
-    // the rule of build_exact_tiles (gibbs.hip) with a tile capacity that tests may shrink
-    uint64_t i = 0;
-    while (i < N1) {
-        tiles.push_back((uint32_t)i);
-        const uint64_t b = row_ptr[i];
-        uint64_t e = i + 1;
-        while (e < N1 && e - i < 64 && row_ptr[e + 1] - b <= (uint64_t)tile_items) ++e;
-        i = e;
-    }
-    tiles.push_back((uint32_t)N1);
-}
 
 struct Machine {
     XShared sh;
@@ -81,7 +69,6 @@ int main(int argc, char** argv) {
     const uint64_t N1 = (uint64_t)hdr[1];
     const uint32_t seed = (uint32_t)hdr[3];
     const int N0 = hdr[4];
-    const int tile_items = hdr[5] > 0 ? hdr[5] : kXItems;
     std::vector<uint64_t> rp(N1 + 1);
     if (fread(rp.data(), 8, N1 + 1, f) != N1 + 1) return 2;
     const uint64_t n = rp[N1];
@@ -89,17 +76,10 @@ int main(int argc, char** argv) {
     std::vector<double> cp(n);
     if (fread(sid.data(), 4, n, f) != n || fread(cp.data(), 8, n, f) != n || fread(init.data(), 4, M + 1, f) != (size_t)M + 1) return 2;
     fclose(f);
-    if (tile_items > kXItems) { fprintf(stderr, "tile_items > kXItems\n"); return 2; }
 
     std::vector<uint32_t> tiles;
-    build_tiles(N1, rp.data(), tile_items, tiles);
-    // a tile capacity below kXItems makes "long" reads out of reads that fit kXItems: the body decides by kXItems, so only
-    // reads longer than kXItems take the global-memory path; shrunken tiles exercise the cut itself
+    gx_build_tiles(N1, rp.data(), tiles);  // the product's own rule
     const uint32_t n_tiles = (uint32_t)tiles.size() - 1;
-    for (uint32_t t = 0; t < n_tiles; t++) {
-        const uint64_t items = rp[tiles[t + 1]] - rp[tiles[t]];
-        if (items > (uint64_t)kXItems && tiles[t + 1] - tiles[t] != 1) { fprintf(stderr, "bad tile table\n"); return 2; }
-    }
     std::vector<int32_t> counts(init), z(N1 ? N1 : 1, 0);
     counts[0] += N0;
     std::vector<int32_t> out((size_t)rounds * (M + 1));

@@ -1,8 +1,8 @@
 """The per-wave body of the Gibbs PARALLEL sweep kernel (rsem_amd/csrc/gibbs_block.hpp -- the file gibbs.hip compiles for the
 GPU) run on the CPU by tests/gibbs_emu.cpp (thread per lane, tests/simt_emu.hpp).  z_i | g must pick alignment j of read i
 with probability g_j * conprb_j / (g_0 * ncp_i + sum_k g_k * conprb_k): every sweep assigns every read once, and the picks
-per transcript over a few sweeps sit where the binomial says (z-scores: rms ~1).  The candidate build (a read's lanes share
-the work of its next G uniforms; non-temporal value loads) must draw the SAME picks: same keys, same numbers.  No GPU involved."""
+per transcript over a few sweeps sit where the binomial says (z-scores: rms ~1), whatever the block length and the size
+of the LDS window.  No GPU involved."""
 import os
 import shutil
 import subprocess
@@ -16,7 +16,7 @@ import test_estep_emu_cpu as te
 ROOT = te.ROOT
 pytestmark = pytest.mark.skipif(not os.path.exists(te.CC), reason="needs hipcc (host compilation of the HIP headers)")
 
-BUILDS = {"product": [], "candidates": ["-DRSEM_GIBBS_RNG_SPREAD=1", "-DRSEM_GIBBS_NT=1", "-DRSEM_GIBBS_DPP=1"]}
+BUILDS = {"product": []}
 
 
 @pytest.fixture(scope="module")
@@ -72,8 +72,6 @@ def test_sweep_body_distribution_and_variants(emulators):
         z = (c.sum(0) - S * exp)[big] / np.sqrt(S * var[big])
         assert big.sum() > 50 and np.abs(z).max() < 5.0 and 0.7 < np.sqrt((z ** 2).mean()) < 1.3, (name, np.abs(z).max(), np.sqrt((z ** 2).mean()))
         assert np.all(c[:, exp == 0] == 0)                        # nothing lands where no alignment points
-    assert np.array_equal(res["product"], res["candidates"])      # same keys, same draws
-    small = _run(emulators["candidates"], M, rp, sid, cp, ncp, g, T=3, sweeps=2, seed=5, window=64)  # odd block length, tiny LDS window
-    ref = _run(emulators["product"], M, rp, sid, cp, ncp, g, T=3, sweeps=2, seed=5, window=64)
-    assert np.array_equal(small, ref)
+    small = _run(emulators["product"], M, rp, sid, cp, ncp, g, T=3, sweeps=S, seed=5, window=64)  # odd block length, tiny LDS window
+    assert np.array_equal(small, res["product"])                  # the picks depend on the keys only, not on the layout's geometry
     assert not np.array_equal(res["product"][0], res["product"][1])  # sweeps differ from one another

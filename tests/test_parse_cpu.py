@@ -303,5 +303,22 @@ def test_binary_handoff_via_environment(tmp_path):
     cmd = [NEW, os.path.join(fx, "ref"), os.path.join(d, "temp", "s"), os.path.join(d, "stat", "s"), os.path.join(fx, "aln.sam"), "1", "-q"]
     subprocess.check_call(cmd, env=dict(os.environ, RSEM_HIP_BINARY="1"))
     assert os.path.exists(os.path.join(d, "temp", "s.rsb", "hdr")) and not os.path.exists(os.path.join(d, "temp", "s.dat"))
+    # ... but the driver's next command is the reference's rsem-build-read-index on the alignable read files
+    # (rsem-calculate-expression:597-604): they are still there, identical to the text run's, and the index builds
+    ali = os.path.join(d, "temp", "s_alignable.fq")
+    assert filecmp.cmp(ali, os.path.join(fx, "temp", "s_alignable.fq"), shallow=False)
+    assert not os.path.exists(os.path.join(d, "temp", "s_un.fq"))
+    ref_idx = os.path.join(ROOT, "oracle", "_ref", "rsem-build-read-index")
+    if os.path.exists(ref_idx):
+        subprocess.check_call([ref_idx, "32", "1", "1", ali])
+        assert os.path.exists(ali + ".ridx")
+    # the flag on the command line (no driver in between) writes no text at all
+    d2 = os.path.join(d, "cli")
+    os.makedirs(os.path.join(d2, "temp")); os.makedirs(os.path.join(d2, "stat"))
+    subprocess.check_call([NEW, os.path.join(fx, "ref"), os.path.join(d2, "temp", "s"), os.path.join(d2, "stat", "s"), os.path.join(fx, "aln.sam"), "1", "-q", "--binary"])
+    assert sorted(os.listdir(os.path.join(d2, "temp"))) == ["s.omit", "s.rsb"]
     subprocess.check_call(cmd, env=dict(os.environ, RSEM_HIP_BINARY="both"))
     assert os.path.exists(os.path.join(d, "temp", "s.rsb", "hdr")) and os.path.exists(os.path.join(d, "temp", "s.dat"))
+    # a later TEXT run on the same sample.temp (kept intermediate files) removes the arrays: rsem-run-em must not find stale ones
+    subprocess.check_call(cmd)
+    assert os.path.exists(os.path.join(d, "temp", "s.dat")) and not os.path.exists(os.path.join(d, "temp", "s.rsb"))
