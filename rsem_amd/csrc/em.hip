@@ -1249,6 +1249,13 @@ __global__ void k_seed_theta_source(int32_t M, const double* __restrict__ theta,
     if (i < 2 * kTotSlots) buf[n + i] = (i == 0) ? -N0 : (i == kTotSlots ? 1.0 - N0 : 0.0);
 }
 
+// The launch after the last round only has that round to close: the closers alone, no E-step work (grid = the number of
+// closers: solo_close_round then makes every workgroup one).  Saves one whole E-step launch per rsem_em_run call.
+__global__ __launch_bounds__(kBlock) void k_solo_close(int M, const double* __restrict__ cur, double N0, const Ctrl* ctrl, SoloArgs solo) {
+    if (ctrl->done) return;
+    solo_close_round(solo, M, N0, cur);
+}
+
 // Measured (profiles/r02c_em_loops.log, same box, back to back), ms per round on BASELINE configs[2] / configs[1]:
 //   plain (E-step kernel, M-step kernel)          1.102 / 0.1393
 //   fused (statistics kernel on a second stream)  1.042 / 0.1468   (two stream hand-offs per round)
@@ -1362,9 +1369,15 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
             sa.min_round = min_round;
             sa.max_round = max_round;
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[2 + 2 * ti], st));
-            hipLaunchKernelGGL((k_estep_lane<true, true>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
-                               (const double*)src, (const double*)(src + c->M + 1), N0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
-                               c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, sa);
+            if (r > max_round) {  // nothing left to accumulate: close round max_round, no E-step work
+                if (c->n_units)
+                    hipLaunchKernelGGL(k_solo_close, dim3(std::min<uint32_t>(c->n_units, (uint32_t)kCloseMax)), dim3(kBlock), 0, st, c->M, (const double*)src, N0,
+                                       (const Ctrl*)c->d_ctrl, sa);
+            } else {
+                hipLaunchKernelGGL((k_estep_lane<true, true>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
+                                   (const double*)src, (const double*)(src + c->M + 1), N0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
+                                   c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, sa);
+            }
             RSEM_HIP_TRY(hipGetLastError());
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));
         } else if (fused) {

@@ -32,6 +32,7 @@
 #include "model_host.hpp"
 #include "reads.hpp"
 #include "results.hpp"
+#include "ofb.hpp"
 #include "rsb.hpp"
 
 using namespace rsemh;
@@ -282,6 +283,10 @@ int main(int argc, char* argv[]) {
     const std::string refName = argv[1];
     const int read_type = atoi(argv[2]);
     const std::string outName = argv[3], imdName = argv[4], statName = argv[5];
+    // Gibbs hand-off (host/ofb.hpp): 0 = imdName.ofg (the reference's text), 1 = imdName.ofb/ (arrays), 2 = both; also
+    // RSEM_HIP_BINARY=1 / =both in the environment, the switch the unmodified Perl driver cannot put on the command line
+    int ofbMode = 0;
+    if (const char* e = getenv("RSEM_HIP_BINARY")) ofbMode = !strcmp(e, "both") ? 2 : ((*e && strcmp(e, "0")) ? 1 : 0);
     bool verbose = true, genBamF = false, genGibbsOut = false, appendNames = false, bamSampling = false, hasSeed = false;
     uint32_t seed = 0;
     std::string inpSamF, devices_s;
@@ -296,6 +301,7 @@ int main(int argc, char* argv[]) {
         }
         if (!strcmp(argv[i], "-q")) verbose = false;
         if (!strcmp(argv[i], "--gibbs-out")) genGibbsOut = true;
+        if (!strcmp(argv[i], "--gibbs-out-binary")) { genGibbsOut = true; ofbMode = 1; }  // not in the reference: imdName.ofb/ only
         if (!strcmp(argv[i], "--append-names")) appendNames = true;
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--ngpus") && i + 1 < argc) ngpus = atoi(argv[i + 1]);
@@ -636,12 +642,35 @@ int main(int argc, char* argv[]) {
             if (X.rc != RSEM_OK) X.err = rsem_hip_last_error();
         });
         check_shards("rsem_model_get_values");
+        if (ofbMode >= 1) {
+            // the items as arrays; every value rounded through the 15-digit text form, so that .ofb == what .ofg parses to
+            const int ntb = N1 > 100000 ? hardware_threads() : 1;
+            std::vector<OfbPart> parts(ntb);
+            parallel_for(ntb, [&](int t) {
+                const uint64_t lo = N1 * t / ntb, hi = N1 * (t + 1) / ntb;
+                OfbPart& P = parts[t];
+                P.lens.reserve((size_t)(hi - lo));
+                P.sid.reserve((size_t)(dat.row_ptr[hi] - dat.row_ptr[lo] + (hi - lo)));
+                P.val.reserve((size_t)(dat.row_ptr[hi] - dat.row_ptr[lo] + (hi - lo)));
+                for (uint64_t i = lo; i < hi; i++) {
+                    uint32_t n = 0;
+                    if (ncp[i] >= kEpsilon) { ++n; P.sid.push_back(0); P.val.push_back(through_15_digits(ncp[i])); }
+                    for (uint64_t k = dat.row_ptr[i]; k < dat.row_ptr[i + 1]; k++)
+                        if (cp[k] >= kEpsilon) { ++n; P.sid.push_back(sid_abs[k]); P.val.push_back(through_15_digits(cp[k])); }
+                    if (n > 0) P.lens.push_back(n);  // (a read without items has no line in .ofg either)
+                }
+            });
+            write_ofb(imdName, M, N0, parts);
+        } else {
+            remove_ofb(imdName);  // never leave an older binary hand-off beside a fresh text one
+        }
         const std::string ofg_path = imdName + ".ofg";
+        if (ofbMode == 1) ::unlink(ofg_path.c_str());
         char head[64];
         const int head_n = snprintf(head, sizeof(head), "%d %llu\n", M, (unsigned long long)N0);
         // rows are formatted by all host threads into per-chunk buffers; every thread then writes its chunk at its own
         // offset of the file (the text is tens of GB at BASELINE sizes: one writer is page-cache bound)
-        const int nt = N1 > 100000 ? hardware_threads() : 1;
+        const int nt = ofbMode == 1 ? 0 : (N1 > 100000 ? hardware_threads() : 1);
         std::vector<std::string> bufs(nt);
         parallel_for(nt, [&](int t) {
             const uint64_t lo = N1 * t / nt, hi = N1 * (t + 1) / nt;
@@ -665,6 +694,7 @@ int main(int argc, char* argv[]) {
         });
         std::vector<uint64_t> at(nt + 1, (uint64_t)head_n);
         for (int t = 0; t < nt; t++) at[t + 1] = at[t] + bufs[t].size();
+        if (ofbMode != 1) {
         const int fd = ::open(ofg_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) die("Cannot open %s.ofg for writing!", imdName.c_str());
         bool wr_ok = ::pwrite(fd, head, head_n, 0) == head_n;
@@ -681,8 +711,9 @@ int main(int argc, char* argv[]) {
         });
         for (char o : okv) wr_ok = wr_ok && o;
         if (::close(fd) != 0 || !wr_ok) die("Cannot write %s.ofg!", imdName.c_str());
+        }
     }
-    lap("write .ofg");
+    lap(ofbMode == 1 ? "write .ofb" : (ofbMode == 2 ? "write .ofg + .ofb" : "write .ofg"));
     // ---- expected counts with the learned theta (EM.cpp:460-478) -------------------------------------------
     std::vector<double> w, w_noise;
     if (genBamF) { w.resize(nnz); w_noise.resize(N1); }

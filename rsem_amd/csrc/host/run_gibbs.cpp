@@ -19,6 +19,7 @@
 
 #include "../../../include/rsem_hip.h"
 #include "files.hpp"
+#include "ofb.hpp"
 #include "model_host.hpp"
 #include "posterior_moments.hpp"
 #include "results.hpp"
@@ -65,7 +66,9 @@ int main(int argc, char* argv[]) {
     // load_data (Gibbs.cpp:101-137)
     RefInfo refs = load_refs(refName + ".seq", false);
     const int M = refs.M;
-    OfgData ofg = load_ofg(imdName + ".ofg");
+    // imdName.ofb/ (rsem-run-em --gibbs-out with the binary hand-off, host/ofb.hpp): the same items, mapped; otherwise the
+    // reference's text file
+    OfgData ofg = ofb_present(imdName) ? load_ofb(imdName) : load_ofg(imdName + ".ofg");
     if (ofg.M != M) die("M in %s.ofg is not consistent with %s.seq!", imdName.c_str(), refName.c_str());
     const uint64_t N0 = ofg.N0, N1 = ofg.row_ptr.size() - 1;
     if (verbose) printf("Loading data is finished!\n");

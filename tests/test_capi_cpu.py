@@ -232,3 +232,20 @@ def test_model_file_reader_and_writer_reproduce_the_reference_files(tmp_path):
         assert filecmp.cmp(src, out, shallow=False), name
         n += 1
     assert n >= 9
+
+
+def test_gibbs_binary_handoff_equals_the_text_file(tmp_path):
+    """host/ofb.hpp (rsem-run-em --gibbs-out -> rsem-run-gibbs as arrays): the arrays are what a reader of imd.ofg gets --
+    values through the 15-digit text form -- on every fixture; a newer text file wins over an older directory."""
+    exe = os.path.join(str(tmp_path), "ofb_rt")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "ofb_roundtrip.cpp"), "-o", exe, "-lz", "-lpthread"])
+    gold = os.path.join(ROOT, "tests", "golden")
+    n = 0
+    for name in sorted(os.listdir(gold)):
+        src = os.path.join(gold, name, "temp", "s.ofg")
+        if not os.path.exists(src):
+            continue
+        r = subprocess.run([exe, src, os.path.join(str(tmp_path), name)], stdout=subprocess.PIPE, text=True)
+        assert r.returncode == 0 and r.stdout.startswith("ok"), (name, r.stdout)
+        n += 1
+    assert n >= 9

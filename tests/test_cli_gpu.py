@@ -334,3 +334,45 @@ def test_rsem_calculate_credibility_intervals_cli(name, tmp_path):
     _run(cmd)
     for f in res_files:
         assert open(imd + "." + f).read() == first[f]
+
+
+@pytest.mark.parametrize("name", ["se_q", "pe_noq"])
+def test_gibbs_binary_handoff_between_the_two_programs(name, tmp_path):
+    """rsem-run-em --gibbs-out with RSEM_HIP_BINARY=both writes imd.ofg AND imd.ofb/ (host/ofb.hpp); rsem-run-gibbs on
+    the arrays alone draws the chains it draws from the text: count-vector files byte-equal (and equal to the reference's,
+    when the EM run reproduces the golden .ofg)."""
+    fx, dst = _stage(name, tmp_path)
+    meta = rf.read_meta(fx)
+    rt = str(meta["model_type"])
+    imd = os.path.join(dst, "temp", "s")
+    env = dict(os.environ, RSEM_HIP_BINARY="both")
+    r = subprocess.run([os.path.join(BIN, "rsem-run-em"), os.path.join(dst, "ref"), rt, os.path.join(dst, "s"), imd, os.path.join(dst, "stat", "s"), "-p", "1",
+                        "--gibbs-out"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert os.path.exists(imd + ".ofb/hdr") and os.path.exists(imd + ".ofg")
+    M, N0, rp, sid, val = rf.read_ofg(imd + ".ofg")
+    brp = np.fromfile(imd + ".ofb/row_ptr", np.uint64)
+    assert np.array_equal(brp, rp) and np.array_equal(np.fromfile(imd + ".ofb/sid", np.int32), sid)
+    assert np.array_equal(np.fromfile(imd + ".ofb/val", np.float64), val)  # bit for bit what the text parses to
+    b, n, g = meta["gibbs"]
+    args = [os.path.join(BIN, "rsem-run-gibbs"), os.path.join(dst, "ref"), imd, os.path.join(dst, "stat", "s"), str(b), str(n), str(g),
+            "-p", str(meta["gibbs_threads"]), "--seed", str(meta["gibbs_seed"]), "-q"]
+    for f in ("iso_res", "gene_res"):
+        shutil.copy(imd + "." + f, imd + "." + f + ".keep")  # (rsem-run-gibbs appends its columns to these files)
+    def chains(tag):
+        for f in ("iso_res", "gene_res"):
+            shutil.copy(imd + "." + f + ".keep", imd + "." + f)
+        _run(args)
+        out = [open(imd + ".countvectors%d" % k, "rb").read() for k in range(meta["gibbs_threads"])]
+        return out
+    from_both = chains("both")       # .ofb present and not older than .ofg: the arrays are used
+    os.remove(imd + ".ofg")
+    from_arrays = chains("arrays")   # the arrays alone
+    shutil.rmtree(imd + ".ofb")
+    with open(imd + ".ofg", "w") as f:  # the text alone, rebuilt from what was parsed above
+        f.write("%d %d\n" % (M, N0))
+        for i in range(len(rp) - 1):
+            a, e = int(rp[i]), int(rp[i + 1])
+            f.write("".join("%d %.15g " % (sid[j], val[j]) for j in range(a, e)) + "\n")
+    from_text = chains("text")
+    assert from_both == from_arrays == from_text
