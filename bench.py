@@ -513,8 +513,8 @@ def main():
         if not args.no_stream:
             try:
                 rd, cp = capi.stream_probe(local, 8 << 30, 5)
-                stream = {"read_GBps": rd, "copy_GBps": cp, "how": "rsem_hip_stream_probe: 8 B/lane wave loads over 4 GiB (read) / 4 GiB -> 4 GiB (copy, "
-                          "read + written bytes counted), best of 5 launches, HIP events, in this process right after the timed region"}
+                stream = {"read_GBps": rd, "copy_GBps": cp, "how": "rsem_hip_stream_probe: 16 B/lane non-temporal wave loads over 4 GiB (read) / 4 GiB -> 4 GiB "
+                          "(copy, read + written bytes counted), best of 5 launches, HIP events, in this process right after the timed region"}
             except Exception as e:
                 stream = {"error": str(e)}
         line = {

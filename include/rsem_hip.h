@@ -41,7 +41,7 @@ int rsem_hip_warmup(int device);
 /* ABI version of this header: bumped on any signature change. */
 int rsem_hip_abi_version(void);
 /* Measurement aid ("also measure a device STREAM-copy and report both"): streams `bytes` of HBM
- * `reps` times with 8-byte-per-lane wave loads (the E step's access width) and reports the best rate seen, in GB/s
+ * `reps` times with 16-byte-per-lane non-temporal wave loads, eight in flight per lane, and reports the best rate seen, in GB/s
  * (1e9 bytes per second; copy counts bytes read + bytes written).  Nothing of the hot path depends on it. */
 int rsem_hip_stream_probe(int device, uint64_t bytes, int reps, double* read_GBps, double* copy_GBps);
 

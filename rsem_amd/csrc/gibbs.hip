@@ -59,7 +59,7 @@ __global__ void k_fill_double(int32_t n, double v, double* g) {
 
 // waves per SIMD the sweep kernel is compiled for (its register budget): 4 = what it needs unconstrained (100 VGPRs)
 #ifndef RSEM_GIBBS_MIN_WAVES
-#define RSEM_GIBBS_MIN_WAVES 4
+#define RSEM_GIBBS_MIN_WAVES 4  /* 5 (95 VGPRs, 2 spilled) measured the same: profiles/r03d_exact_sweep_bench.log */
 #endif
 constexpr int kGWindow = 2048;  // sids per workgroup window (g values: 16 KB, int counts: 8 KB of LDS)
 
@@ -480,29 +480,23 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
 #include "gibbs_exact_wg.hpp"
 
 template <bool kInit>
-__global__ __launch_bounds__(64 * kXW) void k_gibbs_exact_wg(uint32_t n_tiles, const uint32_t* __restrict__ tile_start,
-                                                            const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
-                                                            const double* __restrict__ cp, int32_t* counts_base, int32_t* z_base,
-                                                            double pseudoC, MtState* mt_base, const int32_t* __restrict__ last_round,
-                                                            int round, uint64_t stride_c, uint64_t stride_z, unsigned long long* prof) {
-    __shared__ XShared sh;
-    __shared__ XWaveLds wl[kXW];
+__global__ __launch_bounds__(kXT) void k_gibbs_exact_wg(uint32_t n_tiles, const uint32_t* __restrict__ tile_start,
+                                                        const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
+                                                        const double* __restrict__ cp, int32_t* counts_base, int32_t* z_base,
+                                                        double pseudoC, MtState* mt_base, const int32_t* __restrict__ last_round,
+                                                        int round, uint64_t stride_c, uint64_t stride_z, unsigned long long* prof) {
+    __shared__ XTile tile;
     const int chain = blockIdx.x;
     if (round > last_round[chain]) return;  // (uniform over the workgroup)
     MtState* mt_state = mt_base + chain;
-    for (int i = threadIdx.x; i < 624; i += blockDim.x) sh.mt[i] = mt_state->mt[i];
-    if (threadIdx.x == 0) {
-        sh.idx = mt_state->idx;
-        sh.next_tile = 0u;
-    }
+    for (int i = threadIdx.x; i < 624; i += blockDim.x) tile.mt[i] = mt_state->mt[i];
+    if (threadIdx.x == 0) tile.idx = mt_state->idx;
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    gibbs_exact_wg_body<kInit>(lane, w, &sh, &wl[w], n_tiles, tile_start, row_ptr, sid, cp, counts_base + (uint64_t)chain * stride_c,
+    gibbs_exact_wg_body<kInit>((int)threadIdx.x, &tile, n_tiles, tile_start, row_ptr, sid, cp, counts_base + (uint64_t)chain * stride_c,
                                z_base + (uint64_t)chain * stride_z, pseudoC, prof);
     __syncthreads();
-    for (int i = threadIdx.x; i < 624; i += blockDim.x) mt_state->mt[i] = sh.mt[i];
-    if (threadIdx.x == 0) mt_state->idx = sh.idx;
+    for (int i = threadIdx.x; i < 624; i += blockDim.x) mt_state->mt[i] = tile.mt[i];
+    if (threadIdx.x == 0) mt_state->idx = tile.idx;
 }
 
 constexpr int kSerialTileItems = 3072;
@@ -1159,8 +1153,8 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
 #define EXACT_WG_ARGS c->n_tiles, c->d_tiles, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->pseudoC, \
                       mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z, \
                       ((RSEM_GX_PROFILE && !init) ? prof_buf.as<unsigned long long>() : (unsigned long long*)nullptr)
-                if (init) hipLaunchKernelGGL(k_gibbs_exact_wg<true>, dim3(nchains), dim3(64 * kXW), 0, st, EXACT_WG_ARGS);
-                else hipLaunchKernelGGL(k_gibbs_exact_wg<false>, dim3(nchains), dim3(64 * kXW), 0, st, EXACT_WG_ARGS);
+                if (init) hipLaunchKernelGGL(k_gibbs_exact_wg<true>, dim3(nchains), dim3(kXT), 0, st, EXACT_WG_ARGS);
+                else hipLaunchKernelGGL(k_gibbs_exact_wg<false>, dim3(nchains), dim3(kXT), 0, st, EXACT_WG_ARGS);
 #undef EXACT_WG_ARGS
             } else if (impl == kExactSerial) {
                 if (init) hipLaunchKernelGGL(k_gibbs_exact_serial<true>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
@@ -1189,9 +1183,9 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             RSEM_HIP_TRY(hipMemcpyAsync(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost, st));
             RSEM_HIP_TRY(hipStreamSynchronize(st));
             const double tiles = h[7] ? (double)h[7] : 1.0;
-            fprintf(stderr, "[gibbs exact wg] shader-clock cycles per tile: prepare %.0f | wait for token %.0f | rng %.0f | gather %.0f | first draw %.0f | "
-                            "resolve %.0f (%.2f rounds) | commit + pass %.0f ; tiles %.0f\n",
-                    h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[5] / tiles, h[8] / tiles, h[6] / tiles, tiles);
+            fprintf(stderr, "[gibbs exact wg] shader-clock cycles per tile of <= %d reads: stage %.0f | own + hold + pred %.0f | rng + gather %.0f | first draw %.0f | "
+                            "resolve %.0f (%.2f rounds) | commit %.0f ; tiles %.0f\n",
+                    kXT, h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[8] / tiles, h[5] / tiles, tiles);
         }
         if (dbg & 4) {
             unsigned long long h4[4] = {0, 0, 0, 0};

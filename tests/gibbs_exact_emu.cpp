@@ -1,7 +1,7 @@
 // gibbs_exact_emu.cpp -- TEST INFRASTRUCTURE: runs rsem_amd/csrc/gibbs_exact_wg.hpp (the per-wave body of k_gibbs_exact_wg,
-// the workgroup-per-chain exact Gibbs sampler) on the CPU: one OS thread per lane, kXW waves per chain, the wave
-// synchronisation points as real barriers between the 64 threads of a wave, LDS / count atomics as CPU atomics, the token
-// as an atomic word.  Never part of the product.
+// the workgroup-per-chain exact Gibbs sampler) on the CPU: one OS thread per lane, kXW waves per chain, the workgroup
+// barriers and the wave synchronisation points as real barriers, LDS / count atomics as CPU atomics.  Never part of the
+// product.
 //
 //   gibbs_exact_emu in.bin out.bin     in:  i32 M, N1, rounds, seed, N0, pad, pad, pad; f64 pseudoC
 //                                           u64 row_ptr[N1+1]; i32 sid[n]; f64 cp[n]; i32 init_counts[M+1]
@@ -24,6 +24,7 @@ struct Wave {
 };
 thread_local int t_lane = 0;
 thread_local Wave* t_wave = nullptr;
+thread_local pthread_barrier_t* t_block = nullptr;
 inline void wave_sync() { pthread_barrier_wait(&t_wave->bar); }
 inline unsigned long long ballot(bool p) {
     t_wave->slot[t_lane] = p ? 1ull : 0ull;
@@ -39,21 +40,18 @@ inline unsigned long long ballot(bool p) {
 #define GX_DEVFN inline
 #define GX_HOSTDEVFN inline
 #define GX_WAVE_SYNC() emu::wave_sync()
+#define GX_BLOCK_SYNC() pthread_barrier_wait(emu::t_block)
 #define GX_BALLOT(p) emu::ballot(p)
 #define GX_LDS_OR64(p, v) (void)__atomic_fetch_or(p, v, __ATOMIC_RELAXED)
 #define GX_CNT_LOAD(p) __atomic_load_n(p, __ATOMIC_RELAXED)
 #define GX_CNT_ADD(p, v) (void)__atomic_fetch_add(p, v, __ATOMIC_RELAXED)
-#define GX_TOKEN_LOAD(p) __atomic_load_n(p, __ATOMIC_ACQUIRE)
-#define GX_TOKEN_STORE(p, v) __atomic_store_n(p, v, __ATOMIC_RELEASE)
 #define GX_WAIT_VM() __atomic_thread_fence(__ATOMIC_SEQ_CST)
-#define GX_SLEEP() sched_yield()
 #define __restrict__
 
 #include "../rsem_amd/csrc/gibbs_exact_wg.hpp"
 
 struct Machine {
-    XShared sh;
-    XWaveLds wl[kXW];
+    XTile tile;
     emu::Wave wave[kXW];
     pthread_barrier_t block_bar;
 };
@@ -86,9 +84,9 @@ int main(int argc, char** argv) {
 
     static Machine mc;
     // boost::random::mt19937 seeding (host_mt_seed of gibbs.hip)
-    mc.sh.mt[0] = seed;
-    for (int i = 1; i < 624; i++) mc.sh.mt[i] = 1812433253u * (mc.sh.mt[i - 1] ^ (mc.sh.mt[i - 1] >> 30)) + (uint32_t)i;
-    mc.sh.idx = 624;
+    mc.tile.mt[0] = seed;
+    for (int i = 1; i < 624; i++) mc.tile.mt[i] = 1812433253u * (mc.tile.mt[i - 1] ^ (mc.tile.mt[i - 1] >> 30)) + (uint32_t)i;
+    mc.tile.idx = 624;
     for (int w = 0; w < kXW; w++) pthread_barrier_init(&mc.wave[w].bar, nullptr, 64);
     pthread_barrier_init(&mc.block_bar, nullptr, 64 * kXW);
 
@@ -96,13 +94,14 @@ int main(int argc, char** argv) {
         const int lane = tid & 63, w = tid >> 6;
         emu::t_lane = lane;
         emu::t_wave = &mc.wave[w];
+        emu::t_block = &mc.block_bar;
+        (void)lane;
         for (int round = 0; round <= rounds; round++) {
-            if (tid == 0) mc.sh.next_tile = 0u;
             pthread_barrier_wait(&mc.block_bar);
             if (round == 0)
-                gibbs_exact_wg_body<true>(lane, w, &mc.sh, &mc.wl[w], n_tiles, tiles.data(), rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, nullptr);
+                gibbs_exact_wg_body<true>(tid, &mc.tile, n_tiles, tiles.data(), rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, nullptr);
             else
-                gibbs_exact_wg_body<false>(lane, w, &mc.sh, &mc.wl[w], n_tiles, tiles.data(), rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, nullptr);
+                gibbs_exact_wg_body<false>(tid, &mc.tile, n_tiles, tiles.data(), rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, nullptr);
             pthread_barrier_wait(&mc.block_bar);
             if (tid == 0 && round >= 1) memcpy(&out[(size_t)(round - 1) * (M + 1)], counts.data(), sizeof(int32_t) * (M + 1));
             pthread_barrier_wait(&mc.block_bar);

@@ -14,7 +14,7 @@ def available():
             and os.path.exists(os.path.join(REF_DIR, "rsem-run-em")))
 
 
-def run_pipeline(tmp, tag, fixture, programs, extra=()):
+def run_pipeline(tmp, tag, fixture, programs, extra=(), env=None):
     """-> directory holding s.isoforms.results, s.genes.results, s.stat/.  programs: drop-ins to take from rsem_amd/bin
     ([] = the reference's pipeline untouched)."""
     ov = os.path.join(tmp, "install_" + tag)
@@ -28,7 +28,7 @@ def run_pipeline(tmp, tag, fixture, programs, extra=()):
             shutil.copy(os.path.join(fx, f), work)
     cmd = [os.path.join(ov, "rsem-calculate-expression"), "--alignments"] + FIXTURES_WITH_SAM[fixture] + \
           ["-p", "2", "--no-bam-output", "--seed", "7"] + list(extra) + ["aln.sam", "ref", "s"]
-    r = subprocess.run(cmd, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    r = subprocess.run(cmd, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stdout[-3000:]
     return work, r.stdout
 

@@ -1,9 +1,9 @@
 """The per-wave body of the workgroup-per-chain exact Gibbs sampler (rsem_amd/csrc/gibbs_exact_wg.hpp -- the file gibbs.hip
-compiles for the GPU) run on the CPU by tests/gibbs_exact_emu.cpp: one OS thread per lane, eight waves, the token, the
-fixed-point rounds inside a tile.  Its count vectors after every sweep must be the oracle chain's (Gibbs.cpp:265-311 with
+compiles for the GPU) run on the CPU by tests/gibbs_exact_emu.cpp: one OS thread per lane, four waves, the phases between
+workgroup barriers, the fixed-point rounds inside a tile.  Its count vectors after every sweep must be the oracle chain's (Gibbs.cpp:265-311 with
 MT19937 and sampling.h's sample()) BIT FOR BIT -- on data built to collide: few transcripts, so that most reads of a tile
-share transcripts with earlier reads of the same tile, reads moving to and from the noise transcript, tiles of 64 / 32 /
-16 / 8 lanes (by their longest read), a read longer than a tile holds.  No GPU involved."""
+share transcripts with earlier reads of the same tile, reads moving to and from the noise transcript, tiles cut short
+by the item capacity, a read longer than a tile holds.  No GPU involved."""
 import os
 import shutil
 import subprocess
@@ -76,10 +76,10 @@ def _oracle(M, rp, sid, cp, init, rounds, seed, N0, pseudoC):
 CASES = [
     dict(seed=1, M=12, N1=1500, maxlen=6, noise_scale=0.3, rounds=4, N0=40, pseudoC=1.0),                     # everybody collides; noise moves
     dict(seed=2, M=300, N1=2500, maxlen=20, noise_scale=1e-3, rounds=3, N0=5, pseudoC=1.0),                   # gene-like, 64-read tiles
-    dict(seed=3, M=80, N1=900, maxlen=60, noise_scale=0.05, rounds=3, N0=0, pseudoC=0.1),                     # 32-lane tiles (reads of 33..64 items)
-    dict(seed=8, M=150, N1=500, maxlen=120, noise_scale=0.05, rounds=2, N0=3, pseudoC=1.0),                   # 16-lane tiles
-    dict(seed=9, M=100, N1=300, maxlen=250, noise_scale=0.05, rounds=2, N0=3, pseudoC=1.0),                   # 8-lane tiles; ids repeat inside a read
-    dict(seed=4, M=60, N1=700, maxlen=12, noise_scale=0.01, rounds=3, N0=7, pseudoC=1.0, long_read=1100),     # one read longer than a tile
+    dict(seed=3, M=80, N1=1200, maxlen=60, noise_scale=0.05, rounds=3, N0=0, pseudoC=0.1),                    # tiles cut by the item capacity
+    dict(seed=8, M=150, N1=500, maxlen=120, noise_scale=0.05, rounds=2, N0=3, pseudoC=1.0),                   # ~ 70 reads per tile
+    dict(seed=9, M=100, N1=300, maxlen=250, noise_scale=0.05, rounds=2, N0=3, pseudoC=1.0),                   # ids repeat inside a read
+    dict(seed=4, M=60, N1=700, maxlen=12, noise_scale=0.01, rounds=3, N0=7, pseudoC=1.0, long_read=4500),     # one read longer than a tile
     dict(seed=5, M=5, N1=130, maxlen=4, noise_scale=1.0, rounds=6, N0=3, pseudoC=1.0),                        # a last tile with few reads
 ]
 
