@@ -195,6 +195,9 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
 #pragma unroll
         for (int j = 0; j < kXW; j++) pred[j] = 0ull;
         bool has0 = false;  // the read carries the noise transcript (every read of an .ofg file does)
+        // bit k: item k of this read is the noise item, or some EARLIER thread's read carries its (hashed) id -- the only items
+        // an earlier move can touch; the resolve rounds walk these and nothing else (items past the 64th: always walked)
+        unsigned long long shared = 0ull;
         if (!kInit) {
             for (int k0 = 0; k0 < len; k0 += kXChunk) {
                 int s[kXChunk];
@@ -215,13 +218,19 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                 for (int j = 0; j < kXChunk; j++) s[j] = (k0 + j < len) ? L->sid[fr + k0 + j] : -1;
 #pragma unroll
                 for (int j = 0; j < kXChunk; j++)
-                    if (k0 + j < len && s[j] != 0) {
+                    if (k0 + j < len) {
+                        bool sh = s[j] == 0;
+                        if (s[j] != 0) {
 #pragma unroll
-                        for (int q = 0; q < kXW; q++) pred[q] |= L->hold[gx_slot(s[j])][q];
+                            for (int q = 0; q < kXW; q++) {
+                                const unsigned long long h = L->hold[gx_slot(s[j])][q] & before[q];
+                                pred[q] |= h;
+                                sh = sh || h != 0ull;
+                            }
+                        }
+                        if (sh && k0 + j < 64) shared |= 1ull << (k0 + j);
                     }
             }
-#pragma unroll
-            for (int q = 0; q < kXW; q++) pred[q] &= before[q];
         }
         lap(1);
         uint32_t* mt = L->mt;
@@ -361,14 +370,15 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                 lap(3);
                 bool hasd = false;  // some dl of this thread's items is not zero
                 for (;;) {
-                    unsigned long long M[kXW], NM[kXW];
+                    unsigned long long act[kXW], NM[kXW];  // moved predecessors that share a hashed id / that touch the noise id
                     bool any_moved = false, aff = hasd;
 #pragma unroll
                     for (int q = 0; q < kXW; q++) {
-                        M[q] = L->mm[q];
+                        const unsigned long long Mq = L->mm[q];
+                        act[q] = Mq & pred[q];
                         NM[q] = L->nmov[q] & before[q];
-                        any_moved = any_moved || M[q] != 0ull;
-                        aff = aff || (M[q] & pred[q]) != 0ull || (has0 && NM[q] != 0ull);
+                        any_moved = any_moved || Mq != 0ull;
+                        aff = aff || act[q] != 0ull || (has0 && NM[q] != 0ull);
                     }
                     if (!any_moved) break;  // (uniform) nobody moves: nothing to resolve, nothing to commit
                     if (RSEM_GX_PROFILE) pa[8] += 1;
@@ -377,35 +387,27 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                     bool dirty = false;
                     if (affected) {
                         bool nz = false;
-                        for (int k0 = 0; k0 < len; k0 += kXChunk) {
-                            int s[kXChunk], od[kXChunk];
+                        auto item = [&](int k) {
+                            const int sv = L->sid[fr + k];
+                            const int od = (int)L->dl[fr + k];
+                            int dd = 0;
 #pragma unroll
-                            for (int j = 0; j < kXChunk; j++) {
-                                const bool in = k0 + j < len;
-                                s[j] = in ? L->sid[fr + k0 + j] : -1;
-                                od[j] = in ? (int)L->dl[fr + k0 + j] : 0;
-                            }
-#pragma unroll
-                            for (int j = 0; j < kXChunk; j++) {
-                                int dd = 0;
-                                if (k0 + j < len) {
-#pragma unroll
-                                    for (int q = 0; q < kXW; q++) {
-                                        unsigned long long m = s[j] == 0 ? NM[q] : (L->hold[gx_slot(s[j])][q] & M[q] & before[q]);
-                                        while (m) {  // (rare: an earlier thread that moved AND carries this hashed id)
-                                            const int r1 = q * 64 + __builtin_ctzll(m);
-                                            m &= m - 1ull;
-                                            dd += (L->zn[r1] == s[j] ? 1 : 0) - (L->zo[r1] == s[j] ? 1 : 0);
-                                        }
-                                    }
+                            for (int q = 0; q < kXW; q++) {
+                                unsigned long long m = sv == 0 ? NM[q] : (act[q] != 0ull ? (L->hold[gx_slot(sv)][q] & act[q]) : 0ull);
+                                while (m) {  // an earlier thread that moved AND carries this hashed id
+                                    const int r1 = q * 64 + __builtin_ctzll(m);
+                                    m &= m - 1ull;
+                                    dd += (L->zn[r1] == sv ? 1 : 0) - (L->zo[r1] == sv ? 1 : 0);
                                 }
-                                if (dd != od[j]) {
-                                    L->dl[fr + k0 + j] = (signed char)dd;
-                                    dirty = true;
-                                }
-                                nz = nz || dd != 0;
                             }
-                        }
+                            if (dd != od) {
+                                L->dl[fr + k] = (signed char)dd;
+                                dirty = true;
+                            }
+                            nz = nz || dd != 0;
+                        };
+                        for (unsigned long long it = shared; it != 0ull; it &= it - 1ull) item(__builtin_ctzll(it));
+                        for (int k = 64; k < len; k++) item(k);
                         hasd = nz;
                     }
                     int z2 = z_new;

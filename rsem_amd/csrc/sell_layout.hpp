@@ -111,8 +111,18 @@ __host__ __device__ inline uint32_t mix32(uint32_t h, uint32_t v) {
 // The per-thread bodies of the construction kernels are host-callable functions: tests/simt_emu.hpp builds the layout on
 // the CPU with these very functions.
 //
-// sort key of read i = shape | smallest sid (capped) | hash of the sid tuple.  cp != nullptr: reads that qualify
-// (q32_scale_of) go to the Q32 twin of their shape.  *err: 1 row_ptr not monotone, 2 sid outside 1..M.
+// sort key of read i = shape | anchor sid (capped) | hash of the sid tuple.  The anchor says where the read's LDS window
+// should start: the smallest sid of the read that lies within kAnchorReach below its MEDIAN sid.  For a read whose
+// alignments all sit in one gene that is its smallest sid (the key of rounds 1-2); for a read that ALSO hits a few
+// transcripts of a far-away gene (paralogs, cross-gene multi-mappers) it is still its own gene's first isoform, wherever
+// the foreign ids lie -- with the plain minimum half of those reads sorted into the FOREIGN gene's neighbourhood and sent
+// all their own gene's counts through global atomics (configs[2] with 10 % such reads: 2.05 ms per E step instead of 0.97,
+// profiles/r03d_bench_default.json).  A layout hint only: ids outside a unit's window take the global path, whatever the key.
+// cp != nullptr: reads that qualify (q32_scale_of) go to the Q32 twin of their shape.  *err: 1 row_ptr not monotone,
+// 2 sid outside 1..M.
+constexpr int kLayoutWindow = 2048;               // ids per LDS window of the kernels that walk this layout (em.hip kWindow, gibbs.hip kGWindow)
+constexpr int kAnchorReach = kLayoutWindow / 2;
+constexpr int kMedianExactMax = 64; // reads up to this length: exact median (rank selection); longer: the middle position
 __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint64_t* __restrict__ row_ptr,
                                                const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits,
                                                int* err) {
@@ -131,6 +141,29 @@ __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint
             vmx = fmax(vmx, v);
             if (v > 0.0) vmn = fmin(vmn, v);
         }
+    }
+    const uint64_t L = to - fr;
+    if (L > 1 && !*err) {
+        uint32_t med = (uint32_t)sid[fr + L / 2];
+        if (L <= (uint64_t)kMedianExactMax) {
+            for (uint64_t j = fr; j < to; j++) {  // the sid with <= L/2 smaller ones and > L/2 smaller-or-equal ones
+                const uint32_t v = (uint32_t)sid[j];
+                uint32_t less = 0, leq = 0;
+                for (uint64_t k = fr; k < to; k++) {
+                    const uint32_t u = (uint32_t)sid[k];
+                    less += u < v ? 1u : 0u;
+                    leq += u <= v ? 1u : 0u;
+                }
+                if (less <= L / 2 && L / 2 < leq) { med = v; break; }
+            }
+        }
+        const uint32_t floor_sid = med > (uint32_t)kAnchorReach ? med - (uint32_t)kAnchorReach : 0u;
+        uint32_t lo = med;
+        for (uint64_t j = fr; j < to; j++) {
+            const uint32_t v = (uint32_t)sid[j];
+            if (v >= floor_sid && v < lo) lo = v;
+        }
+        mn = lo;
     }
     if (mn > kKeyMinSidCap) mn = kKeyMinSidCap;
     int shape = shape_id_of(to - fr);
@@ -251,7 +284,7 @@ __global__ void k_slice_masks(const Shape* __restrict__ shapes, int n_shapes, ui
     if (lane == 0) masks[s] = m;
 }
 
-// min sid of the read in row slot 0 of every slice (non-decreasing along the blocks of a shape)
+// anchor sid (row_key_of) of the read in row slot 0 of every slice (non-decreasing along the blocks of a shape)
 __global__ void k_slice_minsid(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_slices,
                                const uint64_t* __restrict__ keys_sorted, uint32_t* slice_minsid) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -264,9 +297,12 @@ __global__ void k_slice_minsid(const Shape* __restrict__ shapes, int n_shapes, u
     slice_minsid[s] = (uint32_t)((keys_sorted[S.row_base + q] >> 32) & kKeyMinSidCap);
 }
 
-// largest sid of every slice (for the extent of a unit's LDS windows)
+// largest sid of every slice that a window starting at the slice's own anchor could still hold (for the extent of a unit's
+// LDS windows: a unit starts at or below the anchors of its slices, so ids beyond anchor + window_cap are outside anyway,
+// and a far-away foreign id must not stretch the window of a small gene to the full capacity)
 __global__ void k_slice_maxsid(const Shape* __restrict__ shapes, int n_shapes, uint32_t n_slices,
-                               const int32_t* __restrict__ ssid, uint32_t* slice_maxsid) {
+                               const int32_t* __restrict__ ssid, const uint32_t* __restrict__ slice_minsid, int window_cap,
+                               uint32_t* slice_maxsid) {
     __shared__ Shape sh_shapes[kMaxShapes];
     for (int i = threadIdx.x; i < n_shapes; i += blockDim.x) sh_shapes[i] = shapes[i];
     __syncthreads();
@@ -278,7 +314,11 @@ __global__ void k_slice_maxsid(const Shape* __restrict__ shapes, int n_shapes, u
     const Shape S = sh_shapes[sh];
     uint64_t pl0 = (S.plane_base + (uint64_t)(s - S.slice_base) * S.K) * 64;
     int mx = 0;
-    for (int k = 0; k < S.K; k++) mx = max(mx, ssid[pl0 + (uint64_t)k * 64 + lane]);
+    const long long lim = (long long)slice_minsid[s] + window_cap;
+    for (int k = 0; k < S.K; k++) {
+        const int v = ssid[pl0 + (uint64_t)k * 64 + lane];
+        if ((long long)v < lim) mx = max(mx, v);
+    }
     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
     if (lane == 0) slice_maxsid[s] = (uint32_t)mx;
 }
@@ -426,7 +466,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
                            L.n_shapes, L.T, L.n_slices, d_keys2, L.d_slice_minsid);
         RSEM_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_slice_maxsid, dim3(rsem::ceil_div(L.n_slices, kBlock / 64)), dim3(kBlock), 0, st, L.d_shapes,
-                           L.n_shapes, L.n_slices, L.d_ssid, L.d_slice_maxsid);
+                           L.n_shapes, L.n_slices, L.d_ssid, L.d_slice_minsid, kLayoutWindow, L.d_slice_maxsid);
         RSEM_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_slice_masks, dim3(rsem::ceil_div(L.n_slices, kBlock / 64)), dim3(kBlock), 0, st,
                            L.d_shapes, L.n_shapes, L.T, L.n_slices, L.d_ssid, L.d_masks);
