@@ -491,6 +491,9 @@ __global__ __launch_bounds__(kXT) void k_gibbs_exact_wg(uint32_t n_tiles, const 
     MtState* mt_state = mt_base + chain;
     for (int i = threadIdx.x; i < 624; i += blockDim.x) tile.mt[i] = mt_state->mt[i];
     if (threadIdx.x == 0) tile.idx = mt_state->idx;
+    // the move-endpoint table starts out all zero (every resolve round leaves it that way)
+    for (int i = threadIdx.x; i < kXKeys * 2 * kXW; i += blockDim.x) (&tile.ends[0][0][0])[i] = 0ull;
+    for (int i = threadIdx.x; i < kXKeys; i += blockDim.x) tile.key[i] = 0;
     __syncthreads();
     gibbs_exact_wg_body<kInit>((int)threadIdx.x, &tile, n_tiles, tile_start, row_ptr, sid, cp, counts_base + (uint64_t)chain * stride_c,
                                z_base + (uint64_t)chain * stride_z, pseudoC, prof);
@@ -1183,7 +1186,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             RSEM_HIP_TRY(hipMemcpyAsync(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost, st));
             RSEM_HIP_TRY(hipStreamSynchronize(st));
             const double tiles = h[7] ? (double)h[7] : 1.0;
-            fprintf(stderr, "[gibbs exact wg] shader-clock cycles per tile of <= %d reads: stage %.0f | own + hold + pred %.0f | rng + gather %.0f | first draw %.0f | "
+            fprintf(stderr, "[gibbs exact wg] shader-clock cycles per tile of <= %d reads: stage %.0f | own flags %.0f | rng + gather %.0f | first draw %.0f | "
                             "resolve %.0f (%.2f rounds) | commit %.0f ; tiles %.0f\n",
                     kXT, h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[8] / tiles, h[5] / tiles, tiles);
         }

@@ -9,18 +9,17 @@
 // are cut into TILES of up to 256 consecutive reads and kXCap items (gx_build_tiles: a table built once per context, the cut
 // depends on the row pointers only).  The workgroup takes the tiles in file order, one read per thread, in phases separated
 // by workgroup barriers, so that every phase's latency is paid once per 256 reads:
-//   1. stage the tile (coalesced loads into LDS) and prepare what does not depend on the counts: which item is the read's
-//      current transcript, per hashed id the threads whose read carries it (`hold`), per thread the EARLIER threads that
-//      share an id with it (`pred`);
+//   1. stage the tile (coalesced loads into LDS) and mark which item is the read's current transcript;
 //   2. take the tile's MT19937 outputs (read r of the tile takes the r-th next output: the sequential order) and gather
 //      counts[sid] for the tile's items -- exact: every earlier tile has been committed;
 //   3. evaluate all reads at once, one read per thread;
 //   4. resolve the dependencies INSIDE the tile by fixed-point rounds: a thread's draw depends on the moves (z_old -> z_new)
-//      of EARLIER threads that touch one of its transcripts; every round the threads with a moved predecessor (the
-//      moved-threads masks ANDed with `pred`) recompute the deltas those moves apply to their items (`hold` finds the
-//      candidates, zo[] / zn[] decide exactly) and redraw with the SAME random number if a delta changed; a round in which
-//      no draw changes leaves every thread consistent with all earlier threads, which by induction over the thread index
-//      is the sequential chain's state (thread 0 depends on nobody);
+//      of EARLIER threads that touch one of its transcripts.  Every round the moving threads enter their two endpoints in an
+//      exact-keyed LDS hash table (per id: the threads that move TO it and the threads that move FROM it, as 256-bit masks);
+//      every thread looks its items up and gets each item's delta as two popcounts over the EARLIER threads' bits -- no
+//      loop over predecessors, whatever the number of reads of one hot gene in the tile -- and redraws with the SAME random
+//      number if a delta changed; a round in which no draw changes leaves every thread consistent with all earlier
+//      threads, which by induction over the thread index is the sequential chain's state (thread 0 depends on nobody);
 //   5. commit the moves (counts[z_old]--, counts[z_new]++, z[]).
 // Same visiting order, same left-to-right cumulative sums (one thread sums one read), same MT19937 stream as the reference:
 // the integer count vectors are the reference's, bit for bit.  Uniform pseudo count only: with --prior (per-transcript
@@ -29,7 +28,9 @@
 // History (profiles/r03b..r03d): a first design gave every wave its own 64-read tile and passed a token from tile to tile
 // (staging hidden behind the other waves' turns).  Its token section was one wave executing ~2500 dependent instructions
 // at ~16 cycles each -- 36-41 k cycles per 64 reads whatever the number of waves, the LDS layout (file order or
-// transposed) or the memory scope of the count updates.  Here the same instructions run in four waves side by side.
+// transposed) or the memory scope of the count updates.  Here the same instructions run in four waves side by side.  The
+// first block-synchronous version found an item's delta by walking the earlier moved threads that share its hashed id:
+// quadratic in the reads of a hot gene per tile, 72 k of 106 k cycles per 256-read tile at configs[2] (profiles/r03e, r03f).
 #pragma once
 #include <type_traits>
 #include <vector>
@@ -47,6 +48,8 @@
 #define GX_BLOCK_SYNC() __syncthreads()
 #define GX_BALLOT(p) __ballot(p)
 #define GX_LDS_OR64(p, v) (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define GX_LDS_CAS32(p, expected, desired) atomicCAS(p, expected, desired) /* returns the old value */
+#define GX_POPC64(x) __popcll(x)
 #define GX_CNT_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GX_CNT_ADD(p, v) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GX_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -55,20 +58,20 @@
 constexpr int kXW = 4;           // waves per chain
 constexpr int kXT = 64 * kXW;    // threads = reads per tile
 constexpr int kXCap = 4096;      // items per tile: 256 reads of 12.4 items (BASELINE configs[2]) = 3175 on average
-constexpr int kXSlots = 512;     // hashed transcript ids (the noise transcript, id 0, which every read carries, is kept apart)
+constexpr int kXKeys = 1024;     // entries of the move-endpoint table (at most 2 * kXT endpoints: load <= 0.5)
 constexpr int kXChunk = 16;      // items of a read handled per step with independent (pipelined) LDS reads
 constexpr int kXPlanes = kXCap / kXT;
 
-struct XTile {  // the workgroup's LDS: 97 KB of the CU's 160 KB
+struct XTile {  // the workgroup's LDS: 149 KB of the CU's 160 KB
     unsigned long long rp[kXT + 1];
-    unsigned long long hold[kXSlots][kXW];  // per hashed id (not the noise id 0): the threads whose read carries such an item
+    unsigned long long ends[kXKeys][2][kXW];  // per entry: the threads that move TO the id / FROM the id (all zero between rounds)
+    int32_t key[kXKeys];                      // id + 1 of the entry, 0 = free (all zero between rounds)
     double p[kXCap];
     int32_t sid[kXCap];
     int32_t c[kXCap];          // counts[sid] after every earlier tile, minus 1 where the read itself sits
-    int32_t zo[kXT], zn[kXT];
     signed char own[kXCap];    // 1: this item is its read's current transcript
-    signed char dl[kXCap];     // what the moves of EARLIER reads of the tile add to this item's count
-    unsigned long long mm[kXW], nmov[kXW], chg[kXW];
+    int16_t dl[kXCap];         // what the moves of EARLIER reads of the tile add to this item's count (-255 .. 255)
+    unsigned long long mm[kXW], chg[kXW];
     uint32_t mt[624];
     int idx;
 };
@@ -90,8 +93,8 @@ inline void gx_build_tiles(uint64_t N1, const uint64_t* row_ptr, std::vector<uin
 }
 
 // Phase profile (variant builds only, -DRSEM_GX_PROFILE=1; the product's kernel reads no timer): shader-clock cycles of
-// thread 0's wave summed into prof[0..5] = stage | own + hold + pred | random numbers + gather | first draw | resolve
-// rounds | commit; prof[7] = tiles, prof[8] = resolve rounds
+// thread 0's wave summed into prof[0..5] = stage | own flags | random numbers + gather | first draw | resolve rounds |
+// commit; prof[7] = tiles, prof[8] = resolve rounds
 #ifndef RSEM_GX_PROFILE
 #define RSEM_GX_PROFILE 0
 #endif
@@ -125,7 +128,8 @@ GX_DEVFN void gx_mt_regen(uint32_t* mt, int lane) {
     }
 }
 
-GX_DEVFN int gx_slot(int s) { return s & (kXSlots - 1); }
+GX_DEVFN unsigned gx_hash(int s) { return ((unsigned)s * 2654435761u) >> 22; }  // 10 bits: kXKeys entries
+static_assert(kXKeys == 1024, "gx_hash returns 10 bits");
 
 // One sweep over all reads in file order (Gibbs.cpp:297-311), or the initial assignment (Gibbs.cpp:281-291) when kInit.
 // Called by every thread of the chain's workgroup (g = 0 .. kXT-1); L->mt / L->idx hold the chain's generator.
@@ -156,10 +160,6 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
         const bool mine = g < nr;
         int z_old = 0;
         if (!kInit && mine) z_old = z[r0 + g];
-        if (!kInit) {
-#pragma unroll
-            for (int u = 0; u < kXSlots * kXW / kXT; u++) (&L->hold[0][0])[u * kXT + g] = 0ull;
-        }
         GX_BLOCK_SYNC();
         const uint64_t base = L->rp[0];
         const uint64_t T64 = L->rp[nr] - base;
@@ -190,47 +190,17 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
         int idx = L->idx;
         GX_BLOCK_SYNC();
         lap(0);
-        // ---- what does not depend on the counts --------------------------------------------------------------------------------
-        unsigned long long pred[kXW];  // the earlier threads of the tile whose read shares a (hashed) id with this one
-#pragma unroll
-        for (int j = 0; j < kXW; j++) pred[j] = 0ull;
-        bool has0 = false;  // the read carries the noise transcript (every read of an .ofg file does)
-        // bit k: item k of this read is the noise item, or some EARLIER thread's read carries its (hashed) id -- the only items
-        // an earlier move can touch; the resolve rounds walk these and nothing else (items past the 64th: always walked)
-        unsigned long long shared = 0ull;
+        // ---- which item is the read's current transcript (Gibbs.cpp:298: the read leaves it before it is weighed) -----------------
         if (!kInit) {
             for (int k0 = 0; k0 < len; k0 += kXChunk) {
-                int s[kXChunk];
+                int sv[kXChunk];
 #pragma unroll
-                for (int j = 0; j < kXChunk; j++) s[j] = (k0 + j < len) ? L->sid[fr + k0 + j] : -1;
-#pragma unroll
-                for (int j = 0; j < kXChunk; j++)
-                    if (k0 + j < len) {
-                        L->own[fr + k0 + j] = (signed char)(s[j] == z_old ? 1 : 0);
-                        if (s[j] != 0) GX_LDS_OR64(&L->hold[gx_slot(s[j])][w], 1ull << lane);
-                        else has0 = true;
-                    }
-            }
-            GX_BLOCK_SYNC();
-            for (int k0 = 0; k0 < len; k0 += kXChunk) {
-                int s[kXChunk];
-#pragma unroll
-                for (int j = 0; j < kXChunk; j++) s[j] = (k0 + j < len) ? L->sid[fr + k0 + j] : -1;
+                for (int j = 0; j < kXChunk; j++) sv[j] = (k0 + j < len) ? L->sid[fr + k0 + j] : -1;
 #pragma unroll
                 for (int j = 0; j < kXChunk; j++)
-                    if (k0 + j < len) {
-                        bool sh = s[j] == 0;
-                        if (s[j] != 0) {
-#pragma unroll
-                            for (int q = 0; q < kXW; q++) {
-                                const unsigned long long h = L->hold[gx_slot(s[j])][q] & before[q];
-                                pred[q] |= h;
-                                sh = sh || h != 0ull;
-                            }
-                        }
-                        if (sh && k0 + j < 64) shared |= 1ull << (k0 + j);
-                    }
+                    if (k0 + j < len) L->own[fr + k0 + j] = (signed char)(sv[j] == z_old ? 1 : 0);
             }
+            GX_BLOCK_SYNC();  // (the gather reads the flags item-major: other threads' items)
         }
         lap(1);
         uint32_t* mt = L->mt;
@@ -356,72 +326,93 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                 return L->sid[fr + l];
             };
             int z_new = mine ? draw(std::false_type{}) : z_old;
+            lap(3);
             if (!kInit) {
-                // the threads whose read moves, and those that move to or from the noise transcript (which is everybody's)
-                auto publish = [&]() {
-                    const bool mv = mine && z_new != z_old;
-                    const unsigned long long bm = GX_BALLOT(mv), bn = GX_BALLOT(mv && (z_old == 0 || z_new == 0));
-                    L->zo[g] = z_old;
-                    L->zn[g] = z_new;
-                    if (lane == 0) { L->mm[w] = bm; L->nmov[w] = bn; }
-                };
-                publish();
-                GX_BLOCK_SYNC();
-                lap(3);
-                bool hasd = false;  // some dl of this thread's items is not zero
+                // Rounds.  The table is all zero here (every round cleans up after itself).
                 for (;;) {
-                    unsigned long long act[kXW], NM[kXW];  // moved predecessors that share a hashed id / that touch the noise id
-                    bool any_moved = false, aff = hasd;
-#pragma unroll
-                    for (int q = 0; q < kXW; q++) {
-                        const unsigned long long Mq = L->mm[q];
-                        act[q] = Mq & pred[q];
-                        NM[q] = L->nmov[q] & before[q];
-                        any_moved = any_moved || Mq != 0ull;
-                        aff = aff || act[q] != 0ull || (has0 && NM[q] != 0ull);
+                    const bool mv = mine && z_new != z_old;
+                    const unsigned long long bm = GX_BALLOT(mv);
+                    if (lane == 0) L->mm[w] = bm;
+                    unsigned h_fr = 0, h_to = 0;  // this thread's entries
+                    if (mv) {
+                        // enter the two endpoints: claim a free entry or find the id's entry (linear probing; key = id + 1)
+                        auto enter = [&](int id, int dir) -> unsigned {
+                            unsigned h = gx_hash(id);
+                            for (;;) {
+                                const int old = GX_LDS_CAS32(&L->key[h], 0, id + 1);
+                                if (old == 0 || old == id + 1) break;
+                                h = (h + 1) & (kXKeys - 1);
+                            }
+                            GX_LDS_OR64(&L->ends[h][dir][w], 1ull << lane);
+                            return h;
+                        };
+                        h_fr = enter(z_old, 1);
+                        h_to = enter(z_new, 0);
                     }
-                    if (!any_moved) break;  // (uniform) nobody moves: nothing to resolve, nothing to commit
-                    if (RSEM_GX_PROFILE) pa[8] += 1;
-                    // only a thread with a moved predecessor (or with deltas left from a predecessor that moved back) has work
-                    const bool affected = mine && aff;
-                    bool dirty = false;
-                    if (affected) {
-                        bool nz = false;
-                        auto item = [&](int k) {
-                            const int sv = L->sid[fr + k];
-                            const int od = (int)L->dl[fr + k];
-                            int dd = 0;
+                    GX_BLOCK_SYNC();
+                    bool any_moved = false;
 #pragma unroll
-                            for (int q = 0; q < kXW; q++) {
-                                unsigned long long m = sv == 0 ? NM[q] : (act[q] != 0ull ? (L->hold[gx_slot(sv)][q] & act[q]) : 0ull);
-                                while (m) {  // an earlier thread that moved AND carries this hashed id
-                                    const int r1 = q * 64 + __builtin_ctzll(m);
-                                    m &= m - 1ull;
-                                    dd += (L->zn[r1] == sv ? 1 : 0) - (L->zo[r1] == sv ? 1 : 0);
+                    for (int q = 0; q < kXW; q++) any_moved = any_moved || L->mm[q] != 0ull;
+                    if (!any_moved) break;  // (uniform) nobody moves: the table is untouched, nothing to resolve or commit
+                    if (RSEM_GX_PROFILE) pa[8] += 1;
+                    // every item's delta: moves of EARLIER threads to its id minus moves from its id
+                    bool dirty = false;
+                    for (int k0 = 0; k0 < len; k0 += kXChunk) {
+                        int sv[kXChunk], od[kXChunk], kk[kXChunk];
+                        unsigned hh[kXChunk];
+#pragma unroll
+                        for (int j = 0; j < kXChunk; j++) {
+                            const bool in = k0 + j < len;
+                            sv[j] = in ? L->sid[fr + k0 + j] : -1;
+                            od[j] = in ? (int)L->dl[fr + k0 + j] : 0;
+                        }
+#pragma unroll
+                        for (int j = 0; j < kXChunk; j++) {
+                            hh[j] = gx_hash(sv[j]);
+                            kk[j] = (k0 + j < len) ? L->key[hh[j]] : 0;
+                        }
+#pragma unroll
+                        for (int j = 0; j < kXChunk; j++) {
+                            int dd = 0;
+                            if (k0 + j < len && kk[j] != 0) {  // (most items: a free entry at the first probe -- nobody moves to or from this id)
+                                unsigned h = hh[j];
+                                int kv = kk[j];
+                                while (kv != 0 && kv != sv[j] + 1) {
+                                    h = (h + 1) & (kXKeys - 1);
+                                    kv = L->key[h];
+                                }
+                                if (kv != 0) {
+#pragma unroll
+                                    for (int q = 0; q < kXW; q++)
+                                        dd += GX_POPC64(L->ends[h][0][q] & before[q]) - GX_POPC64(L->ends[h][1][q] & before[q]);
                                 }
                             }
-                            if (dd != od) {
-                                L->dl[fr + k] = (signed char)dd;
+                            if (dd != od[j]) {
+                                L->dl[fr + k0 + j] = (int16_t)dd;
                                 dirty = true;
                             }
-                            nz = nz || dd != 0;
-                        };
-                        for (unsigned long long it = shared; it != 0ull; it &= it - 1ull) item(__builtin_ctzll(it));
-                        for (int k = 64; k < len; k++) item(k);
-                        hasd = nz;
+                        }
                     }
                     int z2 = z_new;
                     if (dirty) z2 = draw(std::true_type{});
                     const unsigned long long ch = GX_BALLOT(mine && z2 != z_new);
                     z_new = z2;
                     if (lane == 0) L->chg[w] = ch;
-                    GX_BLOCK_SYNC();  // every thread has read zo / zn / mm of this round
+                    GX_BLOCK_SYNC();  // every thread has finished its look-ups
+                    if (mv) {          // leave the table as it was found: all zero
+#pragma unroll
+                        for (int q = 0; q < kXW; q++) {
+                            L->ends[h_fr][0][q] = 0ull; L->ends[h_fr][1][q] = 0ull;
+                            L->ends[h_to][0][q] = 0ull; L->ends[h_to][1][q] = 0ull;
+                        }
+                        L->key[h_fr] = 0;
+                        L->key[h_to] = 0;
+                    }
                     bool any_changed = false;
 #pragma unroll
                     for (int q = 0; q < kXW; q++) any_changed = any_changed || L->chg[q] != 0ull;
+                    GX_BLOCK_SYNC();  // the table is clean again (and chg / mm may be rewritten)
                     if (!any_changed) break;  // (uniform) every thread is consistent with all earlier threads
-                    publish();
-                    GX_BLOCK_SYNC();
                 }
                 lap(4);
                 if (mine && z_new != z_old) {

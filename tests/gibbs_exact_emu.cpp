@@ -43,6 +43,8 @@ inline unsigned long long ballot(bool p) {
 #define GX_BLOCK_SYNC() pthread_barrier_wait(emu::t_block)
 #define GX_BALLOT(p) emu::ballot(p)
 #define GX_LDS_OR64(p, v) (void)__atomic_fetch_or(p, v, __ATOMIC_RELAXED)
+#define GX_LDS_CAS32(p, expected, desired) __sync_val_compare_and_swap(p, expected, desired)
+#define GX_POPC64(x) __builtin_popcountll(x)
 #define GX_CNT_LOAD(p) __atomic_load_n(p, __ATOMIC_RELAXED)
 #define GX_CNT_ADD(p, v) (void)__atomic_fetch_add(p, v, __ATOMIC_RELAXED)
 #define GX_WAIT_VM() __atomic_thread_fence(__ATOMIC_SEQ_CST)
@@ -87,6 +89,8 @@ int main(int argc, char** argv) {
     mc.tile.mt[0] = seed;
     for (int i = 1; i < 624; i++) mc.tile.mt[i] = 1812433253u * (mc.tile.mt[i - 1] ^ (mc.tile.mt[i - 1] >> 30)) + (uint32_t)i;
     mc.tile.idx = 624;
+    memset(mc.tile.ends, 0, sizeof(mc.tile.ends));  // (the kernel wrapper clears the move-endpoint table once per launch)
+    memset(mc.tile.key, 0, sizeof(mc.tile.key));
     for (int w = 0; w < kXW; w++) pthread_barrier_init(&mc.wave[w].bar, nullptr, 64);
     pthread_barrier_init(&mc.block_bar, nullptr, 64 * kXW);
 
