@@ -329,6 +329,7 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
             lap(3);
             if (!kInit) {
                 // Rounds.  The table is all zero here (every round cleans up after itself).
+                unsigned long long nzmask = 0ull;  // bit k: dl of this thread's item k (< 64) is not zero
                 for (;;) {
                     const bool mv = mine && z_new != z_old;
                     const unsigned long long bm = GX_BALLOT(mv);
@@ -339,7 +340,8 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                         auto enter = [&](int id, int dir) -> unsigned {
                             unsigned h = gx_hash(id);
                             for (;;) {
-                                const int old = GX_LDS_CAS32(&L->key[h], 0, id + 1);
+                                int old = L->key[h];  // (a hot id has many movers: all but the first find it with a plain read)
+                                if (old == 0) old = GX_LDS_CAS32(&L->key[h], 0, id + 1);
                                 if (old == 0 || old == id + 1) break;
                                 h = (h + 1) & (kXKeys - 1);
                             }
@@ -355,44 +357,43 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                     for (int q = 0; q < kXW; q++) any_moved = any_moved || L->mm[q] != 0ull;
                     if (!any_moved) break;  // (uniform) nobody moves: the table is untouched, nothing to resolve or commit
                     if (RSEM_GX_PROFILE) pa[8] += 1;
-                    // every item's delta: moves of EARLIER threads to its id minus moves from its id
+                    // every item's delta: moves of EARLIER threads to its id minus moves from its id.  First find the items whose id
+                    // MAY have an entry (first probe not free; pipelined reads), then walk those -- and the items that still carry
+                    // a delta from an earlier round (`nzmask`) -- one at a time: most items are neither.
                     bool dirty = false;
-                    for (int k0 = 0; k0 < len; k0 += kXChunk) {
-                        int sv[kXChunk], od[kXChunk], kk[kXChunk];
-                        unsigned hh[kXChunk];
+                    unsigned long long todo = nzmask;
+                    for (int k0 = 0; k0 < len && k0 < 64; k0 += kXChunk) {
+                        int sv[kXChunk], kk[kXChunk];
 #pragma unroll
-                        for (int j = 0; j < kXChunk; j++) {
-                            const bool in = k0 + j < len;
-                            sv[j] = in ? L->sid[fr + k0 + j] : -1;
-                            od[j] = in ? (int)L->dl[fr + k0 + j] : 0;
-                        }
+                        for (int j = 0; j < kXChunk; j++) sv[j] = (k0 + j < len) ? L->sid[fr + k0 + j] : -1;
 #pragma unroll
-                        for (int j = 0; j < kXChunk; j++) {
-                            hh[j] = gx_hash(sv[j]);
-                            kk[j] = (k0 + j < len) ? L->key[hh[j]] : 0;
-                        }
+                        for (int j = 0; j < kXChunk; j++) kk[j] = (k0 + j < len) ? L->key[gx_hash(sv[j])] : 0;
 #pragma unroll
-                        for (int j = 0; j < kXChunk; j++) {
-                            int dd = 0;
-                            if (k0 + j < len && kk[j] != 0) {  // (most items: a free entry at the first probe -- nobody moves to or from this id)
-                                unsigned h = hh[j];
-                                int kv = kk[j];
-                                while (kv != 0 && kv != sv[j] + 1) {
-                                    h = (h + 1) & (kXKeys - 1);
-                                    kv = L->key[h];
-                                }
-                                if (kv != 0) {
-#pragma unroll
-                                    for (int q = 0; q < kXW; q++)
-                                        dd += GX_POPC64(L->ends[h][0][q] & before[q]) - GX_POPC64(L->ends[h][1][q] & before[q]);
-                                }
-                            }
-                            if (dd != od[j]) {
-                                L->dl[fr + k0 + j] = (int16_t)dd;
-                                dirty = true;
-                            }
-                        }
+                        for (int j = 0; j < kXChunk; j++)
+                            if (kk[j] != 0) todo |= 1ull << (k0 + j);
                     }
+                    auto item = [&](int k) {
+                        const int sv = L->sid[fr + k];
+                        unsigned h = gx_hash(sv);
+                        int kv = L->key[h];
+                        while (kv != 0 && kv != sv + 1) {
+                            h = (h + 1) & (kXKeys - 1);
+                            kv = L->key[h];
+                        }
+                        int dd = 0;
+                        if (kv != 0) {
+#pragma unroll
+                            for (int q = 0; q < kXW; q++)
+                                dd += GX_POPC64(L->ends[h][0][q] & before[q]) - GX_POPC64(L->ends[h][1][q] & before[q]);
+                        }
+                        if (dd != (int)L->dl[fr + k]) {
+                            L->dl[fr + k] = (int16_t)dd;
+                            dirty = true;
+                        }
+                        if (k < 64) nzmask = dd != 0 ? (nzmask | (1ull << k)) : (nzmask & ~(1ull << k));
+                    };
+                    for (; todo != 0ull; todo &= todo - 1ull) item(__builtin_ctzll(todo));
+                    for (int k = 64; k < len; k++) item(k);  // (reads longer than 64 items: every further item, every round)
                     int z2 = z_new;
                     if (dirty) z2 = draw(std::true_type{});
                     const unsigned long long ch = GX_BALLOT(mine && z2 != z_new);
