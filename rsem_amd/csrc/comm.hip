@@ -121,30 +121,41 @@ int comm_world(const rsem_comm* c) { return c ? c->world : 1; }
 
 static int local_exchange(rsem_comm* c, double* d_buf, size_t n, hipStream_t st, bool all, int root) {
     LocalGroup* g = c->grp;
-    RSEM_HIP_TRY(hipSetDevice(c->device));
-    if (c->scratch_n < n) {
+    // A failure on one rank must not leave the others waiting at a barrier: every rank arrives at BOTH barriers whatever
+    // happened to it, the failure is recorded in the group, and every rank returns an error after the second barrier.
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess && c->scratch_n < n) {
         (void)hipFree(c->d_scratch);
         c->d_scratch = nullptr;
-        RSEM_HIP_TRY(hipMalloc((void**)&c->d_scratch, sizeof(double) * n));
-        c->scratch_n = n;
+        c->scratch_n = 0;
+        e = hipMalloc((void**)&c->d_scratch, sizeof(double) * n);
+        if (e == hipSuccess) c->scratch_n = n;
     }
-    RSEM_HIP_TRY(hipStreamSynchronize(st));  // this rank's contribution is complete
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // this rank's contribution is complete
     g->bufs[c->rank] = d_buf;
+    if (e != hipSuccess) { std::lock_guard<std::mutex> lk(g->mu); g->failed = true; }
     g->barrier();                            // ... and so is everybody else's
-    hipError_t e = hipSuccess;
-    if (all || c->rank == root) {
+    bool group_failed;
+    { std::lock_guard<std::mutex> lk(g->mu); group_failed = g->failed; }
+    if (!group_failed && (all || c->rank == root)) {
         e = hipMemcpyAsync(c->d_ptrs, g->bufs.data(), sizeof(double*) * g->world, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_sum_bufs, dim3(ceil_div(n, 256)), dim3(256), 0, st, n, g->world, (double* const*)c->d_ptrs, c->d_scratch);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { std::lock_guard<std::mutex> lk(g->mu); g->failed = true; }
     }
     g->barrier();                            // every reader is done with the peers' buffers
-    if (e == hipSuccess && (all || c->rank == root))
+    { std::lock_guard<std::mutex> lk(g->mu); group_failed = g->failed; }
+    if (!group_failed && (all || c->rank == root))
         e = hipMemcpyAsync(d_buf, c->d_scratch, sizeof(double) * n, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) {
         set_last_error("local exchange: %s", hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? RSEM_ERR_NOMEM : RSEM_ERR_HIP;
+    }
+    if (group_failed) {
+        set_last_error("local exchange: another rank of the group failed");
         return RSEM_ERR_HIP;
     }
     return RSEM_OK;
@@ -246,7 +257,7 @@ int rsem_comm_create_local(rsem_comm** out, int world, const int* devices) {
         if (e != hipSuccess) {
             rsem::set_last_error("rsem_comm_create_local: %s", hipGetErrorString(e));
             if (c) { (void)hipFree(c->d_ptrs); delete c; }
-            for (int q = 0; q < r; q++) { (void)hipFree(out[q]->d_ptrs); delete out[q]; out[q] = nullptr; }
+            for (int q = 0; q < r; q++) { (void)hipSetDevice(devices[q]); (void)hipFree(out[q]->d_ptrs); delete out[q]; out[q] = nullptr; }
             delete g;
             return RSEM_ERR_HIP;
         }

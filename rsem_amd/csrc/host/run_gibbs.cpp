@@ -2,7 +2,7 @@
 //
 //   rsem-run-gibbs refName imdName statName BURNIN NSAMPLES GAP [-p N] [--seed s] [--pseudo-count a]
 //                  [--prior file] [-q]   + ignored-by-the-reference extras:
-//                  [--gibbs-mode exact|parallel] [--gibbs-thin k] [--device d | --devices d0,d1,..]
+//                  [--gibbs-mode auto|exact|parallel] [--gibbs-thin k] [--device d | --devices d0,d1,..]
 //
 // -p N keeps its meaning "N independent chains, N count-vector files" (Gibbs.cpp:211-226, calcCI opens one
 // file per thread).  The chains are dealt to the available GPUs; a GPU advances all of its chains together (one wave
@@ -29,7 +29,7 @@ using namespace rsemh;
 int main(int argc, char* argv[]) {
     if (argc < 7) {
         printf("Usage: rsem-run-gibbs reference_name imdName statName BURNIN NSAMPLES GAP [-p #Threads] [--seed seed] "
-               "[--pseudo-count pseudo_count] [--prior file] [-q] [--gibbs-mode exact|parallel] [--gibbs-thin k] [--device d]\n");
+               "[--pseudo-count pseudo_count] [--prior file] [-q] [--gibbs-mode auto|exact|parallel] [--gibbs-thin k] [--device d]\n");
         exit(-1);
     }
     const std::string refName = argv[1], imdName = argv[2], statName = argv[3];
@@ -148,9 +148,30 @@ int main(int argc, char* argv[]) {
     // of a GPU advancing together; parallel = the data-augmentation sampler for the same posterior (every sweep fills
     // the GPU; the chains of a GPU run one after the other).
     int mode;
-    if (mode_s == "exact" || mode_s == "auto") mode = RSEM_GIBBS_EXACT;
+    // auto (the default): the reference's own chains (exact) unless they would take more than kAutoExactLimitS here -- a chain
+    // is a workgroup and costs about kExactUsPerVisit per read visit whatever the number of chains (up to one per CU;
+    // DESIGN.md section 5), so the estimate is rounds x reads x that.  The choice is printed and recorded in
+    // <statName>.gibbs_sampler; --gibbs-mode exact / parallel overrule it.
+    constexpr double kExactUsPerVisit = 0.12, kAutoExactLimitS = 1800.0;
+    const int rounds_per_chain = BURNIN + 1 + ((NSAMPLES + nThreads - 1) / nThreads - 1) * GAP;
+    const int chains_per_gpu = (nThreads + nworkers - 1) / nworkers;
+    const double est_exact_s = (double)rounds_per_chain * (double)N1 * kExactUsPerVisit * 1e-6 * (double)((chains_per_gpu + 255) / 256);
+    if (mode_s == "exact") mode = RSEM_GIBBS_EXACT;
     else if (mode_s == "parallel") mode = RSEM_GIBBS_PARALLEL;
-    else die("rsem-run-gibbs: unknown --gibbs-mode '%s' (exact, parallel or auto)", mode_s.c_str());
+    else if (mode_s == "auto") {
+        mode = est_exact_s <= kAutoExactLimitS ? RSEM_GIBBS_EXACT : RSEM_GIBBS_PARALLEL;
+        if (mode == RSEM_GIBBS_PARALLEL)
+            fprintf(stderr, "rsem-run-gibbs: the reference's chains would take about %.0f s here (%d rounds x %llu reads); using the data-augmentation "
+                            "sampler for the same posterior instead (--gibbs-mode exact forces the reference's chains)\n",
+                    est_exact_s, rounds_per_chain, (unsigned long long)N1);
+    } else die("rsem-run-gibbs: unknown --gibbs-mode '%s' (exact, parallel or auto)", mode_s.c_str());
+    if (!dry_run) {
+        if (FILE* fs = fopen((statName + ".gibbs_sampler").c_str(), "w")) {
+            fprintf(fs, "sampler %s\nrequested %s\nestimated_exact_seconds %.1f\nrounds_per_chain %d\nchains %d\ngpu_groups %d\n",
+                    mode == RSEM_GIBBS_EXACT ? "exact" : "parallel", mode_s.c_str(), est_exact_s, rounds_per_chain, nThreads, nworkers);
+            fclose(fs);
+        }
+    }
     if (thin <= 0) thin = (mode == RSEM_GIBBS_PARALLEL) ? 8 : 1;
     if (mode == RSEM_GIBBS_PARALLEL)  // never silently: these draws are a different Markov chain than the reference's
         fprintf(stderr, "rsem-run-gibbs: data-augmentation sampler (--gibbs-mode parallel), %d sweeps per round\n", thin);
