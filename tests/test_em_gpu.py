@@ -300,7 +300,7 @@ def test_device_loops_equal_kernel_per_step_loop(loop, monkeypatch):
     ctx.close()
 
 
-@pytest.mark.parametrize("config,scale", [("tinyX", 1.0), ("tinyR", 1.0), ("C3X", 0.01)])
+@pytest.mark.parametrize("config,scale", [("C3X", 0.01), ("C2R", 0.02), ("smallX", 1.0)])
 def test_foreign_side_path(config, scale, monkeypatch):
     """Alignments whose id lies outside their unit's LDS window (reads that also hit another gene; inputs without gene
     structure) leave the E step: listed at layout time, sorted by id, added by k_foreign_counts from theta * conprb /
