@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
     const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, const unsigned char* __restrict__ sval,
     const int16_t* __restrict__ sexp, const int32_t* __restrict__ ssid, const double* __restrict__ sncp,
     const unsigned long long* __restrict__ masks, double* counts, double* noise_partial, double* totals, const Ctrl* ctrl,
-    unsigned long long* trace, SoloArgs solo = SoloArgs(), double* inv_out = nullptr) {
+    unsigned long long* trace, SoloArgs solo = SoloArgs()) {
     if (ctrl->done) return;
     if (trace && threadIdx.x == 0) trace[2 * blockIdx.x] = wall_clock64();  // rsem_em_debug_trace only
     __shared__ double th_win[kWindow];
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
         const uint32_t s_begin = S.slice_base + U.slice_begin + (uint32_t)w * U.per_wave;
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
 #define RSEM_ESTEP_BLOCK(KK, QQ) \
-    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1])>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M, inv_out)
+    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1])>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M)
         if (s_begin < u_end) switch (S.K + 4 * S.fmt) {  // (uniform over the workgroup)
             case 1: RSEM_ESTEP_BLOCK(1, false); break;
             case 2: RSEM_ESTEP_BLOCK(2, false); break;
@@ -438,106 +438,6 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
     }
     block_add_totals(noise, neff, noise_partial, totals);
     if (trace && threadIdx.x == 0) trace[2 * blockIdx.x + 1] = wall_clock64();
-}
-
-// ---- the foreign side path -------------------------------------------------------------------------------------------------
-// An alignment whose id lies outside its unit's LDS window costs a scattered theta load and -- per run of equal tuples -- a
-// global fp64 atomic; this device does ~22-28 G of those per second whatever their scope or placement
-// (profiles/r03h_exact_final_and_atomics.log), against 250+ G/s into LDS.  Reads that also hit a few transcripts of another
-// gene, or inputs without gene structure, are bound by that.  When more than 1 in 500 alignments are of this kind they are
-// LISTED at layout time (id, row slot, plane entry), sorted by id, and their reads flagged (sign bit of the noise slot);
-// the E step then drops their counts and exports 1 / normaliser of the flagged reads, and k_foreign_counts adds
-// theta * conprb / normaliser for the list: neighbouring threads hold the same id, a wave reduces its runs and issues
-// one atomic per run.
-struct ForeignEntry {
-    int32_t sid;
-    uint32_t slot;
-    uint64_t ent;  // entry within the shape's value planes | bit 63: Q32 shape; the shape's val_base is added at fill time
-};
-
-// pass 0: count; pass 1: write the list.  One workgroup per unit, as the E step walks it.
-template <bool kFill>
-__global__ __launch_bounds__(kBlock) void k_foreign_scan(const Unit* __restrict__ units, uint32_t T, const int32_t* __restrict__ ssid,
-                                                         unsigned long long* counter, int32_t* f_sid, uint32_t* f_slot, uint64_t* f_ent,
-                                                         unsigned long long* sncp_bits) {
-    const Unit U = units[blockIdx.x];
-    const Shape& S = U.S;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t u_end = U.slice_begin + U.n_slices;
-    const uint32_t s_begin = U.slice_begin + (uint32_t)w * U.per_wave;
-    const uint32_t s_end = min(u_end, s_begin + U.per_wave);
-    const uint32_t R = shape_R(S);
-    (void)T;
-    for (uint32_t sl = s_begin; sl < s_end; sl++) {  // slice index within the shape
-        for (int k = 0; k < S.K; k++) {
-            const uint64_t local = ((uint64_t)sl * S.K + k) * 64 + lane;
-            const int32_t v = ssid[S.plane_base * 64 + local];
-            const bool f = v > 0 && (unsigned)(v - U.base) >= (unsigned)U.span;
-            const unsigned long long b = __ballot(f);
-            if (b == 0ull) continue;
-            unsigned long long at = 0;
-            if (lane == 0) at = atomicAdd(counter, (unsigned long long)__popcll(b));
-            at = __shfl(at, 0);
-            if (kFill && f) {
-                const unsigned long long i = at + __popcll(b & ((1ull << lane) - 1ull));
-                const uint32_t slot = S.slot_base + sl * R + ((uint32_t)lane >> S.lg);
-                f_sid[i] = v;
-                f_slot[i] = slot;
-                f_ent[i] = (S.val_base + local * (S.fmt == kFmtQ32 ? 4ull : 8ull)) | (S.fmt == kFmtQ32 ? (1ull << 63) : 0ull);  // byte offset into sval
-                atomicOr(&sncp_bits[slot], 1ull << 63);
-            }
-        }
-    }
-}
-
-// after the noise slots were rewritten (set_values): flag the reads of the list again
-__global__ void k_foreign_flag(uint64_t n, const uint32_t* __restrict__ f_slot, unsigned long long* sncp_bits) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicOr(&sncp_bits[f_slot[i]], 1ull << 63);
-}
-
-__global__ void k_foreign_gather(uint64_t n, const uint32_t* __restrict__ order, const uint32_t* __restrict__ slot_in,
-                                 const uint64_t* __restrict__ ent_in, uint32_t* slot_out, uint64_t* ent_out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t o = order[i];
-    slot_out[i] = slot_in[o];
-    ent_out[i] = ent_in[o];
-}
-
-// counts[sid] += theta[sid] * conprb / normaliser(read) for the listed alignments (sorted by sid); the E step's clamp
-// (terms under 1e-300 count as zero, EM.cpp:212) applies to theta * conprb as there
-template <bool kFC>
-__global__ __launch_bounds__(kBlock) void k_foreign_counts(uint64_t n, const int32_t* __restrict__ f_sid, const uint32_t* __restrict__ f_slot,
-                                                           const uint64_t* __restrict__ f_ent, const unsigned char* __restrict__ sval,
-                                                           const int16_t* __restrict__ sexp, const double* __restrict__ inv,
-                                                           const double* __restrict__ theta, const double* __restrict__ tsrc, double N0,
-                                                           double* counts, const Ctrl* ctrl) {
-    if (ctrl->done) return;
-    const int lane = threadIdx.x & 63;
-    const ThetaSrc th = theta_src<kFC>(theta, tsrc, N0, lane);
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int sidv = -1 - lane;  // (past the end: a run of its own that adds nothing)
-    double v = 0.0;
-    if (i < n) {
-        sidv = f_sid[i];
-        const uint64_t e = f_ent[i];
-        const uint32_t slot = f_slot[i];
-        double val;
-        if (e >> 63) val = (double)*(const uint32_t*)(sval + (e & ~(1ull << 63))) * pow2_of((int)sexp[slot]);
-        else val = *(const double*)(sval + e);
-        double f = theta_at<kFC>(th, sidv) * val;
-        if (f < kEpsilon) f = 0.0;
-        v = f * inv[slot];
-    }
-    // segmented sum over the wave's runs of equal ids (the list is sorted): every run's first lane ends with its total
-    for (int d = 1; d < 64; d <<= 1) {
-        const double o = __shfl_down(v, d);
-        const int so = __shfl_down(sidv, d);
-        if (lane + d < 64 && so == sidv) v += o;
-    }
-    const int prev = __shfl_up(sidv, 1);
-    if (i < n && (lane == 0 || prev != sidv) && v != 0.0) unsafeAtomicAdd(&counts[sidv], v);
 }
 
 // ---- M step ----------------------------------------------------------------------------------
@@ -881,13 +781,6 @@ struct rsem_em_ctx {
     int value_range_bits = 8;         // a read qualifies when its non-zero values span less than 2^this
     bool layout_has_q32 = false;      // the current layout was built with Q32 shapes (from the then-current values)
     bool layout_ok = false;           // false between free_layout and a build_layout that went through (a failed rebuild)
-    // foreign side path (k_foreign_scan / k_foreign_counts): the alignments outside their unit's LDS window, sorted by id
-    uint64_t n_foreign = 0;           // 0: path off (out-of-window ids take global atomics inside the E step)
-    int32_t* d_f_sid = nullptr;
-    uint32_t* d_f_slot = nullptr;
-    uint64_t* d_f_ent = nullptr;
-    double* d_inv = nullptr;          // 1 / normaliser of the flagged reads, by row slot
-    int foreign_mode = -1;            // -1 auto (on above 1 in 500 alignments), 0 off, 1 on whenever there is one
     // LANE variant work list
     Unit* d_units = nullptr;
     unsigned long long* d_trace = nullptr;  // per-workgroup timestamps (tune_unit_order, rsem_em_debug_trace)
@@ -931,21 +824,6 @@ int resolved_kernel(const rsem_em_ctx* c) {
     return c->kernel == RSEM_EM_KERNEL_AUTO ? RSEM_EM_KERNEL_LANE : c->kernel;
 }
 
-__global__ void k_iota_u32(uint64_t n, uint32_t* out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (uint32_t)i;
-}
-// the counts of the foreign list, after an E-step launch that dropped them (kFC: theta from the previous round's counts)
-template <bool kFC>
-int launch_foreign(rsem_em_ctx* c, const double* theta, const double* tsrc, double N0, double* counts, hipStream_t st) {
-    if (!c->n_foreign) return RSEM_OK;
-    hipLaunchKernelGGL(k_foreign_counts<kFC>, dim3(rsem::ceil_div(c->n_foreign, kBlock)), dim3(kBlock), 0, st, c->n_foreign, (const int32_t*)c->d_f_sid,
-                       (const uint32_t*)c->d_f_slot, (const uint64_t*)c->d_f_ent, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp,
-                       (const double*)c->d_inv, theta, tsrc, N0, counts, (const Ctrl*)c->d_ctrl);
-    RSEM_HIP_TRY(hipGetLastError());
-    return RSEM_OK;
-}
-
 int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStream_t st, bool use_ctrl) {
     const Ctrl* ctrl = c->d_ctrl;
     const int kern = resolved_kernel(c);
@@ -962,10 +840,7 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
         if (c->n_units)
             hipLaunchKernelGGL((k_estep_lane<false, false>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
                                d_theta, (const double*)nullptr, 0.0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid,
-                               c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs(),
-                               c->n_foreign ? c->d_inv : nullptr);
-        int frc = launch_foreign<false>(c, d_theta, nullptr, 0.0, d_counts, st);
-        if (frc != RSEM_OK) return frc;
+                               c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs());
     } else {
         if (c->layout_has_q32) { rsem::set_last_error("the SELL kernel reads F64 planes only (value_bits = 32 needs the LANE kernel)"); return RSEM_ERR_STATE; }
         hipLaunchKernelGGL(k_estep_sell, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
@@ -1013,15 +888,11 @@ int launch_mstep(rsem_em_ctx* c, double N0, double* d_counts, const double* d_th
 
 int build_layout(rsem_em_ctx* c);
 void free_layout(rsem_em_ctx* c);
+
 int write_values(rsem_em_ctx* c) {
     if (c->d_fill_err) RSEM_HIP_TRY(hipMemsetAsync(c->d_fill_err, 0, sizeof(int), c->stream));
     int rc = sell_fill_values(c->L, c->stream, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_sval, c->d_sncp, c->d_sexp, c->d_fill_err);
     if (rc != RSEM_OK) return rc;
-    if (c->n_foreign) {  // the noise slots were rewritten: flag the reads of the foreign list again
-        hipLaunchKernelGGL(k_foreign_flag, dim3(rsem::ceil_div(c->n_foreign, kBlock)), dim3(kBlock), 0, c->stream, c->n_foreign,
-                           (const uint32_t*)c->d_f_slot, (unsigned long long*)c->d_sncp);
-        RSEM_HIP_TRY(hipGetLastError());
-    }
     if (c->layout_has_q32) {  // a Q32 shape was handed a read that no longer qualifies: cannot happen after a rebuild
         int h = 0;
         RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_fill_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1046,74 +917,10 @@ void free_layout(rsem_em_ctx* c) {
     sell_free(c->L);
     hipFree(c->d_sval); hipFree(c->d_sncp); hipFree(c->d_sexp); hipFree(c->d_fill_err); hipFree(c->d_units); hipFree(c->d_noise_a);
     c->d_sval = nullptr; c->d_sncp = nullptr; c->d_sexp = nullptr; c->d_fill_err = nullptr; c->d_units = nullptr; c->d_noise_a = nullptr;
-    hipFree(c->d_f_sid); hipFree(c->d_f_slot); hipFree(c->d_f_ent); hipFree(c->d_inv);
-    c->d_f_sid = nullptr; c->d_f_slot = nullptr; c->d_f_ent = nullptr; c->d_inv = nullptr;
-    c->n_foreign = 0;
     c->h_units.clear();
     c->n_units = 0;
     c->layout_has_q32 = false;
     c->layout_ok = false;
-}
-
-// List the alignments whose id lies outside their unit's window (see k_foreign_scan); no-op below the threshold.
-int build_foreign(rsem_em_ctx* c) {
-    c->n_foreign = 0;
-    if (c->foreign_mode == 0 || c->n_units == 0 || resolved_kernel(c) != RSEM_EM_KERNEL_LANE) return RSEM_OK;
-    hipStream_t st = c->stream;
-    unsigned long long* d_cnt = nullptr;
-    RSEM_HIP_TRY(dmalloc(&d_cnt, 1));
-    struct Free { void* p; ~Free() { (void)hipFree(p); } } free_cnt{d_cnt};
-    RSEM_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_foreign_scan<false>, dim3(c->n_units), dim3(kBlock), 0, st, (const Unit*)c->d_units, c->L.T, (const int32_t*)c->L.d_ssid, d_cnt,
-                       (int32_t*)nullptr, (uint32_t*)nullptr, (uint64_t*)nullptr, (unsigned long long*)nullptr);
-    RSEM_HIP_TRY(hipGetLastError());
-    unsigned long long n = 0;
-    RSEM_HIP_TRY(hipMemcpyAsync(&n, d_cnt, sizeof(n), hipMemcpyDeviceToHost, st));
-    RSEM_HIP_TRY(hipStreamSynchronize(st));
-    const unsigned long long threshold = c->foreign_mode == 1 ? 1ull : std::max<unsigned long long>(4096ull, c->nnz / 500);
-    if (n < threshold || n >= 0xfffffff0ull) return RSEM_OK;
-    int32_t *sid_a = nullptr, *sid_b = nullptr;
-    uint32_t *slot_a = nullptr, *ord_a = nullptr, *ord_b = nullptr;
-    uint64_t* ent_a = nullptr;
-    void* tmp = nullptr;
-    auto cleanup = [&]() { (void)hipFree(sid_a); (void)hipFree(slot_a); (void)hipFree(ent_a); (void)hipFree(ord_a); (void)hipFree(ord_b); (void)hipFree(tmp); };
-    struct Guard { decltype(cleanup)& f; ~Guard() { f(); } } guard{cleanup};
-    RSEM_HIP_TRY(dmalloc(&sid_a, n)); RSEM_HIP_TRY(dmalloc(&sid_b, n));
-    RSEM_HIP_TRY(dmalloc(&slot_a, n)); RSEM_HIP_TRY(dmalloc(&ent_a, n));
-    RSEM_HIP_TRY(dmalloc(&ord_a, n)); RSEM_HIP_TRY(dmalloc(&ord_b, n));
-    c->d_f_sid = sid_b;  // (owned by the ctx from here on: free_layout releases it)
-    RSEM_HIP_TRY(dmalloc(&c->d_f_slot, n)); RSEM_HIP_TRY(dmalloc(&c->d_f_ent, n));
-    RSEM_HIP_TRY(dmalloc(&c->d_inv, (size_t)c->L.n_slots));
-    RSEM_HIP_TRY(hipMemsetAsync(c->d_inv, 0, sizeof(double) * c->L.n_slots, st));
-    RSEM_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_foreign_scan<true>, dim3(c->n_units), dim3(kBlock), 0, st, (const Unit*)c->d_units, c->L.T, (const int32_t*)c->L.d_ssid, d_cnt,
-                       sid_a, slot_a, ent_a, (unsigned long long*)c->d_sncp);
-    RSEM_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_iota_u32, dim3(rsem::ceil_div(n, kBlock)), dim3(kBlock), 0, st, (uint64_t)n, ord_a);
-    size_t tb = 0;
-    RSEM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, sid_a, sid_b, ord_a, ord_b, n, 0, 32, st));
-    RSEM_HIP_TRY(hipMalloc(&tmp, tb ? tb : 1));
-    RSEM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, sid_a, sid_b, ord_a, ord_b, n, 0, 32, st));
-    hipLaunchKernelGGL(k_foreign_gather, dim3(rsem::ceil_div(n, kBlock)), dim3(kBlock), 0, st, (uint64_t)n, (const uint32_t*)ord_b, (const uint32_t*)slot_a,
-                       (const uint64_t*)ent_a, c->d_f_slot, c->d_f_ent);
-    RSEM_HIP_TRY(hipGetLastError());
-    RSEM_HIP_TRY(hipStreamSynchronize(st));
-    c->n_foreign = n;
-    return RSEM_OK;
-}
-
-// drop the foreign list, rewrite the (then unflagged) noise slots, list again under the current kernel / mode
-int refresh_foreign(rsem_em_ctx* c) {
-    RSEM_HIP_TRY(hipSetDevice(c->device));
-    RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
-    hipFree(c->d_f_sid); hipFree(c->d_f_slot); hipFree(c->d_f_ent); hipFree(c->d_inv);
-    c->d_f_sid = nullptr; c->d_f_slot = nullptr; c->d_f_ent = nullptr; c->d_inv = nullptr;
-    c->n_foreign = 0;
-    if (c->have_values) {
-        int rc = write_values(c);
-        if (rc != RSEM_OK) return rc;
-    }
-    return build_foreign(c);
 }
 
 int build_layout(rsem_em_ctx* c) {
@@ -1153,8 +960,6 @@ int build_layout(rsem_em_ctx* c) {
     RSEM_HIP_TRY(hipMemsetAsync(c->d_noise_a, 0, sizeof(double) * c->noise_cap, c->stream));
 
     c->grid_long = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_long_rows, kBlock)));
-    rc = build_foreign(c);
-    if (rc != RSEM_OK) return rc;
     c->layout_ok = true;
     return RSEM_OK;
 }
@@ -1307,17 +1112,9 @@ int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
     RSEM_REQUIRE(c && key, "NULL argument");
     if (!strcmp(key, "kernel")) {
         RSEM_REQUIRE(value >= RSEM_EM_KERNEL_AUTO && value <= RSEM_EM_KERNEL_LANE, "unknown kernel variant");
-        const bool was_lane = resolved_kernel(c) == RSEM_EM_KERNEL_LANE;
         c->kernel = (int)value;
         set_grid_for_kernel(c);
-        if (c->layout_ok && was_lane != (resolved_kernel(c) == RSEM_EM_KERNEL_LANE)) return refresh_foreign(c);  // only the LANE kernel knows the flags
         return RSEM_OK;
-    }
-    if (!strcmp(key, "foreign_side_path")) {  // -1 auto (above 1 in 500 alignments), 0 off, 1 on whenever an alignment leaves its window
-        RSEM_REQUIRE(value >= -1 && value <= 1, "foreign_side_path must be -1, 0 or 1");
-        if (c->foreign_mode == (int)value) return RSEM_OK;
-        c->foreign_mode = (int)value;
-        return c->layout_ok ? refresh_foreign(c) : RSEM_OK;
     }
     if (!strcmp(key, "value_bits") || !strcmp(key, "value_range_bits")) {
         // Format of the value planes the theta-only E step streams (sell_layout.hpp): 64 = the caller's doubles; 32 = a
@@ -1357,7 +1154,6 @@ int rsem_em_get_info(const rsem_em_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "sid_plane_bytes")) *value = (int64_t)(c->L.n_planes * 256);
     else if (!strcmp(key, "slots")) *value = c->L.n_slots;
     else if (!strcmp(key, "units")) *value = c->n_units;
-    else if (!strcmp(key, "foreign_alignments")) *value = (int64_t)c->n_foreign;            // listed for the side path (0: path off)
     else { rsem::set_last_error("unknown info key '%s'", key); return RSEM_ERR_INVALID; }
     return RSEM_OK;
 }
@@ -1395,7 +1191,6 @@ int rsem_em_destroy(rsem_em_ctx* c) {
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     hipFree(c->d_row_ptr); hipFree(c->d_sid); hipFree(c->d_cp); hipFree(c->d_ncp);
     sell_free(c->L); hipFree(c->d_sval); hipFree(c->d_sncp); hipFree(c->d_sexp); hipFree(c->d_fill_err);
-    hipFree(c->d_f_sid); hipFree(c->d_f_slot); hipFree(c->d_f_ent); hipFree(c->d_inv);
     hipFree(c->d_theta[0]); hipFree(c->d_theta[1]); hipFree(c->d_red3);
     for (int i = 0; i < 4; i++) { if (c->ev_e[i]) (void)hipEventDestroy(c->ev_e[i]); if (c->ev_s[i]) (void)hipEventDestroy(c->ev_s[i]); }
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -1581,10 +1376,7 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
             } else {
                 hipLaunchKernelGGL((k_estep_lane<true, true>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
                                    (const double*)src, (const double*)(src + c->M + 1), N0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
-                                   c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, sa, c->n_foreign ? c->d_inv : nullptr);
-                RSEM_HIP_TRY(hipGetLastError());
-                rc = launch_foreign<true>(c, src, src + c->M + 1, N0, dst, st);
-                if (rc != RSEM_OK) return rc;
+                                   c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, sa);
             }
             RSEM_HIP_TRY(hipGetLastError());
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));
@@ -1595,10 +1387,8 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[2 + 2 * ti], st));
             hipLaunchKernelGGL((k_estep_lane<true, false>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
                                (const double*)src, (const double*)(src + c->M + 1), N0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
-                               c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, SoloArgs(), c->n_foreign ? c->d_inv : nullptr);
+                               c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, SoloArgs());
             RSEM_HIP_TRY(hipGetLastError());
-            rc = launch_foreign<true>(c, src, src + c->M + 1, N0, dst, st);
-            if (rc != RSEM_OK) return rc;
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));
             if (sharded) {  // EM.cpp:385-389 across shards
                 rc = rsem::comm_allreduce_sum_f64(c->comm, dst, R, st);

@@ -114,10 +114,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
                                    const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, double* th_win, double* cnt_win,
                                    const unsigned char* __restrict__ sval, const int16_t* __restrict__ sexp, const int32_t* __restrict__ ssid,
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
-                                   double* counts, double& noise, double& neff, int M, double* inv_out) {
-    // inv_out != nullptr ("foreign side path", em.hip build_foreign): alignments whose id lies outside this unit's LDS window are
-    // NOT accumulated here -- a second kernel adds theta * conprb / normaliser for them, sorted by id, without one global
-    // atomic per alignment -- and the reads that carry such an alignment (sign bit of their noise slot) export 1 / normaliser.
+                                   double* counts, double& noise, double& neff, int M) {
     using ValT = typename std::conditional<kQ, uint32_t, double>::type;
     const ValT* __restrict__ scp = (const ValT*)(sval + S.val_base);  // this shape's value planes
     const int lg = S.lg;
@@ -163,7 +160,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
             if (acc[k] != 0.0) {
                 const unsigned off = (unsigned)(rsid[k] - base);
                 if (off < (unsigned)span) RSEM_LDS_ADD(&cnt_win[off], acc[k]);
-                else if (inv_out == nullptr) RSEM_ATOMIC_ADD(&counts[rsid[k]], acc[k]);
+                else RSEM_ATOMIC_ADD(&counts[rsid[k]], acc[k]);
             }
             acc[k] = 0.0;
         }
@@ -175,7 +172,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
     for (int k = 0; k < K; k++) { rsid[k] = 0; rth[k] = 0.0; acc[k] = 0.0; }
     ThetaSrc th{theta, 0.0, 1.0};
     double th0 = 0.0;
-    auto reduce = [&](const SliceRegs<K, kQ>& cur, unsigned long long cur_m, uint32_t t) {
+    auto reduce = [&](const SliceRegs<K, kQ>& cur, unsigned long long cur_m) {
         if (cur_m != 0ull) {                 // wave-uniform
             if ((cur_m >> lane) & 1ull) {    // lanes whose read starts a new sid tuple
                 spill(rsid, acc);
@@ -188,8 +185,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
                 }
             }
         }
-        const bool flagged = RSEM_DOUBLE_AS_LL(cur.nc) < 0;  // (sign bit: only ever set when the side path is on)
-        double f0 = th0 * fabs(cur.nc);
+        double f0 = th0 * cur.nc;
         if (f0 < kEpsilon) f0 = 0.0;
         double f[K];
         double part = f0;
@@ -205,7 +201,6 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         }
         part = read_sum_dpp(part, lg);
         const double inv = (part >= kEpsilon) ? 1.0 / part : 0.0;
-        if (inv_out != nullptr && flagged) inv_out[S.slot_base + (t - S.slice_base) * R + uslot] = inv;  // (the read's first lane only: the others hold nc = +0)
         noise += f0 * inv;
         // reads whose fractions sum to one: sum(counts) without a reduction
         neff += (g0 && part >= kEpsilon) ? 1.0 : 0.0;
@@ -225,13 +220,13 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
                 mB = mask_of(s + 1);
                 issue(s + 1, mB, B);
             }
-            reduce(A, mA, s);
+            reduce(A, mA);
             if (s + 1 >= s_end) break;
             if (s + 2 < s_end) {
                 mA = mask_of(s + 2);
                 issue(s + 2, mA, A);
             }
-            reduce(B, mB, s + 1);
+            reduce(B, mB);
         }
     } else {
         // ring of NBUF register sets (fully unrolled: every index is static): NBUF - 1 slices in flight while one is reduced
@@ -259,7 +254,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
                         mk[nj] = mask_of(t + ahead);
                         issue(t + ahead, mk[nj], buf[nj]);
                     }
-                    reduce(buf[j], mk[j], t);
+                    reduce(buf[j], mk[j]);
                 }
             }
         }

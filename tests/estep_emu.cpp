@@ -5,7 +5,7 @@
 // table, the Q32 rule); what is being tested is the kernel body: lane -> (read, position) mapping, prefetch rings, Q32
 // arithmetic, reductions over a read's lanes, spills, the compile-time variants.  Never part of the product.
 //
-//   estep_emu in.bin out.bin        in:  i32 M, N1, T, side (0/1: foreign side path), q32 (0/1), range_bits, from_counts (0/1), window; f64 N0
+//   estep_emu in.bin out.bin        in:  i32 M, N1, T, policy, q32 (0/1), range_bits, from_counts (0/1), pad; f64 N0
 //                                        u64 row_ptr[N1+1]; i32 sid[nnz]; f64 cp[nnz]; f64 ncp[N1]; f64 theta[M+1]
 //                                   out: f64 counts[M+1] (without N0), f64 noise total, f64 reads with a non-zero normaliser
 // Build (tests/test_estep_emu_cpu.py): hipcc -DRSEM_EMU [-DRSEM_F64_DEPTHS=... -DRSEM_Q32_DEPTHS=...] tests/estep_emu.cpp -lpthread
@@ -30,7 +30,6 @@ struct Job {
     double* counts;
     double* tot_noise;
     double* tot_neff;
-    double* inv_out;  // the foreign side path (hdr[3] = 1): 1 / normaliser of the flagged reads, by row slot; else nullptr
     double th_win[kWindow], cnt_win[kWindow];
     emu::Block blk;
 };
@@ -50,7 +49,7 @@ static void lane_body(Job* J, int tid) {
     double noise = 0.0, neff = 0.0;
 #define EMU_BLOCK(KK, QQ)                                                                                                          \
     estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1])>(S, s_begin, s_end, lane, J->base, J->span, J->theta, tsrc, J->N0, \
-        J->th_win, J->cnt_win, H.sval.data(), H.sexp.data(), H.ssid.data(), H.sncp.data(), H.masks.data(), J->counts, noise, neff, J->M, J->inv_out)
+        J->th_win, J->cnt_win, H.sval.data(), H.sexp.data(), H.ssid.data(), H.sncp.data(), H.masks.data(), J->counts, noise, neff, J->M)
     if (s_begin < u_end) switch (S.K + 4 * S.fmt) {
         case 1: EMU_BLOCK(1, false); break;
         case 2: EMU_BLOCK(2, false); break;
@@ -96,13 +95,6 @@ int main(int argc, char** argv) {
     build_layout(H, M, N1, rp.data(), sid.data(), cp.data(), ncp.data(), hdr[3], hdr[4] != 0, hdr[5]);
     std::vector<double> counts((size_t)M + 1, 0.0);
     double tot_noise = 0.0, tot_neff = 0.0;
-    // hdr[3] = 1: the foreign side path of em.hip (build_foreign / k_foreign_counts), restated on the host around the kernel
-    // body: entries whose id lies outside their unit's window are listed, their reads flagged (sign bit of the noise slot),
-    // the body drops those entries' counts and exports 1 / normaliser, and the list is added afterwards.
-    const bool side = hdr[3] == 1;
-    struct Foreign { int32_t sid; uint32_t slot; uint64_t plane_entry; int fmt; uint64_t val_base; };
-    std::vector<Foreign> foreign;
-    std::vector<double> inv(H.sncp.size(), 0.0);
     Job* J = new Job();
     pthread_barrier_init(&J->blk.bar, nullptr, 256);
     for (int w = 0; w < 4; w++) pthread_barrier_init(&J->blk.w[w].bar, nullptr, 64);
@@ -125,42 +117,9 @@ int main(int argc, char** argv) {
             J->counts = counts.data();
             J->tot_noise = &tot_noise;
             J->tot_neff = &tot_neff;
-            J->inv_out = side ? inv.data() : nullptr;
-            if (side) {
-                const uint32_t R = shape_R(S);
-                for (uint32_t sl = b0; sl < b0 + J->n_slices; sl++)
-                    for (int k = 0; k < S.K; k++)
-                        for (int l = 0; l < 64; l++) {
-                            const uint64_t local = ((uint64_t)sl * S.K + k) * 64 + l;  // entry within the shape's planes
-                            const int32_t v = H.ssid[S.plane_base * 64 + local];
-                            if (v > 0 && (unsigned)(v - J->base) >= (unsigned)J->span) {
-                                const uint32_t slot = S.slot_base + sl * R + ((uint32_t)l >> S.lg);
-                                foreign.push_back(Foreign{v, slot, local, S.fmt, S.val_base});
-                                H.sncp[slot] = -fabs(H.sncp[slot]);
-                            }
-                        }
-            }
             std::vector<std::thread> th;
             for (int t = 0; t < 256; t++) th.emplace_back(from_counts ? lane_body<true> : lane_body<false>, J, t);
             for (auto& t : th) t.join();
-        }
-    }
-    if (side) {
-        double extra0 = 0.0, sum = 1.0;
-        if (from_counts) {
-            double a = 0.0, b = 0.0;
-            for (int i = 0; i < kTotSlots; i++) { a += theta[M + 1 + i]; b += theta[M + 1 + kTotSlots + i]; }
-            extra0 = a + N0;
-            sum = b + N0;
-        }
-        for (const Foreign& e : foreign) {
-            const double th = from_counts ? (theta[e.sid] + (e.sid == 0 ? extra0 : 0.0)) / sum : theta[e.sid];
-            double val;
-            if (e.fmt == kFmtQ32) val = (double)((const uint32_t*)(H.sval.data() + e.val_base))[e.plane_entry] * std::ldexp(1.0, (int)H.sexp[e.slot]);
-            else val = ((const double*)(H.sval.data() + e.val_base))[e.plane_entry];
-            double v = th * val;
-            if (v < kEpsilon) v = 0.0;
-            counts[e.sid] += v * inv[e.slot];
         }
     }
     f = fopen(argv[2], "wb");

@@ -300,49 +300,26 @@ def test_device_loops_equal_kernel_per_step_loop(loop, monkeypatch):
     ctx.close()
 
 
-@pytest.mark.parametrize("config,scale", [("C3X", 0.01), ("C2R", 0.02), ("smallX", 1.0)])
-def test_foreign_side_path(config, scale, monkeypatch):
-    """Alignments whose id lies outside their unit's LDS window (reads that also hit another gene; inputs without gene
-    structure) leave the E step: listed at layout time, sorted by id, added by k_foreign_counts from theta * conprb /
-    normaliser (em.hip build_foreign).  Off, forced on and automatic give the oracle's step; whole runs in all three loops
-    the oracle's ROUND count and theta; Q32 planes and a values update (set_values) keep working."""
+@pytest.mark.parametrize("config,scale", [("C3X", 0.01), ("smallX", 1.0)])
+def test_reads_that_also_hit_another_gene(config, scale, monkeypatch):
+    """10-30 % of the reads also hit 1-3 transcripts of a far-away gene (paralogs, cross-gene multi-mappers): their layout key
+    is the anchor id (sell_layout.hpp row_key_of), the foreign ids take the out-of-window path.  Step and whole runs (all
+    three loops) against the oracle, F64 and Q32 planes."""
     wl = make_em_workload(config, scale=scale, seed=11)
     M = wl["M"]
     oc = orc.em_estep(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["theta0"])
     oc[0] += wl["N0"]
     ctx = capi().EmContext(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
-    listed = {}
-    for mode in (0, 1, -1):
-        ctx.set_option("foreign_side_path", mode)
-        listed[mode] = ctx.info("foreign_alignments")
-        counts, *_ = ctx.step(wl["theta0"], wl["N0"])
-        assert np.allclose(counts, oc, rtol=1e-9, atol=1e-9), mode
-    assert listed[0] == 0 and listed[1] > 0 and listed[-1] in (0, listed[1])
-    ctx.set_option("foreign_side_path", 1)
+    counts, *_ = ctx.step(wl["theta0"], wl["N0"])
+    assert np.allclose(counts, oc, rtol=1e-9, atol=1e-9)
     oth, orounds, _, _ = orc.em_run(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["N0"], wl["theta0"], max_round=300)
     for loop in ("0", "1", "2"):  # kernel sequence, statistics on a second stream, one launch per round
         monkeypatch.setenv("RSEM_EM_FUSED", loop)
         out = ctx.run(wl["theta0"], wl["N0"], max_round=300)
         assert out["rounds"] == orounds and np.allclose(out["theta"], oth, rtol=1e-6, atol=1e-12), loop
     monkeypatch.delenv("RSEM_EM_FUSED")
-    # other kernels never see the flags
-    for kern in (1, 2, 3):
-        ctx.set_option("kernel", kern)
-        counts, *_ = ctx.step(wl["theta0"], wl["N0"])
-        assert np.allclose(counts, oc, rtol=1e-9, atol=1e-9), kern
-    ctx.set_option("kernel", 0)
-    # new values (rounds 1-11 of rsem-run-em call this every round): the flags survive the refill
-    cp2, ncp2 = wl["conprb"] * 0.5, wl["ncp"] * 2.0
-    ctx.set_values(cp2, ncp2)
-    oc2 = orc.em_estep(M, wl["row_ptr"], wl["sid"], cp2, ncp2, wl["theta0"])
-    oc2[0] += wl["N0"]
-    counts, *_ = ctx.step(wl["theta0"], wl["N0"])
-    assert np.allclose(counts, oc2, rtol=1e-9, atol=1e-9)
-    # Q32 planes: the side kernel decodes the same mantissas the E step streams
     from tools.q32_ref import quantize_q32
-    ctx.set_values(wl["conprb"], wl["ncp"])
     ctx.set_option("value_bits", 32)
-    assert ctx.info("foreign_alignments") > 0
     vq = quantize_q32(wl["row_ptr"], wl["conprb"], 8)[0]
     ocq = orc.em_estep(M, wl["row_ptr"], wl["sid"], vq, wl["ncp"], wl["theta0"])
     ocq[0] += wl["N0"]
