@@ -14,12 +14,12 @@ rm -rf $D
 t=$(now); tools/bin/gen_temp $D $NF $M 3 20250925 100 nosam $ISO | tail -1; echo "gen_s $(el $t)"
 t=$(now); tools/bin/temp_to_rsb $D/temp/s $D/stat/s 3; echo "to_rsb_s $(el $t) (not part of any timing below: the parser writes this directly)"
 rm -f $D/temp/s.dat $D/temp/*.fq; du -sh $D/temp/s.rsb | cut -f1
-echo "== rsem-run-em on the binary hand-off, --gibbs-out"; t=$(now)
-rsem_amd/bin/rsem-run-em $D/ref 3 $D/s $D/temp/s $D/stat/s -p 64 --gibbs-out > $D/em.log 2>&1; echo "em_rsb_rc $? em_rsb_s $(el $t)"
-grep -E "^\[timing\]" $D/em.log; grep ROUND $D/em.log | tail -1; ls -la $D/temp/s.ofg | awk '{print "ofg_bytes", $5}'
-echo "== rsem-run-gibbs 200 1000 1 -p $P, data-augmentation sampler (thin 8)"; t=$(now)
-rsem_amd/bin/rsem-run-gibbs $D/ref $D/temp/s $D/stat/s 200 1000 1 -p $P --seed 1 --gibbs-mode parallel > $D/gibbs.log 2>&1; echo "gibbs_rc $? gibbs_s $(el $t)"
-tail -3 $D/gibbs.log
+echo "== rsem-run-em on the binary hand-off, --gibbs-out as arrays too (RSEM_HIP_BINARY=1: imdName.ofb/, no .ofg text)"; t=$(now)
+RSEM_HIP_BINARY=1 rsem_amd/bin/rsem-run-em $D/ref 3 $D/s $D/temp/s $D/stat/s -p 64 --gibbs-out > $D/em.log 2>&1; echo "em_rsb_rc $? em_rsb_s $(el $t)"
+grep -E "^\[timing\]" $D/em.log; grep ROUND $D/em.log | tail -1; du -sh $D/temp/s.ofb | cut -f1
+echo "== rsem-run-gibbs 200 1000 1 -p $P, --gibbs-mode ${GIBBS_MODE:-auto} (auto: the reference's chains unless they would take > 30 min)"; t=$(now)
+rsem_amd/bin/rsem-run-gibbs $D/ref $D/temp/s $D/stat/s 200 1000 1 -p $P --seed 1 --gibbs-mode ${GIBBS_MODE:-auto} > $D/gibbs.log 2>&1; echo "gibbs_rc $? gibbs_s $(el $t)"
+tail -4 $D/gibbs.log; cat $D/stat/s.gibbs_sampler
 python - <<PY
 import numpy as np
 rows = [l.split("\t") for l in open("$D/temp/s.iso_res").read().strip().split("\n")]
