@@ -334,8 +334,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # called without a launcher: start one rank per GPU ourselves (the contract's launch line)
         port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
-        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-                                  "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:])
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("BENCH_PRINT_LAUNCH"):  # (tests: show the launch line instead of running it)
+            print(json.dumps(cmd))
+            return
+        os.execv(sys.executable, cmd)
 
     # stdout carries exactly one JSON line: libraries that print to the C-level stdout (RCCL's version banner) are sent to
     # stderr for the whole run, the line itself goes to the saved descriptor at the end
