@@ -535,6 +535,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_estep_lane (E step)", "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "achieved / frac use the ALGORITHMIC bytes of SURVEY.md 8(d) (12 B per alignment + 16 B per read + 16 B per transcript); "
+                                 "the kernel physically moves fewer (`traffic`, by PMC): it re-uses a tuple's transcript ids from registers instead of "
+                                 "re-reading them, so frac can pass 1 while frac_of_traffic (physical bytes / time / peak) cannot",
                          "avg_launch_ms": estep_ms, "step_over_launch": elapsed * 1e3 / rounds / estep_ms,
                          # the same launch time against the bytes the kernel physically moved (PMC) and against what a plain
                          # streaming kernel reaches on this device (measured here), beside the 8 TB/s specification
