@@ -35,7 +35,8 @@ constexpr int kShapeBits = 6;
 constexpr int kMaxShapes = 2 * kShapesPerFmt;  // F64 shapes, then Q32 shapes
 constexpr int kShapeIds = 1 << kShapeBits;
 constexpr int kLongShape = kShapeIds - 1;      // rows with more than 256 alignments: CSR kernel
-constexpr uint32_t kKeyMinSidCap = (1u << (32 - kShapeBits)) - 1;  // sort key: shape | min sid (capped) | hash of the tuple
+constexpr uint32_t kKeyMinSidCap = (1u << (31 - kShapeBits)) - 1;  // sort key: shape | apart bit | anchor sid (capped) | hash of the tuple
+constexpr int kKeyApartBit = 63 - kShapeBits;
 constexpr int kFmtF64 = 0, kFmtQ32 = 1;
 constexpr int kMaxK = 4;
 constexpr int kBlock = 256;         // 4 waves
@@ -118,6 +119,11 @@ __host__ __device__ inline uint32_t mix32(uint32_t h, uint32_t v) {
 // the foreign ids lie -- with the plain minimum half of those reads sorted into the FOREIGN gene's neighbourhood and sent
 // all their own gene's counts through global atomics (configs[2] with 10 % such reads: 2.05 ms per E step instead of 0.97,
 // profiles/r03d_bench_default.json).  A layout hint only: ids outside a unit's window take the global path, whatever the key.
+// `apart` (0: off; else the reach, kLayoutWindow in the product): reads with an id outside [anchor, anchor + apart) sort BEHIND all the others of their shape (the apart
+// bit).  Such a read has a tuple of its own, so wherever it sits the lane's run of equal tuples ends, twice (at it and after
+// it), and its slice -- all 64 lanes -- loads the sid planes; mixed in at 10 % they leave hardly a slice without (16 reads
+// per slice: 0.9^16), which is what configs[2] with such reads paid for (profiles/r03m).  Apart, the compact reads keep
+// their runs and only the slices of the others pay.
 // cp != nullptr: reads that qualify (q32_scale_of) go to the Q32 twin of their shape.  *err: 1 row_ptr not monotone,
 // 2 sid outside 1..M.
 constexpr int kLayoutWindow = 2048;               // ids per LDS window of the kernels that walk this layout (em.hip kWindow, gibbs.hip kGWindow)
@@ -125,7 +131,7 @@ constexpr int kAnchorReach = kLayoutWindow / 2;
 constexpr int kMedianExactMax = 64; // reads up to this length: exact median (rank selection); longer: the middle position
 __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint64_t* __restrict__ row_ptr,
                                                const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits,
-                                               int* err) {
+                                               int apart, int* err) {
     uint64_t fr = row_ptr[i], to = row_ptr[i + 1];
     if (to < fr) { *err = 1; return 0; }
     uint32_t h = 0x811c9dc5u, mn = 0xffffffffu;
@@ -165,21 +171,26 @@ __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint
         }
         mn = lo;
     }
+    uint64_t far = 0;
+    if (apart && L > 1 && !*err)
+        for (uint64_t j = fr; j < to; j++) {
+            const uint32_t v = (uint32_t)sid[j];
+            if (v < mn || v >= mn + (uint32_t)apart) far = 1;
+        }
     if (mn > kKeyMinSidCap) mn = kKeyMinSidCap;
     int shape = shape_id_of(to - fr);
     Q32Scale q;
     if (cp && shape != kLongShape && q32_scale_of(vmx, vmn, range_bits, q)) shape += kShapesPerFmt;
-    return ((uint64_t)shape << (64 - kShapeBits)) | ((uint64_t)mn << 32) | h;
+    return ((uint64_t)shape << (64 - kShapeBits)) | (far << kKeyApartBit) | ((uint64_t)mn << 32) | h;
 }
 
 __global__ void k_row_keys(uint64_t N1, int32_t M, const uint64_t* __restrict__ row_ptr,
-                           const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits,
+                           const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits, int apart,
                            uint64_t* keys, uint32_t* vals, int* err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N1) return;
     int e = 0;
-    const uint64_t key = row_key_of(i, M, row_ptr, sid, cp, range_bits,
-                                    &e);
+    const uint64_t key = row_key_of(i, M, row_ptr, sid, cp, range_bits, apart, &e);
     if (e) *err = e;
     if (e == 1) return;
     keys[i] = key;
@@ -284,7 +295,8 @@ __global__ void k_slice_masks(const Shape* __restrict__ shapes, int n_shapes, ui
     if (lane == 0) masks[s] = m;
 }
 
-// anchor sid (row_key_of) of the read in row slot 0 of every slice (non-decreasing along the blocks of a shape)
+// anchor sid (row_key_of) of the read in row slot 0 of every slice (non-decreasing along the blocks of a shape, except
+// where its far-reaching reads begin)
 __global__ void k_slice_minsid(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_slices,
                                const uint64_t* __restrict__ keys_sorted, uint32_t* slice_minsid) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -376,6 +388,8 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
                       const int32_t* d_sid, uint32_t target_waves, uint32_t forced_T = 0,
                       const double* d_cp_for_q32 = nullptr, int range_bits = 0) {
     L.N1 = N1;
+    int apart = kLayoutWindow;
+    if (const char* e = getenv("RSEM_HIP_APART")) apart = atoi(e) ? kLayoutWindow : 0;  // measurement knob: 0 = one sorted sequence per shape
     uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
     uint32_t *d_vals = nullptr, *d_first = nullptr;
     int* d_err = nullptr;
@@ -393,8 +407,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     RSEM_HIP_TRY(hipMemsetAsync(d_first, 0xff, kShapeIds * sizeof(uint32_t), st));
     if (N1) {
         hipLaunchKernelGGL(k_row_keys, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, M, d_row_ptr, d_sid,
-                           d_cp_for_q32, range_bits,
-                           d_keys, d_vals, d_err);
+                           d_cp_for_q32, range_bits, apart, d_keys, d_vals, d_err);
         RSEM_HIP_TRY(hipGetLastError());
         size_t tb = 0;
         RSEM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_keys, d_keys2, d_vals, L.d_order, N1, 0, 64, st));
@@ -513,9 +526,9 @@ inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units, int w
         U.n_slices = n;
         U.per_wave = std::max<uint32_t>(per_wave, 1);
         const uint32_t s0 = S.slice_base + sl0, s1 = s0 + n;
-        U.base = (int32_t)ms[s0];
-        uint32_t top = 0;
-        for (uint32_t t = s0; t < s1; t++) top = std::max(top, mx[t]);
+        uint32_t top = 0, low = ms[s0];
+        for (uint32_t t = s0; t < s1; t++) { top = std::max(top, mx[t]); low = std::min(low, ms[t]); }
+        U.base = (int32_t)low;  // (= ms[s0], but for the one unit of a shape in which the far-reaching reads begin)
         const long long span = (long long)top - U.base + 1;
         U.span = (int32_t)std::min<long long>(std::max<long long>(span, 1), window_cap);
         U.pad[0] = U.pad[1] = 0;

@@ -5,7 +5,7 @@
 // table, the Q32 rule); what is being tested is the kernel body: lane -> (read, position) mapping, prefetch rings, Q32
 // arithmetic, reductions over a read's lanes, spills, the compile-time variants.  Never part of the product.
 //
-//   estep_emu in.bin out.bin        in:  i32 M, N1, T, policy, q32 (0/1), range_bits, from_counts (0/1), pad; f64 N0
+//   estep_emu in.bin out.bin        in:  i32 M, N1, T, policy (1: sort key without the apart bit), q32 (0/1), range_bits, from_counts (0/1), pad; f64 N0
 //                                        u64 row_ptr[N1+1]; i32 sid[nnz]; f64 cp[nnz]; f64 ncp[N1]; f64 theta[M+1]
 //                                   out: f64 counts[M+1] (without N0), f64 noise total, f64 reads with a non-zero normaliser
 // Build (tests/test_estep_emu_cpu.py): hipcc -DRSEM_EMU [-DRSEM_F64_DEPTHS=... -DRSEM_Q32_DEPTHS=...] tests/estep_emu.cpp -lpthread
@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
     fclose(f);
     HostLayout H;
     H.T = (uint32_t)hdr[2];
-    build_layout(H, M, N1, rp.data(), sid.data(), cp.data(), ncp.data(), hdr[3], hdr[4] != 0, hdr[5]);
+    build_layout(H, M, N1, rp.data(), sid.data(), cp.data(), ncp.data(), hdr[3], hdr[4] != 0, hdr[5], hdr[3] == 1 ? 0 : (hdr[7] > 0 ? hdr[7] : kLayoutWindow));  // hdr[3] = 1: the key without its apart bit; a smaller window is also the bit's reach
     std::vector<double> counts((size_t)M + 1, 0.0);
     double tot_noise = 0.0, tot_neff = 0.0;
     Job* J = new Job();

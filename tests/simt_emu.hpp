@@ -114,14 +114,13 @@ struct HostLayout {
 };
 
 static void build_layout(HostLayout& H, int M, uint64_t N1, const uint64_t* rp, const int32_t* sid, const double* cp, const double* ncp,
-                         int policy, bool q32, int range_bits) {
+                         int policy, bool q32, int range_bits, int apart = kLayoutWindow) {
     // keys: sell_layout.hpp's row_key_of (the body of k_row_keys); sorted rows; shapes (the host loop of sell_build)
     std::vector<std::pair<uint64_t, uint32_t>> keyed(N1);
     (void)policy;
     for (uint64_t i = 0; i < N1; i++) {
         int err = 0;
-        const uint64_t key = row_key_of(i, M, rp, sid, q32 ? cp : nullptr, range_bits,
-                                        &err);
+        const uint64_t key = row_key_of(i, M, rp, sid, q32 ? cp : nullptr, range_bits, apart, &err);
         if (err) { fprintf(stderr, "simt_emu: bad CSR (%d)\n", err); exit(2); }
         if ((int)(key >> (64 - kShapeBits)) == kLongShape) { fprintf(stderr, "simt_emu: rows with more than 256 alignments are not modelled\n"); exit(2); }
         keyed[i] = {key, (uint32_t)i};

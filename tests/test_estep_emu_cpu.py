@@ -99,7 +99,9 @@ def _check(exe, seed=1, **kw):
     assert abs(noise - oc[0]) <= 1e-12 * oc[0], kw
 
 
-CASES = [dict(), dict(from_counts=1), dict(window=64), dict(q32=1), dict(q32=1, range_bits=24, T=7, seed=2), dict(T=1, window=16, seed=3)]
+CASES = [dict(), dict(from_counts=1), dict(window=64), dict(q32=1), dict(q32=1, range_bits=24, T=7, seed=2), dict(T=1, window=16, seed=3),
+         # policy=1: the sort key without its apart bit (reads that reach beyond the window stay among the others)
+         dict(policy=1, window=64), dict(policy=1, window=16, from_counts=1, T=3, seed=2)]
 
 
 @pytest.mark.parametrize("kw", CASES, ids=lambda k: "-".join("%s%s" % kv for kv in sorted(k.items())) or "plain")
