@@ -494,6 +494,7 @@ __global__ __launch_bounds__(kXT) void k_gibbs_exact_wg(uint32_t n_tiles, const 
     // the move-endpoint table starts out all zero (every resolve round leaves it that way)
     for (int i = threadIdx.x; i < kXKeys * 2 * kXW; i += blockDim.x) (&tile.ends[0][0][0])[i] = 0ull;
     for (int i = threadIdx.x; i < kXKeys; i += blockDim.x) tile.key[i] = 0;
+    for (int i = threadIdx.x; i < kXBits / 64; i += blockDim.x) tile.bits[i] = 0ull;
     __syncthreads();
     gibbs_exact_wg_body<kInit>((int)threadIdx.x, &tile, n_tiles, tile_start, row_ptr, sid, cp, counts_base + (uint64_t)chain * stride_c,
                                z_base + (uint64_t)chain * stride_z, pseudoC, prof);
@@ -1189,6 +1190,8 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             fprintf(stderr, "[gibbs exact wg] shader-clock cycles per tile of <= %d reads: stage %.0f | own flags %.0f | rng + gather %.0f | first draw %.0f | "
                             "resolve %.0f (%.2f rounds) | commit %.0f ; tiles %.0f\n",
                     kXT, h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[8] / tiles, h[5] / tiles, tiles);
+            fprintf(stderr, "[gibbs exact wg] inside the rounds: enter %.0f | barrier %.0f | scan %.0f | item walk %.0f (%.2f items of thread 0) | redraw %.0f | "
+                            "clean-up %.0f\n", h[9] / tiles, h[10] / tiles, h[11] / tiles, h[12] / tiles, h[15] / tiles, h[13] / tiles, h[14] / tiles);
         }
         if (dbg & 4) {
             unsigned long long h4[4] = {0, 0, 0, 0};

@@ -16,9 +16,9 @@
 //   4. resolve the dependencies INSIDE the tile by fixed-point rounds: a thread's draw depends on the moves (z_old -> z_new)
 //      of EARLIER threads that touch one of its transcripts.  Every round the moving threads enter their two endpoints in an
 //      exact-keyed LDS hash table (per id: the threads that move TO it and the threads that move FROM it, as 256-bit masks);
-//      every thread looks its items up and gets each item's delta as two popcounts over the EARLIER threads' bits -- no
-//      loop over predecessors, whatever the number of reads of one hot gene in the tile -- and redraws with the SAME random
-//      number if a delta changed; a round in which no draw changes leaves every thread consistent with all earlier
+//      the tile's items are then looked up item-major (thread g: items g, g + 256, ...) and each gets its delta as two
+//      popcounts over the bits of the threads EARLIER than its read -- no loop over predecessors, whatever the number of
+//      reads of one hot gene in the tile; a thread whose read has a changed delta redraws with the SAME random number; a round in which no draw changes leaves every thread consistent with all earlier
 //      threads, which by induction over the thread index is the sequential chain's state (thread 0 depends on nobody);
 //   5. commit the moves (counts[z_old]--, counts[z_new]++, z[]).
 // Same visiting order, same left-to-right cumulative sums (one thread sums one read), same MT19937 stream as the reference:
@@ -62,16 +62,19 @@ constexpr int kXKeys = 1024;     // entries of the move-endpoint table (at most 
 constexpr int kXChunk = 16;      // items of a read handled per step with independent (pipelined) LDS reads
 constexpr int kXPlanes = kXCap / kXT;
 
-struct XTile {  // the workgroup's LDS: 149 KB of the CU's 160 KB
+constexpr int kXBits = 8192;
+struct XTile {  // the workgroup's LDS: 150 KB of the CU's 160 KB
     unsigned long long rp[kXT + 1];
     unsigned long long ends[kXKeys][2][kXW];  // per entry: the threads that move TO the id / FROM the id (all zero between rounds)
     int32_t key[kXKeys];                      // id + 1 of the entry, 0 = free (all zero between rounds)
     double p[kXCap];
     int32_t sid[kXCap];
     int32_t c[kXCap];          // counts[sid] after every earlier tile, minus 1 where the read itself sits
-    signed char own[kXCap];    // 1: this item is its read's current transcript
+    unsigned char ownr[kXCap]; // the thread (read of the tile) the item belongs to
     int16_t dl[kXCap];         // what the moves of EARLIER reads of the tile add to this item's count (-255 .. 255)
-    unsigned long long mm[kXW], chg[kXW];
+    int32_t zold[kXT];         // the reads' current transcripts
+    unsigned long long mm[kXW], chg[kXW], dirty[kXW];  // per wave: threads that move / whose draw changed / with a changed delta
+    unsigned long long bits[kXBits / 64];     // one bit per hashed endpoint id (all zero between rounds): the scan's filter
     uint32_t mt[624];
     int idx;
 };
@@ -94,7 +97,8 @@ inline void gx_build_tiles(uint64_t N1, const uint64_t* row_ptr, std::vector<uin
 
 // Phase profile (variant builds only, -DRSEM_GX_PROFILE=1; the product's kernel reads no timer): shader-clock cycles of
 // thread 0's wave summed into prof[0..5] = stage | own flags | random numbers + gather | first draw | resolve rounds |
-// commit; prof[7] = tiles, prof[8] = resolve rounds
+// commit; prof[7] = tiles, prof[8] = resolve rounds; inside the rounds prof[9..14] = enter endpoints | barrier | scan | item
+// walk | redraw | ballot + clean-up + barriers (prof[4] then holds only the rest), prof[15] = items thread 0 walked
 #ifndef RSEM_GX_PROFILE
 #define RSEM_GX_PROFILE 0
 #endif
@@ -129,6 +133,8 @@ GX_DEVFN void gx_mt_regen(uint32_t* mt, int lane) {
 }
 
 GX_DEVFN unsigned gx_hash(int s) { return ((unsigned)s * 2654435761u) >> 22; }  // 10 bits: kXKeys entries
+GX_DEVFN unsigned gx_bit(int s) { return ((unsigned)s * 2246822519u) >> 19; }   // 13 bits: kXBits
+static_assert(kXBits == 8192, "gx_bit returns 13 bits");
 static_assert(kXKeys == 1024, "gx_hash returns 10 bits");
 
 // One sweep over all reads in file order (Gibbs.cpp:297-311), or the initial assignment (Gibbs.cpp:281-291) when kInit.
@@ -138,11 +144,7 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                                   const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid, const double* __restrict__ cp,
                                   int32_t* counts, int32_t* z, double pseudoC, unsigned long long* prof) {
     const int lane = g & 63, w = g >> 6;
-    unsigned long long pa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // the threads before this one, wave by wave
-    unsigned long long before[kXW];
-#pragma unroll
-    for (int j = 0; j < kXW; j++) before[j] = j < w ? ~0ull : (j == w ? (1ull << lane) - 1ull : 0ull);
+    unsigned long long pa[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t t = 0; t < n_tiles; t++) {
         unsigned long long tk = GX_CLOCK();
         auto lap = [&](int i) {
@@ -190,17 +192,12 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
         int idx = L->idx;
         GX_BLOCK_SYNC();
         lap(0);
-        // ---- which item is the read's current transcript (Gibbs.cpp:298: the read leaves it before it is weighed) -----------------
+        // ---- whose item is it (the gather and the rounds walk the items item-major: other threads' items) ---------------------------
         if (!kInit) {
-            for (int k0 = 0; k0 < len; k0 += kXChunk) {
-                int sv[kXChunk];
-#pragma unroll
-                for (int j = 0; j < kXChunk; j++) sv[j] = (k0 + j < len) ? L->sid[fr + k0 + j] : -1;
-#pragma unroll
-                for (int j = 0; j < kXChunk; j++)
-                    if (k0 + j < len) L->own[fr + k0 + j] = (signed char)(sv[j] == z_old ? 1 : 0);
-            }
-            GX_BLOCK_SYNC();  // (the gather reads the flags item-major: other threads' items)
+            for (int k = 0; k < len; k++) L->ownr[fr + k] = (unsigned char)g;
+            L->zold[g] = z_old;
+            if (lane == 0) L->dirty[w] = 0ull;
+            GX_BLOCK_SYNC();
         }
         lap(1);
         uint32_t* mt = L->mt;
@@ -262,8 +259,9 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
             }
             if (!kInit) {
                 // counts of the tile's items as they are after every earlier tile (item-major: neighbouring threads fetch
-                // neighbouring ids), the read's own unit taken off where it sits (Gibbs.cpp:298)
-                int cj[kXPlanes];
+                // neighbouring ids), the read's own unit taken off where it sits (Gibbs.cpp:298: the read leaves its transcript
+                // before it is weighed)
+                int cj[kXPlanes], zo[kXPlanes];
 #pragma unroll
                 for (int u = 0; u < kXPlanes; u++) {
                     const uint32_t j = (uint32_t)u * kXT + g;
@@ -272,7 +270,12 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
 #pragma unroll
                 for (int u = 0; u < kXPlanes; u++) {
                     const uint32_t j = (uint32_t)u * kXT + g;
-                    if (j < T) L->c[j] = cj[u] - (int)L->own[j];
+                    zo[u] = j < T ? L->zold[L->ownr[j]] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < kXPlanes; u++) {
+                    const uint32_t j = (uint32_t)u * kXT + g;
+                    if (j < T) L->c[j] = cj[u] - (sj[u] == zo[u] ? 1 : 0);
                 }
             }
             GX_BLOCK_SYNC();
@@ -328,10 +331,10 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
             int z_new = mine ? draw(std::false_type{}) : z_old;
             lap(3);
             if (!kInit) {
-                // Rounds.  The table is all zero here (every round cleans up after itself).
-                unsigned long long nzmask = 0ull;  // bit k: dl of this thread's item k (< 64) is not zero
+                // Rounds.  The table, the filter and the dirty words are all zero here (every round cleans up after itself).
                 for (;;) {
                     const bool mv = mine && z_new != z_old;
+                    const int z_ent = z_new;  // (the endpoint entered below: z_new may change in this round)
                     const unsigned long long bm = GX_BALLOT(mv);
                     if (lane == 0) L->mm[w] = bm;
                     unsigned h_fr = 0, h_to = 0;  // this thread's entries
@@ -346,34 +349,51 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                                 h = (h + 1) & (kXKeys - 1);
                             }
                             GX_LDS_OR64(&L->ends[h][dir][w], 1ull << lane);
+                            const unsigned b = gx_bit(id);
+                            GX_LDS_OR64(&L->bits[b >> 6], 1ull << (b & 63));
                             return h;
                         };
                         h_fr = enter(z_old, 1);
                         h_to = enter(z_new, 0);
                     }
+                    lap(9);
                     GX_BLOCK_SYNC();
+                    lap(10);
                     bool any_moved = false;
 #pragma unroll
                     for (int q = 0; q < kXW; q++) any_moved = any_moved || L->mm[q] != 0ull;
                     if (!any_moved) break;  // (uniform) nobody moves: the table is untouched, nothing to resolve or commit
                     if (RSEM_GX_PROFILE) pa[8] += 1;
-                    // every item's delta: moves of EARLIER threads to its id minus moves from its id.  First find the items whose id
-                    // MAY have an entry (first probe not free; pipelined reads), then walk those -- and the items that still carry
-                    // a delta from an earlier round (`nzmask`) -- one at a time: most items are neither.
-                    bool dirty = false;
-                    unsigned long long todo = nzmask;
-                    for (int k0 = 0; k0 < len && k0 < 64; k0 += kXChunk) {
-                        int sv[kXChunk], kk[kXChunk];
+                    // Every item's delta: moves of EARLIER threads (earlier than the item's read) to its id minus moves from its
+                    // id.  Item-major -- thread g takes items g, g + 256, ... whoever they belong to: their ids are still in its
+                    // registers and every thread has the same number of them.  Only an item whose id MAY have an entry (its bit
+                    // of the 8192-bit filter the movers set: 512 endpoints at most, so few false hits) or that still carries a
+                    // delta from an earlier round is looked up: most items are neither.  A changed delta marks the item's read.
+                    // (Until r03n every thread walked its own read's items: the slowest lane of a wave set the pace, 21.8 k
+                    // cycles per tile at configs[2] with the table's first probe as the filter, 8.7 k with this one.)
+                    unsigned need = 0;
+                    {
+                        unsigned long long bw[kXPlanes];
+                        int dv[kXPlanes];
 #pragma unroll
-                        for (int j = 0; j < kXChunk; j++) sv[j] = (k0 + j < len) ? L->sid[fr + k0 + j] : -1;
+                        for (int u = 0; u < kXPlanes; u++) {
+                            const uint32_t j = (uint32_t)u * kXT + g;
+                            const unsigned b = gx_bit(sj[u]);
+                            bw[u] = j < T ? L->bits[b >> 6] : 0ull;
+                            dv[u] = j < T ? (int)L->dl[j] : 0;
+                        }
 #pragma unroll
-                        for (int j = 0; j < kXChunk; j++) kk[j] = (k0 + j < len) ? L->key[gx_hash(sv[j])] : 0;
-#pragma unroll
-                        for (int j = 0; j < kXChunk; j++)
-                            if (kk[j] != 0) todo |= 1ull << (k0 + j);
+                        for (int u = 0; u < kXPlanes; u++) {
+                            const unsigned b = gx_bit(sj[u]);
+                            if (((bw[u] >> (b & 63)) & 1ull) != 0ull || dv[u] != 0) need |= 1u << u;
+                        }
                     }
-                    auto item = [&](int k) {
-                        const int sv = L->sid[fr + k];
+                    lap(11);
+                    for (; need != 0u; need &= need - 1u) {
+                        const int u = __builtin_ctz(need);
+                        const uint32_t j = (uint32_t)u * kXT + g;
+                        const int sv = L->sid[j];  // (= sj[u]; a register array cannot be indexed by a variable)
+                        const int o = (int)L->ownr[j], ow = o >> 6;
                         unsigned h = gx_hash(sv);
                         int kv = L->key[h];
                         while (kv != 0 && kv != sv + 1) {
@@ -382,24 +402,29 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                         }
                         int dd = 0;
                         if (kv != 0) {
+                            const unsigned long long part = (1ull << (o & 63)) - 1ull;  // the owner's wave: the lanes before it
 #pragma unroll
-                            for (int q = 0; q < kXW; q++)
-                                dd += GX_POPC64(L->ends[h][0][q] & before[q]) - GX_POPC64(L->ends[h][1][q] & before[q]);
+                            for (int q = 0; q < kXW; q++) {
+                                const unsigned long long bef = q < ow ? ~0ull : (q == ow ? part : 0ull);
+                                dd += GX_POPC64(L->ends[h][0][q] & bef) - GX_POPC64(L->ends[h][1][q] & bef);
+                            }
                         }
-                        if (dd != (int)L->dl[fr + k]) {
-                            L->dl[fr + k] = (int16_t)dd;
-                            dirty = true;
+                        if (dd != (int)L->dl[j]) {
+                            L->dl[j] = (int16_t)dd;
+                            GX_LDS_OR64(&L->dirty[ow], 1ull << (o & 63));
                         }
-                        if (k < 64) nzmask = dd != 0 ? (nzmask | (1ull << k)) : (nzmask & ~(1ull << k));
-                    };
-                    for (; todo != 0ull; todo &= todo - 1ull) item(__builtin_ctzll(todo));
-                    for (int k = 64; k < len; k++) item(k);  // (reads longer than 64 items: every further item, every round)
+                        if (RSEM_GX_PROFILE) pa[15] += 1;
+                    }
+                    lap(12);
+                    GX_BLOCK_SYNC();  // every delta of this round is in place
+                    const bool dirty = ((L->dirty[w] >> lane) & 1ull) != 0ull;
                     int z2 = z_new;
                     if (dirty) z2 = draw(std::true_type{});
+                    lap(13);
                     const unsigned long long ch = GX_BALLOT(mine && z2 != z_new);
                     z_new = z2;
                     if (lane == 0) L->chg[w] = ch;
-                    GX_BLOCK_SYNC();  // every thread has finished its look-ups
+                    GX_BLOCK_SYNC();  // every thread has read its dirty bit (and the look-ups were finished a barrier ago)
                     if (mv) {          // leave the table as it was found: all zero
 #pragma unroll
                         for (int q = 0; q < kXW; q++) {
@@ -408,11 +433,15 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                         }
                         L->key[h_fr] = 0;
                         L->key[h_to] = 0;
+                        L->bits[gx_bit(z_old) >> 6] = 0ull;
+                        L->bits[gx_bit(z_ent) >> 6] = 0ull;
                     }
+                    if (lane == 0) L->dirty[w] = 0ull;
                     bool any_changed = false;
 #pragma unroll
                     for (int q = 0; q < kXW; q++) any_changed = any_changed || L->chg[q] != 0ull;
                     GX_BLOCK_SYNC();  // the table is clean again (and chg / mm may be rewritten)
+                    lap(14);
                     if (!any_changed) break;  // (uniform) every thread is consistent with all earlier threads
                 }
                 lap(4);
@@ -434,7 +463,7 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
     }
 #if RSEM_GX_PROFILE && !defined(GX_EMU)
     if (prof && g == 0)
-        for (int i = 0; i < 9; i++) (void)__hip_atomic_fetch_add(&prof[i], pa[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 16; i++) (void)__hip_atomic_fetch_add(&prof[i], pa[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
     (void)prof;
     (void)pa;

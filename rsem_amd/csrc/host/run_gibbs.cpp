@@ -152,7 +152,7 @@ int main(int argc, char* argv[]) {
     // is a workgroup and costs about kExactUsPerVisit per read visit whatever the number of chains (up to one per CU;
     // DESIGN.md section 5), so the estimate is rounds x reads x that.  The choice is printed and recorded in
     // <statName>.gibbs_sampler; --gibbs-mode exact / parallel overrule it.
-    constexpr double kExactUsPerVisit = 0.12, kAutoExactLimitS = 1800.0;
+    constexpr double kExactUsPerVisit = 0.09, kAutoExactLimitS = 1800.0;
     const int rounds_per_chain = BURNIN + 1 + ((NSAMPLES + nThreads - 1) / nThreads - 1) * GAP;
     const int chains_per_gpu = (nThreads + nworkers - 1) / nworkers;
     const double est_exact_s = (double)rounds_per_chain * (double)N1 * kExactUsPerVisit * 1e-6 * (double)((chains_per_gpu + 255) / 256);

@@ -91,6 +91,7 @@ int main(int argc, char** argv) {
     mc.tile.idx = 624;
     memset(mc.tile.ends, 0, sizeof(mc.tile.ends));  // (the kernel wrapper clears the move-endpoint table once per launch)
     memset(mc.tile.key, 0, sizeof(mc.tile.key));
+    memset(mc.tile.bits, 0, sizeof(mc.tile.bits));
     for (int w = 0; w < kXW; w++) pthread_barrier_init(&mc.wave[w].bar, nullptr, 64);
     pthread_barrier_init(&mc.block_bar, nullptr, 64 * kXW);
 

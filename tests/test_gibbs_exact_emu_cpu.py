@@ -22,7 +22,8 @@ pytestmark = pytest.mark.skipif(CXX is None, reason="needs g++")
 @pytest.fixture(scope="module")
 def emulator(tmp_path_factory):
     exe = os.path.join(str(tmp_path_factory.mktemp("gibbs_exact_emu")), "gibbs_exact_emu")
-    subprocess.check_call([CXX, "-O1", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "gibbs_exact_emu.cpp"), "-o", exe])
+    subprocess.check_call([CXX, "-O1", "-std=c++17", "-pthread"] + os.environ.get("RSEM_EMU_DEFS", "").split()  # (variant builds by hand)
+                          + [os.path.join(ROOT, "tests", "gibbs_exact_emu.cpp"), "-o", exe])
     return exe
 
 

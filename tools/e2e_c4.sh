@@ -1,5 +1,5 @@
 #!/bin/bash
-# BASELINE configs[3] on ONE GPU through the drop-in programs: Gibbs posterior (rsem-run-gibbs) on the 50 M-pair /
+# BASELINE configs[3] on ONE GPU through the drop-in programs (GIBBS_MODE=parallel unless set: `auto` takes the reference's chains here, ~24 min): Gibbs posterior (rsem-run-gibbs) on the 50 M-pair /
 # 200 k-transcript input, 8 chains (the config's "-p 8"; on an 8-GPU node they are dealt one per GPU and meet in one
 # RCCL reduce), pipeline settings BURNIN 200, NSAMPLES 1000, GAP 1.  Also times rsem-run-em on the binary hand-off
 # (imdName.rsb/, what rsem-parse-alignments --binary writes) for the end-to-end table.
@@ -17,8 +17,8 @@ rm -f $D/temp/s.dat $D/temp/*.fq; du -sh $D/temp/s.rsb | cut -f1
 echo "== rsem-run-em on the binary hand-off, --gibbs-out as arrays too (RSEM_HIP_BINARY=1: imdName.ofb/, no .ofg text)"; t=$(now)
 RSEM_HIP_BINARY=1 rsem_amd/bin/rsem-run-em $D/ref 3 $D/s $D/temp/s $D/stat/s -p 64 --gibbs-out > $D/em.log 2>&1; echo "em_rsb_rc $? em_rsb_s $(el $t)"
 grep -E "^\[timing\]" $D/em.log; grep ROUND $D/em.log | tail -1; du -sh $D/temp/s.ofb | cut -f1
-echo "== rsem-run-gibbs 200 1000 1 -p $P, --gibbs-mode ${GIBBS_MODE:-auto} (auto: the reference's chains unless they would take > 30 min)"; t=$(now)
-rsem_amd/bin/rsem-run-gibbs $D/ref $D/temp/s $D/stat/s 200 1000 1 -p $P --seed 1 --gibbs-mode ${GIBBS_MODE:-auto} > $D/gibbs.log 2>&1; echo "gibbs_rc $? gibbs_s $(el $t)"
+echo "== rsem-run-gibbs 200 1000 1 -p $P, --gibbs-mode ${GIBBS_MODE:-parallel} (auto: the reference's chains unless they would take > 30 min)"; t=$(now)
+rsem_amd/bin/rsem-run-gibbs $D/ref $D/temp/s $D/stat/s 200 1000 1 -p $P --seed 1 --gibbs-mode ${GIBBS_MODE:-parallel} > $D/gibbs.log 2>&1; echo "gibbs_rc $? gibbs_s $(el $t)"
 tail -4 $D/gibbs.log; cat $D/stat/s.gibbs_sampler
 python - <<PY
 import numpy as np
