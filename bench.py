@@ -263,6 +263,14 @@ def q32_leg(ctx, wl, N0, K, W, sync, alg_bytes, f64_ms_per_step, f64_estep_ms, t
         return {"error": str(e)}
 
 
+def far_units(ctx):
+    """Units of the hot-loop layout with an id outside their LDS window (they run the loop with the global gather / atomics)."""
+    try:
+        return "%d of %d" % (ctx.info("far_units"), ctx.info("units"))
+    except Exception:  # (a library built before the key existed: RSEM_HIP_LIB experiments)
+        return None
+
+
 def one_step_parity(ctx, wl):
     """One E + M step of the context against the CPU restatement (oracle/, EM.cpp:199-236,391-398) on the WHOLE matrix --
     the checker beside the measurement, not part of it (for configs[4] this is also the > 2^32-alignments index check:
@@ -301,7 +309,8 @@ def em_leg(capi, make_em_workload, config, K, W, kernel, sync, device, q32=False
         out = {"workload": "%s%s: %d reads x %d transcripts, %d alignments" % (WORKLOADS.get(config, config), "" if scale == 1.0 else " at %g of its reads" % scale, N1, M, nnz),
                "ms_per_step": el * 1e3 / rounds, "timed_rounds": rounds, "timed_region_s": el, "value": nnz * rounds / el,
                "estep_avg_launch_ms": estep_ms, "algorithmic_bytes_per_launch": alg, "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS,
-               "theta_sum": ts, "generate_s": gen_s, "parity_one_step": one_step_parity(ctx, wl)}
+               "theta_sum": ts, "generate_s": gen_s, "parity_one_step": one_step_parity(ctx, wl),
+               "units_with_ids_outside_their_window": far_units(ctx)}
         if q32 and kernel in (0, 3):
             out["q32_value_planes"] = q32_leg(ctx, wl, wl["N0"], K, W, sync, alg, el * 1e3 / rounds, estep_ms)
         ctx.close()
@@ -491,6 +500,7 @@ def main():
 
     parity = one_step_parity(ctx, wl) if (rank == 0 and world == 1) else None
     value_plane_bytes = ctx.info("value_plane_bytes")
+    units_far = far_units(ctx)
     q32 = None
     if world == 1 and not distributed and not args.no_q32 and args.value_bits == 64 and args.kernel in (0, 3):
         q32_traffic = None  # the committed PMC measurement of this layout (profiles/pmc_traffic.json), as for the headline
@@ -531,6 +541,7 @@ def main():
                                    "(rounds >= 12)" % (WORKLOADS.get(args.config, args.config), N1, M, nnz, nnz / max(N1, 1)),
                        "synthetic_config": args.config, "kernel": args.kernel, "value_bits": args.value_bits,
                        "value_plane_bytes": value_plane_bytes,
+                       "units_with_ids_outside_their_window": units_far,
                        "parallelism": "1 GPU" if world == 1 else "read-sharded x%d + RCCL all-reduce(M+1 f64)/round from C++ on the EM stream" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,

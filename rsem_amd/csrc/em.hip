@@ -414,17 +414,25 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
         const uint32_t u_end = S.slice_base + U.slice_begin + U.n_slices;
         const uint32_t s_begin = S.slice_base + U.slice_begin + (uint32_t)w * U.per_wave;
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
-#define RSEM_ESTEP_BLOCK(KK, QQ) \
-    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1])>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M)
-        if (s_begin < u_end) switch (S.K + 4 * S.fmt) {  // (uniform over the workgroup)
-            case 1: RSEM_ESTEP_BLOCK(1, false); break;
-            case 2: RSEM_ESTEP_BLOCK(2, false); break;
-            case 3: RSEM_ESTEP_BLOCK(3, false); break;
-            case 4: RSEM_ESTEP_BLOCK(4, false); break;
-            case 5: RSEM_ESTEP_BLOCK(1, true); break;
-            case 6: RSEM_ESTEP_BLOCK(2, true); break;
-            case 7: RSEM_ESTEP_BLOCK(3, true); break;
-            default: RSEM_ESTEP_BLOCK(4, true); break;
+#define RSEM_ESTEP_BLOCK(KK, QQ, FF) \
+    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M)
+        if (s_begin < u_end) switch (S.K + 4 * S.fmt + (U.pad[0] != 0 ? 8 : 0)) {  // (uniform over the workgroup)
+            case 1: RSEM_ESTEP_BLOCK(1, false, false); break;
+            case 2: RSEM_ESTEP_BLOCK(2, false, false); break;
+            case 3: RSEM_ESTEP_BLOCK(3, false, false); break;
+            case 4: RSEM_ESTEP_BLOCK(4, false, false); break;
+            case 5: RSEM_ESTEP_BLOCK(1, true, false); break;
+            case 6: RSEM_ESTEP_BLOCK(2, true, false); break;
+            case 7: RSEM_ESTEP_BLOCK(3, true, false); break;
+            case 8: RSEM_ESTEP_BLOCK(4, true, false); break;
+            case 9: RSEM_ESTEP_BLOCK(1, false, true); break;
+            case 10: RSEM_ESTEP_BLOCK(2, false, true); break;
+            case 11: RSEM_ESTEP_BLOCK(3, false, true); break;
+            case 12: RSEM_ESTEP_BLOCK(4, false, true); break;
+            case 13: RSEM_ESTEP_BLOCK(1, true, true); break;
+            case 14: RSEM_ESTEP_BLOCK(2, true, true); break;
+            case 15: RSEM_ESTEP_BLOCK(3, true, true); break;
+            default: RSEM_ESTEP_BLOCK(4, true, true); break;
 #undef RSEM_ESTEP_BLOCK
         } else {
             const ThetaSrc th = theta_src<kFC>(theta, tsrc, N0, lane);
@@ -785,6 +793,7 @@ struct rsem_em_ctx {
     Unit* d_units = nullptr;
     unsigned long long* d_trace = nullptr;  // per-workgroup timestamps (tune_unit_order, rsem_em_debug_trace)
     std::vector<Unit> h_units;
+    uint32_t n_far_units = 0;               // units with an id outside their LDS window (Unit::pad[0])
     int tune_passes_left = 1;               // measured-lifetime reordering of the units, done on first use
     uint32_t n_units = 0;
     int noise_n = 0;  // workgroups of the last main E-step launch (= valid entries of d_noise_a)
@@ -954,6 +963,10 @@ int build_layout(rsem_em_ctx* c) {
     RSEM_HIP_TRY(dmalloc(&c->d_units, units.size()));
     if (!units.empty())
         RSEM_HIP_TRY(hipMemcpy(c->d_units, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice));
+    rc = sell_flag_far_units(c->L, c->h_units, c->d_units, c->stream);
+    if (rc != RSEM_OK) return rc;
+    c->n_far_units = 0;
+    for (const Unit& u : c->h_units) c->n_far_units += u.pad[0] != 0;
     // per-workgroup noise partials: enough for any variant's grid
     c->noise_cap = std::max<size_t>((size_t)c->n_cus * 8, c->n_units);
     RSEM_HIP_TRY(dmalloc(&c->d_noise_a, c->noise_cap));
@@ -1147,6 +1160,8 @@ int rsem_em_get_info(const rsem_em_ctx* c, const char* key, int64_t* value) {
     RSEM_REQUIRE(c && key && value, "NULL argument");
     if (!strcmp(key, "value_bits")) *value = c->value_bits;
     else if (!strcmp(key, "value_range_bits")) *value = c->value_range_bits;
+    else if (!strcmp(key, "far_units")) *value = c->n_far_units;                        // units with an id outside their LDS window
+    else if (!strcmp(key, "units")) *value = c->n_units;
     else if (!strcmp(key, "reads_q32")) *value = c->L.n_q32_rows;                       // reads held in Q32 planes
     else if (!strcmp(key, "reads_sliced")) *value = c->L.n_sell_rows;                   // reads in the sliced layout
     else if (!strcmp(key, "reads_long")) *value = c->L.n_long_rows;                     // reads left in the CSR

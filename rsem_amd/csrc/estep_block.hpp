@@ -76,7 +76,7 @@ RSEM_DEVFN double pow2_of(int e) { return RSEM_LL_AS_DOUBLE((long long)(1023 + e
 #define RSEM_F64_DEPTHS 2, 2, 2, 2
 #endif
 #ifndef RSEM_Q32_DEPTHS
-#define RSEM_Q32_DEPTHS 8, 6, 4, 3
+#define RSEM_Q32_DEPTHS 4, 4, 3, 2
 #endif
 // Measured in round 3 (profiles/r03a_variants_and_steps.log, C3 / C2, F64 / Q32 launch) and adopted: the per-read normaliser's
 // butterfly over 2..16 lanes with DPP moves instead of ds_bpermute (same additions in the same order: bit-identical; Q32
@@ -109,7 +109,11 @@ RSEM_DEVFN double read_sum_dpp(double part, int lg) {
 constexpr int kF64Depth[4] = {RSEM_F64_DEPTHS};
 constexpr int kQ32Depth[4] = {RSEM_Q32_DEPTHS};
 
-template <int K, bool kFC, bool kQ, int NBUF>
+// kFar: the unit has ids outside its window (Unit::pad[0], found at layout time: sell_flag_far_units).  A unit WITHOUT
+// runs a loop that touches global memory only through its streaming loads: theta and counts in LDS, no gather, no global
+// atomic -- with a global atomic possibly in flight (they do not return in order with loads) every wait the compiler
+// places in the loop is a wait for everything, and a gather in the middle of a slice drains the prefetch.
+template <int K, bool kFC, bool kQ, int NBUF, bool kFar>
 RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
                                    const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, double* th_win, double* cnt_win,
                                    const unsigned char* __restrict__ sval, const int16_t* __restrict__ sexp, const int32_t* __restrict__ ssid,
@@ -128,6 +132,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         if (t - m_base >= 64u) {
             m_base = t;
             mv = (t + lane < s_end) ? masks[t + lane] : ~0ull;
+            RSEM_PIN(mv);  // (the wait for this load stays in this rare branch: at the join it would be a wait for everything, every slice)
         }
         const int src = (int)(t - m_base);
         const uint32_t lo = RSEM_READLANE((int)(uint32_t)mv, src);
@@ -143,15 +148,22 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         const uint32_t sl = t - S.slice_base;
         const uint64_t v0 = (uint64_t)sl * (K * 64);              // first entry of the slice within the shape's planes
         const ValT* __restrict__ vp = scp + v0;
-        if (m != 0ull) {
-            const int32_t* __restrict__ ip = ssid + (S.plane_base * 64 + v0);
+        // The sid planes of a slice are read only where a tuple starts in it (m != 0); for the other slices the same K loads
+        // go to the shape's first slice instead -- always the same few lines, L1 / L2 hits, no HBM traffic.  Loads that are
+        // issued or not depending on m would be a branch, and behind a branch the compiler counts the loads in flight as on
+        // the path with the fewest: its wait for THIS slice's planes then also waits for part of the next slice's.
+        {
+            const int32_t* __restrict__ ip = ssid + (S.plane_base * 64 + (m != 0ull ? v0 : 0ull));
 #pragma unroll
             for (int k = 0; k < K; k++) b.id[k] = ip[k * 64 + ulane];
         }
 #pragma unroll
         for (int k = 0; k < K; k++) b.c[k] = stream_load(&vp[k * 64 + ulane]);
         const uint32_t slot0 = S.slot_base + sl * R;
-        b.nc = g0 ? (sncp + slot0)[uslot] : 0.0;
+        // (all lanes of a read load its noise probability and exponent, not only the first: a load under a lane predicate
+        // is a branch to the compiler, and with a conditional load in flight its waits for the OTHER loads turn into
+        // waits for everything)
+        b.nc = (sncp + slot0)[uslot];
         b.e = kQ ? (int)(sexp + slot0)[uslot] : 0;
     };
     auto spill = [&](const int* rsid, double* acc) {  // lane-private partial counts -> LDS window
@@ -159,7 +171,8 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         for (int k = 0; k < K; k++) {
             if (acc[k] != 0.0) {
                 const unsigned off = (unsigned)(rsid[k] - base);
-                if (off < (unsigned)span) RSEM_LDS_ADD(&cnt_win[off], acc[k]);
+                if (!kFar) RSEM_LDS_ADD(&cnt_win[off < (unsigned)span ? off : 0u], acc[k]);  // (the clamp never acts: no id of the unit is outside)
+                else if (off < (unsigned)span) RSEM_LDS_ADD(&cnt_win[off], acc[k]);
                 else RSEM_ATOMIC_ADD(&counts[rsid[k]], acc[k]);
             }
             acc[k] = 0.0;
@@ -176,16 +189,39 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         if (cur_m != 0ull) {                 // wave-uniform
             if ((cur_m >> lane) & 1ull) {    // lanes whose read starts a new sid tuple
                 spill(rsid, acc);
+                // theta of the new tuple: the window (LDS) for every id -- a clamped offset where the id is outside --, then,
+                // in a branch of its own, global memory for the ids outside.  NOT `in ? th_win[off] : theta[sid]`: the
+                // compiler turns that into one FLAT load of a selected address, and after a flat load every wait is
+                // vmcnt(0) lgkmcnt(0) -- at the join below, i.e. in every slice, with or without a new tuple: the next
+                // slice's loads, issued a moment ago, were waited for before this slice was reduced (no prefetch at all;
+                // profiles/r03p).  The branch consumes its loads itself (RSEM_PIN), so the common path waits only for
+                // what it needs.
+                bool far = false;
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     const int sidv = cur.id[k];
                     rsid[k] = sidv;
                     const unsigned off = (unsigned)(sidv - base);
-                    rth[k] = (off < (unsigned)span) ? th_win[off] : theta_at<kFC>(th, sidv);
+                    const bool in = off < (unsigned)span;
+                    rth[k] = th_win[in ? off : 0u];
+                    far = far || !in;
+                }
+                if (kFar && far) {
+                    double t[K];
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        const bool in = (unsigned)(rsid[k] - base) < (unsigned)span;
+                        t[k] = theta_at<kFC>(th, in ? 0 : rsid[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        RSEM_PIN(t[k]);
+                        if (!((unsigned)(rsid[k] - base) < (unsigned)span)) rth[k] = t[k];
+                    }
                 }
             }
         }
-        double f0 = th0 * cur.nc;
+        double f0 = g0 ? th0 * cur.nc : 0.0;
         if (f0 < kEpsilon) f0 = 0.0;
         double f[K];
         double part = f0;
@@ -215,18 +251,25 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         th = theta_src<kFC>(theta, tsrc, N0, lane);  // (after the first slice's loads were issued: they fly meanwhile)
         th0 = theta_at<kFC>(th, 0);
         stage_windows<kFC>(base, span, M, th, th_win, cnt_win);  // ... and while the windows are staged
-        for (uint32_t s = s_begin; s < s_end; s += 2) {
-            if (s + 1 < s_end) {
-                mB = mask_of(s + 1);
-                issue(s + 1, mB, B);
-            }
+        // The steady loop issues UNCONDITIONALLY (the tail is peeled off): where a path that issued nothing joins one that
+        // did, the compiler's wait for an older load is the one that is right for the path with the fewest loads behind it --
+        // on the other path a wait for the loads just issued, i.e. no prefetch.
+        uint32_t s = s_begin;
+        for (; s + 2 < s_end; s += 2) {
+            mB = mask_of(s + 1);
+            issue(s + 1, mB, B);
             reduce(A, mA);
-            if (s + 1 >= s_end) break;
-            if (s + 2 < s_end) {
-                mA = mask_of(s + 2);
-                issue(s + 2, mA, A);
-            }
+            mA = mask_of(s + 2);
+            issue(s + 2, mA, A);
             reduce(B, mB);
+        }
+        if (s + 1 < s_end) {
+            mB = mask_of(s + 1);
+            issue(s + 1, mB, B);
+            reduce(A, mA);
+            reduce(B, mB);
+        } else {
+            reduce(A, mA);
         }
     } else {
         // ring of NBUF register sets (fully unrolled: every index is static): NBUF - 1 slices in flight while one is reduced
@@ -237,27 +280,31 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         th = theta_src<kFC>(theta, tsrc, N0, lane);
         th0 = theta_at<kFC>(th, 0);
         stage_windows<kFC>(base, span, M, th, th_win, cnt_win);
+        // Every issue is UNCONDITIONAL (see the two-set loop above): past the block's end the last slice is simply loaded
+        // again (NBUF - 1 redundant slices per block of ~160, never reduced), and the steady loop runs over whole groups
+        // of NBUF slices; what is left (< NBUF slices, all issued by then) is reduced after it.
+        auto within = [&](uint32_t t) -> uint32_t { return t < s_end ? t : s_end - 1u; };
 #pragma unroll
-        for (int j = 1; j < NBUF - 1; j++)
-            if (s_begin + j < s_end) {
-                mk[j] = mask_of(s_begin + j);
-                issue(s_begin + j, mk[j], buf[j]);
-            }
-        for (uint32_t s = s_begin; s < s_end; s += NBUF) {
+        for (int j = 1; j < NBUF - 1; j++) {
+            const uint32_t tt = within(s_begin + j);
+            mk[j] = mask_of(tt);
+            issue(tt, mk[j], buf[j]);
+        }
+        uint32_t s = s_begin;
+        for (; s + NBUF <= s_end; s += NBUF) {
 #pragma unroll
             for (int j = 0; j < NBUF; j++) {
-                const uint32_t t = s + j;
-                if (t < s_end) {  // (uniform over the wave)
-                    constexpr int ahead = NBUF - 1;
-                    const int nj = (j + ahead) % NBUF;  // static after unrolling
-                    if (t + ahead < s_end) {
-                        mk[nj] = mask_of(t + ahead);
-                        issue(t + ahead, mk[nj], buf[nj]);
-                    }
-                    reduce(buf[j], mk[j]);
-                }
+                constexpr int ahead = NBUF - 1;
+                const int nj = (j + ahead) % NBUF;  // static after unrolling
+                const uint32_t tt = within(s + j + ahead);
+                mk[nj] = mask_of(tt);
+                issue(tt, mk[nj], buf[nj]);
+                reduce(buf[j], mk[j]);
             }
         }
+#pragma unroll
+        for (int j = 0; j < NBUF - 1; j++)
+            if (s + j < s_end) reduce(buf[j], mk[j]);  // (uniform over the wave)
     }
     spill(rsid, acc);
 }

@@ -95,11 +95,17 @@ __global__ __launch_bounds__(kBlock, RSEM_GIBBS_MIN_WAVES) void k_sample_z_lane(
         const uint32_t s_begin = S.slice_base + U.slice_begin + (uint32_t)w * U.per_wave;
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
         const double g0 = g[0];
-        if (s_begin < u_end) switch (S.K) {
-            case 1: gibbs_block<1>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ptab, ph, sweep, counts, noise, M); break;
-            case 2: gibbs_block<2>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ptab, ph, sweep, counts, noise, M); break;
-            case 3: gibbs_block<3>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ptab, ph, sweep, counts, noise, M); break;
-            default: gibbs_block<4>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ptab, ph, sweep, counts, noise, M); break;
+#define RSEM_GIBBS_BLOCK(KK, FF) gibbs_block<KK, FF>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ptab, ph, sweep, counts, noise, M)
+        if (s_begin < u_end) switch (S.K + (U.pad[0] != 0 ? 4 : 0)) {  // (uniform over the workgroup)
+            case 1: RSEM_GIBBS_BLOCK(1, false); break;
+            case 2: RSEM_GIBBS_BLOCK(2, false); break;
+            case 3: RSEM_GIBBS_BLOCK(3, false); break;
+            case 4: RSEM_GIBBS_BLOCK(4, false); break;
+            case 5: RSEM_GIBBS_BLOCK(1, true); break;
+            case 6: RSEM_GIBBS_BLOCK(2, true); break;
+            case 7: RSEM_GIBBS_BLOCK(3, true); break;
+            default: RSEM_GIBBS_BLOCK(4, true); break;
+#undef RSEM_GIBBS_BLOCK
         } else stage_gwindows(U.base, U.span, M, g, g_win, cnt_win);
     }
     for (int d = 32; d >= 1; d >>= 1) noise += __shfl_xor(noise, d);
@@ -899,6 +905,8 @@ int ensure_parallel_layout(rsem_gibbs_ctx* c) {
     c->n_units = (uint32_t)units.size();
     RSEM_HIP_TRY(dmalloc(&c->d_units, units.size()));
     if (!units.empty()) RSEM_HIP_TRY(hipMemcpy(c->d_units, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice));
+    rc = sell_flag_far_units(c->L, units, c->d_units, st);  // Unit::pad[0]: ids outside the unit's window
+    if (rc != RSEM_OK) return rc;
     RSEM_HIP_TRY(dmalloc(&c->d_g, (size_t)c->M + 1));
     if (c->L.n_long_rows == 0) {  // the split CSR was only needed to build the slices
         hipFree(c->d_sid); hipFree(c->d_cp); hipFree(c->d_row_ptr); hipFree(c->d_ncp);

@@ -43,7 +43,8 @@ __host__ RSEM_DEVFN PtabEntry slice_ptab_entry(const Shape& S, uint32_t T, uint3
 // keeps the g values and integer pick counters of its current sid tuple in registers and spills
 // them to the workgroup's LDS window when the tuple changes.  Weight order inside a read: noise,
 // then the G lanes of the read in order, each lane's K planes in order.
-template <int K>
+// kFar: the unit has ids outside its window (estep_block.hpp); units without never leave LDS inside the loop
+template <int K, bool kFar>
 RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
                                    const double* __restrict__ g, double g0, double* g_win, int* cnt_win,
                                    const double* __restrict__ scp, const int32_t* __restrict__ ssid,
@@ -61,6 +62,7 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
         if (t - m_base >= 64u) {
             m_base = t;
             mv = (t + lane < s_end) ? masks[t + lane] : ~0ull;
+            RSEM_PIN(mv);  // (the wait for this load stays in this rare branch: at the join it would be a wait for everything, every slice)
         }
         const int src = (int)(t - m_base);
         const uint32_t lo = RSEM_READLANE((int)(uint32_t)mv, src);
@@ -73,26 +75,28 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
         // loaded by all lanes or (mask 0) by none
         const uint64_t p0 = (S.plane_base + (uint64_t)sl * K) * 64;
         const unsigned ulane = (unsigned)lane;
-        if (m != 0ull) {
-            const int32_t* __restrict__ ip = ssid + p0;
+        {   // (always K loads: of the shape's first slice where no tuple starts in this one -- estep_block.hpp says why)
+            const int32_t* __restrict__ ip = ssid + (m != 0ull ? p0 : S.plane_base * 64);
 #pragma unroll
             for (int k = 0; k < K; k++) b.id[k] = ip[k * 64 + ulane];
         }
         const double* __restrict__ vp = scp + p0;
 #pragma unroll
         for (int k = 0; k < K; k++) b.c[k] = RSEM_NT_LOAD(&vp[k * 64 + ulane]);
-        b.nc = g0lane ? (sncp + (S.slot_base + sl * R))[ulane >> lg] : 0.0;
+        b.nc = (sncp + (S.slot_base + sl * R))[ulane >> lg];  // (all lanes of the read: no load under a lane predicate)
     };
     int rsid[K], acc[K];
     double rg[K];
 #pragma unroll
     for (int k = 0; k < K; k++) { rsid[k] = 0; acc[k] = 0; rg[k] = 0.0; }
     auto spill = [&]() {
+        // (LDS atomics spelled out: one atomic on a selected address would be a FLAT one)
 #pragma unroll
         for (int k = 0; k < K; k++) {
             if (acc[k] != 0) {
                 const unsigned off = (unsigned)(rsid[k] - base);
-                if (off < (unsigned)span) RSEM_ATOMIC_ADD_I32(&cnt_win[off], acc[k]);
+                if (!kFar) RSEM_LDS_ADD_I32(&cnt_win[off < (unsigned)span ? off : 0u], acc[k]);  // (the clamp never acts)
+                else if (off < (unsigned)span) RSEM_LDS_ADD_I32(&cnt_win[off], acc[k]);
                 else RSEM_ATOMIC_ADD_I32(&counts[rsid[k]], acc[k]);
             }
             acc[k] = 0;
@@ -102,16 +106,31 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
         if (cur_m != 0ull) {
             if ((cur_m >> lane) & 1ull) {
                 spill();
+                // as in the E step (estep_block.hpp): LDS for every id, a branch of its own for the ids outside the window --
+                // never one flat load of a selected address, after which every wait is for everything in flight
+                bool far = false;
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     const int sidv = cur.id[k];
                     rsid[k] = sidv;
                     const unsigned off = (unsigned)(sidv - base);
-                    rg[k] = (off < (unsigned)span) ? g_win[off] : g[sidv];
+                    const bool in = off < (unsigned)span;
+                    rg[k] = g_win[in ? off : 0u];
+                    far = far || !in;
+                }
+                if (kFar && far) {
+                    double t[K];
+#pragma unroll
+                    for (int k = 0; k < K; k++) t[k] = g[(unsigned)(rsid[k] - base) < (unsigned)span ? 0 : rsid[k]];
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        RSEM_PIN(t[k]);
+                        if (!((unsigned)(rsid[k] - base) < (unsigned)span)) rg[k] = t[k];
+                    }
                 }
             }
         }
-        const double f0 = g0 * cur.nc;
+        const double f0 = g0lane ? g0 * cur.nc : 0.0;
         double f[K];
         double part = f0;
 #pragma unroll
@@ -165,12 +184,23 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
     unsigned long long mA = ~0ull, mB = 0;
     issue(s_begin, mA, A);
     stage_gwindows(base, span, M, g, g_win, cnt_win);  // the first slice's loads fly while the windows are staged
-    for (uint32_t s = s_begin; s < s_end; s += 2) {
-        if (s + 1 < s_end) { mB = mask_of(s + 1); issue(s + 1, mB, B); }
+    // (the steady loop issues unconditionally, the tail is peeled off: estep_block.hpp says why)
+    uint32_t s = s_begin;
+    for (; s + 2 < s_end; s += 2) {
+        mB = mask_of(s + 1);
+        issue(s + 1, mB, B);
         sample(A, mA, s);
-        if (s + 1 >= s_end) break;
-        if (s + 2 < s_end) { mA = mask_of(s + 2); issue(s + 2, mA, A); }
+        mA = mask_of(s + 2);
+        issue(s + 2, mA, A);
         sample(B, mB, s + 1);
+    }
+    if (s + 1 < s_end) {
+        mB = mask_of(s + 1);
+        issue(s + 1, mB, B);
+        sample(A, mA, s);
+        sample(B, mB, s + 1);
+    } else {
+        sample(A, mA, s);
     }
     spill();
 }

@@ -501,7 +501,7 @@ struct Unit {
     uint32_t per_wave;     // wave w walks slices [slice_begin + w * per_wave, + per_wave)
     int32_t base;
     int32_t span;          // sids [base, base + span) are staged in LDS (<= the window capacity)
-    int32_t pad[2];
+    int32_t pad[2];        // pad[0]: 1 = some id of the unit lies outside [base, base + span) (sell_flag_far_units)
     Shape S;               // copy of the shape: one dependent load less at the start of every workgroup
 };
 
@@ -558,6 +558,33 @@ inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units, int w
     std::stable_sort(units.begin(), units.end(), [&](const Unit& a, const Unit& b) {
         return (uint64_t)L.h_shapes[a.shape].K * a.n_slices > (uint64_t)L.h_shapes[b.shape].K * b.n_slices;
     });
+    return RSEM_OK;
+}
+
+// Which units have an id outside their window?  The kernels run the others through a loop that never leaves LDS for theta
+// and counts (estep_block.hpp, gibbs_block.hpp: template parameter kFar).  Empty plane entries hold id 0 and value 0: not
+// counted.  One workgroup per unit; the flag lands in Unit::pad[0] on the device and in `units`.
+__host__ __device__ inline bool unit_entry_is_far(const Unit& U, int32_t v) { return v > 0 && (unsigned)(v - U.base) >= (unsigned)U.span; }
+
+__global__ __launch_bounds__(256) void k_unit_far(Unit* units, const int32_t* __restrict__ ssid) {
+    __shared__ int any;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    const Unit U = units[blockIdx.x];
+    const uint64_t p0 = (U.S.plane_base + (uint64_t)U.slice_begin * U.S.K) * 64, n = (uint64_t)U.n_slices * U.S.K * 64;
+    bool far = false;
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) far = far || unit_entry_is_far(U, ssid[p0 + i]);
+    if (far) any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) units[blockIdx.x].pad[0] = any;
+}
+
+inline int sell_flag_far_units(const SellLayout& L, std::vector<Unit>& units, Unit* d_units, hipStream_t st) {
+    if (units.empty()) return RSEM_OK;
+    hipLaunchKernelGGL(k_unit_far, dim3((unsigned)units.size()), dim3(256), 0, st, d_units, (const int32_t*)L.d_ssid);
+    RSEM_HIP_TRY(hipGetLastError());
+    RSEM_HIP_TRY(hipMemcpyAsync(units.data(), d_units, sizeof(Unit) * units.size(), hipMemcpyDeviceToHost, st));
+    RSEM_HIP_TRY(hipStreamSynchronize(st));
     return RSEM_OK;
 }
 

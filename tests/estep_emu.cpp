@@ -24,6 +24,7 @@ struct Job {
     Shape S;
     uint32_t slice_begin, n_slices;
     int base, span, M;
+    bool far;  // the rule of sell_flag_far_units (sell_layout.hpp): some id of the unit lies outside its window
     bool from_counts;
     const double* theta;  // plain: theta[M+1]; from_counts: counts[M+1] followed by 2 * kTotSlots totals
     double N0;
@@ -47,18 +48,26 @@ static void lane_body(Job* J, int tid) {
     const uint32_t s_end = std::min(u_end, s_begin + per_wave);
     const double* tsrc = J->theta + J->M + 1;
     double noise = 0.0, neff = 0.0;
-#define EMU_BLOCK(KK, QQ)                                                                                                          \
-    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1])>(S, s_begin, s_end, lane, J->base, J->span, J->theta, tsrc, J->N0, \
+#define EMU_BLOCK(KK, QQ, FF)                                                                                                      \
+    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF>(S, s_begin, s_end, lane, J->base, J->span, J->theta, tsrc, J->N0, \
         J->th_win, J->cnt_win, H.sval.data(), H.sexp.data(), H.ssid.data(), H.sncp.data(), H.masks.data(), J->counts, noise, neff, J->M)
-    if (s_begin < u_end) switch (S.K + 4 * S.fmt) {
-        case 1: EMU_BLOCK(1, false); break;
-        case 2: EMU_BLOCK(2, false); break;
-        case 3: EMU_BLOCK(3, false); break;
-        case 4: EMU_BLOCK(4, false); break;
-        case 5: EMU_BLOCK(1, true); break;
-        case 6: EMU_BLOCK(2, true); break;
-        case 7: EMU_BLOCK(3, true); break;
-        default: EMU_BLOCK(4, true); break;
+    if (s_begin < u_end) switch (S.K + 4 * S.fmt + (J->far ? 8 : 0)) {
+        case 1: EMU_BLOCK(1, false, false); break;
+        case 2: EMU_BLOCK(2, false, false); break;
+        case 3: EMU_BLOCK(3, false, false); break;
+        case 4: EMU_BLOCK(4, false, false); break;
+        case 5: EMU_BLOCK(1, true, false); break;
+        case 6: EMU_BLOCK(2, true, false); break;
+        case 7: EMU_BLOCK(3, true, false); break;
+        case 8: EMU_BLOCK(4, true, false); break;
+        case 9: EMU_BLOCK(1, false, true); break;
+        case 10: EMU_BLOCK(2, false, true); break;
+        case 11: EMU_BLOCK(3, false, true); break;
+        case 12: EMU_BLOCK(4, false, true); break;
+        case 13: EMU_BLOCK(1, true, true); break;
+        case 14: EMU_BLOCK(2, true, true); break;
+        case 15: EMU_BLOCK(3, true, true); break;
+        default: EMU_BLOCK(4, true, true); break;
     } else {
         const ThetaSrc th = theta_src<kFC>(J->theta, tsrc, J->N0, lane);
         stage_windows<kFC>(J->base, J->span, J->M, th, J->th_win, J->cnt_win);
@@ -110,6 +119,14 @@ int main(int argc, char** argv) {
             if (lo > hi) { lo = 1; hi = 1; }
             J->base = lo;
             J->span = std::min(hi - lo + 1, hdr[7] > 0 ? hdr[7] : kWindow);  // hdr[7]: a smaller window, to force the out-of-window path
+            J->far = false;
+            {
+                Unit U{};
+                U.base = J->base;
+                U.span = J->span;
+                for (uint64_t p = (S.plane_base + (uint64_t)b0 * S.K) * 64; p < (S.plane_base + (uint64_t)(b0 + J->n_slices) * S.K) * 64; p++)
+                    J->far = J->far || unit_entry_is_far(U, H.ssid[p]);
+            }
             J->M = M;
             J->from_counts = from_counts;
             J->theta = theta.data();

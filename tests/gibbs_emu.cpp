@@ -21,6 +21,7 @@ struct Job {
     Shape S;
     uint32_t slice_begin, n_slices;
     int base, span, M;
+    bool far;  // the rule of sell_flag_far_units (sell_layout.hpp)
     const double* g;
     const PtabEntry* ptab;
     Philox ph;
@@ -45,12 +46,16 @@ static void lane_body(Job* J, int tid) {
     const double* scp = (const double*)H.sval.data();  // F64 layout: plane p at scp + p * 64
     int noise = 0;
     const double g0 = J->g[0];
-#define EMU_BLOCK(KK) gibbs_block<KK>(S, T, s_begin, s_end, lane, J->base, J->span, J->g, g0, J->g_win, J->cnt_win, scp, H.ssid.data(), H.sncp.data(), H.masks.data(), J->ptab, J->ph, J->sweep, J->counts, noise, J->M)
-    if (s_begin < u_end) switch (S.K) {
-        case 1: EMU_BLOCK(1); break;
-        case 2: EMU_BLOCK(2); break;
-        case 3: EMU_BLOCK(3); break;
-        default: EMU_BLOCK(4); break;
+#define EMU_BLOCK(KK, FF) gibbs_block<KK, FF>(S, T, s_begin, s_end, lane, J->base, J->span, J->g, g0, J->g_win, J->cnt_win, scp, H.ssid.data(), H.sncp.data(), H.masks.data(), J->ptab, J->ph, J->sweep, J->counts, noise, J->M)
+    if (s_begin < u_end) switch (S.K + (J->far ? 4 : 0)) {
+        case 1: EMU_BLOCK(1, false); break;
+        case 2: EMU_BLOCK(2, false); break;
+        case 3: EMU_BLOCK(3, false); break;
+        case 4: EMU_BLOCK(4, false); break;
+        case 5: EMU_BLOCK(1, true); break;
+        case 6: EMU_BLOCK(2, true); break;
+        case 7: EMU_BLOCK(3, true); break;
+        default: EMU_BLOCK(4, true); break;
     } else stage_gwindows(J->base, J->span, J->M, J->g, J->g_win, J->cnt_win);
 #undef EMU_BLOCK
     if (noise) __atomic_fetch_add(&J->s_noise, noise, __ATOMIC_RELAXED);
@@ -100,6 +105,14 @@ int main(int argc, char** argv) {
                 if (lo > hi) { lo = 1; hi = 1; }
                 J->base = lo;
                 J->span = std::min(hi - lo + 1, hdr[5] > 0 ? hdr[5] : kGWindow);
+                J->far = false;
+                {
+                    Unit U{};
+                    U.base = J->base;
+                    U.span = J->span;
+                    for (uint64_t p = (S.plane_base + (uint64_t)b0 * S.K) * 64; p < (S.plane_base + (uint64_t)(b0 + J->n_slices) * S.K) * 64; p++)
+                        J->far = J->far || unit_entry_is_far(U, H.ssid[p]);
+                }
                 J->M = M;
                 J->g = g.data();
                 J->ptab = ptab.data();

@@ -28,7 +28,7 @@ class FakeCtx:
     def step(self, th, N0):
         n = len(th)
         return np.zeros(n) + 1e300, np.array(th, float), 1.0, 0.0, 0   # (nothing like the oracle's counts: parity must say so)
-    def info(self, k): return {"value_plane_bytes": 1000 if self.opts["value_bits"] == 64 else 520, "reads_q32": 9, "value_range_bits": 8}[k]
+    def info(self, k): return {"value_plane_bytes": 1000 if self.opts["value_bits"] == 64 else 520, "reads_q32": 9, "value_range_bits": 8, "far_units": 1, "units": 7}[k]
     def set_option(self, k, v): self.opts[k] = v
     def set_comm(self, c): pass
     def close(self): pass
