@@ -794,6 +794,7 @@ struct rsem_em_ctx {
     unsigned long long* d_trace = nullptr;  // per-workgroup timestamps (tune_unit_order, rsem_em_debug_trace)
     std::vector<Unit> h_units;
     uint32_t n_far_units = 0;               // units with an id outside their LDS window (Unit::pad[0])
+    unsigned long long n_stray_reads = 0;   // reads the second layout pass sorted apart (sell_build_refined)
     int tune_passes_left = 1;               // measured-lifetime reordering of the units, done on first use
     uint32_t n_units = 0;
     int noise_n = 0;  // workgroups of the last main E-step launch (= valid entries of d_noise_a)
@@ -936,8 +937,9 @@ int build_layout(rsem_em_ctx* c) {
     // one block per wave, ~2.5 blocks per wave slot (6 waves/SIMD) for load balance
     const uint32_t target_waves = (uint32_t)c->n_cus * 4 * 6 * 5 / 2;
     const bool q32 = c->value_bits == 32 && c->have_values;
-    int rc = sell_build(c->L, c->stream, c->N1, c->M, c->d_row_ptr, c->d_sid, target_waves, c->forced_T,
-                        q32 ? c->d_cp : nullptr, c->value_range_bits);
+    std::vector<Unit> units;
+    int rc = sell_build_refined(c->L, c->stream, c->N1, c->M, c->d_row_ptr, c->d_sid, target_waves, c->forced_T,
+                                q32 ? c->d_cp : nullptr, c->value_range_bits, kWindow, units, &c->d_units, &c->n_stray_reads);
     if (rc != RSEM_OK) return rc;
     c->layout_has_q32 = q32;
     RSEM_HIP_TRY(hipMalloc((void**)&c->d_sval, std::max<uint64_t>(c->L.val_bytes, 1)));
@@ -953,18 +955,10 @@ int build_layout(rsem_em_ctx* c) {
         if (rc != RSEM_OK) return rc;
     }
     RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
-    std::vector<Unit> units;
-    rc = sell_build_units(c->L, units, kWindow);
-    if (rc != RSEM_OK) return rc;
     c->n_units = (uint32_t)units.size();
     c->h_units = units;
     c->tune_passes_left = 1;
     if (const char* e = getenv("RSEM_HIP_TUNE")) c->tune_passes_left = atoi(e);  // tuning knob: 0 disables
-    RSEM_HIP_TRY(dmalloc(&c->d_units, units.size()));
-    if (!units.empty())
-        RSEM_HIP_TRY(hipMemcpy(c->d_units, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice));
-    rc = sell_flag_far_units(c->L, c->h_units, c->d_units, c->stream);
-    if (rc != RSEM_OK) return rc;
     c->n_far_units = 0;
     for (const Unit& u : c->h_units) c->n_far_units += u.pad[0] != 0;
     // per-workgroup noise partials: enough for any variant's grid
@@ -1162,6 +1156,7 @@ int rsem_em_get_info(const rsem_em_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "value_range_bits")) *value = c->value_range_bits;
     else if (!strcmp(key, "far_units")) *value = c->n_far_units;                        // units with an id outside their LDS window
     else if (!strcmp(key, "units")) *value = c->n_units;
+    else if (!strcmp(key, "stray_reads")) *value = (int64_t)c->n_stray_reads;             // (a read with two stray ids counts twice)
     else if (!strcmp(key, "reads_q32")) *value = c->L.n_q32_rows;                       // reads held in Q32 planes
     else if (!strcmp(key, "reads_sliced")) *value = c->L.n_sell_rows;                   // reads in the sliced layout
     else if (!strcmp(key, "reads_long")) *value = c->L.n_long_rows;                     // reads left in the CSR

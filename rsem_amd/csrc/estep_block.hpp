@@ -66,17 +66,17 @@ struct SliceRegs {
 // 2^e for the exponents q32_scale_of admits (always a normal double)
 RSEM_DEVFN double pow2_of(int e) { return RSEM_LL_AS_DOUBLE((long long)(1023 + e) << 52); }
 
-// How many slices a wave keeps in flight (register sets).  The loads of a slice are K wave loads of 512 B (F64) or 256 B
-// (Q32): with two sets in flight a Q32 wave has half the bytes outstanding of an F64 wave, and the kernel -- which is
-// bound by memory-level parallelism, not by arithmetic -- then runs no faster on half the traffic (measured:
-// profiles/r02d_bench_with_q32_depth2.json: 3.54 GB instead of 5.83 GB per launch, 1.08 ms instead of 1.05 ms).  Q32 sets
-// are smaller, so the same registers hold more of them; the depths below are what fits in 128 VGPRs (4 waves per SIMD,
-// which the 32 KB of LDS windows allow).  Per K = 1..4.
+// How many slices a wave keeps in flight (register sets), per K = 1..4.  Two: the next slice's loads fly while this one is
+// reduced.  Until round 3 that was true on paper only -- the waits the compiler placed were waits for everything (flat
+// loads, loads under lane predicates and scalar branches, a loop that could leave in the middle: see take_tuples, issue
+// and the loops below) -- and deeper rings of the smaller Q32 sets (8 / 6 / 4 / 3) bought back some of the lost overlap.
+// With exact waits they buy nothing (profiles/r03p_pipelined_waits.log: Q32 at C3 0.713 ms with 2 sets, 0.729 with 4 / 4 /
+// 3 / 2; F64 3 / 3 / 2 / 2 0.970 against 0.975) and cost registers; the ring loop stays for depths > 2 (tests build it).
 #ifndef RSEM_F64_DEPTHS
 #define RSEM_F64_DEPTHS 2, 2, 2, 2
 #endif
 #ifndef RSEM_Q32_DEPTHS
-#define RSEM_Q32_DEPTHS 4, 4, 3, 2
+#define RSEM_Q32_DEPTHS 2, 2, 2, 2
 #endif
 // Measured in round 3 (profiles/r03a_variants_and_steps.log, C3 / C2, F64 / Q32 launch) and adopted: the per-read normaliser's
 // butterfly over 2..16 lanes with DPP moves instead of ds_bpermute (same additions in the same order: bit-identical; Q32

@@ -886,7 +886,9 @@ int ensure_parallel_layout(rsem_gibbs_ctx* c) {
                            c->d_row_ptr, c->d_sid, c->d_cp);
         RSEM_HIP_TRY(hipGetLastError());
     }
-    int rc = sell_build(c->L, st, N1, c->M, c->d_row_ptr, c->d_sid, (uint32_t)c->n_cus * 4 * 6 * 5 / 2);
+    std::vector<Unit> units;
+    int rc = sell_build_refined(c->L, st, N1, c->M, c->d_row_ptr, c->d_sid, (uint32_t)c->n_cus * 4 * 6 * 5 / 2, 0, nullptr, 0, kGWindow, units,
+                                &c->d_units);  // (Unit::pad[0]: ids outside the unit's window)
     if (rc != RSEM_OK) return rc;
     RSEM_HIP_TRY(dmalloc(&c->d_scp, c->L.n_planes * 64));
     RSEM_HIP_TRY(dmalloc(&c->d_sncp, (size_t)c->L.n_slots));
@@ -899,14 +901,7 @@ int ensure_parallel_layout(rsem_gibbs_ctx* c) {
         RSEM_HIP_TRY(hipGetLastError());
     }
     RSEM_HIP_TRY(hipStreamSynchronize(st));
-    std::vector<Unit> units;
-    rc = sell_build_units(c->L, units, kGWindow);
-    if (rc != RSEM_OK) return rc;
     c->n_units = (uint32_t)units.size();
-    RSEM_HIP_TRY(dmalloc(&c->d_units, units.size()));
-    if (!units.empty()) RSEM_HIP_TRY(hipMemcpy(c->d_units, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice));
-    rc = sell_flag_far_units(c->L, units, c->d_units, st);  // Unit::pad[0]: ids outside the unit's window
-    if (rc != RSEM_OK) return rc;
     RSEM_HIP_TRY(dmalloc(&c->d_g, (size_t)c->M + 1));
     if (c->L.n_long_rows == 0) {  // the split CSR was only needed to build the slices
         hipFree(c->d_sid); hipFree(c->d_cp); hipFree(c->d_row_ptr); hipFree(c->d_ncp);

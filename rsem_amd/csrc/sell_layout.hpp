@@ -186,11 +186,12 @@ __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint
 
 __global__ void k_row_keys(uint64_t N1, int32_t M, const uint64_t* __restrict__ row_ptr,
                            const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits, int apart,
-                           uint64_t* keys, uint32_t* vals, int* err) {
+                           const unsigned char* __restrict__ also_apart, uint64_t* keys, uint32_t* vals, int* err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N1) return;
     int e = 0;
-    const uint64_t key = row_key_of(i, M, row_ptr, sid, cp, range_bits, apart, &e);
+    uint64_t key = row_key_of(i, M, row_ptr, sid, cp, range_bits, apart, &e);
+    if (also_apart && also_apart[i]) key |= 1ull << kKeyApartBit;  // (a read the first layout found outside its unit's window)
     if (e) *err = e;
     if (e == 1) return;
     keys[i] = key;
@@ -386,7 +387,7 @@ inline int sell_fill_values(const SellLayout& L, hipStream_t st, const uint64_t*
 // qualify (q32_scale_of with range_bits) are placed in Q32 shapes.
 inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, const uint64_t* d_row_ptr,
                       const int32_t* d_sid, uint32_t target_waves, uint32_t forced_T = 0,
-                      const double* d_cp_for_q32 = nullptr, int range_bits = 0) {
+                      const double* d_cp_for_q32 = nullptr, int range_bits = 0, const unsigned char* d_also_apart = nullptr) {
     L.N1 = N1;
     int apart = kLayoutWindow;
     if (const char* e = getenv("RSEM_HIP_APART")) apart = atoi(e) ? kLayoutWindow : 0;  // measurement knob: 0 = one sorted sequence per shape
@@ -407,7 +408,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     RSEM_HIP_TRY(hipMemsetAsync(d_first, 0xff, kShapeIds * sizeof(uint32_t), st));
     if (N1) {
         hipLaunchKernelGGL(k_row_keys, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, M, d_row_ptr, d_sid,
-                           d_cp_for_q32, range_bits, apart, d_keys, d_vals, d_err);
+                           d_cp_for_q32, range_bits, apart, d_also_apart, d_keys, d_vals, d_err);
         RSEM_HIP_TRY(hipGetLastError());
         size_t tb = 0;
         RSEM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_keys, d_keys2, d_vals, L.d_order, N1, 0, 64, st));
@@ -585,6 +586,83 @@ inline int sell_flag_far_units(const SellLayout& L, std::vector<Unit>& units, Un
     RSEM_HIP_TRY(hipGetLastError());
     RSEM_HIP_TRY(hipMemcpyAsync(units.data(), d_units, sizeof(Unit) * units.size(), hipMemcpyDeviceToHost, st));
     RSEM_HIP_TRY(hipStreamSynchronize(st));
+    return RSEM_OK;
+}
+
+// The reads of the units that are NOT made of far-reaching reads but still have an id outside the unit's window -- a read
+// whose foreign id happens to lie within a window's width of its anchor (so the sort key kept it among the compact reads),
+// while the unit's window, as wide as its reads' ids need, ends before it.  A handful per unit are enough to send the
+// whole unit through the loop with the global gather (kFar).  They are marked here; a second layout sorts them behind the
+// compact reads with the other far-reaching ones (k_row_keys: also_apart), and the compact units stay clean.
+__global__ __launch_bounds__(256) void k_mark_stray_reads(const Unit* __restrict__ units, const int32_t* __restrict__ ssid, const uint32_t* __restrict__ order,
+                                                          uint32_t T, int32_t M, const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
+                                                          unsigned char* also_apart, unsigned long long* n_marked) {
+    const Unit U = units[blockIdx.x];
+    if (U.pad[0] == 0) return;
+    const Shape& S = U.S;
+    const uint32_t R = shape_R(S), rpb = R * T;
+    const uint64_t p0 = (S.plane_base + (uint64_t)U.slice_begin * S.K) * 64, n = (uint64_t)U.n_slices * S.K * 64;
+    unsigned long long mine = 0;
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        if (!unit_entry_is_far(U, ssid[p0 + i])) continue;
+        const uint32_t sl = U.slice_begin + (uint32_t)(i / ((uint64_t)S.K * 64));  // slice within the shape
+        const uint32_t r = (uint32_t)(i % 64) >> S.lg;                            // row slot within the slice
+        const uint32_t b = sl / T, t = sl % T;                                    // the inverse of row_to_slot
+        const uint32_t left = S.n_rows - b * rpb, nb = left < rpb ? left : rpb, Tb = (nb + R - 1) / R;
+        const uint32_t q = b * rpb + r * Tb + t;
+        const uint32_t orig = order[S.row_base + q];
+        int e = 0;
+        const uint64_t key = row_key_of(orig, M, row_ptr, sid, nullptr, 0, kLayoutWindow, &e);
+        if (((key >> kKeyApartBit) & 1ull) == 0ull && also_apart[orig] == 0) {  // (a far-reaching read is where it belongs already)
+            also_apart[orig] = 1;
+            ++mine;
+        }
+    }
+    if (mine) atomicAdd(n_marked, mine);  // (a read with two such ids may count twice: only "any?" matters)
+}
+
+// sell_build + units + far flags, and once more with the stray reads sorted apart if there are any.  d_units: device copy of
+// `units` (allocated here; the caller owns it).  RSEM_HIP_APART=0 switches the apart bit and this refinement off.
+inline int sell_build_refined(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, const uint64_t* d_row_ptr, const int32_t* d_sid,
+                              uint32_t target_waves, uint32_t forced_T, const double* d_cp_for_q32, int range_bits, int window_cap,
+                              std::vector<Unit>& units, Unit** d_units, unsigned long long* n_strays = nullptr) {
+    unsigned char* d_also = nullptr;
+    unsigned long long* d_n = nullptr;
+    if (n_strays) *n_strays = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        int rc = sell_build(L, st, N1, M, d_row_ptr, d_sid, target_waves, forced_T, d_cp_for_q32, range_bits, d_also);
+        if (rc == RSEM_OK) rc = sell_build_units(L, units, window_cap);
+        if (rc != RSEM_OK) { (void)hipFree(d_also); return rc; }
+        (void)hipFree(*d_units);
+        *d_units = nullptr;
+        hipError_t e = dmalloc(d_units, units.size());
+        if (e == hipSuccess && !units.empty()) e = hipMemcpyAsync(*d_units, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { (void)hipFree(d_also); RSEM_HIP_TRY(e); }
+        rc = sell_flag_far_units(L, units, *d_units, st);
+        if (rc != RSEM_OK) { (void)hipFree(d_also); return rc; }
+        bool any_far = false;
+        for (const Unit& u : units) any_far = any_far || u.pad[0] != 0;
+        const char* knob = getenv("RSEM_HIP_APART");
+        if (pass == 1 || !any_far || N1 == 0 || (knob && atoi(knob) == 0)) break;
+        unsigned long long n = 0;
+        e = hipMalloc((void**)&d_also, N1);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_n, sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemsetAsync(d_also, 0, N1, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, sizeof(unsigned long long), st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_mark_stray_reads, dim3((unsigned)units.size()), dim3(256), 0, st, (const Unit*)*d_units, (const int32_t*)L.d_ssid,
+                               (const uint32_t*)L.d_order, L.T, M, d_row_ptr, d_sid, d_also, d_n);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&n, d_n, sizeof(n), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d_n);
+        if (e != hipSuccess) { (void)hipFree(d_also); RSEM_HIP_TRY(e); }
+        if (n == 0) break;  // every far unit is made of far-reaching reads: nothing to gain
+        if (n_strays) *n_strays = n;
+        sell_free(L);       // second pass with the marks
+    }
+    (void)hipFree(d_also);
     return RSEM_OK;
 }
 

@@ -325,4 +325,18 @@ def test_reads_that_also_hit_another_gene(config, scale, monkeypatch):
     ocq[0] += wl["N0"]
     counts, *_ = ctx.step(wl["theta0"], wl["N0"])
     assert np.allclose(counts, ocq, rtol=1e-9, atol=1e-9)
+    ctx.set_option("value_bits", 64)
+    # the layout: far-reaching reads sort behind the others of their shape and the few compact reads whose foreign id lies
+    # within a window's width join them in a second pass (sell_build_refined), so that most units keep every id inside their
+    # LDS window; with the knob off they are mixed in and (nearly) every unit has ids outside.  Same counts either way.
+    far, units, strays = ctx.info("far_units"), ctx.info("units"), ctx.info("stray_reads")
+    ctx.close()
+    monkeypatch.setenv("RSEM_HIP_APART", "0")
+    ctx = capi().EmContext(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
+    counts, *_ = ctx.step(wl["theta0"], wl["N0"])
+    assert np.allclose(counts, oc, rtol=1e-9, atol=1e-9)
+    far_mixed = ctx.info("far_units")
+    print("%s: units with ids outside their window %d of %d (reads sorted apart in the second pass: %d); all reads in one sequence: %d" % (
+        config, far, units, strays, far_mixed))
+    assert far < far_mixed and ctx.info("stray_reads") == 0
     ctx.close()
