@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
 #include "gibbs_exact_wg.hpp"
 
 template <bool kInit>
-__global__ __launch_bounds__(kXT) void k_gibbs_exact_wg(uint32_t n_tiles, const uint32_t* __restrict__ tile_start,
+__global__ __launch_bounds__(kXT) void k_gibbs_exact_wg(uint32_t n_tiles, const uint32_t* __restrict__ tile_start, const uint64_t* __restrict__ tile_items,
                                                         const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
                                                         const double* __restrict__ cp, int32_t* counts_base, int32_t* z_base,
                                                         double pseudoC, MtState* mt_base, const int32_t* __restrict__ last_round,
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(kXT) void k_gibbs_exact_wg(uint32_t n_tiles, const 
     for (int i = threadIdx.x; i < kXKeys; i += blockDim.x) tile.key[i] = 0;
     for (int i = threadIdx.x; i < kXBits / 64; i += blockDim.x) tile.bits[i] = 0ull;
     __syncthreads();
-    gibbs_exact_wg_body<kInit>((int)threadIdx.x, &tile, n_tiles, tile_start, row_ptr, sid, cp, counts_base + (uint64_t)chain * stride_c,
+    gibbs_exact_wg_body<kInit>((int)threadIdx.x, &tile, n_tiles, tile_start, tile_items, row_ptr, sid, cp, counts_base + (uint64_t)chain * stride_c,
                                z_base + (uint64_t)chain * stride_z, pseudoC, prof);
     __syncthreads();
     for (int i = threadIdx.x; i < 624; i += blockDim.x) mt_state->mt[i] = tile.mt[i];
@@ -765,6 +765,7 @@ struct rsem_gibbs_ctx {
     int32_t* d_isid = nullptr;
     double* d_icp = nullptr;
     uint32_t* d_tiles = nullptr;  // k_gibbs_exact_wg: first read of every tile (+ N1), gx_build_tiles
+    uint64_t* d_tile_items = nullptr;  // ... and its first item (row_ptr[d_tiles[t]])
     uint32_t n_tiles = 0;
     // PARALLEL mode, built on the device at its first use: noise split out + the sliced layout
     bool have_parallel = false;
@@ -941,7 +942,7 @@ int rsem_gibbs_chain_seeds(uint32_t seed, int nchains, uint32_t* out) {
 int rsem_gibbs_destroy(rsem_gibbs_ctx* c) {
     if (!c) return RSEM_OK;
     (void)hipSetDevice(c->device);
-    hipFree(c->d_irp); hipFree(c->d_isid); hipFree(c->d_icp); hipFree(c->d_tiles); hipFree(c->d_row_ptr); hipFree(c->d_sid);
+    hipFree(c->d_irp); hipFree(c->d_isid); hipFree(c->d_icp); hipFree(c->d_tiles); hipFree(c->d_tile_items); hipFree(c->d_row_ptr); hipFree(c->d_sid);
     hipFree(c->d_ptab);
     hipFree(c->d_cp); hipFree(c->d_ncp); sell_free(c->L); hipFree(c->d_scp); hipFree(c->d_sncp);
     hipFree(c->d_init_counts); hipFree(c->d_g); hipFree(c->d_alpha);
@@ -1044,6 +1045,11 @@ int rsem_gibbs_create(rsem_gibbs_ctx** out, int device, int32_t M, uint64_t N1, 
     c->n_tiles = (uint32_t)tiles.size() - 1;
     G_TRY(dmalloc(&c->d_tiles, tiles.size()));
     G_TRY(hipMemcpyAsync(c->d_tiles, tiles.data(), sizeof(uint32_t) * tiles.size(), hipMemcpyHostToDevice, st));
+    std::vector<uint64_t> tile_items(tiles.size());
+    for (size_t i = 0; i < tiles.size(); i++) tile_items[i] = row_ptr[tiles[i]];
+    G_TRY(dmalloc(&c->d_tile_items, tile_items.size()));
+    G_TRY(hipMemcpyAsync(c->d_tile_items, tile_items.data(), sizeof(uint64_t) * tile_items.size(), hipMemcpyHostToDevice, st));
+    G_TRY(hipStreamSynchronize(st));  // (tile_items is a local)
     // the ids index counts[] on the device: check them there (the host copy is not walked)
     int* d_err = nullptr;
     int h_err = 0;
@@ -1157,7 +1163,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
 #define EXACT_ARGS c->N1, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->d_alpha, c->pseudoC, \
                    mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z
             if (impl == kExactWg) {
-#define EXACT_WG_ARGS c->n_tiles, c->d_tiles, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->pseudoC, \
+#define EXACT_WG_ARGS c->n_tiles, c->d_tiles, c->d_tile_items, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->pseudoC, \
                       mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z, \
                       ((RSEM_GX_PROFILE && !init) ? prof_buf.as<unsigned long long>() : (unsigned long long*)nullptr)
                 if (init) hipLaunchKernelGGL(k_gibbs_exact_wg<true>, dim3(nchains), dim3(kXT), 0, st, EXACT_WG_ARGS);

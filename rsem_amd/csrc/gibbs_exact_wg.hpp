@@ -140,11 +140,52 @@ static_assert(kXKeys == 1024, "gx_hash returns 10 bits");
 // One sweep over all reads in file order (Gibbs.cpp:297-311), or the initial assignment (Gibbs.cpp:281-291) when kInit.
 // Called by every thread of the chain's workgroup (g = 0 .. kXT-1); L->mt / L->idx hold the chain's generator.
 template <bool kInit>
-GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint32_t* __restrict__ tile_start,
+GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint32_t* __restrict__ tile_start, const uint64_t* __restrict__ tile_items,
                                   const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid, const double* __restrict__ cp,
                                   int32_t* counts, int32_t* z, double pseudoC, unsigned long long* prof) {
     const int lane = g & 63, w = g >> 6;
     unsigned long long pa[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // What the staging of a tile needs is loaded one tile AHEAD, into registers (the kernel may use 512 of them): issued when
+    // the tile before it starts its first draw, after that tile's gather of counts -- loads return in order, so anything
+    // issued earlier would sit in front of the gather --, used a resolve round later.  Staging is then LDS writes only (it
+    // was three global round trips: row pointers, two batches of items; 6.5 k of a tile's 51 k cycles, profiles/r03o).
+    // tile_items[t] = row_ptr[tile_start[t]] (host table, so that no load of the look-ahead depends on another one); the
+    // four numbers a fetch needs are themselves read one step earlier (`la`).
+    struct Ahead {
+        uint32_t r0;
+        int nr;
+        uint64_t base, T64;
+        unsigned long long rp;
+        int z;
+        int s[kXPlanes];
+        double p[kXPlanes];
+    } A;
+    struct { uint32_t r0, r1; uint64_t b0, b1; } la;
+    auto look = [&](uint32_t tn) {  // the numbers of tile tn (or of the empty tile behind the last one)
+        const uint32_t a = tn < n_tiles ? tn : n_tiles, b = tn < n_tiles ? tn + 1 : n_tiles;
+        la.r0 = tile_start[a];
+        la.r1 = tile_start[b];
+        la.b0 = tile_items[a];
+        la.b1 = tile_items[b];
+    };
+    auto fetch = [&]() {  // the tile `la` describes -> A
+        A.r0 = la.r0;
+        A.nr = (int)(la.r1 - la.r0);
+        A.base = la.b0;
+        A.T64 = la.b1 - la.b0;
+        const uint32_t Tn = A.T64 > (uint64_t)kXCap ? 0u : (uint32_t)A.T64;
+        A.rp = A.nr > 0 ? row_ptr[(uint64_t)A.r0 + (uint64_t)(g < A.nr ? g : A.nr)] : la.b0;
+        A.z = (!kInit && g < A.nr) ? z[(uint64_t)A.r0 + g] : 0;
+#pragma unroll
+        for (int u = 0; u < kXPlanes; u++) {
+            const uint32_t j = (uint32_t)u * kXT + g;
+            A.s[u] = j < Tn ? sid[A.base + j] : 0;
+            A.p[u] = j < Tn ? cp[A.base + j] : 0.0;
+        }
+    };
+    look(0);
+    fetch();
+    look(1);
     for (uint32_t t = 0; t < n_tiles; t++) {
         unsigned long long tk = GX_CLOCK();
         auto lap = [&](int i) {
@@ -154,43 +195,32 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                 tk = n;
             }
         };
-        const uint64_t r0 = tile_start[t];
-        const int nr = (int)(tile_start[t + 1] - tile_start[t]);  // 1 .. kXT
-        // ---- stage -----------------------------------------------------------------------------------------------------------
-        L->rp[g] = row_ptr[r0 + (uint64_t)(g < nr ? g : nr)];
-        if (g == 0) L->rp[kXT] = row_ptr[r0 + (uint64_t)nr];
-        const bool mine = g < nr;
-        int z_old = 0;
-        if (!kInit && mine) z_old = z[r0 + g];
-        GX_BLOCK_SYNC();
-        const uint64_t base = L->rp[0];
-        const uint64_t T64 = L->rp[nr] - base;
+        const uint64_t r0 = A.r0;
+        const int nr = A.nr;  // 1 .. kXT
+        // ---- stage (from the registers loaded ahead) -------------------------------------------------------------------------
+        const uint64_t base = A.base;
+        const uint64_t T64 = A.T64;
         const bool long_tile = T64 > (uint64_t)kXCap;  // one read with more items than a tile holds (then nr == 1)
         const uint32_t T = long_tile ? 0u : (uint32_t)T64;
-        int sj[kXPlanes];  // the tile's ids item-major (item u * kXT + g): kept in registers for the gather
+        L->rp[g] = A.rp;
+        if (g == 0) L->rp[kXT] = base + T64;
+        const bool mine = g < nr;
+        const int z_old = A.z;
+        int sj[kXPlanes];  // the tile's ids item-major (item u * kXT + g): kept in registers for the gather and the rounds
 #pragma unroll
-        for (int u0 = 0; u0 < kXPlanes; u0 += 8) {  // coalesced, eight (sid, conprb) pairs in flight per thread
-            double p8[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t j = (uint32_t)(u0 + u) * kXT + g;
-                sj[u0 + u] = j < T ? sid[base + j] : 0;
-                p8[u] = j < T ? cp[base + j] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t j = (uint32_t)(u0 + u) * kXT + g;
-                if (j < T) {
-                    L->sid[j] = sj[u0 + u];
-                    L->p[j] = p8[u];
-                    if (!kInit) L->dl[j] = 0;
-                }
+        for (int u = 0; u < kXPlanes; u++) {
+            const uint32_t j = (uint32_t)u * kXT + g;
+            sj[u] = A.s[u];
+            if (j < T) {
+                L->sid[j] = A.s[u];
+                L->p[j] = A.p[u];
+                if (!kInit) L->dl[j] = 0;
             }
         }
+        GX_BLOCK_SYNC();
         const uint32_t fr = mine ? (uint32_t)(L->rp[g] - base) : 0;
         const int len = (mine && !long_tile) ? (int)(L->rp[g + 1] - L->rp[g]) : 0;
         int idx = L->idx;
-        GX_BLOCK_SYNC();
         lap(0);
         // ---- whose item is it (the gather and the rounds walk the items item-major: other threads' items) ---------------------------
         if (!kInit) {
@@ -236,6 +266,8 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                 z[r0] = zn;
             }
             idx += 1;
+            fetch();  // (the next tile's staging data, as below)
+            look(t + 2);
         } else {
             // the next nr MT19937 outputs; read r of the tile takes the r-th
             uint32_t rnd = 0;
@@ -280,6 +312,8 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
             }
             GX_BLOCK_SYNC();
             lap(2);
+            fetch();      // the next tile's staging data (tile t + 1, described by `la`), in flight from here on
+            look(t + 2);  // ... and the numbers of the one after it
             // sample() of sampling.h:50-65 on arr[k] = arr[k-1] + weight_k: the index of the first partial sum > prb, which for
             // a non-decreasing array is the number of partial sums <= prb (what the binary search there finds), capped at
             // len-1.  0.0 + a == a and x + 0.0 == x exactly, so the padded positions leave the left-to-right sums bit-identical.

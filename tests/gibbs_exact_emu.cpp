@@ -79,6 +79,8 @@ int main(int argc, char** argv) {
 
     std::vector<uint32_t> tiles;
     gx_build_tiles(N1, rp.data(), tiles);  // the product's own rule
+    std::vector<uint64_t> tile_items(tiles.size());
+    for (size_t i = 0; i < tiles.size(); i++) tile_items[i] = rp[tiles[i]];
     const uint32_t n_tiles = (uint32_t)tiles.size() - 1;
     std::vector<int32_t> counts(init), z(N1 ? N1 : 1, 0);
     counts[0] += N0;
@@ -104,9 +106,9 @@ int main(int argc, char** argv) {
         for (int round = 0; round <= rounds; round++) {
             pthread_barrier_wait(&mc.block_bar);
             if (round == 0)
-                gibbs_exact_wg_body<true>(tid, &mc.tile, n_tiles, tiles.data(), rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, nullptr);
+                gibbs_exact_wg_body<true>(tid, &mc.tile, n_tiles, tiles.data(), tile_items.data(), rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, nullptr);
             else
-                gibbs_exact_wg_body<false>(tid, &mc.tile, n_tiles, tiles.data(), rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, nullptr);
+                gibbs_exact_wg_body<false>(tid, &mc.tile, n_tiles, tiles.data(), tile_items.data(), rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, nullptr);
             pthread_barrier_wait(&mc.block_bar);
             if (tid == 0 && round >= 1) memcpy(&out[(size_t)(round - 1) * (M + 1)], counts.data(), sizeof(int32_t) * (M + 1));
             pthread_barrier_wait(&mc.block_bar);
