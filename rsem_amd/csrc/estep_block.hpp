@@ -148,12 +148,13 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         const uint32_t sl = t - S.slice_base;
         const uint64_t v0 = (uint64_t)sl * (K * 64);              // first entry of the slice within the shape's planes
         const ValT* __restrict__ vp = scp + v0;
-        // The sid planes of a slice are read only where a tuple starts in it (m != 0); for the other slices the same K loads
-        // go to the shape's first slice instead -- always the same few lines, L1 / L2 hits, no HBM traffic.  Loads that are
-        // issued or not depending on m would be a branch, and behind a branch the compiler counts the loads in flight as on
-        // the path with the fewest: its wait for THIS slice's planes then also waits for part of the next slice's.
-        {
-            const int32_t* __restrict__ ip = ssid + (S.plane_base * 64 + (m != 0ull ? v0 : 0ull));
+        // The sid planes of a slice are read only where a tuple starts in it (m != 0), then by all lanes: one scalar branch.
+        // (Behind a branch the compiler counts the loads in flight as on the path with the fewest, so its wait for this
+        // slice's planes also waits for the next slice's sid planes where that slice has them.  Issuing the same K loads
+        // always -- to the shape's first slice where m == 0: L1 / L2 hits, exact waits on every path -- was measured and
+        // is slower: 0.971 against 0.936 ms at configs[2], Q32 0.713 against 0.700, profiles/r03t.)
+        if (m != 0ull) {
+            const int32_t* __restrict__ ip = ssid + (S.plane_base * 64 + v0);
 #pragma unroll
             for (int k = 0; k < K; k++) b.id[k] = ip[k * 64 + ulane];
         }

@@ -75,8 +75,8 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
         // loaded by all lanes or (mask 0) by none
         const uint64_t p0 = (S.plane_base + (uint64_t)sl * K) * 64;
         const unsigned ulane = (unsigned)lane;
-        {   // (always K loads: of the shape's first slice where no tuple starts in this one -- estep_block.hpp says why)
-            const int32_t* __restrict__ ip = ssid + (m != 0ull ? p0 : S.plane_base * 64);
+        if (m != 0ull) {  // (a scalar branch; loading the K planes always, for exact waits on every path, is slower: estep_block.hpp, profiles/r03u)
+            const int32_t* __restrict__ ip = ssid + p0;
 #pragma unroll
             for (int k = 0; k < K; k++) b.id[k] = ip[k * 64 + ulane];
         }
