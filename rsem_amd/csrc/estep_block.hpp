@@ -24,8 +24,8 @@ RSEM_DEVFN double wave_sum(double v) {
 // change (slice mask bit clear) the lane multiplies cached theta values with the streamed conprb
 // and adds the normalised fractions into registers; on a change it spills its registers to the
 // LDS window and takes sid / theta of the new tuple (the sid planes of a slice are loaded only when its mask is not zero,
-// then by all lanes).  The loads of the next slices are issued before slice s is reduced (software pipeline of 2 register
-// sets for doubles, up to 8 for Q32 mantissas; static instruction stream per K and format).
+// then by all lanes).  The loads of the next slice are issued before slice s is reduced (software pipeline of 2 register
+// sets; static instruction stream per K, format and kFar).
 // Where theta comes from.  Plain: the array the M-step kernel wrote.  kFC ("from counts", the fused loop of rsem_em_run):
 // the PREVIOUS round's raw counts and its two totals -- theta_i = (counts_i + (i == 0 ? noise + N0 : 0)) / (N0 + reads with
 // a non-zero normaliser), the very expression the M step evaluates (EM.cpp:392-398), so the E step does not wait for an
