@@ -487,7 +487,7 @@ def main():
                                   "sweeps_per_s_all_gpus": world * 1e3 / sw if sw > 0 else None,
                                   "items_per_s_all_gpus": world * len(isid) * 1e3 / sw if sw > 0 else None,
                                   "final_reduce_ms": max(r[1] for r in per_rank) if distributed else None},
-                     "exact": {"mode": "reference chain (bit-identical draws), %d chains per GPU advancing together, one workgroup of 8 waves per chain" % n_exact,
+                     "exact": {"mode": "reference chain (bit-identical draws), %d chains per GPU advancing together, one workgroup of 4 waves per chain" % n_exact,
                                "ms_per_round": ex, "ms_per_round_per_rank": [r[2] for r in per_rank], "chains_per_gpu": n_exact,
                                "rounds_timed": args.gibbs_exact_rounds,
                                "us_per_read_visit_and_chain": ex * 1e3 / N1 if N1 else None,
