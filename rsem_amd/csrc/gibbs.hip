@@ -66,20 +66,12 @@ constexpr int kGWindow = 2048;  // sids per workgroup window (g values: 16 KB, i
 // the per-wave body of the sweep kernel (also run on the CPU by tests/gibbs_emu.cpp)
 #include "gibbs_block.hpp"
 
-__global__ void k_slice_ptab(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_slices, PtabEntry* ptab) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_slices) return;
-    int sh = 0;
-    while (sh + 1 < n_shapes && s >= shapes[sh + 1].slice_base) ++sh;
-    ptab[s] = slice_ptab_entry(shapes[sh], T, s - shapes[sh].slice_base);
-}
 
 __global__ __launch_bounds__(kBlock, RSEM_GIBBS_MIN_WAVES) void k_sample_z_lane(
     const Shape* __restrict__ shapes, const Unit* __restrict__ units, uint32_t T, int M,
     const double* __restrict__ g, const double* __restrict__ scp, const int32_t* __restrict__ ssid,
     const double* __restrict__ sncp, const unsigned long long* __restrict__ masks, Philox ph, uint32_t sweep,
     int32_t* counts
-    , const PtabEntry* __restrict__ ptab
     ) {
     __shared__ double g_win[kGWindow];
     __shared__ int cnt_win[kGWindow];
@@ -95,7 +87,7 @@ __global__ __launch_bounds__(kBlock, RSEM_GIBBS_MIN_WAVES) void k_sample_z_lane(
         const uint32_t s_begin = S.slice_base + U.slice_begin + (uint32_t)w * U.per_wave;
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
         const double g0 = g[0];
-#define RSEM_GIBBS_BLOCK(KK, FF) gibbs_block<KK, FF>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ptab, ph, sweep, counts, noise, M)
+#define RSEM_GIBBS_BLOCK(KK, FF) gibbs_block<KK, FF>(S, T, s_begin, s_end, lane, U.base, U.span, g, g0, g_win, cnt_win, scp, ssid, sncp, masks, ph, sweep, counts, noise, M)
         if (s_begin < u_end) switch (S.K + (U.pad[0] != 0 ? 4 : 0)) {  // (uniform over the workgroup)
             case 1: RSEM_GIBBS_BLOCK(1, false); break;
             case 2: RSEM_GIBBS_BLOCK(2, false); break;
@@ -776,7 +768,6 @@ struct rsem_gibbs_ctx {
     SellLayout L;
     double* d_scp = nullptr;
     double* d_sncp = nullptr;
-    PtabEntry* d_ptab = nullptr;      // k_slice_ptab
     Unit* d_units = nullptr;
     uint32_t n_units = 0;
     double* d_g = nullptr;
@@ -895,12 +886,6 @@ int ensure_parallel_layout(rsem_gibbs_ctx* c) {
     RSEM_HIP_TRY(dmalloc(&c->d_sncp, (size_t)c->L.n_slots));
     rc = sell_fill_values(c->L, st, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_scp, c->d_sncp);
     if (rc != RSEM_OK) return rc;
-    RSEM_HIP_TRY(dmalloc(&c->d_ptab, (size_t)c->L.n_slices));
-    if (c->L.n_slices) {
-        hipLaunchKernelGGL(k_slice_ptab, dim3(rsem::ceil_div(c->L.n_slices, kBlock)), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
-                           c->L.T, c->L.n_slices, c->d_ptab);
-        RSEM_HIP_TRY(hipGetLastError());
-    }
     RSEM_HIP_TRY(hipStreamSynchronize(st));
     c->n_units = (uint32_t)units.size();
     RSEM_HIP_TRY(dmalloc(&c->d_g, (size_t)c->M + 1));
@@ -943,7 +928,6 @@ int rsem_gibbs_destroy(rsem_gibbs_ctx* c) {
     if (!c) return RSEM_OK;
     (void)hipSetDevice(c->device);
     hipFree(c->d_irp); hipFree(c->d_isid); hipFree(c->d_icp); hipFree(c->d_tiles); hipFree(c->d_tile_items); hipFree(c->d_row_ptr); hipFree(c->d_sid);
-    hipFree(c->d_ptab);
     hipFree(c->d_cp); hipFree(c->d_ncp); sell_free(c->L); hipFree(c->d_scp); hipFree(c->d_sncp);
     hipFree(c->d_init_counts); hipFree(c->d_g); hipFree(c->d_alpha);
     hipFree(c->d_eel); hipFree(c->d_mw); hipFree(c->d_grp);
@@ -1220,7 +1204,6 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                 if (c->n_units)
                     hipLaunchKernelGGL(k_sample_z_lane, dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
                                        c->d_g, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, ph, sw, ck
-                                       , (const PtabEntry*)c->d_ptab
                                        );
                 if (c->L.n_long_rows)
                     hipLaunchKernelGGL(k_sample_z_long, dim3(rsem::ceil_div(c->L.n_long_rows, kBlock)), dim3(kBlock), 0, st,

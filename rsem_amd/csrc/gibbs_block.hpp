@@ -9,7 +9,9 @@
 // 1.538 -> 1.35 ms per sweep at C3): scalar slice addressing with a per-slice table of sorted positions (no divisions by T
 // and R in every slice), the read's uniform from Philox2x32-10 (64 bits per call) instead of Philox4x32-10, the non-temporal
 // hint on the value planes.  Measured and dropped (within the +-3 % run-to-run noise of this kernel, identical picks): the
-// scan over a read's lanes with DPP moves, the read's lanes sharing the work of its next G uniforms.
+// scan over a read's lanes with DPP moves.  The read's lanes sharing the work of its next G uniforms was within the noise
+// too while every wait of the loop was a wait for everything; with exact waits (estep_block.hpp) the kernel is bound by
+// its instructions and the sharing is worth 4-6 % (profiles/r03z): adopted, positions by arithmetic instead of a table.
 // g[base, base+span) -> LDS, count window zeroed; every wave of the workgroup calls this exactly once
 RSEM_DEVFN void stage_gwindows(int base, int span, int M, const double* __restrict__ g, double* g_win, int* cnt_win) {
     for (int i = RSEM_TIDX; i < span; i += RSEM_BDIM) {
@@ -27,9 +29,8 @@ struct SliceRegs {
     double nc;
 };
 
-// per slice: the sorted position of the read in row slot 0 and the slot stride of its block, so that the position of the
-// read in slot r (the key of its random number) is x + r * y without the divisions by T and R in every slice
-// (k_slice_ptab in gibbs.hip tabulates it)
+// of a slice: the sorted position of the read in row slot 0 and the slot stride of its block, so that the position of the
+// read in slot r (the key of its random number) is x + r * y; within a block x grows by one per slice
 struct PtabEntry { uint32_t x, y; };
 __host__ RSEM_DEVFN PtabEntry slice_ptab_entry(const Shape& S, uint32_t T, uint32_t sl) {
     const uint32_t R = shape_R(S);
@@ -49,7 +50,6 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
                                    const double* __restrict__ g, double g0, double* g_win, int* cnt_win,
                                    const double* __restrict__ scp, const int32_t* __restrict__ ssid,
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
-                                   const PtabEntry* __restrict__ ptab,
                                    const Philox& ph, uint32_t sweep, int32_t* counts, int& noise, int M) {
     const int lg = S.lg, G = 1 << lg;
     const int gl = lane & (G - 1);
@@ -85,6 +85,16 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
         for (int k = 0; k < K; k++) b.c[k] = RSEM_NT_LOAD(&vp[k * 64 + ulane]);
         b.nc = (sncp + (S.slot_base + sl * R))[ulane >> lg];  // (all lanes of the read: no load under a lane predicate)
     };
+    // the sorted position of the read in row slot r of slice t (the key of its random number), by arithmetic: a wave's
+    // slices lie in at most two blocks, whose first positions and slot strides are taken once (slice_ptab_entry)
+    const uint32_t sl0 = s_begin - S.slice_base;
+    const PtabEntry eA = slice_ptab_entry(S, T, sl0);
+    const uint32_t startB = S.slice_base + (sl0 / T + 1) * T;  // first slice of the next block (possibly >= s_end)
+    const PtabEntry eB = startB < s_end ? slice_ptab_entry(S, T, startB - S.slice_base) : eA;
+    auto pos_of = [&](uint32_t t, uint32_t r) -> uint32_t {
+        return t < startB ? eA.x + (t - s_begin) + r * eA.y : eB.x + (t - startB) + r * eB.y;
+    };
+    double u_bank = 0.0;
     int rsid[K], acc[K];
     double rg[K];
 #pragma unroll
@@ -152,12 +162,24 @@ RSEM_DEVFN void gibbs_block(const Shape& S, uint32_t T, uint32_t s_begin, uint32
         }
         // one uniform per read, keyed by the read's position in the sorted order (layout independent)
         const uint32_t key = ph.k0 ^ ((ph.k1 << 13) | (ph.k1 >> 19)) ^ 0x5a5a5a5au;
-        const PtabEntry pt = ptab[s];  // (s is uniform over the wave: a scalar load)
-        const uint32_t p = pt.x + ((uint32_t)lane >> lg) * pt.y;
-        uint32_t rnd[2] = {0, 0};
-        if (g0lane) rsem::philox2x32_10(key, p, sweep, rnd);
-        double u = u53(rnd[0], rnd[1]);
-        if (lg > 0) u = RSEM_SHFL(u, gbase);
+        double u;
+        // The G lanes of a read take turns: every G slices lane i of the read draws the read slot's uniform for slice s + i
+        // (all lanes busy in one Philox pass instead of one lane in G, G times), and each slice fetches its uniform from the
+        // lane that drew it.  Same uniform for the same (sorted position, sweep) as before: the picks do not change.
+        if (lg == 0) {
+            uint32_t rnd[2];
+            rsem::philox2x32_10(key, pos_of(s, (uint32_t)lane), sweep, rnd);
+            u = u53(rnd[0], rnd[1]);
+        } else {
+            const uint32_t phase = (s - s_begin) & (uint32_t)(G - 1);  // (uniform over the wave)
+            if (phase == 0u) {
+                const uint32_t t = s + (uint32_t)gl;
+                uint32_t rnd[2] = {0, 0};
+                if (t < s_end) rsem::philox2x32_10(key, pos_of(t, (uint32_t)lane >> lg), sweep, rnd);
+                u_bank = u53(rnd[0], rnd[1]);
+            }
+            u = RSEM_SHFL(u_bank, gbase + (int)phase);
+        }
         double target = u * total;
         if (target >= total) target = total * (1.0 - 1.1102230246251565e-16);
         int pick = -2;  // -2: not mine, -1: noise, k >= 0: my plane k

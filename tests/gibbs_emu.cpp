@@ -23,7 +23,6 @@ struct Job {
     int base, span, M;
     bool far;  // the rule of sell_flag_far_units (sell_layout.hpp)
     const double* g;
-    const PtabEntry* ptab;
     Philox ph;
     uint32_t sweep;
     int32_t* counts;
@@ -46,7 +45,7 @@ static void lane_body(Job* J, int tid) {
     const double* scp = (const double*)H.sval.data();  // F64 layout: plane p at scp + p * 64
     int noise = 0;
     const double g0 = J->g[0];
-#define EMU_BLOCK(KK, FF) gibbs_block<KK, FF>(S, T, s_begin, s_end, lane, J->base, J->span, J->g, g0, J->g_win, J->cnt_win, scp, H.ssid.data(), H.sncp.data(), H.masks.data(), J->ptab, J->ph, J->sweep, J->counts, noise, J->M)
+#define EMU_BLOCK(KK, FF) gibbs_block<KK, FF>(S, T, s_begin, s_end, lane, J->base, J->span, J->g, g0, J->g_win, J->cnt_win, scp, H.ssid.data(), H.sncp.data(), H.masks.data(), J->ph, J->sweep, J->counts, noise, J->M)
     if (s_begin < u_end) switch (S.K + (J->far ? 4 : 0)) {
         case 1: EMU_BLOCK(1, false); break;
         case 2: EMU_BLOCK(2, false); break;
@@ -85,9 +84,6 @@ int main(int argc, char** argv) {
     HostLayout H;
     H.T = (uint32_t)hdr[2];
     build_layout(H, M, N1, rp.data(), sid.data(), cp.data(), ncp.data(), 0, false, 0);
-    std::vector<PtabEntry> ptab(H.n_slices);
-    for (const Shape& S : H.shapes)
-        for (uint32_t sl = 0; sl < S.n_slices; sl++) ptab[S.slice_base + sl] = slice_ptab_entry(S, H.T, sl);
     std::vector<int32_t> counts((size_t)n_sweeps * (M + 1), 0);
     Job* J = new Job();
     pthread_barrier_init(&J->blk.bar, nullptr, 256);
@@ -115,7 +111,6 @@ int main(int argc, char** argv) {
                 }
                 J->M = M;
                 J->g = g.data();
-                J->ptab = ptab.data();
                 J->ph = Philox{(uint32_t)hdr[4], 0x52534547u};
                 J->sweep = (uint32_t)sw;
                 J->counts = counts.data() + (size_t)sw * (M + 1);
