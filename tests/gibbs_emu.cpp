@@ -19,7 +19,7 @@ constexpr int kGWindow = 2048;
 struct Job {
     const HostLayout* H;
     Shape S;
-    uint32_t slice_begin, n_slices;
+    uint32_t slice_begin, n_slices, per_wave;
     int base, span, M;
     bool far;  // the rule of sell_flag_far_units (sell_layout.hpp)
     const double* g;
@@ -40,8 +40,8 @@ static void lane_body(Job* J, int tid) {
     const Shape& S = J->S;
     const uint32_t T = H.T;
     const uint32_t u_end = S.slice_base + J->slice_begin + J->n_slices;
-    const uint32_t s_begin = S.slice_base + J->slice_begin + (uint32_t)w * T;
-    const uint32_t s_end = std::min(u_end, s_begin + T);
+    const uint32_t s_begin = S.slice_base + J->slice_begin + (uint32_t)w * J->per_wave;
+    const uint32_t s_end = std::min(u_end, s_begin + J->per_wave);
     const double* scp = (const double*)H.sval.data();  // F64 layout: plane p at scp + p * 64
     int noise = 0;
     const double g0 = J->g[0];
@@ -90,11 +90,14 @@ int main(int argc, char** argv) {
     for (int w = 0; w < 4; w++) pthread_barrier_init(&J->blk.w[w].bar, nullptr, 64);
     for (int sw = 0; sw < n_sweeps; sw++)
         for (const Shape& S : H.shapes)
-            for (uint32_t b0 = 0; b0 < S.n_slices; b0 += 4 * H.T) {
+            // a unit = 4 blocks, a wave each (sell_build_units' full-size unit); hdr[6] = 1: 2 blocks, half a block per wave
+            // (its half-size unit: with an odd T the second wave starts in one block and ends in the next)
+            for (uint32_t b0 = 0; b0 < S.n_slices; b0 += (hdr[6] == 1 ? 2 : 4) * H.T) {
                 J->H = &H;
                 J->S = S;
                 J->slice_begin = b0;
-                J->n_slices = std::min<uint32_t>(4 * H.T, S.n_slices - b0);
+                J->n_slices = std::min<uint32_t>((hdr[6] == 1 ? 2 : 4) * H.T, S.n_slices - b0);
+                J->per_wave = hdr[6] == 1 ? (H.T + 1) / 2 : H.T;
                 int lo = 0x7fffffff, hi = 0;
                 for (uint64_t p = (S.plane_base + (uint64_t)b0 * S.K) * 64; p < (S.plane_base + (uint64_t)(b0 + J->n_slices) * S.K) * 64; p++)
                     if (H.ssid[p] > 0) { lo = std::min(lo, (int)H.ssid[p]); hi = std::max(hi, (int)H.ssid[p]); }

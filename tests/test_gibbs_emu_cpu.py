@@ -36,12 +36,12 @@ def emulators(tmp_path_factory):
     return out
 
 
-def _run(exe, M, rp, sid, cp, ncp, g, T, sweeps, seed, window=0):
+def _run(exe, M, rp, sid, cp, ncp, g, T, sweeps, seed, window=0, half_units=0):
     d = tempfile.mkdtemp()
     try:
         inp, outp = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
         with open(inp, "wb") as f:
-            f.write(np.array([M, len(rp) - 1, T, sweeps, seed, window, 0, 0], np.int32).tobytes())
+            f.write(np.array([M, len(rp) - 1, T, sweeps, seed, window, half_units, 0], np.int32).tobytes())
             for a, t in ((rp, np.uint64), (sid, np.int32), (cp, np.float64), (ncp, np.float64), (g, np.float64)):
                 f.write(np.ascontiguousarray(a, t).tobytes())
         subprocess.check_call([exe, inp, outp], timeout=900)
@@ -74,4 +74,6 @@ def test_sweep_body_distribution_and_variants(emulators):
         assert np.all(c[:, exp == 0] == 0)                        # nothing lands where no alignment points
     small = _run(emulators["product"], M, rp, sid, cp, ncp, g, T=3, sweeps=S, seed=5, window=64)  # odd block length, tiny LDS window
     assert np.array_equal(small, res["product"])                  # the picks depend on the keys only, not on the layout's geometry
+    halves = _run(emulators["product"], M, rp, sid, cp, ncp, g, T=7, sweeps=S, seed=5, half_units=1)  # waves that cross from one block into the next
+    assert np.array_equal(halves, res["product"])
     assert not np.array_equal(res["product"][0], res["product"][1])  # sweeps differ from one another
