@@ -102,6 +102,20 @@ __host__ __device__ inline void row_to_slot(const Shape& S, uint32_t T, uint32_t
     slice_local = b * T + qb % Tb;
 }
 
+// ... and back: (slice within the shape, row slot within the slice) -> sorted read q of the shape.  false: the slot is empty
+// (the last block of a shape is shorter).
+__host__ __device__ inline bool slot_to_row(const Shape& S, uint32_t T, uint32_t slice_local, uint32_t r, uint32_t& q) {
+    const uint32_t R = shape_R(S), rpb = R * T;
+    const uint32_t b = slice_local / T, t = slice_local % T;
+    if ((uint64_t)b * rpb >= S.n_rows) return false;
+    const uint32_t left = S.n_rows - b * rpb;
+    const uint32_t nb = left < rpb ? left : rpb;
+    const uint32_t Tb = (nb + R - 1) / R;
+    if (t >= Tb || r * Tb + t >= nb) return false;
+    q = b * rpb + r * Tb + t;
+    return true;
+}
+
 __host__ __device__ inline uint32_t mix32(uint32_t h, uint32_t v) {
     h ^= v + 0x9e3779b9u + (h << 6) + (h >> 2);
     return h;
@@ -600,16 +614,14 @@ __global__ __launch_bounds__(256) void k_mark_stray_reads(const Unit* __restrict
     const Unit U = units[blockIdx.x];
     if (U.pad[0] == 0) return;
     const Shape& S = U.S;
-    const uint32_t R = shape_R(S), rpb = R * T;
     const uint64_t p0 = (S.plane_base + (uint64_t)U.slice_begin * S.K) * 64, n = (uint64_t)U.n_slices * S.K * 64;
     unsigned long long mine = 0;
     for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
         if (!unit_entry_is_far(U, ssid[p0 + i])) continue;
         const uint32_t sl = U.slice_begin + (uint32_t)(i / ((uint64_t)S.K * 64));  // slice within the shape
         const uint32_t r = (uint32_t)(i % 64) >> S.lg;                            // row slot within the slice
-        const uint32_t b = sl / T, t = sl % T;                                    // the inverse of row_to_slot
-        const uint32_t left = S.n_rows - b * rpb, nb = left < rpb ? left : rpb, Tb = (nb + R - 1) / R;
-        const uint32_t q = b * rpb + r * Tb + t;
+        uint32_t q;
+        if (!slot_to_row(S, T, sl, r, q)) continue;  // (cannot happen: an empty slot holds id 0)
         const uint32_t orig = order[S.row_base + q];
         int e = 0;
         const uint64_t key = row_key_of(orig, M, row_ptr, sid, nullptr, 0, kLayoutWindow, &e);

@@ -162,6 +162,11 @@ static void build_layout(HostLayout& H, int M, uint64_t N1, const uint64_t* rp, 
     // planes: sell_fill_row (the body of k_fill_sell)
     for (const Shape& S : H.shapes)
         for (uint32_t q = 0; q < S.n_rows; q++) {
+            {   // slot_to_row (what k_mark_stray_reads finds a read by) inverts row_to_slot
+                uint32_t sl, r, back = ~0u;
+                row_to_slot(S, H.T, q, sl, r);
+                if (!slot_to_row(S, H.T, sl, r, back) || back != q) { fprintf(stderr, "simt_emu: slot_to_row(row_to_slot(%u)) = %u\n", q, back); exit(2); }
+            }
             int err = 0;
             sell_fill_row<true>(S, H.T, S.row_base + q, H.order.data(), rp, sid, cp, ncp, H.ssid.data(), H.sval.data(), H.sncp.data(), H.sexp.data(), &err);
             if (err) { fprintf(stderr, "simt_emu: inconsistent Q32 decision\n"); exit(2); }
