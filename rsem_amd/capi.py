@@ -24,6 +24,9 @@ class RsemHipError(RuntimeError):
         self.status = status
 
 
+ABI_VERSION = 3  # rsem_hip_abi_version() of the include/rsem_hip.h these bindings were written against
+
+
 class CiProfile(C.Structure):
     _fields_ = [("sample_ms", C.c_double), ("sort_ms", C.c_double), ("interval_ms", C.c_double), ("total_ms", C.c_double),
                 ("n_draws", C.c_uint64), ("n_keys_sorted", C.c_uint64)]
@@ -56,6 +59,9 @@ def lib():
         L.rsem_hip_last_error.restype = C.c_char_p
         L.rsem_hip_device_count.argtypes = [C.POINTER(ci)]
         L.rsem_hip_abi_version.restype = ci
+        if L.rsem_hip_abi_version() != ABI_VERSION:  # the ctypes structures below mirror ONE layout of include/rsem_hip.h
+            raise ImportError("%s speaks ABI %d, rsem_amd/capi.py expects %d: rebuild it (`python -m rsem_amd.build --force`)"
+                              % (LIB_PATH, L.rsem_hip_abi_version(), ABI_VERSION))
         L.rsem_hip_stream_probe.argtypes = [ci, u64, ci, C.POINTER(dbl), C.POINTER(dbl)]
         L.rsem_em_create.argtypes = [C.POINTER(vp), ci, i32, u64, u64, _u64p, vp, vp, vp]
         L.rsem_em_set_values.argtypes = [vp, _f64p, _f64p]

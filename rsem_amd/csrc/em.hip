@@ -43,6 +43,7 @@ using rsem::kEpsilon;
 constexpr int kReduceBlocks = 64;   // partial sums of the M step
 constexpr int kMaxTimedRounds = 4096;
 constexpr int kWindow = 2048;        // doubles of LDS count window per workgroup (16 KB)
+static_assert(kWindow == kLayoutWindow, "the layout sorts reads apart and sizes windows for the E step's LDS window (sell_layout.hpp)");
 
 constexpr int kTotSlots = 64;  // addresses per device-wide total (E-step workgroups add round-robin)
 
@@ -58,6 +59,7 @@ struct Ctrl {  // device-resident loop control, one per ctx
     int last_totNum;
     int last_round;
     unsigned long long tick2;  // k_mstep_fast: (sum of totNum) << 32 | arrivals, one atomic per workgroup
+    double fsum;               // accumulating: the floating-point sum of the round's counts, the SUM of the reference's ROUND line
 };
 
 // What the host reads while the loop runs, in pinned host memory the M-step kernel writes directly (no stream sync, no
@@ -296,8 +298,9 @@ __device__ inline void solo_close_round(const SoloArgs& A, int M, double N0, con
     const double extra_c = wave_sum(cur[n + lane]) + N0, sum_c = wave_sum(cur[n + kTotSlots + lane]) + N0;
     const double extra_p = wave_sum(A.prev[n + lane]) + N0, sum_p = wave_sum(A.prev[n + kTotSlots + lane]) + N0;
     int tot = 0;
-    double bmax = 0.0;
+    double bmax = 0.0, csum = 0.0;
     auto one = [&](int i, double craw, double praw) {
+        csum += craw + (i == 0 ? extra_c : 0.0);
         const double th = (craw + (i == 0 ? extra_c : 0.0)) / sum_c;
         const double old = (praw + (i == 0 ? extra_p : 0.0)) / sum_p;
         A.prev[i] = 0.0;
@@ -320,12 +323,13 @@ __device__ inline void solo_close_round(const SoloArgs& A, int M, double N0, con
         tot += __shfl_xor(tot, d);
         bmax = fmax(bmax, __shfl_xor(bmax, d));
     }
+    csum = wave_sum(csum);
     __shared__ int s_tot[kBlock / 64];
-    __shared__ double s_b[kBlock / 64];
-    if (lane == 0) { s_tot[threadIdx.x >> 6] = tot; s_b[threadIdx.x >> 6] = bmax; }
+    __shared__ double s_b[kBlock / 64], s_c[kBlock / 64];
+    if (lane == 0) { s_tot[threadIdx.x >> 6] = tot; s_b[threadIdx.x >> 6] = bmax; s_c[threadIdx.x >> 6] = csum; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < kBlock / 64; i++) { tot += s_tot[i]; bmax = fmax(bmax, s_b[i]); }
+        for (int i = 1; i < kBlock / 64; i++) { tot += s_tot[i]; bmax = fmax(bmax, s_b[i]); csum += s_c[i]; }
         Ctrl* ctrl = A.ctrl;
         // The arrival must not overtake the maximum.  No fence: an agent-scope fence in the middle of this kernel writes
         // back and invalidates the XCD's L2 under everybody else's feet.  The arrival's operand is made to depend on the
@@ -336,13 +340,20 @@ __device__ inline void solo_close_round(const SoloArgs& A, int M, double N0, con
                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"((unsigned int)was));
         }
+        {   // this closer's share of the floating-point sum of the counts (the reference's SUM, EM.cpp:394-398,415)
+            const double was = __hip_atomic_fetch_add(&ctrl->fsum, csum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned int z2;
+            asm volatile("v_and_b32 %0, 0, %1" : "=v"(z2) : "v"((unsigned int)__double_as_longlong(was)));
+            zero += z2;
+        }
         const unsigned long long old = __hip_atomic_fetch_add(&ctrl->tick2, (((unsigned long long)(unsigned)tot << 32) | 1ull) + zero,
                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)(old & 0xffffffffull) == n_close - 1) {  // last closer: stop rule (EM.cpp:416) for round stat_round
             const int round = A.stat_round;
             const int totNum = (int)(old >> 32) + tot;
             const unsigned long long bb = __hip_atomic_load(&ctrl->bbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ctrl->last_sum = sum_c;
+            const double fsum = __hip_atomic_load(&ctrl->fsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctrl->last_sum = fsum;
             ctrl->last_bchange = __longlong_as_double((long long)bb);
             ctrl->last_totNum = totNum;
             ctrl->last_round = round;
@@ -353,7 +364,7 @@ __device__ inline void solo_close_round(const SoloArgs& A, int M, double N0, con
             }
             if (A.mirror) {
                 RoundStat* h = &A.mirror->hist[(round - 1) % kHistCap];
-                h->sum = sum_c;
+                h->sum = fsum;
                 h->bchange = __longlong_as_double((long long)bb);
                 h->totNum = totNum;
                 h->round = round;
@@ -363,6 +374,7 @@ __device__ inline void solo_close_round(const SoloArgs& A, int M, double N0, con
             }
             __hip_atomic_store(&ctrl->bbits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctrl->tick2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctrl->fsum, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int k = 0; k < 2 * kTotSlots; k++) A.prev[n + k] = 0.0;  // every other closer has read them
         }
     }
@@ -685,9 +697,10 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, dou
     const double extra0 = s_totals[0] + N0;  // counts[0] += noise + N0 (EM.cpp:392)
     const double sum = s_totals[1] + N0;
     int tot = 0;
-    double bmax = 0.0;
+    double bmax = 0.0, csum = 0.0;
     auto one = [&](int i, double craw, double old) {
         const double c = craw + (i == 0 ? extra0 : 0.0);
+        csum += c;
         const double th = c / sum;
         theta_new[i] = th;
         counts_last[i] = c;
@@ -710,17 +723,18 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, dou
         for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) one(i, counts[i], theta_old[i]);
     }
     __shared__ int s_tot[kBlock / 64];
-    __shared__ double s_b[kBlock / 64];
+    __shared__ double s_b[kBlock / 64], s_c[kBlock / 64];
     for (int d = 32; d >= 1; d >>= 1) {
         tot += __shfl_xor(tot, d);
         bmax = fmax(bmax, __shfl_xor(bmax, d));
     }
+    csum = wave_sum(csum);
     __shared__ int s_last;
-    if ((threadIdx.x & 63) == 0) { s_tot[threadIdx.x >> 6] = tot; s_b[threadIdx.x >> 6] = bmax; }
+    if ((threadIdx.x & 63) == 0) { s_tot[threadIdx.x >> 6] = tot; s_b[threadIdx.x >> 6] = bmax; s_c[threadIdx.x >> 6] = csum; }
     if (threadIdx.x == 0) s_last = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < kBlock / 64; i++) { tot += s_tot[i]; bmax = fmax(bmax, s_b[i]); }
+        for (int i = 1; i < kBlock / 64; i++) { tot += s_tot[i]; bmax = fmax(bmax, s_b[i]); csum += s_c[i]; }
         // one max, one returning add that carries both this workgroup's count and its arrival; the add follows the max by a
         // data dependency instead of a fence (see solo_close_round: this kernel runs beside an E step in the fused loop)
         unsigned int zero = 0;
@@ -729,12 +743,19 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, dou
                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"((unsigned int)was));
         }
+        {   // the floating-point sum of the counts, for the ROUND line only (theta divides by the exact `sum` above)
+            const double was = __hip_atomic_fetch_add(&ctrl->fsum, csum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned int z2;
+            asm volatile("v_and_b32 %0, 0, %1" : "=v"(z2) : "v"((unsigned int)__double_as_longlong(was)));
+            zero += z2;
+        }
         const unsigned long long old = __hip_atomic_fetch_add(&ctrl->tick2, (((unsigned long long)(unsigned)tot << 32) | 1ull) + zero,
                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(old & 0xffffffffull) == gridDim.x - 1) {  // last workgroup: stop rule (EM.cpp:416)
             const int totNum = (int)(old >> 32) + tot;
             const unsigned long long bb = __hip_atomic_load(&ctrl->bbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ctrl->last_sum = sum;
+            const double fsum = __hip_atomic_load(&ctrl->fsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctrl->last_sum = fsum;
             ctrl->last_bchange = __longlong_as_double((long long)bb);
             ctrl->last_totNum = totNum;
             ctrl->last_round = round;
@@ -745,7 +766,7 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, dou
             }
             if (mirror) {  // the host's view: this round's line first, then the counters that announce it
                 RoundStat* h = &mirror->hist[(round - 1) % kHistCap];
-                h->sum = sum;
+                h->sum = fsum;
                 h->bchange = __longlong_as_double((long long)bb);
                 h->totNum = totNum;
                 h->round = round;
@@ -755,6 +776,7 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, dou
             }
             __hip_atomic_store(&ctrl->bbits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctrl->tick2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctrl->fsum, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = 1;
         }
     }

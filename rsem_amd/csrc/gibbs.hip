@@ -62,6 +62,7 @@ __global__ void k_fill_double(int32_t n, double v, double* g) {
 #define RSEM_GIBBS_MIN_WAVES 4  /* 5 (95 VGPRs, 2 spilled) measured the same: profiles/r03d_exact_sweep_bench.log */
 #endif
 constexpr int kGWindow = 2048;  // sids per workgroup window (g values: 16 KB, int counts: 8 KB of LDS)
+static_assert(kGWindow == kLayoutWindow, "the layout sorts reads apart and sizes windows for the sweep's LDS window (sell_layout.hpp)");
 
 // the per-wave body of the sweep kernel (also run on the CPU by tests/gibbs_emu.cpp)
 #include "gibbs_block.hpp"

@@ -59,7 +59,10 @@ struct OfbPart {
     std::vector<double> val;
 };
 
-inline void write_ofb(const std::string& imdName, int M, uint64_t N0, std::vector<OfbPart>& parts) {
+// The arrays are written by write_ofb_arrays, the header by write_ofb_header: the header is the completeness marker AND
+// the time stamp ofb_present() compares with a .ofg beside it, so a writer of both hand-offs writes the header LAST,
+// after the text file is closed (otherwise the text would always be the newer one and the arrays would never be used).
+inline OfbHeader write_ofb_arrays(const std::string& imdName, int M, uint64_t N0, std::vector<OfbPart>& parts) {
     const std::string dir = ofb_dir(imdName);
     remove_ofb(imdName);
     if (mkdir(dir.c_str(), 0777) != 0) die("Cannot create %s!", dir.c_str());
@@ -98,9 +101,19 @@ inline void write_ofb(const std::string& imdName, int M, uint64_t N0, std::vecto
     memset(&h, 0, sizeof(h));
     memcpy(h.magic, "RSEMOFB1", 8);
     h.version = 1; h.M = M; h.N0 = N0; h.N1 = r0[nt]; h.nitems = h0[nt];
-    const int f_h = open_w("hdr");
-    ok = put(f_h, &h, sizeof(h), 0);
-    if (::close(f_h) != 0 || !ok) die("Cannot write %s/hdr!", dir.c_str());
+    return h;
+}
+
+inline void write_ofb_header(const std::string& imdName, const OfbHeader& h) {
+    const std::string path = ofb_dir(imdName) + "/hdr";
+    const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) die("Cannot open %s for writing!", path.c_str());
+    const bool ok = ::pwrite(fd, &h, sizeof(h), 0) == (ssize_t)sizeof(h);
+    if (::close(fd) != 0 || !ok) die("Cannot write %s!", path.c_str());
+}
+
+inline void write_ofb(const std::string& imdName, int M, uint64_t N0, std::vector<OfbPart>& parts) {
+    write_ofb_header(imdName, write_ofb_arrays(imdName, M, N0, parts));
 }
 
 // used when the header exists and is not older than a text file lying next to it (a kept sample.temp may hold the arrays

@@ -637,6 +637,7 @@ int main(int argc, char* argv[]) {
     // ---- imd.ofg for the Gibbs sampler (EM.cpp:421-458) ---------------------------------------------------
     if (genGibbsOut) {
         std::unique_ptr<double[]> cp(new double[nnz ? nnz : 1]), ncp(new double[N1 ? N1 : 1]);  // filled by the copies below
+        OfbHeader ofb_hdr;
         each_shard([&](Shard& X, int) {
             X.rc = rsem_model_get_values(X.mc, cp.get() + X.a, ncp.get() + X.lo);
             if (X.rc != RSEM_OK) X.err = rsem_hip_last_error();
@@ -660,7 +661,8 @@ int main(int argc, char* argv[]) {
                     if (n > 0) P.lens.push_back(n);  // (a read without items has no line in .ofg either)
                 }
             });
-            write_ofb(imdName, M, N0, parts);
+            ofb_hdr = write_ofb_arrays(imdName, M, N0, parts);
+            if (ofbMode == 1) write_ofb_header(imdName, ofb_hdr);  // (with a text file beside it: after that file is closed, below)
         } else {
             remove_ofb(imdName);  // never leave an older binary hand-off beside a fresh text one
         }
@@ -711,6 +713,7 @@ int main(int argc, char* argv[]) {
         });
         for (char o : okv) wr_ok = wr_ok && o;
         if (::close(fd) != 0 || !wr_ok) die("Cannot write %s.ofg!", imdName.c_str());
+        if (ofbMode == 2) write_ofb_header(imdName, ofb_hdr);  // not older than the text: rsem-run-gibbs takes the arrays (ofb_present)
         }
     }
     lap(ofbMode == 1 ? "write .ofb" : (ofbMode == 2 ? "write .ofg + .ofb" : "write .ofg"));

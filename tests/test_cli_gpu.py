@@ -74,6 +74,9 @@ def test_rsem_run_em_matches_reference(name, extra, tmp_path):
     for a, b in zip(my_log[11:], ref_log[11:]):  # rounds >= 12: same totNum, bChange to the printed precision
         fa, fb = a.replace(",", "").split(), b.replace(",", "").split()
         assert fa[-1] == fb[-1] and abs(float(fa[8]) - float(fb[8])) <= 2e-5 * max(float(fb[8]), 1e-3), (a, b)
+        # SUM: the floating-point sum of the round's counts, as the reference prints it (EM.cpp:394-398,415) -- the same
+        # number up to the order of the additions
+        assert abs(float(fa[5]) - float(fb[5])) <= 1e-9 * float(fb[5]), (a, b)
     if extra:
         assert sum(l.startswith("GPU ") for l in out.split("\n")) == 2
     # the first 11 rounds print the same SUM / totNum lines as the reference
@@ -152,12 +155,15 @@ def test_rsem_run_gibbs_parallel_runs_and_is_close(tmp_path):
     assert np.all(np.abs(pme[big] - em_counts[big]) < 0.25 * em_counts[big] + 3)
 
 
-@pytest.mark.parametrize("read_type,n_reads,M,threads", [(1, 40000, 2000, 4), (3, 30000, 2000, 4), (3, 1_060_000, 20000, 64)])
+@pytest.mark.parametrize("read_type,n_reads,M,threads", [(0, 100_000, 1000, 1), (2, 50_000, 2000, 4), (1, 40000, 2000, 4), (3, 30000, 2000, 4),
+                                                          (3, 1_060_000, 20000, 64)])
 def test_generated_dataset_vs_reference_binary(read_type, n_reads, M, threads, tmp_path):
     """A fresh, larger synthetic .temp directory (tools/gen_temp.cpp): run the reference binary (oracle/_ref, shipped
     to the GPU box) and the drop-in on the same files; same ROUND count, theta within 1e-6 relative.  The last case is
     paired-end at > 1 M pairs over 20 k transcripts: more transcripts than one LDS window holds (2048), several
-    workgroup units per shape -- the out-of-window and multi-unit paths against the REFERENCE, not only the oracle."""
+    workgroup units per shape -- the out-of-window and multi-unit paths against the REFERENCE, not only the oracle.
+    The first case is BASELINE configs[0] as named: SingleModel (type 0, FASTA reads), 100 k reads, 1 k transcripts,
+    the reference with -p 1 (SingleModel.h:95-146); the second the paired-end model without qualities."""
     gen = os.path.join(ROOT, "tools", "bin", "gen_temp")
     ref_em = os.path.join(ROOT, "oracle", "_ref", "rsem-run-em")
     ref_idx = os.path.join(ROOT, "oracle", "_ref", "rsem-build-read-index")
@@ -165,8 +171,10 @@ def test_generated_dataset_vs_reference_binary(read_type, n_reads, M, threads, t
         pytest.skip("generator or reference binaries not built")
     d = str(tmp_path)
     _run([gen, d, str(n_reads), str(M), str(read_type), "7", "75"])
-    reads = ["s_alignable.fq"] if read_type == 1 else ["s_alignable_1.fq", "s_alignable_2.fq"]
-    _run([ref_idx, "32", "1", "1"] + [os.path.join(d, "temp", r) for r in reads])
+    ext = ".fq" if read_type in (1, 3) else ".fa"
+    reads = ["s_alignable" + ext] if read_type < 2 else ["s_alignable_1" + ext, "s_alignable_2" + ext]
+    # rsem-build-read-index gap hasQ quiet files (buildReadIndex.cpp:72-84), as rsem-calculate-expression calls it
+    _run([ref_idx, "32", "1" if read_type in (1, 3) else "0", "1"] + [os.path.join(d, "temp", r) for r in reads])
     args = [os.path.join(d, "ref"), str(read_type), os.path.join(d, "s"), os.path.join(d, "temp", "s"), os.path.join(d, "stat", "s")]
     out_ref = _run([ref_em] + args + ["-p", str(threads)])
     graw, gpol = rf.read_theta(os.path.join(d, "stat", "s.theta"))
@@ -350,6 +358,8 @@ def test_gibbs_binary_handoff_between_the_two_programs(name, tmp_path):
                         "--gibbs-out"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert os.path.exists(imd + ".ofb/hdr") and os.path.exists(imd + ".ofg")
+    # the header is written after the text file is closed: rsem-run-gibbs must find the arrays not older than the text
+    assert os.stat(imd + ".ofb/hdr").st_mtime_ns >= os.stat(imd + ".ofg").st_mtime_ns
     M, N0, rp, sid, val = rf.read_ofg(imd + ".ofg")
     brp = np.fromfile(imd + ".ofb/row_ptr", np.uint64)
     assert np.array_equal(brp, rp) and np.array_equal(np.fromfile(imd + ".ofb/sid", np.int32), sid)
@@ -362,10 +372,13 @@ def test_gibbs_binary_handoff_between_the_two_programs(name, tmp_path):
     def chains(tag):
         for f in ("iso_res", "gene_res"):
             shutil.copy(imd + "." + f + ".keep", imd + "." + f)
-        _run(args)
+        log = _run(args)
+        assert ("newer than" in log) == (tag == "stale"), log[-1500:]  # the warning of ofb_present() = the text was chosen
         out = [open(imd + ".countvectors%d" % k, "rb").read() for k in range(meta["gibbs_threads"])]
         return out
-    from_both = chains("both")       # .ofb present and not older than .ofg: the arrays are used
+    from_both = chains("both")       # .ofb present and not older than .ofg: the arrays are used (no warning)
+    os.utime(imd + ".ofg")           # a text file written AFTER the arrays wins, and says so
+    assert chains("stale") == from_both
     os.remove(imd + ".ofg")
     from_arrays = chains("arrays")   # the arrays alone
     shutil.rmtree(imd + ".ofb")

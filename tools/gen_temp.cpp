@@ -1,7 +1,10 @@
 // gen_temp.cpp -- seeded generator of a complete rsem-run-em input directory at benchmark scale
 // (".temp generator without SAM").  TEST / BENCH INFRASTRUCTURE, not product.
 //
-//   gen_temp <outdir> <n_reads> <M> <read_type 1|3> [seed] [read_len] [sam|nosam] [kmin-kmax]
+//   gen_temp <outdir> <n_reads> <M> <read_type 0|1|2|3> [seed] [read_len] [sam|nosam] [kmin-kmax]
+//
+// read_type 0 / 2 (SingleModel / PairedEndModel): the same reads without qualities, as FASTA (utils.h:129-149,
+// SingleRead.h:37-52); the bases still carry errors drawn at the phred rate of the hidden quality chain.
 //
 // kmin-kmax = isoforms per gene (default 2-9, ~6 alignments per read; 6-20 gives the ~12 per read of BASELINE configs[2])
 //
@@ -38,12 +41,13 @@ int main(int argc, char** argv) {
     const int M = atoi(argv[3]), read_type = atoi(argv[4]);
     const unsigned seed = argc > 5 ? (unsigned)atoll(argv[5]) : 20250925u;
     const int L = argc > 6 ? atoi(argv[6]) : 100;
-    const bool pe = read_type == 3;
+    const bool pe = read_type >= 2, hasq = (read_type & 1) != 0;
+    const std::string ext = hasq ? ".fq" : ".fa";
     const bool want_sam = argc > 7 && std::string(argv[7]) == "sam";
     int kmin = 2, kmax = 9;
     if (argc > 8 && sscanf(argv[8], "%d-%d", &kmin, &kmax) != 2) { fprintf(stderr, "isoforms per gene: kmin-kmax\n"); return 1; }
     if (kmin < 1 || kmax < kmin) { fprintf(stderr, "isoforms per gene: 1 <= kmin <= kmax\n"); return 1; }
-    if (read_type != 1 && read_type != 3) { fprintf(stderr, "read_type must be 1 or 3\n"); return 1; }
+    if (read_type < 0 || read_type > 3) { fprintf(stderr, "read_type must be 0..3\n"); return 1; }
     std::mt19937_64 rng(seed);
     auto uni = [&](double a, double b) { return std::uniform_real_distribution<double>(a, b)(rng); };
     auto irand = [&](int a, int b) { return std::uniform_int_distribution<int>(a, b)(rng); };
@@ -100,8 +104,8 @@ int main(int argc, char** argv) {
     const long long N0 = N / 20;
     const long long N1 = N - N0;
     FILE* fdat = fopen((out + "/temp/s.dat").c_str(), "w");
-    FILE* fq1 = fopen((out + (pe ? "/temp/s_alignable_1.fq" : "/temp/s_alignable.fq")).c_str(), "w");
-    FILE* fq2 = pe ? fopen((out + "/temp/s_alignable_2.fq").c_str(), "w") : nullptr;
+    FILE* fq1 = fopen((out + (pe ? "/temp/s_alignable_1" + ext : "/temp/s_alignable" + ext)).c_str(), "w");
+    FILE* fq2 = pe ? fopen((out + "/temp/s_alignable_2" + ext).c_str(), "w") : nullptr;
     setvbuf(fdat, nullptr, _IOFBF, 1 << 22); setvbuf(fq1, nullptr, _IOFBF, 1 << 22); if (fq2) setvbuf(fq2, nullptr, _IOFBF, 1 << 22);
     FILE* fsam = nullptr;
     if (want_sam) {
@@ -133,8 +137,10 @@ int main(int argc, char** argv) {
             O.sam += is_rev ? rev(ql) : ql; O.sam += '\n';
         };
         auto emit_read = [&](std::string& f, long long id, const std::string& sq, const std::string& q) {
-            snprintf(tmp, sizeof(tmp), "@r%lld\n", id);
-            f += tmp; f += sq; f += "\n+\n"; f += q; f += '\n';
+            snprintf(tmp, sizeof(tmp), "%cr%lld\n", hasq ? '@' : '>', id);
+            f += tmp; f += sq;
+            if (hasq) { f += "\n+\n"; f += q; }
+            f += '\n';
         };
         auto make_read = [&](int t, int dir, int spos, std::string& sq, std::string& q) {
             const std::string& g = gseq[tx[t].gene];
@@ -230,13 +236,14 @@ int main(int argc, char** argv) {
         fwrite(b2.data(), 1, b2.size(), fsam); fputc('\n', fsam);
     };
     auto emit_read = [&](FILE* f, long long id, const std::string& sq, const std::string& q) {
-        fprintf(f, "@r%lld\n", id);
-        fwrite(sq.data(), 1, sq.size(), f); fputs("\n+\n", f);
-        fwrite(q.data(), 1, q.size(), f); fputc('\n', f);
+        fprintf(f, "%cr%lld\n", hasq ? '@' : '>', id);
+        fwrite(sq.data(), 1, sq.size(), f);
+        if (hasq) { fputs("\n+\n", f); fwrite(q.data(), 1, q.size(), f); }
+        fputc('\n', f);
     };
     {   // unalignable reads
-        FILE* fu1 = fopen((out + (pe ? "/temp/s_un_1.fq" : "/temp/s_un.fq")).c_str(), "w");
-        FILE* fu2 = pe ? fopen((out + "/temp/s_un_2.fq").c_str(), "w") : nullptr;
+        FILE* fu1 = fopen((out + (pe ? "/temp/s_un_1" + ext : "/temp/s_un" + ext)).c_str(), "w");
+        FILE* fu2 = pe ? fopen((out + "/temp/s_un_2" + ext).c_str(), "w") : nullptr;
         for (long long r = 0; r < N0; r++) {
             for (int mth = 0; mth < (pe ? 2 : 1); mth++) {
                 int qv = irand(10, 40);
