@@ -246,6 +246,7 @@ def q32_leg(ctx, wl, N0, K, W, sync, alg_bytes, f64_ms_per_step, f64_estep_ms, t
         bytes32, n_q32 = ctx.info("value_plane_bytes"), ctx.info("reads_q32")
         el, rounds, reps, estep_ms, ts = timed_rounds(ctx, wl, N0, K, W, sync, lambda: None)
         th = ctx.run(wl["theta0"], N0, min_round=K, max_round=K)["theta"]
+        phys = physical(ctx, estep_ms, traffic)
         ctx.set_option("value_bits", 64)
         big = ref >= 1e-7
         own = alg_bytes - (bytes64 - bytes32) + 2 * n_q32  # what this layout stores per round instead of the doubles
@@ -258,9 +259,43 @@ def q32_leg(ctx, wl, N0, K, W, sync, alg_bytes, f64_ms_per_step, f64_estep_ms, t
                 "frac_this_format": own / (estep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "frac_by_the_f64_formula": alg_bytes / (estep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "theta_max_rel_diff_vs_f64_after_%d_rounds" % K: float(np.max(np.abs(th - ref)[big] / ref[big])) if big.any() else 0.0,
-                "theta_sum": ts, "traffic": traffic}
+                "theta_sum": ts, "traffic": traffic, "physical": phys, "frac_physical": phys.get("frac_physical")}
     except Exception as e:
         return {"error": str(e)}
+
+
+def physical(ctx, estep_ms, pmc_traffic=None):
+    """The bytes one E-step launch moves through HBM BY CONSTRUCTION of the layout this context holds right now
+    (rsem_em_get_info "physical_bytes_per_launch": every value plane incl. padding, the sid planes of the slices in which a
+    tuple starts, noise value + mask + unit records, theta into / counts out of every LDS window) against the launch time
+    measured in this run -- the roofline fraction this run can vouch for itself.  pmc_traffic: the committed rocprofv3
+    counter measurement of the same workload, when there is one (profiles/pmc_traffic.json), as a cross-check of the
+    accounting."""
+    try:
+        b = ctx.info("physical_bytes_per_launch")
+        out = {"physical_bytes_per_launch": b, "physical_GBps": b / (estep_ms * 1e-3) / 1e9,
+               "frac_physical": b / (estep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+               "parts": {"value_planes": ctx.info("value_plane_bytes"), "sid_planes_loaded": ctx.info("sid_plane_bytes_loaded"),
+                         "sid_planes_stored": ctx.info("sid_plane_bytes"), "noise_values": 8 * ctx.info("slots"),
+                         "masks": 8 * ctx.info("slices"), "lds_windows_theta_in_counts_out": 16 * ctx.info("window_entries")}}
+        if pmc_traffic:
+            out["pmc_traffic_bytes_per_launch"] = pmc_traffic
+            out["physical_over_pmc"] = b / pmc_traffic
+        return out
+    except Exception as e:  # (a library built before the keys existed: RSEM_HIP_LIB experiments)
+        return {"error": str(e)}
+
+
+def pmc_traffic_of(key, scale=1.0, kernel=0):
+    """(bytes per launch, source) of the committed PMC measurement for a workload key of profiles/pmc_traffic.json."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pm = json.load(f).get(key)
+        if pm and scale == 1.0 and kernel in (0, 3):
+            return pm["traffic_bytes_per_launch"], pm.get("source")
+    except Exception:
+        pass
+    return None, None
 
 
 def far_units(ctx):
@@ -306,9 +341,11 @@ def em_leg(capi, make_em_workload, config, K, W, kernel, sync, device, q32=False
         el, rounds, reps, estep_ms, ts = timed_rounds(ctx, wl, wl["N0"], K, W, sync, lambda: None)
         alg = 12 * nnz + 16 * N1 + 16 * (M + 1)
         ach = alg / (estep_ms * 1e-3) / 1e9
+        phys = physical(ctx, estep_ms, pmc_traffic_of(config, scale, kernel)[0])
         out = {"workload": "%s%s: %d reads x %d transcripts, %d alignments" % (WORKLOADS.get(config, config), "" if scale == 1.0 else " at %g of its reads" % scale, N1, M, nnz),
                "ms_per_step": el * 1e3 / rounds, "timed_rounds": rounds, "timed_region_s": el, "value": nnz * rounds / el,
                "estep_avg_launch_ms": estep_ms, "algorithmic_bytes_per_launch": alg, "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS,
+               "frac_physical": phys.get("frac_physical"), "physical": phys,
                "theta_sum": ts, "generate_s": gen_s, "parity_one_step": one_step_parity(ctx, wl),
                "units_with_ids_outside_their_window": far_units(ctx)}
         if q32 and kernel in (0, 3):
@@ -379,9 +416,17 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ["RSEM_COMM_FORCE"] = "1"
+    # tensors of the timing collectives live on the GPU ("nccl" is RCCL on ROCm); BENCH_DIST_BACKEND=gloo (tests/, no GPU:
+    # the C-ABI wrappers are stand-ins there) keeps them on the host so that the N > 1 control flow and the JSON line it
+    # assembles run as world-size-2 CPU processes
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    tdev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=tdev)
+        else:
+            dist.init_process_group(backend)
     if rank == 0:
         build.build()
     if distributed:
@@ -412,7 +457,7 @@ def main():
     def agree(x):
         if not distributed:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=torch.device("cuda", local))
+        t = torch.tensor([x], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -420,7 +465,7 @@ def main():
     total_nnz = nnz
     dist_info = None
     if distributed:
-        dev = torch.device("cuda", local)
+        dev = tdev
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -428,11 +473,12 @@ def main():
         dist.all_reduce(tn)
         total_nnz = int(tn.item())
         # per-rank E-step time and the cost of the per-round collective alone (same size, same communicator)
-        es = torch.zeros(world, dtype=torch.float64, device=dev)
-        es[rank] = estep_ms
+        es = torch.zeros(world, 2, dtype=torch.float64, device=dev)
+        es[rank, 0] = estep_ms
+        es[rank, 1] = physical(ctx, estep_ms).get("frac_physical") or 0.0   # every GPU's own layout against its own launch time
         dist.all_reduce(es)
         buf = torch.zeros(M + 1 + 128, dtype=torch.float64, device=dev)
-        st = torch.cuda.current_stream().cuda_stream
+        st = torch.cuda.current_stream().cuda_stream if backend == "nccl" else 0
         for _ in range(5):
             comm.allreduce(buf.data_ptr(), buf.numel(), st)
         sync()
@@ -442,8 +488,10 @@ def main():
             comm.allreduce(buf.data_ptr(), buf.numel(), st)
         sync()
         ar_ms = (time.perf_counter() - t1) / 200 * 1e3
-        dist_info = {"rccl_ranks": comm.world, "estep_ms_per_rank": [float(x) for x in es.cpu()], "allreduce_ms": ar_ms,
-                     "allreduce_doubles": int(buf.numel())}
+        dist_info = {"rccl_ranks": comm.world, "estep_ms_per_rank": [float(x) for x in es[:, 0].cpu()],
+                     "frac_physical_per_rank": [float(x) for x in es[:, 1].cpu()],
+                     "em_iterations_per_s_per_rank": [1e3 / float(x) if x > 0 else None for x in es[:, 0].cpu()],
+                     "allreduce_ms": ar_ms, "allreduce_doubles": int(buf.numel())}
 
     gibbs = None
     if not args.no_gibbs:
@@ -473,7 +521,7 @@ def main():
             b_g = 12 * (len(isid) - N1) + 16 * N1  # conprb + sid per alignment, noise conprb + row slot per read
             per_rank = [[pp.sweep_ms, pp.reduce_ms, pe.sweep_ms, pe.reduce_ms]]
             if distributed:
-                t = torch.zeros(world, 4, dtype=torch.float64, device=torch.device("cuda", local))
+                t = torch.zeros(world, 4, dtype=torch.float64, device=tdev)
                 t[rank] = torch.tensor(per_rank[0], dtype=torch.float64)
                 dist.all_reduce(t)
                 per_rank = t.cpu().tolist()
@@ -482,6 +530,8 @@ def main():
             gibbs = {"items_per_chain": int(len(isid)), "gpus": world, "chains_to_ranks": "chain k on rank k % world, one reduce to rank 0 at the end",
                      "parallel": {"mode": "data-augmentation sampler, 1 chain per GPU", "ms_per_sweep": sw,
                                   "ms_per_sweep_per_rank": [r[0] for r in per_rank],
+                                  "sweeps_per_s_per_rank": [1e3 / r[0] if r[0] > 0 else None for r in per_rank],
+                                  "frac_of_hbm_peak_per_rank": [b_g / r[0] / 1e6 / HBM_PEAK_GBPS if r[0] > 0 else None for r in per_rank],
                                   "algorithmic_GBps_per_gpu": b_g / sw / 1e6 if sw > 0 else None,
                                   "frac_of_hbm_peak_per_gpu": b_g / sw / 1e6 / HBM_PEAK_GBPS if sw > 0 else None,
                                   "sweeps_per_s_all_gpus": world * 1e3 / sw if sw > 0 else None,
@@ -500,29 +550,19 @@ def main():
 
     parity = one_step_parity(ctx, wl) if (rank == 0 and world == 1) else None
     value_plane_bytes = ctx.info("value_plane_bytes")
+    key_pmc = args.config + ("_q32" if args.value_bits == 32 else "")
+    phys_headline = physical(ctx, estep_ms, pmc_traffic_of(key_pmc, args.scale, args.kernel)[0])
     units_far = far_units(ctx)
     q32 = None
     if world == 1 and not distributed and not args.no_q32 and args.value_bits == 64 and args.kernel in (0, 3):
-        q32_traffic = None  # the committed PMC measurement of this layout (profiles/pmc_traffic.json), as for the headline
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pm = json.load(f).get(args.config + "_q32")
-            if pm and args.scale == 1.0:
-                q32_traffic = pm["traffic_bytes_per_launch"]
-        except Exception:
-            pass
+        # the committed PMC measurement of this layout (profiles/pmc_traffic.json), as for the headline
+        q32_traffic = pmc_traffic_of(args.config + "_q32", args.scale, args.kernel)[0]
         q32 = q32_leg(ctx, wl, N0g, K, W, sync, alg_bytes, elapsed * 1e3 / rounds, estep_ms, q32_traffic)
     ctx.close()
     if rank == 0:
         achieved = alg_bytes / (estep_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None  # PMC passes cannot run inside this process: the committed measurement for this workload
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pm = json.load(f).get(args.config)
-            if pm and args.scale == 1.0 and args.kernel in (0, 3):
-                traffic, traffic_src = pm["traffic_bytes_per_launch"], pm.get("source")
-        except Exception:
-            pass
+        # PMC passes cannot run inside this process: `traffic` is the committed counter measurement for this workload
+        traffic, traffic_src = pmc_traffic_of(key_pmc, args.scale, args.kernel)
         stream = None
         if not args.no_stream:
             try:
@@ -547,8 +587,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_estep_lane (E step)", "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "achieved / frac use the ALGORITHMIC bytes of SURVEY.md 8(d) (12 B per alignment + 16 B per read + 16 B per transcript); "
-                                 "the kernel physically moves fewer (`traffic`, by PMC): it re-uses a tuple's transcript ids from registers instead of "
-                                 "re-reading them, so frac can pass 1 while frac_of_traffic (physical bytes / time / peak) cannot",
+                                 "the kernel physically moves fewer: it re-uses a tuple's transcript ids from registers instead of re-reading them and "
+                                 "needs no row pointers, so frac can pass 1.  frac_physical = the bytes the layout of THIS run moves by construction "
+                                 "(physical.parts, from rsem_em_get_info) / this run's launch time / peak: the roofline fraction proper.  `traffic` = the "
+                                 "committed rocprofv3 PMC measurement of the same workload (cannot be taken inside this process); physical_over_pmc "
+                                 "says how well the two agree",
+                         "frac_physical": phys_headline.get("frac_physical"), "physical": phys_headline,
                          "avg_launch_ms": estep_ms, "step_over_launch": elapsed * 1e3 / rounds / estep_ms,
                          # the same launch time against the bytes the kernel physically moved (PMC) and against what a plain
                          # streaming kernel reaches on this device (measured here), beside the 8 TB/s specification

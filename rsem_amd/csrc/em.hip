@@ -815,6 +815,7 @@ struct rsem_em_ctx {
     Unit* d_units = nullptr;
     unsigned long long* d_trace = nullptr;  // per-workgroup timestamps (tune_unit_order, rsem_em_debug_trace)
     std::vector<Unit> h_units;
+    uint64_t long_nnz = 0;  // alignments of the reads left in the CSR
     uint32_t n_far_units = 0;               // units with an id outside their LDS window (Unit::pad[0])
     unsigned long long n_stray_reads = 0;   // reads the second layout pass sorted apart (sell_build_refined)
     int tune_passes_left = 1;               // measured-lifetime reordering of the units, done on first use
@@ -921,6 +922,14 @@ int launch_mstep(rsem_em_ctx* c, double N0, double* d_counts, const double* d_th
 int build_layout(rsem_em_ctx* c);
 void free_layout(rsem_em_ctx* c);
 
+// alignments of the reads that stay in the CSR (> 256 alignments): their bytes are part of a launch's physical traffic
+__global__ void k_sum_row_lengths(uint32_t n, const uint32_t* __restrict__ rows, const uint64_t* __restrict__ row_ptr, unsigned long long* out) {
+    unsigned long long v = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v += row_ptr[rows[i] + 1] - row_ptr[rows[i]];
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
 int write_values(rsem_em_ctx* c) {
     if (c->d_fill_err) RSEM_HIP_TRY(hipMemsetAsync(c->d_fill_err, 0, sizeof(int), c->stream));
     int rc = sell_fill_values(c->L, c->stream, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_sval, c->d_sncp, c->d_sexp, c->d_fill_err);
@@ -989,6 +998,18 @@ int build_layout(rsem_em_ctx* c) {
     RSEM_HIP_TRY(hipMemsetAsync(c->d_noise_a, 0, sizeof(double) * c->noise_cap, c->stream));
 
     c->grid_long = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_long_rows, kBlock)));
+    c->long_nnz = 0;
+    if (c->L.n_long_rows) {
+        unsigned long long* d_n = (unsigned long long*)c->d_noise_a;  // (cleared again below)
+        hipLaunchKernelGGL(k_sum_row_lengths, dim3(c->grid_long), dim3(kBlock), 0, c->stream, c->L.n_long_rows, c->L.d_order + c->L.n_sell_rows,
+                           c->d_row_ptr, d_n);
+        RSEM_HIP_TRY(hipGetLastError());
+        unsigned long long h = 0;
+        RSEM_HIP_TRY(hipMemcpyAsync(&h, d_n, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        RSEM_HIP_TRY(hipMemsetAsync(c->d_noise_a, 0, sizeof(double), c->stream));
+        RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+        c->long_nnz = h;
+    }
     c->layout_ok = true;
     return RSEM_OK;
 }
@@ -1185,6 +1206,25 @@ int rsem_em_get_info(const rsem_em_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "value_plane_bytes")) *value = (int64_t)c->L.val_bytes;       // incl. padding
     else if (!strcmp(key, "sid_plane_bytes")) *value = (int64_t)(c->L.n_planes * 256);
     else if (!strcmp(key, "slots")) *value = c->L.n_slots;
+    else if (!strcmp(key, "sid_plane_bytes_loaded")) *value = (int64_t)(c->L.n_sid_planes_loaded * 256);  // slices where a tuple starts
+    else if (!strcmp(key, "slices")) *value = c->L.n_slices;
+    else if (!strcmp(key, "window_entries")) {  // ids staged in (theta) and flushed from (counts) the LDS windows of all units
+        int64_t w = 0;
+        for (const Unit& u : c->h_units) w += u.span;
+        *value = w;
+    } else if (!strcmp(key, "physical_bytes_per_launch")) {
+        // What one E-step launch of the LANE kernel moves through HBM by construction of the layout: every value plane,
+        // the sid planes of the slices in which a tuple starts, one noise value (and, Q32, one exponent) per row slot, one
+        // mask per slice, the unit table, theta into and counts out of every unit's window, and the CSR entries of the
+        // reads with more than 256 alignments.  (Cache hits are not counted: the first sid slice of a shape, re-read by the
+        // slices without a new tuple, and theta of neighbouring units.)
+        int64_t w = 0;
+        for (const Unit& u : c->h_units) w += u.span;
+        const uint64_t long_nnz = c->long_nnz + (c->L.n_long_rows * 4ull) / 3;  // 12 B per alignment + 16 B per read
+        *value = (int64_t)(c->L.val_bytes + c->L.n_sid_planes_loaded * 256 + (uint64_t)c->L.n_slots * (8 + (c->layout_has_q32 ? 2 : 0)) +
+                           (uint64_t)c->L.n_slices * 8 + (uint64_t)c->n_units * sizeof(Unit) + (uint64_t)w * 16 + 16 * ((uint64_t)c->M + 1)) +
+                 (int64_t)(12 * long_nnz);
+    }
     else if (!strcmp(key, "units")) *value = c->n_units;
     else { rsem::set_last_error("unknown info key '%s'", key); return RSEM_ERR_INVALID; }
     return RSEM_OK;

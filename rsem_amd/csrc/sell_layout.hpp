@@ -310,6 +310,22 @@ __global__ void k_slice_masks(const Shape* __restrict__ shapes, int n_shapes, ui
     if (lane == 0) masks[s] = m;
 }
 
+// How many sid planes does a pass over the layout fetch?  A slice's sid planes are loaded from HBM only when some lane
+// starts a new tuple there (mask != 0); the other slices re-read the shape's first sid slice (cache hits).  Planes of the
+// slices with a set bit, summed over the layout: the "physical bytes" of the roofline (bench.py) come from this.
+__global__ void k_count_sid_planes(const Shape* __restrict__ shapes, int n_shapes, uint32_t n_slices,
+                                   const unsigned long long* __restrict__ masks, unsigned long long* out) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long k = 0;
+    if (s < n_slices && masks[s] != 0ull) {
+        int sh = 0;
+        while (sh + 1 < n_shapes && s >= shapes[sh + 1].slice_base) ++sh;
+        k = (unsigned long long)shapes[sh].K;
+    }
+    for (int d = 32; d >= 1; d >>= 1) k += __shfl_xor(k, d);
+    if ((threadIdx.x & 63) == 0 && k) atomicAdd(out, k);
+}
+
 // anchor sid (row_key_of) of the read in row slot 0 of every slice (non-decreasing along the blocks of a shape, except
 // where its far-reaching reads begin)
 __global__ void k_slice_minsid(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_slices,
@@ -368,6 +384,7 @@ struct SellLayout {
     uint64_t val_bytes = 0;       // value planes of all shapes (Shape::val_base points into them)
     uint32_t n_q32_rows = 0;      // sorted rows held in Q32 shapes
     uint64_t n_q32_planes = 0;
+    uint64_t n_sid_planes_loaded = 0;  // sid planes of the slices in which some lane starts a new tuple (k_count_sid_planes)
     int32_t* d_ssid = nullptr;
     unsigned long long* d_masks = nullptr;
     uint32_t* d_slice_minsid = nullptr;
@@ -499,6 +516,15 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
         hipLaunchKernelGGL(k_slice_masks, dim3(rsem::ceil_div(L.n_slices, kBlock / 64)), dim3(kBlock), 0, st,
                            L.d_shapes, L.n_shapes, L.T, L.n_slices, L.d_ssid, L.d_masks);
         RSEM_HIP_TRY(hipGetLastError());
+        unsigned long long* d_cnt = (unsigned long long*)d_keys;  // (the unsorted keys are spent)
+        RSEM_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_count_sid_planes, dim3(rsem::ceil_div(L.n_slices, kBlock)), dim3(kBlock), 0, st, L.d_shapes, L.n_shapes,
+                           L.n_slices, (const unsigned long long*)L.d_masks, d_cnt);
+        RSEM_HIP_TRY(hipGetLastError());
+        unsigned long long h_cnt = 0;
+        RSEM_HIP_TRY(hipMemcpyAsync(&h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
+        RSEM_HIP_TRY(hipStreamSynchronize(st));
+        L.n_sid_planes_loaded = h_cnt;
     }
     RSEM_HIP_TRY(hipStreamSynchronize(st));
     cleanup();

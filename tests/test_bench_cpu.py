@@ -28,26 +28,53 @@ class FakeCtx:
     def step(self, th, N0):
         n = len(th)
         return np.zeros(n) + 1e300, np.array(th, float), 1.0, 0.0, 0   # (nothing like the oracle's counts: parity must say so)
-    def info(self, k): return {"value_plane_bytes": 1000 if self.opts["value_bits"] == 64 else 520, "reads_q32": 9, "value_range_bits": 8, "far_units": 1, "units": 7}[k]
+    def info(self, k): return {"value_plane_bytes": 1000 if self.opts["value_bits"] == 64 else 520, "reads_q32": 9, "value_range_bits": 8, "far_units": 1, "units": 7,
+                               "physical_bytes_per_launch": 1500 if self.opts["value_bits"] == 64 else 1020, "sid_plane_bytes_loaded": 100, "sid_plane_bytes": 500,
+                               "slots": 20, "slices": 5, "window_entries": 10}[k]
     def set_option(self, k, v): self.opts[k] = v
     def set_comm(self, c): pass
     def close(self): pass
 capi.EmContext = FakeCtx
 def boom(*a, **k): raise RuntimeError("stand-in: no device")
 capi.GibbsContext = boom
+%(extra)s
 capi.ci_calculate = boom
 capi.stream_probe = lambda device=0, nbytes=0, reps=0: (6000.0, 5000.0)
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(%(root)r, "bench.py"))
 b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 b.MIN_TIMED_S = 0.0
-sys.argv = ["bench.py", "--config", "tiny", "--legs", "tinyR,tiny@0.5", "--no-cpu-baseline", "--steps", "3", "--warmup", "1"]
+sys.argv = ["bench.py", "--config", "tiny", "--legs", "tinyR,tiny@0.5", "--no-cpu-baseline", "--steps", "3", "--warmup", "1"] + %(argv)r
 b.main()
+'''
+
+# stand-ins of the N > 1 run: a communicator whose all-reduce does nothing, a Gibbs context that reports rank-dependent times
+DIST_EXTRA = r'''
+class FakeComm:
+    world = int(os.environ["WORLD_SIZE"]); rank = int(os.environ["RANK"])
+    @staticmethod
+    def unique_id(): return b"x" * 128
+    @classmethod
+    def create(cls, device, rank, world, uid): return cls()
+    def allreduce(self, ptr, n, stream=0): pass
+    def close(self): pass
+capi.Comm = FakeComm
+class GP:
+    def __init__(self, sweep, red): self.sweep_ms, self.reduce_ms = sweep, red
+class FakeGibbs:
+    def __init__(self, *a, **k): pass
+    def set_comm(self, c): pass
+    def run_chains(self, mode, seeds, *a, **k):
+        r = int(os.environ["RANK"])
+        return None, [np.ones(3)], None, GP(2.0 + r, 0.25)
+    def close(self): pass
+capi.GibbsContext = FakeGibbs
+capi.gibbs_chain_seeds = lambda seed, n: list(range(n))
 '''
 
 
 def test_bench_main_prints_one_contract_line():
-    r = subprocess.run([sys.executable, "-c", DRIVER % {"root": ROOT}], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", DRIVER % {"root": ROOT, "extra": "", "argv": []}], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.split("\n") if l.strip()]
     assert len(lines) == 1, r.stdout[:500]
@@ -66,6 +93,44 @@ def test_bench_main_prints_one_contract_line():
     assert d["checks"]["parity_one_step"]["ok"] is False and d["other_configs"]["tinyR"]["parity_one_step"]["ok"] is False
     assert d["roofline"]["stream"]["read_GBps"] == 6000.0 and d["roofline"]["achieved_over_stream_read"] > 0
     assert "frac_of_traffic" in d["roofline"]
+    # the roofline fraction the run can vouch for: the layout's own bytes over its own launch time, on the headline AND every leg
+    assert d["roofline"]["frac_physical"] == 1500 / 1e-3 / 1e9 / 8000.0 and d["roofline"]["physical"]["parts"]["sid_planes_loaded"] == 100
+    for leg in d["other_configs"].values():
+        assert leg["frac_physical"] > 0 and leg["physical"]["physical_bytes_per_launch"] == 1500
+    assert d["q32_value_planes"]["frac_physical"] == 1020 / 1e-3 / 1e9 / 8000.0
+
+
+def test_bench_two_ranks_line_carries_per_rank_numbers():
+    """The N > 1 control flow of bench.py as two gloo processes on the CPU (BENCH_DIST_BACKEND=gloo; the C-ABI wrappers and
+    the communicator are stand-ins): rank 0 prints ONE line, n_gpus = 2, value = the sum over ranks, and the line carries what
+    a scaling run is read for -- per-rank E-step times and physical roofline fractions, per-rank sweeps/s of the PARALLEL Gibbs
+    split (the split that scales: one chain per GPU) and the cost of its single final reduce."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   BENCH_DIST_BACKEND="gloo")
+        code = DRIVER % {"root": ROOT, "extra": DIST_EXTRA, "argv": ["--gpus", "2", "--no-ci"]}
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    assert not outs[1][0].strip()  # only rank 0 prints
+    lines = [l for l in outs[0][0].split("\n") if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "other_configs" not in d and "cpu_baseline" not in d
+    di = d["distributed"]
+    assert di["rccl_ranks"] == 2 and len(di["estep_ms_per_rank"]) == 2 and len(di["frac_physical_per_rank"]) == 2
+    assert all(x > 0 for x in di["frac_physical_per_rank"]) and di["allreduce_ms"] >= 0
+    g = d["gibbs"]["parallel"]
+    assert g["ms_per_sweep_per_rank"] == [2.0, 3.0] and g["ms_per_sweep"] == 3.0  # the slowest GPU sets the job's rate
+    assert g["sweeps_per_s_per_rank"] == [500.0, 1e3 / 3.0] and g["sweeps_per_s_all_gpus"] == 2 * 1e3 / 3.0
+    assert g["final_reduce_ms"] == 0.25 and len(g["frac_of_hbm_peak_per_rank"]) == 2
+    assert d["gibbs"]["exact"]["final_reduce_ms"] == 0.25
 
 
 def test_bench_starts_its_own_ranks():

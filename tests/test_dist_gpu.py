@@ -78,3 +78,30 @@ def test_rccl_calls_with_a_one_rank_communicator(monkeypatch):
     comm.close()
     # (floating-point atomics: two runs of the same ctx agree to the last few bits, not bit for bit)
     assert viarccl["rounds"] == plain["rounds"] and np.allclose(viarccl["theta"], plain["theta"], rtol=1e-12, atol=0)
+
+
+def test_bench_forced_dist_line_on_one_gpu():
+    """The N > 1 code path of bench.py, executed on HEAD every round on a one-GPU box (BENCH_FORCE_DIST=1: process group,
+    communicator id through torch.distributed, RCCL all-reduce per round from C++, Gibbs chains dealt to ranks, the single
+    final reduce) -- the driver's 8-GPU scaling run is the first time this path meets real ranks, so every round must at
+    least have executed it and seen the keys a scaling run is read for."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_PORT="29631")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C2", "--scale", "0.1", "--legs=", "--no-cpu-baseline", "--no-ci",
+                        "--steps", "5", "--warmup", "1", "--gibbs-sweeps", "6", "--gibbs-exact-rounds", "2"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1, r.stdout[:1000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["roofline"]["frac_physical"] > 0
+    di = d["distributed"]
+    assert di["rccl_ranks"] == 1 and len(di["estep_ms_per_rank"]) == 1 and di["frac_physical_per_rank"][0] > 0 and di["allreduce_ms"] > 0
+    g = d["gibbs"]
+    assert "error" not in g, g
+    assert g["parallel"]["sweeps_per_s_per_rank"][0] > 0 and g["parallel"]["final_reduce_ms"] is not None and g["parallel"]["final_reduce_ms"] >= 0
+    assert g["exact"]["final_reduce_ms"] is not None
