@@ -18,6 +18,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 namespace rsemh {
@@ -62,9 +63,13 @@ struct MappedFile {
 
 // A typed array that either owns its storage (uninitialised on allocation: the parsers fill it from many threads, which
 // also spreads the first-touch page faults) or views memory owned elsewhere (a mapped file).
+// Big arrays are 2 MB-aligned and advised as huge pages (transparent_hugepage = madvise / always): 512 x fewer page faults
+// while the parsers fill them and 512 x fewer pages to give back at exit -- at BASELINE configs[2] the process holds
+// 35 GB of parsed arrays, and tearing down that many 4 KB pages was 3 s of wall clock after main() had returned.
+struct ArrFree { void operator()(void* q) const { free(q); } };
 template <typename T>
 struct Arr {
-    std::unique_ptr<T[]> own;
+    std::unique_ptr<T[], ArrFree> own;
     std::shared_ptr<MappedFile> keep;
     const T* p = nullptr;
     size_t n = 0;
@@ -72,13 +77,31 @@ struct Arr {
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
     const T& operator[](size_t i) const { return p[i]; }
-    T* alloc(size_t m) { own.reset(new T[m ? m : 1]); p = own.get(); n = m; return own.get(); }
+    T* alloc(size_t m) {
+        static_assert(std::is_trivial<T>::value, "Arr holds plain data");
+        const size_t bytes = (m ? m : 1) * sizeof(T);
+        void* q = nullptr;
+        if (bytes >= ((size_t)32 << 20)) {
+            const size_t huge = (size_t)2 << 20, rounded = (bytes + huge - 1) / huge * huge;
+            if (posix_memalign(&q, huge, rounded) != 0) q = nullptr;
+            else madvise(q, rounded, MADV_HUGEPAGE);
+        } else q = malloc(bytes);
+        if (!q) die("Out of memory (%zu bytes)!", bytes);
+        own.reset((T*)q); p = own.get(); n = m;
+        return own.get();
+    }
     void view(const T* q, size_t m, std::shared_ptr<MappedFile> k) { own.reset(); keep = std::move(k); p = q; n = m; }
+    void release() { own.reset(); keep.reset(); p = nullptr; n = 0; }
 };
 
 inline int hardware_threads() {
     unsigned n = std::thread::hardware_concurrency();
     return (int)std::min<unsigned>(std::max<unsigned>(n, 1), 64);
+}
+// threads for ONE of several files that are parsed at the same time (run_em.cpp parses .dat and the read files concurrently)
+inline int file_parse_threads(int files_in_flight) {
+    const unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    return (int)std::min<unsigned>(std::max<unsigned>(n / (unsigned)std::max(1, files_in_flight), 1), 64);
 }
 
 // split [begin, end) into ~n chunks that end right after a '\n'

@@ -61,11 +61,11 @@ inline bool calc_lq_single_ids(const uint8_t* s, int len, bool hasPolyA, int see
 }
 
 // FASTA: 2 lines per read; FASTQ: 4 lines per read (SingleRead.h:38-50, SingleReadQ.h:38-56)
-inline ReadFile parse_read_file(const std::string& path, bool fastq, bool hasPolyA, int seedLen) {
+inline ReadFile parse_read_file(const std::string& path, bool fastq, bool hasPolyA, int seedLen, int threads = 0) {
     MappedFile f;
     if (!f.open(path)) die("Cannot open %s! It may not exist.", path.c_str());
     const int L = fastq ? 4 : 2;
-    const int nt = f.size > (32u << 20) ? hardware_threads() : 1;
+    const int nt = f.size > (32u << 20) ? (threads > 0 ? threads : hardware_threads()) : 1;
     std::vector<size_t> cut = line_chunks(f.data, 0, f.size, nt);
     const int nc = (int)cut.size() - 1;
     // phase of every chunk = (#lines before it) mod L
@@ -104,6 +104,13 @@ inline ReadFile parse_read_file(const std::string& path, bool fastq, bool hasPol
             return true;
         };
         const char *b, *le;
+        {   // the pieces never regrow: a record is header + bases (+ '+' + as many qualities), so bases <= bytes / 2 (FASTQ)
+            const size_t chunk = cut[c + 1] - cut[c];
+            P.seq.reserve(fastq ? chunk / 2 + 64 : chunk);
+            if (fastq) P.qual.reserve(chunk / 2 + 64);
+            P.lens.reserve(chunk / 32 + 16);
+            P.lq.reserve(chunk / 32 + 16);
+        }
         while (line % L != 0 && p < e) next(b, le);  // skip the tail of a record owned by the previous chunk
         while (p < e) {
             if (!next(b, le)) break;
@@ -175,7 +182,7 @@ struct DatData {  // imd.dat (HitContainer.h:63-91, SingleHit.h:44-51, PairedEnd
     Arr<int32_t> sid_signed, pos, insertL;
 };
 
-inline DatData load_dat(const std::string& path, int expect_read_type) {
+inline DatData load_dat(const std::string& path, int expect_read_type, int threads = 0) {
     MappedFile f;
     if (!f.open(path)) die("Cannot open %s! It may not exist.", path.c_str());
     DatData D;
@@ -188,7 +195,7 @@ inline DatData load_dat(const std::string& path, int expect_read_type) {
     const bool pe = D.read_type >= 2;
     const char* nl = (const char*)memchr(p, '\n', end - p);
     size_t body = nl ? (size_t)(nl - f.data) + 1 : f.size;
-    const int nt = f.size > (32u << 20) ? hardware_threads() : 1;
+    const int nt = f.size > (32u << 20) ? (threads > 0 ? threads : hardware_threads()) : 1;
     std::vector<size_t> cut = line_chunks(f.data, body, f.size, nt);
     const int nc = (int)cut.size() - 1;
     struct Part { std::vector<uint32_t> lens; std::vector<int32_t> sid, pos, ins; };
@@ -197,6 +204,13 @@ inline DatData load_dat(const std::string& path, int expect_read_type) {
         Part& P = parts[ci];
         const char* q = f.data + cut[ci];
         const char* e = f.data + cut[ci + 1];
+        {   // never regrow: an alignment is at least " s p" (4 characters; 6 with the insert length), a read at least "1 s p\n"
+            const size_t chunk = cut[ci + 1] - cut[ci];
+            P.sid.reserve(chunk / (pe ? 6 : 4) + 16);
+            P.pos.reserve(chunk / (pe ? 6 : 4) + 16);
+            if (pe) P.ins.reserve(chunk / 6 + 16);
+            P.lens.reserve(chunk / 6 + 16);
+        }
         while (q < e) {
             const char* le = (const char*)memchr(q, '\n', e - q);
             if (!le) le = e;

@@ -360,8 +360,31 @@ int main(int argc, char* argv[]) {
     const bool binary_in = rsb_present(imdName);
     DatData dat;
     ReadSetFiles rs;
+    const uint64_t Ncat[3] = {N0, N1, N2};
+    // Text inputs: imd.dat and the read files of every category are independent, so they are parsed at the same time, each
+    // by its share of the host threads (at BASELINE configs[2] that is 30 GB of text: 7.7 GB of .dat, 2 x 11 GB of
+    // alignable mates, 2 x 0.6 GB of unalignable ones).
+    std::thread reads_parser;
+    Joiner reads_joiner{reads_parser};
     if (binary_in) load_rsb(imdName, read_type, refs.has_polyA, P.seedLen, dat, rs);
-    else dat = load_dat(imdName + ".dat", read_type);
+    else {
+        struct Job { int tag, m; std::string path; };
+        std::vector<Job> jobs;
+        for (int tag = 0; tag < 3; tag++) {
+            if (Ncat[tag] == 0) continue;
+            std::vector<std::string> names = read_file_names(imdName, tag, read_type);
+            for (size_t m = 0; m < names.size(); m++) jobs.push_back(Job{tag, (int)m, names[m]});
+            rs.present[tag] = true;
+        }
+        const int share = file_parse_threads((int)jobs.size() + 1);
+        reads_parser = std::thread([&, jobs, share]() {
+            std::vector<std::thread> th;
+            for (const Job& J : jobs)
+                th.emplace_back([&, J]() { rs.mate[J.tag][J.m] = parse_read_file(J.path, hasQ, refs.has_polyA, P.seedLen, share); });
+            for (auto& t : th) t.join();
+        });
+        dat = load_dat(imdName + ".dat", read_type, share);
+    }
     if (dat.N1 != N1) die("Number of alignable reads does not match!");
     lap(binary_in ? "map .rsb" : "parse .dat");
     // the EM context (CSR upload, device-side sort into the sliced layout) only needs the hits: build it while the
@@ -432,20 +455,15 @@ int main(int argc, char* argv[]) {
         });
     });
     Joiner em_joiner{em_builder};
-    const uint64_t Ncat[3] = {N0, N1, N2};
+    if (reads_parser.joinable()) reads_parser.join();
     for (int tag = 0; tag < 3; tag++) {
         if (Ncat[tag] == 0) continue;
-        if (binary_in) {
-            if (rs.mate[tag][0].n != Ncat[tag]) die("%s.rsb holds %llu reads of category %d, %s.cnt says %llu!", imdName.c_str(),
-                                                    (unsigned long long)rs.mate[tag][0].n, tag, statName.c_str(), (unsigned long long)Ncat[tag]);
-            if (verbose) printf("estimateFromReads, N%d finished.\n", tag);
-            continue;
+        if (rs.mate[tag][0].n != Ncat[tag]) {
+            if (binary_in) die("%s.rsb holds %llu reads of category %d, %s.cnt says %llu!", imdName.c_str(), (unsigned long long)rs.mate[tag][0].n, tag,
+                               statName.c_str(), (unsigned long long)Ncat[tag]);
+            die("%s holds %llu reads, %s.cnt says %llu!", read_file_names(imdName, tag, read_type)[0].c_str(), (unsigned long long)rs.mate[tag][0].n,
+                statName.c_str(), (unsigned long long)Ncat[tag]);
         }
-        std::vector<std::string> names = read_file_names(imdName, tag, read_type);
-        for (size_t m = 0; m < names.size(); m++) rs.mate[tag][m] = parse_read_file(names[m], hasQ, refs.has_polyA, P.seedLen);
-        rs.present[tag] = true;
-        if (rs.mate[tag][0].n != Ncat[tag]) die("%s holds %llu reads, %s.cnt says %llu!", names[0].c_str(),
-                                                (unsigned long long)rs.mate[tag][0].n, statName.c_str(), (unsigned long long)Ncat[tag]);
         if (verbose) printf("estimateFromReads, N%d finished.\n", tag);
     }
     lap("parse read files");
@@ -522,6 +540,19 @@ int main(int argc, char* argv[]) {
     }
     lap("device contexts + upload");
     if (verbose) printf("EM_init finished!\n");
+    // Everything the device needs is in HBM now.  The parsed reads, alignment coordinates and packed references (tens of
+    // GB at BASELINE sizes) go back to the system on a helper thread while the GPU works, instead of at exit, where
+    // unmapping them was seconds of wall clock with nothing else left to do.  Kept: row_ptr and the transcript ids
+    // (.ofg / BAM output).
+    std::thread releaser([&]() {
+        for (int tag = 0; tag < 3; tag++)
+            for (int m = 0; m < 2; m++) rs.mate[tag][m] = ReadFile();
+        dat.pos.release(); dat.insertL.release(); dat.sid_signed.release();
+        std::vector<uint8_t>().swap(ref_seq);
+        std::vector<uint32_t>().swap(mask_words);
+        std::vector<uint8_t>().swap(lq);
+    });
+    Joiner release_joiner{releaser};
 
     // ---- EM (EM.cpp:343-416) ---------------------------------------------------------------------------
     std::vector<double> theta(M + 1, 0.0), theta_new(M + 1, 0.0), counts(M + 1, 0.0);
