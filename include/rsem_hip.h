@@ -36,6 +36,8 @@ typedef enum {
 const char* rsem_hip_strerror(int status);
 const char* rsem_hip_last_error(void);
 int rsem_hip_device_count(int* n);
+/* Properties of a device the host programs size their decisions by: key = "compute_units" | "clock_khz" | "hbm_bytes". */
+int rsem_hip_device_info(int device, const char* key, int64_t* value);
 /* Initialise the HIP runtime and the device context (callable from a helper thread while inputs are parsed). */
 int rsem_hip_warmup(int device);
 /* ABI version of this header: bumped on any signature change. */

@@ -58,6 +58,7 @@ def lib():
         L.rsem_hip_strerror.argtypes = [ci]
         L.rsem_hip_last_error.restype = C.c_char_p
         L.rsem_hip_device_count.argtypes = [C.POINTER(ci)]
+        L.rsem_hip_device_info.argtypes = [ci, C.c_char_p, C.POINTER(C.c_int64)]
         L.rsem_hip_abi_version.restype = ci
         if L.rsem_hip_abi_version() != ABI_VERSION:  # the ctypes structures below mirror ONE layout of include/rsem_hip.h
             raise ImportError("%s speaks ABI %d, rsem_amd/capi.py expects %d: rebuild it (`python -m rsem_amd.build --force`)"

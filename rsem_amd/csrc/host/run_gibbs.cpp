@@ -148,22 +148,37 @@ int main(int argc, char* argv[]) {
     // of a GPU advancing together; parallel = the data-augmentation sampler for the same posterior (every sweep fills
     // the GPU; the chains of a GPU run one after the other).
     int mode;
-    // auto (the default): the reference's own chains (exact) unless they would take more than kAutoExactLimitS here -- a chain
-    // is a workgroup and costs about kExactUsPerVisit per read visit whatever the number of chains (up to one per CU;
-    // DESIGN.md section 5), so the estimate is rounds x reads x that.  The choice is printed and recorded in
-    // <statName>.gibbs_sampler; --gibbs-mode exact / parallel overrule it.
-    constexpr double kExactUsPerVisit = 0.09, kAutoExactLimitS = 1800.0;
+    // auto (the default): the reference's own chains (exact) unless they would take more than kAutoExactLimitS here.  A chain
+    // is a workgroup and costs about kExactCyclesPerVisit shader cycles per read visit whatever the number of chains, up to
+    // one per compute unit (0.085 us at BASELINE configs[2]'s shape on a 2.4 GHz MI355X); clock and
+    // compute units are the device's own (rsem_hip_device_info), so the estimate is rounds x reads x cycles / clock x
+    // ceil(chains per GPU / CUs).  The choice is printed and recorded in <statName>.gibbs_sampler; --gibbs-mode exact /
+    // parallel overrule it.  Above the limit the DEFAULT outputs are therefore not the reference's chains (same posterior,
+    // a different Markov chain): INTEGRATION.md says so, and so does the program, on stdout and stderr.
+    constexpr double kExactCyclesPerVisit = 216.0, kAutoExactLimitS = 900.0;
+    int64_t dev_cus = 256, dev_khz = 2400000;
+    if (!dry_run) {
+        (void)rsem_hip_device_info(devs[0], "compute_units", &dev_cus);
+        (void)rsem_hip_device_info(devs[0], "clock_khz", &dev_khz);
+        if (dev_cus < 1) dev_cus = 256;
+        if (dev_khz < 100000) dev_khz = 2400000;
+    }
     const int rounds_per_chain = BURNIN + 1 + ((NSAMPLES + nThreads - 1) / nThreads - 1) * GAP;
     const int chains_per_gpu = (nThreads + nworkers - 1) / nworkers;
-    const double est_exact_s = (double)rounds_per_chain * (double)N1 * kExactUsPerVisit * 1e-6 * (double)((chains_per_gpu + 255) / 256);
+    const double us_per_visit = kExactCyclesPerVisit / ((double)dev_khz * 1e-3);
+    const double est_exact_s = (double)rounds_per_chain * (double)N1 * us_per_visit * 1e-6 * (double)((chains_per_gpu + dev_cus - 1) / dev_cus);
     if (mode_s == "exact") mode = RSEM_GIBBS_EXACT;
     else if (mode_s == "parallel") mode = RSEM_GIBBS_PARALLEL;
     else if (mode_s == "auto") {
         mode = est_exact_s <= kAutoExactLimitS ? RSEM_GIBBS_EXACT : RSEM_GIBBS_PARALLEL;
-        if (mode == RSEM_GIBBS_PARALLEL)
+        if (mode == RSEM_GIBBS_PARALLEL) {
             fprintf(stderr, "rsem-run-gibbs: the reference's chains would take about %.0f s here (%d rounds x %llu reads); using the data-augmentation "
                             "sampler for the same posterior instead (--gibbs-mode exact forces the reference's chains)\n",
                     est_exact_s, rounds_per_chain, (unsigned long long)N1);
+            if (verbose)
+                printf("Gibbs sampler: data-augmentation (auto: the reference's own chains were estimated at %.0f s, limit %.0f s; "
+                       "--gibbs-mode exact forces them)\n", est_exact_s, kAutoExactLimitS);
+        }
     } else die("rsem-run-gibbs: unknown --gibbs-mode '%s' (exact, parallel or auto)", mode_s.c_str());
     if (!dry_run) {
         if (FILE* fs = fopen((statName + ".gibbs_sampler").c_str(), "w")) {

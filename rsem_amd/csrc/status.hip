@@ -1,4 +1,5 @@
 // status.hip -- error strings, device probing (C ABI: include/rsem_hip.h).
+#include <cstring>
 #include <cstdarg>
 
 #include "common.hpp"
@@ -63,6 +64,20 @@ const char* rsem_hip_strerror(int status) {
 const char* rsem_hip_last_error(void) { return rsem::g_last_error; }
 
 int rsem_hip_abi_version(void) { return 3; }
+
+int rsem_hip_device_info(int device, const char* key, int64_t* value) {
+    if (!key || !value) return RSEM_ERR_INVALID;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return RSEM_ERR_NODEVICE;
+    }
+    if (!strcmp(key, "compute_units")) *value = p.multiProcessorCount;
+    else if (!strcmp(key, "clock_khz")) *value = p.clockRate;
+    else if (!strcmp(key, "hbm_bytes")) *value = (int64_t)p.totalGlobalMem;
+    else { rsem::set_last_error("unknown device info key '%s'", key); return RSEM_ERR_INVALID; }
+    return RSEM_OK;
+}
 
 int rsem_hip_device_count(int* n) {
     if (!n) return RSEM_ERR_INVALID;
