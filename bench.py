@@ -182,6 +182,21 @@ def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True):
                                 "extrapolation": "reference(full) = %.2f x (startup + rounds 1-11 measured above) + (%d - 11) rounds x %.2f x %.2f ms"
                                                  % (scale, new_rounds, scale, per_round * 1e3),
                                 "speedup_extrapolated": ref_full / new_wall}
+            try:  # the reference itself on these very files (same generator, same seed), measured once in round 4: profiles/
+                with open(os.path.join(ROOT, "profiles", "e2e_full_size_reference.json")) as f:
+                    mref = json.load(f)
+                if config == "C3" and fh == 560141751:
+                    r = mref["reference"]
+                    e2e["full_size"].update({
+                        "reference_s": r["wall_s_measured"], "reference_rounds": r["rounds"], "reference_measured_in": mref["source"],
+                        "reference_conditions": r["conditions"],
+                        "reference_s_undisturbed": r["wall_s_if_all_late_rounds_at_the_undisturbed_rate"],
+                        "same_round_count_as_the_reference": new_rounds == r["rounds"],
+                        "speedup": r["wall_s_measured"] / new_wall,
+                        "speedup_against_undisturbed_reference": r["wall_s_if_all_late_rounds_at_the_undisturbed_rate"] / new_wall,
+                        "parity_full_size_recorded": mref["parity_full_size"]})
+            except Exception:
+                pass
         return cpu, e2e
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -631,9 +646,9 @@ def main():
                 line["speedup_vs_cpu_baseline_rounds"] = line["value"] / cb["value"]
                 if e2e is not None:
                     line["e2e_wall_clock"] = e2e
-            try:  # an earlier round's builder-run record of the same comparison (tools/e2e_c3.sh), for reference only
-                with open(os.path.join(ROOT, "profiles", "e2e_wall_clock.json")) as f:
-                    line["e2e_wall_clock_recorded_round2"] = json.load(f)
+            try:  # the builder-run record of both programs at FULL size (tools/gpu_r04a.sh), for reference
+                with open(os.path.join(ROOT, "profiles", "e2e_full_size_reference.json")) as f:
+                    line["e2e_full_size_recorded_round4"] = json.load(f)
             except Exception:
                 pass
         os.write(json_fd, (json.dumps(line) + "\n").encode())

@@ -229,6 +229,13 @@ int rsem_model_calc_conprb(rsem_model_ctx* ctx);
 int rsem_model_estep_update(rsem_model_ctx* ctx, const double* theta, double N0, double* counts,
                             double* theta_new, double* sum, double* bChange, int32_t* totNum,
                             rsem_model_accum* acc);
+/* One whole model round (EM.cpp:199-236 with needCalcConPrb = true; updateModel = (acc != NULL)) in ONE pass over the
+ * reads: P(read, alignment | transcript) from the tables last set (SingleQModel.h:101-162, PairedEndQModel.h:94-155 and
+ * twins), the posterior weights for `theta` (EM.cpp:227,234) and, when `acc` is given, the model's sufficient statistics
+ * (SingleQModel.h:168-221, PairedEndQModel.h:161-188); outputs as rsem_em_step.  Equivalent to rsem_model_calc_conprb
+ * followed by rsem_model_estep_update (acc != NULL) or rsem_em_step (acc == NULL). */
+int rsem_model_round(rsem_model_ctx* ctx, const double* theta, double N0, double* counts, double* theta_new,
+                     double* sum, double* bChange, int32_t* totNum, rsem_model_accum* acc /* NULL: no statistics */);
 /* current CSR values back to the host in file order (for imd.ofg, EM.cpp:421-457) */
 int rsem_model_get_values(rsem_model_ctx* ctx, double* conprb, double* ncp);
 int rsem_model_destroy(rsem_model_ctx* ctx);

@@ -24,7 +24,7 @@ class RsemHipError(RuntimeError):
         self.status = status
 
 
-ABI_VERSION = 3  # rsem_hip_abi_version() of the include/rsem_hip.h these bindings were written against
+ABI_VERSION = 4  # rsem_hip_abi_version() of the include/rsem_hip.h these bindings were written against
 
 
 class CiProfile(C.Structure):

@@ -575,28 +575,28 @@ int main(int argc, char* argv[]) {
         rsem_model_tables t = tables_of(model);
         each_shard([&](Shard& X, int k) {
             X.rc = RSEM_OK;
-            if (calc) {
-                X.rc = rsem_model_set_tables(X.mc, &t);
-                if (X.rc == RSEM_OK) X.rc = rsem_model_calc_conprb(X.mc);
-            }
+            if (calc) X.rc = rsem_model_set_tables(X.mc, &t);
             if (X.rc != RSEM_OK) { X.err = rsem_hip_last_error(); return; }
             // one shard: the device M step is the round's M step; several: raw counts (N0 = 0), reduced below
             double* cts = S == 1 ? counts.data() : s_counts[k].data();
             double s1 = 0.0, b1 = 0.0;
             int32_t t1 = 0;
+            rsem_model_accum a;
             if (updateModel) {
                 Model::Accum& A = S == 1 ? acc : s_acc[k];
-                rsem_model_accum a;
                 a.prof = A.prof.data(); a.noise = A.noise.data(); a.rspd = A.rspd.data(); a.gld = A.gld.data();
                 a.gld0_lb = P.minL - 1; a.gld0_ub = P.maxL;
-                X.rc = rsem_model_estep_update(X.mc, theta.data(), S == 1 ? (double)N0 : 0.0, cts, S == 1 ? theta_new.data() : nullptr, &s1, &b1, &t1, &a);
-            } else {
-                X.rc = rsem_em_step(X.em, theta.data(), S == 1 ? (double)N0 : 0.0, cts, S == 1 ? theta_new.data() : nullptr, &s1, &b1, &t1);
             }
+            const double n0 = S == 1 ? (double)N0 : 0.0;
+            double* thn = S == 1 ? theta_new.data() : nullptr;
+            if (calc)  // the whole round in one pass over the reads: probabilities, weights, statistics (rsem_model_round)
+                X.rc = rsem_model_round(X.mc, theta.data(), n0, cts, thn, &s1, &b1, &t1, updateModel ? &a : nullptr);
+            else if (updateModel) X.rc = rsem_model_estep_update(X.mc, theta.data(), n0, cts, thn, &s1, &b1, &t1, &a);
+            else X.rc = rsem_em_step(X.em, theta.data(), n0, cts, thn, &s1, &b1, &t1);
             if (X.rc != RSEM_OK) { X.err = rsem_hip_last_error(); return; }
             if (S == 1) { sum = s1; bChange = b1; totNum = t1; }
         });
-        check_shards(updateModel ? "rsem_model_estep_update" : "rsem_em_step");
+        check_shards(calc ? "rsem_model_round" : (updateModel ? "rsem_model_estep_update" : "rsem_em_step"));
         model.needCalcConPrb = false;  // EM.cpp:383
         if (S > 1) {
             for (int j = 0; j <= M; j++) {

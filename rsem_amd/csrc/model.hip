@@ -27,73 +27,9 @@ namespace {
 
 using rsem::kEpsilon;
 constexpr int kBlk = 256;
-constexpr int kProfLds = 5120;  // doubles of the profile table kept in LDS by k_update (Q: 2500; no-Q: 204 positions)
-constexpr int kGldLds = 1024;
-constexpr int kRspdLds = 128;
-constexpr int kNoiseLds = 512;
 
-struct DevTables {  // device copies of rsem_model_tables
-    double probF;
-    int seedLen, estRSPD, B;
-    const double *rspd_pdf, *rspd_cdf;
-    int gld_lb, gld_ub;
-    const double *gld_pdf, *gld_cdf;
-    int has_mld, mld_lb, mld_ub;
-    const double *mld_pdf, *mld_cdf;
-    int prof_rows;
-    const double* prof;
-    const double* noise;
-    const double* mw;
-};
-
-struct DevData {
-    int model_type, M;
-    uint64_t N1, nnz;
-    const uint64_t* row_ptr;
-    const uint32_t* hit_row;
-    const int32_t* sid_signed;
-    const int32_t* pos;
-    const int32_t* insertL;
-    // reads, packed 8 base ids (or qualities) per 64-bit word, every read starting on a word boundary
-    const uint64_t* roff8[2];   // [N1+1] first word of read i
-    const int32_t* rlen[2];     // [N1]
-    const uint64_t* rseq_w[2];
-    const uint64_t* rqual_w[2];
-    const uint8_t* lq;
-    // both strands of every transcript as base ids (strand 1 = reverse complement), word-aligned starts
-    const uint64_t* soff;       // [2*(M+1)] byte offset of strand dir of transcript sid: soff[2*sid + dir]
-    const uint64_t* refw;
-    const int32_t* fullLen;
-    const int32_t* totLen;
-    const uint64_t* mask_off;
-    const uint32_t* mask_words;
-    // per alignment: bit 0 / bit 1 = the reference window of mate 1 / mate 2 holds the same bases as the window of the
-    // read's PREVIOUS alignment (computed once at create: the windows never change); 0 for a read's first alignment
-    const uint8_t* same_prev;
-};
-
-// LenDist::getAdjustedProb (LenDist.h:63-68)
-__device__ inline double ld_adj(const double* pdf, const double* cdf, int lb, int ub, int len, int refL) {
-    if (len <= lb || len > ub || refL <= lb) return 0.0;
-    return pdf[len - lb] / cdf[min(ub, refL) - lb];
-}
-// RSPD::evalCDF / getAdjustedProb (RSPD.h:63-75)
-__device__ inline double rspd_cdf_at(const DevTables& T, int fpos, int fullLen) {
-    int i = (int)(((long long)fpos) * T.B / fullLen);
-    double val = fpos * 1.0 / fullLen * T.B;
-    return T.rspd_cdf[i] + (val - i) * T.rspd_pdf[i + 1];
-}
-__device__ inline double rspd_adj(const DevTables& T, int fpos, int effL, int fullLen) {
-    if (!T.estRSPD) return 1.0 / effL;
-    double denom = rspd_cdf_at(T, effL, fullLen);
-    return denom >= kEpsilon ? (rspd_cdf_at(T, fpos + 1, fullLen) - rspd_cdf_at(T, fpos, fullLen)) / denom : 0.0;
-}
-// RefSeq::get_id (RefSeq.h:84-87) is a table look-up here: both strands are stored, so the base ids of strand
-// positions p..p+7 are eight consecutive bytes.  load8() fetches them from the word-aligned array.
-__device__ inline uint64_t funnel8(uint64_t w0, uint64_t w1, int sh) { return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0; }
-__device__ inline bool ref_mask(const DevData& D, int sid, int p) {  // RefSeq.h:89-92
-    return (D.mask_words[D.mask_off[sid] + (p >> 5)] >> (p & 31)) & 1u;
-}
+// tables, data views, the scalar pieces of getConPrb / update, and the group-per-read body of the model rounds' kernel
+#include "model_block.hpp"
 
 // (Q)Profile::getProb (QProfile.h:111-120, Profile.h:114-120): product over the read, 8 bases per step
 // (three 8-byte loads instead of 24 byte loads; the factors are multiplied in read order, padding multiplies by 1).
@@ -387,38 +323,8 @@ __global__ __launch_bounds__(kBlk) void k_noise(DevData D, DevTables T, double* 
 
 // ---- sufficient statistics (updateModel rounds) ----------------------------------------------------
 
-struct AccumPtrs {
-    double* prof;   // [prof_rows*25]
-    double* noise;  // [100*5] or [5]
-    double* rspd;   // [B+2]
-    double* gld;    // [span0+1]
-    int gld0_lb, gld0_ub;
-};
-
-// The LDS side is spelled as an LDS operation: left as a generic pointer, the two branches can be merged into one flat
-// atomic on a selected address, which this compiler then fails to encode (and which would be slower anyway).
-__device__ inline void lds_add_f64(double* p, double v) {
-    (void)__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)p, v);
-}
-__device__ inline void add_tbl(double* lds, int cap, double* glob, int idx, double v) {
-    if (idx < cap) lds_add_f64(&lds[idx], v);
-    else unsafeAtomicAdd(&glob[idx], v);
-}
-
-// RSPD::update (RSPD.h:43-59)
-__device__ inline void rspd_update(double* lds, double* glob, int B, int fpos, int fullLen, double frac) {
-    if (fpos >= fullLen) return;
-    int i;
-    double a = fpos * 1.0 / fullLen, b;
-    for (i = (int)(((long long)fpos) * B / fullLen + 1); i < (int)((((long long)fpos + 1) * B - 1) / fullLen + 1); i++) {
-        b = i * 1.0 / B;
-        add_tbl(lds, kRspdLds, glob, i, (b - a) * fullLen * frac);
-        a = b;
-    }
-    b = (fpos + 1.0) / fullLen;
-    add_tbl(lds, kRspdLds, glob, i, (b - a) * fullLen * frac);
-}
-
+// The LDS side is spelled as an LDS operation (RSEM_LDS_ADD in add_tbl): left as a generic pointer, the two branches can be
+// merged into one flat atomic on a selected address, which this compiler then fails to encode (and which would be slower).
 template <bool kQ>
 __device__ inline void profile_update(double* lds, double* glob, const uint64_t* __restrict__ rs,
                                       const uint64_t* __restrict__ rq, int len, const uint64_t* __restrict__ refw, uint64_t a,
@@ -646,6 +552,51 @@ __global__ __launch_bounds__(kBlk) void k_update_read(DevData D, DevTables T, co
             if (s_gld[i] != 0.0) unsafeAtomicAdd(&A.gld[i], s_gld[i]);
 }
 
+// The model rounds' kernel (model_block.hpp): a group of 16 lanes per read, 512 threads per workgroup (two per CU: the
+// probability and count tables take 57 KB of LDS each), persistent grid, reads dealt to the waves four at a time.
+constexpr int kGroupBlk = 512;
+#ifndef RSEM_GROUP_ATTR
+#define RSEM_GROUP_ATTR
+#endif
+template <bool kQ, bool kPE, bool kUpdate>
+__global__ __launch_bounds__(kGroupBlk) RSEM_GROUP_ATTR void k_model_group(DevData D, DevTables T, const double* __restrict__ theta, double* __restrict__ cp,
+                                                             double* __restrict__ ncp, AccumPtrs A) {
+    __shared__ double s_prob[kQ ? 2500 : 1];                 // QProfile (100 x 5 x 5); the position-indexed Profile stays in global memory
+    __shared__ double s_nprob[kQ ? 500 : 8];
+    __shared__ double s_prof[kUpdate ? (kQ ? 2500 : kProfLds) : 1];
+    __shared__ double s_noise[kUpdate ? kNoiseLds : 1];
+    __shared__ double s_rspd[kUpdate ? kRspdLds : 1];
+    __shared__ double s_gld[kUpdate ? kGldLds : 1];
+    if (kQ) for (int i = threadIdx.x; i < 2500; i += blockDim.x) s_prob[i] = T.prof[i];
+    for (int i = threadIdx.x; i < (kQ ? 500 : 5); i += blockDim.x) s_nprob[i] = T.noise[i];
+    constexpr int kProfCap = kQ ? 2500 : kProfLds;           // entries of the count table held in LDS (the rest: global atomics)
+    if (kUpdate) {
+        for (int i = threadIdx.x; i < kProfCap; i += blockDim.x) s_prof[i] = 0.0;
+        for (int i = threadIdx.x; i < kNoiseLds; i += blockDim.x) s_noise[i] = 0.0;
+        for (int i = threadIdx.x; i < kRspdLds; i += blockDim.x) s_rspd[i] = 0.0;
+        for (int i = threadIdx.x; i < kGldLds; i += blockDim.x) s_gld[i] = 0.0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint64_t waves_per_block = blockDim.x / 64, wave = (uint64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
+    model_group_rows<kQ, kPE, kUpdate>(D, T, theta, cp, ncp, A, kQ ? s_prob : T.prof, s_nprob, s_prof, s_noise, s_rspd, s_gld, wave * 4, n_waves * 4, lane);
+    if (!kUpdate) return;
+    __syncthreads();
+    const int nprof = min(kProfCap, T.prof_rows * 25);
+    for (int i = threadIdx.x; i < nprof; i += blockDim.x)
+        if (s_prof[i] != 0.0) unsafeAtomicAdd(&A.prof[i], s_prof[i]);
+    const int nnoise = kQ ? 500 : 5;
+    for (int i = threadIdx.x; i < nnoise; i += blockDim.x)
+        if (s_noise[i] != 0.0) unsafeAtomicAdd(&A.noise[i], s_noise[i]);
+    if (A.rspd)
+        for (int i = threadIdx.x; i < min(kRspdLds, T.B + 2); i += blockDim.x)
+            if (s_rspd[i] != 0.0) unsafeAtomicAdd(&A.rspd[i], s_rspd[i]);
+    if (A.gld)
+        for (int i = threadIdx.x; i < min(kGldLds, A.gld0_ub - A.gld0_lb + 1); i += blockDim.x)
+            if (s_gld[i] != 0.0) unsafeAtomicAdd(&A.gld[i], s_gld[i]);
+}
+
 __global__ void k_hit_rows(uint64_t N1, const uint64_t* __restrict__ row_ptr, uint32_t* hit_row) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N1) return;
@@ -699,6 +650,8 @@ struct rsem_model_ctx {
     int B_alloc = 0, gld_n = 0, mld_n = 0, prof_n = 0, noise_n = 0;
     std::vector<void*> owned;       // device allocations of the immutable data
     double *d_P1 = nullptr, *d_P2 = nullptr;  // profile products of the run heads (k_profile_heads), [nnz] each
+    double* d_theta = nullptr;                // the round's theta for the weights of k_model_group, [M+1]
+    int n_cus = 0;
     // table buffers (re-uploaded every round)
     double *t_rspd_pdf = nullptr, *t_rspd_cdf = nullptr, *t_gld_pdf = nullptr, *t_gld_cdf = nullptr, *t_mld_pdf = nullptr,
            *t_mld_cdf = nullptr, *t_prof = nullptr, *t_noise = nullptr, *t_mw = nullptr;
@@ -770,6 +723,38 @@ int launch_update(rsem_model_ctx* c, const AccumPtrs& A) {
     return RSEM_OK;
 }
 
+// the group-per-read kernel: conprb + noise (+ weights and statistics when theta / accumulators are given)
+bool group_kernel_selected() {
+    const char* e = getenv("RSEM_MODEL_KERNELS");
+    return !(e && (!strcmp(e, "alignment") || !strcmp(e, "read")));
+}
+template <bool kQ, bool kPE>
+int launch_group(rsem_model_ctx* c, const double* d_theta, const AccumPtrs* A) {
+    if (!c->D.N1) return RSEM_OK;
+    if (!c->n_cus) {
+        hipDeviceProp_t p;
+        RSEM_HIP_TRY(hipGetDeviceProperties(&p, c->v.device));
+        c->n_cus = std::max(1, p.multiProcessorCount);
+    }
+    const uint64_t quads = (c->D.N1 + 3) / 4;
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->n_cus * 2, (quads + kGroupBlk / 64 - 1) / (kGroupBlk / 64)));
+    if (A)
+        hipLaunchKernelGGL((k_model_group<kQ, kPE, true>), dim3(grid), dim3(kGroupBlk), 0, c->v.stream, c->D, c->T, d_theta, c->v.d_cp, c->v.d_ncp, *A);
+    else
+        hipLaunchKernelGGL((k_model_group<kQ, kPE, false>), dim3(grid), dim3(kGroupBlk), 0, c->v.stream, c->D, c->T, (const double*)nullptr, c->v.d_cp,
+                           c->v.d_ncp, AccumPtrs{nullptr, nullptr, nullptr, nullptr, 0, 0});
+    RSEM_HIP_TRY(hipGetLastError());
+    return RSEM_OK;
+}
+int launch_group_any(rsem_model_ctx* c, const double* d_theta, const AccumPtrs* A) {
+    switch (c->D.model_type) {
+        case 0: return launch_group<false, false>(c, d_theta, A);
+        case 1: return launch_group<true, false>(c, d_theta, A);
+        case 2: return launch_group<false, true>(c, d_theta, A);
+        default: return launch_group<true, true>(c, d_theta, A);
+    }
+}
+
 int resize_buf(double** p, int* cur, int n) {
     if (*p && *cur >= n) return RSEM_OK;
     if (*p) hipFree(*p);
@@ -790,7 +775,7 @@ int rsem_model_destroy(rsem_model_ctx* c) {
     hipFree(c->t_rspd_pdf); hipFree(c->t_rspd_cdf); hipFree(c->t_gld_pdf); hipFree(c->t_gld_cdf); hipFree(c->t_mld_pdf);
     hipFree(c->t_mld_cdf); hipFree(c->t_prof); hipFree(c->t_noise); hipFree(c->t_mw);
     hipFree(c->a_prof); hipFree(c->a_noise); hipFree(c->a_rspd); hipFree(c->a_gld);
-    hipFree(c->d_P1); hipFree(c->d_P2);
+    hipFree(c->d_P1); hipFree(c->d_P2); hipFree(c->d_theta);
     delete c;
     return RSEM_OK;
 }
@@ -974,6 +959,11 @@ int rsem_model_calc_conprb(rsem_model_ctx* c) {
     if (!c->have_tables) { rsem::set_last_error("model tables were never set"); return RSEM_ERR_STATE; }
     RSEM_HIP_TRY(hipSetDevice(c->v.device));
     int rc;
+    if (group_kernel_selected()) {
+        rc = launch_group_any(c, nullptr, nullptr);
+        if (rc != RSEM_OK) return rc;
+        return rsem::em_values_changed(c->em);
+    }
     switch (c->D.model_type) {
         case 0: rc = launch_conprb<false, false>(c); break;
         case 1: rc = launch_conprb<true, false>(c); break;
@@ -1018,6 +1008,59 @@ int rsem_model_estep_update(rsem_model_ctx* c, const double* theta, double N0, d
     if (c->T.estRSPD) RSEM_HIP_TRY(hipMemcpyAsync(acc->rspd, c->a_rspd, sizeof(double) * nr, hipMemcpyDeviceToHost, st));
     if (pe) RSEM_HIP_TRY(hipMemcpyAsync(acc->gld, c->a_gld, sizeof(double) * ng, hipMemcpyDeviceToHost, st));
     RSEM_HIP_TRY(hipStreamSynchronize(st));
+    return RSEM_OK;
+}
+
+// One model round in one pass over the reads (rounds 1-11 of EM.cpp:383-404): alignment probabilities with the tables last
+// set, the E step's posterior weights for `theta` and -- when `acc` is given (rounds 1-10) -- the model's statistics, all
+// by k_model_group; then the round's counts / theta / convergence numbers from the E-step kernel on the refreshed planes.
+int rsem_model_round(rsem_model_ctx* c, const double* theta, double N0, double* counts, double* theta_new, double* sum,
+                     double* bChange, int32_t* totNum, rsem_model_accum* acc) {
+    RSEM_REQUIRE(c && theta, "NULL argument");
+    if (!c->have_tables) { rsem::set_last_error("model tables were never set"); return RSEM_ERR_STATE; }
+    if (!group_kernel_selected()) {  // the older kernel families (cross-checks): the same round as two calls
+        int rc = rsem_model_calc_conprb(c);
+        if (rc != RSEM_OK) return rc;
+        if (acc) return rsem_model_estep_update(c, theta, N0, counts, theta_new, sum, bChange, totNum, acc);
+        return rsem_em_step(c->em, theta, N0, counts, theta_new, sum, bChange, totNum);
+    }
+    const bool q = c->D.model_type == 1 || c->D.model_type == 3, pe = c->D.model_type >= 2;
+    RSEM_REQUIRE(!acc || (acc->prof && acc->noise), "NULL accumulator");
+    RSEM_REQUIRE(!acc || !pe || acc->gld, "paired-end models accumulate the fragment length distribution");
+    RSEM_REQUIRE(!acc || !c->T.estRSPD || acc->rspd, "estRSPD needs the rspd accumulator");
+    RSEM_HIP_TRY(hipSetDevice(c->v.device));
+    hipStream_t st = c->v.stream;
+    int rc;
+    const size_t np = (size_t)c->T.prof_rows * 25, nn = q ? 500 : 5, nr = (size_t)c->T.B + 2;
+    const size_t ng = (acc && pe) ? (size_t)(acc->gld0_ub - acc->gld0_lb + 1) : 1;
+    if (acc) {
+        if (!c->d_theta) RSEM_HIP_TRY(dmalloc(&c->d_theta, (size_t)c->D.M + 1));
+        RSEM_HIP_TRY(hipMemcpyAsync(c->d_theta, theta, sizeof(double) * ((size_t)c->D.M + 1), hipMemcpyHostToDevice, st));
+        if (c->a_prof_n < np) { hipFree(c->a_prof); c->a_prof = nullptr; RSEM_HIP_TRY(dmalloc(&c->a_prof, np)); c->a_prof_n = np; }
+        if (!c->a_noise) RSEM_HIP_TRY(dmalloc(&c->a_noise, (size_t)500));
+        if (!c->a_rspd) RSEM_HIP_TRY(dmalloc(&c->a_rspd, std::max<size_t>(nr, 1024)));
+        if (c->a_gld_n < ng) { hipFree(c->a_gld); c->a_gld = nullptr; RSEM_HIP_TRY(dmalloc(&c->a_gld, ng)); c->a_gld_n = ng; }
+        RSEM_HIP_TRY(hipMemsetAsync(c->a_prof, 0, sizeof(double) * np, st));
+        RSEM_HIP_TRY(hipMemsetAsync(c->a_noise, 0, sizeof(double) * 500, st));
+        RSEM_HIP_TRY(hipMemsetAsync(c->a_rspd, 0, sizeof(double) * nr, st));
+        RSEM_HIP_TRY(hipMemsetAsync(c->a_gld, 0, sizeof(double) * ng, st));
+        AccumPtrs A{c->a_prof, c->a_noise, c->T.estRSPD ? c->a_rspd : nullptr, pe ? c->a_gld : nullptr, acc->gld0_lb, acc->gld0_ub};
+        rc = launch_group_any(c, c->d_theta, &A);
+    } else {
+        rc = launch_group_any(c, nullptr, nullptr);
+    }
+    if (rc != RSEM_OK) return rc;
+    rc = rsem::em_values_changed(c->em);
+    if (rc != RSEM_OK) return rc;
+    rc = rsem_em_step(c->em, theta, N0, counts, theta_new, sum, bChange, totNum);
+    if (rc != RSEM_OK) return rc;
+    if (acc) {
+        RSEM_HIP_TRY(hipMemcpyAsync(acc->prof, c->a_prof, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+        RSEM_HIP_TRY(hipMemcpyAsync(acc->noise, c->a_noise, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
+        if (c->T.estRSPD) RSEM_HIP_TRY(hipMemcpyAsync(acc->rspd, c->a_rspd, sizeof(double) * nr, hipMemcpyDeviceToHost, st));
+        if (pe) RSEM_HIP_TRY(hipMemcpyAsync(acc->gld, c->a_gld, sizeof(double) * ng, hipMemcpyDeviceToHost, st));
+        RSEM_HIP_TRY(hipStreamSynchronize(st));
+    }
     return RSEM_OK;
 }
 

@@ -63,7 +63,7 @@ const char* rsem_hip_strerror(int status) {
 
 const char* rsem_hip_last_error(void) { return rsem::g_last_error; }
 
-int rsem_hip_abi_version(void) { return 3; }
+int rsem_hip_abi_version(void) { return 4; }
 
 int rsem_hip_device_info(int device, const char* key, int64_t* value) {
     if (!key || !value) return RSEM_ERR_INVALID;
