@@ -816,6 +816,7 @@ struct rsem_em_ctx {
     unsigned long long* d_trace = nullptr;  // per-workgroup timestamps (tune_unit_order, rsem_em_debug_trace)
     std::vector<Unit> h_units;
     uint64_t long_nnz = 0;  // alignments of the reads left in the CSR
+    uint32_t* d_rank = nullptr;  // caller row -> sorted row (inverse of L.d_order), built on first use (em_planes_view)
     uint32_t n_far_units = 0;               // units with an id outside their LDS window (Unit::pad[0])
     unsigned long long n_stray_reads = 0;   // reads the second layout pass sorted apart (sell_build_refined)
     int tune_passes_left = 1;               // measured-lifetime reordering of the units, done on first use
@@ -956,6 +957,8 @@ int fill_values(rsem_em_ctx* c) {
 
 void free_layout(rsem_em_ctx* c) {
     sell_free(c->L);
+    hipFree(c->d_rank);
+    c->d_rank = nullptr;
     hipFree(c->d_sval); hipFree(c->d_sncp); hipFree(c->d_sexp); hipFree(c->d_fill_err); hipFree(c->d_units); hipFree(c->d_noise_a);
     c->d_sval = nullptr; c->d_sncp = nullptr; c->d_sexp = nullptr; c->d_fill_err = nullptr; c->d_units = nullptr; c->d_noise_a = nullptr;
     c->h_units.clear();
@@ -1623,6 +1626,37 @@ int em_device_view(rsem_em_ctx* c, EmDeviceView* v) {
     v->d_ncp = c->d_ncp;
     v->d_w = c->d_w;
     v->d_wn = c->d_wn;
+    return RSEM_OK;
+}
+
+__global__ void k_invert_order(uint64_t n, const uint32_t* __restrict__ order, uint32_t* rank) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) rank[order[p]] = (uint32_t)p;
+}
+
+int em_planes_view(rsem_em_ctx* c, EmPlanesView* v) {
+    RSEM_REQUIRE(c && v, "NULL argument");
+    if (!c->layout_ok || c->layout_has_q32 || c->value_bits == 32) { set_last_error("the layout holds Q32 planes"); return RSEM_ERR_STATE; }
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_rank && c->N1) {
+        RSEM_HIP_TRY(dmalloc(&c->d_rank, (size_t)c->N1));
+        hipLaunchKernelGGL(k_invert_order, dim3(ceil_div(c->N1, kBlock)), dim3(kBlock), 0, c->stream, c->N1, (const uint32_t*)c->L.d_order, c->d_rank);
+        RSEM_HIP_TRY(hipGetLastError());
+    }
+    v->d_rank = c->d_rank;
+    v->d_shapes = c->L.d_shapes;
+    v->n_shapes = c->L.n_shapes;
+    v->T = c->L.T;
+    v->n_sell_rows = c->L.n_sell_rows;
+    v->d_sval = c->d_sval;
+    v->d_sncp = c->d_sncp;
+    return RSEM_OK;
+}
+
+int em_values_written_in_place(rsem_em_ctx* c) {
+    RSEM_REQUIRE(c, "NULL argument");
+    if (!c->layout_ok || c->layout_has_q32) { set_last_error("the layout cannot have been written in place"); return RSEM_ERR_STATE; }
+    c->have_values = true;
     return RSEM_OK;
 }
 

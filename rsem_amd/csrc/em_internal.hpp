@@ -17,10 +17,25 @@ struct EmDeviceView {
     double* d_wn;
 };
 
+// Where the hot-loop layout keeps the values of caller row i, for a producer that writes them in place (model.hip's round
+// kernel).  shapes points at the device copy of the layout's Shape table (sell_shape.hpp).
+struct EmPlanesView {
+    const uint32_t* d_rank;  // caller row -> sorted row
+    const void* d_shapes;
+    int n_shapes;
+    uint32_t T, n_sell_rows;
+    unsigned char* d_sval;
+    double* d_sncp;
+};
+
 // device pointers of the ctx (allocates the weight buffers on first use)
 int em_device_view(rsem_em_ctx* c, EmDeviceView* v);
 // d_cp / d_ncp were rewritten on the device: rebuild the sliced value planes
 int em_values_changed(rsem_em_ctx* c);
+// The planes of the current layout, for in-place writers.  RSEM_ERR_STATE when the layout cannot take doubles in place (Q32
+// shapes) -- the caller then falls back to em_values_changed.  After writing d_cp / d_ncp AND the planes:
+int em_planes_view(rsem_em_ctx* c, EmPlanesView* v);
+int em_values_written_in_place(rsem_em_ctx* c);
 // E step with posterior write-back into d_w / d_wn (EM.cpp:199-244, calcExpectedWeights-style) followed by the M
 // step; host outputs as rsem_em_step.  The weights stay on the device for the model accumulation kernels.
 int em_step_with_weights(rsem_em_ctx* c, const double* theta, double N0, double* counts, double* theta_new,

@@ -29,6 +29,7 @@ using rsem::kEpsilon;
 constexpr int kBlk = 256;
 
 // tables, data views, the scalar pieces of getConPrb / update, and the group-per-read body of the model rounds' kernel
+#include "sell_shape.hpp"
 #include "model_block.hpp"
 
 // (Q)Profile::getProb (QProfile.h:111-120, Profile.h:114-120): product over the read, 8 bases per step
@@ -560,7 +561,7 @@ constexpr int kGroupBlk = 512;
 #endif
 template <bool kQ, bool kPE, bool kUpdate>
 __global__ __launch_bounds__(kGroupBlk) RSEM_GROUP_ATTR void k_model_group(DevData D, DevTables T, const double* __restrict__ theta, double* __restrict__ cp,
-                                                             double* __restrict__ ncp, AccumPtrs A) {
+                                                             double* __restrict__ ncp, AccumPtrs A, PlaneOut PO) {
     __shared__ double s_prob[kQ ? 2500 : 1];                 // QProfile (100 x 5 x 5); the position-indexed Profile stays in global memory
     __shared__ double s_nprob[kQ ? 500 : 8];
     __shared__ double s_prof[kUpdate ? (kQ ? 2500 : kProfLds) : 1];
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(kGroupBlk) RSEM_GROUP_ATTR void k_model_group(DevDa
     const int lane = threadIdx.x & 63;
     const uint64_t waves_per_block = blockDim.x / 64, wave = (uint64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
-    model_group_rows<kQ, kPE, kUpdate>(D, T, theta, cp, ncp, A, kQ ? s_prob : T.prof, s_nprob, s_prof, s_noise, s_rspd, s_gld, wave * 4, n_waves * 4, lane);
+    model_group_rows<kQ, kPE, kUpdate>(D, T, theta, cp, ncp, A, kQ ? s_prob : T.prof, s_nprob, s_prof, s_noise, s_rspd, s_gld, wave * 4, n_waves * 4, lane, PO);
     if (!kUpdate) return;
     __syncthreads();
     const int nprof = min(kProfCap, T.prof_rows * 25);
@@ -729,7 +730,7 @@ bool group_kernel_selected() {
     return !(e && (!strcmp(e, "alignment") || !strcmp(e, "read")));
 }
 template <bool kQ, bool kPE>
-int launch_group(rsem_model_ctx* c, const double* d_theta, const AccumPtrs* A) {
+int launch_group(rsem_model_ctx* c, const double* d_theta, const AccumPtrs* A, const PlaneOut& PO) {
     if (!c->D.N1) return RSEM_OK;
     if (!c->n_cus) {
         hipDeviceProp_t p;
@@ -739,20 +740,30 @@ int launch_group(rsem_model_ctx* c, const double* d_theta, const AccumPtrs* A) {
     const uint64_t quads = (c->D.N1 + 3) / 4;
     const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->n_cus * 2, (quads + kGroupBlk / 64 - 1) / (kGroupBlk / 64)));
     if (A)
-        hipLaunchKernelGGL((k_model_group<kQ, kPE, true>), dim3(grid), dim3(kGroupBlk), 0, c->v.stream, c->D, c->T, d_theta, c->v.d_cp, c->v.d_ncp, *A);
+        hipLaunchKernelGGL((k_model_group<kQ, kPE, true>), dim3(grid), dim3(kGroupBlk), 0, c->v.stream, c->D, c->T, d_theta, c->v.d_cp, c->v.d_ncp, *A, PO);
     else
         hipLaunchKernelGGL((k_model_group<kQ, kPE, false>), dim3(grid), dim3(kGroupBlk), 0, c->v.stream, c->D, c->T, (const double*)nullptr, c->v.d_cp,
-                           c->v.d_ncp, AccumPtrs{nullptr, nullptr, nullptr, nullptr, 0, 0});
+                           c->v.d_ncp, AccumPtrs{nullptr, nullptr, nullptr, nullptr, 0, 0}, PO);
     RSEM_HIP_TRY(hipGetLastError());
     return RSEM_OK;
 }
+// The round kernel, then the EM context's planes: written in place by the kernel where the layout takes doubles (the
+// default), else (Q32 planes, RSEM_MODEL_PLANES=0) refreshed from the CSR by the scatter pass.
 int launch_group_any(rsem_model_ctx* c, const double* d_theta, const AccumPtrs* A) {
+    PlaneOut PO{nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
+    rsem::EmPlanesView pv;
+    const char* e = getenv("RSEM_MODEL_PLANES");
+    const bool in_place = !(e && !strcmp(e, "0")) && rsem::em_planes_view(c->em, &pv) == RSEM_OK;
+    if (in_place) PO = PlaneOut{pv.d_rank, (const Shape*)pv.d_shapes, pv.n_shapes, pv.T, pv.n_sell_rows, pv.d_sval, pv.d_sncp};
+    int rc;
     switch (c->D.model_type) {
-        case 0: return launch_group<false, false>(c, d_theta, A);
-        case 1: return launch_group<true, false>(c, d_theta, A);
-        case 2: return launch_group<false, true>(c, d_theta, A);
-        default: return launch_group<true, true>(c, d_theta, A);
+        case 0: rc = launch_group<false, false>(c, d_theta, A, PO); break;
+        case 1: rc = launch_group<true, false>(c, d_theta, A, PO); break;
+        case 2: rc = launch_group<false, true>(c, d_theta, A, PO); break;
+        default: rc = launch_group<true, true>(c, d_theta, A, PO); break;
     }
+    if (rc != RSEM_OK) return rc;
+    return in_place ? rsem::em_values_written_in_place(c->em) : rsem::em_values_changed(c->em);
 }
 
 int resize_buf(double** p, int* cur, int n) {
@@ -960,9 +971,7 @@ int rsem_model_calc_conprb(rsem_model_ctx* c) {
     RSEM_HIP_TRY(hipSetDevice(c->v.device));
     int rc;
     if (group_kernel_selected()) {
-        rc = launch_group_any(c, nullptr, nullptr);
-        if (rc != RSEM_OK) return rc;
-        return rsem::em_values_changed(c->em);
+        return launch_group_any(c, nullptr, nullptr);
     }
     switch (c->D.model_type) {
         case 0: rc = launch_conprb<false, false>(c); break;
@@ -1049,8 +1058,6 @@ int rsem_model_round(rsem_model_ctx* c, const double* theta, double N0, double* 
     } else {
         rc = launch_group_any(c, nullptr, nullptr);
     }
-    if (rc != RSEM_OK) return rc;
-    rc = rsem::em_values_changed(c->em);
     if (rc != RSEM_OK) return rc;
     rc = rsem_em_step(c->em, theta, N0, counts, theta_new, sum, bChange, totNum);
     if (rc != RSEM_OK) return rc;

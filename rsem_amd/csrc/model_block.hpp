@@ -74,6 +74,19 @@ struct DevData {
     const uint8_t* same_prev;
 };
 
+// Where the sliced layout of the EM context (sell_layout.hpp) keeps the values of a read: with this the round kernel writes
+// every alignment probability straight into its value plane (and the noise probability into its row slot) instead of
+// leaving that to a scatter pass over the CSR (k_fill_sell: thread per read, 17.5 ms per round at configs[2]).  F64 planes
+// only (the model rounds run before the planes are switched to Q32); reads with > 256 alignments live in the CSR alone.
+struct PlaneOut {
+    const uint32_t* rank;   // caller row -> sorted row (inverse of SellLayout::d_order); nullptr: no plane output
+    const Shape* shapes;
+    int n_shapes;
+    uint32_t T, n_sell_rows;
+    unsigned char* sval;
+    double* sncp;
+};
+
 struct AccumPtrs {
     double* prof;   // [prof_rows*25]
     double* noise;  // [100*5] or [5]
@@ -295,7 +308,8 @@ RSEM_DEVFN double alignment_prob(const DevData& D, const DevTables& T, const Chu
 template <bool kQ, bool kPE, bool kUpdate>
 RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const double* __restrict__ theta, double* __restrict__ cp,
                                  double* __restrict__ ncp, const AccumPtrs& A, const double* prob, const double* nprob, double* s_prof,
-                                 double* s_noise, double* s_rspd, double* s_gld, uint64_t row0, uint64_t row_stride, int lane) {
+                                 double* s_noise, double* s_rspd, double* s_gld, uint64_t row0, uint64_t row_stride, int lane,
+                                 const PlaneOut& PO) {
     const int g = lane & (kGrp - 1);
     const int g0 = lane & ~(kGrp - 1);  // first lane of my group
     constexpr int kMates = kPE ? 2 : 1;
@@ -319,6 +333,26 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
             W[m].q0 = (kQ && mine) ? W[m].qual[g] : 0;
         }
         const int len1 = W[0].len, len2 = kPE ? W[kMates - 1].len : 0;
+        // the read's place in the sliced layout: alignment c goes to plane c >> lg of its slice, lane r * G + (c & (G - 1))
+        double* plane = nullptr;
+        int p_lg = 0;
+        uint32_t p_r = 0;
+        if (PO.rank && valid) {
+            const uint32_t ps = PO.rank[row];
+            if (ps < PO.n_sell_rows) {
+                int sh = 0;
+                while (sh + 1 < PO.n_shapes && ps >= PO.shapes[sh + 1].row_base) ++sh;
+                const Shape S = PO.shapes[sh];
+                uint32_t slice_local;
+                row_to_slot(S, PO.T, ps - S.row_base, slice_local, p_r);
+                plane = (double*)(PO.sval + S.val_base) + (uint64_t)slice_local * S.K * 64;
+                p_lg = S.lg;
+                p_r = (p_r << p_lg);  // first lane of the read within a plane row
+            }
+        }
+        auto plane_put = [&](int c_idx, double v) {
+            if (plane) plane[(uint64_t)(c_idx >> p_lg) * 64 + p_r + (uint32_t)(c_idx & ((1 << p_lg) - 1))] = v;
+        };
 
         // per-chunk state carried from one chunk of a long read to the next: the window and product of the run that was open
         // at the end of the chunk
@@ -343,7 +377,7 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
             R.a[0] = R.has ? D.soff[2 * R.sid + R.dir] + (uint64_t)R.pos : 0;
             if (kPE) R.a[kMates - 1] = R.has ? D.soff[2 * R.sid + (R.dir ^ 1)] + (uint64_t)(R.totLen - R.pos - R.insertL) : 0;
             R.cp = 0.0;
-            if (in && !R.has) cp[j] = 0.0;  // low-quality read: every alignment gets probability 0 (SingleQModel.h:102)
+            if (in && !R.has) { cp[j] = 0.0; plane_put(idx, 0.0); }  // low-quality read: every alignment gets probability 0 (SingleQModel.h:102)
         };
         // Runs of one mate within a chunk.  heads: bit i = lane i of the group starts a run here (its window differs from its
         // predecessor's, or it is lane 0 of a later chunk, where the run open at the end of the previous chunk continues:
@@ -398,6 +432,7 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
             if (R.has) {
                 R.cp = alignment_prob<kPE>(D, T, R, len1, len2, pp[0], kPE ? pp[kMates - 1] : 1.0);
                 cp[fr + (uint64_t)(c * kGrp + g)] = R.cp;
+                plane_put(c * kGrp + g, R.cp);
             }
             if (kUpdate) {
                 double f = R.has ? theta[R.sid] * R.cp : 0.0;
@@ -420,7 +455,18 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
             if (pr < kEpsilon) pr = 0.0;
             nval = (T.mw[0] < kEpsilon) ? 0.0 : pr / T.mw[0];
             if (!active) nval = 0.0;
-            if (valid && g == 0) ncp[row] = nval;
+            if (valid && g == 0) {
+                ncp[row] = nval;
+                if (plane) {
+                    const uint32_t ps = PO.rank[row];
+                    int sh = 0;
+                    while (sh + 1 < PO.n_shapes && ps >= PO.shapes[sh + 1].row_base) ++sh;
+                    const Shape S = PO.shapes[sh];
+                    uint32_t slice_local, r;
+                    row_to_slot(S, PO.T, ps - S.row_base, slice_local, r);
+                    PO.sncp[S.slot_base + slice_local * shape_R(S) + r] = nval;
+                }
+            }
         }
         if (!kUpdate) continue;
 

@@ -30,6 +30,8 @@
 
 namespace {
 
+#include "sell_shape.hpp"
+
 constexpr int kShapesPerFmt = 28;   // (lg 0..6) x (K 1..4)
 constexpr int kShapeBits = 6;
 constexpr int kMaxShapes = 2 * kShapesPerFmt;  // F64 shapes, then Q32 shapes
@@ -37,24 +39,8 @@ constexpr int kShapeIds = 1 << kShapeBits;
 constexpr int kLongShape = kShapeIds - 1;      // rows with more than 256 alignments: CSR kernel
 constexpr uint32_t kKeyMinSidCap = (1u << (31 - kShapeBits)) - 1;  // sort key: shape | apart bit | anchor sid (capped) | hash of the tuple
 constexpr int kKeyApartBit = 63 - kShapeBits;
-constexpr int kFmtF64 = 0, kFmtQ32 = 1;
 constexpr int kMaxK = 4;
 constexpr int kBlock = 256;         // 4 waves
-
-struct Shape {
-    uint64_t plane_base;  // first plane of this shape (one plane = 64 entries)
-    uint32_t slice_base;  // first slice
-    uint32_t n_slices;
-    uint32_t row_base;    // first sorted row
-    uint32_t n_rows;
-    uint32_t slot_base;   // first row slot (slot = slice * rows_per_slice + r)
-    int32_t K;            // planes per slice
-    int32_t lg;           // log2(lanes per read)
-    int32_t fmt;          // kFmtF64 / kFmtQ32
-    uint64_t val_base;    // byte offset of this shape's value planes (512 B per F64 plane, 256 B per Q32 plane)
-};
-
-__host__ __device__ inline uint32_t plane_bytes(int fmt) { return fmt == kFmtQ32 ? 256u : 512u; }
 
 // ---- Q32 quantisation rule (one read) ----------------------------------------------------------
 // mx = the read's largest value.  Returns false when the read must stay F64: no positive value, a non-zero value
@@ -73,14 +59,6 @@ __host__ __device__ inline uint32_t q32_mantissa(double v, int e) {
     return m >= 4294967295.0 ? 0xffffffffu : (uint32_t)m;
 }
 
-__host__ __device__ inline int shape_G(const Shape& S) {  // lanes per read
-    return 1 << S.lg;
-}
-__host__ __device__ inline uint32_t shape_R(const Shape& S) {  // reads per slice
-    return 64u >> S.lg;
-}
-
-
 __host__ __device__ inline int shape_id_of(uint64_t L) {
     if (L <= 4) return (int)(L == 0 ? 0 : L - 1);  // lg = 0, K = L
     int lg = 1;
@@ -89,17 +67,6 @@ __host__ __device__ inline int shape_id_of(uint64_t L) {
     if (lg > 6) return kLongShape;
     int K = (int)((L + (1u << lg) - 1) >> lg);  // 3 or 4
     return lg * 4 + (K - 1);
-}
-
-// sorted read q of a shape  ->  (slice within the shape, row slot within the slice)
-__host__ __device__ inline void row_to_slot(const Shape& S, uint32_t T, uint32_t q, uint32_t& slice_local, uint32_t& r) {
-    const uint32_t R = shape_R(S), rpb = R * T;
-    const uint32_t b = q / rpb, qb = q % rpb;
-    const uint32_t left = S.n_rows - b * rpb;
-    const uint32_t nb = left < rpb ? left : rpb;
-    const uint32_t Tb = (nb + R - 1) / R;
-    r = qb / Tb;
-    slice_local = b * T + qb % Tb;
 }
 
 // ... and back: (slice within the shape, row slot within the slice) -> sorted read q of the shape.  false: the slot is empty

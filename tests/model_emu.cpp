@@ -24,6 +24,7 @@ struct Job {
     const double* theta;
     double *cp, *ncp;
     AccumPtrs A;
+    PlaneOut PO;
     bool q, pe, update;
     int n_blocks, block;
     // "LDS"
@@ -48,7 +49,7 @@ static void lane_body(Job* J, int tid) {
     const int lane = tid & 63;
     const uint64_t wave = (uint64_t)J->block * 4 + (uint64_t)(tid >> 6), n_waves = (uint64_t)J->n_blocks * 4;
     model_group_rows<kQ, kPE, kUpdate>(J->D, J->T, J->theta, J->cp, J->ncp, J->A, kQ ? J->s_prob : J->T.prof, J->s_nprob, J->s_prof, J->s_noise,
-                                       J->s_rspd, J->s_gld, wave * 4, n_waves * 4, lane);
+                                       J->s_rspd, J->s_gld, wave * 4, n_waves * 4, lane, J->PO);
     if (!kUpdate) return;
     RSEM_SYNC();
     const int nprof = std::min(kQ ? 2500 : kProfLds, J->T.prof_rows * 25);
@@ -139,7 +140,7 @@ int main(int argc, char** argv) {
         const int len1 = irand(minLen, maxLen), len2 = irand(minLen, maxLen);
         const int insert = pe ? irand(std::max(len1, len2), std::min(std::max(len1, len2) + 150, 380)) : len1;
         const int dir = (int)(rng() & 1);
-        const int p0 = irand(0, 400 - insert - 1);  // all family members are >= 400 long
+        const int p0 = irand(0, 400 - insert - 3);  // all family members are >= 400 long; alignments are shifted by up to 2
         const int nal = (i % 17 == 0) ? irand(17, 40) : irand(1, 12);  // some reads take several 16-alignment chunks
         lq[i] = (i % 23 == 5) ? 1 : 0;
         for (int k = 0; k < nal; k++) {
@@ -315,17 +316,39 @@ int main(int argc, char** argv) {
         printf("%-22s n=%zu max rel diff %.3g%s\n", what, a.size(), worst, worst > tol ? "   <-- MISMATCH" : "");
         if (worst > tol) { printf("   at %zu: %.17g vs %.17g\n", at, a[at], b[at]); ++bad; }
     };
+    // the EM context's sliced layout of these reads (simt_emu.hpp builds it with sell_layout.hpp's own helpers): the kernel
+    // writes the values in place, and must leave exactly what the scatter pass (sell_fill_row) makes of its CSR output
+    std::vector<int32_t> sid_abs(nnz);
+    for (uint64_t j = 0; j < nnz; j++) sid_abs[j] = std::abs(sid_signed[j]);
+    HostLayout H;
+    H.T = 3;
+    build_layout(H, M, N1, row_ptr.data(), sid_abs.data(), nullptr, nullptr, 0, false, 0);
+    std::vector<uint32_t> rank(N1);
+    for (uint64_t p = 0; p < N1; p++) rank[H.order[p]] = (uint32_t)p;
     for (int update = 0; update < 2; update++) {
+        std::vector<unsigned char> sval(H.sval.size(), 0);
+        std::vector<double> sncp(H.sncp.size(), 0.0);
         std::vector<double> cp(nnz, -1.0), ncp(N1, -1.0), aprof(prof.size(), 0.0), anoise(noise.size(), 0.0), arspd(B + 2, 0.0), agld(rgld.size(), 0.0);
         Job* J = new Job();
         pthread_barrier_init(&J->blk.bar, nullptr, 256);
         for (int w = 0; w < 4; w++) pthread_barrier_init(&J->blk.w[w].bar, nullptr, 64);
         J->D = D; J->T = T; J->theta = theta.data(); J->cp = cp.data(); J->ncp = ncp.data();
         J->A = AccumPtrs{aprof.data(), anoise.data(), estRSPD ? arspd.data() : nullptr, pe ? agld.data() : nullptr, gld0_lb, gld0_ub};
+        J->PO = PlaneOut{rank.data(), H.shapes.data(), (int)H.shapes.size(), H.T, (uint32_t)N1, sval.data(), sncp.data()};
         J->q = q; J->pe = pe; J->update = update != 0;
         J->n_blocks = 3;
         for (J->block = 0; J->block < J->n_blocks; J->block++) run_block(J);
         delete J;
+        {   // planes written in place == the scatter pass over the kernel's own CSR output, bit for bit
+            std::vector<unsigned char> want(H.sval.size(), 0);
+            std::vector<double> wncp(H.sncp.size(), 0.0);
+            for (const Shape& S : H.shapes)
+                for (uint32_t qq = 0; qq < S.n_rows; qq++)
+                    sell_fill_row<false>(S, H.T, S.row_base + qq, H.order.data(), row_ptr.data(), nullptr, cp.data(), ncp.data(), nullptr, want.data(), wncp.data(), nullptr, nullptr);
+            const bool same = !memcmp(want.data(), sval.data(), want.size()) && !memcmp(wncp.data(), sncp.data(), wncp.size() * 8);
+            printf("%-22s %zu bytes of value planes, %zu row slots: %s\n", "planes in place", want.size(), wncp.size(), same ? "identical" : "DIFFERENT   <-- MISMATCH");
+            if (!same) ++bad;
+        }
         cmp(update ? "conprb (update pass)" : "conprb", cp, rcp, 1e-12);
         cmp(update ? "noise conprb (update)" : "noise conprb", ncp, rncp, 1e-12);
         if (update) {
