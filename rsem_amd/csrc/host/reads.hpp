@@ -60,20 +60,40 @@ inline bool calc_lq_single_ids(const uint8_t* s, int len, bool hasPolyA, int see
     return false;
 }
 
-// FASTA: 2 lines per read; FASTQ: 4 lines per read (SingleRead.h:38-50, SingleReadQ.h:38-56)
+// FASTA: 2 lines per read; FASTQ: 4 lines per read (SingleRead.h:38-50, SingleReadQ.h:38-56).
+// Three parallel scans of the mapped text, nothing in between: (0) newlines per chunk, which gives every chunk's phase
+// within the 2 / 4-line records, and the chunk boundaries are moved to record starts; (1) records and bases per chunk,
+// which gives every chunk its place in the final arrays; (2) the bases, qualities, lengths and low-quality flags are
+// written straight to those places.  (Until round 4 every chunk collected its reads in vectors of its own that were
+// then copied into place: at BASELINE configs[2] 22 GB of intermediate 4 KB pages, first-touched by 64 threads of one
+// address space -- the page faults, not the parsing, set the time.)
+inline void prefault_text(const char* p, size_t n) {
+#ifdef MADV_POPULATE_READ
+    static const bool on = !getenv("RSEM_HIP_NO_PREFAULT");
+    if (on && n >= ((size_t)1 << 20)) {
+        const uintptr_t a = (uintptr_t)p & ~(uintptr_t)4095;
+        (void)madvise((void*)a, (size_t)((uintptr_t)p + n - a), MADV_POPULATE_READ);  // page tables of the chunk in one call
+    }
+#else
+    (void)p; (void)n;
+#endif
+}
+
 inline ReadFile parse_read_file(const std::string& path, bool fastq, bool hasPolyA, int seedLen, int threads = 0) {
     MappedFile f;
     if (!f.open(path)) die("Cannot open %s! It may not exist.", path.c_str());
     const int L = fastq ? 4 : 2;
     const int nt = f.size > (32u << 20) ? (threads > 0 ? threads : hardware_threads()) : 1;
     std::vector<size_t> cut = line_chunks(f.data, 0, f.size, nt);
-    const int nc = (int)cut.size() - 1;
-    // phase of every chunk = (#lines before it) mod L
+    int nc = (int)cut.size() - 1;
+    const char* fend = f.data + f.size;
+    // scan 0: lines per chunk
     std::vector<uint64_t> nl(nc, 0);
     parallel_for(nc, [&](int c) {
         uint64_t k = 0;
         const char* p = f.data + cut[c];
         const char* e = f.data + cut[c + 1];
+        prefault_text(p, (size_t)(e - p));
         while (p < e) {
             const char* q = (const char*)memchr(p, '\n', e - p);
             if (!q) { ++k; break; }  // last line without a newline
@@ -82,82 +102,95 @@ inline ReadFile parse_read_file(const std::string& path, bool fastq, bool hasPol
         }
         nl[c] = k;
     });
-    std::vector<uint64_t> first_line(nc + 1, 0);
-    for (int c = 0; c < nc; c++) first_line[c + 1] = first_line[c] + nl[c];
-    struct Part { std::vector<uint32_t> lens; std::vector<uint8_t> seq, qual, lq; };
-    std::vector<Part> parts(nc);
-    const int8_t* tbl = base_table();
-    const char* fend = f.data + f.size;
+    // chunk boundaries -> record starts (a chunk that starts in the middle of a record gives its head to the chunk before)
+    {
+        uint64_t line = 0;
+        for (int c = 0; c < nc; c++) {
+            const uint64_t first = line;
+            line += nl[c];
+            if (c == 0) continue;
+            size_t q = cut[c];
+            for (uint64_t k = first; k % L != 0 && q < f.size; k++) {
+                const char* e2 = (const char*)memchr(f.data + q, '\n', f.size - q);
+                q = e2 ? (size_t)(e2 - f.data) + 1 : f.size;
+            }
+            cut[c] = std::min(q, f.size);
+        }
+        for (int c = 1; c <= nc; c++) cut[c] = std::max(cut[c], cut[c - 1]);  // (a chunk shorter than a record becomes empty)
+    }
+    auto next_line = [&](const char*& p, const char*& b, const char*& le) -> bool {
+        if (p >= fend) return false;
+        b = p;
+        const char* q = (const char*)memchr(p, '\n', fend - p);
+        le = q ? q : fend;
+        p = q ? q + 1 : fend;
+        if (le > b && le[-1] == '\r') --le;
+        return true;
+    };
+    // scan 1: records and bases per chunk
+    std::vector<uint64_t> nrec(nc, 0), nbase(nc, 0);
     parallel_for(nc, [&](int c) {
-        Part& P = parts[c];
         const char* p = f.data + cut[c];
         const char* e = f.data + cut[c + 1];
-        uint64_t line = first_line[c];
-        auto next = [&](const char*& b, const char*& le) -> bool {  // may run past e to finish a record
-            if (p >= fend) return false;
-            b = p;
-            const char* q = (const char*)memchr(p, '\n', fend - p);
-            le = q ? q : fend;
-            p = q ? q + 1 : fend;
-            ++line;
-            if (le > b && le[-1] == '\r') --le;
-            return true;
-        };
         const char *b, *le;
-        {   // the pieces never regrow: a record is header + bases (+ '+' + as many qualities), so bases <= bytes / 2 (FASTQ)
-            const size_t chunk = cut[c + 1] - cut[c];
-            P.seq.reserve(fastq ? chunk / 2 + 64 : chunk);
-            if (fastq) P.qual.reserve(chunk / 2 + 64);
-            P.lens.reserve(chunk / 32 + 16);
-            P.lq.reserve(chunk / 32 + 16);
-        }
-        while (line % L != 0 && p < e) next(b, le);  // skip the tail of a record owned by the previous chunk
+        uint64_t r = 0, nb = 0;
         while (p < e) {
-            if (!next(b, le)) break;
+            if (!next_line(p, b, le)) break;
             if (b == le) continue;  // stray empty line at the end
             if (*b != (fastq ? '@' : '>')) die("Read file %s does not look like a %s file!", path.c_str(), fastq ? "FASTQ" : "FASTA");
-            if (!next(b, le)) die("%s: truncated record", path.c_str());
-            const int len = (int)(le - b);
-            const size_t o = P.seq.size();
-            P.seq.resize(o + len);
-            for (int i = 0; i < len; i++) {
-                int8_t id = tbl[(unsigned char)b[i]];
-                if (id < 0) die("Found unknown sequence letter %c at function get_base_id!", b[i]);
-                P.seq[o + i] = (uint8_t)id;
-            }
-            P.lq.push_back(calc_lq_single(b, len, hasPolyA, seedLen) ? 1 : 0);
-            P.lens.push_back((uint32_t)len);
+            if (!next_line(p, b, le)) die("%s: truncated record", path.c_str());
+            nb += (uint64_t)(le - b);
+            ++r;
             if (fastq) {
-                if (!next(b, le) || b == le || *b != '+') die("Read file %s does not look like a FASTQ file!", path.c_str());
-                if (!next(b, le)) die("%s: truncated record", path.c_str());
-                if ((int)(le - b) != len) die("%s: quality string and sequence differ in length", path.c_str());
-                P.qual.resize(o + len);
-                for (int i = 0; i < len; i++) {
-                    int qv = (unsigned char)b[i] - 33;  // c2q (QProfile.h:44)
-                    if (qv < 0 || qv > 93) die("%s: quality character out of range", path.c_str());
-                    P.qual[o + i] = (uint8_t)qv;
-                }
+                if (!next_line(p, b, le) || b == le || *b != '+') die("Read file %s does not look like a FASTQ file!", path.c_str());
+                if (!next_line(p, b, le)) die("%s: truncated record", path.c_str());
             }
         }
+        nrec[c] = r; nbase[c] = nb;
     });
-    // the chunks' pieces go to their final places in parallel
     ReadFile R;
     std::vector<uint64_t> r0(nc + 1, 0), b0(nc + 1, 0);
-    for (int c = 0; c < nc; c++) { r0[c + 1] = r0[c] + parts[c].lens.size(); b0[c + 1] = b0[c] + parts[c].seq.size(); }
+    for (int c = 0; c < nc; c++) { r0[c + 1] = r0[c] + nrec[c]; b0[c + 1] = b0[c] + nbase[c]; }
     R.n = r0[nc];
     uint64_t* off = R.off.alloc(R.n + 1);
     uint8_t* seq = R.seq.alloc(b0[nc]);
     uint8_t* qual = fastq ? R.qual.alloc(b0[nc]) : nullptr;
     R.lq1.resize(R.n);
     off[R.n] = b0[nc];
+    const int8_t* tbl = base_table();
+    // scan 2: straight into place
     parallel_for(nc, [&](int c) {
-        Part& P = parts[c];
-        uint64_t o = b0[c];
-        for (size_t i = 0; i < P.lens.size(); i++) { off[r0[c] + i] = o; o += P.lens[i]; }
-        if (!P.seq.empty()) memcpy(seq + b0[c], P.seq.data(), P.seq.size());
-        if (fastq && !P.qual.empty()) memcpy(qual + b0[c], P.qual.data(), P.qual.size());
-        if (!P.lq.empty()) memcpy(R.lq1.data() + r0[c], P.lq.data(), P.lq.size());
-        P = Part();
+        const char* p = f.data + cut[c];
+        const char* e = f.data + cut[c + 1];
+        const char *b, *le;
+        uint64_t r = r0[c], o = b0[c];
+        while (p < e) {
+            if (!next_line(p, b, le)) break;
+            if (b == le) continue;
+            if (!next_line(p, b, le)) break;
+            const int len = (int)(le - b);
+            off[r] = o;
+            uint8_t* sq = seq + o;
+            for (int i = 0; i < len; i++) {
+                int8_t id = tbl[(unsigned char)b[i]];
+                if (id < 0) die("Found unknown sequence letter %c at function get_base_id!", b[i]);
+                sq[i] = (uint8_t)id;
+            }
+            R.lq1[r] = calc_lq_single(b, len, hasPolyA, seedLen) ? 1 : 0;
+            if (fastq) {
+                next_line(p, b, le);
+                if (!next_line(p, b, le)) break;
+                if ((int)(le - b) != len) die("%s: quality string and sequence differ in length", path.c_str());
+                uint8_t* ql = qual + o;
+                for (int i = 0; i < len; i++) {
+                    int qv = (unsigned char)b[i] - 33;  // c2q (QProfile.h:44)
+                    if (qv < 0 || qv > 93) die("%s: quality character out of range", path.c_str());
+                    ql[i] = (uint8_t)qv;
+                }
+            }
+            o += (uint64_t)len;
+            ++r;
+        }
     });
     return R;
 }
@@ -198,55 +231,56 @@ inline DatData load_dat(const std::string& path, int expect_read_type, int threa
     const int nt = f.size > (32u << 20) ? (threads > 0 ? threads : hardware_threads()) : 1;
     std::vector<size_t> cut = line_chunks(f.data, body, f.size, nt);
     const int nc = (int)cut.size() - 1;
-    struct Part { std::vector<uint32_t> lens; std::vector<int32_t> sid, pos, ins; };
-    std::vector<Part> parts(nc);
+    // scan 1: reads and alignments per chunk (the first number of every line); scan 2: the numbers, straight into place
+    // (no per-chunk vectors in between: see parse_read_file)
+    std::vector<uint64_t> nrow(nc, 0), nhit(nc, 0);
     parallel_for(nc, [&](int ci) {
-        Part& P = parts[ci];
         const char* q = f.data + cut[ci];
         const char* e = f.data + cut[ci + 1];
-        {   // never regrow: an alignment is at least " s p" (4 characters; 6 with the insert length), a read at least "1 s p\n"
-            const size_t chunk = cut[ci + 1] - cut[ci];
-            P.sid.reserve(chunk / (pe ? 6 : 4) + 16);
-            P.pos.reserve(chunk / (pe ? 6 : 4) + 16);
-            if (pe) P.ins.reserve(chunk / 6 + 16);
-            P.lens.reserve(chunk / 6 + 16);
-        }
+        prefault_text(q, (size_t)(e - q));
+        uint64_t r = 0, h = 0;
         while (q < e) {
             const char* le = (const char*)memchr(q, '\n', e - q);
             if (!le) le = e;
             long long k;
             if (parse_long(q, le, k)) {
                 if (k <= 0) die("%s: a read without alignments", path.c_str());
-                for (long long t = 0; t < k; t++) {
-                    long long s, ps, il = 0;
-                    if (!parse_long(q, le, s) || !parse_long(q, le, ps) || (pe && !parse_long(q, le, il)))
-                        die("Cannot read alignments from .dat file!");
-                    P.sid.push_back((int32_t)s);
-                    P.pos.push_back((int32_t)ps);
-                    if (pe) P.ins.push_back((int32_t)il);
-                }
-                P.lens.push_back((uint32_t)k);
+                ++r;
+                h += (uint64_t)k;
             }
             q = le + 1;
         }
+        nrow[ci] = r; nhit[ci] = h;
     });
     std::vector<uint64_t> r0(nc + 1, 0), h0(nc + 1, 0);
-    for (int c = 0; c < nc; c++) { r0[c + 1] = r0[c] + parts[c].lens.size(); h0[c + 1] = h0[c] + parts[c].sid.size(); }
+    for (int c = 0; c < nc; c++) { r0[c + 1] = r0[c] + nrow[c]; h0[c + 1] = h0[c] + nhit[c]; }
     uint64_t* rp = D.row_ptr.alloc(r0[nc] + 1);
     int32_t* sidp = D.sid_signed.alloc(h0[nc]);
     int32_t* posp = D.pos.alloc(h0[nc]);
     int32_t* insp = pe ? D.insertL.alloc(h0[nc]) : nullptr;
     rp[r0[nc]] = h0[nc];
-    parallel_for(nc, [&](int c) {
-        Part& P = parts[c];
-        uint64_t o = h0[c];
-        for (size_t i = 0; i < P.lens.size(); i++) { rp[r0[c] + i] = o; o += P.lens[i]; }
-        if (!P.sid.empty()) {
-            memcpy(sidp + h0[c], P.sid.data(), sizeof(int32_t) * P.sid.size());
-            memcpy(posp + h0[c], P.pos.data(), sizeof(int32_t) * P.pos.size());
-            if (pe) memcpy(insp + h0[c], P.ins.data(), sizeof(int32_t) * P.ins.size());
+    parallel_for(nc, [&](int ci) {
+        const char* q = f.data + cut[ci];
+        const char* e = f.data + cut[ci + 1];
+        uint64_t r = r0[ci], o = h0[ci];
+        while (q < e) {
+            const char* le = (const char*)memchr(q, '\n', e - q);
+            if (!le) le = e;
+            long long k;
+            if (parse_long(q, le, k)) {
+                rp[r++] = o;
+                for (long long t = 0; t < k; t++) {
+                    long long sv, ps, il = 0;
+                    if (!parse_long(q, le, sv) || !parse_long(q, le, ps) || (pe && !parse_long(q, le, il)))
+                        die("Cannot read alignments from .dat file!");
+                    sidp[o] = (int32_t)sv;
+                    posp[o] = (int32_t)ps;
+                    if (pe) insp[o] = (int32_t)il;
+                    ++o;
+                }
+            }
+            q = le + 1;
         }
-        P = Part();
     });
     if (D.row_ptr.size() - 1 != D.N1) die("Number of alignable reads does not match!");
     return D;

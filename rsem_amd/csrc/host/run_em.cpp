@@ -540,19 +540,6 @@ int main(int argc, char* argv[]) {
     }
     lap("device contexts + upload");
     if (verbose) printf("EM_init finished!\n");
-    // Everything the device needs is in HBM now.  The parsed reads, alignment coordinates and packed references (tens of
-    // GB at BASELINE sizes) go back to the system on a helper thread while the GPU works, instead of at exit, where
-    // unmapping them was seconds of wall clock with nothing else left to do.  Kept: row_ptr and the transcript ids
-    // (.ofg / BAM output).
-    std::thread releaser([&]() {
-        for (int tag = 0; tag < 3; tag++)
-            for (int m = 0; m < 2; m++) rs.mate[tag][m] = ReadFile();
-        dat.pos.release(); dat.insertL.release(); dat.sid_signed.release();
-        std::vector<uint8_t>().swap(ref_seq);
-        std::vector<uint32_t>().swap(mask_words);
-        std::vector<uint8_t>().swap(lq);
-    });
-    Joiner release_joiner{releaser};
 
     // ---- EM (EM.cpp:343-416) ---------------------------------------------------------------------------
     std::vector<double> theta(M + 1, 0.0), theta_new(M + 1, 0.0), counts(M + 1, 0.0);
@@ -630,6 +617,20 @@ int main(int argc, char* argv[]) {
         if (ROUND >= 11 && !model.needCalcConPrb) break;  // the CSR values are frozen from here on
     } while (ROUND < MIN_ROUND || (totNum > 0 && ROUND < MAX_ROUND));
     lap("rounds 1-11 (model rounds)");
+    // Everything the device needs has long been in HBM.  The parsed reads, alignment coordinates and packed references (tens
+    // of GB at BASELINE sizes) go back to the system on a helper thread while the device loop runs -- the host only polls a
+    // pinned mirror then -- instead of at exit, where unmapping them was 3 s of wall clock with nothing else left to do.
+    // (Not during the model rounds: unmapping takes the address space's lock, and every call of those rounds that touches
+    // memory waited for it -- 1.8 s over 11 rounds at configs[2].)  Kept: row_ptr and the transcript ids (.ofg / BAM output).
+    std::thread releaser([&]() {
+        for (int tag = 0; tag < 3; tag++)
+            for (int m = 0; m < 2; m++) rs.mate[tag][m] = ReadFile();
+        dat.pos.release(); dat.insertL.release(); dat.sid_signed.release();
+        std::vector<uint8_t>().swap(ref_seq);
+        std::vector<uint32_t>().swap(mask_words);
+        std::vector<uint8_t>().swap(lq);
+    });
+    Joiner release_joiner{releaser};
     if (ROUND < MIN_ROUND || (totNum > 0 && ROUND < MAX_ROUND)) {
         const int round0 = ROUND;
         std::vector<std::vector<double>> s_theta(S, theta);

@@ -556,8 +556,11 @@ __global__ __launch_bounds__(kBlk) void k_update_read(DevData D, DevTables T, co
 // The model rounds' kernel (model_block.hpp): a group of 16 lanes per read, 512 threads per workgroup (two per CU: the
 // probability and count tables take 57 KB of LDS each), persistent grid, reads dealt to the waves four at a time.
 constexpr int kGroupBlk = 512;
+// 4 waves per SIMD (<= 128 VGPRs, a few dwords of scratch in the variants with the update) instead of the 2-3 the
+// allocator would settle for: 14.1 against 17.1 ms per round at a fifth of configs[2] (profiles/r04b_call.log) -- the kernel
+// waits on dependent loads, and the fourth wave hides more of them than the spills cost.
 #ifndef RSEM_GROUP_ATTR
-#define RSEM_GROUP_ATTR
+#define RSEM_GROUP_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
 template <bool kQ, bool kPE, bool kUpdate>
 __global__ __launch_bounds__(kGroupBlk) RSEM_GROUP_ATTR void k_model_group(DevData D, DevTables T, const double* __restrict__ theta, double* __restrict__ cp,

@@ -33,7 +33,8 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.rsem_hip_abi_version() == 3
+    from rsem_amd import capi
+    assert lib.rsem_hip_abi_version() == capi.ABI_VERSION == 4
     assert lib.rsem_hip_strerror(0) == b"ok"
     assert b"gfx950" in lib.rsem_hip_strerror(-4)
 
