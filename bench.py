@@ -33,7 +33,8 @@ WORKLOADS = {"C2R": "configs[1]'s size with NO gene structure (every read hits r
              "C2": "BASELINE configs[1] (SingleQModel-shaped)", "C3": "BASELINE configs[2] (PairedEndQModel-shaped, the north-star target config)",
              "C5": "BASELINE configs[4] (multi-mapping stress: > 2^32 alignments in one context)",
              "C3X": "configs[2] with cross-gene multi-mappers: 10 % of the reads also hit 1-3 transcripts of another gene (between C3, where no read "
-                    "leaves its gene, and C2R)"}
+                    "leaves its gene, and C2R)",
+             "C3X30": "configs[2] with 30 % cross-gene multi-mappers"}
 
 
 def log(*a):
@@ -313,6 +314,14 @@ def pmc_traffic_of(key, scale=1.0, kernel=0):
     return None, None
 
 
+def split_info(ctx):
+    """Reads laid out as an in-window row plus far entries (sell_layout.hpp split rows): counts, for the leg's record."""
+    try:
+        return {"reads": ctx.info("split_rows"), "far_entries": ctx.info("far_entries")}
+    except Exception:
+        return None
+
+
 def far_units(ctx):
     """Units of the hot-loop layout with an id outside their LDS window (they run the loop with the global gather / atomics)."""
     try:
@@ -362,7 +371,7 @@ def em_leg(capi, make_em_workload, config, K, W, kernel, sync, device, q32=False
                "estep_avg_launch_ms": estep_ms, "algorithmic_bytes_per_launch": alg, "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS,
                "frac_physical": phys.get("frac_physical"), "physical": phys,
                "theta_sum": ts, "generate_s": gen_s, "parity_one_step": one_step_parity(ctx, wl),
-               "units_with_ids_outside_their_window": far_units(ctx)}
+               "units_with_ids_outside_their_window": far_units(ctx), "split_rows": split_info(ctx)}
         if q32 and kernel in (0, 3):
             out["q32_value_planes"] = q32_leg(ctx, wl, wl["N0"], K, W, sync, alg, el * 1e3 / rounds, estep_ms)
         ctx.close()
@@ -377,7 +386,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--legs", default="C2,C2R,C3X,C5", help="extra single-GPU E-step legs on other configs (comma list, '' for none; NAME@scale for a fraction of the reads, e.g. C5@0.1)")
+    ap.add_argument("--legs", default="C2,C2R,C3X,C3X30,C5", help="extra single-GPU E-step legs on other configs (comma list, '' for none; NAME@scale for a fraction of the reads, e.g. C5@0.1)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--no-q32", action="store_true", help="skip the Q32 value-plane measurement beside the headline")

@@ -201,6 +201,47 @@ __device__ inline bool seg_reduce(int key, double& v, int lane, int lg) {
     return (lane + G >= 64) || (knext != key);
 }
 
+// ---- split rows: the two passes around the lane kernel (sell_layout.hpp: sell_build_far) ----------------------------------------
+// Before: the far part of every split read's normaliser, sum over its far alignments of theta[sid] * conprb (each clamped
+// like every term of EM.cpp:212-219).  Thread per read: a split read has a handful of far alignments.
+__global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_x, const uint64_t* __restrict__ far_ptr, const int32_t* __restrict__ far_sid,
+                                                        const double* __restrict__ far_cp, const uint32_t* __restrict__ xslot, uint32_t slot_base,
+                                                        const double* __restrict__ theta, double* __restrict__ extra, const Ctrl* ctrl) {
+    if (ctrl->done) return;
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n_x) return;
+    double sum = 0.0;
+    for (uint64_t e = far_ptr[x]; e < far_ptr[x + 1]; e++) {
+        double f = theta[far_sid[e]] * far_cp[e];
+        if (f < kEpsilon) f = 0.0;
+        sum += f;
+    }
+    extra[xslot[x] - slot_base] = sum;
+}
+// After: the far alignments' fractions, theta[sid] * conprb / normaliser of their read (inv[], left by the lane kernel), added
+// to counts[sid] in transcript order: consecutive entries of one id are summed by a segmented shuffle reduction, one atomic
+// per id and wave -- the transposed (CSC) pass instead of a global atomic per alignment.
+__global__ __launch_bounds__(kBlock) void k_far_colsum(uint64_t n_far, const int32_t* __restrict__ csc_sid, const double* __restrict__ csc_cp,
+                                                        const uint32_t* __restrict__ csc_slot, uint32_t slot_base, const double* __restrict__ theta,
+                                                        const double* __restrict__ inv, double* counts, const Ctrl* ctrl) {
+    if (ctrl->done) return;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t b = wave * 64; b < n_far; b += n_waves * 64) {  // (uniform over the wave)
+        const uint64_t i = b + (uint64_t)lane;
+        int key = -1;
+        double v = 0.0;
+        if (i < n_far) {
+            key = csc_sid[i];
+            double f = theta[key] * stream_load(&csc_cp[i]);
+            if (f < kEpsilon) f = 0.0;
+            v = f * inv[csc_slot[i] - slot_base];
+        }
+        const bool tail = seg_reduce(key, v, lane, 0);
+        if (tail && key > 0 && v != 0.0) unsafeAtomicAdd(&counts[key], v);
+    }
+}
+
 // Variant SELL (cross-check / fallback): every slice on its own, per-plane segmented shuffle
 // reduction keyed by sid, run tails issue device atomics.  Makes no use of the lane-major order.
 __global__ __launch_bounds__(kBlock) void k_estep_sell(
@@ -400,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
     const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, const unsigned char* __restrict__ sval,
     const int16_t* __restrict__ sexp, const int32_t* __restrict__ ssid, const double* __restrict__ sncp,
     const unsigned long long* __restrict__ masks, double* counts, double* noise_partial, double* totals, const Ctrl* ctrl,
-    unsigned long long* trace, SoloArgs solo = SoloArgs()) {
+    unsigned long long* trace, SoloArgs solo = SoloArgs(), XArgs xa = XArgs()) {
     if (ctrl->done) return;
     if (trace && threadIdx.x == 0) trace[2 * blockIdx.x] = wall_clock64();  // rsem_em_debug_trace only
     __shared__ double th_win[kWindow];
@@ -426,25 +467,40 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
         const uint32_t u_end = S.slice_base + U.slice_begin + U.n_slices;
         const uint32_t s_begin = S.slice_base + U.slice_begin + (uint32_t)w * U.per_wave;
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
-#define RSEM_ESTEP_BLOCK(KK, QQ, FF) \
-    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M)
-        if (s_begin < u_end) switch (S.K + 4 * S.fmt + (U.pad[0] != 0 ? 8 : 0)) {  // (uniform over the workgroup)
-            case 1: RSEM_ESTEP_BLOCK(1, false, false); break;
-            case 2: RSEM_ESTEP_BLOCK(2, false, false); break;
-            case 3: RSEM_ESTEP_BLOCK(3, false, false); break;
-            case 4: RSEM_ESTEP_BLOCK(4, false, false); break;
-            case 5: RSEM_ESTEP_BLOCK(1, true, false); break;
-            case 6: RSEM_ESTEP_BLOCK(2, true, false); break;
-            case 7: RSEM_ESTEP_BLOCK(3, true, false); break;
-            case 8: RSEM_ESTEP_BLOCK(4, true, false); break;
-            case 9: RSEM_ESTEP_BLOCK(1, false, true); break;
-            case 10: RSEM_ESTEP_BLOCK(2, false, true); break;
-            case 11: RSEM_ESTEP_BLOCK(3, false, true); break;
-            case 12: RSEM_ESTEP_BLOCK(4, false, true); break;
-            case 13: RSEM_ESTEP_BLOCK(1, true, true); break;
-            case 14: RSEM_ESTEP_BLOCK(2, true, true); break;
-            case 15: RSEM_ESTEP_BLOCK(3, true, true); break;
-            default: RSEM_ESTEP_BLOCK(4, true, true); break;
+#define RSEM_ESTEP_BLOCK(KK, QQ, FF, XX) \
+    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF, XX>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M, xa)
+        // (uniform over the workgroup)  split rows (F64X) only exist where theta is a plain array: the loops that read theta
+        // out of the previous round's counts (kFC) are not taken for a layout with split rows (loop_wanted)
+        const int code = (S.K - 1) | ((S.fmt == kFmtQ32 ? 1 : 0) << 2) | ((U.pad[0] != 0 ? 1 : 0) << 3) | (((!kFC && S.fmt == kFmtF64X) ? 1 : 0) << 4);
+        if (s_begin < u_end) switch (code) {
+            case 0: RSEM_ESTEP_BLOCK(1, false, false, false); break;
+            case 1: RSEM_ESTEP_BLOCK(2, false, false, false); break;
+            case 2: RSEM_ESTEP_BLOCK(3, false, false, false); break;
+            case 3: RSEM_ESTEP_BLOCK(4, false, false, false); break;
+            case 4: RSEM_ESTEP_BLOCK(1, true, false, false); break;
+            case 5: RSEM_ESTEP_BLOCK(2, true, false, false); break;
+            case 6: RSEM_ESTEP_BLOCK(3, true, false, false); break;
+            case 7: RSEM_ESTEP_BLOCK(4, true, false, false); break;
+            case 8: RSEM_ESTEP_BLOCK(1, false, true, false); break;
+            case 9: RSEM_ESTEP_BLOCK(2, false, true, false); break;
+            case 10: RSEM_ESTEP_BLOCK(3, false, true, false); break;
+            case 11: RSEM_ESTEP_BLOCK(4, false, true, false); break;
+            case 12: RSEM_ESTEP_BLOCK(1, true, true, false); break;
+            case 13: RSEM_ESTEP_BLOCK(2, true, true, false); break;
+            case 14: RSEM_ESTEP_BLOCK(3, true, true, false); break;
+            case 15: RSEM_ESTEP_BLOCK(4, true, true, false); break;
+            default:
+                if constexpr (!kFC) switch (code & 11) {
+                    case 0: RSEM_ESTEP_BLOCK(1, false, false, true); break;
+                    case 1: RSEM_ESTEP_BLOCK(2, false, false, true); break;
+                    case 2: RSEM_ESTEP_BLOCK(3, false, false, true); break;
+                    case 3: RSEM_ESTEP_BLOCK(4, false, false, true); break;
+                    case 8: RSEM_ESTEP_BLOCK(1, false, true, true); break;
+                    case 9: RSEM_ESTEP_BLOCK(2, false, true, true); break;
+                    case 10: RSEM_ESTEP_BLOCK(3, false, true, true); break;
+                    default: RSEM_ESTEP_BLOCK(4, false, true, true); break;
+                }
+                break;
 #undef RSEM_ESTEP_BLOCK
         } else {
             const ThetaSrc th = theta_src<kFC>(theta, tsrc, N0, lane);
@@ -817,6 +873,8 @@ struct rsem_em_ctx {
     std::vector<Unit> h_units;
     uint64_t long_nnz = 0;  // alignments of the reads left in the CSR
     uint32_t* d_rank = nullptr;  // caller row -> sorted row (inverse of L.d_order), built on first use (em_planes_view)
+    double *d_xextra = nullptr, *d_xinv = nullptr;  // split rows: far part of the normaliser / its reciprocal, per row slot from L.x_slot_base
+    int split_rows = 1;          // lay reads with ids outside their window out as split rows (LANE kernel only; option "split_rows")
     uint32_t n_far_units = 0;               // units with an id outside their LDS window (Unit::pad[0])
     unsigned long long n_stray_reads = 0;   // reads the second layout pass sorted apart (sell_build_refined)
     int tune_passes_left = 1;               // measured-lifetime reordering of the units, done on first use
@@ -871,11 +929,24 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
         return RSEM_OK;
     }
     if (kern == RSEM_EM_KERNEL_LANE) {
+        XArgs xa;
+        if (c->L.n_x_rows) {  // split rows: the far part of their normalisers first
+            xa.extra = c->d_xextra; xa.inv = c->d_xinv; xa.slot_base = c->L.x_slot_base;
+            hipLaunchKernelGGL(k_far_rowsum, dim3(rsem::ceil_div(c->L.n_x_rows, kBlock)), dim3(kBlock), 0, st, c->L.n_x_rows, (const uint64_t*)c->L.d_far_ptr,
+                               (const int32_t*)c->L.d_far_sid, (const double*)c->L.d_far_cp, (const uint32_t*)c->L.d_xslot, c->L.x_slot_base, d_theta,
+                               c->d_xextra, ctrl);
+        }
         if (c->n_units)
             hipLaunchKernelGGL((k_estep_lane<false, false>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
                                d_theta, (const double*)nullptr, 0.0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid,
-                               c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs());
+                               c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs(), xa);
+        if (c->L.n_far) {  // ... and their far alignments' fractions afterwards, in transcript order
+            const int grid = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_far, kBlock)));
+            hipLaunchKernelGGL(k_far_colsum, dim3(grid), dim3(kBlock), 0, st, c->L.n_far, (const int32_t*)c->L.d_csc_sid, (const double*)c->L.d_csc_cp,
+                               (const uint32_t*)c->L.d_csc_slot, c->L.x_slot_base, d_theta, (const double*)c->d_xinv, d_counts, ctrl);
+        }
     } else {
+        if (c->L.n_x_rows) { rsem::set_last_error("the SELL kernel cannot walk a layout with split rows (set the kernel before the values, or option split_rows = 0)"); return RSEM_ERR_STATE; }
         if (c->layout_has_q32) { rsem::set_last_error("the SELL kernel reads F64 planes only (value_bits = 32 needs the LANE kernel)"); return RSEM_ERR_STATE; }
         hipLaunchKernelGGL(k_estep_sell, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
                            c->L.n_slices, d_theta, (const double*)c->d_sval, c->L.d_ssid, c->d_sncp, d_counts, c->d_noise_a, ctrl);
@@ -933,7 +1004,7 @@ __global__ void k_sum_row_lengths(uint32_t n, const uint32_t* __restrict__ rows,
 
 int write_values(rsem_em_ctx* c) {
     if (c->d_fill_err) RSEM_HIP_TRY(hipMemsetAsync(c->d_fill_err, 0, sizeof(int), c->stream));
-    int rc = sell_fill_values(c->L, c->stream, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_sval, c->d_sncp, c->d_sexp, c->d_fill_err);
+    int rc = sell_fill_values(c->L, c->stream, c->d_row_ptr, c->d_cp, c->d_ncp, c->d_sval, c->d_sncp, c->d_sexp, c->d_fill_err, c->d_sid);
     if (rc != RSEM_OK) return rc;
     if (c->layout_has_q32) {  // a Q32 shape was handed a read that no longer qualifies: cannot happen after a rebuild
         int h = 0;
@@ -957,8 +1028,8 @@ int fill_values(rsem_em_ctx* c) {
 
 void free_layout(rsem_em_ctx* c) {
     sell_free(c->L);
-    hipFree(c->d_rank);
-    c->d_rank = nullptr;
+    hipFree(c->d_rank); hipFree(c->d_xextra); hipFree(c->d_xinv);
+    c->d_rank = nullptr; c->d_xextra = nullptr; c->d_xinv = nullptr;
     hipFree(c->d_sval); hipFree(c->d_sncp); hipFree(c->d_sexp); hipFree(c->d_fill_err); hipFree(c->d_units); hipFree(c->d_noise_a);
     c->d_sval = nullptr; c->d_sncp = nullptr; c->d_sexp = nullptr; c->d_fill_err = nullptr; c->d_units = nullptr; c->d_noise_a = nullptr;
     c->h_units.clear();
@@ -972,9 +1043,19 @@ int build_layout(rsem_em_ctx* c) {
     const uint32_t target_waves = (uint32_t)c->n_cus * 4 * 6 * 5 / 2;
     const bool q32 = c->value_bits == 32 && c->have_values;
     std::vector<Unit> units;
+    // (not together with Q32 planes: which reads take that format is a documented function of their values alone)
+    int split = c->split_rows && resolved_kernel(c) == RSEM_EM_KERNEL_LANE && !q32;
+    if (const char* e = getenv("RSEM_HIP_SPLIT")) split = split && atoi(e) != 0;  // measurement knob: 0 = reads that leave their window stay whole
     int rc = sell_build_refined(c->L, c->stream, c->N1, c->M, c->d_row_ptr, c->d_sid, target_waves, c->forced_T,
-                                q32 ? c->d_cp : nullptr, c->value_range_bits, kWindow, units, &c->d_units, &c->n_stray_reads);
+                                q32 ? c->d_cp : nullptr, c->value_range_bits, kWindow, units, &c->d_units, &c->n_stray_reads, split);
     if (rc != RSEM_OK) return rc;
+    if (c->L.n_x_rows) {
+        const size_t nxs = (size_t)(c->L.n_slots - c->L.x_slot_base);
+        RSEM_HIP_TRY(dmalloc(&c->d_xextra, nxs));
+        RSEM_HIP_TRY(dmalloc(&c->d_xinv, nxs));
+        RSEM_HIP_TRY(hipMemsetAsync(c->d_xextra, 0, sizeof(double) * std::max<size_t>(nxs, 1), c->stream));
+        RSEM_HIP_TRY(hipMemsetAsync(c->d_xinv, 0, sizeof(double) * std::max<size_t>(nxs, 1), c->stream));
+    }
     c->layout_has_q32 = q32;
     RSEM_HIP_TRY(hipMalloc((void**)&c->d_sval, std::max<uint64_t>(c->L.val_bytes, 1)));
     RSEM_HIP_TRY(dmalloc(&c->d_sncp, (size_t)c->L.n_slots));
@@ -1166,6 +1247,26 @@ int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
     if (!strcmp(key, "kernel")) {
         RSEM_REQUIRE(value >= RSEM_EM_KERNEL_AUTO && value <= RSEM_EM_KERNEL_LANE, "unknown kernel variant");
         c->kernel = (int)value;
+        if (c->layout_ok && c->L.n_x_rows && resolved_kernel(c) != RSEM_EM_KERNEL_LANE) {  // only the LANE kernel walks split rows
+            RSEM_HIP_TRY(hipSetDevice(c->device));
+            free_layout(c);
+            int rc = build_layout(c);
+            if (rc != RSEM_OK) return rc;
+        }
+        set_grid_for_kernel(c);
+        return RSEM_OK;
+    }
+    if (!strcmp(key, "split_rows")) {
+        // 1 (default): a read with transcript ids outside the LDS window of its own gene is laid out as a row of its in-window
+        // alignments plus far entries handled by two side passes (k_far_rowsum / k_far_colsum); 0: such reads stay whole and
+        // their far ids take global atomics.  Rebuilds the layout.
+        RSEM_REQUIRE(value == 0 || value == 1, "split_rows must be 0 or 1");
+        if (c->split_rows == (int)value) return RSEM_OK;
+        c->split_rows = (int)value;
+        RSEM_HIP_TRY(hipSetDevice(c->device));
+        free_layout(c);
+        int rc = build_layout(c);
+        if (rc != RSEM_OK) return rc;
         set_grid_for_kernel(c);
         return RSEM_OK;
     }
@@ -1211,6 +1312,8 @@ int rsem_em_get_info(const rsem_em_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "slots")) *value = c->L.n_slots;
     else if (!strcmp(key, "sid_plane_bytes_loaded")) *value = (int64_t)(c->L.n_sid_planes_loaded * 256);  // slices where a tuple starts
     else if (!strcmp(key, "slices")) *value = c->L.n_slices;
+    else if (!strcmp(key, "split_rows")) *value = c->L.n_x_rows;    // reads laid out as an in-window row + far entries
+    else if (!strcmp(key, "far_entries")) *value = (int64_t)c->L.n_far;
     else if (!strcmp(key, "window_entries")) {  // ids staged in (theta) and flushed from (counts) the LDS windows of all units
         int64_t w = 0;
         for (const Unit& u : c->h_units) w += u.span;
@@ -1224,9 +1327,13 @@ int rsem_em_get_info(const rsem_em_ctx* c, const char* key, int64_t* value) {
         int64_t w = 0;
         for (const Unit& u : c->h_units) w += u.span;
         const uint64_t long_nnz = c->long_nnz + (c->L.n_long_rows * 4ull) / 3;  // 12 B per alignment + 16 B per read
+        // split rows: their far entries once in row order (sid + value, 12 B) and once in column order (sid + value + slot, 16 B),
+        // per split row its far_ptr / slot (12 B) and extra written, read, inv written, read (4 x 8 B; the gathers of inv by
+        // column-order entries beyond the first are cache hits)
+        const uint64_t far_bytes = 28 * c->L.n_far + 44 * (uint64_t)c->L.n_x_rows;
         *value = (int64_t)(c->L.val_bytes + c->L.n_sid_planes_loaded * 256 + (uint64_t)c->L.n_slots * (8 + (c->layout_has_q32 ? 2 : 0)) +
                            (uint64_t)c->L.n_slices * 8 + (uint64_t)c->n_units * sizeof(Unit) + (uint64_t)w * 16 + 16 * ((uint64_t)c->M + 1)) +
-                 (int64_t)(12 * long_nnz);
+                 (int64_t)(12 * long_nnz + far_bytes);
     }
     else if (!strcmp(key, "units")) *value = c->n_units;
     else { rsem::set_last_error("unknown info key '%s'", key); return RSEM_ERR_INVALID; }
@@ -1341,7 +1448,9 @@ __global__ __launch_bounds__(kBlock) void k_solo_close(int M, const double* __re
 // whenever the counts need not cross devices between the E step and theta; RSEM_EM_FUSED=2 asks for it explicitly.
 enum class Loop { PLAIN, FUSED, SOLO };
 Loop loop_wanted(const rsem_em_ctx* c, bool sharded) {
-    const bool possible = resolved_kernel(c) == RSEM_EM_KERNEL_LANE && c->L.n_long_rows == 0 && c->n_units > 0;
+    // (split rows take the kernel sequence: their two side passes stand before and after the lane kernel, which then reads
+    // theta as a plain array)
+    const bool possible = resolved_kernel(c) == RSEM_EM_KERNEL_LANE && c->L.n_long_rows == 0 && c->n_units > 0 && c->L.n_x_rows == 0;
     if (!possible) return Loop::PLAIN;
     const char* e = getenv("RSEM_EM_FUSED");
     if (e && !strcmp(e, "0")) return Loop::PLAIN;
@@ -1636,7 +1745,10 @@ __global__ void k_invert_order(uint64_t n, const uint32_t* __restrict__ order, u
 
 int em_planes_view(rsem_em_ctx* c, EmPlanesView* v) {
     RSEM_REQUIRE(c && v, "NULL argument");
-    if (!c->layout_ok || c->layout_has_q32 || c->value_bits == 32) { set_last_error("the layout holds Q32 planes"); return RSEM_ERR_STATE; }
+    if (!c->layout_ok || c->layout_has_q32 || c->value_bits == 32 || c->L.n_x_rows) {
+        set_last_error("the layout holds Q32 planes or split rows");
+        return RSEM_ERR_STATE;
+    }
     RSEM_HIP_TRY(hipSetDevice(c->device));
     if (!c->d_rank && c->N1) {
         RSEM_HIP_TRY(dmalloc(&c->d_rank, (size_t)c->N1));

@@ -54,6 +54,16 @@ RSEM_DEVFN void stage_windows(int base, int span, int M, const ThetaSrc& th, dou
     RSEM_SYNC();
 }
 
+// Split rows (F64X shapes, sell_layout.hpp): the row holds a read's in-window alignments only.  extra[slot - slot_base] =
+// the sum of theta * conprb over the read's other alignments (written before this kernel by k_far_rowsum), added to the
+// read's normaliser here; inv[slot - slot_base] = the reciprocal of the normaliser (0 when the read carries no mass), handed
+// on to k_far_colsum, which adds the far alignments' fractions to the counts in transcript order.
+struct XArgs {
+    const double* extra = nullptr;
+    double* inv = nullptr;
+    uint32_t slot_base = 0;
+};
+
 // one slice's loads: sids (only where a tuple starts), values (doubles, or Q32 mantissas + the read's exponent), noise
 template <int K, bool kQ>
 struct SliceRegs {
@@ -61,6 +71,8 @@ struct SliceRegs {
     typename std::conditional<kQ, uint32_t, double>::type c[K];
     double nc;
     int e;
+    double x;        // split rows: the far part of the normaliser
+    uint32_t slot0;  // first row slot of the slice (split rows: where the reciprocal goes)
 };
 
 // 2^e for the exponents q32_scale_of admits (always a normal double)
@@ -113,12 +125,12 @@ constexpr int kQ32Depth[4] = {RSEM_Q32_DEPTHS};
 // runs a loop that touches global memory only through its streaming loads: theta and counts in LDS, no gather, no global
 // atomic -- with a global atomic possibly in flight (they do not return in order with loads) every wait the compiler
 // places in the loop is a wait for everything, and a gather in the middle of a slice drains the prefetch.
-template <int K, bool kFC, bool kQ, int NBUF, bool kFar>
+template <int K, bool kFC, bool kQ, int NBUF, bool kFar, bool kX = false>
 RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
                                    const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, double* th_win, double* cnt_win,
                                    const unsigned char* __restrict__ sval, const int16_t* __restrict__ sexp, const int32_t* __restrict__ ssid,
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
-                                   double* counts, double& noise, double& neff, int M) {
+                                   double* counts, double& noise, double& neff, int M, const XArgs& X = XArgs()) {
     using ValT = typename std::conditional<kQ, uint32_t, double>::type;
     const ValT* __restrict__ scp = (const ValT*)(sval + S.val_base);  // this shape's value planes
     const int lg = S.lg;
@@ -166,6 +178,8 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         // waits for everything)
         b.nc = (sncp + slot0)[uslot];
         b.e = kQ ? (int)(sexp + slot0)[uslot] : 0;
+        b.x = kX ? (X.extra + (slot0 - X.slot_base))[uslot] : 0.0;  // (unconditional within the instantiation, like the noise value)
+        b.slot0 = slot0;
     };
     auto spill = [&](const int* rsid, double* acc) {  // lane-private partial counts -> LDS window
 #pragma unroll
@@ -225,7 +239,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         double f0 = g0 ? th0 * cur.nc : 0.0;
         if (f0 < kEpsilon) f0 = 0.0;
         double f[K];
-        double part = f0;
+        double part = f0 + ((kX && g0) ? cur.x : 0.0);
         const double scale = kQ ? pow2_of(cur.e) : 1.0;
 #pragma unroll
         for (int k = 0; k < K; k++) {
@@ -238,6 +252,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         }
         part = read_sum_dpp(part, lg);
         const double inv = (part >= kEpsilon) ? 1.0 / part : 0.0;
+        if (kX && g0) (X.inv + (cur.slot0 - X.slot_base))[uslot] = inv;
         noise += f0 * inv;
         // reads whose fractions sum to one: sum(counts) without a reduction
         neff += (g0 && part >= kEpsilon) ? 1.0 : 0.0;

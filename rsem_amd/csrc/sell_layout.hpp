@@ -33,8 +33,8 @@ namespace {
 #include "sell_shape.hpp"
 
 constexpr int kShapesPerFmt = 28;   // (lg 0..6) x (K 1..4)
-constexpr int kShapeBits = 6;
-constexpr int kMaxShapes = 2 * kShapesPerFmt;  // F64 shapes, then Q32 shapes
+constexpr int kShapeBits = 7;
+constexpr int kMaxShapes = 3 * kShapesPerFmt;  // F64 shapes, then Q32 shapes, then F64X shapes (split rows)
 constexpr int kShapeIds = 1 << kShapeBits;
 constexpr int kLongShape = kShapeIds - 1;      // rows with more than 256 alignments: CSR kernel
 constexpr uint32_t kKeyMinSidCap = (1u << (31 - kShapeBits)) - 1;  // sort key: shape | apart bit | anchor sid (capped) | hash of the tuple
@@ -110,9 +110,13 @@ __host__ __device__ inline uint32_t mix32(uint32_t h, uint32_t v) {
 constexpr int kLayoutWindow = 2048;               // ids per LDS window of the kernels that walk this layout (em.hip kWindow, gibbs.hip kGWindow)
 constexpr int kAnchorReach = kLayoutWindow / 2;
 constexpr int kMedianExactMax = 64; // reads up to this length: exact median (rank selection); longer: the middle position
+// `split` (with apart): a read with an id outside [anchor, anchor + apart) is SPLIT -- its ids inside that range form a row of
+// an F64X shape (length, sort key and tuple hash are those of the in-window part alone, so it sits among reads of its own
+// gene that share that part), the others go to the far-entry side arrays (sell_build_far).  No apart bit then: the row no
+// longer holds a foreign id.
 __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint64_t* __restrict__ row_ptr,
                                                const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits,
-                                               int apart, int* err) {
+                                               int apart, int* err, int split = 0) {
     uint64_t fr = row_ptr[i], to = row_ptr[i + 1];
     if (to < fr) { *err = 1; return 0; }
     uint32_t h = 0x811c9dc5u, mn = 0xffffffffu;
@@ -152,27 +156,34 @@ __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint
         }
         mn = lo;
     }
-    uint64_t far = 0;
+    uint64_t far = 0, L_in = 0;
+    uint32_t h_in = 0x811c9dc5u;
     if (apart && L > 1 && !*err)
         for (uint64_t j = fr; j < to; j++) {
             const uint32_t v = (uint32_t)sid[j];
             if (v < mn || v >= mn + (uint32_t)apart) far = 1;
+            else { ++L_in; h_in = mix32(h_in, v); }
         }
-    if (mn > kKeyMinSidCap) mn = kKeyMinSidCap;
     int shape = shape_id_of(to - fr);
+    if (far && split && shape != kLongShape && (uint64_t)mn <= kKeyMinSidCap) {  // split row: keyed by its in-window part
+        shape = shape_id_of(L_in) + 2 * kShapesPerFmt;
+        return ((uint64_t)shape << (64 - kShapeBits)) | ((uint64_t)mn << 32) | h_in;
+    }
+    if (mn > kKeyMinSidCap) mn = kKeyMinSidCap;
     Q32Scale q;
     if (cp && shape != kLongShape && q32_scale_of(vmx, vmn, range_bits, q)) shape += kShapesPerFmt;
     return ((uint64_t)shape << (64 - kShapeBits)) | (far << kKeyApartBit) | ((uint64_t)mn << 32) | h;
 }
 
 __global__ void k_row_keys(uint64_t N1, int32_t M, const uint64_t* __restrict__ row_ptr,
-                           const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits, int apart,
+                           const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits, int apart, int split,
                            const unsigned char* __restrict__ also_apart, uint64_t* keys, uint32_t* vals, int* err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N1) return;
     int e = 0;
-    uint64_t key = row_key_of(i, M, row_ptr, sid, cp, range_bits, apart, &e);
-    if (also_apart && also_apart[i]) key |= 1ull << kKeyApartBit;  // (a read the first layout found outside its unit's window)
+    uint64_t key = row_key_of(i, M, row_ptr, sid, cp, range_bits, apart, &e, split);
+    // (a read the first layout found outside its unit's window; split rows have no such bit: their key's hash is all 32 bits)
+    if (also_apart && also_apart[i] && (int)(key >> (64 - kShapeBits)) < 2 * kShapesPerFmt) key |= 1ull << kKeyApartBit;
     if (e) *err = e;
     if (e == 1) return;
     keys[i] = key;
@@ -194,11 +205,17 @@ __device__ inline int find_shape_by_row(const Shape* shapes, int n, uint32_t p) 
 
 // sorted row p of shape S: scatter its alignments into the planes (values optional; sval = the value planes of all shapes,
 // F64 or Q32 per shape; sexp = per-slot exponents of the Q32 reads)
+// A split row (F64X shape) holds only the alignments whose id lies in [anchor, anchor + kLayoutWindow), in file order; the
+// anchor is the one its sort key was made of.
+// (reach = the `apart` the keys were made with: kLayoutWindow in the product, smaller in the CPU emulator's tests)
+__host__ __device__ inline bool in_split_window(int32_t id, uint32_t anchor, int reach) { return (uint32_t)id - anchor < (uint32_t)reach; }
+
 template <bool kIds>
 __host__ __device__ inline void sell_fill_row(const Shape& S, uint32_t T, uint32_t p, const uint32_t* __restrict__ order,
                                               const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
                                               const double* __restrict__ cp, const double* __restrict__ ncp, int32_t* ssid,
-                                              unsigned char* sval, double* sncp, int16_t* sexp, int* err) {
+                                              unsigned char* sval, double* sncp, int16_t* sexp, int* err, uint32_t anchor = 0,
+                                              int reach = kLayoutWindow) {
     const int G = shape_G(S);
     uint32_t slice_local, r;
     row_to_slot(S, T, p - S.row_base, slice_local, r);
@@ -216,8 +233,11 @@ __host__ __device__ inline void sell_fill_row(const Shape& S, uint32_t T, uint32
         if (!q32_scale_of(vmx, vmx, 0, q)) { if (err) *err = 3; q.e = 0; }
         if (sexp) sexp[slot] = (int16_t)q.e;
     }
+    int ci = 0;  // position within the row: = c, except in a split row (its in-window alignments only)
     for (int c = 0; c < L; c++) {
-        const uint64_t off = (uint64_t)(c >> S.lg) * 64 + r * G + (c & (G - 1));
+        if (S.fmt == kFmtF64X && !in_split_window(sid[fr + c], anchor, reach)) continue;
+        const uint64_t off = (uint64_t)(ci >> S.lg) * 64 + r * G + (ci & (G - 1));
+        ++ci;
         if (kIds) ssid[pl0 + off] = sid[fr + c];
         if (cp) {
             if (S.fmt == kFmtQ32) ((uint32_t*)(sval + S.val_base))[pl_local + off] = q32_mantissa(cp[fr + c], q.e);
@@ -227,16 +247,17 @@ __host__ __device__ inline void sell_fill_row(const Shape& S, uint32_t T, uint32
     if (ncp) sncp[slot] = ncp[orig];
 }
 
+// d_xanchor: anchors of the split rows, indexed by sorted row - x_row_base (nullptr: no split rows)
 template <bool kIds>
 __global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_sell_rows,
                             const uint32_t* __restrict__ order, const uint64_t* __restrict__ row_ptr,
                             const int32_t* __restrict__ sid, const double* __restrict__ cp,
                             const double* __restrict__ ncp, int32_t* ssid, unsigned char* sval, double* sncp,
-                            int16_t* sexp, int* err) {
+                            int16_t* sexp, int* err, const uint32_t* __restrict__ xanchor, uint32_t x_row_base, int reach) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_sell_rows) return;
     const Shape S = shapes[find_shape_by_row(shapes, n_shapes, p)];
-    sell_fill_row<kIds>(S, T, p, order, row_ptr, sid, cp, ncp, ssid, sval, sncp, sexp, err);
+    sell_fill_row<kIds>(S, T, p, order, row_ptr, sid, cp, ncp, ssid, sval, sncp, sexp, err, S.fmt == kFmtF64X ? xanchor[p - x_row_base] : 0u, reach);
 }
 
 // per slice: bit l set when lane l's read has a different sid tuple than the same lane's read in
@@ -336,6 +357,69 @@ __global__ void k_slice_maxsid(const Shape* __restrict__ shapes, int n_shapes, u
 template <typename T>
 hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)); }
 
+// ---- split rows: the far entries -------------------------------------------------------------------------------------------
+// Per round the E step handles them in two more passes (em.hip): BEFORE the lane kernel, split row x gets
+// extra[x] = sum over its far entries of theta[sid] * conprb (row order: far_ptr / far_sid / far_cp), which the lane kernel
+// adds to the row's normaliser; AFTER it, every far entry adds theta[sid] * conprb / normaliser to counts[sid] in COLUMN order
+// (csc_*: sorted by transcript id, so the sums per id are segmented reductions and the counts see a handful of atomics) --
+// the "transposed CSC pass" instead of one global atomic per entry.
+__global__ void k_x_anchors(uint32_t n_x, uint32_t x_row_base, const uint64_t* __restrict__ keys_sorted, uint32_t* xanchor) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n_x) xanchor[x] = (uint32_t)((keys_sorted[x_row_base + x] >> 32) & kKeyMinSidCap);
+}
+// far entries of split row x: count (far_ptr == nullptr) or write
+__global__ void k_x_far(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_x, uint32_t x_row_base, const uint32_t* __restrict__ order,
+                        const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid, const uint32_t* __restrict__ xanchor, uint64_t* nfar,
+                        const uint64_t* __restrict__ far_ptr, int32_t* far_sid, uint64_t* far_src, uint32_t* xslot, int reach) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n_x) return;
+    const uint32_t p = x_row_base + x, orig = order[p], anchor = xanchor[x];
+    const uint64_t fr = row_ptr[orig], to = row_ptr[orig + 1];
+    if (!far_ptr) {
+        uint64_t n = 0;
+        for (uint64_t j = fr; j < to; j++) n += in_split_window(sid[j], anchor, reach) ? 0 : 1;
+        nfar[x] = n;
+        return;
+    }
+    uint64_t e = far_ptr[x];
+    for (uint64_t j = fr; j < to; j++)
+        if (!in_split_window(sid[j], anchor, reach)) { far_sid[e] = sid[j]; far_src[e] = j; ++e; }
+    const Shape S = shapes[find_shape_by_row(shapes, n_shapes, p)];
+    uint32_t slice_local, r;
+    row_to_slot(S, T, p - S.row_base, slice_local, r);
+    xslot[x] = S.slot_base + slice_local * shape_R(S) + r;
+}
+// entry e (row order) -> its split row: the x with far_ptr[x] <= e < far_ptr[x + 1]
+__device__ inline uint32_t x_of_entry(const uint64_t* __restrict__ far_ptr, uint32_t n_x, uint64_t e) {
+    uint32_t lo = 0, hi = n_x;  // far_ptr[lo] <= e < far_ptr[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (far_ptr[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+__global__ void k_x_csc(uint64_t n_far, uint32_t n_x, const uint64_t* __restrict__ perm, const uint64_t* __restrict__ far_ptr,
+                        const int32_t* __restrict__ far_sid, const uint64_t* __restrict__ far_src, const uint32_t* __restrict__ xslot,
+                        int32_t* csc_sid, uint64_t* csc_src, uint32_t* csc_slot) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_far) return;
+    const uint64_t e = perm[i];
+    csc_sid[i] = far_sid[e];
+    csc_src[i] = far_src[e];
+    csc_slot[i] = xslot[x_of_entry(far_ptr, n_x, e)];
+}
+__global__ void k_x_values(uint64_t n_far, const double* __restrict__ cp, const uint64_t* __restrict__ far_src, const uint64_t* __restrict__ csc_src,
+                           double* far_cp, double* csc_cp) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_far) return;
+    far_cp[i] = cp[far_src[i]];
+    csc_cp[i] = cp[csc_src[i]];
+}
+__global__ void k_iota64(uint64_t n, uint64_t* v) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
 struct SellLayout {
     uint64_t N1 = 0;
     uint32_t T = 16;              // slices per block (one wave's unit of work)
@@ -352,6 +436,20 @@ struct SellLayout {
     uint32_t n_q32_rows = 0;      // sorted rows held in Q32 shapes
     uint64_t n_q32_planes = 0;
     uint64_t n_sid_planes_loaded = 0;  // sid planes of the slices in which some lane starts a new tuple (k_count_sid_planes)
+    // split rows (F64X shapes: the last shapes of the table) and their far entries (sell_build_far)
+    uint32_t x_row_base = 0, n_x_rows = 0;   // sorted rows [x_row_base, x_row_base + n_x_rows)
+    uint32_t x_slot_base = 0;                // their row slots start here (extra / inv arrays are indexed by slot - x_slot_base)
+    uint64_t n_far = 0;                      // alignments of split rows outside their window
+    uint32_t* d_xanchor = nullptr;           // [n_x_rows]
+    uint32_t* d_xslot = nullptr;             // [n_x_rows] row slot of split row x
+    uint64_t* d_far_ptr = nullptr;           // [n_x_rows + 1] far entries of split row x, in file order
+    int32_t* d_far_sid = nullptr;            // [n_far]
+    uint64_t* d_far_src = nullptr;           // [n_far] index into the caller's CSR
+    double* d_far_cp = nullptr;              // [n_far] values (sell_fill_values)
+    int32_t* d_csc_sid = nullptr;            // the same entries sorted by transcript id ...
+    uint64_t* d_csc_src = nullptr;
+    uint32_t* d_csc_slot = nullptr;          // ... each with the row slot of its read
+    double* d_csc_cp = nullptr;
     int32_t* d_ssid = nullptr;
     unsigned long long* d_masks = nullptr;
     uint32_t* d_slice_minsid = nullptr;
@@ -360,6 +458,8 @@ struct SellLayout {
 
 inline void sell_free(SellLayout& L) {
     hipFree(L.d_order); hipFree(L.d_shapes); hipFree(L.d_ssid); hipFree(L.d_masks); hipFree(L.d_slice_minsid); hipFree(L.d_slice_maxsid);
+    hipFree(L.d_xanchor); hipFree(L.d_xslot); hipFree(L.d_far_ptr); hipFree(L.d_far_sid); hipFree(L.d_far_src); hipFree(L.d_far_cp);
+    hipFree(L.d_csc_sid); hipFree(L.d_csc_src); hipFree(L.d_csc_slot); hipFree(L.d_csc_cp);
     L = SellLayout();
 }
 
@@ -367,16 +467,86 @@ inline void sell_free(SellLayout& L) {
 // d_sval: L.val_bytes bytes (= n_planes * 512 for a layout without Q32 shapes); d_sexp / d_err only with Q32 shapes.
 inline int sell_fill_values(const SellLayout& L, hipStream_t st, const uint64_t* d_row_ptr, const double* d_cp,
                             const double* d_ncp, void* d_sval, double* d_sncp, int16_t* d_sexp = nullptr,
-                            int* d_err = nullptr) {
+                            int* d_err = nullptr, const int32_t* d_sid = nullptr) {
     RSEM_HIP_TRY(hipMemsetAsync(d_sval, 0, L.val_bytes, st));
     RSEM_HIP_TRY(hipMemsetAsync(d_sncp, 0, sizeof(double) * L.n_slots, st));
     if (d_sexp) RSEM_HIP_TRY(hipMemsetAsync(d_sexp, 0, sizeof(int16_t) * L.n_slots, st));
+    if (L.n_x_rows && !d_sid) { rsem::set_last_error("a layout with split rows needs the transcript ids to place their values"); return RSEM_ERR_STATE; }
     if (L.n_sell_rows) {
         hipLaunchKernelGGL(k_fill_sell<false>, dim3(rsem::ceil_div(L.n_sell_rows, kBlock)), dim3(kBlock), 0, st,
-                           L.d_shapes, L.n_shapes, L.T, L.n_sell_rows, L.d_order, d_row_ptr, (const int32_t*)nullptr,
-                           d_cp, d_ncp, (int32_t*)nullptr, (unsigned char*)d_sval, d_sncp, d_sexp, d_err);
+                           L.d_shapes, L.n_shapes, L.T, L.n_sell_rows, L.d_order, d_row_ptr, d_sid,
+                           d_cp, d_ncp, (int32_t*)nullptr, (unsigned char*)d_sval, d_sncp, d_sexp, d_err, (const uint32_t*)L.d_xanchor, L.x_row_base, kLayoutWindow);
         RSEM_HIP_TRY(hipGetLastError());
     }
+    if (L.n_far) {
+        hipLaunchKernelGGL(k_x_values, dim3(rsem::ceil_div(L.n_far, kBlock)), dim3(kBlock), 0, st, L.n_far, d_cp, (const uint64_t*)L.d_far_src,
+                           (const uint64_t*)L.d_csc_src, L.d_far_cp, L.d_csc_cp);
+        RSEM_HIP_TRY(hipGetLastError());
+    }
+    return RSEM_OK;
+}
+
+// The far entries of the split rows, in row order and in column (transcript id) order.  Called by sell_build once the shape
+// table and the sorted order stand.
+inline int sell_build_far(SellLayout& L, hipStream_t st, const uint64_t* d_row_ptr, const int32_t* d_sid, const uint64_t* d_keys_sorted) {
+    const uint32_t nx = L.n_x_rows;
+    if (!nx) return RSEM_OK;
+    RSEM_HIP_TRY(dmalloc(&L.d_xanchor, nx));
+    RSEM_HIP_TRY(dmalloc(&L.d_xslot, nx));
+    RSEM_HIP_TRY(dmalloc(&L.d_far_ptr, (size_t)nx + 1));
+    hipLaunchKernelGGL(k_x_anchors, dim3(rsem::ceil_div(nx, kBlock)), dim3(kBlock), 0, st, nx, L.x_row_base, d_keys_sorted, L.d_xanchor);
+    uint64_t* d_n = nullptr;
+    void* d_tmp = nullptr;
+    uint64_t *d_perm_in = nullptr, *d_perm = nullptr;
+    uint32_t *d_k_in = nullptr, *d_k_out = nullptr;
+    auto cleanup = [&]() { hipFree(d_n); hipFree(d_tmp); hipFree(d_perm_in); hipFree(d_perm); hipFree(d_k_in); hipFree(d_k_out); };
+    hipError_t e = dmalloc(&d_n, (size_t)nx + 1);
+    if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, sizeof(uint64_t) * ((size_t)nx + 1), st);
+    if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
+    hipLaunchKernelGGL(k_x_far, dim3(rsem::ceil_div(nx, kBlock)), dim3(kBlock), 0, st, (const Shape*)L.d_shapes, L.n_shapes, L.T, nx, L.x_row_base,
+                       (const uint32_t*)L.d_order, d_row_ptr, d_sid, (const uint32_t*)L.d_xanchor, d_n, (const uint64_t*)nullptr, (int32_t*)nullptr,
+                       (uint64_t*)nullptr, (uint32_t*)nullptr, kLayoutWindow);
+    size_t tb = 0;
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_n, L.d_far_ptr, (size_t)nx + 1, st);
+    if (e == hipSuccess) e = hipMalloc(&d_tmp, tb ? tb : 1);
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_n, L.d_far_ptr, (size_t)nx + 1, st);
+    uint64_t nf = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&nf, L.d_far_ptr + nx, sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
+    L.n_far = nf;
+    e = dmalloc(&L.d_far_sid, nf);
+    if (e == hipSuccess) e = dmalloc(&L.d_far_src, nf);
+    if (e == hipSuccess) e = dmalloc(&L.d_far_cp, nf);
+    if (e == hipSuccess) e = dmalloc(&L.d_csc_sid, nf);
+    if (e == hipSuccess) e = dmalloc(&L.d_csc_src, nf);
+    if (e == hipSuccess) e = dmalloc(&L.d_csc_slot, nf);
+    if (e == hipSuccess) e = dmalloc(&L.d_csc_cp, nf);
+    if (e == hipSuccess) e = hipMemsetAsync(L.d_far_cp, 0, sizeof(double) * std::max<uint64_t>(nf, 1), st);
+    if (e == hipSuccess) e = hipMemsetAsync(L.d_csc_cp, 0, sizeof(double) * std::max<uint64_t>(nf, 1), st);
+    if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
+    hipLaunchKernelGGL(k_x_far, dim3(rsem::ceil_div(nx, kBlock)), dim3(kBlock), 0, st, (const Shape*)L.d_shapes, L.n_shapes, L.T, nx, L.x_row_base,
+                       (const uint32_t*)L.d_order, d_row_ptr, d_sid, (const uint32_t*)L.d_xanchor, (uint64_t*)nullptr, (const uint64_t*)L.d_far_ptr,
+                       L.d_far_sid, L.d_far_src, L.d_xslot, kLayoutWindow);
+    if (nf) {  // column order: a stable sort of the entries by transcript id (ids are positive: their bits sort as unsigned)
+        hipFree(d_tmp); d_tmp = nullptr;
+        e = dmalloc(&d_perm_in, nf);
+        if (e == hipSuccess) e = dmalloc(&d_perm, nf);
+        if (e == hipSuccess) e = dmalloc(&d_k_out, nf);
+        if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
+        hipLaunchKernelGGL(k_iota64, dim3(rsem::ceil_div(nf, kBlock)), dim3(kBlock), 0, st, nf, d_perm_in);
+        tb = 0;
+        e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint32_t*)L.d_far_sid, d_k_out, (const uint64_t*)d_perm_in, d_perm, nf, 0, 32, st);
+        if (e == hipSuccess) e = hipMalloc(&d_tmp, tb ? tb : 1);
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, (const uint32_t*)L.d_far_sid, d_k_out, (const uint64_t*)d_perm_in, d_perm, nf, 0, 32, st);
+        if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
+        hipLaunchKernelGGL(k_x_csc, dim3(rsem::ceil_div(nf, kBlock)), dim3(kBlock), 0, st, nf, nx, (const uint64_t*)d_perm, (const uint64_t*)L.d_far_ptr,
+                           (const int32_t*)L.d_far_sid, (const uint64_t*)L.d_far_src, (const uint32_t*)L.d_xslot, L.d_csc_sid, L.d_csc_src, L.d_csc_slot);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    cleanup();
+    RSEM_HIP_TRY(e);
     return RSEM_OK;
 }
 
@@ -385,7 +555,7 @@ inline int sell_fill_values(const SellLayout& L, hipStream_t st, const uint64_t*
 // qualify (q32_scale_of with range_bits) are placed in Q32 shapes.
 inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, const uint64_t* d_row_ptr,
                       const int32_t* d_sid, uint32_t target_waves, uint32_t forced_T = 0,
-                      const double* d_cp_for_q32 = nullptr, int range_bits = 0, const unsigned char* d_also_apart = nullptr) {
+                      const double* d_cp_for_q32 = nullptr, int range_bits = 0, const unsigned char* d_also_apart = nullptr, int split = 0) {
     L.N1 = N1;
     int apart = kLayoutWindow;
     if (const char* e = getenv("RSEM_HIP_APART")) apart = atoi(e) ? kLayoutWindow : 0;  // measurement knob: 0 = one sorted sequence per shape
@@ -406,7 +576,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     RSEM_HIP_TRY(hipMemsetAsync(d_first, 0xff, kShapeIds * sizeof(uint32_t), st));
     if (N1) {
         hipLaunchKernelGGL(k_row_keys, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, M, d_row_ptr, d_sid,
-                           d_cp_for_q32, range_bits, apart, d_also_apart, d_keys, d_vals, d_err);
+                           d_cp_for_q32, range_bits, apart, apart ? split : 0, d_also_apart, d_keys, d_vals, d_err);
         RSEM_HIP_TRY(hipGetLastError());
         size_t tb = 0;
         RSEM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_keys, d_keys2, d_vals, L.d_order, N1, 0, 64, st));
@@ -432,6 +602,10 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     L.val_bytes = 0;
     L.n_q32_rows = 0;
     L.n_q32_planes = 0;
+    L.n_x_rows = 0;
+    L.x_row_base = 0;
+    L.x_slot_base = 0;
+    L.n_far = 0;
     uint32_t long_first = (h_first[kLongShape] == 0xffffffffu) ? (uint32_t)N1 : h_first[kLongShape];
     L.n_sell_rows = long_first;
     L.n_long_rows = (uint32_t)N1 - long_first;
@@ -457,6 +631,10 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
         L.n_slots += S.n_slices * rps;
         L.val_bytes += (uint64_t)S.n_slices * S.K * plane_bytes(S.fmt);
         if (S.fmt == kFmtQ32) { L.n_q32_rows += S.n_rows; L.n_q32_planes += (uint64_t)S.n_slices * S.K; }
+        if (S.fmt == kFmtF64X) {  // (the split shapes are the last ones of the table: their rows and slots are contiguous)
+            if (!L.n_x_rows) { L.x_row_base = S.row_base; L.x_slot_base = S.slot_base; }
+            L.n_x_rows += S.n_rows;
+        }
     }
     // slices per block: enough blocks to fill the chip a few times over, long enough lane runs
     uint32_t T = forced_T ? forced_T : L.n_slices / std::max(1u, target_waves);
@@ -468,11 +646,15 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     RSEM_HIP_TRY(dmalloc(&L.d_slice_minsid, (size_t)L.n_slices));
     RSEM_HIP_TRY(dmalloc(&L.d_slice_maxsid, (size_t)L.n_slices));
     RSEM_HIP_TRY(hipMemsetAsync(L.d_ssid, 0, sizeof(int32_t) * L.n_planes * 64, st));
+    if (L.n_x_rows) {
+        const int frc = sell_build_far(L, st, d_row_ptr, d_sid, d_keys2);
+        if (frc != RSEM_OK) { cleanup(); return frc; }
+    }
     if (L.n_sell_rows) {
         hipLaunchKernelGGL(k_fill_sell<true>, dim3(rsem::ceil_div(L.n_sell_rows, kBlock)), dim3(kBlock), 0, st,
                            L.d_shapes, L.n_shapes, L.T, L.n_sell_rows, L.d_order, d_row_ptr, d_sid, (const double*)nullptr,
                            (const double*)nullptr, L.d_ssid, (unsigned char*)nullptr, (double*)nullptr, (int16_t*)nullptr,
-                           (int*)nullptr);
+                           (int*)nullptr, (const uint32_t*)L.d_xanchor, L.x_row_base, kLayoutWindow);
         RSEM_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_slice_minsid, dim3(rsem::ceil_div(L.n_slices, kBlock)), dim3(kBlock), 0, st, L.d_shapes,
                            L.n_shapes, L.T, L.n_slices, d_keys2, L.d_slice_minsid);
@@ -630,12 +812,12 @@ __global__ __launch_bounds__(256) void k_mark_stray_reads(const Unit* __restrict
 // `units` (allocated here; the caller owns it).  RSEM_HIP_APART=0 switches the apart bit and this refinement off.
 inline int sell_build_refined(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, const uint64_t* d_row_ptr, const int32_t* d_sid,
                               uint32_t target_waves, uint32_t forced_T, const double* d_cp_for_q32, int range_bits, int window_cap,
-                              std::vector<Unit>& units, Unit** d_units, unsigned long long* n_strays = nullptr) {
+                              std::vector<Unit>& units, Unit** d_units, unsigned long long* n_strays = nullptr, int split = 0) {
     unsigned char* d_also = nullptr;
     unsigned long long* d_n = nullptr;
     if (n_strays) *n_strays = 0;
     for (int pass = 0; pass < 2; pass++) {
-        int rc = sell_build(L, st, N1, M, d_row_ptr, d_sid, target_waves, forced_T, d_cp_for_q32, range_bits, d_also);
+        int rc = sell_build(L, st, N1, M, d_row_ptr, d_sid, target_waves, forced_T, d_cp_for_q32, range_bits, d_also, split);
         if (rc == RSEM_OK) rc = sell_build_units(L, units, window_cap);
         if (rc != RSEM_OK) { (void)hipFree(d_also); return rc; }
         (void)hipFree(*d_units);

@@ -3,7 +3,10 @@
 // by model.hip, whose round kernel writes the alignment probabilities straight into the value planes.
 #pragma once
 
-constexpr int kFmtF64 = 0, kFmtQ32 = 1;  // value plane formats (sell_layout.hpp)
+// value plane formats (sell_layout.hpp).  F64X: doubles, rows that are only the IN-WINDOW part of a read whose other
+// alignments live in the far-entry side arrays (split rows); such a row carries an extra term in its normaliser and hands
+// its reciprocal on.
+constexpr int kFmtF64 = 0, kFmtQ32 = 1, kFmtF64X = 2;
 
 struct Shape {
     uint64_t plane_base;  // first plane of this shape (one plane = 64 entries)

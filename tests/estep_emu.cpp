@@ -32,6 +32,7 @@ struct Job {
     double* tot_noise;
     double* tot_neff;
     double th_win[kWindow], cnt_win[kWindow];
+    XArgs xa;  // split rows (policy 2)
     emu::Block blk;
 };
 
@@ -48,26 +49,40 @@ static void lane_body(Job* J, int tid) {
     const uint32_t s_end = std::min(u_end, s_begin + per_wave);
     const double* tsrc = J->theta + J->M + 1;
     double noise = 0.0, neff = 0.0;
-#define EMU_BLOCK(KK, QQ, FF)                                                                                                      \
-    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF>(S, s_begin, s_end, lane, J->base, J->span, J->theta, tsrc, J->N0, \
-        J->th_win, J->cnt_win, H.sval.data(), H.sexp.data(), H.ssid.data(), H.sncp.data(), H.masks.data(), J->counts, noise, neff, J->M)
-    if (s_begin < u_end) switch (S.K + 4 * S.fmt + (J->far ? 8 : 0)) {
-        case 1: EMU_BLOCK(1, false, false); break;
-        case 2: EMU_BLOCK(2, false, false); break;
-        case 3: EMU_BLOCK(3, false, false); break;
-        case 4: EMU_BLOCK(4, false, false); break;
-        case 5: EMU_BLOCK(1, true, false); break;
-        case 6: EMU_BLOCK(2, true, false); break;
-        case 7: EMU_BLOCK(3, true, false); break;
-        case 8: EMU_BLOCK(4, true, false); break;
-        case 9: EMU_BLOCK(1, false, true); break;
-        case 10: EMU_BLOCK(2, false, true); break;
-        case 11: EMU_BLOCK(3, false, true); break;
-        case 12: EMU_BLOCK(4, false, true); break;
-        case 13: EMU_BLOCK(1, true, true); break;
-        case 14: EMU_BLOCK(2, true, true); break;
-        case 15: EMU_BLOCK(3, true, true); break;
-        default: EMU_BLOCK(4, true, true); break;
+#define EMU_BLOCK(KK, QQ, FF, XX)                                                                                                      \
+    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF, XX>(S, s_begin, s_end, lane, J->base, J->span, J->theta, tsrc, J->N0, \
+        J->th_win, J->cnt_win, H.sval.data(), H.sexp.data(), H.ssid.data(), H.sncp.data(), H.masks.data(), J->counts, noise, neff, J->M, J->xa)
+    // the dispatch of k_estep_lane (em.hip)
+    const int code = (S.K - 1) | ((S.fmt == kFmtQ32 ? 1 : 0) << 2) | ((J->far ? 1 : 0) << 3) | (((!kFC && S.fmt == kFmtF64X) ? 1 : 0) << 4);
+    if (s_begin < u_end) switch (code) {
+        case 0: EMU_BLOCK(1, false, false, false); break;
+        case 1: EMU_BLOCK(2, false, false, false); break;
+        case 2: EMU_BLOCK(3, false, false, false); break;
+        case 3: EMU_BLOCK(4, false, false, false); break;
+        case 4: EMU_BLOCK(1, true, false, false); break;
+        case 5: EMU_BLOCK(2, true, false, false); break;
+        case 6: EMU_BLOCK(3, true, false, false); break;
+        case 7: EMU_BLOCK(4, true, false, false); break;
+        case 8: EMU_BLOCK(1, false, true, false); break;
+        case 9: EMU_BLOCK(2, false, true, false); break;
+        case 10: EMU_BLOCK(3, false, true, false); break;
+        case 11: EMU_BLOCK(4, false, true, false); break;
+        case 12: EMU_BLOCK(1, true, true, false); break;
+        case 13: EMU_BLOCK(2, true, true, false); break;
+        case 14: EMU_BLOCK(3, true, true, false); break;
+        case 15: EMU_BLOCK(4, true, true, false); break;
+        default:
+            if constexpr (!kFC) switch (code & 11) {
+                case 0: EMU_BLOCK(1, false, false, true); break;
+                case 1: EMU_BLOCK(2, false, false, true); break;
+                case 2: EMU_BLOCK(3, false, false, true); break;
+                case 3: EMU_BLOCK(4, false, false, true); break;
+                case 8: EMU_BLOCK(1, false, true, true); break;
+                case 9: EMU_BLOCK(2, false, true, true); break;
+                case 10: EMU_BLOCK(3, false, true, true); break;
+                default: EMU_BLOCK(4, false, true, true); break;
+            }
+            break;
     } else {
         const ThetaSrc th = theta_src<kFC>(J->theta, tsrc, J->N0, lane);
         stage_windows<kFC>(J->base, J->span, J->M, th, J->th_win, J->cnt_win);
@@ -104,7 +119,18 @@ int main(int argc, char** argv) {
     build_layout(H, M, N1, rp.data(), sid.data(), cp.data(), ncp.data(), hdr[3], hdr[4] != 0, hdr[5], hdr[3] == 1 ? 0 : (hdr[7] > 0 ? hdr[7] : kLayoutWindow));  // hdr[3] = 1: the key without its apart bit; a smaller window is also the bit's reach
     std::vector<double> counts((size_t)M + 1, 0.0);
     double tot_noise = 0.0, tot_neff = 0.0;
+    // split rows (policy 2, plain theta only): k_far_rowsum of em.hip before the blocks ...
+    std::vector<double> xextra(H.n_slots - H.x_slot_base + 1, 0.0), xinv(H.n_slots - H.x_slot_base + 1, 0.0);
+    if (!H.far.empty() && from_counts) { fprintf(stderr, "estep_emu: split rows need a plain theta\n"); return 5; }
+    for (const HostLayout::Far& e : H.far) {
+        double fv = theta[e.sid] * e.cp;
+        if (fv < kEpsilon) fv = 0.0;
+        xextra[e.slot - H.x_slot_base] += fv;
+    }
     Job* J = new Job();
+    J->xa.extra = xextra.data();
+    J->xa.inv = xinv.data();
+    J->xa.slot_base = H.x_slot_base;
     pthread_barrier_init(&J->blk.bar, nullptr, 256);
     for (int w = 0; w < 4; w++) pthread_barrier_init(&J->blk.w[w].bar, nullptr, 64);
     for (const Shape& S : H.shapes) {
@@ -139,6 +165,13 @@ int main(int argc, char** argv) {
             for (auto& t : th) t.join();
         }
     }
+    // ... and k_far_colsum after them: the far alignments' fractions with the reciprocal normalisers the blocks left
+    for (const HostLayout::Far& e : H.far) {
+        double fv = theta[e.sid] * e.cp;
+        if (fv < kEpsilon) fv = 0.0;
+        counts[e.sid] += fv * xinv[e.slot - H.x_slot_base];
+    }
+    fprintf(stderr, "estep_emu: %zu far entries of split rows\n", H.far.size());
     f = fopen(argv[2], "wb");
     if (!f) return 4;
     fwrite(counts.data(), 8, counts.size(), f);

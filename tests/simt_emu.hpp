@@ -113,6 +113,11 @@ struct HostLayout {
     std::vector<int16_t> sexp;
     std::vector<unsigned long long> masks;
     uint32_t n_slices = 0;
+    // split rows (policy 2): far entries in file order, each with the row slot of its read; extra / inv per slot from x_slot_base
+    struct Far { int32_t sid; double cp; uint32_t slot; };
+    std::vector<Far> far;
+    uint32_t x_slot_base = 0, n_slots = 0;
+    bool has_x = false;
 };
 
 static void build_layout(HostLayout& H, int M, uint64_t N1, const uint64_t* rp, const int32_t* sid, const double* cp, const double* ncp,
@@ -122,7 +127,7 @@ static void build_layout(HostLayout& H, int M, uint64_t N1, const uint64_t* rp, 
     (void)policy;
     for (uint64_t i = 0; i < N1; i++) {
         int err = 0;
-        const uint64_t key = row_key_of(i, M, rp, sid, q32 ? cp : nullptr, range_bits, apart, &err);
+        const uint64_t key = row_key_of(i, M, rp, sid, q32 ? cp : nullptr, range_bits, apart, &err, policy == 2 ? 1 : 0);
         if (err) { fprintf(stderr, "simt_emu: bad CSR (%d)\n", err); exit(2); }
         if ((int)(key >> (64 - kShapeBits)) == kLongShape) { fprintf(stderr, "simt_emu: rows with more than 256 alignments are not modelled\n"); exit(2); }
         keyed[i] = {key, (uint32_t)i};
@@ -150,6 +155,7 @@ static void build_layout(HostLayout& H, int M, uint64_t N1, const uint64_t* rp, 
         S.val_base = val_bytes;
         H.n_slices += S.n_slices;
         n_planes += (uint64_t)S.n_slices * S.K;
+        if (S.fmt == kFmtF64X && !H.has_x) { H.x_slot_base = n_slots; H.has_x = true; }
         n_slots += S.n_slices * rps;
         val_bytes += (uint64_t)S.n_slices * S.K * plane_bytes(S.fmt);
         H.shapes.push_back(S);
@@ -159,6 +165,7 @@ static void build_layout(HostLayout& H, int M, uint64_t N1, const uint64_t* rp, 
     H.sval.assign(val_bytes + 8, 0);
     H.sncp.assign(n_slots + 1, 0.0);
     H.sexp.assign(n_slots + 1, 0);
+    H.n_slots = n_slots;
     // planes: sell_fill_row (the body of k_fill_sell)
     for (const Shape& S : H.shapes)
         for (uint32_t q = 0; q < S.n_rows; q++) {
@@ -168,8 +175,18 @@ static void build_layout(HostLayout& H, int M, uint64_t N1, const uint64_t* rp, 
                 if (!slot_to_row(S, H.T, sl, r, back) || back != q) { fprintf(stderr, "simt_emu: slot_to_row(row_to_slot(%u)) = %u\n", q, back); exit(2); }
             }
             int err = 0;
-            sell_fill_row<true>(S, H.T, S.row_base + q, H.order.data(), rp, sid, cp, ncp, H.ssid.data(), H.sval.data(), H.sncp.data(), H.sexp.data(), &err);
+            const uint32_t anchor = (uint32_t)((keyed[S.row_base + q].first >> 32) & kKeyMinSidCap);
+            sell_fill_row<true>(S, H.T, S.row_base + q, H.order.data(), rp, sid, cp, ncp, H.ssid.data(), H.sval.data(), H.sncp.data(), H.sexp.data(), &err,
+                                anchor, apart);
             if (err) { fprintf(stderr, "simt_emu: inconsistent Q32 decision\n"); exit(2); }
+            if (S.fmt == kFmtF64X) {  // the far entries of a split row (k_x_far of sell_layout.hpp)
+                uint32_t sl, r;
+                row_to_slot(S, H.T, q, sl, r);
+                const uint32_t slot = S.slot_base + sl * shape_R(S) + r;
+                const uint32_t orig = H.order[S.row_base + q];
+                for (uint64_t j = rp[orig]; j < rp[orig + 1]; j++)
+                    if (!in_split_window(sid[j], anchor, apart)) H.far.push_back({sid[j], cp ? cp[j] : 0.0, slot});
+            }
         }
     // masks: slice_lane_changed / read_lanes_of (the body of k_slice_masks; its two ballots are the loops over l)
     H.masks.assign(H.n_slices, 0);

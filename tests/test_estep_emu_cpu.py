@@ -101,7 +101,10 @@ def _check(exe, seed=1, **kw):
 
 CASES = [dict(), dict(from_counts=1), dict(window=64), dict(q32=1), dict(q32=1, range_bits=24, T=7, seed=2), dict(T=1, window=16, seed=3),
          # policy=1: the sort key without its apart bit (reads that reach beyond the window stay among the others)
-         dict(policy=1, window=64), dict(policy=1, window=16, from_counts=1, T=3, seed=2)]
+         dict(policy=1, window=64), dict(policy=1, window=16, from_counts=1, T=3, seed=2),
+         # policy=2: split rows -- a read that reaches beyond the window keeps its in-window alignments in the planes (F64X shapes,
+         # an extra term in its normaliser, its reciprocal handed on), the others are far entries summed before / after the blocks
+         dict(policy=2, window=64), dict(policy=2, window=16, T=3, seed=2), dict(policy=2, window=128, T=1, seed=3)]
 
 
 @pytest.mark.parametrize("kw", CASES, ids=lambda k: "-".join("%s%s" % kv for kv in sorted(k.items())) or "plain")

@@ -36,6 +36,7 @@ FAST_CONFIGS = {
     "C5": (100_000_000, 500_000, 40.0, (32, 64), 0.0),
     # configs[2] with cross-gene multi-mappers (paralogs): between C3 (no read leaves its gene) and C2R (no genes at all)
     "C3X": (50_000_000, 200_000, 10.0, (8, 24), 0.10),
+    "C3X30": (50_000_000, 200_000, 10.0, (8, 24), 0.30),  # ... and with 30 % such reads
     "tinyX": (20_000, 400, 5.0, (4, 12), 0.25),
     "smallX": (300_000, 20_000, 6.0, (4, 12), 0.30),  # more ids than an LDS window holds: cross-gene hits really leave it
 }
