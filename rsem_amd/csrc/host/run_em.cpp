@@ -489,13 +489,18 @@ int main(int argc, char* argv[]) {
     std::vector<uint8_t> ref_seq(ref_off[M + 1]);
     std::vector<uint32_t> mask_words(mask_off[M + 1]);
     const int8_t* tbl = base_table();
-    for (int i = 1; i <= M; i++) {
-        for (size_t k = 0; k < refs.seq[i].size(); k++) {
-            int8_t id = tbl[(unsigned char)refs.seq[i][k]];
-            if (id < 0) die("Found unknown sequence letter %c at function get_base_id!", refs.seq[i][k]);
-            ref_seq[ref_off[i] + k] = (uint8_t)id;
-        }
-        std::copy(refs.masks[i].begin(), refs.masks[i].end(), mask_words.begin() + mask_off[i]);
+    {
+        const int nt = M > 2000 ? hardware_threads() : 1;  // (0.6 GB of letters at GENCODE scale: not a job for one thread)
+        parallel_for(nt, [&](int t) {
+            for (int i = 1 + t; i <= M; i += nt) {
+                for (size_t k = 0; k < refs.seq[i].size(); k++) {
+                    int8_t id = tbl[(unsigned char)refs.seq[i][k]];
+                    if (id < 0) die("Found unknown sequence letter %c at function get_base_id!", refs.seq[i][k]);
+                    ref_seq[ref_off[i] + k] = (uint8_t)id;
+                }
+                std::copy(refs.masks[i].begin(), refs.masks[i].end(), mask_words.begin() + mask_off[i]);
+            }
+        });
     }
     each_shard([&](Shard& X, int) {
         rsem_model_data md;
