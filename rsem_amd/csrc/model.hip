@@ -571,6 +571,11 @@ __global__ __launch_bounds__(kGroupBlk) RSEM_GROUP_ATTR void k_model_group(DevDa
     __shared__ double s_noise[kUpdate ? kNoiseLds : 1];
     __shared__ double s_rspd[kUpdate ? kRspdLds : 1];
     __shared__ double s_gld[kUpdate ? kGldLds : 1];
+    __shared__ Shape s_shapes[kPlaneShapesMax];              // the EM layout's shape table (every read looks its shape up)
+    if (PO.rank) {
+        for (int i = threadIdx.x; i < PO.n_shapes && i < kPlaneShapesMax; i += blockDim.x) s_shapes[i] = PO.shapes[i];
+        PO.shapes = s_shapes;
+    }
     if (kQ) for (int i = threadIdx.x; i < 2500; i += blockDim.x) s_prob[i] = T.prof[i];
     for (int i = threadIdx.x; i < (kQ ? 500 : 5); i += blockDim.x) s_nprob[i] = T.noise[i];
     constexpr int kProfCap = kQ ? 2500 : kProfLds;           // entries of the count table held in LDS (the rest: global atomics)

@@ -80,12 +80,23 @@ struct DevData {
 // only (the model rounds run before the planes are switched to Q32); reads with > 256 alignments live in the CSR alone.
 struct PlaneOut {
     const uint32_t* rank;   // caller row -> sorted row (inverse of SellLayout::d_order); nullptr: no plane output
-    const Shape* shapes;
+    const Shape* shapes;    // the layout's shape table (the kernel keeps a copy in LDS: every read looks its shape up)
     int n_shapes;
     uint32_t T, n_sell_rows;
     unsigned char* sval;
     double* sncp;
 };
+constexpr int kPlaneShapesMax = 96;  // >= kMaxShapes of sell_layout.hpp
+
+// the shape a sorted row belongs to: the last one whose first row is <= ps (binary search over the LDS copy)
+RSEM_DEVFN int plane_shape_of(const Shape* shapes, int n_shapes, uint32_t ps) {
+    int lo = 0, hi = n_shapes;  // shapes[lo].row_base <= ps < shapes[hi].row_base (hi == n: past the end)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (shapes[mid].row_base <= ps) lo = mid; else hi = mid;
+    }
+    return lo;
+}
 
 struct AccumPtrs {
     double* prof;   // [prof_rows*25]
@@ -166,13 +177,13 @@ RSEM_DEVFN int grp_ctz(unsigned m) {  // index of the lowest set bit of a 16-bit
     return i;
 }
 
-// One mate of a group's read: where its packed words are, its length, and the first 128 positions' words of lane g
-// (positions 8g .. 8g+7): kept in registers for all the products and count updates of the read.
+// One mate of a group's read: where its packed words are and its length.  (The words of lane g are loaded where they are used,
+// every time: L1 hits, against 8 registers per lane that would cost the kernel's fourth wave per SIMD.)
 struct MateWords {
-    const uint64_t* seq;
+    const uint64_t* seq;   // base of the mate's word arrays (uniform: scalar registers) ...
     const uint64_t* qual;
+    uint64_t r8;           // ... and the read's first word in them
     int len;
-    uint64_t s0, q0;
 };
 
 // (Q)Profile::getProb over the lane's share of the read (QProfile.h:111-120, Profile.h:114-120): positions 8wi..8wi+7 for
@@ -185,8 +196,8 @@ RSEM_DEVFN double lane_profile_product(const double* prof, const MateWords& W, c
     const int sh = (int)(a & 7) * 8;
     for (int wi = g; wi * 8 < W.len; wi += kGrp) {
         const uint64_t rf = funnel8(rw[wi], rw[wi + 1], sh);
-        const uint64_t sb = wi < kGrp ? W.s0 : W.seq[wi];
-        const uint64_t qb = kQ ? (wi < kGrp ? W.q0 : W.qual[wi]) : 0;
+        const uint64_t sb = W.seq[W.r8 + wi];
+        const uint64_t qb = kQ ? W.qual[W.r8 + wi] : 0;
         const int n = W.len - wi * 8;
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -207,8 +218,8 @@ RSEM_DEVFN void lane_profile_update(double* s_prof, double* g_prof, const MateWo
     const int sh = (int)(a & 7) * 8;
     for (int wi = g; wi * 8 < W.len; wi += kGrp) {
         const uint64_t rf = funnel8(rw[wi], rw[wi + 1], sh);
-        const uint64_t sb = wi < kGrp ? W.s0 : W.seq[wi];
-        const uint64_t qb = kQ ? (wi < kGrp ? W.q0 : W.qual[wi]) : 0;
+        const uint64_t sb = W.seq[W.r8 + wi];
+        const uint64_t qb = kQ ? W.qual[W.r8 + wi] : 0;
         const int n = W.len - wi * 8 < 8 ? W.len - wi * 8 : 8;
         for (int u = 0; u < n; u++) {
             const int row = kQ ? (int)((qb >> (8 * u)) & 0xff) : wi * 8 + u;
@@ -224,8 +235,8 @@ RSEM_DEVFN double lane_noise_product(const double* nprob, const MateWords& W, in
     double p = 1.0;
     if (!on) return p;
     for (int wi = g; wi * 8 < W.len; wi += kGrp) {
-        const uint64_t sb = wi < kGrp ? W.s0 : W.seq[wi];
-        const uint64_t qb = kQ ? (wi < kGrp ? W.q0 : W.qual[wi]) : 0;
+        const uint64_t sb = W.seq[W.r8 + wi];
+        const uint64_t qb = kQ ? W.qual[W.r8 + wi] : 0;
         const int n = W.len - wi * 8;
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -239,8 +250,8 @@ RSEM_DEVFN double lane_noise_product(const double* nprob, const MateWords& W, in
 template <bool kQ>
 RSEM_DEVFN void lane_noise_update(double* s_noise, const MateWords& W, int g, double frac) {
     for (int wi = g; wi * 8 < W.len; wi += kGrp) {
-        const uint64_t sb = wi < kGrp ? W.s0 : W.seq[wi];
-        const uint64_t qb = kQ ? (wi < kGrp ? W.q0 : W.qual[wi]) : 0;
+        const uint64_t sb = W.seq[W.r8 + wi];
+        const uint64_t qb = kQ ? W.qual[W.r8 + wi] : 0;
         const int n = W.len - wi * 8 < 8 ? W.len - wi * 8 : 8;
         for (int u = 0; u < n; u++) {
             const int b = (int)((sb >> (8 * u)) & 0xff);
@@ -324,28 +335,25 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
         MateWords W[kMates];
 #pragma unroll
         for (int m = 0; m < kMates; m++) {
-            const uint64_t r8 = active ? D.roff8[m][row] : 0;
-            W[m].seq = D.rseq_w[m] + r8;
-            W[m].qual = kQ ? D.rqual_w[m] + r8 : nullptr;
+            W[m].r8 = active ? D.roff8[m][row] : 0;
+            W[m].seq = D.rseq_w[m];
+            W[m].qual = kQ ? D.rqual_w[m] : nullptr;
             W[m].len = active ? D.rlen[m][row] : 0;
-            const bool mine = g * 8 < W[m].len;
-            W[m].s0 = mine ? W[m].seq[g] : 0;
-            W[m].q0 = (kQ && mine) ? W[m].qual[g] : 0;
         }
         const int len1 = W[0].len, len2 = kPE ? W[kMates - 1].len : 0;
         // the read's place in the sliced layout: alignment c goes to plane c >> lg of its slice, lane r * G + (c & (G - 1))
         double* plane = nullptr;
+        double* nslot = nullptr;  // the read's noise value in the layout
         int p_lg = 0;
         uint32_t p_r = 0;
         if (PO.rank && valid) {
             const uint32_t ps = PO.rank[row];
             if (ps < PO.n_sell_rows) {
-                int sh = 0;
-                while (sh + 1 < PO.n_shapes && ps >= PO.shapes[sh + 1].row_base) ++sh;
-                const Shape S = PO.shapes[sh];
+                const Shape& S = PO.shapes[plane_shape_of(PO.shapes, PO.n_shapes, ps)];
                 uint32_t slice_local;
                 row_to_slot(S, PO.T, ps - S.row_base, slice_local, p_r);
                 plane = (double*)(PO.sval + S.val_base) + (uint64_t)slice_local * S.K * 64;
+                nslot = PO.sncp + (S.slot_base + slice_local * shape_R(S) + p_r);
                 p_lg = S.lg;
                 p_r = (p_r << p_lg);  // first lane of the read within a plane row
             }
@@ -408,7 +416,6 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
         };
 
         double rowsum = 0.0;  // sum over the read's alignments of theta * conprb (each clamped), for the weights
-        ChunkRegs R0;         // chunk 0 stays in registers for the second pass (reads of <= 16 alignments: nearly all)
         const int nchunks = (maxL + kGrp - 1) / kGrp;
         for (int c = 0; c < nchunks; c++) {
             ChunkRegs R;
@@ -439,7 +446,6 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
                 if (f < kEpsilon) f = 0.0;
                 rowsum += grp_sum(f);
             }
-            if (c == 0) R0 = R;
         }
         // noise (getNoiseConPrb): SingleQModel.h:153-162, PairedEndQModel.h:140-155
         double nval = 0.0;
@@ -457,15 +463,7 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
             if (!active) nval = 0.0;
             if (valid && g == 0) {
                 ncp[row] = nval;
-                if (plane) {
-                    const uint32_t ps = PO.rank[row];
-                    int sh = 0;
-                    while (sh + 1 < PO.n_shapes && ps >= PO.shapes[sh + 1].row_base) ++sh;
-                    const Shape S = PO.shapes[sh];
-                    uint32_t slice_local, r;
-                    row_to_slot(S, PO.T, ps - S.row_base, slice_local, r);
-                    PO.sncp[S.slot_base + slice_local * shape_R(S) + r] = nval;
-                }
+                if (nslot) *nslot = nval;
             }
         }
         if (!kUpdate) continue;
@@ -479,12 +477,11 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
 #pragma unroll
         for (int m = 0; m < kMates; m++) carry_a[m] = 0;
         for (int c = 0; c < nchunks; c++) {
+            // (the chunk is loaded again rather than kept: L1 / L2 hits, against 16 registers that cost the kernel its fourth
+            // wave per SIMD or 14 GB of scratch traffic per launch at a fifth of configs[2], profiles/r04c_model_group_pmc_fifth_size.json)
             ChunkRegs R;
-            if (c == 0) R = R0;
-            else {
-                load_chunk(c, R);
-                R.cp = R.has ? cp[fr + (uint64_t)(c * kGrp + g)] : 0.0;
-            }
+            load_chunk(c, R);
+            R.cp = R.has ? cp[fr + (uint64_t)(c * kGrp + g)] : 0.0;
             double f = R.has ? theta[R.sid] * R.cp : 0.0;
             if (f < kEpsilon) f = 0.0;
             double w = ok ? f / sum : 0.0;
