@@ -210,35 +210,69 @@ __global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_x, const uint6
     if (ctrl->done) return;
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n_x) return;
+    const uint64_t e0 = far_ptr[x], e1 = far_ptr[x + 1];
+    const uint32_t slot = xslot[x];
     double sum = 0.0;
-    for (uint64_t e = far_ptr[x]; e < far_ptr[x + 1]; e++) {
-        double f = theta[far_sid[e]] * far_cp[e];
-        if (f < kEpsilon) f = 0.0;
-        sum += f;
+    // four entries at a time, their loads issued together (the pass is a chain of dependent trips to memory: pointer ->
+    // entries -> theta; with one entry per trip a read of four took nine of them, profiles/r04d_call.log)
+    for (uint64_t e = e0; e < e1; e += 4) {
+        int id[4];
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool in = e + u < e1;
+            id[u] = in ? far_sid[e + u] : 0;
+            v[u] = in ? stream_load(&far_cp[e + u]) : 0.0;
+        }
+        double t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) t[u] = theta[id[u]];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            double f = t[u] * v[u];
+            if (f < kEpsilon) f = 0.0;
+            sum += f;
+        }
     }
-    extra[xslot[x] - slot_base] = sum;
+    extra[slot - slot_base] = sum;
 }
 // After: the far alignments' fractions, theta[sid] * conprb / normaliser of their read (inv[], left by the lane kernel), added
 // to counts[sid] in transcript order: consecutive entries of one id are summed by a segmented shuffle reduction, one atomic
-// per id and wave -- the transposed (CSC) pass instead of a global atomic per alignment.
+// per id and wave -- the transposed (CSC) pass instead of a global atomic per alignment.  A wave takes 4 x 64 consecutive
+// entries per step and issues all their loads, then all their gathers, before it reduces.
 __global__ __launch_bounds__(kBlock) void k_far_colsum(uint64_t n_far, const int32_t* __restrict__ csc_sid, const double* __restrict__ csc_cp,
                                                         const uint32_t* __restrict__ csc_slot, uint32_t slot_base, const double* __restrict__ theta,
                                                         const double* __restrict__ inv, double* counts, const Ctrl* ctrl) {
     if (ctrl->done) return;
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t b = wave * 64; b < n_far; b += n_waves * 64) {  // (uniform over the wave)
-        const uint64_t i = b + (uint64_t)lane;
-        int key = -1;
-        double v = 0.0;
-        if (i < n_far) {
-            key = csc_sid[i];
-            double f = theta[key] * stream_load(&csc_cp[i]);
-            if (f < kEpsilon) f = 0.0;
-            v = f * inv[csc_slot[i] - slot_base];
+    constexpr int kU = 4;
+    for (uint64_t b = wave * (64 * kU); b < n_far; b += n_waves * (64 * kU)) {  // (uniform over the wave)
+        int key[kU];
+        double cv[kU];
+        uint32_t sl[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const uint64_t i = b + (uint64_t)(u * 64 + lane);
+            const bool in = i < n_far;
+            key[u] = in ? csc_sid[i] : -1;
+            cv[u] = in ? stream_load(&csc_cp[i]) : 0.0;
+            sl[u] = in ? csc_slot[i] : slot_base;
         }
-        const bool tail = seg_reduce(key, v, lane, 0);
-        if (tail && key > 0 && v != 0.0) unsafeAtomicAdd(&counts[key], v);
+        double th[kU], iv[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            th[u] = theta[key[u] > 0 ? key[u] : 0];
+            iv[u] = inv[sl[u] - slot_base];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            double f = th[u] * cv[u];
+            if (f < kEpsilon) f = 0.0;
+            double v = key[u] > 0 ? f * iv[u] : 0.0;
+            const bool tail = seg_reduce(key[u], v, lane, 0);
+            if (tail && key[u] > 0 && v != 0.0) unsafeAtomicAdd(&counts[key[u]], v);
+        }
     }
 }
 
@@ -941,7 +975,7 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
                                d_theta, (const double*)nullptr, 0.0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid,
                                c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs(), xa);
         if (c->L.n_far) {  // ... and their far alignments' fractions afterwards, in transcript order
-            const int grid = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_far, kBlock)));
+            const int grid = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_far, kBlock * 4)));
             hipLaunchKernelGGL(k_far_colsum, dim3(grid), dim3(kBlock), 0, st, c->L.n_far, (const int32_t*)c->L.d_csc_sid, (const double*)c->L.d_csc_cp,
                                (const uint32_t*)c->L.d_csc_slot, c->L.x_slot_base, d_theta, (const double*)c->d_xinv, d_counts, ctrl);
         }
@@ -1722,8 +1756,8 @@ namespace rsem {
 int em_device_view(rsem_em_ctx* c, EmDeviceView* v) {
     RSEM_REQUIRE(c && v, "NULL argument");
     RSEM_HIP_TRY(hipSetDevice(c->device));
-    if (!c->d_w) RSEM_HIP_TRY(dmalloc(&c->d_w, c->nnz));
-    if (!c->d_wn) RSEM_HIP_TRY(dmalloc(&c->d_wn, c->N1));
+    // (the weight buffers -- 8 B per alignment -- are allocated by the first pass that fills them, em_step_with_weights /
+    // rsem_em_expected_weights: the round kernel of model.hip never needs them)
     v->device = c->device;
     v->stream = c->stream;
     v->M = c->M;

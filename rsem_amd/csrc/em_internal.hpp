@@ -28,7 +28,7 @@ struct EmPlanesView {
     double* d_sncp;
 };
 
-// device pointers of the ctx (allocates the weight buffers on first use)
+// device pointers of the ctx (d_w / d_wn are NULL until a weights pass has run: take the view again after em_step_with_weights)
 int em_device_view(rsem_em_ctx* c, EmDeviceView* v);
 // d_cp / d_ncp were rewritten on the device: rebuild the sliced value planes
 int em_values_changed(rsem_em_ctx* c);

@@ -1000,6 +1000,8 @@ int rsem_model_estep_update(rsem_model_ctx* c, const double* theta, double N0, d
     RSEM_REQUIRE(!c->T.estRSPD || acc->rspd, "estRSPD needs the rspd accumulator");
     int rc = rsem::em_step_with_weights(c->em, theta, N0, counts, theta_new, sum, bChange, totNum);
     if (rc != RSEM_OK) return rc;
+    rc = rsem::em_device_view(c->em, &c->v);  // (the weight buffers exist from the first such pass on)
+    if (rc != RSEM_OK) return rc;
     RSEM_HIP_TRY(hipSetDevice(c->v.device));
     hipStream_t st = c->v.stream;
     const size_t np = (size_t)c->T.prof_rows * 25, nn = q ? 500 : 5, nr = (size_t)c->T.B + 2;

@@ -165,7 +165,12 @@ __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint
             else { ++L_in; h_in = mix32(h_in, v); }
         }
     int shape = shape_id_of(to - fr);
-    if (far && split && shape != kLongShape && (uint64_t)mn <= kKeyMinSidCap) {  // split row: keyed by its in-window part
+    // Split only where the far alignments are at least half of the read (a read without a gene to speak of: each of its
+    // alignments would otherwise be a global atomic per round).  A read of a gene that ALSO hits a few transcripts elsewhere
+    // stays whole: as a row of its own shape its tuple runs are too short for the lane kernel to skip anything (a wave
+    // re-reads its ids whenever ANY of its 64 lanes starts a new tuple), so the split only added the two side passes
+    // (configs[2] with 10 % such reads: 1.48 ms split against 1.17-1.25 whole, profiles/r04d_call.log).
+    if (far && split && 2 * L_in <= L && shape != kLongShape && (uint64_t)mn <= kKeyMinSidCap) {  // split row: keyed by its in-window part
         shape = shape_id_of(L_in) + 2 * kShapesPerFmt;
         return ((uint64_t)shape << (64 - kShapeBits)) | ((uint64_t)mn << 32) | h_in;
     }
