@@ -204,14 +204,13 @@ __device__ inline bool seg_reduce(int key, double& v, int lane, int lg) {
 // ---- split rows: the two passes around the lane kernel (sell_layout.hpp: sell_build_far) ----------------------------------------
 // Before: the far part of every split read's normaliser, sum over its far alignments of theta[sid] * conprb (each clamped
 // like every term of EM.cpp:212-219).  Thread per read: a split read has a handful of far alignments.
-__global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_x, const uint64_t* __restrict__ far_ptr, const int32_t* __restrict__ far_sid,
-                                                        const double* __restrict__ far_cp, const uint32_t* __restrict__ xslot, uint32_t slot_base,
-                                                        const double* __restrict__ theta, double* __restrict__ extra, const Ctrl* ctrl) {
+__global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_xs, const uint64_t* __restrict__ far_ptr, const int32_t* __restrict__ far_sid,
+                                                        const double* __restrict__ far_cp, const double* __restrict__ theta, double* __restrict__ extra,
+                                                        const Ctrl* ctrl) {
     if (ctrl->done) return;
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= n_x) return;
-    const uint64_t e0 = far_ptr[x], e1 = far_ptr[x + 1];
-    const uint32_t slot = xslot[x];
+    const uint32_t xs = blockIdx.x * blockDim.x + threadIdx.x;  // row slot - x_slot_base (far entries are kept in slot order)
+    if (xs >= n_xs) return;
+    const uint64_t e0 = far_ptr[xs], e1 = far_ptr[xs + 1];
     double sum = 0.0;
     // four entries at a time, their loads issued together (the pass is a chain of dependent trips to memory: pointer ->
     // entries -> theta; with one entry per trip a read of four took nine of them, profiles/r04d_call.log)
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_x, const uint6
             sum += f;
         }
     }
-    extra[slot - slot_base] = sum;
+    extra[xs] = sum;
 }
 // After: the far alignments' fractions, theta[sid] * conprb / normaliser of their read (inv[], left by the lane kernel), added
 // to counts[sid] in transcript order: consecutive entries of one id are summed by a segmented shuffle reduction, one atomic
@@ -966,9 +965,8 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
         XArgs xa;
         if (c->L.n_x_rows) {  // split rows: the far part of their normalisers first
             xa.extra = c->d_xextra; xa.inv = c->d_xinv; xa.slot_base = c->L.x_slot_base;
-            hipLaunchKernelGGL(k_far_rowsum, dim3(rsem::ceil_div(c->L.n_x_rows, kBlock)), dim3(kBlock), 0, st, c->L.n_x_rows, (const uint64_t*)c->L.d_far_ptr,
-                               (const int32_t*)c->L.d_far_sid, (const double*)c->L.d_far_cp, (const uint32_t*)c->L.d_xslot, c->L.x_slot_base, d_theta,
-                               c->d_xextra, ctrl);
+            hipLaunchKernelGGL(k_far_rowsum, dim3(rsem::ceil_div(c->L.n_x_slots, kBlock)), dim3(kBlock), 0, st, c->L.n_x_slots, (const uint64_t*)c->L.d_far_ptr,
+                               (const int32_t*)c->L.d_far_sid, (const double*)c->L.d_far_cp, d_theta, c->d_xextra, ctrl);
         }
         if (c->n_units)
             hipLaunchKernelGGL((k_estep_lane<false, false>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
@@ -1362,9 +1360,9 @@ int rsem_em_get_info(const rsem_em_ctx* c, const char* key, int64_t* value) {
         for (const Unit& u : c->h_units) w += u.span;
         const uint64_t long_nnz = c->long_nnz + (c->L.n_long_rows * 4ull) / 3;  // 12 B per alignment + 16 B per read
         // split rows: their far entries once in row order (sid + value, 12 B) and once in column order (sid + value + slot, 16 B),
-        // per split row its far_ptr / slot (12 B) and extra written, read, inv written, read (4 x 8 B; the gathers of inv by
-        // column-order entries beyond the first are cache hits)
-        const uint64_t far_bytes = 28 * c->L.n_far + 44 * (uint64_t)c->L.n_x_rows;
+        // per row slot of the split shapes its far_ptr (8 B) and extra written, read, inv written, read (4 x 8 B; the gathers of
+        // inv by the column-order entries stay within a block of slots: cache hits beyond the first)
+        const uint64_t far_bytes = 28 * c->L.n_far + 40 * (uint64_t)c->L.n_x_slots;
         *value = (int64_t)(c->L.val_bytes + c->L.n_sid_planes_loaded * 256 + (uint64_t)c->L.n_slots * (8 + (c->layout_has_q32 ? 2 : 0)) +
                            (uint64_t)c->L.n_slices * 8 + (uint64_t)c->n_units * sizeof(Unit) + (uint64_t)w * 16 + 16 * ((uint64_t)c->M + 1)) +
                  (int64_t)(12 * long_nnz + far_bytes);

@@ -116,7 +116,7 @@ constexpr int kMedianExactMax = 64; // reads up to this length: exact median (ra
 // longer holds a foreign id.
 __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint64_t* __restrict__ row_ptr,
                                                const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits,
-                                               int apart, int* err, int split = 0) {
+                                               int apart, int* err, int split = 0, uint32_t* split_far = nullptr) {
     uint64_t fr = row_ptr[i], to = row_ptr[i + 1];
     if (to < fr) { *err = 1; return 0; }
     uint32_t h = 0x811c9dc5u, mn = 0xffffffffu;
@@ -172,6 +172,7 @@ __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint
     // (configs[2] with 10 % such reads: 1.48 ms split against 1.17-1.25 whole, profiles/r04d_call.log).
     if (far && split && 2 * L_in <= L && shape != kLongShape && (uint64_t)mn <= kKeyMinSidCap) {  // split row: keyed by its in-window part
         shape = shape_id_of(L_in) + 2 * kShapesPerFmt;
+        if (split_far) *split_far = (uint32_t)(L - L_in);
         return ((uint64_t)shape << (64 - kShapeBits)) | ((uint64_t)mn << 32) | h_in;
     }
     if (mn > kKeyMinSidCap) mn = kKeyMinSidCap;
@@ -182,11 +183,14 @@ __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint
 
 __global__ void k_row_keys(uint64_t N1, int32_t M, const uint64_t* __restrict__ row_ptr,
                            const int32_t* __restrict__ sid, const double* __restrict__ cp, int range_bits, int apart, int split,
-                           const unsigned char* __restrict__ also_apart, uint64_t* keys, uint32_t* vals, int* err) {
+                           const unsigned char* __restrict__ also_apart, uint64_t* keys, uint32_t* vals, int* err,
+                           unsigned long long* n_split = nullptr /* [0] rows that split, [1] their far alignments */) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N1) return;
     int e = 0;
-    uint64_t key = row_key_of(i, M, row_ptr, sid, cp, range_bits, apart, &e, split);
+    uint32_t nf = 0;
+    uint64_t key = row_key_of(i, M, row_ptr, sid, cp, range_bits, apart, &e, split, &nf);
+    if (n_split && nf) { atomicAdd(&n_split[0], 1ull); atomicAdd(&n_split[1], (unsigned long long)nf); }
     // (a read the first layout found outside its unit's window; split rows have no such bit: their key's hash is all 32 bits)
     if (also_apart && also_apart[i] && (int)(key >> (64 - kShapeBits)) < 2 * kShapesPerFmt) key |= 1ull << kKeyApartBit;
     if (e) *err = e;
@@ -372,46 +376,52 @@ __global__ void k_x_anchors(uint32_t n_x, uint32_t x_row_base, const uint64_t* _
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x < n_x) xanchor[x] = (uint32_t)((keys_sorted[x_row_base + x] >> 32) & kKeyMinSidCap);
 }
-// far entries of split row x: count (far_ptr == nullptr) or write
-__global__ void k_x_far(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_x, uint32_t x_row_base, const uint32_t* __restrict__ order,
-                        const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid, const uint32_t* __restrict__ xanchor, uint64_t* nfar,
-                        const uint64_t* __restrict__ far_ptr, int32_t* far_sid, uint64_t* far_src, uint32_t* xslot, int reach) {
+// The far entries are kept in ROW SLOT order (index xs = slot - x_slot_base, empty slots included): the pass that sums them
+// per read then reads and writes contiguous memory, as the lane kernel reads extra[] / writes inv[] by slot.  (In sorted-row
+// order -- lane-major, a slot apart is 512 B apart -- that pass made ten million scattered 8-byte stores per round at
+// configs[1]'s size without gene structure: 0.41 ms, profiles/r04e_call.log.)
+// far entries of split row x: count into nfar[xs] (far_ptr == nullptr) or write at far_ptr[xs]
+__global__ void k_x_far(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_x, uint32_t x_row_base, uint32_t x_slot_base,
+                        const uint32_t* __restrict__ order, const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
+                        const uint32_t* __restrict__ xanchor, uint64_t* nfar, const uint64_t* __restrict__ far_ptr, int32_t* far_sid, uint64_t* far_src,
+                        uint32_t* far_eslot, int reach) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n_x) return;
     const uint32_t p = x_row_base + x, orig = order[p], anchor = xanchor[x];
     const uint64_t fr = row_ptr[orig], to = row_ptr[orig + 1];
-    if (!far_ptr) {
-        uint64_t n = 0;
-        for (uint64_t j = fr; j < to; j++) n += in_split_window(sid[j], anchor, reach) ? 0 : 1;
-        nfar[x] = n;
-        return;
-    }
-    uint64_t e = far_ptr[x];
-    for (uint64_t j = fr; j < to; j++)
-        if (!in_split_window(sid[j], anchor, reach)) { far_sid[e] = sid[j]; far_src[e] = j; ++e; }
     const Shape S = shapes[find_shape_by_row(shapes, n_shapes, p)];
     uint32_t slice_local, r;
     row_to_slot(S, T, p - S.row_base, slice_local, r);
-    xslot[x] = S.slot_base + slice_local * shape_R(S) + r;
-}
-// entry e (row order) -> its split row: the x with far_ptr[x] <= e < far_ptr[x + 1]
-__device__ inline uint32_t x_of_entry(const uint64_t* __restrict__ far_ptr, uint32_t n_x, uint64_t e) {
-    uint32_t lo = 0, hi = n_x;  // far_ptr[lo] <= e < far_ptr[hi]
-    while (hi - lo > 1) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if (far_ptr[mid] <= e) lo = mid; else hi = mid;
+    const uint32_t slot = S.slot_base + slice_local * shape_R(S) + r, xs = slot - x_slot_base;
+    if (!far_ptr) {
+        uint64_t n = 0;
+        for (uint64_t j = fr; j < to; j++) n += in_split_window(sid[j], anchor, reach) ? 0 : 1;
+        nfar[xs] = n;
+        return;
     }
-    return lo;
+    uint64_t e = far_ptr[xs];
+    for (uint64_t j = fr; j < to; j++)
+        if (!in_split_window(sid[j], anchor, reach)) { far_sid[e] = sid[j]; far_src[e] = j; far_eslot[e] = slot; ++e; }
 }
-__global__ void k_x_csc(uint64_t n_far, uint32_t n_x, const uint64_t* __restrict__ perm, const uint64_t* __restrict__ far_ptr,
-                        const int32_t* __restrict__ far_sid, const uint64_t* __restrict__ far_src, const uint32_t* __restrict__ xslot,
-                        int32_t* csc_sid, uint64_t* csc_src, uint32_t* csc_slot) {
+// Column order = (block of row slots, transcript id): within a block of kCscSlotBlock slots the reciprocals the column pass
+// gathers are 1 MB of memory -- they stay in the L2 of whichever XCD asks -- where a gather over all the slots of
+// configs[1]'s size (80 MB) went to the Infinity Cache for every entry (0.68 ms per round, profiles/r04e_call.log).
+constexpr int kCscSlotBlockLg = 17;
+__global__ void k_x_csc_keys(uint64_t n_far, uint32_t x_slot_base, const int32_t* __restrict__ far_sid, const uint32_t* __restrict__ far_eslot,
+                             uint64_t* keys, uint64_t* vals) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_far) return;
+    keys[e] = ((uint64_t)((far_eslot[e] - x_slot_base) >> kCscSlotBlockLg) << 32) | (uint32_t)far_sid[e];
+    vals[e] = e;
+}
+__global__ void k_x_csc(uint64_t n_far, const uint64_t* __restrict__ perm, const int32_t* __restrict__ far_sid, const uint64_t* __restrict__ far_src,
+                        const uint32_t* __restrict__ far_eslot, int32_t* csc_sid, uint64_t* csc_src, uint32_t* csc_slot) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_far) return;
     const uint64_t e = perm[i];
     csc_sid[i] = far_sid[e];
     csc_src[i] = far_src[e];
-    csc_slot[i] = xslot[x_of_entry(far_ptr, n_x, e)];
+    csc_slot[i] = far_eslot[e];
 }
 __global__ void k_x_values(uint64_t n_far, const double* __restrict__ cp, const uint64_t* __restrict__ far_src, const uint64_t* __restrict__ csc_src,
                            double* far_cp, double* csc_cp) {
@@ -419,10 +429,6 @@ __global__ void k_x_values(uint64_t n_far, const double* __restrict__ cp, const 
     if (i >= n_far) return;
     far_cp[i] = cp[far_src[i]];
     csc_cp[i] = cp[csc_src[i]];
-}
-__global__ void k_iota64(uint64_t n, uint64_t* v) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = i;
 }
 
 struct SellLayout {
@@ -446,8 +452,8 @@ struct SellLayout {
     uint32_t x_slot_base = 0;                // their row slots start here (extra / inv arrays are indexed by slot - x_slot_base)
     uint64_t n_far = 0;                      // alignments of split rows outside their window
     uint32_t* d_xanchor = nullptr;           // [n_x_rows]
-    uint32_t* d_xslot = nullptr;             // [n_x_rows] row slot of split row x
-    uint64_t* d_far_ptr = nullptr;           // [n_x_rows + 1] far entries of split row x, in file order
+    uint32_t n_x_slots = 0;                  // n_slots - x_slot_base
+    uint64_t* d_far_ptr = nullptr;           // [n_x_slots + 1] far entries of the split row in slot x_slot_base + xs, in file order
     int32_t* d_far_sid = nullptr;            // [n_far]
     uint64_t* d_far_src = nullptr;           // [n_far] index into the caller's CSR
     double* d_far_cp = nullptr;              // [n_far] values (sell_fill_values)
@@ -463,7 +469,7 @@ struct SellLayout {
 
 inline void sell_free(SellLayout& L) {
     hipFree(L.d_order); hipFree(L.d_shapes); hipFree(L.d_ssid); hipFree(L.d_masks); hipFree(L.d_slice_minsid); hipFree(L.d_slice_maxsid);
-    hipFree(L.d_xanchor); hipFree(L.d_xslot); hipFree(L.d_far_ptr); hipFree(L.d_far_sid); hipFree(L.d_far_src); hipFree(L.d_far_cp);
+    hipFree(L.d_xanchor); hipFree(L.d_far_ptr); hipFree(L.d_far_sid); hipFree(L.d_far_src); hipFree(L.d_far_cp);
     hipFree(L.d_csc_sid); hipFree(L.d_csc_src); hipFree(L.d_csc_slot); hipFree(L.d_csc_cp);
     L = SellLayout();
 }
@@ -496,27 +502,28 @@ inline int sell_fill_values(const SellLayout& L, hipStream_t st, const uint64_t*
 inline int sell_build_far(SellLayout& L, hipStream_t st, const uint64_t* d_row_ptr, const int32_t* d_sid, const uint64_t* d_keys_sorted) {
     const uint32_t nx = L.n_x_rows;
     if (!nx) return RSEM_OK;
+    const uint32_t nxs = L.n_slots - L.x_slot_base;
+    L.n_x_slots = nxs;
     RSEM_HIP_TRY(dmalloc(&L.d_xanchor, nx));
-    RSEM_HIP_TRY(dmalloc(&L.d_xslot, nx));
-    RSEM_HIP_TRY(dmalloc(&L.d_far_ptr, (size_t)nx + 1));
+    RSEM_HIP_TRY(dmalloc(&L.d_far_ptr, (size_t)nxs + 1));
     hipLaunchKernelGGL(k_x_anchors, dim3(rsem::ceil_div(nx, kBlock)), dim3(kBlock), 0, st, nx, L.x_row_base, d_keys_sorted, L.d_xanchor);
     uint64_t* d_n = nullptr;
     void* d_tmp = nullptr;
-    uint64_t *d_perm_in = nullptr, *d_perm = nullptr;
-    uint32_t *d_k_in = nullptr, *d_k_out = nullptr;
-    auto cleanup = [&]() { hipFree(d_n); hipFree(d_tmp); hipFree(d_perm_in); hipFree(d_perm); hipFree(d_k_in); hipFree(d_k_out); };
-    hipError_t e = dmalloc(&d_n, (size_t)nx + 1);
-    if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, sizeof(uint64_t) * ((size_t)nx + 1), st);
+    uint64_t *d_perm_in = nullptr, *d_perm = nullptr, *d_k_in = nullptr, *d_k_out = nullptr;
+    uint32_t* d_eslot = nullptr;
+    auto cleanup = [&]() { hipFree(d_n); hipFree(d_tmp); hipFree(d_perm_in); hipFree(d_perm); hipFree(d_k_in); hipFree(d_k_out); hipFree(d_eslot); };
+    hipError_t e = dmalloc(&d_n, (size_t)nxs + 1);
+    if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, sizeof(uint64_t) * ((size_t)nxs + 1), st);
     if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
-    hipLaunchKernelGGL(k_x_far, dim3(rsem::ceil_div(nx, kBlock)), dim3(kBlock), 0, st, (const Shape*)L.d_shapes, L.n_shapes, L.T, nx, L.x_row_base,
+    hipLaunchKernelGGL(k_x_far, dim3(rsem::ceil_div(nx, kBlock)), dim3(kBlock), 0, st, (const Shape*)L.d_shapes, L.n_shapes, L.T, nx, L.x_row_base, L.x_slot_base,
                        (const uint32_t*)L.d_order, d_row_ptr, d_sid, (const uint32_t*)L.d_xanchor, d_n, (const uint64_t*)nullptr, (int32_t*)nullptr,
                        (uint64_t*)nullptr, (uint32_t*)nullptr, kLayoutWindow);
     size_t tb = 0;
-    e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_n, L.d_far_ptr, (size_t)nx + 1, st);
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_n, L.d_far_ptr, (size_t)nxs + 1, st);
     if (e == hipSuccess) e = hipMalloc(&d_tmp, tb ? tb : 1);
-    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_n, L.d_far_ptr, (size_t)nx + 1, st);
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_n, L.d_far_ptr, (size_t)nxs + 1, st);
     uint64_t nf = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&nf, L.d_far_ptr + nx, sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&nf, L.d_far_ptr + nxs, sizeof(uint64_t), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
     L.n_far = nf;
@@ -527,26 +534,29 @@ inline int sell_build_far(SellLayout& L, hipStream_t st, const uint64_t* d_row_p
     if (e == hipSuccess) e = dmalloc(&L.d_csc_src, nf);
     if (e == hipSuccess) e = dmalloc(&L.d_csc_slot, nf);
     if (e == hipSuccess) e = dmalloc(&L.d_csc_cp, nf);
+    if (e == hipSuccess) e = dmalloc(&d_eslot, nf);
     if (e == hipSuccess) e = hipMemsetAsync(L.d_far_cp, 0, sizeof(double) * std::max<uint64_t>(nf, 1), st);
     if (e == hipSuccess) e = hipMemsetAsync(L.d_csc_cp, 0, sizeof(double) * std::max<uint64_t>(nf, 1), st);
     if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
-    hipLaunchKernelGGL(k_x_far, dim3(rsem::ceil_div(nx, kBlock)), dim3(kBlock), 0, st, (const Shape*)L.d_shapes, L.n_shapes, L.T, nx, L.x_row_base,
+    hipLaunchKernelGGL(k_x_far, dim3(rsem::ceil_div(nx, kBlock)), dim3(kBlock), 0, st, (const Shape*)L.d_shapes, L.n_shapes, L.T, nx, L.x_row_base, L.x_slot_base,
                        (const uint32_t*)L.d_order, d_row_ptr, d_sid, (const uint32_t*)L.d_xanchor, (uint64_t*)nullptr, (const uint64_t*)L.d_far_ptr,
-                       L.d_far_sid, L.d_far_src, L.d_xslot, kLayoutWindow);
-    if (nf) {  // column order: a stable sort of the entries by transcript id (ids are positive: their bits sort as unsigned)
+                       L.d_far_sid, L.d_far_src, d_eslot, kLayoutWindow);
+    if (nf) {  // column order: a stable sort of the entries by (block of row slots, transcript id)
         hipFree(d_tmp); d_tmp = nullptr;
         e = dmalloc(&d_perm_in, nf);
         if (e == hipSuccess) e = dmalloc(&d_perm, nf);
+        if (e == hipSuccess) e = dmalloc(&d_k_in, nf);
         if (e == hipSuccess) e = dmalloc(&d_k_out, nf);
         if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
-        hipLaunchKernelGGL(k_iota64, dim3(rsem::ceil_div(nf, kBlock)), dim3(kBlock), 0, st, nf, d_perm_in);
+        hipLaunchKernelGGL(k_x_csc_keys, dim3(rsem::ceil_div(nf, kBlock)), dim3(kBlock), 0, st, nf, L.x_slot_base, (const int32_t*)L.d_far_sid,
+                           (const uint32_t*)d_eslot, d_k_in, d_perm_in);
         tb = 0;
-        e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint32_t*)L.d_far_sid, d_k_out, (const uint64_t*)d_perm_in, d_perm, nf, 0, 32, st);
+        e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint64_t*)d_k_in, d_k_out, (const uint64_t*)d_perm_in, d_perm, nf, 0, 64, st);
         if (e == hipSuccess) e = hipMalloc(&d_tmp, tb ? tb : 1);
-        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, (const uint32_t*)L.d_far_sid, d_k_out, (const uint64_t*)d_perm_in, d_perm, nf, 0, 32, st);
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, (const uint64_t*)d_k_in, d_k_out, (const uint64_t*)d_perm_in, d_perm, nf, 0, 64, st);
         if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
-        hipLaunchKernelGGL(k_x_csc, dim3(rsem::ceil_div(nf, kBlock)), dim3(kBlock), 0, st, nf, nx, (const uint64_t*)d_perm, (const uint64_t*)L.d_far_ptr,
-                           (const int32_t*)L.d_far_sid, (const uint64_t*)L.d_far_src, (const uint32_t*)L.d_xslot, L.d_csc_sid, L.d_csc_src, L.d_csc_slot);
+        hipLaunchKernelGGL(k_x_csc, dim3(rsem::ceil_div(nf, kBlock)), dim3(kBlock), 0, st, nf, (const uint64_t*)d_perm, (const int32_t*)L.d_far_sid,
+                           (const uint64_t*)L.d_far_src, (const uint32_t*)d_eslot, L.d_csc_sid, L.d_csc_src, L.d_csc_slot);
     }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -568,8 +578,9 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     uint32_t *d_vals = nullptr, *d_first = nullptr;
     int* d_err = nullptr;
     void* d_tmp = nullptr;
+    unsigned long long* d_ns = nullptr;
     auto cleanup = [&]() {
-        hipFree(d_keys); hipFree(d_keys2); hipFree(d_vals); hipFree(d_first); hipFree(d_err); hipFree(d_tmp);
+        hipFree(d_keys); hipFree(d_keys2); hipFree(d_vals); hipFree(d_first); hipFree(d_err); hipFree(d_tmp); hipFree(d_ns);
     };
     RSEM_HIP_TRY(dmalloc(&d_keys, N1));
     RSEM_HIP_TRY(dmalloc(&d_keys2, N1));
@@ -580,9 +591,26 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     RSEM_HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), st));
     RSEM_HIP_TRY(hipMemsetAsync(d_first, 0xff, kShapeIds * sizeof(uint32_t), st));
     if (N1) {
-        hipLaunchKernelGGL(k_row_keys, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, M, d_row_ptr, d_sid,
-                           d_cp_for_q32, range_bits, apart, apart ? split : 0, d_also_apart, d_keys, d_vals, d_err);
-        RSEM_HIP_TRY(hipGetLastError());
+        // Split rows pay for two more passes and the kernel-sequence loop: taken only where they carry weight -- at least one
+        // read in twenty would split (a read splits where most of its alignments lie outside its window: row_key_of).
+        // Otherwise (a transcriptome with genes, a few stray multi-mappers) every read stays whole.
+        int do_split = apart ? split : 0;
+        if (do_split) {
+            unsigned long long h_ns[2] = {0, 0};
+            RSEM_HIP_TRY(dmalloc(&d_ns, 2));
+            RSEM_HIP_TRY(hipMemsetAsync(d_ns, 0, 2 * sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(k_row_keys, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, M, d_row_ptr, d_sid,
+                               d_cp_for_q32, range_bits, apart, 1, d_also_apart, d_keys, d_vals, d_err, d_ns);
+            RSEM_HIP_TRY(hipGetLastError());
+            RSEM_HIP_TRY(hipMemcpyAsync(h_ns, d_ns, sizeof(h_ns), hipMemcpyDeviceToHost, st));
+            RSEM_HIP_TRY(hipStreamSynchronize(st));
+            if (h_ns[0] * 20ull < N1 && !getenv("RSEM_HIP_SPLIT_ALWAYS")) do_split = 0;
+        }
+        if (!do_split) {
+            hipLaunchKernelGGL(k_row_keys, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, M, d_row_ptr, d_sid,
+                               d_cp_for_q32, range_bits, apart, 0, d_also_apart, d_keys, d_vals, d_err, (unsigned long long*)nullptr);
+            RSEM_HIP_TRY(hipGetLastError());
+        }
         size_t tb = 0;
         RSEM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_keys, d_keys2, d_vals, L.d_order, N1, 0, 64, st));
         RSEM_HIP_TRY(hipMalloc(&d_tmp, tb ? tb : 1));
@@ -611,6 +639,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     L.x_row_base = 0;
     L.x_slot_base = 0;
     L.n_far = 0;
+    L.n_x_slots = 0;
     uint32_t long_first = (h_first[kLongShape] == 0xffffffffu) ? (uint32_t)N1 : h_first[kLongShape];
     L.n_sell_rows = long_first;
     L.n_long_rows = (uint32_t)N1 - long_first;

@@ -221,6 +221,20 @@ def test_unstructured_tuples_all_variants():
     out = ctx.run(wl["theta0"], wl["N0"], max_round=200)
     oth, orounds, _, _ = orc.em_run(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["N0"], wl["theta0"], max_round=200)
     assert out["rounds"] == orounds and np.allclose(out["theta"], oth, rtol=1e-6, atol=1e-12)
+    # Such reads are laid out as SPLIT rows (sell_layout.hpp: the alignments inside the read's window in the planes, the
+    # others as far entries summed per read before and per transcript after the lane kernel -- no global atomic per
+    # alignment): most reads here, and nearly all alignments are far entries.  Whole rows give the same numbers.
+    N1, nnz = len(wl["row_ptr"]) - 1, len(wl["sid"])
+    assert ctx.info("split_rows") > 0.5 * N1 and 0.5 * nnz < ctx.info("far_entries") < nnz
+    oc = orc.em_estep(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["theta0"])
+    oc[0] += wl["N0"]
+    c_split, *_ = ctx.step(wl["theta0"], wl["N0"])
+    ctx.set_option("split_rows", 0)
+    assert ctx.info("split_rows") == 0 and ctx.info("far_entries") == 0
+    c_whole, *_ = ctx.step(wl["theta0"], wl["N0"])
+    assert np.allclose(c_split, oc, rtol=1e-9, atol=1e-9) and np.allclose(c_whole, oc, rtol=1e-9, atol=1e-9)
+    out2 = ctx.run(wl["theta0"], wl["N0"], max_round=200)
+    assert out2["rounds"] == orounds and np.allclose(out2["theta"], oth, rtol=1e-6, atol=1e-12)
     ctx.close()
 
 
