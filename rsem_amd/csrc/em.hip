@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_xs, const uint
         for (int u = 0; u < 4; u++) {
             const bool in = e + u < e1;
             id[u] = in ? far_sid[e + u] : 0;
-            v[u] = in ? stream_load(&far_cp[e + u]) : 0.0;
+            v[u] = in ? far_cp[e + u] : 0.0;  // (not a streaming load: the four loads of a thread and its neighbours' share lines)
         }
         double t[4];
 #pragma unroll
