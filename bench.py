@@ -655,7 +655,7 @@ def main():
                 line["speedup_vs_cpu_baseline_rounds"] = line["value"] / cb["value"]
                 if e2e is not None:
                     line["e2e_wall_clock"] = e2e
-            try:  # the builder-run record of both programs at FULL size (tools/gpu_r04a.sh), for reference
+            try:  # the builder-run record of both programs at FULL size (profiles/scripts/gpu_r04a.sh), for reference
                 with open(os.path.join(ROOT, "profiles", "e2e_full_size_reference.json")) as f:
                     line["e2e_full_size_recorded_round4"] = json.load(f)
             except Exception:

@@ -235,44 +235,6 @@ __global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_xs, const uint
     }
     extra[xs] = sum;
 }
-// The same sums with a wave per 256 consecutive entries (coalesced loads, segmented reduction keyed by the read's slot, one
-// atomic per read and wave; extra[] cleared before): RSEM_HIP_ROWSUM=wave, measured beside the thread-per-slot pass.
-__global__ __launch_bounds__(kBlock) void k_far_rowsum_wave(uint64_t n_far, const int32_t* __restrict__ far_sid, const double* __restrict__ far_cp,
-                                                             const uint32_t* __restrict__ far_xs, const double* __restrict__ theta, double* extra,
-                                                             const Ctrl* ctrl) {
-    if (ctrl->done) return;
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    constexpr int kU = 4;
-    for (uint64_t b = wave * (64 * kU); b < n_far; b += n_waves * (64 * kU)) {  // (uniform over the wave)
-        int key[kU], id[kU];
-        double cv[kU];
-#pragma unroll
-        for (int u = 0; u < kU; u++) {
-            const uint64_t i = b + (uint64_t)(u * 64 + lane);
-            const bool in = i < n_far;
-            key[u] = in ? (int)far_xs[i] : -1;
-            id[u] = in ? far_sid[i] : 0;
-            cv[u] = in ? stream_load(&far_cp[i]) : 0.0;
-        }
-        double th[kU];
-#pragma unroll
-        for (int u = 0; u < kU; u++) th[u] = theta[id[u]];
-#pragma unroll
-        for (int u = 0; u < kU; u++) {
-            double v = th[u] * cv[u];
-            if (v < kEpsilon) v = 0.0;
-            const bool tail = seg_reduce(key[u], v, lane, 0);
-            // a read whose entries all lie inside these 64 lanes is written with a plain store (extra[] was cleared; nobody
-            // else adds to it); only the reads cut by the group's ends take an atomic
-            const int key0 = __shfl(key[u], 0);
-            if (tail && key[u] >= 0) {
-                if (lane == 63 || key[u] == key0) { if (v != 0.0) unsafeAtomicAdd(&extra[key[u]], v); }
-                else extra[key[u]] = v;
-            }
-        }
-    }
-}
 // After: the far alignments' fractions, theta[sid] * conprb / normaliser of their read (inv[], left by the lane kernel), added
 // to counts[sid] in transcript order: consecutive entries of one id are summed by a segmented shuffle reduction, one atomic
 // per id and wave -- the transposed (CSC) pass instead of a global atomic per alignment.  A wave takes 4 x 64 consecutive
@@ -1003,13 +965,6 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
         XArgs xa;
         if (c->L.n_x_rows) {  // split rows: the far part of their normalisers first
             xa.extra = c->d_xextra; xa.inv = c->d_xinv; xa.slot_base = c->L.x_slot_base;
-            static const bool by_wave = []() { const char* e = getenv("RSEM_HIP_ROWSUM"); return e && !strcmp(e, "wave"); }();
-            if (by_wave) {
-                RSEM_HIP_TRY(hipMemsetAsync(c->d_xextra, 0, sizeof(double) * c->L.n_x_slots, st));
-                const int grid = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_far, kBlock * 4)));
-                hipLaunchKernelGGL(k_far_rowsum_wave, dim3(grid), dim3(kBlock), 0, st, c->L.n_far, (const int32_t*)c->L.d_far_sid, (const double*)c->L.d_far_cp,
-                                   (const uint32_t*)c->L.d_far_xs, d_theta, c->d_xextra, ctrl);
-            } else
             hipLaunchKernelGGL(k_far_rowsum, dim3(rsem::ceil_div(c->L.n_x_slots, kBlock)), dim3(kBlock), 0, st, c->L.n_x_slots, (const uint64_t*)c->L.d_far_ptr,
                                (const int32_t*)c->L.d_far_sid, (const double*)c->L.d_far_cp, d_theta, c->d_xextra, ctrl);
         }

@@ -252,15 +252,10 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         }
         part = read_sum_dpp(part, lg);
         const double inv = (part >= kEpsilon) ? 1.0 / part : 0.0;
-#if defined(RSEM_X_STORE_G0)    /* measurement builds (tools/gpu_r04d.sh) */
-        if (kX && g0) (X.inv + (cur.slot0 - X.slot_base))[uslot] = inv;
-#elif defined(RSEM_X_NO_STORE)
-        if (kX && inv == -1.0) (X.inv + (cur.slot0 - X.slot_base))[uslot] = inv;
-#else
-        // (every lane of the read stores the same value: a store under a lane predicate is a branch, and past a branch the
-        // compiler's waits for the prefetched slice turn into waits for everything)
+        // (every lane of the read stores the same value rather than its first lane alone: no lane predicate, no branch; the
+        // store costs the split shapes' loop 90 us of 1.2 ms at configs[2] with 10 % cross-gene reads either way,
+        // profiles/r04d_call.log)
         if (kX) (X.inv + (cur.slot0 - X.slot_base))[uslot] = inv;
-#endif
         noise += f0 * inv;
         // reads whose fractions sum to one: sum(counts) without a reduction
         neff += (g0 && part >= kEpsilon) ? 1.0 : 0.0;

@@ -384,7 +384,7 @@ __global__ void k_x_anchors(uint32_t n_x, uint32_t x_row_base, const uint64_t* _
 __global__ void k_x_far(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_x, uint32_t x_row_base, uint32_t x_slot_base,
                         const uint32_t* __restrict__ order, const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
                         const uint32_t* __restrict__ xanchor, uint64_t* nfar, const uint64_t* __restrict__ far_ptr, int32_t* far_sid, uint64_t* far_src,
-                        uint32_t* far_eslot, int reach, uint32_t* far_xs = nullptr) {
+                        uint32_t* far_eslot, int reach) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n_x) return;
     const uint32_t p = x_row_base + x, orig = order[p], anchor = xanchor[x];
@@ -401,7 +401,7 @@ __global__ void k_x_far(const Shape* __restrict__ shapes, int n_shapes, uint32_t
     }
     uint64_t e = far_ptr[xs];
     for (uint64_t j = fr; j < to; j++)
-        if (!in_split_window(sid[j], anchor, reach)) { far_sid[e] = sid[j]; far_src[e] = j; far_eslot[e] = slot; if (far_xs) far_xs[e] = xs; ++e; }
+        if (!in_split_window(sid[j], anchor, reach)) { far_sid[e] = sid[j]; far_src[e] = j; far_eslot[e] = slot; ++e; }
 }
 // Column order = (block of row slots, transcript id): within a block of kCscSlotBlock slots the reciprocals the column pass
 // gathers are 1 MB of memory -- they stay in the L2 of whichever XCD asks -- where a gather over all the slots of
@@ -455,7 +455,6 @@ struct SellLayout {
     uint32_t n_x_slots = 0;                  // n_slots - x_slot_base
     uint64_t* d_far_ptr = nullptr;           // [n_x_slots + 1] far entries of the split row in slot x_slot_base + xs, in file order
     int32_t* d_far_sid = nullptr;            // [n_far]
-    uint32_t* d_far_xs = nullptr;            // [n_far] row slot - x_slot_base of the entry's read
     uint64_t* d_far_src = nullptr;           // [n_far] index into the caller's CSR
     double* d_far_cp = nullptr;              // [n_far] values (sell_fill_values)
     int32_t* d_csc_sid = nullptr;            // the same entries sorted by transcript id ...
@@ -470,7 +469,7 @@ struct SellLayout {
 
 inline void sell_free(SellLayout& L) {
     hipFree(L.d_order); hipFree(L.d_shapes); hipFree(L.d_ssid); hipFree(L.d_masks); hipFree(L.d_slice_minsid); hipFree(L.d_slice_maxsid);
-    hipFree(L.d_xanchor); hipFree(L.d_far_ptr); hipFree(L.d_far_xs); hipFree(L.d_far_sid); hipFree(L.d_far_src); hipFree(L.d_far_cp);
+    hipFree(L.d_xanchor); hipFree(L.d_far_ptr); hipFree(L.d_far_sid); hipFree(L.d_far_src); hipFree(L.d_far_cp);
     hipFree(L.d_csc_sid); hipFree(L.d_csc_src); hipFree(L.d_csc_slot); hipFree(L.d_csc_cp);
     L = SellLayout();
 }
@@ -536,13 +535,12 @@ inline int sell_build_far(SellLayout& L, hipStream_t st, const uint64_t* d_row_p
     if (e == hipSuccess) e = dmalloc(&L.d_csc_slot, nf);
     if (e == hipSuccess) e = dmalloc(&L.d_csc_cp, nf);
     if (e == hipSuccess) e = dmalloc(&d_eslot, nf);
-    if (e == hipSuccess) e = dmalloc(&L.d_far_xs, nf);
     if (e == hipSuccess) e = hipMemsetAsync(L.d_far_cp, 0, sizeof(double) * std::max<uint64_t>(nf, 1), st);
     if (e == hipSuccess) e = hipMemsetAsync(L.d_csc_cp, 0, sizeof(double) * std::max<uint64_t>(nf, 1), st);
     if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
     hipLaunchKernelGGL(k_x_far, dim3(rsem::ceil_div(nx, kBlock)), dim3(kBlock), 0, st, (const Shape*)L.d_shapes, L.n_shapes, L.T, nx, L.x_row_base, L.x_slot_base,
                        (const uint32_t*)L.d_order, d_row_ptr, d_sid, (const uint32_t*)L.d_xanchor, (uint64_t*)nullptr, (const uint64_t*)L.d_far_ptr,
-                       L.d_far_sid, L.d_far_src, d_eslot, kLayoutWindow, L.d_far_xs);
+                       L.d_far_sid, L.d_far_src, d_eslot, kLayoutWindow);
     if (nf) {  // column order: a stable sort of the entries by (block of row slots, transcript id)
         hipFree(d_tmp); d_tmp = nullptr;
         e = dmalloc(&d_perm_in, nf);
