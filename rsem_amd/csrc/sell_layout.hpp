@@ -850,6 +850,8 @@ inline int sell_build_refined(SellLayout& L, hipStream_t st, uint64_t N1, int32_
     unsigned char* d_also = nullptr;
     unsigned long long* d_n = nullptr;
     if (n_strays) *n_strays = 0;
+    const char* knob = getenv("RSEM_HIP_APART");
+    const bool refine = !(knob && atoi(knob) == 0);
     for (int pass = 0; pass < 2; pass++) {
         int rc = sell_build(L, st, N1, M, d_row_ptr, d_sid, target_waves, forced_T, d_cp_for_q32, range_bits, d_also, split);
         if (rc == RSEM_OK) rc = sell_build_units(L, units, window_cap);
@@ -861,10 +863,9 @@ inline int sell_build_refined(SellLayout& L, hipStream_t st, uint64_t N1, int32_
         if (e != hipSuccess) { (void)hipFree(d_also); RSEM_HIP_TRY(e); }
         rc = sell_flag_far_units(L, units, *d_units, st);
         if (rc != RSEM_OK) { (void)hipFree(d_also); return rc; }
-        bool any_far = false;
-        for (const Unit& u : units) any_far = any_far || u.pad[0] != 0;
-        const char* knob = getenv("RSEM_HIP_APART");
-        if (pass == 1 || !any_far || N1 == 0 || (knob && atoi(knob) == 0)) break;
+        size_t n_far_units = 0;
+        for (const Unit& u : units) n_far_units += u.pad[0] != 0;
+        if (pass == 1 || !n_far_units || N1 == 0 || !refine) break;
         unsigned long long n = 0;
         e = hipMalloc((void**)&d_also, N1);
         if (e == hipSuccess) e = hipMalloc((void**)&d_n, sizeof(unsigned long long));
@@ -880,6 +881,9 @@ inline int sell_build_refined(SellLayout& L, hipStream_t st, uint64_t N1, int32_
         (void)hipFree(d_n);
         if (e != hipSuccess) { (void)hipFree(d_also); RSEM_HIP_TRY(e); }
         if (n == 0) break;  // every far unit is made of far-reaching reads: nothing to gain
+        // a second build costs what the first did: only where the stray reads matter -- one read in a thousand, or one unit
+        // in a hundred running the loop with the global gather because of them
+        if (n * 1000ull < N1 && n_far_units * 100 < units.size()) break;
         if (n_strays) *n_strays = n;
         sell_free(L);       // second pass with the marks
     }
