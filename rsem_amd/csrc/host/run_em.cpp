@@ -560,6 +560,8 @@ int main(int argc, char* argv[]) {
     // per-shard outputs of a round (more than one shard: summed on the host in shard order, EM.cpp:385-389,400-404)
     std::vector<std::vector<double>> s_counts(S > 1 ? S : 0, std::vector<double>(M + 1, 0.0));
     std::vector<Model::Accum> s_acc(S > 1 ? S : 0, acc);
+    const bool round_times = getenv("RSEM_HIP_TIMING") != nullptr;
+    auto t_round = std::chrono::steady_clock::now();
     do {
         ++ROUND;
         const bool updateModel = ROUND <= 10;  // doesUpdateModel (EM.cpp:307-310)
@@ -619,6 +621,11 @@ int main(int argc, char* argv[]) {
         if (updateModel) model.finish_round(acc, refs);  // model.init(); collect; finish  (EM.cpp:400-404)
         theta.swap(theta_new);
         if (verbose) printf("ROUND = %d, SUM = %.15g, bChange = %g, totNum = %d\n", ROUND, sum, bChange, totNum);
+        if (round_times) {
+            const auto now = std::chrono::steady_clock::now();
+            printf("[timing]   model round %-2d            %8.3f s\n", ROUND, std::chrono::duration<double>(now - t_round).count());
+            t_round = now;
+        }
         if (ROUND >= 11 && !model.needCalcConPrb) break;  // the CSR values are frozen from here on
     } while (ROUND < MIN_ROUND || (totNum > 0 && ROUND < MAX_ROUND));
     lap("rounds 1-11 (model rounds)");
@@ -628,6 +635,7 @@ int main(int argc, char* argv[]) {
     // (Not during the model rounds: unmapping takes the address space's lock, and every call of those rounds that touches
     // memory waited for it -- 1.8 s over 11 rounds at configs[2].)  Kept: row_ptr and the transcript ids (.ofg / BAM output).
     std::thread releaser([&]() {
+        if (getenv("RSEM_HIP_NO_RELEASE")) return;  // (measurement: everything stays until exit)
         for (int tag = 0; tag < 3; tag++)
             for (int m = 0; m < 2; m++) rs.mate[tag][m] = ReadFile();
         dat.pos.release(); dat.insertL.release(); dat.sid_signed.release();
