@@ -102,6 +102,7 @@ struct Model {
     std::vector<double> pro;               // [proLen*5*5]       Profile.h
     double np_c[kNCodes] = {0, 0, 0, 0, 0}, np_p[kNCodes] = {0, 0, 0, 0, 0};  // NoiseProfile.h
     std::vector<double> mw;                // [M+1]
+    std::vector<char> needs_mw;            // [M+1] the transcript has a masked position or a poly(A) tail (found once: calc_mw runs every round)
     bool needCalcConPrb = true;
 
     bool hasQ() const { return type == 1 || type == 3; }
@@ -216,6 +217,14 @@ struct Model {
     void calc_mw(const RefInfo& R) {
         mw.assign(M + 1, 0.0);
         mw[0] = 1.0;
+        if ((int)needs_mw.size() != M + 1) {  // (the references do not change between the rounds)
+            needs_mw.assign(M + 1, 0);
+            for (int i = 1; i <= M; i++) {
+                bool any_mask = R.totLen[i] != R.fullLen[i];
+                for (size_t w = 0; !any_mask && w < R.masks[i].size(); w++) any_mask = R.masks[i][w] != 0;
+                needs_mw[i] = any_mask ? 1 : 0;
+            }
+        }
         const double probR = 1.0 - probF;
         const int seedLen = P.seedLen;
         for (int i = 1; i <= M; i++) {
@@ -223,9 +232,7 @@ struct Model {
             double value = 0.0;
             // nothing to integrate for a transcript without masked positions and without a poly(A) tail: every loop
             // below is either guarded by getMask() or runs over [fullLen, totLen) -- mw = 1 exactly as in the reference
-            bool any_mask = totLen != fullLen;
-            for (size_t w = 0; !any_mask && w < R.masks[i].size(); w++) any_mask = R.masks[i][w] != 0;
-            if (!any_mask) { mw[i] = 1.0; continue; }
+            if (!needs_mw[i]) { mw[i] = 1.0; continue; }
             if (paired()) {
                 const int end = std::min(fullLen, totLen - gld.minL() + 1);
                 for (int seedPos = 0; seedPos < end; seedPos++)

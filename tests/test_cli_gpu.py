@@ -225,16 +225,18 @@ def test_rsem_run_em_binary_input_equals_text_input(name, tmp_path):
 
 @pytest.mark.parametrize("name", ["pe_q", "se_noq_rev_rspd_omit", "se_q_fragmean"])
 def test_per_read_model_kernels_equal_per_alignment_kernels(name, tmp_path):
-    """k_conprb_read / k_update_read (one thread per read, profile products and profile counts shared by alignments whose
-    reference windows hold the same bases) against the thread-per-alignment kernels (RSEM_MODEL_KERNELS=alignment): same
-    rounds, theta and .ofg values to 1e-9 (the products are bit-identical; the count sums differ in summation order)."""
+    """The model rounds' kernel of the product (k_model_group: a group of 16 lanes per read, profile products and profile
+    counts shared by alignments whose reference windows hold the same bases, probabilities written into the value planes in
+    place) against the two older kernel families kept for this cross-check -- thread per alignment
+    (RSEM_MODEL_KERNELS=alignment) and thread per read (=read): same rounds, theta and .ofg values to 1e-9 (the products
+    and count sums differ in the order of their operations)."""
     fx, dst = _stage(name, tmp_path)
     meta = rf.read_meta(fx)
     args = [os.path.join(dst, "ref"), str(meta["model_type"]), os.path.join(dst, "s"), os.path.join(dst, "temp", "s"), os.path.join(dst, "stat", "s"), "--gibbs-out"]
     out_r = _run([os.path.join(BIN, "rsem-run-em")] + args)
     th_r = rf.read_theta(os.path.join(dst, "stat", "s.theta"))
     ofg_r = rf.read_ofg(os.path.join(dst, "temp", "s.ofg"))
-    for family in ("alignment", "read"):  # the default: two-pass conprb sharing the products, per-read update
+    for family in ("alignment", "read"):
         r = subprocess.run([os.path.join(BIN, "rsem-run-em")] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                            env=dict(os.environ, RSEM_MODEL_KERNELS=family))
         assert r.returncode == 0, r.stdout[-2000:]
