@@ -67,6 +67,13 @@ inline bool calc_lq_single_ids(const uint8_t* s, int len, bool hasPolyA, int see
 // written straight to those places.  (Until round 4 every chunk collected its reads in vectors of its own that were
 // then copied into place: at BASELINE configs[2] 22 GB of intermediate 4 KB pages, first-touched by 64 threads of one
 // address space -- the page faults, not the parsing, set the time.)
+// files above this size are parsed by several threads, each a run of whole records (RSEM_HIP_PARSE_SPLIT_BYTES: tests set it
+// to a few hundred bytes so that the chunk-boundary logic is exercised on small files)
+inline size_t parse_split_bytes() {
+    static const size_t v = []() { const char* e = getenv("RSEM_HIP_PARSE_SPLIT_BYTES"); return e ? (size_t)atoll(e) : ((size_t)32 << 20); }();
+    return v;
+}
+
 inline void prefault_text(const char* p, size_t n) {
 #ifdef MADV_POPULATE_READ
     static const bool on = !getenv("RSEM_HIP_NO_PREFAULT");
@@ -83,7 +90,7 @@ inline ReadFile parse_read_file(const std::string& path, bool fastq, bool hasPol
     MappedFile f;
     if (!f.open(path)) die("Cannot open %s! It may not exist.", path.c_str());
     const int L = fastq ? 4 : 2;
-    const int nt = f.size > (32u << 20) ? (threads > 0 ? threads : hardware_threads()) : 1;
+    const int nt = f.size > parse_split_bytes() ? (threads > 0 ? threads : hardware_threads()) : 1;
     std::vector<size_t> cut = line_chunks(f.data, 0, f.size, nt);
     int nc = (int)cut.size() - 1;
     const char* fend = f.data + f.size;
@@ -228,7 +235,7 @@ inline DatData load_dat(const std::string& path, int expect_read_type, int threa
     const bool pe = D.read_type >= 2;
     const char* nl = (const char*)memchr(p, '\n', end - p);
     size_t body = nl ? (size_t)(nl - f.data) + 1 : f.size;
-    const int nt = f.size > (32u << 20) ? (threads > 0 ? threads : hardware_threads()) : 1;
+    const int nt = f.size > parse_split_bytes() ? (threads > 0 ? threads : hardware_threads()) : 1;
     std::vector<size_t> cut = line_chunks(f.data, body, f.size, nt);
     const int nc = (int)cut.size() - 1;
     // scan 1: reads and alignments per chunk (the first number of every line); scan 2: the numbers, straight into place

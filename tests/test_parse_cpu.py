@@ -322,3 +322,16 @@ def test_binary_handoff_via_environment(tmp_path):
     # a later TEXT run on the same sample.temp (kept intermediate files) removes the arrays: rsem-run-em must not find stale ones
     subprocess.check_call(cmd)
     assert os.path.exists(os.path.join(d, "temp", "s.dat")) and not os.path.exists(os.path.join(d, "temp", "s.rsb"))
+
+
+def test_text_parsers_are_independent_of_the_thread_count(tmp_path):
+    """rsem-run-em's parsers of imd.dat and the read files (host/reads.hpp: three scans, every thread a run of whole records
+    written straight into place) on files with CRLF line ends, a last line without a newline, stray empty lines, reads of very
+    different lengths: 2, 3, 7 and 16 threads give the arrays one thread gives (tests/parse_chunks_check.cpp; the split
+    threshold is lowered so that these small files are split at all)."""
+    exe = str(tmp_path / "parse_chunks_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "parse_chunks_check.cpp"), "-o", exe])
+    d = tmp_path / "files"
+    d.mkdir()
+    r = subprocess.run([exe, str(d)], env=dict(os.environ, RSEM_HIP_PARSE_SPLIT_BYTES="64"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:]
