@@ -194,6 +194,7 @@ __device__ inline bool seg_reduce(int key, double& v, int lane, int lg) {
     int knext = __shfl_down(key, G);
     int flag = (lane < G) || (kprev != key);
     for (int d = G; d < 64; d <<= 1) {
+        if (__ballot(!flag) == 0ull) break;  // every lane has reached the head of its run: the remaining steps would add nothing
         double ov = __shfl_up(v, d);
         int of = __shfl_up(flag, d);
         if (lane >= d && !flag) { v += ov; flag = of; }

@@ -408,10 +408,10 @@ __global__ void k_x_far(const Shape* __restrict__ shapes, int n_shapes, uint32_t
 // configs[1]'s size (80 MB) went to the Infinity Cache for every entry (0.68 ms per round, profiles/r04e_call.log).
 constexpr int kCscSlotBlockLg = 17;
 __global__ void k_x_csc_keys(uint64_t n_far, uint32_t x_slot_base, const int32_t* __restrict__ far_sid, const uint32_t* __restrict__ far_eslot,
-                             uint64_t* keys, uint64_t* vals) {
+                             uint64_t* keys, uint64_t* vals, int block_lg) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_far) return;
-    keys[e] = ((uint64_t)((far_eslot[e] - x_slot_base) >> kCscSlotBlockLg) << 32) | (uint32_t)far_sid[e];
+    keys[e] = ((uint64_t)((far_eslot[e] - x_slot_base) >> block_lg) << 32) | (uint32_t)far_sid[e];
     vals[e] = e;
 }
 __global__ void k_x_csc(uint64_t n_far, const uint64_t* __restrict__ perm, const int32_t* __restrict__ far_sid, const uint64_t* __restrict__ far_src,
@@ -548,8 +548,10 @@ inline int sell_build_far(SellLayout& L, hipStream_t st, const uint64_t* d_row_p
         if (e == hipSuccess) e = dmalloc(&d_k_in, nf);
         if (e == hipSuccess) e = dmalloc(&d_k_out, nf);
         if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
+        int block_lg = kCscSlotBlockLg;
+        if (const char* eb = getenv("RSEM_HIP_CSC_BLOCK_LG")) block_lg = std::min(31, std::max(8, atoi(eb)));  // measurement knob
         hipLaunchKernelGGL(k_x_csc_keys, dim3(rsem::ceil_div(nf, kBlock)), dim3(kBlock), 0, st, nf, L.x_slot_base, (const int32_t*)L.d_far_sid,
-                           (const uint32_t*)d_eslot, d_k_in, d_perm_in);
+                           (const uint32_t*)d_eslot, d_k_in, d_perm_in, block_lg);
         tb = 0;
         e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint64_t*)d_k_in, d_k_out, (const uint64_t*)d_perm_in, d_perm, nf, 0, 64, st);
         if (e == hipSuccess) e = hipMalloc(&d_tmp, tb ? tb : 1);
