@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r04j; mkdir -p $out
 export RSEM_WL_CACHE=/dev/shm/rsem_wl
-for lg in 17 19 20 21 22 31; do
+for lg in ${LGS:-17 19 20 21 22 31}; do
   rm -rf /tmp/prof_j
   RSEM_HIP_CSC_BLOCK_LG=$lg timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_j -o p -- python bench.py --config C2R --legs= --steps 20 --warmup 3 --no-cpu-baseline --no-gibbs --no-ci --no-q32 --no-stream > $out/lg$lg.json 2> $out/lg$lg.err
   python - /tmp/prof_j $lg <<'PY'
