@@ -205,31 +205,39 @@ __device__ inline bool seg_reduce(int key, double& v, int lane, int lg) {
 // ---- split rows: the two passes around the lane kernel (sell_layout.hpp: sell_build_far) ----------------------------------------
 // Before: the far part of every split read's normaliser, sum over its far alignments of theta[sid] * conprb (each clamped
 // like every term of EM.cpp:212-219).  Thread per read: a split read has a handful of far alignments.
+constexpr int kRowsumCap = 1024;  // far entries of a wave's 64 row slots staged in LDS (8 KB per wave); beyond that the slots walk global memory
 __global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_xs, const uint64_t* __restrict__ far_ptr, const int32_t* __restrict__ far_sid,
                                                         const double* __restrict__ far_cp, const double* __restrict__ theta, double* __restrict__ extra,
                                                         const Ctrl* ctrl) {
     if (ctrl->done) return;
-    const uint32_t xs = blockIdx.x * blockDim.x + threadIdx.x;  // row slot - x_slot_base (far entries are kept in slot order)
-    if (xs >= n_xs) return;
-    const uint64_t e0 = far_ptr[xs], e1 = far_ptr[xs + 1];
-    double sum = 0.0;
-    // four entries at a time, their loads issued together (the pass is a chain of dependent trips to memory: pointer ->
-    // entries -> theta; with one entry per trip a read of four took nine of them, profiles/r04d_call.log)
-    for (uint64_t e = e0; e < e1; e += 4) {
-        int id[4];
-        double v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const bool in = e + u < e1;
-            id[u] = in ? far_sid[e + u] : 0;
-            v[u] = in ? far_cp[e + u] : 0.0;  // (not a streaming load: the four loads of a thread and its neighbours' share lines)
+    // A wave = 64 consecutive row slots = one contiguous run of far entries (they are kept in slot order).  The run is read
+    // with coalesced loads -- lane i takes entries i, i + 64, ... --, every entry's term theta[sid] * conprb (clamped like
+    // every term of EM.cpp:212-219) goes to LDS, and each lane then adds up its own slot's terms from there.  (With every
+    // lane reading its own slot's entries straight from global memory the loads of a wave were 48 bytes apart: 0.29 ms for
+    // 37 M entries at configs[1]'s size, profiles/r04g_call.log.)
+    __shared__ double s_term[kBlock / 64][kRowsumCap];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t xs = blockIdx.x * blockDim.x + threadIdx.x;  // row slot - x_slot_base
+    const bool in = xs < n_xs;
+    const uint64_t e0 = far_ptr[in ? xs : n_xs], e1 = far_ptr[in ? xs + 1 : n_xs];
+    const uint64_t E0 = __shfl(e0, 0), E1 = __shfl(e1, 63);
+    const uint64_t n = E1 - E0;
+    const bool staged = n <= (uint64_t)kRowsumCap;
+    if (staged) {
+        for (uint64_t k = (uint64_t)lane; k < n; k += 64) {
+            double f = theta[far_sid[E0 + k]] * stream_load(&far_cp[E0 + k]);
+            if (f < kEpsilon) f = 0.0;
+            s_term[w][k] = f;
         }
-        double t[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) t[u] = theta[id[u]];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            double f = t[u] * v[u];
+    }
+    __syncthreads();
+    if (!in) return;
+    double sum = 0.0;
+    if (staged) {
+        for (uint64_t e = e0; e < e1; e++) sum += s_term[w][e - E0];
+    } else {
+        for (uint64_t e = e0; e < e1; e++) {
+            double f = theta[far_sid[e]] * far_cp[e];
             if (f < kEpsilon) f = 0.0;
             sum += f;
         }
@@ -237,43 +245,41 @@ __global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_xs, const uint
     extra[xs] = sum;
 }
 // After: the far alignments' fractions, theta[sid] * conprb / normaliser of their read (inv[], left by the lane kernel), added
-// to counts[sid] in transcript order: consecutive entries of one id are summed by a segmented shuffle reduction, one atomic
-// per id and wave -- the transposed (CSC) pass instead of a global atomic per alignment.  A wave takes 4 x 64 consecutive
-// entries per step and issues all their loads, then all their gathers, before it reduces.
-__global__ __launch_bounds__(kBlock) void k_far_colsum(uint64_t n_far, const int32_t* __restrict__ csc_sid, const double* __restrict__ csc_cp,
-                                                        const uint32_t* __restrict__ csc_slot, uint32_t slot_base, const double* __restrict__ theta,
+// to counts[sid] in column order -- the transposed (CSC) pass instead of a global atomic per alignment.  One workgroup per
+// task = a piece of one range of 2048 ids (sell_layout.hpp CscTask): theta of the range is staged in LDS, the fractions are
+// summed per id by a segmented shuffle reduction and added to an LDS window, which leaves with one device atomic per
+// touched id.  Within a piece the entries come block of row slots by block, so the reciprocals it gathers stay in L2.
+__global__ __launch_bounds__(kBlock) void k_far_colsum(const CscTask* __restrict__ tasks, const int32_t* __restrict__ csc_sid, const double* __restrict__ csc_cp,
+                                                        const uint32_t* __restrict__ csc_slot, uint32_t slot_base, int M, const double* __restrict__ theta,
                                                         const double* __restrict__ inv, double* counts, const Ctrl* ctrl) {
     if (ctrl->done) return;
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    constexpr int kU = 4;
-    for (uint64_t b = wave * (64 * kU); b < n_far; b += n_waves * (64 * kU)) {  // (uniform over the wave)
-        int key[kU];
-        double cv[kU];
-        uint32_t sl[kU];
-#pragma unroll
-        for (int u = 0; u < kU; u++) {
-            const uint64_t i = b + (uint64_t)(u * 64 + lane);
-            const bool in = i < n_far;
-            key[u] = in ? csc_sid[i] : -1;
-            cv[u] = in ? stream_load(&csc_cp[i]) : 0.0;
-            sl[u] = in ? csc_slot[i] : slot_base;
-        }
-        double th[kU], iv[kU];
-#pragma unroll
-        for (int u = 0; u < kU; u++) {
-            th[u] = theta[key[u] > 0 ? key[u] : 0];
-            iv[u] = inv[sl[u] - slot_base];
-        }
-#pragma unroll
-        for (int u = 0; u < kU; u++) {
-            double f = th[u] * cv[u];
-            if (f < kEpsilon) f = 0.0;
-            double v = key[u] > 0 ? f * iv[u] : 0.0;
-            const bool tail = seg_reduce(key[u], v, lane, 0);
-            if (tail && key[u] > 0 && v != 0.0) unsafeAtomicAdd(&counts[key[u]], v);
-        }
+    constexpr int kRange = 1 << kCscSidRangeLg;
+    __shared__ double s_th[kRange], s_cnt[kRange];
+    const CscTask t = tasks[blockIdx.x];
+    for (int i = threadIdx.x; i < kRange; i += blockDim.x) {
+        const int id = t.base + i;
+        s_th[i] = (id >= 1 && id <= M) ? theta[id] : 0.0;
+        s_cnt[i] = 0.0;
     }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (uint32_t b = 0; b < t.count; b += kBlock) {  // (uniform over the workgroup)
+        const uint32_t k = b + threadIdx.x;
+        int key = -1;
+        double v = 0.0;
+        if (k < t.count) {
+            const uint64_t i = t.begin + k;
+            key = csc_sid[i] - t.base;
+            double f = s_th[key] * stream_load(&csc_cp[i]);
+            if (f < kEpsilon) f = 0.0;
+            v = f * inv[csc_slot[i] - slot_base];
+        }
+        const bool tail = seg_reduce(key, v, lane, 0);
+        if (tail && key >= 0 && v != 0.0) RSEM_LDS_ADD(&s_cnt[key], v);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kRange; i += blockDim.x)
+        if (s_cnt[i] != 0.0) unsafeAtomicAdd(&counts[t.base + i], s_cnt[i]);
 }
 
 // Variant SELL (cross-check / fallback): every slice on its own, per-plane segmented shuffle
@@ -974,9 +980,9 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
                                d_theta, (const double*)nullptr, 0.0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid,
                                c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs(), xa);
         if (c->L.n_far) {  // ... and their far alignments' fractions afterwards, in transcript order
-            const int grid = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_far, kBlock * 4)));
-            hipLaunchKernelGGL(k_far_colsum, dim3(grid), dim3(kBlock), 0, st, c->L.n_far, (const int32_t*)c->L.d_csc_sid, (const double*)c->L.d_csc_cp,
-                               (const uint32_t*)c->L.d_csc_slot, c->L.x_slot_base, d_theta, (const double*)c->d_xinv, d_counts, ctrl);
+            hipLaunchKernelGGL(k_far_colsum, dim3(c->L.n_csc_tasks), dim3(kBlock), 0, st, (const CscTask*)c->L.d_csc_tasks, (const int32_t*)c->L.d_csc_sid,
+                               (const double*)c->L.d_csc_cp, (const uint32_t*)c->L.d_csc_slot, c->L.x_slot_base, c->M, d_theta, (const double*)c->d_xinv,
+                               d_counts, ctrl);
         }
     } else {
         if (c->L.n_x_rows) { rsem::set_last_error("the SELL kernel cannot walk a layout with split rows (set the kernel before the values, or option split_rows = 0)"); return RSEM_ERR_STATE; }
