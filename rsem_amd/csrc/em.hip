@@ -247,11 +247,14 @@ __global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_xs, const uint
 // After: the far alignments' fractions, theta[sid] * conprb / normaliser of their read (inv[], left by the lane kernel), added
 // to counts[sid] in column order -- the transposed (CSC) pass instead of a global atomic per alignment.  One workgroup per
 // task = a piece of one range of 2048 ids (sell_layout.hpp CscTask): theta of the range is staged in LDS, the fractions are
-// summed per id by a segmented shuffle reduction and added to an LDS window, which leaves with one device atomic per
-// touched id.  Within a piece the entries come block of row slots by block, so the reciprocals it gathers stay in L2.
+// summed per id by a segmented shuffle reduction and added to an LDS window, which the workgroup leaves as a row of `part`
+// (plain coalesced stores); k_far_colsum_close then adds the rows of every range's tasks to the counts -- no atomic at
+// all.  (Windows flushed by device atomics: the ~90 workgroups of a range hit the same 2048 addresses at about the same
+// time, 0.71 ms; one atomic per (block of row slots, id) run without windows: 8 M atomics, 0.34 ms; profiles/r04k_call.log,
+// r04j.)  Within a piece the entries come block of row slots by block, so the reciprocals it gathers stay in L2.
 __global__ __launch_bounds__(kBlock) void k_far_colsum(const CscTask* __restrict__ tasks, const int32_t* __restrict__ csc_sid, const double* __restrict__ csc_cp,
                                                         const uint32_t* __restrict__ csc_slot, uint32_t slot_base, int M, const double* __restrict__ theta,
-                                                        const double* __restrict__ inv, double* counts, const Ctrl* ctrl) {
+                                                        const double* __restrict__ inv, double* __restrict__ part, const Ctrl* ctrl) {
     if (ctrl->done) return;
     constexpr int kRange = 1 << kCscSidRangeLg;
     __shared__ double s_th[kRange], s_cnt[kRange];
@@ -278,8 +281,24 @@ __global__ __launch_bounds__(kBlock) void k_far_colsum(const CscTask* __restrict
         if (tail && key >= 0 && v != 0.0) RSEM_LDS_ADD(&s_cnt[key], v);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kRange; i += blockDim.x)
-        if (s_cnt[i] != 0.0) unsafeAtomicAdd(&counts[t.base + i], s_cnt[i]);
+    double* row = part + (size_t)blockIdx.x * kRange;
+    for (int i = threadIdx.x; i < kRange; i += blockDim.x) row[i] = s_cnt[i];
+}
+// counts[id] += the sum over the tasks of id's range of their rows (one workgroup per range; the lane kernel's own adds to
+// counts are complete: stream order)
+__global__ __launch_bounds__(kBlock) void k_far_colsum_close(const uint32_t* __restrict__ range_tasks, const double* __restrict__ part, int M, double* counts,
+                                                              const Ctrl* ctrl) {
+    if (ctrl->done) return;
+    constexpr int kRange = 1 << kCscSidRangeLg;
+    const uint32_t t0 = range_tasks[blockIdx.x], t1 = range_tasks[blockIdx.x + 1];
+    if (t0 == t1) return;
+    for (int i = threadIdx.x; i < kRange; i += blockDim.x) {
+        const int id = (int)(blockIdx.x << kCscSidRangeLg) + i;
+        if (id < 1 || id > M) continue;
+        double sum = 0.0;
+        for (uint32_t t = t0; t < t1; t++) sum += part[(size_t)t * kRange + i];
+        if (sum != 0.0) counts[id] += sum;
+    }
 }
 
 // Variant SELL (cross-check / fallback): every slice on its own, per-plane segmented shuffle
@@ -914,6 +933,7 @@ struct rsem_em_ctx {
     uint64_t long_nnz = 0;  // alignments of the reads left in the CSR
     uint32_t* d_rank = nullptr;  // caller row -> sorted row (inverse of L.d_order), built on first use (em_planes_view)
     double *d_xextra = nullptr, *d_xinv = nullptr;  // split rows: far part of the normaliser / its reciprocal, per row slot from L.x_slot_base
+    double* d_xpart = nullptr;   // split rows: one row of 2048 partial counts per task of the column pass
     int split_rows = 1;          // lay reads with ids outside their window out as split rows (LANE kernel only; option "split_rows")
     uint32_t n_far_units = 0;               // units with an id outside their LDS window (Unit::pad[0])
     unsigned long long n_stray_reads = 0;   // reads the second layout pass sorted apart (sell_build_refined)
@@ -982,7 +1002,9 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
         if (c->L.n_far) {  // ... and their far alignments' fractions afterwards, in transcript order
             hipLaunchKernelGGL(k_far_colsum, dim3(c->L.n_csc_tasks), dim3(kBlock), 0, st, (const CscTask*)c->L.d_csc_tasks, (const int32_t*)c->L.d_csc_sid,
                                (const double*)c->L.d_csc_cp, (const uint32_t*)c->L.d_csc_slot, c->L.x_slot_base, c->M, d_theta, (const double*)c->d_xinv,
-                               d_counts, ctrl);
+                               c->d_xpart, ctrl);
+            hipLaunchKernelGGL(k_far_colsum_close, dim3(c->L.n_csc_ranges), dim3(kBlock), 0, st, (const uint32_t*)c->L.d_csc_range_tasks,
+                               (const double*)c->d_xpart, c->M, d_counts, ctrl);
         }
     } else {
         if (c->L.n_x_rows) { rsem::set_last_error("the SELL kernel cannot walk a layout with split rows (set the kernel before the values, or option split_rows = 0)"); return RSEM_ERR_STATE; }
@@ -1067,8 +1089,8 @@ int fill_values(rsem_em_ctx* c) {
 
 void free_layout(rsem_em_ctx* c) {
     sell_free(c->L);
-    hipFree(c->d_rank); hipFree(c->d_xextra); hipFree(c->d_xinv);
-    c->d_rank = nullptr; c->d_xextra = nullptr; c->d_xinv = nullptr;
+    hipFree(c->d_rank); hipFree(c->d_xextra); hipFree(c->d_xinv); hipFree(c->d_xpart);
+    c->d_rank = nullptr; c->d_xextra = nullptr; c->d_xinv = nullptr; c->d_xpart = nullptr;
     hipFree(c->d_sval); hipFree(c->d_sncp); hipFree(c->d_sexp); hipFree(c->d_fill_err); hipFree(c->d_units); hipFree(c->d_noise_a);
     c->d_sval = nullptr; c->d_sncp = nullptr; c->d_sexp = nullptr; c->d_fill_err = nullptr; c->d_units = nullptr; c->d_noise_a = nullptr;
     c->h_units.clear();
@@ -1094,6 +1116,7 @@ int build_layout(rsem_em_ctx* c) {
         RSEM_HIP_TRY(dmalloc(&c->d_xinv, nxs));
         RSEM_HIP_TRY(hipMemsetAsync(c->d_xextra, 0, sizeof(double) * std::max<size_t>(nxs, 1), c->stream));
         RSEM_HIP_TRY(hipMemsetAsync(c->d_xinv, 0, sizeof(double) * std::max<size_t>(nxs, 1), c->stream));
+        RSEM_HIP_TRY(dmalloc(&c->d_xpart, (size_t)c->L.n_csc_tasks << kCscSidRangeLg));
     }
     c->layout_has_q32 = q32;
     RSEM_HIP_TRY(hipMalloc((void**)&c->d_sval, std::max<uint64_t>(c->L.val_bytes, 1)));

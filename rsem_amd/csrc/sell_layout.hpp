@@ -482,6 +482,8 @@ struct SellLayout {
     double* d_csc_cp = nullptr;
     CscTask* d_csc_tasks = nullptr;          // pieces of id ranges, one workgroup each (k_far_colsum)
     uint32_t n_csc_tasks = 0;
+    uint32_t* d_csc_range_tasks = nullptr;   // [n_csc_ranges + 1] the tasks of id range r: [range_tasks[r], range_tasks[r + 1])
+    uint32_t n_csc_ranges = 0;
     int32_t* d_ssid = nullptr;
     unsigned long long* d_masks = nullptr;
     uint32_t* d_slice_minsid = nullptr;
@@ -491,7 +493,7 @@ struct SellLayout {
 inline void sell_free(SellLayout& L) {
     hipFree(L.d_order); hipFree(L.d_shapes); hipFree(L.d_ssid); hipFree(L.d_masks); hipFree(L.d_slice_minsid); hipFree(L.d_slice_maxsid);
     hipFree(L.d_xanchor); hipFree(L.d_far_ptr); hipFree(L.d_far_sid); hipFree(L.d_far_src); hipFree(L.d_far_cp);
-    hipFree(L.d_csc_sid); hipFree(L.d_csc_src); hipFree(L.d_csc_slot); hipFree(L.d_csc_cp); hipFree(L.d_csc_tasks);
+    hipFree(L.d_csc_sid); hipFree(L.d_csc_src); hipFree(L.d_csc_slot); hipFree(L.d_csc_cp); hipFree(L.d_csc_tasks); hipFree(L.d_csc_range_tasks);
     L = SellLayout();
 }
 
@@ -595,11 +597,18 @@ inline int sell_build_far(SellLayout& L, hipStream_t st, const uint64_t* d_row_p
         if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
         for (size_t r = n_ranges; r-- > 0;) first[r] = std::min(first[r], first[r + 1]);  // (an absent range: empty, at its successor's start)
         std::vector<CscTask> tasks;
-        for (uint32_t r = 0; r < n_ranges; r++)
+        std::vector<uint32_t> range_tasks((size_t)n_ranges + 1, 0);
+        for (uint32_t r = 0; r < n_ranges; r++) {
+            range_tasks[r] = (uint32_t)tasks.size();
             for (uint64_t b = first[r]; b < first[r + 1]; b += kCscTaskEntries)
                 tasks.push_back(CscTask{b, (uint32_t)std::min<uint64_t>(kCscTaskEntries, first[r + 1] - b), (int32_t)(r << kCscSidRangeLg)});
+        }
+        range_tasks[n_ranges] = (uint32_t)tasks.size();
         L.n_csc_tasks = (uint32_t)tasks.size();
+        L.n_csc_ranges = n_ranges;
         e = dmalloc(&L.d_csc_tasks, tasks.size());
+        if (e == hipSuccess) e = dmalloc(&L.d_csc_range_tasks, range_tasks.size());
+        if (e == hipSuccess) e = hipMemcpyAsync(L.d_csc_range_tasks, range_tasks.data(), sizeof(uint32_t) * range_tasks.size(), hipMemcpyHostToDevice, st);
         if (e == hipSuccess && !tasks.empty()) e = hipMemcpyAsync(L.d_csc_tasks, tasks.data(), sizeof(CscTask) * tasks.size(), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
@@ -687,6 +696,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     L.n_far = 0;
     L.n_x_slots = 0;
     L.n_csc_tasks = 0;
+    L.n_csc_ranges = 0;
     uint32_t long_first = (h_first[kLongShape] == 0xffffffffu) ? (uint32_t)N1 : h_first[kLongShape];
     L.n_sell_rows = long_first;
     L.n_long_rows = (uint32_t)N1 - long_first;
