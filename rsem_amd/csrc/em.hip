@@ -245,59 +245,42 @@ __global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_xs, const uint
     extra[xs] = sum;
 }
 // After: the far alignments' fractions, theta[sid] * conprb / normaliser of their read (inv[], left by the lane kernel), added
-// to counts[sid] in column order -- the transposed (CSC) pass instead of a global atomic per alignment.  One workgroup per
-// task = a piece of one range of 2048 ids (sell_layout.hpp CscTask): theta of the range is staged in LDS, the fractions are
-// summed per id by a segmented shuffle reduction and added to an LDS window, which the workgroup leaves as a row of `part`
-// (plain coalesced stores); k_far_colsum_close then adds the rows of every range's tasks to the counts -- no atomic at
-// all.  (Windows flushed by device atomics: the ~90 workgroups of a range hit the same 2048 addresses at about the same
-// time, 0.71 ms; one atomic per (block of row slots, id) run without windows: 8 M atomics, 0.34 ms; profiles/r04k_call.log,
-// r04j.)  Within a piece the entries come block of row slots by block, so the reciprocals it gathers stay in L2.
-__global__ __launch_bounds__(kBlock) void k_far_colsum(const CscTask* __restrict__ tasks, const int32_t* __restrict__ csc_sid, const double* __restrict__ csc_cp,
-                                                        const uint32_t* __restrict__ csc_slot, uint32_t slot_base, int M, const double* __restrict__ theta,
-                                                        const double* __restrict__ inv, double* __restrict__ part, const Ctrl* ctrl) {
+// to counts[sid] in transcript order: consecutive entries of one id are summed by a segmented shuffle reduction, one atomic
+// per id and wave -- the transposed (CSC) pass instead of a global atomic per alignment.  A wave takes 4 x 64 consecutive
+// entries per step and issues all their loads, then all their gathers, before it reduces.
+__global__ __launch_bounds__(kBlock) void k_far_colsum(uint64_t n_far, const int32_t* __restrict__ csc_sid, const double* __restrict__ csc_cp,
+                                                        const uint32_t* __restrict__ csc_slot, uint32_t slot_base, const double* __restrict__ theta,
+                                                        const double* __restrict__ inv, double* counts, const Ctrl* ctrl) {
     if (ctrl->done) return;
-    constexpr int kRange = 1 << kCscSidRangeLg;
-    __shared__ double s_th[kRange], s_cnt[kRange];
-    const CscTask t = tasks[blockIdx.x];
-    for (int i = threadIdx.x; i < kRange; i += blockDim.x) {
-        const int id = t.base + i;
-        s_th[i] = (id >= 1 && id <= M) ? theta[id] : 0.0;
-        s_cnt[i] = 0.0;
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63;
-    for (uint32_t b = 0; b < t.count; b += kBlock) {  // (uniform over the workgroup)
-        const uint32_t k = b + threadIdx.x;
-        int key = -1;
-        double v = 0.0;
-        if (k < t.count) {
-            const uint64_t i = t.begin + k;
-            key = csc_sid[i] - t.base;
-            double f = s_th[key] * stream_load(&csc_cp[i]);
-            if (f < kEpsilon) f = 0.0;
-            v = f * inv[csc_slot[i] - slot_base];
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr int kU = 4;
+    for (uint64_t b = wave * (64 * kU); b < n_far; b += n_waves * (64 * kU)) {  // (uniform over the wave)
+        int key[kU];
+        double cv[kU];
+        uint32_t sl[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const uint64_t i = b + (uint64_t)(u * 64 + lane);
+            const bool in = i < n_far;
+            key[u] = in ? csc_sid[i] : -1;
+            cv[u] = in ? stream_load(&csc_cp[i]) : 0.0;
+            sl[u] = in ? csc_slot[i] : slot_base;
         }
-        const bool tail = seg_reduce(key, v, lane, 0);
-        if (tail && key >= 0 && v != 0.0) RSEM_LDS_ADD(&s_cnt[key], v);
-    }
-    __syncthreads();
-    double* row = part + (size_t)blockIdx.x * kRange;
-    for (int i = threadIdx.x; i < kRange; i += blockDim.x) row[i] = s_cnt[i];
-}
-// counts[id] += the sum over the tasks of id's range of their rows (one workgroup per range; the lane kernel's own adds to
-// counts are complete: stream order)
-__global__ __launch_bounds__(kBlock) void k_far_colsum_close(const uint32_t* __restrict__ range_tasks, const double* __restrict__ part, int M, double* counts,
-                                                              const Ctrl* ctrl) {
-    if (ctrl->done) return;
-    constexpr int kRange = 1 << kCscSidRangeLg;
-    const uint32_t t0 = range_tasks[blockIdx.x], t1 = range_tasks[blockIdx.x + 1];
-    if (t0 == t1) return;
-    for (int i = threadIdx.x; i < kRange; i += blockDim.x) {
-        const int id = (int)(blockIdx.x << kCscSidRangeLg) + i;
-        if (id < 1 || id > M) continue;
-        double sum = 0.0;
-        for (uint32_t t = t0; t < t1; t++) sum += part[(size_t)t * kRange + i];
-        if (sum != 0.0) counts[id] += sum;
+        double th[kU], iv[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            th[u] = theta[key[u] > 0 ? key[u] : 0];
+            iv[u] = inv[sl[u] - slot_base];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            double f = th[u] * cv[u];
+            if (f < kEpsilon) f = 0.0;
+            double v = key[u] > 0 ? f * iv[u] : 0.0;
+            const bool tail = seg_reduce(key[u], v, lane, 0);
+            if (tail && key[u] > 0 && v != 0.0) unsafeAtomicAdd(&counts[key[u]], v);
+        }
     }
 }
 
@@ -933,7 +916,6 @@ struct rsem_em_ctx {
     uint64_t long_nnz = 0;  // alignments of the reads left in the CSR
     uint32_t* d_rank = nullptr;  // caller row -> sorted row (inverse of L.d_order), built on first use (em_planes_view)
     double *d_xextra = nullptr, *d_xinv = nullptr;  // split rows: far part of the normaliser / its reciprocal, per row slot from L.x_slot_base
-    double* d_xpart = nullptr;   // split rows: one row of 2048 partial counts per task of the column pass
     int split_rows = 1;          // lay reads with ids outside their window out as split rows (LANE kernel only; option "split_rows")
     uint32_t n_far_units = 0;               // units with an id outside their LDS window (Unit::pad[0])
     unsigned long long n_stray_reads = 0;   // reads the second layout pass sorted apart (sell_build_refined)
@@ -1000,11 +982,10 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
                                d_theta, (const double*)nullptr, 0.0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid,
                                c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs(), xa);
         if (c->L.n_far) {  // ... and their far alignments' fractions afterwards, in transcript order
-            hipLaunchKernelGGL(k_far_colsum, dim3(c->L.n_csc_tasks), dim3(kBlock), 0, st, (const CscTask*)c->L.d_csc_tasks, (const int32_t*)c->L.d_csc_sid,
-                               (const double*)c->L.d_csc_cp, (const uint32_t*)c->L.d_csc_slot, c->L.x_slot_base, c->M, d_theta, (const double*)c->d_xinv,
-                               c->d_xpart, ctrl);
-            hipLaunchKernelGGL(k_far_colsum_close, dim3(c->L.n_csc_ranges), dim3(kBlock), 0, st, (const uint32_t*)c->L.d_csc_range_tasks,
-                               (const double*)c->d_xpart, c->M, d_counts, ctrl);
+            static const int per_cu = []() { const char* e = getenv("RSEM_HIP_COLSUM_WG_PER_CU"); return e ? std::max(1, atoi(e)) : 8; }();  // measurement knob
+            const int grid = std::max(1, std::min<int>(c->n_cus * per_cu, rsem::ceil_div(c->L.n_far, kBlock * 4)));
+            hipLaunchKernelGGL(k_far_colsum, dim3(grid), dim3(kBlock), 0, st, c->L.n_far, (const int32_t*)c->L.d_csc_sid, (const double*)c->L.d_csc_cp,
+                               (const uint32_t*)c->L.d_csc_slot, c->L.x_slot_base, d_theta, (const double*)c->d_xinv, d_counts, ctrl);
         }
     } else {
         if (c->L.n_x_rows) { rsem::set_last_error("the SELL kernel cannot walk a layout with split rows (set the kernel before the values, or option split_rows = 0)"); return RSEM_ERR_STATE; }
@@ -1089,8 +1070,8 @@ int fill_values(rsem_em_ctx* c) {
 
 void free_layout(rsem_em_ctx* c) {
     sell_free(c->L);
-    hipFree(c->d_rank); hipFree(c->d_xextra); hipFree(c->d_xinv); hipFree(c->d_xpart);
-    c->d_rank = nullptr; c->d_xextra = nullptr; c->d_xinv = nullptr; c->d_xpart = nullptr;
+    hipFree(c->d_rank); hipFree(c->d_xextra); hipFree(c->d_xinv);
+    c->d_rank = nullptr; c->d_xextra = nullptr; c->d_xinv = nullptr;
     hipFree(c->d_sval); hipFree(c->d_sncp); hipFree(c->d_sexp); hipFree(c->d_fill_err); hipFree(c->d_units); hipFree(c->d_noise_a);
     c->d_sval = nullptr; c->d_sncp = nullptr; c->d_sexp = nullptr; c->d_fill_err = nullptr; c->d_units = nullptr; c->d_noise_a = nullptr;
     c->h_units.clear();
@@ -1116,7 +1097,6 @@ int build_layout(rsem_em_ctx* c) {
         RSEM_HIP_TRY(dmalloc(&c->d_xinv, nxs));
         RSEM_HIP_TRY(hipMemsetAsync(c->d_xextra, 0, sizeof(double) * std::max<size_t>(nxs, 1), c->stream));
         RSEM_HIP_TRY(hipMemsetAsync(c->d_xinv, 0, sizeof(double) * std::max<size_t>(nxs, 1), c->stream));
-        RSEM_HIP_TRY(dmalloc(&c->d_xpart, (size_t)c->L.n_csc_tasks << kCscSidRangeLg));
     }
     c->layout_has_q32 = q32;
     RSEM_HIP_TRY(hipMalloc((void**)&c->d_sval, std::max<uint64_t>(c->L.val_bytes, 1)));

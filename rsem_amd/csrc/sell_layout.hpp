@@ -403,35 +403,20 @@ __global__ void k_x_far(const Shape* __restrict__ shapes, int n_shapes, uint32_t
     for (uint64_t j = fr; j < to; j++)
         if (!in_split_window(sid[j], anchor, reach)) { far_sid[e] = sid[j]; far_src[e] = j; far_eslot[e] = slot; ++e; }
 }
-// Column order = (range of kCscSidRange transcript ids, block of 2^kCscSlotBlockLg row slots, id).  One workgroup of the
-// column pass takes a piece of ONE id range (CscTask): it sums into an LDS window of that range and leaves with one atomic
-// per touched id, instead of one per (block, id) run; within the piece the entries come block by block, so the reciprocals
-// it gathers lie within 512 KB at a time -- L2 of whichever XCD asks -- where a gather over all the slots of configs[1]'s
-// size (80 MB) went to the Infinity Cache for every entry (0.68 ms per round; blocks of 2^12 ... 2^31 slots measured:
-// profiles/r04j_call.log).
+// Column order = (block of row slots, transcript id): within a block of 2^kCscSlotBlockLg slots the reciprocals the column
+// pass gathers are 512 KB of memory -- they stay in the L2 of whichever XCD asks -- where a gather over all the slots of
+// configs[1]'s size (80 MB) went to the Infinity Cache for every entry (0.68 ms per round).  Smaller blocks mean more
+// (block, id) runs, i.e. more atomics: 2^12 ... 2^31 slots measured, 2^15-2^16 is the minimum (0.335 ms; profiles/r04j_call.log,
+// r04j2_call.log).  Measured and dropped: workgroup tasks per range of 2048 ids with an LDS window (0.70 ms whether the
+// windows leave by atomics or as rows summed afterwards: a workgroup walks its piece one dependent step at a time,
+// profiles/r04k_call.log, r04k2_call.log).
 constexpr int kCscSlotBlockLg = 16;
-constexpr int kCscSidRangeLg = 11;              // 2048 ids: the window of the column pass (16 KB of LDS)
-constexpr uint32_t kCscTaskEntries = 1u << 14;  // entries per workgroup task
-struct CscTask {
-    uint64_t begin;  // first entry
-    uint32_t count;
-    int32_t base;    // first id of the range
-};
 __global__ void k_x_csc_keys(uint64_t n_far, uint32_t x_slot_base, const int32_t* __restrict__ far_sid, const uint32_t* __restrict__ far_eslot,
                              uint64_t* keys, uint64_t* vals, int block_lg) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_far) return;
-    const uint32_t id = (uint32_t)far_sid[e];
-    keys[e] = ((uint64_t)(id >> kCscSidRangeLg) << 27) | ((uint64_t)(((far_eslot[e] - x_slot_base) >> block_lg) & 0xffffu) << kCscSidRangeLg) |
-              (id & ((1u << kCscSidRangeLg) - 1));
+    keys[e] = ((uint64_t)((far_eslot[e] - x_slot_base) >> block_lg) << 32) | (uint32_t)far_sid[e];
     vals[e] = e;
-}
-// first entry of every id range present in the sorted entries
-__global__ void k_x_csc_first(uint64_t n_far, const int32_t* __restrict__ csc_sid, uint64_t* first) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_far) return;
-    const uint32_t r = (uint32_t)csc_sid[i] >> kCscSidRangeLg;
-    if (i == 0 || ((uint32_t)csc_sid[i - 1] >> kCscSidRangeLg) != r) first[r] = i;
 }
 __global__ void k_x_csc(uint64_t n_far, const uint64_t* __restrict__ perm, const int32_t* __restrict__ far_sid, const uint64_t* __restrict__ far_src,
                         const uint32_t* __restrict__ far_eslot, int32_t* csc_sid, uint64_t* csc_src, uint32_t* csc_slot) {
@@ -480,10 +465,6 @@ struct SellLayout {
     uint64_t* d_csc_src = nullptr;
     uint32_t* d_csc_slot = nullptr;          // ... each with the row slot of its read
     double* d_csc_cp = nullptr;
-    CscTask* d_csc_tasks = nullptr;          // pieces of id ranges, one workgroup each (k_far_colsum)
-    uint32_t n_csc_tasks = 0;
-    uint32_t* d_csc_range_tasks = nullptr;   // [n_csc_ranges + 1] the tasks of id range r: [range_tasks[r], range_tasks[r + 1])
-    uint32_t n_csc_ranges = 0;
     int32_t* d_ssid = nullptr;
     unsigned long long* d_masks = nullptr;
     uint32_t* d_slice_minsid = nullptr;
@@ -493,7 +474,7 @@ struct SellLayout {
 inline void sell_free(SellLayout& L) {
     hipFree(L.d_order); hipFree(L.d_shapes); hipFree(L.d_ssid); hipFree(L.d_masks); hipFree(L.d_slice_minsid); hipFree(L.d_slice_maxsid);
     hipFree(L.d_xanchor); hipFree(L.d_far_ptr); hipFree(L.d_far_sid); hipFree(L.d_far_src); hipFree(L.d_far_cp);
-    hipFree(L.d_csc_sid); hipFree(L.d_csc_src); hipFree(L.d_csc_slot); hipFree(L.d_csc_cp); hipFree(L.d_csc_tasks); hipFree(L.d_csc_range_tasks);
+    hipFree(L.d_csc_sid); hipFree(L.d_csc_src); hipFree(L.d_csc_slot); hipFree(L.d_csc_cp);
     L = SellLayout();
 }
 
@@ -522,7 +503,7 @@ inline int sell_fill_values(const SellLayout& L, hipStream_t st, const uint64_t*
 
 // The far entries of the split rows, in row order and in column (transcript id) order.  Called by sell_build once the shape
 // table and the sorted order stand.
-inline int sell_build_far(SellLayout& L, hipStream_t st, const uint64_t* d_row_ptr, const int32_t* d_sid, const uint64_t* d_keys_sorted, int32_t M) {
+inline int sell_build_far(SellLayout& L, hipStream_t st, const uint64_t* d_row_ptr, const int32_t* d_sid, const uint64_t* d_keys_sorted) {
     const uint32_t nx = L.n_x_rows;
     if (!nx) return RSEM_OK;
     const uint32_t nxs = L.n_slots - L.x_slot_base;
@@ -576,42 +557,12 @@ inline int sell_build_far(SellLayout& L, hipStream_t st, const uint64_t* d_row_p
         hipLaunchKernelGGL(k_x_csc_keys, dim3(rsem::ceil_div(nf, kBlock)), dim3(kBlock), 0, st, nf, L.x_slot_base, (const int32_t*)L.d_far_sid,
                            (const uint32_t*)d_eslot, d_k_in, d_perm_in, block_lg);
         tb = 0;
-        e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint64_t*)d_k_in, d_k_out, (const uint64_t*)d_perm_in, d_perm, nf, 0, 48, st);
+        e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint64_t*)d_k_in, d_k_out, (const uint64_t*)d_perm_in, d_perm, nf, 0, 64, st);
         if (e == hipSuccess) e = hipMalloc(&d_tmp, tb ? tb : 1);
-        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, (const uint64_t*)d_k_in, d_k_out, (const uint64_t*)d_perm_in, d_perm, nf, 0, 48, st);
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, (const uint64_t*)d_k_in, d_k_out, (const uint64_t*)d_perm_in, d_perm, nf, 0, 64, st);
         if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
         hipLaunchKernelGGL(k_x_csc, dim3(rsem::ceil_div(nf, kBlock)), dim3(kBlock), 0, st, nf, (const uint64_t*)d_perm, (const int32_t*)L.d_far_sid,
                            (const uint64_t*)L.d_far_src, (const uint32_t*)d_eslot, L.d_csc_sid, L.d_csc_src, L.d_csc_slot);
-        // the workgroup tasks: every id range present, cut into pieces of kCscTaskEntries entries
-        const uint32_t n_ranges = ((uint32_t)M >> kCscSidRangeLg) + 1;
-        hipFree(d_k_in); d_k_in = nullptr;
-        e = dmalloc(&d_k_in, (size_t)n_ranges + 1);
-        if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
-        std::vector<uint64_t> first((size_t)n_ranges + 1, nf);
-        e = hipMemcpyAsync(d_k_in, first.data(), sizeof(uint64_t) * first.size(), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_x_csc_first, dim3(rsem::ceil_div(nf, kBlock)), dim3(kBlock), 0, st, nf, (const int32_t*)L.d_csc_sid, d_k_in);
-            e = hipMemcpyAsync(first.data(), d_k_in, sizeof(uint64_t) * first.size(), hipMemcpyDeviceToHost, st);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
-        for (size_t r = n_ranges; r-- > 0;) first[r] = std::min(first[r], first[r + 1]);  // (an absent range: empty, at its successor's start)
-        std::vector<CscTask> tasks;
-        std::vector<uint32_t> range_tasks((size_t)n_ranges + 1, 0);
-        for (uint32_t r = 0; r < n_ranges; r++) {
-            range_tasks[r] = (uint32_t)tasks.size();
-            for (uint64_t b = first[r]; b < first[r + 1]; b += kCscTaskEntries)
-                tasks.push_back(CscTask{b, (uint32_t)std::min<uint64_t>(kCscTaskEntries, first[r + 1] - b), (int32_t)(r << kCscSidRangeLg)});
-        }
-        range_tasks[n_ranges] = (uint32_t)tasks.size();
-        L.n_csc_tasks = (uint32_t)tasks.size();
-        L.n_csc_ranges = n_ranges;
-        e = dmalloc(&L.d_csc_tasks, tasks.size());
-        if (e == hipSuccess) e = dmalloc(&L.d_csc_range_tasks, range_tasks.size());
-        if (e == hipSuccess) e = hipMemcpyAsync(L.d_csc_range_tasks, range_tasks.data(), sizeof(uint32_t) * range_tasks.size(), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess && !tasks.empty()) e = hipMemcpyAsync(L.d_csc_tasks, tasks.data(), sizeof(CscTask) * tasks.size(), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
     }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -695,8 +646,6 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     L.x_slot_base = 0;
     L.n_far = 0;
     L.n_x_slots = 0;
-    L.n_csc_tasks = 0;
-    L.n_csc_ranges = 0;
     uint32_t long_first = (h_first[kLongShape] == 0xffffffffu) ? (uint32_t)N1 : h_first[kLongShape];
     L.n_sell_rows = long_first;
     L.n_long_rows = (uint32_t)N1 - long_first;
@@ -738,7 +687,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     RSEM_HIP_TRY(dmalloc(&L.d_slice_maxsid, (size_t)L.n_slices));
     RSEM_HIP_TRY(hipMemsetAsync(L.d_ssid, 0, sizeof(int32_t) * L.n_planes * 64, st));
     if (L.n_x_rows) {
-        const int frc = sell_build_far(L, st, d_row_ptr, d_sid, d_keys2, M);
+        const int frc = sell_build_far(L, st, d_row_ptr, d_sid, d_keys2);
         if (frc != RSEM_OK) { cleanup(); return frc; }
     }
     if (L.n_sell_rows) {
