@@ -982,8 +982,10 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
                                d_theta, (const double*)nullptr, 0.0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid,
                                c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs(), xa);
         if (c->L.n_far) {  // ... and their far alignments' fractions afterwards, in transcript order
-            static const int per_cu = []() { const char* e = getenv("RSEM_HIP_COLSUM_WG_PER_CU"); return e ? std::max(1, atoi(e)) : 8; }();  // measurement knob
-            const int grid = std::max(1, std::min<int>(c->n_cus * per_cu, rsem::ceil_div(c->L.n_far, kBlock * 4)));
+            // one step of 4 x 64 entries per wave: the pass is a chain of dependent trips (entries -> theta, reciprocal -> shuffles ->
+            // atomic), and more waves in flight hide more of it than a loop per wave (8 / 16 / 32 workgroups per CU: 335 / 326 /
+            // 312 us at configs[1]'s size without gene structure, the whole grid 294: profiles/r04l_call.log)
+            const int grid = std::max(1, rsem::ceil_div(c->L.n_far, kBlock * 4));
             hipLaunchKernelGGL(k_far_colsum, dim3(grid), dim3(kBlock), 0, st, c->L.n_far, (const int32_t*)c->L.d_csc_sid, (const double*)c->L.d_csc_cp,
                                (const uint32_t*)c->L.d_csc_slot, c->L.x_slot_base, d_theta, (const double*)c->d_xinv, d_counts, ctrl);
         }
