@@ -205,7 +205,7 @@ __device__ inline bool seg_reduce(int key, double& v, int lane, int lg) {
 // ---- split rows: the two passes around the lane kernel (sell_layout.hpp: sell_build_far) ----------------------------------------
 // Before: the far part of every split read's normaliser, sum over its far alignments of theta[sid] * conprb (each clamped
 // like every term of EM.cpp:212-219).  Thread per read: a split read has a handful of far alignments.
-constexpr int kRowsumCap = 1024;  // far entries of a wave's 64 row slots staged in LDS (8 KB per wave); beyond that the slots walk global memory
+constexpr int kRowsumCap = 512;  // far entries of a wave's 64 row slots staged in LDS (4 KB per wave: room for 32 waves per CU); beyond that the slots walk global memory
 __global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_xs, const uint64_t* __restrict__ far_ptr, const int32_t* __restrict__ far_sid,
                                                         const double* __restrict__ far_cp, const double* __restrict__ theta, double* __restrict__ extra,
                                                         const Ctrl* ctrl) {
