@@ -633,7 +633,8 @@ int main(int argc, char* argv[]) {
     // of GB at BASELINE sizes) go back to the system on a helper thread while the device loop runs -- the host only polls a
     // pinned mirror then -- instead of at exit, where unmapping them was 3 s of wall clock with nothing else left to do.
     // (Not during the model rounds: unmapping takes the address space's lock, and every call of those rounds that touches
-    // memory waited for it -- 1.8 s over 11 rounds at configs[2].)  Kept: row_ptr and the transcript ids (.ofg / BAM output).
+    // memory waited for it -- about 1.5 s over 11 rounds at configs[2], profiles/r04b_call.log.  During the device loop it costs
+    // 0.3-0.6 s and saves 1.3 s at exit: profiles/r04i_call.log.)  Kept: row_ptr and the transcript ids (.ofg / BAM output).
     std::thread releaser([&]() {
         if (getenv("RSEM_HIP_NO_RELEASE")) return;  // (measurement: everything stays until exit)
         for (int tag = 0; tag < 3; tag++)
