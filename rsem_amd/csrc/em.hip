@@ -206,6 +206,7 @@ __device__ inline bool seg_reduce(int key, double& v, int lane, int lg) {
 // Before: the far part of every split read's normaliser, sum over its far alignments of theta[sid] * conprb (each clamped
 // like every term of EM.cpp:212-219).  Thread per read: a split read has a handful of far alignments.
 constexpr int kRowsumCap = 512;  // far entries of a wave's 64 row slots staged in LDS (4 KB per wave: room for 32 waves per CU); beyond that the slots walk global memory
+template <bool kBatched>
 __global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_xs, const uint64_t* __restrict__ far_ptr, const int32_t* __restrict__ far_sid,
                                                         const double* __restrict__ far_cp, const double* __restrict__ theta, double* __restrict__ extra,
                                                         const Ctrl* ctrl) {
@@ -215,6 +216,9 @@ __global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_xs, const uint
     // every term of EM.cpp:212-219) goes to LDS, and each lane then adds up its own slot's terms from there.  (With every
     // lane reading its own slot's entries straight from global memory the loads of a wave were 48 bytes apart: 0.29 ms for
     // 37 M entries at configs[1]'s size, profiles/r04g_call.log.)
+    // kBatched: the wave issues the loads of 4 x 64 entries, then their 4 x 64 theta gathers, then writes the terms -- two
+    // dependent trips to memory per 256 entries instead of two per 64 --, and waits for nobody but itself: its LDS row is its
+    // own, and the LDS serves a wave's instructions in order.
     __shared__ double s_term[kBlock / 64][kRowsumCap];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t xs = blockIdx.x * blockDim.x + threadIdx.x;  // row slot - x_slot_base
@@ -224,13 +228,44 @@ __global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_xs, const uint
     const uint64_t n = E1 - E0;
     const bool staged = n <= (uint64_t)kRowsumCap;
     if (staged) {
-        for (uint64_t k = (uint64_t)lane; k < n; k += 64) {
-            double f = theta[far_sid[E0 + k]] * stream_load(&far_cp[E0 + k]);
-            if (f < kEpsilon) f = 0.0;
-            s_term[w][k] = f;
+        if (kBatched) {
+            constexpr int kB = 4;
+            for (uint32_t k0 = 0; k0 < (uint32_t)n; k0 += 64 * kB) {  // (uniform over the wave)
+                int sd[kB];
+                double cv[kB], th[kB];
+#pragma unroll
+                for (int u = 0; u < kB; u++) {
+                    // (an entry past the end reads the last one instead: a load under a condition becomes a branch and a
+                    // wait per load)
+                    const uint32_t k = min(k0 + (uint32_t)(u * 64 + lane), (uint32_t)n - 1u);
+                    sd[u] = far_sid[E0 + k];
+                    cv[u] = stream_load(&far_cp[E0 + k]);
+                }
+#pragma unroll
+                for (int u = 0; u < kB; u++) th[u] = theta[sd[u]];
+#pragma unroll
+                for (int u = 0; u < kB; u++) {
+                    const uint32_t k = min(k0 + (uint32_t)(u * 64 + lane), (uint32_t)n - 1u);  // (past the end: the last entry's own term once more)
+                    double f = th[u] * cv[u];
+                    if (f < kEpsilon) f = 0.0;
+                    s_term[w][k] = f;
+                }
+            }
+        } else {
+            for (uint64_t k = (uint64_t)lane; k < n; k += 64) {
+                double f = theta[far_sid[E0 + k]] * stream_load(&far_cp[E0 + k]);
+                if (f < kEpsilon) f = 0.0;
+                s_term[w][k] = f;
+            }
         }
     }
-    __syncthreads();
+    if (kBatched) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
     if (!in) return;
     double sum = 0.0;
     if (staged) {
@@ -248,25 +283,39 @@ __global__ __launch_bounds__(kBlock) void k_far_rowsum(uint32_t n_xs, const uint
 // to counts[sid] in transcript order: consecutive entries of one id are summed by a segmented shuffle reduction, one atomic
 // per id and wave -- the transposed (CSC) pass instead of a global atomic per alignment.  A wave takes 4 x 64 consecutive
 // entries per step and issues all their loads, then all their gathers, before it reduces.
+// kXcd: workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup dispatch"; only speed depends on it), so the
+// workgroups are renumbered to give every XCD one contiguous eighth of the entries: the block of row slots whose reciprocals
+// its waves gather is then in ONE L2 at a time instead of every block in flight in all eight.
+template <bool kXcd>
 __global__ __launch_bounds__(kBlock) void k_far_colsum(uint64_t n_far, const int32_t* __restrict__ csc_sid, const double* __restrict__ csc_cp,
                                                         const uint32_t* __restrict__ csc_slot, uint32_t slot_base, const double* __restrict__ theta,
                                                         const double* __restrict__ inv, double* counts, const Ctrl* ctrl) {
     if (ctrl->done) return;
     const int lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t wg = blockIdx.x;
+    if (kXcd) {
+        const uint32_t x = blockIdx.x & 7, i = blockIdx.x >> 3, q = gridDim.x >> 3, r = gridDim.x & 7;
+        wg = x * q + (x < r ? x : r) + i;  // XCD x takes workgroups [x q + min(x, r), ...): q + (x < r) of them
+    }
+    const uint64_t wave = ((uint64_t)wg * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     constexpr int kU = 4;
     for (uint64_t b = wave * (64 * kU); b < n_far; b += n_waves * (64 * kU)) {  // (uniform over the wave)
-        int key[kU];
+        int key[kU], past[kU];
         double cv[kU];
         uint32_t sl[kU];
 #pragma unroll
         for (int u = 0; u < kU; u++) {
-            const uint64_t i = b + (uint64_t)(u * 64 + lane);
-            const bool in = i < n_far;
-            key[u] = in ? csc_sid[i] : -1;
-            cv[u] = in ? stream_load(&csc_cp[i]) : 0.0;
-            sl[u] = in ? csc_slot[i] : slot_base;
+            // (an entry past the end reads the last one instead and is keyed -1: a load under a condition becomes a branch and
+            // a wait per load)
+            const uint64_t i = b + (uint64_t)(u * 64 + lane), ic = i < n_far ? i : n_far - 1;
+            past[u] = -(int)(i >= n_far);
+            key[u] = csc_sid[ic];
+            cv[u] = stream_load(&csc_cp[ic]);
+            sl[u] = csc_slot[ic];
         }
+        __builtin_amdgcn_sched_barrier(0);  // (every load above is issued before the first one is waited for)
+#pragma unroll
+        for (int u = 0; u < kU; u++) key[u] |= past[u];
         double th[kU], iv[kU];
 #pragma unroll
         for (int u = 0; u < kU; u++) {
@@ -974,8 +1023,9 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
         XArgs xa;
         if (c->L.n_x_rows) {  // split rows: the far part of their normalisers first
             xa.extra = c->d_xextra; xa.inv = c->d_xinv; xa.slot_base = c->L.x_slot_base;
-            hipLaunchKernelGGL(k_far_rowsum, dim3(rsem::ceil_div(c->L.n_x_slots, kBlock)), dim3(kBlock), 0, st, c->L.n_x_slots, (const uint64_t*)c->L.d_far_ptr,
-                               (const int32_t*)c->L.d_far_sid, (const double*)c->L.d_far_cp, d_theta, c->d_xextra, ctrl);
+            static const bool batched = !(getenv("RSEM_HIP_ROWSUM_BATCHED") && atoi(getenv("RSEM_HIP_ROWSUM_BATCHED")) == 0);  // measurement knob
+            hipLaunchKernelGGL(batched ? k_far_rowsum<true> : k_far_rowsum<false>, dim3(rsem::ceil_div(c->L.n_x_slots, kBlock)), dim3(kBlock), 0, st, c->L.n_x_slots,
+                               (const uint64_t*)c->L.d_far_ptr, (const int32_t*)c->L.d_far_sid, (const double*)c->L.d_far_cp, d_theta, c->d_xextra, ctrl);
         }
         if (c->n_units)
             hipLaunchKernelGGL((k_estep_lane<false, false>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
@@ -986,8 +1036,9 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
             // atomic), and more waves in flight hide more of it than a loop per wave (8 / 16 / 32 workgroups per CU: 335 / 326 /
             // 312 us at configs[1]'s size without gene structure, the whole grid 294: profiles/r04l_call.log)
             const int grid = std::max(1, rsem::ceil_div(c->L.n_far, kBlock * 4));
-            hipLaunchKernelGGL(k_far_colsum, dim3(grid), dim3(kBlock), 0, st, c->L.n_far, (const int32_t*)c->L.d_csc_sid, (const double*)c->L.d_csc_cp,
-                               (const uint32_t*)c->L.d_csc_slot, c->L.x_slot_base, d_theta, (const double*)c->d_xinv, d_counts, ctrl);
+            static const bool xcd = !(getenv("RSEM_HIP_COLSUM_XCD") && atoi(getenv("RSEM_HIP_COLSUM_XCD")) == 0);  // measurement knob
+            hipLaunchKernelGGL(xcd ? k_far_colsum<true> : k_far_colsum<false>, dim3(grid), dim3(kBlock), 0, st, c->L.n_far, (const int32_t*)c->L.d_csc_sid,
+                               (const double*)c->L.d_csc_cp, (const uint32_t*)c->L.d_csc_slot, c->L.x_slot_base, d_theta, (const double*)c->d_xinv, d_counts, ctrl);
         }
     } else {
         if (c->L.n_x_rows) { rsem::set_last_error("the SELL kernel cannot walk a layout with split rows (set the kernel before the values, or option split_rows = 0)"); return RSEM_ERR_STATE; }
