@@ -76,6 +76,35 @@ def _theta_line(path):
         return np.array(f.read().split("\n")[1].split(), float)
 
 
+def one_socket_cores(want=64):
+    """`want` cpus of ONE package, one hardware thread per physical core (sysfs), or None if the host has no such set or no
+    `taskset`.  The reference's rounds >= 12 are bound by memory bandwidth and thread hand-offs: -p 64 pinned like this was
+    its fastest setting on the GPU box (11.8 ms per round at 5 % of configs[2]; unpinned 13.2; -p 128 pinned / unpinned
+    15.6 / 15.2: profiles/r04p_ref_threads_probe.json, tools/ref_threads_probe.py; -p 256: 25.4, round 2)."""
+    import glob
+    import shutil
+    if not shutil.which("taskset"):
+        return None
+    try:
+        by_pkg = {}
+        for d in glob.glob("/sys/devices/system/cpu/cpu[0-9]*"):
+            cpu = int(os.path.basename(d)[3:])
+            with open(d + "/topology/physical_package_id") as f:
+                pkg = int(f.read())
+            with open(d + "/topology/thread_siblings_list") as f:
+                first = int(f.read().strip().replace("-", ",").split(",")[0])
+            if first == cpu:
+                by_pkg.setdefault(pkg, []).append(cpu)
+        allowed = os.sched_getaffinity(0)
+        for pkg in sorted(by_pkg):
+            cpus = sorted(c for c in by_pkg[pkg] if c in allowed)
+            if len(cpus) >= want:
+                return cpus[:want]
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True):
     """The UNMODIFIED reference binary (oracle/_ref/rsem-run-em, built from /root/reference) and the drop-in
     (rsem_amd/bin/rsem-run-em) on the SAME generated .temp files of the bench workload's shape (tools/gen_temp.cpp: model
@@ -98,7 +127,9 @@ def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True):
     cs = CPU_SAMPLE[config]
     rt = cs["read_type"]
     ncpu = os.cpu_count() or 1
-    cores = min(64, ncpu)  # -p 64 beat -p 256 in every run of rounds 1-2 (13.0 vs 25.4 ms per round, profiles/r02b_bench_default_driver_args.json)
+    cores = min(64, ncpu)  # -p 64 beat -p 128 and -p 256 in every run (one_socket_cores)
+    pinned = one_socket_cores(cores) if cores == 64 else None
+    pin = ["taskset", "-c", ",".join(map(str, pinned))] if pinned else []
     d = tempfile.mkdtemp(prefix="rsem_bench_", dir="/tmp")
 
     def generate(root, n_reads):
@@ -127,7 +158,7 @@ def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True):
         nhits, n1, gen_s = generate(small, n_reads)
         # --- the reference, to convergence (or to the limit: then only its per-round rate is known)
         t0 = time.perf_counter()
-        p = subprocess.Popen([ref_em] + em_args(small), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        p = subprocess.Popen(pin + [ref_em] + em_args(small), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
         marks = []  # (ROUND, arrival time)
         finished = False
         for line in p.stdout:
@@ -150,13 +181,13 @@ def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True):
         startup_s = marks[0][1] - t0
         early_s = late[0][1] - marks[0][1]
         cpu = {"value": nhits / per_round, "unit": "read-alignments/s", "cores": cores, "kind": "reference",
-               "sample": "oracle/_ref/rsem-run-em -p %d on a generated %s input of the bench workload's shape at %.0f %% of its reads: %d alignable "
+               "sample": "oracle/_ref/rsem-run-em -p %d%s on a generated %s input of the bench workload's shape at %.0f %% of its reads: %d alignable "
                          "reads, %d alignments (%.2f/read), %d transcripts; rounds >= 12 timed from its ROUND lines (%d rounds, %.2f ms/round); rate "
                          "per alignment, so it carries over to the full size (E step is O(alignments))"
-                         % (cores, {1: "SingleQModel", 3: "PairedEndQModel"}[rt], cs["frac"] * 100, n1, nhits, nhits / n1, cs["M"],
+                         % (cores, " pinned to the physical cores of one socket (its fastest setting found: profiles/r04p_ref_threads_probe.json)" if pinned else "", {1: "SingleQModel", 3: "PairedEndQModel"}[rt], cs["frac"] * 100, n1, nhits, nhits / n1, cs["M"],
                             late[-1][0] - late[0][0], per_round * 1e3),
                "ms_per_round": per_round * 1e3, "rounds_timed": late[-1][0] - late[0][0], "startup_s": startup_s,
-               "host_cores_available": ncpu, "generate_s": gen_s}
+               "host_cores_available": ncpu, "pinned_cpus": ",".join(map(str, pinned)) if pinned else None, "generate_s": gen_s}
         e2e = {"what": "whole programs on the same files, wall clock: parse the .temp files, rounds 1-11 with the model, rounds >= 12 to convergence, "
                        "expected counts, results",
                "measured": {"size": "%d alignable reads, %d alignments, %d transcripts (%.0f %% of the bench workload's reads)" % (n1, nhits, cs["M"], cs["frac"] * 100),

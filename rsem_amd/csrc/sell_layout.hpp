@@ -407,7 +407,8 @@ __global__ void k_x_far(const Shape* __restrict__ shapes, int n_shapes, uint32_t
 // pass gathers are 512 KB of memory -- they stay in the L2 of whichever XCD asks -- where a gather over all the slots of
 // configs[1]'s size (80 MB) went to the Infinity Cache for every entry (0.68 ms per round).  Smaller blocks mean more
 // (block, id) runs, i.e. more atomics: 2^12 ... 2^31 slots measured, 2^15-2^16 is the minimum (0.335 ms; profiles/r04j_call.log,
-// r04j2_call.log).  Measured and dropped: workgroup tasks per range of 2048 ids with an LDS window (0.70 ms whether the
+// r04j2_call.log; with the pass's workgroups dealt to the XCDs in contiguous eighths 2^16 / 2^17 / 2^18 are the same to 0.4 %,
+// 2^20 is 20 % slower: profiles/r04p_call.log).  Measured and dropped: workgroup tasks per range of 2048 ids with an LDS window (0.70 ms whether the
 // windows leave by atomics or as rows summed afterwards: a workgroup walks its piece one dependent step at a time,
 // profiles/r04k_call.log, r04k2_call.log).
 constexpr int kCscSlotBlockLg = 16;
