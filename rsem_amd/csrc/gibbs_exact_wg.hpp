@@ -60,6 +60,7 @@ constexpr int kXT = 64 * kXW;    // threads = reads per tile
 constexpr int kXCap = 4096;      // items per tile: 256 reads of 12.4 items (BASELINE configs[2]) = 3175 on average
 constexpr int kXKeys = 1024;     // entries of the move-endpoint table (at most 2 * kXT endpoints: load <= 0.5)
 constexpr int kXChunk = 16;      // items of a read handled per step with independent (pipelined) LDS reads
+constexpr int kXTail = 4;        // ... per step behind the last whole step of kXChunk
 constexpr int kXPlanes = kXCap / kXT;
 
 constexpr int kXBits = 8192;
@@ -217,6 +218,7 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                 if (!kInit) L->dl[j] = 0;
             }
         }
+        GX_WAIT_VM();  // the previous tile's count updates (this thread's) are performed: after the barrier, everybody's
         GX_BLOCK_SYNC();
         const uint32_t fr = mine ? (uint32_t)(L->rp[g] - base) : 0;
         const int len = (mine && !long_tile) ? (int)(L->rp[g + 1] - L->rp[g]) : 0;
@@ -294,20 +296,23 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                 // neighbouring ids), the read's own unit taken off where it sits (Gibbs.cpp:298: the read leaves its transcript
                 // before it is weighed)
                 int cj[kXPlanes], zo[kXPlanes];
+                // (unconditional loads, see draw(): an item past the tile's end has id 0 in sj[] and reads item 0's owner.  Issuing the
+                // count loads a phase earlier, behind the staging barrier, bought nothing: 4.2 k -> 2.9 k here, 2.1 k -> 3.5 k there,
+                // profiles/r04r4_call.log.)
+#pragma unroll
+                for (int u = 0; u < kXPlanes; u++) cj[u] = GX_CNT_LOAD(&counts[sj[u]]);
+                int ow_[kXPlanes];
 #pragma unroll
                 for (int u = 0; u < kXPlanes; u++) {
                     const uint32_t j = (uint32_t)u * kXT + g;
-                    cj[u] = j < T ? GX_CNT_LOAD(&counts[sj[u]]) : 0;
+                    ow_[u] = (int)L->ownr[j < T ? j : 0u];
                 }
 #pragma unroll
-                for (int u = 0; u < kXPlanes; u++) {
-                    const uint32_t j = (uint32_t)u * kXT + g;
-                    zo[u] = j < T ? L->zold[L->ownr[j]] : -1;
-                }
+                for (int u = 0; u < kXPlanes; u++) zo[u] = L->zold[ow_[u]];
 #pragma unroll
                 for (int u = 0; u < kXPlanes; u++) {
                     const uint32_t j = (uint32_t)u * kXT + g;
-                    if (j < T) L->c[j] = cj[u] - (sj[u] == zo[u] ? 1 : 0);
+                    if (j < T) L->c[j] = cj[u] - (sj[u] == zo[u] ? 1 : 0);  // (j >= T: nothing stored, whatever was read)
                 }
             }
             GX_BLOCK_SYNC();
@@ -320,43 +325,76 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
             // kDelta: the items' counts carry the deltas of earlier reads' moves (a redraw).
             auto draw = [&](auto with_delta) -> int {
                 constexpr bool kDelta = decltype(with_delta)::value;
-                auto load = [&](int k0, double* a) {  // the weights of items k0 .. k0 + kXChunk - 1 (0.0 past the read's end)
-                    int cc[kXChunk];
-                    double pp[kXChunk];
+                // (No load sits under a condition: `in ? L->p[..] : 0.0` compiles to a branch around the load with its own wait,
+                // sixteen LDS round trips one after the other -- 10.2 k of a tile's 50 k cycles in the first draw alone,
+                // profiles/r04r_call.log.  Positions past the read's end read its last item again and are masked afterwards.)
+                const int last = len > 0 ? len - 1 : 0;
+                auto load = [&](auto width, int k0, double* a) {  // the weights of items k0 .. k0 + W - 1 (0.0 past the read's end)
+                    constexpr int W = decltype(width)::value;
+                    int cc[W];
+                    double pp[W];
 #pragma unroll
-                    for (int j = 0; j < kXChunk; j++) {
-                        const bool in = k0 + j < len;
-                        pp[j] = in ? L->p[fr + k0 + j] : 0.0;
-                        cc[j] = (in && !kInit) ? L->c[fr + k0 + j] : 0;
-                        if (kDelta && in) cc[j] += (int)L->dl[fr + k0 + j];
+                    for (int j = 0; j < W; j++) {
+                        const uint32_t at = fr + (uint32_t)(k0 + j < len ? k0 + j : last);
+                        pp[j] = L->p[at];
+                        cc[j] = kInit ? 0 : L->c[at];
+                        if (kDelta) cc[j] += (int)L->dl[at];
                     }
 #pragma unroll
-                    for (int j = 0; j < kXChunk; j++) a[j] = kInit ? pp[j] : ((double)cc[j] + pseudoC) * pp[j];
+                    for (int j = 0; j < W; j++) {
+                        const double wgt = kInit ? pp[j] : ((double)cc[j] + pseudoC) * pp[j];
+                        a[j] = (k0 + j < len) ? wgt : 0.0;
+                    }
                 };
+                // Items 0 .. 15 in one step (their partial sums are kept for the second pass); behind them steps of 16 while the
+                // read has 16 more, then steps of 4: a wave runs a step if ANY of its reads needs it, and with one read of 17 items
+                // among 64 a second step of 16 cost as much as the first (3 of them per draw, 10 k cycles per tile at
+                // configs[2], profiles/r04r_call.log).  Every read still adds its own items strictly left to right.
+                using Wide = std::integral_constant<int, kXChunk>;
+                using Narrow = std::integral_constant<int, kXTail>;
                 double part[kXChunk], a[kXChunk];
                 double run = 0.0;
-                load(0, a);
+                load(Wide{}, 0, a);
 #pragma unroll
                 for (int j = 0; j < kXChunk; j++) {
                     run += (j < len) ? a[j] : 0.0;
                     part[j] = run;
                 }
-                for (int k0 = kXChunk; k0 < len; k0 += kXChunk) {
-                    load(k0, a);
+                {
+                    int k0 = kXChunk;
+                    for (; k0 + kXChunk <= len; k0 += kXChunk) {
+                        load(Wide{}, k0, a);
 #pragma unroll
-                    for (int j = 0; j < kXChunk; j++) run += (k0 + j < len) ? a[j] : 0.0;
+                        for (int j = 0; j < kXChunk; j++) run += a[j];
+                    }
+                    for (; k0 < len; k0 += kXTail) {
+                        load(Narrow{}, k0, a);
+#pragma unroll
+                        for (int j = 0; j < kXTail; j++) run += (k0 + j < len) ? a[j] : 0.0;
+                    }
                 }
                 const double prb = ((double)rnd * (1.0 / 4294967296.0)) * run;
                 int cnt = 0;
 #pragma unroll
                 for (int j = 0; j < kXChunk; j++) cnt += (j < len && part[j] <= prb) ? 1 : 0;
                 double r2 = part[kXChunk - 1];
-                for (int k0 = kXChunk; k0 < len; k0 += kXChunk) {
-                    load(k0, a);
+                {
+                    int k0 = kXChunk;
+                    for (; k0 + kXChunk <= len; k0 += kXChunk) {
+                        load(Wide{}, k0, a);
 #pragma unroll
-                    for (int j = 0; j < kXChunk; j++) {
-                        r2 += (k0 + j < len) ? a[j] : 0.0;
-                        cnt += (k0 + j < len && r2 <= prb) ? 1 : 0;
+                        for (int j = 0; j < kXChunk; j++) {
+                            r2 += a[j];
+                            cnt += (r2 <= prb) ? 1 : 0;
+                        }
+                    }
+                    for (; k0 < len; k0 += kXTail) {
+                        load(Narrow{}, k0, a);
+#pragma unroll
+                        for (int j = 0; j < kXTail; j++) {
+                            r2 += (k0 + j < len) ? a[j] : 0.0;
+                            cnt += (k0 + j < len && r2 <= prb) ? 1 : 0;
+                        }
                     }
                 }
                 const int l = cnt < len ? cnt : len - 1;
@@ -413,8 +451,13 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                         for (int u = 0; u < kXPlanes; u++) {
                             const uint32_t j = (uint32_t)u * kXT + g;
                             const unsigned b = gx_bit(sj[u]);
-                            bw[u] = j < T ? L->bits[b >> 6] : 0ull;
-                            dv[u] = j < T ? (int)L->dl[j] : 0;
+                            bw[u] = L->bits[b >> 6];           // (unconditional loads, see draw(); masked below)
+                            dv[u] = (int)L->dl[j < T ? j : 0u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < kXPlanes; u++) {
+                            const uint32_t j = (uint32_t)u * kXT + g;
+                            if (j >= T) { bw[u] = 0ull; dv[u] = 0; }
                         }
 #pragma unroll
                         for (int u = 0; u < kXPlanes; u++) {
@@ -423,6 +466,8 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                         }
                     }
                     lap(11);
+                    // (Two items per step -- two independent chains of LDS round trips sharing their waits -- was slower: 15.6 k
+                    // cycles per tile instead of 11.7 k, profiles/r04r4_call.log.)
                     for (; need != 0u; need &= need - 1u) {
                         const int u = __builtin_ctz(need);
                         const uint32_t j = (uint32_t)u * kXT + g;
@@ -451,6 +496,10 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                     }
                     lap(12);
                     GX_BLOCK_SYNC();  // every delta of this round is in place
+                    // (Measured and dropped: the redraw of a marked read by its whole wave -- lane k weighs item k, every lane adds
+                    // the weights up in order, one ballot counts the partial sums -- costs ~1 k cycles per read, and a round marks
+                    // about twenty reads per wave, most of them in the tile's last wave: 21 k + 61 k cycles per tile instead of
+                    // 4 k + 6 k, profiles/r04r3_call.log.)
                     const bool dirty = ((L->dirty[w] >> lane) & 1ull) != 0ull;
                     int z2 = z_new;
                     if (dirty) z2 = draw(std::true_type{});
@@ -489,7 +538,8 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                 z[r0 + g] = z_new;
             }
         }
-        GX_WAIT_VM();  // this tile's count updates are performed before the next tile gathers (barriers in between)
+        // (this tile's count updates must be performed before the next tile gathers: every thread waits for its own at the next
+        // tile's first barrier, behind that tile's staging -- LDS writes from registers --, not here)
         if (g == 0) L->idx = idx;
         GX_BLOCK_SYNC();
         lap(5);
