@@ -203,8 +203,10 @@ RSEM_DEVFN double lane_profile_product(const double* prof, const MateWords& W, c
         for (int u = 0; u < 8; u++) {
             const int row = kQ ? (int)((qb >> (8 * u)) & 0xff) : wi * 8 + u;
             const int idx = (row * 5 + (int)((rf >> (8 * u)) & 0xff)) * 5 + (int)((sb >> (8 * u)) & 0xff);
-            const double f = (u < n) ? prof[idx] : 1.0;
-            p *= f;
+            // (no look-up under a condition: `(u < n) ? prof[idx] : 1.0` compiles to a branch around the load with a wait of
+            // its own, eight round trips one after the other; past the read's end entry 0 is read and not used)
+            const double t = prof[(u < n) ? idx : 0];
+            p *= (u < n) ? t : 1.0;
         }
     }
     return p;
@@ -241,8 +243,9 @@ RSEM_DEVFN double lane_noise_product(const double* nprob, const MateWords& W, in
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int b = (int)((sb >> (8 * u)) & 0xff);
-            const double f = (u < n) ? (kQ ? nprob[(int)((qb >> (8 * u)) & 0xff) * 5 + b] : nprob[b]) : 1.0;
-            p *= f;
+            const int idx = kQ ? (int)((qb >> (8 * u)) & 0xff) * 5 + b : b;
+            const double t = nprob[(u < n) ? idx : 0];  // (see lane_profile_product)
+            p *= (u < n) ? t : 1.0;
         }
     }
     return p;
@@ -327,18 +330,29 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
     for (uint64_t rbase = row0; rbase < D.N1; rbase += row_stride) {  // (wave-uniform)
         const uint64_t row = rbase + (uint64_t)(lane >> 4);
         const bool valid = row < D.N1;
-        const bool active = valid && !D.lq[row];
-        const uint64_t fr = valid ? D.row_ptr[row] : 0, to = valid ? D.row_ptr[row + 1] : 0;
+        // Everything the kernel needs to know about the read is loaded at once, for a row that exists (the last one stands in
+        // for the rows past the end), and masked afterwards: a load under a condition is a branch with a wait of its own, and
+        // `valid && !lq[row]`, then `active ? roff8[row] : 0` made three round trips to memory out of one.
+        const uint64_t rowc = valid ? row : D.N1 - 1;
+        const uint8_t lq_v = D.lq[rowc];
+        const uint64_t fr_v = D.row_ptr[rowc], to_v = D.row_ptr[rowc + 1];
+        uint64_t r8_v[2] = {0, 0};
+        int rl_v[2] = {0, 0};
+#pragma unroll
+        for (int m = 0; m < (kPE ? 2 : 1); m++) { r8_v[m] = D.roff8[m][rowc]; rl_v[m] = D.rlen[m][rowc]; }
+        const uint32_t rank_v = PO.rank ? PO.rank[rowc] : 0u;
+        const bool active = valid && !lq_v;
+        const uint64_t fr = valid ? fr_v : 0, to = valid ? to_v : 0;
         const int L = (int)(to - fr);
         int maxL = L;
         { int o = RSEM_SHFL_XOR(maxL, 16); maxL = o > maxL ? o : maxL; o = RSEM_SHFL_XOR(maxL, 32); maxL = o > maxL ? o : maxL; }
         MateWords W[kMates];
 #pragma unroll
         for (int m = 0; m < kMates; m++) {
-            W[m].r8 = active ? D.roff8[m][row] : 0;
+            W[m].r8 = active ? r8_v[m] : 0;
             W[m].seq = D.rseq_w[m];
             W[m].qual = kQ ? D.rqual_w[m] : nullptr;
-            W[m].len = active ? D.rlen[m][row] : 0;
+            W[m].len = active ? rl_v[m] : 0;
         }
         const int len1 = W[0].len, len2 = kPE ? W[kMates - 1].len : 0;
         // the read's place in the sliced layout: alignment c goes to plane c >> lg of its slice, lane r * G + (c & (G - 1))
@@ -347,7 +361,7 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
         int p_lg = 0;
         uint32_t p_r = 0;
         if (PO.rank && valid) {
-            const uint32_t ps = PO.rank[row];
+            const uint32_t ps = rank_v;
             if (ps < PO.n_sell_rows) {
                 const Shape& S = PO.shapes[plane_shape_of(PO.shapes, PO.n_shapes, ps)];
                 uint32_t slice_local;
@@ -373,17 +387,23 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
             const int idx = c * kGrp + g;
             const bool in = valid && idx < L;
             R.has = active && idx < L;
+            // (two round trips: the alignment's own fields, then what hangs on its transcript id -- every load issued for an
+            // alignment that exists, the read's first or the file's first for the lanes without one, and masked afterwards)
             const uint64_t j = fr + (uint64_t)(in ? idx : 0);
-            const int s = R.has ? D.sid_signed[j] : 1;
+            const int s_v = D.sid_signed[j], pos_v = D.pos[j], ins_v = kPE ? D.insertL[j] : 0;
+            const unsigned fl_v = D.same_prev[j];
+            const int s = R.has ? s_v : 1;
             R.sid = s < 0 ? -s : s;
             R.dir = s < 0 ? 1 : 0;
-            R.pos = R.has ? D.pos[j] : 0;
-            R.insertL = (kPE && R.has) ? D.insertL[j] : 0;
-            R.flags = R.has ? D.same_prev[j] : 0u;
-            R.fullLen = R.has ? D.fullLen[R.sid] : 1;
-            R.totLen = R.has ? D.totLen[R.sid] : 1;
-            R.a[0] = R.has ? D.soff[2 * R.sid + R.dir] + (uint64_t)R.pos : 0;
-            if (kPE) R.a[kMates - 1] = R.has ? D.soff[2 * R.sid + (R.dir ^ 1)] + (uint64_t)(R.totLen - R.pos - R.insertL) : 0;
+            R.pos = R.has ? pos_v : 0;
+            R.insertL = R.has ? ins_v : 0;
+            R.flags = R.has ? fl_v : 0u;
+            const int full_v = D.fullLen[R.sid], tot_v = D.totLen[R.sid];
+            const uint64_t so0 = D.soff[2 * R.sid + R.dir], so1 = kPE ? D.soff[2 * R.sid + (R.dir ^ 1)] : 0;
+            R.fullLen = R.has ? full_v : 1;
+            R.totLen = R.has ? tot_v : 1;
+            R.a[0] = R.has ? so0 + (uint64_t)R.pos : 0;
+            if (kPE) R.a[kMates - 1] = R.has ? so1 + (uint64_t)(R.totLen - R.pos - R.insertL) : 0;
             R.cp = 0.0;
             if (in && !R.has) { cp[j] = 0.0; plane_put(idx, 0.0); }  // low-quality read: every alignment gets probability 0 (SingleQModel.h:102)
         };
@@ -442,7 +462,8 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
                 plane_put(c * kGrp + g, R.cp);
             }
             if (kUpdate) {
-                double f = R.has ? theta[R.sid] * R.cp : 0.0;
+                const double th_v = theta[R.sid];  // (sid = 1 for a lane without an alignment)
+                double f = R.has ? th_v * R.cp : 0.0;
                 if (f < kEpsilon) f = 0.0;
                 rowsum += grp_sum(f);
             }
@@ -481,8 +502,9 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
             // wave per SIMD or 14 GB of scratch traffic per launch at a fifth of configs[2], profiles/r04c_model_group_pmc_fifth_size.json)
             ChunkRegs R;
             load_chunk(c, R);
-            R.cp = R.has ? cp[fr + (uint64_t)(c * kGrp + g)] : 0.0;
-            double f = R.has ? theta[R.sid] * R.cp : 0.0;
+            const double cp_v = cp[fr + (uint64_t)((valid && c * kGrp + g < L) ? c * kGrp + g : 0)], th_v = theta[R.sid];
+            R.cp = R.has ? cp_v : 0.0;
+            double f = R.has ? th_v * R.cp : 0.0;
             if (f < kEpsilon) f = 0.0;
             double w = ok ? f / sum : 0.0;
             if (w < kEpsilon) w = 0.0;  // `if (frac < kEpsilon) continue;` of the update loops
