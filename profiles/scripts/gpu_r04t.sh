@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 4, call T: the model rounds' kernel without loads under conditions against the kernel before (variants/model_before = the
 # library of commit 577e7ad), a fifth of configs[2] through the program; then the CLI tests (every model type against the reference).
+# (variants/model_before/ was a copy of rsem_amd/librsem_hip.so and rsem_amd/bin/rsem-run-em built at commit 577e7ad; it is not kept.)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export RSEM_HIP_TIMING=1
 start=$(date +%s)
