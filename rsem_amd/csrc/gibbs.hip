@@ -479,7 +479,7 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
 #include "gibbs_exact_wg.hpp"
 
 template <bool kInit>
-__global__ __launch_bounds__(kXT) void k_gibbs_exact_wg(uint32_t n_tiles, const uint32_t* __restrict__ tile_start, const uint64_t* __restrict__ tile_items,
+__global__ __launch_bounds__(kXThr) void k_gibbs_exact_wg(uint32_t n_tiles, const uint32_t* __restrict__ tile_start, const uint64_t* __restrict__ tile_items,
                                                         const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
                                                         const double* __restrict__ cp, int32_t* counts_base, int32_t* z_base,
                                                         double pseudoC, MtState* mt_base, const int32_t* __restrict__ last_round,
@@ -1151,8 +1151,8 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
 #define EXACT_WG_ARGS c->n_tiles, c->d_tiles, c->d_tile_items, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->pseudoC, \
                       mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z, \
                       ((RSEM_GX_PROFILE && !init) ? prof_buf.as<unsigned long long>() : (unsigned long long*)nullptr)
-                if (init) hipLaunchKernelGGL(k_gibbs_exact_wg<true>, dim3(nchains), dim3(kXT), 0, st, EXACT_WG_ARGS);
-                else hipLaunchKernelGGL(k_gibbs_exact_wg<false>, dim3(nchains), dim3(kXT), 0, st, EXACT_WG_ARGS);
+                if (init) hipLaunchKernelGGL(k_gibbs_exact_wg<true>, dim3(nchains), dim3(kXThr), 0, st, EXACT_WG_ARGS);
+                else hipLaunchKernelGGL(k_gibbs_exact_wg<false>, dim3(nchains), dim3(kXThr), 0, st, EXACT_WG_ARGS);
 #undef EXACT_WG_ARGS
             } else if (impl == kExactSerial) {
                 if (init) hipLaunchKernelGGL(k_gibbs_exact_serial<true>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);

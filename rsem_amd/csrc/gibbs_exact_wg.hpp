@@ -55,13 +55,23 @@
 #define GX_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
-constexpr int kXW = 4;           // waves per chain
-constexpr int kXT = 64 * kXW;    // threads = reads per tile
+constexpr int kXW = 4;           // waves of READS per tile
+constexpr int kXT = 64 * kXW;    // reads per tile = the threads that own a read
+// Threads of the workgroup.  256 (the product, what every number in DESIGN.md was measured with): every thread owns a read and
+// 16 of the tile's items.  -DRSEM_GX_THREADS=512 (a variant build for tools/build_variants.sh, NOT measured yet): four more
+// waves that own no read and share the item-major phases (staging, gather, filter scan, look-ups) -- two waves per SIMD,
+// so that one wave's dependent instructions (~16 cycles each with a SIMD to itself) overlap the other's.  The emulator
+// runs both (tests/test_gibbs_exact_emu_cpu.py).
+#ifndef RSEM_GX_THREADS
+#define RSEM_GX_THREADS 256
+#endif
+constexpr int kXThr = RSEM_GX_THREADS;
+static_assert(kXThr == kXT || kXThr == 2 * kXT, "256 or 512 threads per chain");
 constexpr int kXCap = 4096;      // items per tile: 256 reads of 12.4 items (BASELINE configs[2]) = 3175 on average
 constexpr int kXKeys = 1024;     // entries of the move-endpoint table (at most 2 * kXT endpoints: load <= 0.5)
 constexpr int kXChunk = 16;      // items of a read handled per step with independent (pipelined) LDS reads
 constexpr int kXTail = 4;        // ... per step behind the last whole step of kXChunk
-constexpr int kXPlanes = kXCap / kXT;
+constexpr int kXPlanes = kXCap / kXThr;  // items per thread in the item-major phases
 
 constexpr int kXBits = 8192;
 struct XTile {  // the workgroup's LDS: 150 KB of the CU's 160 KB
@@ -139,12 +149,13 @@ static_assert(kXBits == 8192, "gx_bit returns 13 bits");
 static_assert(kXKeys == 1024, "gx_hash returns 10 bits");
 
 // One sweep over all reads in file order (Gibbs.cpp:297-311), or the initial assignment (Gibbs.cpp:281-291) when kInit.
-// Called by every thread of the chain's workgroup (g = 0 .. kXT-1); L->mt / L->idx hold the chain's generator.
+// Called by every thread of the chain's workgroup (g = 0 .. kXThr-1; the threads g >= kXT own no read); L->mt / L->idx hold the chain's generator.
 template <bool kInit>
 GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint32_t* __restrict__ tile_start, const uint64_t* __restrict__ tile_items,
                                   const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid, const double* __restrict__ cp,
                                   int32_t* counts, int32_t* z, double pseudoC, unsigned long long* prof) {
     const int lane = g & 63, w = g >> 6;
+    const bool rd = kXThr == kXT || g < kXT;  // a thread that owns one of the tile's read slots (all of them in the 256-thread build)
     unsigned long long pa[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // What the staging of a tile needs is loaded one tile AHEAD, into registers (the kernel may use 512 of them): issued when
     // the tile before it starts its first draw, after that tile's gather of counts -- loads return in order, so anything
@@ -179,7 +190,7 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
         A.z = (!kInit && g < A.nr) ? z[(uint64_t)A.r0 + g] : 0;
 #pragma unroll
         for (int u = 0; u < kXPlanes; u++) {
-            const uint32_t j = (uint32_t)u * kXT + g;
+            const uint32_t j = (uint32_t)u * kXThr + g;
             A.s[u] = j < Tn ? sid[A.base + j] : 0;
             A.p[u] = j < Tn ? cp[A.base + j] : 0.0;
         }
@@ -203,14 +214,14 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
         const uint64_t T64 = A.T64;
         const bool long_tile = T64 > (uint64_t)kXCap;  // one read with more items than a tile holds (then nr == 1)
         const uint32_t T = long_tile ? 0u : (uint32_t)T64;
-        L->rp[g] = A.rp;
+        if (rd) L->rp[g] = A.rp;
         if (g == 0) L->rp[kXT] = base + T64;
         const bool mine = g < nr;
         const int z_old = A.z;
-        int sj[kXPlanes];  // the tile's ids item-major (item u * kXT + g): kept in registers for the gather and the rounds
+        int sj[kXPlanes];  // the tile's ids item-major (item u * kXThr + g): kept in registers for the gather and the rounds
 #pragma unroll
         for (int u = 0; u < kXPlanes; u++) {
-            const uint32_t j = (uint32_t)u * kXT + g;
+            const uint32_t j = (uint32_t)u * kXThr + g;
             sj[u] = A.s[u];
             if (j < T) {
                 L->sid[j] = A.s[u];
@@ -227,8 +238,8 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
         // ---- whose item is it (the gather and the rounds walk the items item-major: other threads' items) ---------------------------
         if (!kInit) {
             for (int k = 0; k < len; k++) L->ownr[fr + k] = (unsigned char)g;
-            L->zold[g] = z_old;
-            if (lane == 0) L->dirty[w] = 0ull;
+            if (rd) L->zold[g] = z_old;
+            if (rd && lane == 0) L->dirty[w] = 0ull;
             GX_BLOCK_SYNC();
         }
         lap(1);
@@ -304,14 +315,14 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                 int ow_[kXPlanes];
 #pragma unroll
                 for (int u = 0; u < kXPlanes; u++) {
-                    const uint32_t j = (uint32_t)u * kXT + g;
+                    const uint32_t j = (uint32_t)u * kXThr + g;
                     ow_[u] = (int)L->ownr[j < T ? j : 0u];
                 }
 #pragma unroll
                 for (int u = 0; u < kXPlanes; u++) zo[u] = L->zold[ow_[u]];
 #pragma unroll
                 for (int u = 0; u < kXPlanes; u++) {
-                    const uint32_t j = (uint32_t)u * kXT + g;
+                    const uint32_t j = (uint32_t)u * kXThr + g;
                     if (j < T) L->c[j] = cj[u] - (sj[u] == zo[u] ? 1 : 0);  // (j >= T: nothing stored, whatever was read)
                 }
             }
@@ -408,7 +419,7 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                     const bool mv = mine && z_new != z_old;
                     const int z_ent = z_new;  // (the endpoint entered below: z_new may change in this round)
                     const unsigned long long bm = GX_BALLOT(mv);
-                    if (lane == 0) L->mm[w] = bm;
+                    if (rd && lane == 0) L->mm[w] = bm;
                     unsigned h_fr = 0, h_to = 0;  // this thread's entries
                     if (mv) {
                         // enter the two endpoints: claim a free entry or find the id's entry (linear probing; key = id + 1)
@@ -449,14 +460,14 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                         int dv[kXPlanes];
 #pragma unroll
                         for (int u = 0; u < kXPlanes; u++) {
-                            const uint32_t j = (uint32_t)u * kXT + g;
+                            const uint32_t j = (uint32_t)u * kXThr + g;
                             const unsigned b = gx_bit(sj[u]);
                             bw[u] = L->bits[b >> 6];           // (unconditional loads, see draw(); masked below)
                             dv[u] = (int)L->dl[j < T ? j : 0u];
                         }
 #pragma unroll
                         for (int u = 0; u < kXPlanes; u++) {
-                            const uint32_t j = (uint32_t)u * kXT + g;
+                            const uint32_t j = (uint32_t)u * kXThr + g;
                             if (j >= T) { bw[u] = 0ull; dv[u] = 0; }
                         }
 #pragma unroll
@@ -470,7 +481,7 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                     // cycles per tile instead of 11.7 k, profiles/r04r4_call.log.)
                     for (; need != 0u; need &= need - 1u) {
                         const int u = __builtin_ctz(need);
-                        const uint32_t j = (uint32_t)u * kXT + g;
+                        const uint32_t j = (uint32_t)u * kXThr + g;
                         const int sv = L->sid[j];  // (= sj[u]; a register array cannot be indexed by a variable)
                         const int o = (int)L->ownr[j], ow = o >> 6;
                         unsigned h = gx_hash(sv);
@@ -500,13 +511,13 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                     // the weights up in order, one ballot counts the partial sums -- costs ~1 k cycles per read, and a round marks
                     // about twenty reads per wave, most of them in the tile's last wave: 21 k + 61 k cycles per tile instead of
                     // 4 k + 6 k, profiles/r04r3_call.log.)
-                    const bool dirty = ((L->dirty[w] >> lane) & 1ull) != 0ull;
+                    const bool dirty = rd && ((L->dirty[w] >> lane) & 1ull) != 0ull;
                     int z2 = z_new;
                     if (dirty) z2 = draw(std::true_type{});
                     lap(13);
                     const unsigned long long ch = GX_BALLOT(mine && z2 != z_new);
                     z_new = z2;
-                    if (lane == 0) L->chg[w] = ch;
+                    if (rd && lane == 0) L->chg[w] = ch;
                     GX_BLOCK_SYNC();  // every thread has read its dirty bit (and the look-ups were finished a barrier ago)
                     if (mv) {          // leave the table as it was found: all zero
 #pragma unroll
@@ -519,7 +530,7 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                         L->bits[gx_bit(z_old) >> 6] = 0ull;
                         L->bits[gx_bit(z_ent) >> 6] = 0ull;
                     }
-                    if (lane == 0) L->dirty[w] = 0ull;
+                    if (rd && lane == 0) L->dirty[w] = 0ull;
                     bool any_changed = false;
 #pragma unroll
                     for (int q = 0; q < kXW; q++) any_changed = any_changed || L->chg[q] != 0ull;

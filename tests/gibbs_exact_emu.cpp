@@ -54,7 +54,7 @@ inline unsigned long long ballot(bool p) {
 
 struct Machine {
     XTile tile;
-    emu::Wave wave[kXW];
+    emu::Wave wave[kXThr / 64];
     pthread_barrier_t block_bar;
 };
 
@@ -94,8 +94,8 @@ int main(int argc, char** argv) {
     memset(mc.tile.ends, 0, sizeof(mc.tile.ends));  // (the kernel wrapper clears the move-endpoint table once per launch)
     memset(mc.tile.key, 0, sizeof(mc.tile.key));
     memset(mc.tile.bits, 0, sizeof(mc.tile.bits));
-    for (int w = 0; w < kXW; w++) pthread_barrier_init(&mc.wave[w].bar, nullptr, 64);
-    pthread_barrier_init(&mc.block_bar, nullptr, 64 * kXW);
+    for (int w = 0; w < kXThr / 64; w++) pthread_barrier_init(&mc.wave[w].bar, nullptr, 64);
+    pthread_barrier_init(&mc.block_bar, nullptr, kXThr);
 
     auto thread_main = [&](int tid) {
         const int lane = tid & 63, w = tid >> 6;
@@ -115,7 +115,7 @@ int main(int argc, char** argv) {
         }
     };
     std::vector<std::thread> th;
-    for (int t = 0; t < 64 * kXW; t++) th.emplace_back(thread_main, t);
+    for (int t = 0; t < kXThr; t++) th.emplace_back(thread_main, t);
     for (auto& t : th) t.join();
     FILE* g = fopen(argv[2], "wb");
     if (!g) { perror(argv[2]); return 2; }
