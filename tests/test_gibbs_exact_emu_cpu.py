@@ -19,12 +19,22 @@ CXX = shutil.which("g++")
 pytestmark = pytest.mark.skipif(CXX is None, reason="needs g++")
 
 
-@pytest.fixture(scope="module")
-def emulator(tmp_path_factory):
-    exe = os.path.join(str(tmp_path_factory.mktemp("gibbs_exact_emu")), "gibbs_exact_emu")
-    subprocess.check_call([CXX, "-O1", "-std=c++17", "-pthread"] + os.environ.get("RSEM_EMU_DEFS", "").split()  # (variant builds by hand)
+def _build(tmp_path_factory, name, defs):
+    exe = os.path.join(str(tmp_path_factory.mktemp(name)), name)
+    subprocess.check_call([CXX, "-O1", "-std=c++17", "-pthread"] + defs + os.environ.get("RSEM_EMU_DEFS", "").split()  # (variant builds by hand)
                           + [os.path.join(ROOT, "tests", "gibbs_exact_emu.cpp"), "-o", exe])
     return exe
+
+
+@pytest.fixture(scope="module")
+def emulator(tmp_path_factory):
+    return _build(tmp_path_factory, "gibbs_exact_emu", [])
+
+
+@pytest.fixture(scope="module")
+def emulator_512(tmp_path_factory):
+    """the variant with 512 threads per chain (gibbs_exact_wg.hpp: RSEM_GX_THREADS): four more waves that own no read"""
+    return _build(tmp_path_factory, "gibbs_exact_emu_512", ["-DRSEM_GX_THREADS=512"])
 
 
 def _items(seed, M, N1, maxlen, noise_scale, long_read=0):
@@ -94,6 +104,11 @@ def test_workgroup_chain_is_the_reference_chain(emulator, case):
     want = _oracle(c["M"], rp, sid, cp, init, c["rounds"], 1000 + c["seed"], c["N0"], c["pseudoC"])
     assert got.sum(1).tolist() == [c["N0"] + c["N1"]] * c["rounds"]
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[5], CASES[6]], ids=lambda c: "seed%d" % c["seed"])
+def test_workgroup_chain_with_512_threads_is_the_reference_chain(emulator_512, case):
+    test_workgroup_chain_is_the_reference_chain(emulator_512, case)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 4, 5, 6])
