@@ -113,6 +113,12 @@ inline void gx_build_tiles(uint64_t N1, const uint64_t* row_ptr, std::vector<uin
 #ifndef RSEM_GX_PROFILE
 #define RSEM_GX_PROFILE 0
 #endif
+// -DRSEM_GX_FENCES=1 (a variant build, not measured yet): a scheduling fence at every phase boundary and nothing else.  The
+// build that reads the phase clocks runs a tile in 186 ms-per-round terms where the product's runs 206 (profiles/r04s_call.log,
+// r04v_call.log): the clock reads keep the compiler from mixing the phases' instructions, and this asks for the same without them.
+#ifndef RSEM_GX_FENCES
+#define RSEM_GX_FENCES 0
+#endif
 #if RSEM_GX_PROFILE && !defined(GX_EMU)
 #define GX_CLOCK() ((unsigned long long)clock64())
 #else
@@ -206,6 +212,9 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                 pa[i] += n - tk;
                 tk = n;
             }
+#if RSEM_GX_FENCES && !defined(GX_EMU)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         };
         const uint64_t r0 = A.r0;
         const int nr = A.nr;  // 1 .. kXT
