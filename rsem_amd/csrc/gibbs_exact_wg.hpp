@@ -119,6 +119,10 @@ inline void gx_build_tiles(uint64_t N1, const uint64_t* row_ptr, std::vector<uin
 #ifndef RSEM_GX_FENCES
 #define RSEM_GX_FENCES 0
 #endif
+// -DRSEM_GX_STATIC_WALK=1 (a variant build, not measured yet): see the look-ups of a round.
+#ifndef RSEM_GX_STATIC_WALK
+#define RSEM_GX_STATIC_WALK 0
+#endif
 #if RSEM_GX_PROFILE && !defined(GX_EMU)
 #define GX_CLOCK() ((unsigned long long)clock64())
 #else
@@ -464,9 +468,9 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                     // (Until r03n every thread walked its own read's items: the slowest lane of a wave set the pace, 21.8 k
                     // cycles per tile at configs[2] with the table's first probe as the filter, 8.7 k with this one.)
                     unsigned need = 0;
+                    int dv[kXPlanes];  // the items' deltas as the round found them
                     {
                         unsigned long long bw[kXPlanes];
-                        int dv[kXPlanes];
 #pragma unroll
                         for (int u = 0; u < kXPlanes; u++) {
                             const uint32_t j = (uint32_t)u * kXThr + g;
@@ -486,6 +490,41 @@ GX_DEVFN void gibbs_exact_wg_body(int g, XTile* L, uint32_t n_tiles, const uint3
                         }
                     }
                     lap(11);
+#if RSEM_GX_STATIC_WALK
+                    // Variant (not measured yet): the look-ups plane by plane instead of item by item -- every plane's first probe,
+                    // owner and masks are loaded whether the thread needs them or not, so no load waits for a decision and the
+                    // ids stay in registers; only an item whose first probe hits ANOTHER id's entry (rare: the table is at most
+                    // half full) is left to the loop below.
+                    {
+                        unsigned again = 0;
+#pragma unroll
+                        for (int u = 0; u < kXPlanes; u++) {
+                            const uint32_t j = (uint32_t)u * kXThr + g, jc = j < T ? j : 0u;
+                            const unsigned h = gx_hash(sj[u]);
+                            const int kv = L->key[h];
+                            const int o = (int)L->ownr[jc], ow = o >> 6;
+                            unsigned long long to[kXW], from[kXW];
+#pragma unroll
+                            for (int q = 0; q < kXW; q++) { to[q] = L->ends[h][0][q]; from[q] = L->ends[h][1][q]; }
+                            const unsigned long long part = (1ull << (o & 63)) - 1ull;
+                            int dd = 0;
+#pragma unroll
+                            for (int q = 0; q < kXW; q++) {
+                                const unsigned long long bef = q < ow ? ~0ull : (q == ow ? part : 0ull);
+                                dd += GX_POPC64(to[q] & bef) - GX_POPC64(from[q] & bef);
+                            }
+                            const bool wanted = ((need >> u) & 1u) != 0u;
+                            const bool other = kv != 0 && kv != sj[u] + 1;  // another id's entry: probe on, below
+                            if (kv == 0) dd = 0;
+                            if (wanted && other) again |= 1u << u;
+                            if (wanted && !other && dd != dv[u]) {
+                                L->dl[j] = (int16_t)dd;
+                                GX_LDS_OR64(&L->dirty[ow], 1ull << (o & 63));
+                            }
+                        }
+                        need = again;
+                    }
+#endif
                     // (Two items per step -- two independent chains of LDS round trips sharing their waits -- was slower: 15.6 k
                     // cycles per tile instead of 11.7 k, profiles/r04r4_call.log.)
                     for (; need != 0u; need &= need - 1u) {
