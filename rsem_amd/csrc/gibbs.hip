@@ -502,6 +502,62 @@ __global__ __launch_bounds__(kXThr) void k_gibbs_exact_wg(uint32_t n_tiles, cons
     if (threadIdx.x == 0) mt_state->idx = tile.idx;
 }
 
+// ---- EXACT mode, W workgroups per chain (gibbs_exact_team.hpp): the same chain, W tiles of a window at once ---------------------
+#include "gibbs_exact_team.hpp"
+
+struct TeamArgs {  // what every workgroup of every team needs (one argument: cooperative launches take an array of pointers)
+    int W, nchains;
+    XTeamCtl* ctl;       // [nchains]
+    uint32_t* net;       // [nchains][(M + 2) * nw]
+    uint32_t* gnet;      // [nchains][(M + 2) * 2]
+    int32_t* ref;        // [nchains][M + 2]
+    uint32_t nw;
+    const XSlot* slots;  // [n_win][W]
+    uint32_t n_win;
+    uint64_t N1;
+    int32_t M;
+};
+
+// Workgroup b belongs to chain b % nchains: workgroups are dealt to the 8 XCDs round-robin, so with 8 chains (or a divisor or
+// multiple of 8) a chain's team shares one XCD and its L2.  The generator is read from mt_in and handed on in mt_out (two
+// buffers: a launch without team barriers -- the initial assignment -- has workgroups that start after workgroup 0 has left).
+template <bool kInit>
+__global__ __launch_bounds__(kXThr) void k_gibbs_exact_team(TeamArgs ta, const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
+                                                          const double* __restrict__ cp, int32_t* counts_base, int32_t* z_base, double pseudoC,
+                                                          const MtState* __restrict__ mt_in, MtState* mt_out, const int32_t* __restrict__ last_round,
+                                                          int round, uint64_t stride_c, uint64_t stride_z, unsigned long long* prof) {
+    __shared__ XTile tile;
+    const int chain = (int)(blockIdx.x % (unsigned)ta.nchains), tw = (int)(blockIdx.x / (unsigned)ta.nchains);
+    if (round > last_round[chain]) return;  // (uniform over the team)
+    const MtState* src = mt_in + chain;
+    for (int i = threadIdx.x; i < 624; i += blockDim.x) tile.mt[i] = src->mt[i];
+    if (threadIdx.x == 0) tile.idx = src->idx;
+    for (int i = threadIdx.x; i < kXKeys * 2 * kXW; i += blockDim.x) (&tile.ends[0][0][0])[i] = 0ull;
+    for (int i = threadIdx.x; i < kXKeys; i += blockDim.x) tile.key[i] = 0;
+    for (int i = threadIdx.x; i < kXBits / 64; i += blockDim.x) tile.bits[i] = 0ull;
+    __syncthreads();
+    XTeam tm;
+    tm.W = ta.W;
+    tm.tw = tw;
+    tm.ctl = ta.ctl + chain;
+    tm.net = ta.net + (size_t)chain * ((size_t)ta.M + 2) * ta.nw;
+    tm.gnet = ta.gnet + (size_t)chain * ((size_t)ta.M + 2) * 2;
+    tm.ref = ta.ref + (size_t)chain * ((size_t)ta.M + 2);
+    tm.nw = ta.nw;
+    tm.slots = ta.slots;
+    tm.n_win = ta.n_win;
+    tm.N1 = ta.N1;
+    tm.M = ta.M;
+    const bool ok = gibbs_exact_team_body<kInit>((int)threadIdx.x, &tile, tm, row_ptr, sid, cp, counts_base + (uint64_t)chain * stride_c,
+                                                 z_base + (uint64_t)chain * stride_z, pseudoC, prof);
+    __syncthreads();
+    if (ok && tw == 0) {
+        MtState* dst = mt_out + chain;
+        for (int i = threadIdx.x; i < 624; i += blockDim.x) dst->mt[i] = tile.mt[i];
+        if (threadIdx.x == 0) dst->idx = tile.idx;
+    }
+}
+
 constexpr int kSerialTileItems = 3072;
 
 // The previous implementation: lane 0 walks the chain, the other 63 lanes stage the next tile of reads into LDS.
@@ -760,6 +816,11 @@ struct rsem_gibbs_ctx {
     uint32_t* d_tiles = nullptr;  // k_gibbs_exact_wg: first read of every tile (+ N1), gx_build_tiles
     uint64_t* d_tile_items = nullptr;  // ... and its first item (row_ptr[d_tiles[t]])
     uint32_t n_tiles = 0;
+    std::vector<uint32_t> h_tiles;       // host copies of the two (the windows of k_gibbs_exact_team are cut from them per team size)
+    std::vector<uint64_t> h_tile_items;
+    int team_W = 0;                      // the team size d_slots was built for (0: none yet)
+    void* d_slots = nullptr;             // XSlot[n_win][team_W]
+    uint32_t n_win = 0;
     // PARALLEL mode, built on the device at its first use: noise split out + the sliced layout
     bool have_parallel = false;
     uint64_t* d_row_ptr = nullptr;
@@ -928,7 +989,7 @@ int rsem_gibbs_chain_seeds(uint32_t seed, int nchains, uint32_t* out) {
 int rsem_gibbs_destroy(rsem_gibbs_ctx* c) {
     if (!c) return RSEM_OK;
     (void)hipSetDevice(c->device);
-    hipFree(c->d_irp); hipFree(c->d_isid); hipFree(c->d_icp); hipFree(c->d_tiles); hipFree(c->d_tile_items); hipFree(c->d_row_ptr); hipFree(c->d_sid);
+    hipFree(c->d_irp); hipFree(c->d_isid); hipFree(c->d_icp); hipFree(c->d_tiles); hipFree(c->d_tile_items); hipFree(c->d_slots); hipFree(c->d_row_ptr); hipFree(c->d_sid);
     hipFree(c->d_cp); hipFree(c->d_ncp); sell_free(c->L); hipFree(c->d_scp); hipFree(c->d_sncp);
     hipFree(c->d_init_counts); hipFree(c->d_g); hipFree(c->d_alpha);
     hipFree(c->d_eel); hipFree(c->d_mw); hipFree(c->d_grp);
@@ -1035,6 +1096,8 @@ int rsem_gibbs_create(rsem_gibbs_ctx** out, int device, int32_t M, uint64_t N1, 
     G_TRY(dmalloc(&c->d_tile_items, tile_items.size()));
     G_TRY(hipMemcpyAsync(c->d_tile_items, tile_items.data(), sizeof(uint64_t) * tile_items.size(), hipMemcpyHostToDevice, st));
     G_TRY(hipStreamSynchronize(st));  // (tile_items is a local)
+    c->h_tiles = tiles;
+    c->h_tile_items = tile_items;
     // the ids index counts[] on the device: check them there (the host copy is not walked)
     int* d_err = nullptr;
     int h_err = 0;
@@ -1089,7 +1152,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
     DevBuf counts, z, mts, acc, acc_g, acc_t, partials, d_ns, d_last, d_cvoff, cv, outb;
     RSEM_HIP_TRY(counts.alloc(sizeof(int32_t) * nM * nchains));
     if (exact) RSEM_HIP_TRY(z.alloc(sizeof(int32_t) * c->N1 * nchains));
-    if (exact) RSEM_HIP_TRY(mts.alloc(sizeof(MtState) * nchains));
+    if (exact) RSEM_HIP_TRY(mts.alloc(sizeof(MtState) * nchains * 2));  // (two buffers: see k_gibbs_exact_team)
     RSEM_HIP_TRY(acc.alloc(sizeof(double) * 4 * nM * nchains));
     RSEM_HIP_TRY(acc_g.alloc(sizeof(double) * m * nchains));
     RSEM_HIP_TRY(acc_t.alloc(sizeof(double) * mt * nchains));
@@ -1144,7 +1207,78 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         DevBuf prof_buf;  // RSEM_GX_PROFILE builds: the workgroup kernel's phase cycles
         RSEM_HIP_TRY(prof_buf.alloc(16 * sizeof(unsigned long long)));
         RSEM_HIP_TRY(hipMemsetAsync(prof_buf.p, 0, 16 * sizeof(unsigned long long), st));
+        // The team kernel: W workgroups per chain (gibbs_exact_team.hpp) when the device has compute units to spare for them --
+        // W = compute units / chains of this call, at most kXTeamMax; RSEM_GX_TEAM=<W> overrules (1: one workgroup per chain).
+        // A cooperative launch: the team barrier needs every workgroup resident, and the runtime refuses a grid that is not.
+        int W = 1;
+        if (impl == kExactWg) {
+            W = std::max(1, std::min(kXTeamMax, c->n_cus / std::max(1, nchains)));
+            if (const char* e = getenv("RSEM_GX_TEAM")) W = std::max(1, std::min(kXTeamMax, atoi(e)));
+            W = (int)std::min<uint64_t>((uint64_t)W, std::max<uint64_t>(1, c->n_tiles));
+            int coop = 0, per_cu = 0;
+            (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gibbs_exact_team<false>, kXThr, 0) != hipSuccess) per_cu = 0;
+            (void)hipGetLastError();
+            if (!coop || per_cu < 1) W = 1;
+            else W = std::min(W, std::max(1, per_cu * c->n_cus / std::max(1, nchains)));
+        }
+        DevBuf t_ctl, t_net, t_gnet, t_ref;
+        TeamArgs ta{};
+        if (W > 1) {
+            if (c->team_W != W) {
+                std::vector<XSlot> slots;
+                gx_build_windows(W, c->h_tiles, c->h_tile_items, slots);
+                if (c->d_slots) { (void)hipFree(c->d_slots); c->d_slots = nullptr; }
+                RSEM_HIP_TRY(hipMalloc(&c->d_slots, std::max<size_t>(sizeof(XSlot) * slots.size(), 8)));
+                RSEM_HIP_TRY(hipMemcpy(c->d_slots, slots.data(), sizeof(XSlot) * slots.size(), hipMemcpyHostToDevice));
+                c->n_win = (uint32_t)(slots.size() / (size_t)W);
+                c->team_W = W;
+            }
+            ta.W = W;
+            ta.nchains = nchains;
+            ta.nw = (uint32_t)(((W + 15) / 16) * 16 / 2);
+            const size_t rows = (size_t)c->M + 2;
+            RSEM_HIP_TRY(t_ctl.alloc(sizeof(XTeamCtl) * nchains));
+            RSEM_HIP_TRY(t_net.alloc(sizeof(uint32_t) * rows * ta.nw * nchains));
+            RSEM_HIP_TRY(t_gnet.alloc(sizeof(uint32_t) * rows * 2 * nchains));
+            RSEM_HIP_TRY(t_ref.alloc(sizeof(int32_t) * rows * nchains));
+            RSEM_HIP_TRY(hipMemsetAsync(t_ctl.p, 0, sizeof(XTeamCtl) * nchains, st));
+            RSEM_HIP_TRY(hipMemsetAsync(t_net.p, 0x80, sizeof(uint32_t) * rows * ta.nw * nchains, st));  // every cell at kXBias
+            RSEM_HIP_TRY(hipMemsetAsync(t_gnet.p, 0x80, sizeof(uint32_t) * rows * 2 * nchains, st));
+            RSEM_HIP_TRY(hipMemsetAsync(t_ref.p, 0, sizeof(int32_t) * rows * nchains, st));
+            ta.ctl = t_ctl.as<XTeamCtl>();
+            ta.net = t_net.as<uint32_t>();
+            ta.gnet = t_gnet.as<uint32_t>();
+            ta.ref = t_ref.as<int32_t>();
+            ta.slots = (const XSlot*)c->d_slots;
+            ta.n_win = c->n_win;
+            ta.N1 = c->N1;
+            ta.M = c->M;
+            if (getenv("RSEM_GX_VERBOSE")) fprintf(stderr, "[gibbs exact] teams of %d workgroups per chain, %u windows per sweep\n", W, c->n_win);
+        }
+        int mt_flip = 0;  // which half of mts holds the chains' generators
+        hipError_t team_err = hipSuccess;
+        auto sweep_team = [&](bool init, int round) {
+            const uint64_t* a_rp = c->d_irp;
+            const int32_t* a_sid = c->d_isid;
+            const double* a_cp = c->d_icp;
+            int32_t* a_counts = counts.as<int32_t>();
+            int32_t* a_z = z.as<int32_t>();
+            double a_pc = c->pseudoC;
+            const MtState* a_in = mts.as<MtState>() + (size_t)mt_flip * nchains;
+            MtState* a_out = mts.as<MtState>() + (size_t)(mt_flip ^ 1) * nchains;
+            const int32_t* a_last = d_last.as<int32_t>();
+            int a_round = round;
+            uint64_t a_sc = stride_c, a_sz = stride_z;
+            unsigned long long* a_prof = (RSEM_GX_PROFILE && !init) ? prof_buf.as<unsigned long long>() : (unsigned long long*)nullptr;
+            void* args[] = {&ta, &a_rp, &a_sid, &a_cp, &a_counts, &a_z, &a_pc, &a_in, &a_out, &a_last, &a_round, &a_sc, &a_sz, &a_prof};
+            const void* fn = init ? (const void*)k_gibbs_exact_team<true> : (const void*)k_gibbs_exact_team<false>;
+            hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)(nchains * W)), dim3(kXThr), args, 0, st);
+            if (e != hipSuccess && team_err == hipSuccess) team_err = e;
+            mt_flip ^= 1;
+        };
         auto sweep = [&](bool init, int round) {
+            if (W > 1) { sweep_team(init, round); return; }
 #define EXACT_ARGS c->N1, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->d_alpha, c->pseudoC, \
                    mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z
             if (impl == kExactWg) {
@@ -1176,7 +1310,36 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                 if (rc != RSEM_OK) return rc;
             }
         }
-        if (RSEM_GX_PROFILE && impl == kExactWg) {
+        if (W > 1) {
+            if (team_err != hipSuccess) {
+                rsem::set_last_error("k_gibbs_exact_team: cooperative launch of %d x %d workgroups failed: %s", nchains, W, hipGetErrorString(team_err));
+                return RSEM_ERR_HIP;
+            }
+            std::vector<XTeamCtl> hc(nchains);
+            RSEM_HIP_TRY(hipMemcpyAsync(hc.data(), t_ctl.p, sizeof(XTeamCtl) * nchains, hipMemcpyDeviceToHost, st));
+            RSEM_HIP_TRY(hipStreamSynchronize(st));
+            for (int k = 0; k < nchains; k++)
+                if (hc[k].abort) {
+                    rsem::set_last_error("k_gibbs_exact_team: chain %d's team gave up waiting at a team barrier (a workgroup of the team was not running)", k);
+                    return RSEM_ERR_HIP;
+                }
+            if (getenv("RSEM_GX_VERBOSE")) {
+                unsigned long long nb = 0;
+                for (int k = 0; k < nchains; k++) nb += hc[k].epoch;
+                fprintf(stderr, "[gibbs exact] %.2f team barriers per window\n", (double)nb / std::max(1.0, (double)nchains * (double)c->n_win * (double)sweeps));
+            }
+        }
+        if (RSEM_GX_PROFILE && impl == kExactWg && W > 1) {
+            unsigned long long h[16];
+            RSEM_HIP_TRY(hipMemcpyAsync(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost, st));
+            RSEM_HIP_TRY(hipStreamSynchronize(st));
+            const double tiles = h[7] ? (double)h[7] : 1.0;
+            fprintf(stderr, "[gibbs exact team] shader-clock cycles per tile: stage %.0f | own flags %.0f | rng + gather %.0f | first draw %.0f | resolve %.0f (%.2f rounds) | "
+                            "publish %.0f | team barrier %.0f | cross look-ups %.0f | cross redraw %.0f | cross resolve %.0f | commit + barrier %.0f ; cross iterations %.2f ; tiles %.0f\n",
+                    h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[8] / tiles, h[5] / tiles, h[6] / tiles, h[10] / tiles, h[11] / tiles,
+                    h[12] / tiles, h[13] / tiles, h[9] / tiles, tiles);
+        }
+        if (RSEM_GX_PROFILE && impl == kExactWg && W == 1) {
             unsigned long long h[16];
             RSEM_HIP_TRY(hipMemcpyAsync(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost, st));
             RSEM_HIP_TRY(hipStreamSynchronize(st));

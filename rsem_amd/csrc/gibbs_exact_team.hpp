@@ -1,0 +1,671 @@
+// gibbs_exact_team.hpp -- the body of k_gibbs_exact_team (gibbs.hip): the reference's Gibbs chain (Gibbs.cpp:265-311,
+// sampling.h:50-65) advanced by a TEAM of W workgroups per chain -- the same chain, bit for bit, as the one workgroup of
+// gibbs_exact_wg.hpp, whose tile machinery (staging, gather, draws, the resolve rounds inside a tile) this file re-uses.
+//
+// Included by gibbs.hip inside its anonymous namespace and by tests/gibbs_exact_team_emu.cpp, which runs this very code on the
+// CPU (one OS thread per lane, W workgroups side by side, real barriers) against the oracle's chain.
+//
+// Why a team.  The chain is sequential from read to read only through `counts`, and one visit changes at most two entries.  One
+// workgroup resolves that inside a 256-read tile by fixed-point rounds (gibbs_exact_wg.hpp); between tiles it is still one
+// instruction stream per chain, and `-p 8` keeps 8 of 256 compute units busy.  Here W consecutive tiles form a WINDOW and are
+// taken by W workgroups AT ONCE, tile w of the window by workgroup w:
+//   1. every workgroup resolves its tile as if it were alone, on the counts as they are after the previous window;
+//   2. it PUBLISHES its reads' moves (z_old -> z_new) in the chain's net table: per transcript id one cell per workgroup (and one
+//      per group of 16 workgroups) holding moves-to minus moves-from of that workgroup's tile, and a reference count per id that
+//      says whether any cell of the id is in use;
+//   3. team barrier; a workgroup then takes, for every item of its tile whose id is in use, the sum of the cells of the EARLIER
+//      workgroups of the window -- what the earlier tiles' moves add to that id's count, X -- and where X differs from the
+//      value it used, corrects the item's count, redraws the item's read with the SAME random number and resolves the tile
+//      again; if draws changed it publishes the difference;
+//   4. team barrier; while any workgroup published a change, step 3 is repeated.  Tile 0 depends on nobody and is final after
+//      step 1; once tiles 0 .. w-1 are final, tile w reads their final cells and is final one iteration later: at most W
+//      iterations, in practice two or three, and a pass in which nobody publishes leaves every tile consistent with all
+//      earlier ones -- the sequential chain's state (induction over the tile index, as inside a tile over the thread index);
+//   5. commit: counts and z, the workgroup's cells and reference counts taken back (the tables are all-bias / all-zero between
+//      windows); team barrier; next window.
+// Values read while another workgroup is still publishing are intermediate guesses like any other: only the pass in which
+// nothing is published decides, and in that pass nothing is written.  The random stream is position-addressed: read r of a sweep
+// takes the r-th output of the sweep whoever visits it, every workgroup carries its own copy of the generator and twists it
+// forward to the block its tile starts in.
+// A read with more items than a tile holds is a window of its own (workgroup 0 walks it over global memory, as before).
+// Uniform pseudo count only (see gibbs_exact_wg.hpp).
+#pragma once
+#include "gibbs_exact_wg.hpp"
+
+#ifndef GX_EMU
+#define GX_G_LOAD32(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GX_G_LOAD64(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GX_G_STORE32(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GX_G_STORE64(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GX_G_ADD32(p, v) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GX_G_ADD64(p, v) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GX_TEAM_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define GX_TEAM_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define GX_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
+#define GX_WALL() ((unsigned long long)wall_clock64()) /* 100 MHz, constant */
+#endif
+
+constexpr int kXTeamMax = 64;          // workgroups per chain at most (one 8-byte word of group cells: 4 groups of 16)
+constexpr int kXStep = 4;             // items per thread whose cells are loaded together in the cross look-ups
+static_assert(kXPlanes % kXStep == 0, "whole steps");
+constexpr unsigned kXBias = 0x8080u;   // a cell holds net + bias (hipMemset with 0x80 makes an all-bias table)
+constexpr unsigned long long kXSpinLimit = 3000000000ull;  // wall-clock ticks (30 s) a workgroup waits for its team at most
+
+// One tile of a window as the workgroup that takes it needs it (host table, gx_build_windows): slot [win * W + w].
+struct XSlot {
+    uint64_t base;   // first item of the tile
+    uint64_t T64;    // items of the tile
+    uint32_t r0;     // first read
+    uint32_t nr;     // reads (0: this workgroup has no tile in this window)
+    uint32_t flags;  // bit 0: the window is a single long read (workgroup 0 walks it; no publishing, one barrier)
+    uint32_t pad;
+};
+
+// Per chain, in global memory; zeroed before the first launch of a run.
+struct XTeamCtl {
+    unsigned long long arrive;  // arrivals at team barriers (never reset during a run)
+    unsigned long long epoch;   // barriers completed by the launches so far (workgroup 0 adds its count when it leaves)
+    unsigned int flag[4];       // "somebody published a change" of barrier k in flag[k & 3]
+    unsigned int abort;         // a workgroup waited longer than kXSpinLimit: everybody leaves, the host reports it
+    unsigned int pad[3];
+};
+
+struct XTeam {
+    int W, tw;             // workgroups of the team, this one's index
+    XTeamCtl* ctl;
+    uint32_t* net;         // [(M + 2)][nw] words of two cells: cell w of id s = what workgroup w's tile adds to counts[s] (+ bias)
+    uint32_t* gnet;        // [(M + 2)][2] words: cell g = the sum over workgroups 16 g .. 16 g + 15 (+ bias)
+    int32_t* ref;          // [(M + 2)] moves of the window that hold a reference on the id (0: every cell of the id is at bias)
+    uint32_t nw;           // words per row of net: roundup(W, 16) / 2
+    const XSlot* slots;
+    uint32_t n_win;
+    uint64_t N1;
+    int32_t M;             // row M + 1 of the tables is never written (the address of loads that are not needed)
+};
+
+// Windows: up to W consecutive tiles; a long tile is a window of its own.  (Host; also the emulator.)
+inline void gx_build_windows(int W, const std::vector<uint32_t>& tiles, const std::vector<uint64_t>& tile_items, std::vector<XSlot>& slots) {
+    slots.clear();
+    const size_t n_tiles = tiles.size() - 1;
+    size_t t = 0;
+    while (t < n_tiles) {
+        const bool lng = tile_items[t + 1] - tile_items[t] > (uint64_t)kXCap;
+        size_t e = t + 1;
+        if (!lng)
+            while (e < n_tiles && e - t < (size_t)W && tile_items[e + 1] - tile_items[e] <= (uint64_t)kXCap) ++e;
+        for (int w = 0; w < W; w++) {
+            XSlot s{};
+            const size_t q = t + (size_t)w;
+            if (q < e) {
+                s.base = tile_items[q];
+                s.T64 = tile_items[q + 1] - tile_items[q];
+                s.r0 = tiles[q];
+                s.nr = tiles[q + 1] - tiles[q];
+            }
+            s.flags = lng ? 1u : 0u;
+            slots.push_back(s);
+        }
+        t = e;
+    }
+}
+
+// All threads of the workgroup call this.  `flag`: this workgroup's contribution to the OR over the team (uniform over the
+// workgroup).  Returns the OR, or -1 when the team gave up (then everybody returns from the body at once).
+GX_DEVFN int gx_team_barrier(int g, XTile* L, const XTeam& tm, unsigned long long epoch, unsigned& nbar, bool flag) {
+    GX_WAIT_VM();      // this thread's global writes are performed ...
+    GX_BLOCK_SYNC();   // ... and so are the workgroup's
+    if (g == 0) {
+        XTeamCtl* c = tm.ctl;
+        const unsigned slot = nbar & 3u;
+        if (flag) GX_G_ADD32(&c->flag[slot], 1u);
+        GX_TEAM_RELEASE();
+        GX_G_ADD64(&c->arrive, 1ull);
+        const unsigned long long target = (epoch + (unsigned long long)nbar + 1ull) * (unsigned long long)tm.W;
+        int res = 0;
+        unsigned long long t0 = 0;
+        unsigned polls = 0;
+        for (;;) {
+            if (GX_G_LOAD64(&c->arrive) >= target) break;
+            if (GX_G_LOAD32(&c->abort) != 0u) { res = -1; break; }
+            if ((++polls & 1023u) == 0u) {
+                const unsigned long long now = GX_WALL();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > kXSpinLimit) { GX_G_STORE32(&c->abort, 1u); res = -1; break; }
+            }
+            GX_SPIN_PAUSE();
+        }
+        GX_TEAM_ACQUIRE();
+        if (res == 0) {
+            res = GX_G_LOAD32(&c->flag[slot]) != 0u ? 1 : 0;
+            // the slot of barrier k + 2 (= of barrier k - 2: everybody read it before arriving at barrier k - 1)
+            if (tm.tw == 0) GX_G_STORE32(&c->flag[(slot + 2u) & 3u], 0u);
+        }
+        L->team_res = res;
+    }
+    GX_BLOCK_SYNC();
+    nbar += 1u;
+    return L->team_res;
+}
+
+// One sweep over all reads (Gibbs.cpp:297-311), or the initial assignment (Gibbs.cpp:281-291) when kInit, by the team.  Called
+// by every thread of every workgroup of the chain's team; L->mt / L->idx hold the chain's generator as it is BEFORE the sweep
+// (every workgroup has the same copy) and, in workgroup 0, as it is after the sweep when the function returns true.
+// Returns false when the team gave up (XTeamCtl::abort).
+template <bool kInit>
+GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
+                                    const double* __restrict__ cp, int32_t* counts, int32_t* z, double pseudoC, unsigned long long* prof) {
+    const int lane = g & 63, w = g >> 6;
+    const bool rd = kXThr == kXT || g < kXT;
+    const int W = tm.W, tw = tm.tw;
+    unsigned long long pa[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- what does not change over the sweep ---------------------------------------------------------------------------------
+    const unsigned long long idx0 = (unsigned long long)L->idx;  // raw position of the sweep's first output in block 0 (0 .. 624)
+    unsigned long long blk_cur = 0;                              // the block L->mt holds
+    GX_BLOCK_SYNC();
+    unsigned long long epoch = 0;
+    if (!kInit && W > 1) {
+        if (g == 0) L->team_epoch = GX_G_LOAD64(&tm.ctl->epoch);
+        GX_BLOCK_SYNC();
+        epoch = L->team_epoch;
+    }
+    unsigned nbar = 0;
+    // the cells of EARLIER workgroups: of my group of 16 in net (4 words of 4 cells), of the groups before mine in gnet (1 word)
+    const int grp = tw >> 4;
+    unsigned long long m_net[4], m_g = 0ull;
+    int n_cells = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        m_net[q] = 0ull;
+        for (int i = 0; i < 4; i++)
+            if (grp * 16 + q * 4 + i < tw) { m_net[q] |= 0xFFFFull << (16 * i); ++n_cells; }
+    }
+    for (int i = 0; i < 4; i++)
+        if (i < grp) { m_g |= 0xFFFFull << (16 * i); ++n_cells; }
+    const int bias_total = n_cells * (int)kXBias;
+    const size_t dummy_row = (size_t)tm.M + 1;
+    auto swar = [](unsigned long long v) -> int {  // the sum of the four 16-bit fields
+        const unsigned long long t = (v & 0x0000FFFF0000FFFFull) + ((v >> 16) & 0x0000FFFF0000FFFFull);
+        return (int)(unsigned)((t + (t >> 32)) & 0xFFFFFFFFull);
+    };
+    auto cell_add = [&](int s, int delta) {  // this workgroup's cell of id s, and its group's
+        GX_G_ADD32(&tm.net[(size_t)s * tm.nw + (size_t)(tw >> 1)], (uint32_t)delta << (16 * (tw & 1)));
+        GX_G_ADD32(&tm.gnet[(size_t)s * 2 + (size_t)(grp >> 1)], (uint32_t)delta << (16 * (grp & 1)));
+    };
+
+    struct Ahead {
+        uint32_t r0;
+        int nr;
+        uint64_t base, T64;
+        uint32_t flags;
+        unsigned long long rp;
+        int z;
+        int s[kXPlanes];
+        double p[kXPlanes];
+    } A;
+    XSlot la;
+    auto look = [&](uint32_t win) {  // the slot of window `win` (or an empty one behind the last)
+        if (win < tm.n_win) la = tm.slots[(size_t)win * (size_t)W + (size_t)tw];
+        else { la.base = 0; la.T64 = 0; la.r0 = 0; la.nr = 0; la.flags = 0; la.pad = 0; }
+    };
+    auto fetch = [&]() {  // the tile `la` describes -> A
+        A.r0 = la.r0;
+        A.nr = (int)la.nr;
+        A.base = la.base;
+        A.T64 = la.T64;
+        A.flags = la.flags;
+        const uint32_t Tn = A.T64 > (uint64_t)kXCap ? 0u : (uint32_t)A.T64;
+        A.rp = A.nr > 0 ? row_ptr[(uint64_t)A.r0 + (uint64_t)(g < A.nr ? g : A.nr)] : la.base;
+        A.z = (!kInit && g < A.nr) ? z[(uint64_t)A.r0 + g] : 0;
+#pragma unroll
+        for (int u = 0; u < kXPlanes; u++) {
+            const uint32_t j = (uint32_t)u * kXThr + g;
+            A.s[u] = j < Tn ? sid[A.base + j] : 0;
+            A.p[u] = j < Tn ? cp[A.base + j] : 0.0;
+        }
+    };
+    uint32_t* mt = L->mt;
+    auto seek = [&](unsigned long long b) {  // (uniform) twist the generator forward to block b
+        if (blk_cur < b) {
+            if (w == 0)
+                for (unsigned long long k = blk_cur; k < b; k++) gx_mt_regen(mt, lane);
+            blk_cur = b;
+            GX_BLOCK_SYNC();
+        }
+    };
+    look(0);
+    fetch();
+    look(1);
+    for (uint32_t win = 0; win < tm.n_win; win++) {
+        unsigned long long tk = GX_CLOCK();
+        auto lap = [&](int i) {
+            if (RSEM_GX_PROFILE) {
+                const unsigned long long n = GX_CLOCK();
+                pa[i] += n - tk;
+                tk = n;
+            }
+        };
+        const uint64_t r0 = A.r0;
+        const int nr = A.nr;  // 0 .. kXT (0: no tile for this workgroup in this window)
+        const bool win_long = (A.flags & 1u) != 0u;
+        // ---- stage (from the registers loaded ahead) -------------------------------------------------------------------------
+        const uint64_t base = A.base;
+        const uint64_t T64 = A.T64;
+        const bool long_tile = T64 > (uint64_t)kXCap;
+        const uint32_t T = long_tile ? 0u : (uint32_t)T64;
+        if (rd) L->rp[g] = A.rp;
+        if (g == 0) L->rp[kXT] = base + T64;
+        const bool mine = g < nr;
+        const int z_old = A.z;
+        int sj[kXPlanes];
+        int xc[kXPlanes];  // what the earlier tiles of the window add to the item's count, as this tile currently has it
+#pragma unroll
+        for (int u = 0; u < kXPlanes; u++) {
+            const uint32_t j = (uint32_t)u * kXThr + g;
+            sj[u] = A.s[u];
+            xc[u] = 0;
+            if (j < T) {
+                L->sid[j] = A.s[u];
+                L->p[j] = A.p[u];
+                if (!kInit) L->dl[j] = 0;
+            }
+        }
+        GX_WAIT_VM();
+        GX_BLOCK_SYNC();
+        const uint32_t fr = mine ? (uint32_t)(L->rp[g] - base) : 0;
+        const int len = (mine && !long_tile) ? (int)(L->rp[g + 1] - L->rp[g]) : 0;
+        lap(0);
+        if (!kInit) {
+            for (int k = 0; k < len; k++) L->ownr[fr + k] = (unsigned char)g;
+            if (rd) L->zold[g] = z_old;
+            if (rd && lane == 0) L->dirty[w] = 0ull;
+            GX_BLOCK_SYNC();
+        }
+        lap(1);
+        // ---- the tile's random numbers: read r of the sweep takes output r ------------------------------------------------------
+        uint32_t rnd = 0;
+        if (nr > 0) {  // (uniform)
+            const unsigned long long first = idx0 + (unsigned long long)r0;
+            const unsigned long long b0 = first / 624ull;
+            const int off = (int)(first - b0 * 624ull);
+            seek(b0);
+            const int avail = 624 - off;
+            if (g < avail && mine) rnd = gx_temper(mt[off + g]);
+            if (nr > avail) {
+                GX_BLOCK_SYNC();
+                seek(b0 + 1ull);
+                if (g >= avail && mine) rnd = gx_temper(mt[g - avail]);
+            }
+        }
+        int z_new = z_old, z_pub = z_old;
+        // sample() of sampling.h:50-65 on the staged tile, exactly as in gibbs_exact_wg.hpp (see there for why it looks like this)
+        auto draw = [&](auto with_delta) -> int {
+            constexpr bool kDelta = decltype(with_delta)::value;
+            const int last = len > 0 ? len - 1 : 0;
+            auto load = [&](auto width, int k0, double* a) {
+                constexpr int Wd = decltype(width)::value;
+                int cc[Wd];
+                double pp[Wd];
+#pragma unroll
+                for (int j = 0; j < Wd; j++) {
+                    const uint32_t at = fr + (uint32_t)(k0 + j < len ? k0 + j : last);
+                    pp[j] = L->p[at];
+                    cc[j] = kInit ? 0 : L->c[at];
+                    if (kDelta) cc[j] += (int)L->dl[at];
+                }
+#pragma unroll
+                for (int j = 0; j < Wd; j++) {
+                    const double wgt = kInit ? pp[j] : ((double)cc[j] + pseudoC) * pp[j];
+                    a[j] = (k0 + j < len) ? wgt : 0.0;
+                }
+            };
+            using Wide = std::integral_constant<int, kXChunk>;
+            using Narrow = std::integral_constant<int, kXTail>;
+            double part[kXChunk], a[kXChunk];
+            double run = 0.0;
+            load(Wide{}, 0, a);
+#pragma unroll
+            for (int j = 0; j < kXChunk; j++) {
+                run += (j < len) ? a[j] : 0.0;
+                part[j] = run;
+            }
+            {
+                int k0 = kXChunk;
+                for (; k0 + kXChunk <= len; k0 += kXChunk) {
+                    load(Wide{}, k0, a);
+#pragma unroll
+                    for (int j = 0; j < kXChunk; j++) run += a[j];
+                }
+                for (; k0 < len; k0 += kXTail) {
+                    load(Narrow{}, k0, a);
+#pragma unroll
+                    for (int j = 0; j < kXTail; j++) run += (k0 + j < len) ? a[j] : 0.0;
+                }
+            }
+            const double prb = ((double)rnd * (1.0 / 4294967296.0)) * run;
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < kXChunk; j++) cnt += (j < len && part[j] <= prb) ? 1 : 0;
+            double r2 = part[kXChunk - 1];
+            {
+                int k0 = kXChunk;
+                for (; k0 + kXChunk <= len; k0 += kXChunk) {
+                    load(Wide{}, k0, a);
+#pragma unroll
+                    for (int j = 0; j < kXChunk; j++) {
+                        r2 += a[j];
+                        cnt += (r2 <= prb) ? 1 : 0;
+                    }
+                }
+                for (; k0 < len; k0 += kXTail) {
+                    load(Narrow{}, k0, a);
+#pragma unroll
+                    for (int j = 0; j < kXTail; j++) {
+                        r2 += (k0 + j < len) ? a[j] : 0.0;
+                        cnt += (k0 + j < len && r2 <= prb) ? 1 : 0;
+                    }
+                }
+            }
+            const int l = cnt < len ? cnt : len - 1;
+            return L->sid[fr + l];
+        };
+        // The resolve rounds inside the tile (gibbs_exact_wg.hpp, step 4): called after the first draw and again whenever the
+        // counts under the tile changed.  `rescan`: deltas of an earlier call may be in place although nobody moves any more (the
+        // tile's first mover was itself redrawn, which cannot happen inside one call): scan once even without movers.
+        auto resolve = [&](bool rescan) {
+            for (;;) {
+                const bool mv = mine && z_new != z_old;
+                const int z_ent = z_new;
+                const unsigned long long bm = GX_BALLOT(mv);
+                if (rd && lane == 0) L->mm[w] = bm;
+                unsigned h_fr = 0, h_to = 0;
+                if (mv) {
+                    auto enter = [&](int id, int dir) -> unsigned {
+                        unsigned h = gx_hash(id);
+                        for (;;) {
+                            int old = L->key[h];
+                            if (old == 0) old = GX_LDS_CAS32(&L->key[h], 0, id + 1);
+                            if (old == 0 || old == id + 1) break;
+                            h = (h + 1) & (kXKeys - 1);
+                        }
+                        GX_LDS_OR64(&L->ends[h][dir][w], 1ull << lane);
+                        const unsigned b = gx_bit(id);
+                        GX_LDS_OR64(&L->bits[b >> 6], 1ull << (b & 63));
+                        return h;
+                    };
+                    h_fr = enter(z_old, 1);
+                    h_to = enter(z_new, 0);
+                }
+                GX_BLOCK_SYNC();
+                bool any_moved = false;
+#pragma unroll
+                for (int q = 0; q < kXW; q++) any_moved = any_moved || L->mm[q] != 0ull;
+                if (!any_moved && !rescan) break;  // (uniform) the table is untouched and no delta is in place
+                rescan = false;
+                if (RSEM_GX_PROFILE) pa[8] += 1;
+                unsigned need = 0;
+                int dv[kXPlanes];
+                {
+                    unsigned long long bw[kXPlanes];
+#pragma unroll
+                    for (int u = 0; u < kXPlanes; u++) {
+                        const uint32_t j = (uint32_t)u * kXThr + g;
+                        const unsigned b = gx_bit(sj[u]);
+                        bw[u] = L->bits[b >> 6];
+                        dv[u] = (int)L->dl[j < T ? j : 0u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kXPlanes; u++) {
+                        const uint32_t j = (uint32_t)u * kXThr + g;
+                        if (j >= T) { bw[u] = 0ull; dv[u] = 0; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kXPlanes; u++) {
+                        const unsigned b = gx_bit(sj[u]);
+                        if (((bw[u] >> (b & 63)) & 1ull) != 0ull || dv[u] != 0) need |= 1u << u;
+                    }
+                }
+                for (; need != 0u; need &= need - 1u) {
+                    const int u = __builtin_ctz(need);
+                    const uint32_t j = (uint32_t)u * kXThr + g;
+                    const int sv = L->sid[j];
+                    const int o = (int)L->ownr[j], ow = o >> 6;
+                    unsigned h = gx_hash(sv);
+                    int kv = L->key[h];
+                    while (kv != 0 && kv != sv + 1) {
+                        h = (h + 1) & (kXKeys - 1);
+                        kv = L->key[h];
+                    }
+                    int dd = 0;
+                    if (kv != 0) {
+                        const unsigned long long part = (1ull << (o & 63)) - 1ull;
+#pragma unroll
+                        for (int q = 0; q < kXW; q++) {
+                            const unsigned long long bef = q < ow ? ~0ull : (q == ow ? part : 0ull);
+                            dd += GX_POPC64(L->ends[h][0][q] & bef) - GX_POPC64(L->ends[h][1][q] & bef);
+                        }
+                    }
+                    if (dd != (int)L->dl[j]) {
+                        L->dl[j] = (int16_t)dd;
+                        GX_LDS_OR64(&L->dirty[ow], 1ull << (o & 63));
+                    }
+                }
+                GX_BLOCK_SYNC();
+                const bool dirty = rd && ((L->dirty[w] >> lane) & 1ull) != 0ull;
+                int z2 = z_new;
+                if (dirty) z2 = draw(std::true_type{});
+                const unsigned long long ch = GX_BALLOT(mine && z2 != z_new);
+                z_new = z2;
+                if (rd && lane == 0) L->chg[w] = ch;
+                GX_BLOCK_SYNC();
+                if (mv) {
+#pragma unroll
+                    for (int q = 0; q < kXW; q++) {
+                        L->ends[h_fr][0][q] = 0ull; L->ends[h_fr][1][q] = 0ull;
+                        L->ends[h_to][0][q] = 0ull; L->ends[h_to][1][q] = 0ull;
+                    }
+                    L->key[h_fr] = 0;
+                    L->key[h_to] = 0;
+                    L->bits[gx_bit(z_old) >> 6] = 0ull;
+                    L->bits[gx_bit(z_ent) >> 6] = 0ull;
+                }
+                if (rd && lane == 0) L->dirty[w] = 0ull;
+                bool any_changed = false;
+#pragma unroll
+                for (int q = 0; q < kXW; q++) any_changed = any_changed || L->chg[q] != 0ull;
+                GX_BLOCK_SYNC();
+                if (!any_changed) break;
+            }
+        };
+        if (long_tile) {
+            // thread 0 of workgroup 0 walks the read over global memory, two passes; nobody else has a tile in this window
+            if (g == 0) {
+                const uint64_t fr64 = base, n = T64;
+                if (!kInit) {
+                    GX_CNT_ADD(&counts[z_old], -1);
+                    GX_WAIT_VM();
+                }
+                auto wt = [&](uint64_t j) -> double {
+                    const int s = sid[j];
+                    const double p = cp[j];
+                    if (kInit) return p;
+                    return ((double)GX_CNT_LOAD(&counts[s]) + pseudoC) * p;
+                };
+                double tot = 0.0;
+                for (uint64_t j = 0; j < n; j++) { const double a = wt(fr64 + j); tot = (j == 0) ? a : tot + a; }
+                const double prb = ((double)rnd * (1.0 / 4294967296.0)) * tot;
+                double cum = 0.0;
+                uint64_t l = n - 1;
+                for (uint64_t j = 0; j < n; j++) {
+                    const double a = wt(fr64 + j);
+                    cum = (j == 0) ? a : cum + a;
+                    if (cum > prb) { l = j; break; }
+                }
+                const int zn = sid[fr64 + l];
+                GX_CNT_ADD(&counts[zn], 1);
+                z[r0] = zn;
+            }
+            fetch();
+            look(win + 2);
+        } else {
+            if (!kInit && nr > 0) {
+                // counts of the tile's items as they are after the previous window, the read's own unit taken off where it sits
+                int cj[kXPlanes], zo[kXPlanes];
+#pragma unroll
+                for (int u = 0; u < kXPlanes; u++) cj[u] = GX_CNT_LOAD(&counts[sj[u]]);
+                int ow_[kXPlanes];
+#pragma unroll
+                for (int u = 0; u < kXPlanes; u++) {
+                    const uint32_t j = (uint32_t)u * kXThr + g;
+                    ow_[u] = (int)L->ownr[j < T ? j : 0u];
+                }
+#pragma unroll
+                for (int u = 0; u < kXPlanes; u++) zo[u] = L->zold[ow_[u]];
+#pragma unroll
+                for (int u = 0; u < kXPlanes; u++) {
+                    const uint32_t j = (uint32_t)u * kXThr + g;
+                    if (j < T) L->c[j] = cj[u] - (sj[u] == zo[u] ? 1 : 0);
+                }
+            }
+            GX_BLOCK_SYNC();
+            lap(2);
+            fetch();        // the tile this workgroup takes in the next window, in flight from here on
+            look(win + 2);  // ... and the slot of the one after it
+            if (mine) z_new = draw(std::false_type{});
+            lap(3);
+            if (!kInit && nr > 0) resolve(false);
+            lap(4);
+        }
+        // ---- the window: publish, take the earlier tiles' moves, repeat until nobody publishes --------------------------------------
+        if (!kInit && W > 1 && !win_long) {
+            for (;;) {
+                // publish what changed since the last time (z_pub: what this read has in the tables; z_old: nothing)
+                const bool ch = mine && z_new != z_pub;
+                if (ch) {
+                    cell_add(z_pub, -1);
+                    cell_add(z_new, 1);
+                    // a published move holds one reference on either endpoint
+                    if (z_pub == z_old) GX_G_ADD32(&tm.ref[z_old], 1);
+                    else GX_G_ADD32(&tm.ref[z_pub], -1);
+                    if (z_new == z_old) GX_G_ADD32(&tm.ref[z_old], -1);
+                    else GX_G_ADD32(&tm.ref[z_new], 1);
+                    z_pub = z_new;
+                }
+                const unsigned long long cb = GX_BALLOT(ch);
+                if (rd && lane == 0) L->pub[w] = cb;
+                GX_BLOCK_SYNC();
+                bool any_pub = false;
+#pragma unroll
+                for (int q = 0; q < kXW; q++) any_pub = any_pub || L->pub[q] != 0ull;
+                lap(5);
+                const int any = gx_team_barrier(g, L, tm, epoch, nbar, any_pub);
+                lap(6);
+                if (any < 0) return false;
+                if (any == 0) break;  // (uniform over the team) every tile is consistent with all earlier ones
+                if (RSEM_GX_PROFILE) pa[9] += 1;
+                if (tw > 0 && nr > 0) {  // (uniform over the workgroup)
+                    // X of every item: the cells of the earlier workgroups, only where the id holds a reference.  All loads are
+                    // issued whether needed or not (an item that needs none reads row M + 1, which nobody writes): no load waits
+                    // for a decision.
+                    int rf[kXPlanes];
+#pragma unroll
+                    for (int u = 0; u < kXPlanes; u++) rf[u] = GX_G_LOAD32(&tm.ref[sj[u]]);
+                    // (kXStep items at a time: 5 loads each in flight together, and no more registers than that)
+#pragma unroll
+                    for (int u0 = 0; u0 < kXPlanes; u0 += kXStep) {
+                        unsigned long long vn[kXStep][4], vg[kXStep];
+#pragma unroll
+                        for (int i = 0; i < kXStep; i++) {
+                            const int u = u0 + i;
+                            const uint32_t j = (uint32_t)u * kXThr + g;
+                            const size_t row = (j < T && rf[u] != 0) ? (size_t)sj[u] : dummy_row;
+                            const unsigned long long* pn = (const unsigned long long*)(tm.net + row * tm.nw + (size_t)grp * 8);
+                            const unsigned long long* pg = (const unsigned long long*)(tm.gnet + row * 2);
+#pragma unroll
+                            for (int q = 0; q < 4; q++) vn[i][q] = GX_G_LOAD64(pn + q);
+                            vg[i] = GX_G_LOAD64(pg);
+                        }
+#pragma unroll
+                        for (int i = 0; i < kXStep; i++) {
+                            const int u = u0 + i;
+                            const uint32_t j = (uint32_t)u * kXThr + g;
+                            int x = swar(vg[i] & m_g) - bias_total;
+#pragma unroll
+                            for (int q = 0; q < 4; q++) x += swar(vn[i][q] & m_net[q]);
+                            if (j < T && x != xc[u]) {
+                                L->c[j] += x - xc[u];
+                                xc[u] = x;
+                                const int o = (int)L->ownr[j];
+                                GX_LDS_OR64(&L->dirty[o >> 6], 1ull << (o & 63));
+                            }
+                        }
+                    }
+                    GX_BLOCK_SYNC();  // the corrected counts and the marks are in place
+                    lap(10);
+                    const bool dirty = rd && ((L->dirty[w] >> lane) & 1ull) != 0ull;
+                    int z2 = z_new;
+                    if (dirty) z2 = draw(std::true_type{});
+                    const unsigned long long c2 = GX_BALLOT(mine && z2 != z_new);
+                    z_new = z2;
+                    if (rd && lane == 0) L->chg[w] = c2;
+                    GX_BLOCK_SYNC();
+                    if (rd && lane == 0) L->dirty[w] = 0ull;
+                    bool any_changed = false;
+#pragma unroll
+                    for (int q = 0; q < kXW; q++) any_changed = any_changed || L->chg[q] != 0ull;
+                    GX_BLOCK_SYNC();  // (chg may be rewritten; the marks are cleared)
+                    lap(11);
+                    if (any_changed) resolve(true);  // draws changed: the deltas inside the tile follow
+                    lap(12);
+                }
+            }
+        }
+        // ---- commit --------------------------------------------------------------------------------------------------------------
+        if (!kInit) {
+            if (!long_tile && mine && z_new != z_old) {
+                GX_CNT_ADD(&counts[z_old], -1);
+                GX_CNT_ADD(&counts[z_new], 1);
+                z[r0 + g] = z_new;
+            }
+            if (W > 1) {
+                if (!win_long && mine && z_pub != z_old) {  // take the published move back: the tables are clean between windows
+                    cell_add(z_old, 1);
+                    cell_add(z_pub, -1);
+                    GX_G_ADD32(&tm.ref[z_old], -1);
+                    GX_G_ADD32(&tm.ref[z_pub], -1);
+                }
+                // every workgroup's updates of counts are performed before anybody gathers for the next window
+                if (gx_team_barrier(g, L, tm, epoch, nbar, false) < 0) return false;
+            } else {
+                GX_BLOCK_SYNC();  // (the next tile's staging overwrites what a draw may still be reading)
+            }
+        } else {
+            if (mine && !long_tile) {
+                GX_CNT_ADD(&counts[z_new], 1);
+                z[r0 + g] = z_new;
+            }
+            GX_BLOCK_SYNC();  // (as above: the initial assignment has no other barrier behind its draw)
+        }
+        lap(13);
+        if (RSEM_GX_PROFILE && nr > 0) pa[7] += 1;
+    }
+    // ---- the generator after the sweep (workgroup 0 hands it on) ----------------------------------------------------------------------
+    if (tw == 0) {
+        if (tm.N1 > 0) {
+            const unsigned long long last = idx0 + (unsigned long long)tm.N1 - 1ull;
+            const unsigned long long b = last / 624ull;
+            GX_BLOCK_SYNC();
+            seek(b);
+            if (g == 0) L->idx = (int)(last - b * 624ull) + 1;
+        }
+        if (!kInit && W > 1 && g == 0) GX_G_STORE64(&tm.ctl->epoch, epoch + (unsigned long long)nbar);
+    }
+    GX_BLOCK_SYNC();
+#if RSEM_GX_PROFILE && !defined(GX_EMU)
+    if (prof && g == 0)
+        for (int i = 0; i < 16; i++) (void)__hip_atomic_fetch_add(&prof[i], pa[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    (void)prof;
+    (void)pa;
+#endif
+    return true;
+}

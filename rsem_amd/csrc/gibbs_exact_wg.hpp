@@ -57,13 +57,13 @@
 
 constexpr int kXW = 4;           // waves of READS per tile
 constexpr int kXT = 64 * kXW;    // reads per tile = the threads that own a read
-// Threads of the workgroup.  256 (the product, what every number in DESIGN.md was measured with): every thread owns a read and
-// 16 of the tile's items.  -DRSEM_GX_THREADS=512 (a variant build for tools/build_variants.sh, NOT measured yet): four more
-// waves that own no read and share the item-major phases (staging, gather, filter scan, look-ups) -- two waves per SIMD,
-// so that one wave's dependent instructions (~16 cycles each with a SIMD to itself) overlap the other's.  The emulator
-// runs both (tests/test_gibbs_exact_emu_cpu.py).
+// Threads of the workgroup.  512 (the product since round 5): the first four waves own a read each thread, the other four own
+// none and share the item-major phases (staging, gather, filter scan, look-ups) -- two waves per SIMD, so that one wave's
+// dependent instructions (~16 cycles each with a SIMD to itself) overlap the other's: 0.068 us per read visit against 0.083
+// with 256 threads (profiles/r04u_call.log).  -DRSEM_GX_THREADS=256: every thread owns a read and 16 of the tile's items
+// (rounds 3-4's product).  The emulator runs both (tests/test_gibbs_exact_emu_cpu.py).
 #ifndef RSEM_GX_THREADS
-#define RSEM_GX_THREADS 256
+#define RSEM_GX_THREADS 512
 #endif
 constexpr int kXThr = RSEM_GX_THREADS;
 static_assert(kXThr == kXT || kXThr == 2 * kXT, "256 or 512 threads per chain");
@@ -88,6 +88,10 @@ struct XTile {  // the workgroup's LDS: 150 KB of the CU's 160 KB
     unsigned long long bits[kXBits / 64];     // one bit per hashed endpoint id (all zero between rounds): the scan's filter
     uint32_t mt[624];
     int idx;
+    // the team of workgroups of gibbs_exact_team.hpp: which waves published a change; what the team barrier returned
+    unsigned long long pub[kXW];
+    unsigned long long team_epoch;
+    int team_res;
 };
 
 // Tiles: greedy cut into runs of <= kXT consecutive reads holding <= kXCap items; a read with more items than that is a tile

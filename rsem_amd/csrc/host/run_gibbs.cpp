@@ -150,12 +150,12 @@ int main(int argc, char* argv[]) {
     int mode;
     // auto (the default): the reference's own chains (exact) unless they would take more than kAutoExactLimitS here.  A chain
     // is a workgroup and costs about kExactCyclesPerVisit shader cycles per read visit whatever the number of chains, up to
-    // one per compute unit (0.083 us at BASELINE configs[2]'s shape on a 2.4 GHz MI355X); clock and
+    // one per compute unit (0.068 us at BASELINE configs[2]'s shape on a 2.4 GHz MI355X); clock and
     // compute units are the device's own (rsem_hip_device_info), so the estimate is rounds x reads x cycles / clock x
     // ceil(chains per GPU / CUs).  The choice is printed and recorded in <statName>.gibbs_sampler; --gibbs-mode exact /
     // parallel overrule it.  Above the limit the DEFAULT outputs are therefore not the reference's chains (same posterior,
     // a different Markov chain): INTEGRATION.md says so, and so does the program, on stdout and stderr.
-    constexpr double kExactCyclesPerVisit = 200.0, kAutoExactLimitS = 900.0;
+    constexpr double kExactCyclesPerVisit = 165.0, kAutoExactLimitS = 900.0;
     int64_t dev_cus = 256, dev_khz = 2400000;
     if (!dry_run) {
         (void)rsem_hip_device_info(devs[0], "compute_units", &dev_cus);

@@ -1,0 +1,83 @@
+"""The reference's Gibbs chain advanced by a TEAM of workgroups (rsem_amd/csrc/gibbs_exact_team.hpp -- the file gibbs.hip compiles
+for the GPU as k_gibbs_exact_team) run on the CPU by tests/gibbs_exact_team_emu.cpp: W workgroups of one OS thread per lane side
+by side, each taking one tile of a window of W tiles, the moves of earlier tiles published through the team's tables, the team
+barrier as the very spin loop the GPU runs.  The count vectors after every sweep must be the oracle chain's (Gibbs.cpp:265-311
+with MT19937 and sampling.h's sample()) BIT FOR BIT whatever W is, on the collision-heavy data of test_gibbs_exact_emu_cpu.py
+(12 transcripts: every tile's draws depend on every earlier tile's moves).  The emulator itself checks after every sweep that the
+tables are back at bias / zero and that every arrival at a team barrier was counted.  No GPU involved."""
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests.test_gibbs_exact_emu_cpu import CASES, ROOT, CXX, _items, _oracle
+
+pytestmark = pytest.mark.skipif(CXX is None, reason="needs g++")
+
+
+def _build(tmp_path_factory, name, defs):
+    exe = os.path.join(str(tmp_path_factory.mktemp(name)), name)
+    subprocess.check_call([CXX, "-O1", "-std=c++17", "-pthread"] + defs + os.environ.get("RSEM_EMU_DEFS", "").split()
+                          + [os.path.join(ROOT, "tests", "gibbs_exact_team_emu.cpp"), "-o", exe])
+    return exe
+
+
+@pytest.fixture(scope="module")
+def team_256(tmp_path_factory):
+    return _build(tmp_path_factory, "gibbs_exact_team_emu_256", ["-DRSEM_GX_THREADS=256"])
+
+
+@pytest.fixture(scope="module")
+def team_512(tmp_path_factory):
+    return _build(tmp_path_factory, "gibbs_exact_team_emu_512", [])  # the product's workgroup: 512 threads
+
+
+def _run(exe, W, M, rp, sid, cp, init, rounds, seed, N0, pseudoC):
+    d = tempfile.mkdtemp()
+    try:
+        inp, outp = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(inp, "wb") as f:
+            f.write(np.array([M, len(rp) - 1, rounds, seed, N0, 0, 0, 0], np.int32).tobytes())
+            f.write(np.array([pseudoC], np.float64).tobytes())
+            for a, t in ((rp, np.uint64), (sid, np.int32), (cp, np.float64), (init, np.int32)):
+                f.write(np.ascontiguousarray(a, t).tobytes())
+        r = subprocess.run([exe, inp, outp, str(W)], timeout=1200, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return np.fromfile(outp, np.int32).reshape(rounds, M + 1), r.stderr
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def _check(exe, W, case):
+    c = dict(case)
+    rp, sid, cp = _items(c["seed"], c["M"], c["N1"], c["maxlen"], c["noise_scale"], c.get("long_read", 0))
+    init = np.zeros(c["M"] + 1, np.int32)
+    got, log = _run(exe, W, c["M"], rp, sid, cp, init, c["rounds"], 1000 + c["seed"], c["N0"], c["pseudoC"])
+    want = _oracle(c["M"], rp, sid, cp, init, c["rounds"], 1000 + c["seed"], c["N0"], c["pseudoC"])
+    assert np.array_equal(got, want)
+    return log
+
+
+@pytest.mark.parametrize("W", [1, 2, 3])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "seed%d" % c["seed"])
+def test_team_chain_is_the_reference_chain(team_256, case, W):
+    log = _check(team_256, W, case)
+    if W > 1:
+        assert "team barriers" in log and " 0 team barriers" not in log  # the windows really went through the team's protocol
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[5]], ids=lambda c: "seed%d" % c["seed"])
+def test_team_of_512_thread_workgroups(team_512, case):
+    _check(team_512, 2, case)
+
+
+@pytest.mark.parametrize("W", [8, 18])
+def test_wide_teams_and_the_group_cells(team_256, W):
+    """18 workgroups: workgroups 16 and 17 sum the first group's cell of gnet and their own group's cells of net"""
+    _check(team_256, W, CASES[0])
+    _check(team_256, W, CASES[1])
+
+

@@ -133,6 +133,42 @@ def test_exact_tile_kernel_at_scale_vs_oracle_and_serial_kernel(n_reads, long_ev
     ctx.close()
 
 
+@pytest.mark.parametrize("n_reads,long_every,chains", [(150_000, 0, 8), (30_000, 4000, 3), (60_000, 0, 1)])
+def test_exact_chain_is_the_same_for_every_team_size(n_reads, long_every, chains, monkeypatch):
+    """k_gibbs_exact_team (gibbs_exact_team.hpp): W workgroups per chain take W tiles of a window at once and settle the moves
+    between them through the team's tables.  Whatever W is -- one workgroup per chain (the kernel of rounds 3-4), 2, 7 (no
+    divisor of anything), 16 / 17 (the boundary of the group cells), what the device offers for this many chains -- the count
+    vectors are the same integers, and they are the oracle's sequential chain's."""
+    M, (irp, isid, icp) = _synthetic_items(n_reads, long_row_every=long_every)
+    init = np.zeros(M + 1, np.int32)
+    N0, pseudoC = 777, 1.0
+    eel, mw = np.full(M + 1, 700.0), np.ones(M + 1)
+    grp = np.array([1, M + 1], np.int32)
+    totc = (M + 1) * pseudoC + N0 + n_reads
+    seeds = capi().gibbs_chain_seeds(4242, chains)
+    ns = [2 + (k % 2) for k in range(chains)]
+    burnin, gap = 2, 2
+    ctx = capi().GibbsContext(M, irp, isid, icp, init, None, pseudoC, totc, N0, eel, mw, grp)
+    monkeypatch.setenv("RSEM_GX_TEAM", "1")
+    base, acc1, _, p1 = ctx.run_chains(capi().GIBBS_EXACT, seeds, burnin, ns, gap)
+    ocv, _ = orc.gibbs_chain(M, irp, isid, icp, init, None, pseudoC, totc, N0, eel, mw, grp, seeds[0], burnin, ns[0], gap)
+    assert np.array_equal(base[0], ocv)
+    times = {1: p1.sweep_ms}
+    for W in (2, 7, 16, 17, 0):
+        if W:
+            monkeypatch.setenv("RSEM_GX_TEAM", str(W))
+        else:
+            monkeypatch.delenv("RSEM_GX_TEAM")  # the product's choice: compute units / chains, at most 64
+        cvs, acc, _, p = ctx.run_chains(capi().GIBBS_EXACT, seeds, burnin, ns, gap)
+        for k in range(chains):
+            assert np.array_equal(cvs[k], base[k]), (W, k)
+        for a, b in zip(acc, acc1):
+            assert np.array_equal(a, b)
+        times[W] = p.sweep_ms
+    print("exact sweeps by team size (0 = the product's choice), ms per round, %d chains x %d reads: %s" % (chains, n_reads, times))
+    ctx.close()
+
+
 def test_chain_groups_reduce_over_local_comm():
     """Chains dealt to two groups (here: both on GPU 0, the LOCAL communicator; on a multi-GPU node the same calls run
     over RCCL): group sums meet in one reduce on rank 0 and equal the single-group run; count vectors stay with the
