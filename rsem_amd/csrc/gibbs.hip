@@ -23,6 +23,7 @@
 //
 // Per kept sample (Gibbs.cpp:313-346): theta = (counts + alpha) / totc, polishTheta,
 // calcExpressionValues (WriteResults.h:55-104) and the running sums -- on the device.
+#include <atomic>
 #include <cmath>
 
 #include <cstdlib>
@@ -961,6 +962,8 @@ int ensure_parallel_layout(rsem_gibbs_ctx* c) {
 
 // RSEM_GIBBS_EXACT_IMPL = wg (default) | coop | serial: the three implementations of the same chain (cross-checks)
 enum ExactImpl { kExactWg, kExactCoop, kExactSerial };
+constexpr int kMaxTeamDevices = 64;
+std::atomic<int> g_team_busy[kMaxTeamDevices];  // team runs in flight per device (zero-initialised)
 ExactImpl exact_impl_requested(bool have_alpha) {
     const char* e = getenv("RSEM_GIBBS_EXACT_IMPL");
     if (e && !strcmp(e, "serial")) return kExactSerial;
@@ -1210,9 +1213,20 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         // The team kernel: W workgroups per chain (gibbs_exact_team.hpp) when the device has compute units to spare for them --
         // W = compute units / chains of this call, at most kXTeamMax; RSEM_GX_TEAM=<W> overrules (1: one workgroup per chain).
         // A cooperative launch: the team barrier needs every workgroup resident, and the runtime refuses a grid that is not.
+        // One team run per device and process at a time: two cooperative grids that each want every compute unit cannot both be
+        // resident (contexts of two host threads sharing a GPU -- the LOCAL communicator of the tests -- take one workgroup per
+        // chain for whichever comes second).
+        struct TeamLease {
+            int dev = -1;
+            bool mine = false;
+            void take(int d) { dev = d; mine = d >= 0 && d < kMaxTeamDevices && g_team_busy[d].fetch_add(1) == 0; if (!mine && dev >= 0 && dev < kMaxTeamDevices) g_team_busy[dev].fetch_sub(1); }
+            ~TeamLease() { if (mine) g_team_busy[dev].fetch_sub(1); }
+        } lease;
         int W = 1;
-        if (impl == kExactWg) {
+        if (impl == kExactWg) lease.take(c->device);
+        if (impl == kExactWg && lease.mine) {
             W = std::max(1, std::min(kXTeamMax, c->n_cus / std::max(1, nchains)));
+            if (W < 8) W = 1;  // with every compute unit busy, teams of 4 advance a chain no faster than one workgroup (profiles/r05b_c3_64chains.log)
             if (const char* e = getenv("RSEM_GX_TEAM")) W = std::max(1, std::min(kXTeamMax, atoi(e)));
             W = (int)std::min<uint64_t>((uint64_t)W, std::max<uint64_t>(1, c->n_tiles));
             int coop = 0, per_cu = 0;
@@ -1334,10 +1348,10 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             RSEM_HIP_TRY(hipMemcpyAsync(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost, st));
             RSEM_HIP_TRY(hipStreamSynchronize(st));
             const double tiles = h[7] ? (double)h[7] : 1.0;
-            fprintf(stderr, "[gibbs exact team] shader-clock cycles per tile: stage %.0f | own flags %.0f | rng + gather %.0f | first draw %.0f | resolve %.0f (%.2f rounds) | "
-                            "publish %.0f | team barrier %.0f | cross look-ups %.0f | cross redraw %.0f | cross resolve %.0f | commit + barrier %.0f ; cross iterations %.2f ; tiles %.0f\n",
-                    h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[8] / tiles, h[5] / tiles, h[6] / tiles, h[10] / tiles, h[11] / tiles,
-                    h[12] / tiles, h[13] / tiles, h[9] / tiles, tiles);
+            fprintf(stderr, "[gibbs exact team] shader-clock cycles per tile: stage %.0f | own flags %.0f | rng + gather %.0f | first draw %.0f | rounds %.0f (%.2f scans) | "
+                            "redraw + clean-up %.0f | publish %.0f | team barrier %.0f | cross look-ups %.0f | commit + barrier %.0f ; phases %.2f ; tiles %.0f\n",
+                    h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[8] / tiles, h[11] / tiles, h[5] / tiles, h[6] / tiles, h[10] / tiles,
+                    h[13] / tiles, h[9] / tiles, tiles);
         }
         if (RSEM_GX_PROFILE && impl == kExactWg && W == 1) {
             unsigned long long h[16];

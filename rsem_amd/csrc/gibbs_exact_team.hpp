@@ -39,8 +39,20 @@
 #define GX_G_STORE64(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GX_G_ADD32(p, v) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GX_G_ADD64(p, v) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// Everything workgroups of a team exchange goes through relaxed agent-scope atomics (performed at the device's coherence point,
+// never served from a cache that another workgroup does not see); what orders them around the barrier's counter is program order
+// plus a wait for this wave's outstanding memory operations.  An agent-scope release / acquire FENCE would in addition write the
+// whole L2 back and invalidate it (buffer_wbl2 / buffer_inv) for data nobody shares: -DRSEM_GX_TEAM_FENCES=1 builds that variant.
+#ifndef RSEM_GX_TEAM_FENCES
+#define RSEM_GX_TEAM_FENCES 0
+#endif
+#if RSEM_GX_TEAM_FENCES
 #define GX_TEAM_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
 #define GX_TEAM_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define GX_TEAM_RELEASE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define GX_TEAM_ACQUIRE() asm volatile("" ::: "memory")
+#endif
 #define GX_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
 #define GX_WALL() ((unsigned long long)wall_clock64()) /* 100 MHz, constant */
 #endif
@@ -63,11 +75,10 @@ struct XSlot {
 
 // Per chain, in global memory; zeroed before the first launch of a run.
 struct XTeamCtl {
-    unsigned long long arrive;  // arrivals at team barriers (never reset during a run)
+    unsigned long long cnt[4];  // barrier k of a run counts in cnt[k & 3]: arrivals in the low half, "my workgroup changed a draw" in the high
     unsigned long long epoch;   // barriers completed by the launches so far (workgroup 0 adds its count when it leaves)
-    unsigned int flag[4];       // "somebody published a change" of barrier k in flag[k & 3]
     unsigned int abort;         // a workgroup waited longer than kXSpinLimit: everybody leaves, the host reports it
-    unsigned int pad[3];
+    unsigned int pad;
 };
 
 struct XTeam {
@@ -109,6 +120,32 @@ inline void gx_build_windows(int W, const std::vector<uint32_t>& tiles, const st
     }
 }
 
+// The MT19937 twist by the whole workgroup, in place: three steps of up to 227 independent words (0 .. 226 need old words only,
+// 227 .. 453 the new words of the first step, 454 .. 623 those of the second, word 623 the new word 0), reads and writes of a
+// step separated by barriers.  A workgroup of a team twists through every block of the sweep (13 per window of 32 tiles) to reach
+// the one its tile starts in: with one wave doing it in ten passes (gx_mt_regen) that was 20 k cycles per window.  All threads
+// call; returns behind a barrier.
+GX_DEVFN void gx_mt_regen_wg(uint32_t* mt, int g) {
+    auto tw = [](uint32_t a, uint32_t b) -> uint32_t {
+        const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+        return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    };
+    static_assert(kXThr >= 227, "a step has up to 227 words");
+    uint32_t v = 0;
+    if (g < 227) v = mt[g + 397] ^ tw(mt[g], mt[g + 1]);
+    GX_BLOCK_SYNC();
+    if (g < 227) mt[g] = v;
+    GX_BLOCK_SYNC();
+    if (g < 227) v = mt[g] ^ tw(mt[g + 227], mt[g + 228]);
+    GX_BLOCK_SYNC();
+    if (g < 227) mt[g + 227] = v;
+    GX_BLOCK_SYNC();
+    if (g < 170) v = mt[g + 227] ^ tw(mt[g + 454], mt[(g + 455) % 624]);
+    GX_BLOCK_SYNC();
+    if (g < 170) mt[g + 454] = v;
+    GX_BLOCK_SYNC();
+}
+
 // All threads of the workgroup call this.  `flag`: this workgroup's contribution to the OR over the team (uniform over the
 // workgroup).  Returns the OR, or -1 when the team gave up (then everybody returns from the body at once).
 GX_DEVFN int gx_team_barrier(int g, XTile* L, const XTeam& tm, unsigned long long epoch, unsigned& nbar, bool flag) {
@@ -116,18 +153,17 @@ GX_DEVFN int gx_team_barrier(int g, XTile* L, const XTeam& tm, unsigned long lon
     GX_BLOCK_SYNC();   // ... and so are the workgroup's
     if (g == 0) {
         XTeamCtl* c = tm.ctl;
-        const unsigned slot = nbar & 3u;
-        if (flag) GX_G_ADD32(&c->flag[slot], 1u);
-        GX_TEAM_RELEASE();
-        GX_G_ADD64(&c->arrive, 1ull);
-        const unsigned long long target = (epoch + (unsigned long long)nbar + 1ull) * (unsigned long long)tm.W;
+        const unsigned slot = (unsigned)((epoch + (unsigned long long)nbar) & 3ull);
+        // one atomic per workgroup: arrival and flag together, so that whoever sees W arrivals sees every flag
+        GX_G_ADD64(&c->cnt[slot], 1ull + (flag ? (1ull << 32) : 0ull));
         int res = 0;
-        unsigned long long t0 = 0;
+        unsigned long long t0 = 0, v = 0;
         unsigned polls = 0;
         for (;;) {
-            if (GX_G_LOAD64(&c->arrive) >= target) break;
-            if (GX_G_LOAD32(&c->abort) != 0u) { res = -1; break; }
+            v = GX_G_LOAD64(&c->cnt[slot]);
+            if ((unsigned)(v & 0xFFFFFFFFull) >= (unsigned)tm.W) break;
             if ((++polls & 1023u) == 0u) {
+                if (GX_G_LOAD32(&c->abort) != 0u) { res = -1; break; }
                 const unsigned long long now = GX_WALL();
                 if (t0 == 0) t0 = now;
                 else if (now - t0 > kXSpinLimit) { GX_G_STORE32(&c->abort, 1u); res = -1; break; }
@@ -136,9 +172,10 @@ GX_DEVFN int gx_team_barrier(int g, XTile* L, const XTeam& tm, unsigned long lon
         }
         GX_TEAM_ACQUIRE();
         if (res == 0) {
-            res = GX_G_LOAD32(&c->flag[slot]) != 0u ? 1 : 0;
-            // the slot of barrier k + 2 (= of barrier k - 2: everybody read it before arriving at barrier k - 1)
-            if (tm.tw == 0) GX_G_STORE32(&c->flag[(slot + 2u) & 3u], 0u);
+            res = (v >> 32) != 0ull ? 1 : 0;
+            // the slot of barrier k + 2 (= of barrier k - 2: everybody left its loop before arriving at barrier k - 1, and nobody
+            // arrives at barrier k + 2 before this workgroup has arrived at k + 1, behind this store)
+            if (tm.tw == 0) GX_G_STORE64(&c->cnt[(slot + 2u) & 3u], 0ull);
         }
         L->team_res = res;
     }
@@ -224,13 +261,8 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
         }
     };
     uint32_t* mt = L->mt;
-    auto seek = [&](unsigned long long b) {  // (uniform) twist the generator forward to block b
-        if (blk_cur < b) {
-            if (w == 0)
-                for (unsigned long long k = blk_cur; k < b; k++) gx_mt_regen(mt, lane);
-            blk_cur = b;
-            GX_BLOCK_SYNC();
-        }
+    auto seek = [&](unsigned long long b) {  // (uniform) twist the generator forward to block b; every thread may read mt afterwards
+        for (; blk_cur < b; blk_cur++) gx_mt_regen_wg(mt, g);
     };
     look(0);
     fetch();
@@ -368,114 +400,6 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
             const int l = cnt < len ? cnt : len - 1;
             return L->sid[fr + l];
         };
-        // The resolve rounds inside the tile (gibbs_exact_wg.hpp, step 4): called after the first draw and again whenever the
-        // counts under the tile changed.  `rescan`: deltas of an earlier call may be in place although nobody moves any more (the
-        // tile's first mover was itself redrawn, which cannot happen inside one call): scan once even without movers.
-        auto resolve = [&](bool rescan) {
-            for (;;) {
-                const bool mv = mine && z_new != z_old;
-                const int z_ent = z_new;
-                const unsigned long long bm = GX_BALLOT(mv);
-                if (rd && lane == 0) L->mm[w] = bm;
-                unsigned h_fr = 0, h_to = 0;
-                if (mv) {
-                    auto enter = [&](int id, int dir) -> unsigned {
-                        unsigned h = gx_hash(id);
-                        for (;;) {
-                            int old = L->key[h];
-                            if (old == 0) old = GX_LDS_CAS32(&L->key[h], 0, id + 1);
-                            if (old == 0 || old == id + 1) break;
-                            h = (h + 1) & (kXKeys - 1);
-                        }
-                        GX_LDS_OR64(&L->ends[h][dir][w], 1ull << lane);
-                        const unsigned b = gx_bit(id);
-                        GX_LDS_OR64(&L->bits[b >> 6], 1ull << (b & 63));
-                        return h;
-                    };
-                    h_fr = enter(z_old, 1);
-                    h_to = enter(z_new, 0);
-                }
-                GX_BLOCK_SYNC();
-                bool any_moved = false;
-#pragma unroll
-                for (int q = 0; q < kXW; q++) any_moved = any_moved || L->mm[q] != 0ull;
-                if (!any_moved && !rescan) break;  // (uniform) the table is untouched and no delta is in place
-                rescan = false;
-                if (RSEM_GX_PROFILE) pa[8] += 1;
-                unsigned need = 0;
-                int dv[kXPlanes];
-                {
-                    unsigned long long bw[kXPlanes];
-#pragma unroll
-                    for (int u = 0; u < kXPlanes; u++) {
-                        const uint32_t j = (uint32_t)u * kXThr + g;
-                        const unsigned b = gx_bit(sj[u]);
-                        bw[u] = L->bits[b >> 6];
-                        dv[u] = (int)L->dl[j < T ? j : 0u];
-                    }
-#pragma unroll
-                    for (int u = 0; u < kXPlanes; u++) {
-                        const uint32_t j = (uint32_t)u * kXThr + g;
-                        if (j >= T) { bw[u] = 0ull; dv[u] = 0; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < kXPlanes; u++) {
-                        const unsigned b = gx_bit(sj[u]);
-                        if (((bw[u] >> (b & 63)) & 1ull) != 0ull || dv[u] != 0) need |= 1u << u;
-                    }
-                }
-                for (; need != 0u; need &= need - 1u) {
-                    const int u = __builtin_ctz(need);
-                    const uint32_t j = (uint32_t)u * kXThr + g;
-                    const int sv = L->sid[j];
-                    const int o = (int)L->ownr[j], ow = o >> 6;
-                    unsigned h = gx_hash(sv);
-                    int kv = L->key[h];
-                    while (kv != 0 && kv != sv + 1) {
-                        h = (h + 1) & (kXKeys - 1);
-                        kv = L->key[h];
-                    }
-                    int dd = 0;
-                    if (kv != 0) {
-                        const unsigned long long part = (1ull << (o & 63)) - 1ull;
-#pragma unroll
-                        for (int q = 0; q < kXW; q++) {
-                            const unsigned long long bef = q < ow ? ~0ull : (q == ow ? part : 0ull);
-                            dd += GX_POPC64(L->ends[h][0][q] & bef) - GX_POPC64(L->ends[h][1][q] & bef);
-                        }
-                    }
-                    if (dd != (int)L->dl[j]) {
-                        L->dl[j] = (int16_t)dd;
-                        GX_LDS_OR64(&L->dirty[ow], 1ull << (o & 63));
-                    }
-                }
-                GX_BLOCK_SYNC();
-                const bool dirty = rd && ((L->dirty[w] >> lane) & 1ull) != 0ull;
-                int z2 = z_new;
-                if (dirty) z2 = draw(std::true_type{});
-                const unsigned long long ch = GX_BALLOT(mine && z2 != z_new);
-                z_new = z2;
-                if (rd && lane == 0) L->chg[w] = ch;
-                GX_BLOCK_SYNC();
-                if (mv) {
-#pragma unroll
-                    for (int q = 0; q < kXW; q++) {
-                        L->ends[h_fr][0][q] = 0ull; L->ends[h_fr][1][q] = 0ull;
-                        L->ends[h_to][0][q] = 0ull; L->ends[h_to][1][q] = 0ull;
-                    }
-                    L->key[h_fr] = 0;
-                    L->key[h_to] = 0;
-                    L->bits[gx_bit(z_old) >> 6] = 0ull;
-                    L->bits[gx_bit(z_ent) >> 6] = 0ull;
-                }
-                if (rd && lane == 0) L->dirty[w] = 0ull;
-                bool any_changed = false;
-#pragma unroll
-                for (int q = 0; q < kXW; q++) any_changed = any_changed || L->chg[q] != 0ull;
-                GX_BLOCK_SYNC();
-                if (!any_changed) break;
-            }
-        };
         if (long_tile) {
             // thread 0 of workgroup 0 walks the read over global memory, two passes; nobody else has a tile in this window
             if (g == 0) {
@@ -532,90 +456,222 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
             look(win + 2);  // ... and the slot of the one after it
             if (mine) z_new = draw(std::false_type{});
             lap(3);
-            if (!kInit && nr > 0) resolve(false);
-            lap(4);
         }
-        // ---- the window: publish, take the earlier tiles' moves, repeat until nobody publishes --------------------------------------
-        if (!kInit && W > 1 && !win_long) {
-            for (;;) {
-                // publish what changed since the last time (z_pub: what this read has in the tables; z_old: nothing)
-                const bool ch = mine && z_new != z_pub;
-                if (ch) {
-                    cell_add(z_pub, -1);
-                    cell_add(z_new, 1);
-                    // a published move holds one reference on either endpoint
-                    if (z_pub == z_old) GX_G_ADD32(&tm.ref[z_old], 1);
-                    else GX_G_ADD32(&tm.ref[z_pub], -1);
-                    if (z_new == z_old) GX_G_ADD32(&tm.ref[z_old], -1);
-                    else GX_G_ADD32(&tm.ref[z_new], 1);
-                    z_pub = z_new;
-                }
-                const unsigned long long cb = GX_BALLOT(ch);
-                if (rd && lane == 0) L->pub[w] = cb;
-                GX_BLOCK_SYNC();
-                bool any_pub = false;
-#pragma unroll
-                for (int q = 0; q < kXW; q++) any_pub = any_pub || L->pub[q] != 0ull;
-                lap(5);
-                const int any = gx_team_barrier(g, L, tm, epoch, nbar, any_pub);
-                lap(6);
-                if (any < 0) return false;
-                if (any == 0) break;  // (uniform over the team) every tile is consistent with all earlier ones
-                if (RSEM_GX_PROFILE) pa[9] += 1;
-                if (tw > 0 && nr > 0) {  // (uniform over the workgroup)
-                    // X of every item: the cells of the earlier workgroups, only where the id holds a reference.  All loads are
-                    // issued whether needed or not (an item that needs none reads row M + 1, which nobody writes): no load waits
-                    // for a decision.
+        // ---- the phases of a window ---------------------------------------------------------------------------------------------------
+        // A phase = take what the EARLIER tiles of the window published (not in the first phase), one resolve round inside the tile
+        // (gibbs_exact_wg.hpp, step 4: the movers enter their endpoints, every item gets the delta of the earlier reads of the
+        // tile), ONE redraw of every read whose counts changed either way, publish what changed, team barrier.  The window is done
+        // after a phase in which no draw of any tile changed: every read is then consistent with the moves of all earlier reads of
+        // the tile and of all earlier tiles.  (The rounds inside a tile are not run to their own fixed point first: a tile that
+        // needs a second round would keep 31 others waiting at the barrier, and the window needs a second phase anyway.)
+        if (!kInit && !win_long) {
+            bool dl_live = false;      // (uniform) deltas of an earlier round may be in place
+            bool z_moved = true;       // (uniform) some draw of the tile changed since its last round (the first draw counts)
+            for (int phase = 0;; phase++) {
+                // -- X of every item: the cells of the earlier workgroups (see the head of the file) --------------------------------------
+                if (phase > 0 && tw > 0 && nr > 0) {  // (uniform over the workgroup)
                     int rf[kXPlanes];
 #pragma unroll
                     for (int u = 0; u < kXPlanes; u++) rf[u] = GX_G_LOAD32(&tm.ref[sj[u]]);
-                    // (kXStep items at a time: 5 loads each in flight together, and no more registers than that)
+                    // All loads of a step are issued whether needed or not (an item that needs none reads row M + 1, which nobody
+                    // writes): no load waits for a decision.  Words that hold no earlier workgroup's cell are not loaded at all.
+                    auto take = [&](auto n_words, auto with_groups) {
+                        constexpr int NQ = decltype(n_words)::value;
+                        constexpr bool kG = decltype(with_groups)::value;
 #pragma unroll
-                    for (int u0 = 0; u0 < kXPlanes; u0 += kXStep) {
-                        unsigned long long vn[kXStep][4], vg[kXStep];
+                        for (int u0 = 0; u0 < kXPlanes; u0 += kXStep) {
+                            unsigned long long vn[kXStep][NQ > 0 ? NQ : 1], vg[kXStep];
 #pragma unroll
-                        for (int i = 0; i < kXStep; i++) {
-                            const int u = u0 + i;
-                            const uint32_t j = (uint32_t)u * kXThr + g;
-                            const size_t row = (j < T && rf[u] != 0) ? (size_t)sj[u] : dummy_row;
-                            const unsigned long long* pn = (const unsigned long long*)(tm.net + row * tm.nw + (size_t)grp * 8);
-                            const unsigned long long* pg = (const unsigned long long*)(tm.gnet + row * 2);
+                            for (int i = 0; i < kXStep; i++) {
+                                const int u = u0 + i;
+                                const uint32_t j = (uint32_t)u * kXThr + g;
+                                const size_t row = (j < T && rf[u] != 0) ? (size_t)sj[u] : dummy_row;
+                                const unsigned long long* pn = (const unsigned long long*)(tm.net + row * tm.nw + (size_t)grp * 8);
+                                const unsigned long long* pg = (const unsigned long long*)(tm.gnet + row * 2);
 #pragma unroll
-                            for (int q = 0; q < 4; q++) vn[i][q] = GX_G_LOAD64(pn + q);
-                            vg[i] = GX_G_LOAD64(pg);
-                        }
+                                for (int q = 0; q < NQ; q++) vn[i][q] = GX_G_LOAD64(pn + q);
+                                vg[i] = kG ? GX_G_LOAD64(pg) : 0ull;
+                            }
 #pragma unroll
-                        for (int i = 0; i < kXStep; i++) {
-                            const int u = u0 + i;
-                            const uint32_t j = (uint32_t)u * kXThr + g;
-                            int x = swar(vg[i] & m_g) - bias_total;
+                            for (int i = 0; i < kXStep; i++) {
+                                const int u = u0 + i;
+                                const uint32_t j = (uint32_t)u * kXThr + g;
+                                int x = (kG ? swar(vg[i] & m_g) : 0) - bias_total;
 #pragma unroll
-                            for (int q = 0; q < 4; q++) x += swar(vn[i][q] & m_net[q]);
-                            if (j < T && x != xc[u]) {
-                                L->c[j] += x - xc[u];
-                                xc[u] = x;
-                                const int o = (int)L->ownr[j];
-                                GX_LDS_OR64(&L->dirty[o >> 6], 1ull << (o & 63));
+                                for (int q = 0; q < NQ; q++) x += swar(vn[i][q] & m_net[q]);
+                                if (j < T && x != xc[u]) {
+                                    L->c[j] += x - xc[u];
+                                    xc[u] = x;
+                                    const int o = (int)L->ownr[j];
+                                    GX_LDS_OR64(&L->dirty[o >> 6], 1ull << (o & 63));
+                                }
                             }
                         }
+                    };
+                    using Y = std::true_type;
+                    using N = std::false_type;
+                    const int nq = (tw - grp * 16 + 3) >> 2;  // words of my group of 16 that hold an earlier workgroup's cell (0 .. 4)
+                    switch (nq * 2 + (grp > 0 ? 1 : 0)) {      // (uniform)
+                        case 1: take(std::integral_constant<int, 0>{}, Y{}); break;
+                        case 2: take(std::integral_constant<int, 1>{}, N{}); break;
+                        case 3: take(std::integral_constant<int, 1>{}, Y{}); break;
+                        case 4: take(std::integral_constant<int, 2>{}, N{}); break;
+                        case 5: take(std::integral_constant<int, 2>{}, Y{}); break;
+                        case 6: take(std::integral_constant<int, 3>{}, N{}); break;
+                        case 7: take(std::integral_constant<int, 3>{}, Y{}); break;
+                        case 8: take(std::integral_constant<int, 4>{}, N{}); break;
+                        default: take(std::integral_constant<int, 4>{}, Y{}); break;
                     }
-                    GX_BLOCK_SYNC();  // the corrected counts and the marks are in place
                     lap(10);
+                }
+                // -- one resolve round inside the tile ----------------------------------------------------------------------------------
+                bool any_changed = false;
+                if (nr > 0 && !z_moved) {  // (uniform) no draw of the tile changed since its last round: every delta inside the tile stands
+                    GX_BLOCK_SYNC();       // the corrected counts and the marks of the look-ups above are in place
                     const bool dirty = rd && ((L->dirty[w] >> lane) & 1ull) != 0ull;
                     int z2 = z_new;
                     if (dirty) z2 = draw(std::true_type{});
-                    const unsigned long long c2 = GX_BALLOT(mine && z2 != z_new);
+                    const unsigned long long ch = GX_BALLOT(mine && z2 != z_new);
                     z_new = z2;
-                    if (rd && lane == 0) L->chg[w] = c2;
+                    if (rd && lane == 0) L->chg[w] = ch;
                     GX_BLOCK_SYNC();
                     if (rd && lane == 0) L->dirty[w] = 0ull;
-                    bool any_changed = false;
 #pragma unroll
                     for (int q = 0; q < kXW; q++) any_changed = any_changed || L->chg[q] != 0ull;
-                    GX_BLOCK_SYNC();  // (chg may be rewritten; the marks are cleared)
+                    z_moved = any_changed;
                     lap(11);
-                    if (any_changed) resolve(true);  // draws changed: the deltas inside the tile follow
-                    lap(12);
+                } else if (nr > 0) {  // (uniform)
+                    const bool mv = mine && z_new != z_old;
+                    const int z_ent = z_new;
+                    const unsigned long long bm = GX_BALLOT(mv);
+                    if (rd && lane == 0) L->mm[w] = bm;
+                    unsigned h_fr = 0, h_to = 0;
+                    if (mv) {
+                        auto enter = [&](int id, int dir) -> unsigned {
+                            unsigned h = gx_hash(id);
+                            for (;;) {
+                                int old = L->key[h];
+                                if (old == 0) old = GX_LDS_CAS32(&L->key[h], 0, id + 1);
+                                if (old == 0 || old == id + 1) break;
+                                h = (h + 1) & (kXKeys - 1);
+                            }
+                            GX_LDS_OR64(&L->ends[h][dir][w], 1ull << lane);
+                            const unsigned b = gx_bit(id);
+                            GX_LDS_OR64(&L->bits[b >> 6], 1ull << (b & 63));
+                            return h;
+                        };
+                        h_fr = enter(z_old, 1);
+                        h_to = enter(z_new, 0);
+                    }
+                    GX_BLOCK_SYNC();  // the endpoints are entered (and the corrected counts and marks of the look-ups above are in place)
+                    bool any_moved = false;
+#pragma unroll
+                    for (int q = 0; q < kXW; q++) any_moved = any_moved || L->mm[q] != 0ull;
+                    if (any_moved || dl_live) {  // (uniform) otherwise the table is empty and every delta is zero
+                        if (RSEM_GX_PROFILE) pa[8] += 1;
+                        unsigned need = 0;
+                        int dv[kXPlanes];
+                        {
+                            unsigned long long bw[kXPlanes];
+#pragma unroll
+                            for (int u = 0; u < kXPlanes; u++) {
+                                const uint32_t j = (uint32_t)u * kXThr + g;
+                                const unsigned b = gx_bit(sj[u]);
+                                bw[u] = L->bits[b >> 6];
+                                dv[u] = (int)L->dl[j < T ? j : 0u];
+                            }
+#pragma unroll
+                            for (int u = 0; u < kXPlanes; u++) {
+                                const uint32_t j = (uint32_t)u * kXThr + g;
+                                if (j >= T) { bw[u] = 0ull; dv[u] = 0; }
+                            }
+#pragma unroll
+                            for (int u = 0; u < kXPlanes; u++) {
+                                const unsigned b = gx_bit(sj[u]);
+                                if (((bw[u] >> (b & 63)) & 1ull) != 0ull || dv[u] != 0) need |= 1u << u;
+                            }
+                        }
+                        for (; need != 0u; need &= need - 1u) {
+                            const int u = __builtin_ctz(need);
+                            const uint32_t j = (uint32_t)u * kXThr + g;
+                            const int sv = L->sid[j];
+                            const int o = (int)L->ownr[j], ow = o >> 6;
+                            unsigned h = gx_hash(sv);
+                            int kv = L->key[h];
+                            while (kv != 0 && kv != sv + 1) {
+                                h = (h + 1) & (kXKeys - 1);
+                                kv = L->key[h];
+                            }
+                            int dd = 0;
+                            if (kv != 0) {
+                                const unsigned long long part = (1ull << (o & 63)) - 1ull;
+#pragma unroll
+                                for (int q = 0; q < kXW; q++) {
+                                    const unsigned long long bef = q < ow ? ~0ull : (q == ow ? part : 0ull);
+                                    dd += GX_POPC64(L->ends[h][0][q] & bef) - GX_POPC64(L->ends[h][1][q] & bef);
+                                }
+                            }
+                            if (dd != (int)L->dl[j]) {
+                                L->dl[j] = (int16_t)dd;
+                                GX_LDS_OR64(&L->dirty[ow], 1ull << (o & 63));
+                            }
+                        }
+                        GX_BLOCK_SYNC();  // every delta of this round is in place
+                    }
+                    dl_live = any_moved;
+                    lap(4);
+                    const bool dirty = rd && ((L->dirty[w] >> lane) & 1ull) != 0ull;
+                    int z2 = z_new;
+                    if (dirty) z2 = draw(std::true_type{});
+                    const unsigned long long ch = GX_BALLOT(mine && z2 != z_new);
+                    z_new = z2;
+                    if (rd && lane == 0) L->chg[w] = ch;
+                    GX_BLOCK_SYNC();  // every thread has read its mark (and the look-ups were finished a barrier ago)
+                    if (mv) {          // leave the table as it was found: all zero
+#pragma unroll
+                        for (int q = 0; q < kXW; q++) {
+                            L->ends[h_fr][0][q] = 0ull; L->ends[h_fr][1][q] = 0ull;
+                            L->ends[h_to][0][q] = 0ull; L->ends[h_to][1][q] = 0ull;
+                        }
+                        L->key[h_fr] = 0;
+                        L->key[h_to] = 0;
+                        L->bits[gx_bit(z_old) >> 6] = 0ull;
+                        L->bits[gx_bit(z_ent) >> 6] = 0ull;
+                    }
+                    if (rd && lane == 0) L->dirty[w] = 0ull;
+#pragma unroll
+                    for (int q = 0; q < kXW; q++) any_changed = any_changed || L->chg[q] != 0ull;
+                    z_moved = any_changed;
+                    lap(11);
+                }
+                // -- publish what changed since the last time (z_pub: what this read has in the tables; z_old: nothing) -------------------
+                bool flag = any_changed;
+                if (W > 1) {
+                    const bool ch = mine && z_new != z_pub;
+                    if (ch) {
+                        cell_add(z_pub, -1);
+                        cell_add(z_new, 1);
+                        // a published move holds one reference on either endpoint
+                        if (z_pub == z_old) GX_G_ADD32(&tm.ref[z_old], 1);
+                        else GX_G_ADD32(&tm.ref[z_pub], -1);
+                        if (z_new == z_old) GX_G_ADD32(&tm.ref[z_old], -1);
+                        else GX_G_ADD32(&tm.ref[z_new], 1);
+                        z_pub = z_new;
+                    }
+                    const unsigned long long cb = GX_BALLOT(ch);
+                    if (rd && lane == 0) L->pub[w] = cb;
+                    GX_BLOCK_SYNC();  // (also: the table is clean again, chg / mm may be rewritten)
+#pragma unroll
+                    for (int q = 0; q < kXW; q++) flag = flag || L->pub[q] != 0ull;
+                    lap(5);
+                    const int any = gx_team_barrier(g, L, tm, epoch, nbar, flag);
+                    lap(6);
+                    if (any < 0) return false;
+                    if (RSEM_GX_PROFILE) pa[9] += 1;
+                    if (any == 0) break;  // (uniform over the team) no draw of any tile changed in this phase
+                } else {
+                    GX_BLOCK_SYNC();  // the table is clean again (and chg / mm may be rewritten)
+                    if (!flag) break;
                 }
             }
         }

@@ -57,13 +57,14 @@
 
 constexpr int kXW = 4;           // waves of READS per tile
 constexpr int kXT = 64 * kXW;    // reads per tile = the threads that own a read
-// Threads of the workgroup.  512 (the product since round 5): the first four waves own a read each thread, the other four own
-// none and share the item-major phases (staging, gather, filter scan, look-ups) -- two waves per SIMD, so that one wave's
-// dependent instructions (~16 cycles each with a SIMD to itself) overlap the other's: 0.068 us per read visit against 0.083
-// with 256 threads (profiles/r04u_call.log).  -DRSEM_GX_THREADS=256: every thread owns a read and 16 of the tile's items
-// (rounds 3-4's product).  The emulator runs both (tests/test_gibbs_exact_emu_cpu.py).
+// Threads of the workgroup.  256 (the product): every thread owns a read and 16 of the tile's items.  -DRSEM_GX_THREADS=512: the
+// first four waves own a read each thread, the other four own none and share the item-major phases (staging, gather, filter
+// scan, look-ups) -- two waves per SIMD, so that one wave's dependent instructions (~16 cycles each with a SIMD to itself)
+// overlap the other's: 0.065 us per read visit against 0.079 with ONE workgroup per chain (profiles/r04u_call.log,
+// r05b_team_profile.log), but 119 against 105 ms per round for the teams of gibbs_exact_team.hpp (more waves at every barrier),
+// which is what runs whenever the device has compute units to spare.  The emulator runs both (tests/test_gibbs_exact_emu_cpu.py).
 #ifndef RSEM_GX_THREADS
-#define RSEM_GX_THREADS 512
+#define RSEM_GX_THREADS 256
 #endif
 constexpr int kXThr = RSEM_GX_THREADS;
 static_assert(kXThr == kXT || kXThr == 2 * kXT, "256 or 512 threads per chain");

@@ -148,14 +148,16 @@ int main(int argc, char* argv[]) {
     // of a GPU advancing together; parallel = the data-augmentation sampler for the same posterior (every sweep fills
     // the GPU; the chains of a GPU run one after the other).
     int mode;
-    // auto (the default): the reference's own chains (exact) unless they would take more than kAutoExactLimitS here.  A chain
-    // is a workgroup and costs about kExactCyclesPerVisit shader cycles per read visit whatever the number of chains, up to
-    // one per compute unit (0.068 us at BASELINE configs[2]'s shape on a 2.4 GHz MI355X); clock and
-    // compute units are the device's own (rsem_hip_device_info), so the estimate is rounds x reads x cycles / clock x
-    // ceil(chains per GPU / CUs).  The choice is printed and recorded in <statName>.gibbs_sampler; --gibbs-mode exact /
-    // parallel overrule it.  Above the limit the DEFAULT outputs are therefore not the reference's chains (same posterior,
-    // a different Markov chain): INTEGRATION.md says so, and so does the program, on stdout and stderr.
-    constexpr double kExactCyclesPerVisit = 165.0, kAutoExactLimitS = 900.0;
+    // auto (the default): the reference's own chains (exact) unless they would take more than kAutoExactLimitS here.  A chain is
+    // advanced by a team of W = min(64, compute units / chains of the GPU) workgroups (gibbs_exact_team.hpp); a read visit costs
+    // about kTeamCyclesBase + kTeamCyclesPerW / W shader cycles per chain (measured at BASELINE configs[2]'s
+    // shape on a 2.4 GHz MI355X: 0.0146 us with W = 32, 0.019 with 16, 0.028 with 8, 0.047 with 4) and kExactCyclesPerVisit with
+    // one workgroup per chain (more chains than half the compute units); clock and compute units are the device's own
+    // (rsem_hip_device_info).  The choice is printed and recorded in <statName>.gibbs_sampler; --gibbs-mode exact / parallel
+    // overrule it.  Above the limit the DEFAULT outputs are not the reference's chains (same posterior, a different Markov
+    // chain): INTEGRATION.md says so, and so does the program, on stdout and stderr.
+    constexpr double kTeamCyclesBase = 27.0, kTeamCyclesPerW = 315.0;
+    constexpr double kExactCyclesPerVisit = 195.0, kAutoExactLimitS = 900.0;
     int64_t dev_cus = 256, dev_khz = 2400000;
     if (!dry_run) {
         (void)rsem_hip_device_info(devs[0], "compute_units", &dev_cus);
@@ -165,7 +167,10 @@ int main(int argc, char* argv[]) {
     }
     const int rounds_per_chain = BURNIN + 1 + ((NSAMPLES + nThreads - 1) / nThreads - 1) * GAP;
     const int chains_per_gpu = (nThreads + nworkers - 1) / nworkers;
-    const double us_per_visit = kExactCyclesPerVisit / ((double)dev_khz * 1e-3);
+    int team_w = (int)std::min<int64_t>(64, dev_cus / std::max(1, chains_per_gpu));
+    if (team_w < 8) team_w = 1;  // (gibbs.hip: smaller teams do not pay)
+    const double cycles_per_visit = team_w > 1 ? kTeamCyclesBase + kTeamCyclesPerW / (double)team_w : kExactCyclesPerVisit;
+    const double us_per_visit = cycles_per_visit / ((double)dev_khz * 1e-3);
     const double est_exact_s = (double)rounds_per_chain * (double)N1 * us_per_visit * 1e-6 * (double)((chains_per_gpu + dev_cus - 1) / dev_cus);
     if (mode_s == "exact") mode = RSEM_GIBBS_EXACT;
     else if (mode_s == "parallel") mode = RSEM_GIBBS_PARALLEL;

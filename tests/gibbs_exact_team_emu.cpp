@@ -150,7 +150,6 @@ int main(int argc, char** argv) {
                 for (size_t i = 0; i < net.size(); i++) if (net[i] != (kXBias | (kXBias << 16))) failed = 2;
                 for (size_t i = 0; i < gnet.size(); i++) if (gnet[i] != (kXBias | (kXBias << 16))) failed = 2;
                 for (size_t i = 0; i < ref.size(); i++) if (ref[i] != 0) failed = 2;
-                if (ctl.epoch * (unsigned long long)W != ctl.arrive) failed = 3;
                 if (round >= 1)
                     fprintf(stderr, "sweep %d: %u windows, %llu team barriers\n", round, n_win, ctl.epoch - bars_before);
                 bars_before = ctl.epoch;
@@ -162,7 +161,7 @@ int main(int argc, char** argv) {
     for (int k = 0; k < W; k++)
         for (int t = 0; t < kXThr; t++) th.emplace_back(thread_main, k, t);
     for (auto& t : th) t.join();
-    if (failed) { fprintf(stderr, "gibbs_exact_team_emu: failure %d (1: the team gave up, 2: tables not clean after a sweep, 3: barrier count)\n", failed.load()); return 3; }
+    if (failed) { fprintf(stderr, "gibbs_exact_team_emu: failure %d (1: the team gave up, 2: tables not clean after a sweep)\n", failed.load()); return 3; }
     FILE* g = fopen(argv[2], "wb");
     if (!g) { perror(argv[2]); return 2; }
     fwrite(out.data(), 4, out.size(), g);

@@ -32,10 +32,9 @@ def emulator(tmp_path_factory):
 
 
 @pytest.fixture(scope="module")
-def emulator_256(tmp_path_factory):
-    """the variant with 256 threads per chain (gibbs_exact_wg.hpp: RSEM_GX_THREADS; the product has 512: four more waves that
-    own no read)"""
-    return _build(tmp_path_factory, "gibbs_exact_emu_256", ["-DRSEM_GX_THREADS=256"])
+def emulator_512(tmp_path_factory):
+    """the variant with 512 threads per chain (gibbs_exact_wg.hpp: RSEM_GX_THREADS): four more waves that own no read"""
+    return _build(tmp_path_factory, "gibbs_exact_emu_512", ["-DRSEM_GX_THREADS=512"])
 
 
 def _items(seed, M, N1, maxlen, noise_scale, long_read=0):
@@ -108,8 +107,8 @@ def test_workgroup_chain_is_the_reference_chain(emulator, case):
 
 
 @pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[5], CASES[6]], ids=lambda c: "seed%d" % c["seed"])
-def test_workgroup_chain_with_256_threads_is_the_reference_chain(emulator_256, case):
-    test_workgroup_chain_is_the_reference_chain(emulator_256, case)
+def test_workgroup_chain_with_512_threads_is_the_reference_chain(emulator_512, case):
+    test_workgroup_chain_is_the_reference_chain(emulator_512, case)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 4, 5, 6])

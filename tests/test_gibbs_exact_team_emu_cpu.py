@@ -27,12 +27,12 @@ def _build(tmp_path_factory, name, defs):
 
 @pytest.fixture(scope="module")
 def team_256(tmp_path_factory):
-    return _build(tmp_path_factory, "gibbs_exact_team_emu_256", ["-DRSEM_GX_THREADS=256"])
+    return _build(tmp_path_factory, "gibbs_exact_team_emu_256", [])  # the product's workgroup: 256 threads
 
 
 @pytest.fixture(scope="module")
 def team_512(tmp_path_factory):
-    return _build(tmp_path_factory, "gibbs_exact_team_emu_512", [])  # the product's workgroup: 512 threads
+    return _build(tmp_path_factory, "gibbs_exact_team_emu_512", ["-DRSEM_GX_THREADS=512"])
 
 
 def _run(exe, W, M, rp, sid, cp, init, rounds, seed, N0, pseudoC):
@@ -81,3 +81,31 @@ def test_wide_teams_and_the_group_cells(team_256, W):
     _check(team_256, W, CASES[1])
 
 
+
+
+@pytest.mark.parametrize("seed", [1, 2, 4, 5, 6])
+def test_a_predecessor_that_moves_back(team_256, seed):
+    """the three reads of test_gibbs_exact_emu_cpu.py's test of the same name: a delta must be dropped although none of the
+    read's predecessors moves any more -- here the round that drops it is a phase of the window's loop"""
+    M = 4
+    rp = np.array([0, 3, 6, 9], np.uint64)
+    sid = np.array([0, 1, 2, 0, 2, 3, 0, 3, 4], np.int32)
+    cp = np.array([1e-9, 1.0, 1.0, 1e-9, 1.0, 1.0, 1e-9, 1.0, 1.0])
+    init = np.zeros(M + 1, np.int32)
+    got, _ = _run(team_256, 1, M, rp, sid, cp, init, 40, seed, 0, 0.05)
+    assert np.array_equal(got, _oracle(M, rp, sid, cp, init, 40, seed, 0, 0.05))
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_single_read_tiles_across_a_team(team_256, seed):
+    """reads of 3000 items: one read per tile, so every dependence between reads is a dependence between TILES -- the chain
+    A -> B -> C of the test above played across workgroups (a published move taken back by a later phase)"""
+    rng = np.random.default_rng(seed)
+    M, N1, k = 6, 9, 3000
+    rp = (np.arange(N1 + 1) * k).astype(np.uint64)
+    sid = rng.integers(0, M + 1, N1 * k).astype(np.int32)
+    cp = 10.0 ** rng.uniform(-2, 0, N1 * k)
+    init = np.zeros(M + 1, np.int32)
+    for W in (2, 4):
+        got, _ = _run(team_256, W, M, rp, sid, cp, init, 12, seed, 0, 0.05)
+        assert np.array_equal(got, _oracle(M, rp, sid, cp, init, 12, seed, 0, 0.05))
