@@ -217,15 +217,17 @@ def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True):
             try:  # the reference itself on these very files (same generator, same seed), measured once in round 4: profiles/
                 with open(os.path.join(ROOT, "profiles", "e2e_full_size_reference.json")) as f:
                     mref = json.load(f)
-                if config == "C3" and fh == 560141751:
+                if config == "C3" and ("%d alignments" % fh).replace(",", "") in mref["workload"].replace(",", ""):  # the very files of the recording
                     r = mref["reference"]
                     e2e["full_size"].update({
                         "reference_s": r["wall_s_measured"], "reference_rounds": r["rounds"], "reference_measured_in": mref["source"],
                         "reference_conditions": r["conditions"],
                         "reference_s_undisturbed": r["wall_s_if_all_late_rounds_at_the_undisturbed_rate"],
                         "same_round_count_as_the_reference": new_rounds == r["rounds"],
-                        "speedup": r["wall_s_measured"] / new_wall,
-                        "speedup_against_undisturbed_reference": r["wall_s_if_all_late_rounds_at_the_undisturbed_rate"] / new_wall,
+                        "speedup_vs_recorded_reference": r["wall_s_measured"] / new_wall,
+                        "speedup_vs_recorded_reference_undisturbed": r["wall_s_if_all_late_rounds_at_the_undisturbed_rate"] / new_wall,
+                        "recorded_reference_note": "the reference's time is a RECORDING (round 4, another session and host state: reference_measured_in); "
+                                                   "only `measured.speedup` above divides two times of this run",
                         "parity_full_size_recorded": mref["parity_full_size"]})
             except Exception:
                 pass
@@ -399,8 +401,8 @@ def em_leg(capi, make_em_workload, config, K, W, kernel, sync, device, q32=False
         phys = physical(ctx, estep_ms, pmc_traffic_of(config, scale, kernel)[0])
         out = {"workload": "%s%s: %d reads x %d transcripts, %d alignments" % (WORKLOADS.get(config, config), "" if scale == 1.0 else " at %g of its reads" % scale, N1, M, nnz),
                "ms_per_step": el * 1e3 / rounds, "timed_rounds": rounds, "timed_region_s": el, "value": nnz * rounds / el,
-               "estep_avg_launch_ms": estep_ms, "algorithmic_bytes_per_launch": alg, "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS,
-               "frac_physical": phys.get("frac_physical"), "physical": phys,
+               "estep_avg_launch_ms": estep_ms, "algorithmic_bytes_per_launch": alg, "achieved_algorithmic_GBps": ach, "frac_algorithmic": ach / HBM_PEAK_GBPS,
+               "frac": phys.get("frac_physical"), "frac_physical": phys.get("frac_physical"), "physical": phys,
                "theta_sum": ts, "generate_s": gen_s, "parity_one_step": one_step_parity(ctx, wl),
                "units_with_ids_outside_their_window": far_units(ctx), "split_rows": split_info(ctx)}
         if q32 and kernel in (0, 3):
@@ -429,7 +431,7 @@ def main():
     ap.add_argument("--no-ci", action="store_true")
     ap.add_argument("--no-stream", action="store_true", help="skip the device STREAM probe beside the roofline")
     ap.add_argument("--gibbs-sweeps", type=int, default=30)
-    ap.add_argument("--gibbs-exact-rounds", type=int, default=3, help="rounds of the exact (reference) chain timed in the Gibbs leg (>= 2)")
+    ap.add_argument("--gibbs-exact-rounds", type=int, default=6, help="rounds of the exact (reference) chain timed in the Gibbs leg (>= 2)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -592,7 +594,13 @@ def main():
                                   "sweeps_per_s_all_gpus": world * 1e3 / sw if sw > 0 else None,
                                   "items_per_s_all_gpus": world * len(isid) * 1e3 / sw if sw > 0 else None,
                                   "final_reduce_ms": max(r[1] for r in per_rank) if distributed else None},
-                     "exact": {"mode": "reference chain (bit-identical draws), %d chains per GPU advancing together, one workgroup of 4 waves per chain" % n_exact,
+                     "exact": {"mode": "reference chain (bit-identical draws), %d chains per GPU advancing together, a team of %d workgroups per chain "
+                                       "(k_gibbs_exact_team: the tiles of a window at once)" % (n_exact, pe.team),
+                               "workgroups_per_chain": pe.team,
+                               "scaling_note": "chains are dealt to the GPUs (chain k on rank k % N); a chain's team grows with the compute units its GPU has "
+                                               "to spare -- min(64, CUs / chains of the GPU) -- so this leg keeps 8 chains PER GPU (weak scaling); 8 chains "
+                                               "in all on N GPUs would run 8 / N chains per GPU with larger teams (1 chain, 64 workgroups: 56 ms against "
+                                               "97 ms per round at a fifth of this size, profiles/r05e_*)",
                                "ms_per_round": ex, "ms_per_round_per_rank": [r[2] for r in per_rank], "chains_per_gpu": n_exact,
                                "rounds_timed": args.gibbs_exact_rounds,
                                "us_per_read_visit_and_chain": ex * 1e3 / N1 if N1 else None,
@@ -626,6 +634,7 @@ def main():
                           "(copy, read + written bytes counted), best of 5 launches, HIP events, in this process right after the timed region"}
             except Exception as e:
                 stream = {"error": str(e)}
+        phys_achieved = (phys_headline.get("frac_physical") or 0.0) * HBM_PEAK_GBPS
         line = {
             "metric": "EM read-alignments/s (nnz x EM iterations per second), rsem-run-em theta-only rounds",
             "value": total_nnz * rounds / elapsed, "unit": "read-alignments/s",
@@ -638,15 +647,17 @@ def main():
                        "value_plane_bytes": value_plane_bytes,
                        "units_with_ids_outside_their_window": units_far,
                        "parallelism": "1 GPU" if world == 1 else "read-sharded x%d + RCCL all-reduce(M+1 f64)/round from C++ on the EM stream" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"bound": "hbm", "achieved": phys_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": phys_achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_estep_lane (E step)", "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "achieved / frac use the ALGORITHMIC bytes of SURVEY.md 8(d) (12 B per alignment + 16 B per read + 16 B per transcript); "
-                                 "the kernel physically moves fewer: it re-uses a tuple's transcript ids from registers instead of re-reading them and "
-                                 "needs no row pointers, so frac can pass 1.  frac_physical = the bytes the layout of THIS run moves by construction "
-                                 "(physical.parts, from rsem_em_get_info) / this run's launch time / peak: the roofline fraction proper.  `traffic` = the "
-                                 "committed rocprofv3 PMC measurement of the same workload (cannot be taken inside this process); physical_over_pmc "
-                                 "says how well the two agree",
+                         "achieved_algorithmic": achieved, "frac_algorithmic": achieved / HBM_PEAK_GBPS,
+                         "note": "achieved / frac = the bytes the layout of THIS run moves per launch by construction (physical.parts, from "
+                                 "rsem_em_get_info; within 0.3 % of the rocprofv3 PMC counters on every config measured: physical_over_pmc) / this "
+                                 "run's average launch time (HIP events on the kernel's stream) / peak: at most 1 by construction.  "
+                                 "achieved_algorithmic / frac_algorithmic use the ALGORITHMIC bytes of SURVEY.md 8(d) (12 B per alignment + 16 B per "
+                                 "read + 16 B per transcript) over the same launch time; the layout moves fewer (a tuple's transcript ids are re-used "
+                                 "from registers, there are no row pointers), so that fraction can pass 1.  `traffic` = the committed rocprofv3 PMC "
+                                 "measurement of the same workload (counter passes cannot run inside this process)",
                          "frac_physical": phys_headline.get("frac_physical"), "physical": phys_headline,
                          "avg_launch_ms": estep_ms, "step_over_launch": elapsed * 1e3 / rounds / estep_ms,
                          # the same launch time against the bytes the kernel physically moved (PMC) and against what a plain

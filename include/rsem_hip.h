@@ -263,6 +263,8 @@ typedef struct {
     double sweep_ms;   /* total_ms / sweeps */
     int64_t sweeps;    /* EXACT: rounds (every chain advances in each); PARALLEL: z passes summed over the chains */
     int32_t chains;
+    int32_t team;      /* EXACT: workgroups per chain (k_gibbs_exact_team; 1 = one workgroup per chain); 0 otherwise.  (Sits in what
+                        * was padding: the layout of the other fields is unchanged.) */
     double reduce_ms;  /* the ONE collective of the multi-GPU split (reduce of the chain sums to rank 0), 0 without a communicator */
 } rsem_gibbs_profile;
 

@@ -33,7 +33,7 @@ class CiProfile(C.Structure):
 
 
 class GibbsProfile(C.Structure):
-    _fields_ = [("total_ms", C.c_double), ("sweep_ms", C.c_double), ("sweeps", C.c_int64), ("chains", C.c_int32), ("reduce_ms", C.c_double)]
+    _fields_ = [("total_ms", C.c_double), ("sweep_ms", C.c_double), ("sweeps", C.c_int64), ("chains", C.c_int32), ("team", C.c_int32), ("reduce_ms", C.c_double)]
 
 
 class EmProfile(C.Structure):

@@ -1196,6 +1196,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
     };
 
     long long sweeps = 0;
+    int team_used = 0;  // EXACT: workgroups per chain
     RSEM_HIP_TRY(hipEventRecord(ev.a, st));
     if (exact) {
         // all chains advance together, one wave each (Gibbs.cpp:207-254: the reference's threads)
@@ -1270,6 +1271,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             ta.M = c->M;
             if (getenv("RSEM_GX_VERBOSE")) fprintf(stderr, "[gibbs exact] teams of %d workgroups per chain, %u windows per sweep\n", W, c->n_win);
         }
+        team_used = W;
         int mt_flip = 0;  // which half of mts holds the chains' generators
         hipError_t team_err = hipSuccess;
         auto sweep_team = [&](bool init, int round) {
@@ -1452,6 +1454,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         prof->sweeps = sweeps;
         prof->sweep_ms = sweeps ? ms / (double)sweeps : 0.0;
         prof->chains = nchains;
+        prof->team = team_used;
         prof->reduce_ms = 0.0;
         if (reduce) {
             float rms = 0.f;

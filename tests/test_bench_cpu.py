@@ -60,7 +60,7 @@ class FakeComm:
     def close(self): pass
 capi.Comm = FakeComm
 class GP:
-    def __init__(self, sweep, red): self.sweep_ms, self.reduce_ms = sweep, red
+    def __init__(self, sweep, red): self.sweep_ms, self.reduce_ms, self.team = sweep, red, 32
 class FakeGibbs:
     def __init__(self, *a, **k): pass
     def set_comm(self, c): pass
@@ -95,6 +95,9 @@ def test_bench_main_prints_one_contract_line():
     assert "frac_of_traffic" in d["roofline"]
     # the roofline fraction the run can vouch for: the layout's own bytes over its own launch time, on the headline AND every leg
     assert d["roofline"]["frac_physical"] == 1500 / 1e-3 / 1e9 / 8000.0 and d["roofline"]["physical"]["parts"]["sid_planes_loaded"] == 100
+    # the contract's fraction is the physical one (never above 1 for a kernel that moves what its layout says); the formula's sits beside it
+    assert d["roofline"]["frac"] == d["roofline"]["frac_physical"] and d["roofline"]["achieved"] == d["roofline"]["frac"] * 8000.0
+    assert d["roofline"]["frac_algorithmic"] > 0 and "achieved_algorithmic" in d["roofline"]
     for leg in d["other_configs"].values():
         assert leg["frac_physical"] > 0 and leg["physical"]["physical_bytes_per_launch"] == 1500
     assert d["q32_value_planes"]["frac_physical"] == 1020 / 1e-3 / 1e9 / 8000.0
