@@ -29,6 +29,9 @@
 #pragma once
 #include "simt_macros.hpp"
 
+#ifndef RSEM_MODEL_AHEAD
+#define RSEM_MODEL_AHEAD 0
+#endif
 constexpr int kProfLds = 5120;  // doubles of the profile COUNT table kept in LDS (Q: 2500; no-Q: 204 positions)
 constexpr int kGldLds = 1024;
 constexpr int kRspdLds = 128;
@@ -327,20 +330,48 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
     const int g = lane & (kGrp - 1);
     const int g0 = lane & ~(kGrp - 1);  // first lane of my group
     constexpr int kMates = kPE ? 2 : 1;
+    // What the kernel needs to know about a read before it can ask for anything else (its row header), loaded for a row that
+    // exists (the last one stands in for the rows past the end) and masked afterwards: a load under a condition is a branch with
+    // a wait of its own.  -DRSEM_MODEL_AHEAD=1: the header of the NEXT step's read is requested at the top of a step and used a
+    // step later (10 more registers per lane), so that a step starts with its first dependent round trip already made.
+    struct RowHdr {
+        uint8_t lq;
+        uint64_t fr, to;
+        uint64_t r8[2];
+        int rl[2];
+        uint32_t rank;
+    };
+    auto load_hdr = [&](uint64_t row) -> RowHdr {
+        RowHdr H;
+        const uint64_t rowc = row < D.N1 ? row : D.N1 - 1;
+        H.lq = D.lq[rowc];
+        H.fr = D.row_ptr[rowc];
+        H.to = D.row_ptr[rowc + 1];
+        H.r8[0] = H.r8[1] = 0;
+        H.rl[0] = H.rl[1] = 0;
+#pragma unroll
+        for (int m = 0; m < (kPE ? 2 : 1); m++) { H.r8[m] = D.roff8[m][rowc]; H.rl[m] = D.rlen[m][rowc]; }
+        H.rank = PO.rank ? PO.rank[rowc] : 0u;
+        return H;
+    };
+#if RSEM_MODEL_AHEAD
+    RowHdr Hnext = load_hdr(row0 + (uint64_t)(lane >> 4));
+#endif
     for (uint64_t rbase = row0; rbase < D.N1; rbase += row_stride) {  // (wave-uniform)
         const uint64_t row = rbase + (uint64_t)(lane >> 4);
         const bool valid = row < D.N1;
-        // Everything the kernel needs to know about the read is loaded at once, for a row that exists (the last one stands in
-        // for the rows past the end), and masked afterwards: a load under a condition is a branch with a wait of its own, and
-        // `valid && !lq[row]`, then `active ? roff8[row] : 0` made three round trips to memory out of one.
-        const uint64_t rowc = valid ? row : D.N1 - 1;
-        const uint8_t lq_v = D.lq[rowc];
-        const uint64_t fr_v = D.row_ptr[rowc], to_v = D.row_ptr[rowc + 1];
-        uint64_t r8_v[2] = {0, 0};
-        int rl_v[2] = {0, 0};
-#pragma unroll
-        for (int m = 0; m < (kPE ? 2 : 1); m++) { r8_v[m] = D.roff8[m][rowc]; rl_v[m] = D.rlen[m][rowc]; }
-        const uint32_t rank_v = PO.rank ? PO.rank[rowc] : 0u;
+#if RSEM_MODEL_AHEAD
+        const RowHdr H = Hnext;
+        Hnext = load_hdr(row + row_stride);
+        RSEM_SCHED_FENCE();  // (keep the requests up here: the scheduler would sink them to their use, a step later)
+#else
+        const RowHdr H = load_hdr(row);
+#endif
+        const uint8_t lq_v = H.lq;
+        const uint64_t fr_v = H.fr, to_v = H.to;
+        uint64_t r8_v[2] = {H.r8[0], H.r8[1]};
+        int rl_v[2] = {H.rl[0], H.rl[1]};
+        const uint32_t rank_v = H.rank;
         const bool active = valid && !lq_v;
         const uint64_t fr = valid ? fr_v : 0, to = valid ? to_v : 0;
         const int L = (int)(to - fr);

@@ -19,6 +19,8 @@
 #define RSEM_LDS_ADD_I32(p, v) (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 /* the value must be in its register HERE: the wait for its load is placed at this point and not at a later join of paths */
 #define RSEM_PIN(x) asm volatile("" : "+v"(x))
+/* nothing moves across this point in the instruction schedule */
+#define RSEM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define RSEM_RCP(x) __builtin_amdgcn_rcp(x)
 #define RSEM_DPP_MOV(v, ctrl) __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false)
 #define RSEM_LL_AS_DOUBLE(x) __longlong_as_double(x)

@@ -96,6 +96,7 @@ inline long long double_as_ll(double d) { long long x; memcpy(&x, &d, 8); return
 #define RSEM_LDS_ADD(p, v) emu::atomic_add(p, v)
 #define RSEM_LDS_ADD_I32(p, v) __atomic_fetch_add(p, v, __ATOMIC_RELAXED)
 #define RSEM_PIN(x) (void)(x)
+#define RSEM_SCHED_FENCE() (void)0
 #define RSEM_RCP(x) (1.0 / (x) * (1.0 + 3e-8))  /* v_rcp_f64 is not exact either: the Newton steps must repair this */
 #define RSEM_DPP_MOV(v, ctrl) emu::exchange(v, emu::dpp_src(ctrl))
 #define RSEM_LL_AS_DOUBLE(x) emu::ll_as_double(x)

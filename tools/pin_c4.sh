@@ -27,8 +27,25 @@ cp $D/temp/s.iso_res $D/iso_res.em; cp $D/temp/s.gene_res $D/gene_res.em
 mkdir -p $D/tref; ln -s $D/temp/s.ofg $D/tref/s.ofg
 for f in omit iso_res gene_res; do [ -e $D/temp/s.$f ] && cp $D/temp/s.$f $D/tref/s.$f; done
 [ -e $D/tref/s.omit ] || : > $D/tref/s.omit
-( t=$(now); taskset -c 64-71 oracle/_ref/rsem-run-gibbs $D/ref $D/tref/s $D/stat/s 200 1000 1 -p $P --seed 1 -q > $O/reference_gibbs.log 2>&1
-  echo "reference_gibbs_rc $? reference_gibbs_s $(el $t) (8 threads on cores 64-71)" > $D/ref.done ) &
+# 8 physical cores of the LAST package (bench.py pins the reference EM of its own baseline leg to the first package's cores)
+CORES=$(python - <<PY
+import glob, os
+by = {}
+for d in glob.glob("/sys/devices/system/cpu/cpu[0-9]*"):
+    cpu = int(os.path.basename(d)[3:])
+    try:
+        pkg = int(open(d + "/topology/physical_package_id").read())
+        first = int(open(d + "/topology/thread_siblings_list").read().strip().replace("-", ",").split(",")[0])
+    except OSError:
+        continue
+    if first == cpu: by.setdefault(pkg, []).append(cpu)
+last = sorted(by[max(by)]) if by else list(range(8))
+print(",".join(map(str, last[-$P:])))
+PY
+)
+echo "reference on cpus $CORES"
+( t=$(now); taskset -c $CORES oracle/_ref/rsem-run-gibbs $D/ref $D/tref/s $D/stat/s 200 1000 1 -p $P --seed 1 -q > $O/reference_gibbs.log 2>&1
+  echo "reference_gibbs_rc $? reference_gibbs_s $(el $t) ($P threads on cpus $CORES)" > $D/ref.done ) &
 REFJOB=$!; TREF=$(now)
 # ---- the drop-in ----------------------------------------------------------------------------------------------------------------------
 run_dropin() {  # name, extra arguments

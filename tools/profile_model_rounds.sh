@@ -5,9 +5,15 @@ N=${1:-5263157}; M=${2:-200000}; D=/tmp/pmr
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf $D; tools/bin/gen_temp $D $N $M 3 20250925 100 nosam 5-16 | tail -1
 tools/bin/temp_to_rsb $D/temp/s $D/stat/s 3 > /dev/null
+# a mode "lib:<tag>" runs the default kernels of the variant build rsem_amd/librsem_hip_<tag>.so (tools/build_model_variant.sh)
 for mode in ${MODES:-default alignment}; do
   export RSEM_HIP_NORMAL_EXIT=1
-  if [ $mode = default ]; then unset RSEM_MODEL_KERNELS; else export RSEM_MODEL_KERNELS=$mode; fi
+  unset LD_LIBRARY_PATH
+  if [ $mode = default ]; then unset RSEM_MODEL_KERNELS
+  elif [[ $mode == lib:* ]]; then
+    unset RSEM_MODEL_KERNELS; tag=${mode#lib:}; mkdir -p /tmp/pmr_lib_$tag; cp rsem_amd/librsem_hip_$tag.so /tmp/pmr_lib_$tag/librsem_hip.so
+    export LD_LIBRARY_PATH=/tmp/pmr_lib_$tag; mode=lib_$tag
+  else export RSEM_MODEL_KERNELS=$mode; fi
   rm -rf gpurun_out/pmr_$mode
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmr_$mode -o p -- rsem_amd/bin/rsem-run-em $D/ref 3 $D/s $D/temp/s $D/stat/s -q > /dev/null 2>&1
   echo "== RSEM_MODEL_KERNELS=$mode"
