@@ -67,6 +67,7 @@ def cpu_baseline_port(wl, budget_s=8.0):
 
 # the reference binary's input: a complete .temp directory, same shape as the bench workload at a stated fraction of
 # its reads (tools/gen_temp.cpp: genes of kmin..kmax overlapping isoforms)
+BAM_FRAC = 0.02  # of the workload's reads, for the -b leg of the end-to-end comparison
 CPU_SAMPLE = {"C2": dict(read_type=1, frac=0.1, M=50_000, iso="4-12"), "C3": dict(read_type=3, frac=0.05, M=200_000, iso="5-16"),
               "C5": dict(read_type=1, frac=0.01, M=500_000, iso="32-64"), "tiny": dict(read_type=1, frac=1.0, M=400, iso="4-12")}
 
@@ -105,7 +106,7 @@ def one_socket_cores(want=64):
     return None
 
 
-def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True):
+def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True, bam_leg=True):
     """The UNMODIFIED reference binary (oracle/_ref/rsem-run-em, built from /root/reference) and the drop-in
     (rsem_amd/bin/rsem-run-em) on the SAME generated .temp files of the bench workload's shape (tools/gen_temp.cpp: model
     type, transcripts, isoforms per gene; `frac` of its reads), each run to convergence, wall clock of the whole program.
@@ -132,9 +133,9 @@ def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True):
     pin = ["taskset", "-c", ",".join(map(str, pinned))] if pinned else []
     d = tempfile.mkdtemp(prefix="rsem_bench_", dir="/tmp")
 
-    def generate(root, n_reads):
+    def generate(root, n_reads, sam=False):
         t0 = time.perf_counter()
-        out = subprocess.run([gen, root, str(n_reads), str(cs["M"]), str(rt), "20250925", "100", "nosam", cs["iso"]],
+        out = subprocess.run([gen, root, str(n_reads), str(cs["M"]), str(rt), "20250925", "100", "sam" if sam else "nosam", cs["iso"]],
                              stdout=subprocess.PIPE, text=True, check=True).stdout
         reads = ["s_alignable.fq"] if rt == 1 else ["s_alignable_1.fq", "s_alignable_2.fq"]
         subprocess.run([ref_idx, "32", "1", "1"] + [os.path.join(root, "temp", r) for r in reads], stdout=subprocess.DEVNULL, check=True)
@@ -202,6 +203,37 @@ def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True):
                                     "same_round_count": new_rounds == marks[-1][0],
                                     "theta_max_rel_diff": float(np.max(np.abs(new_theta - ref_theta)[big] / ref_theta[big])) if big.any() else 0.0})
         shutil.rmtree(small, ignore_errors=True)
+        if bam_leg and finished:
+            # -b is ON by default in rsem-calculate-expression (:61,626-632): the same comparison with the transcript.bam pass
+            # (BamWriter.h: every input alignment copied with MAPQ and ZW:f set from its posterior weight), at BAM_FRAC of the
+            # workload's reads -- the SAM text alone is 4.5 GB there.  Both programs get the same -p (the reference hands it to
+            # htslib's compression threads, the drop-in to the threads of host/bam_io.hpp).
+            try:
+                bamd = os.path.join(d, "bam")
+                bh, b1, bgen_s = generate(bamd, max(100_000, int(n_full * BAM_FRAC / 0.95)), sam=True)
+                bargs = em_args(bamd) + ["-b", os.path.join(bamd, "aln.sam"), "0", "-q"]
+                t0 = time.perf_counter()
+                rr = subprocess.run(pin + [ref_em] + bargs, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=ref_limit_s)
+                ref_b = time.perf_counter() - t0
+                ref_size = os.path.getsize(os.path.join(bamd, "s.transcript.bam")) if rr.returncode == 0 else 0
+                ref_theta_b = _theta_line(os.path.join(bamd, "stat", "s.theta"))
+                t0 = time.perf_counter()
+                rn = subprocess.run([new_em] + bargs, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                new_b = time.perf_counter() - t0
+                if rr.returncode != 0 or rn.returncode != 0:
+                    raise RuntimeError("a -b run failed: reference rc %d, drop-in rc %d %s" % (rr.returncode, rn.returncode, rn.stdout[-300:]))
+                new_theta_b = _theta_line(os.path.join(bamd, "stat", "s.theta"))
+                bigb = ref_theta_b >= 1e-7
+                e2e["bam_on"] = {"size": "%d alignable reads, %d alignments, %d transcripts (%.0f %% of the bench workload's reads), SAM input of %.2f GB"
+                                         % (b1, bh, cs["M"], BAM_FRAC * 100, os.path.getsize(os.path.join(bamd, "aln.sam")) / 1e9),
+                                 "what": "rsem-run-em ... -p %d -b aln.sam 0: the EM and the transcript.bam pass (the pipeline's default), wall clock" % cores,
+                                 "reference_s": ref_b, "dropin_s": new_b, "speedup": ref_b / new_b, "generate_s": bgen_s,
+                                 "transcript_bam_bytes": {"reference": ref_size, "dropin": os.path.getsize(os.path.join(bamd, "s.transcript.bam"))},
+                                 "theta_max_rel_diff": float(np.max(np.abs(new_theta_b - ref_theta_b)[bigb] / ref_theta_b[bigb])) if bigb.any() else 0.0,
+                                 "records_compared_in": "tests/test_cli_gpu.py::test_transcript_bam_matches_reference, tests/test_bam_cpu.py"}
+            except Exception as e:
+                e2e["bam_on"] = {"error": str(e)[:300]}
+            shutil.rmtree(os.path.join(d, "bam"), ignore_errors=True)
         if full_size:
             full = os.path.join(d, "full")
             fh, f1, fgen_s = generate(full, int(n_full / 0.95))
@@ -431,6 +463,7 @@ def main():
     ap.add_argument("--no-ci", action="store_true")
     ap.add_argument("--no-stream", action="store_true", help="skip the device STREAM probe beside the roofline")
     ap.add_argument("--gibbs-sweeps", type=int, default=30)
+    ap.add_argument("--no-bam-leg", action="store_true", help="skip the -b (transcript.bam) leg of the end-to-end comparison")
     ap.add_argument("--gibbs-exact-rounds", type=int, default=6, help="rounds of the exact (reference) chain timed in the Gibbs leg (>= 2)")
     args = ap.parse_args()
 
@@ -686,7 +719,7 @@ def main():
             if not args.no_cpu_baseline:  # reported baseline + whole-program wall clock: rank 0 at N=1 only
                 cb, e2e = None, None
                 try:
-                    cb, e2e = reference_e2e(args.config, N1, full_size=not args.no_e2e_full)
+                    cb, e2e = reference_e2e(args.config, N1, full_size=not args.no_e2e_full, bam_leg=not args.no_bam_leg)
                 except Exception as e:
                     log("reference_e2e failed: %s" % e)
                 if cb is None:

@@ -2,8 +2,19 @@
 // input alignments to <sample>.transcript.bam with MAPQ and a ZW:f tag set from each alignment's posterior
 // weight.  The reference links htslib for this; here the two formats involved are implemented directly on
 // zlib: a BGZF reader/writer, a BAM record walker, and a SAM-text -> BAM record encoder (SAM spec v1).
+//
+// The reference hands the output to htslib with nThreads compression threads (BamWriter.h:72, hts_set_threads) and reads,
+// re-weights and writes the records on one thread.  Here the whole pass is cut into pieces that N threads take side by side
+// (write_transcript_bam below): BGZF blocks are independent deflate streams of at most 64 KB, so a piece of the input becomes a
+// run of blocks of its own, and the pieces' runs are written in order; which alignment weight a piece starts with is settled by
+// a counting pass before it.  -b is on by default in rsem-calculate-expression (:61,626-632): at BASELINE configs[2] that is
+// 560 M records through zlib.
 #pragma once
 #include <zlib.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 
 #include "files.hpp"
 
@@ -11,52 +22,87 @@ namespace rsemh {
 
 // ---- BGZF (blocked gzip, SAM spec 4.1) ----------------------------------------------------------------
 
-class BgzfWriter {
-   public:
-    bool open(const std::string& path) { f_ = fopen(path.c_str(), "wb"); buf_.reserve(kBlock); return f_ != nullptr; }
-    void write(const void* p, size_t n) {
-        const uint8_t* s = (const uint8_t*)p;
-        while (n) {
-            size_t k = std::min(n, (size_t)kBlock - buf_.size());
-            buf_.insert(buf_.end(), s, s + k);
-            s += k; n -= k;
-            if (buf_.size() == kBlock) flush();
-        }
+// One deflate stream per thread, re-used from block to block.
+struct BgzfDeflater {
+    z_stream zs;
+    bool live = false;
+    static constexpr size_t kBlock = 0xff00;  // input bytes per block, as htslib cuts them
+    ~BgzfDeflater() { if (live) deflateEnd(&zs); }
+    // append the BGZF block of p[0..n), n <= kBlock, to out
+    void block(const uint8_t* p, size_t n, std::vector<uint8_t>& out) {
+        if (!live) {
+            memset(&zs, 0, sizeof(zs));
+            if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("zlib deflateInit2 failed");
+            live = true;
+        } else if (deflateReset(&zs) != Z_OK) die("zlib deflateReset failed");
+        const size_t at = out.size();
+        out.resize(at + 0x10000);
+        uint8_t* o = out.data() + at;
+        zs.next_in = (Bytef*)p; zs.avail_in = (uInt)n;
+        zs.next_out = o + 18; zs.avail_out = 0x10000 - 18 - 8;
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) die("BGZF block does not fit");
+        const uint32_t clen = (uint32_t)zs.total_out;
+        static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        memcpy(o, hdr, 16);
+        const uint16_t bsize = (uint16_t)(clen + 25);  // total block size - 1
+        o[16] = bsize & 0xff; o[17] = bsize >> 8;
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
+        const uint32_t isize = (uint32_t)n;
+        memcpy(o + 18 + clen, &crc, 4);
+        memcpy(o + 22 + clen, &isize, 4);
+        out.resize(at + clen + 26);
     }
-    void close() {
-        flush();
-        static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        fwrite(eof, 1, 28, f_);
-        fclose(f_);
-        f_ = nullptr;
+    // a run of blocks for p[0..n)
+    void stream(const uint8_t* p, size_t n, std::vector<uint8_t>& out) {
+        for (size_t i = 0; i < n; i += kBlock) block(p + i, std::min(kBlock, n - i), out);
+    }
+};
+inline void bgzf_write_eof(FILE* f) {
+    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    fwrite(eof, 1, 28, f);
+}
+
+// N threads that take the items 0 .. n-1 of a stage as they become free; run() returns when the stage is done.
+class StagePool {
+   public:
+    explicit StagePool(int n) : n_(std::max(1, n)) {
+        for (int i = 1; i < n_; i++) th_.emplace_back([this, i] { loop(i); });
+    }
+    ~StagePool() {
+        { std::lock_guard<std::mutex> g(m_); quit_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    int threads() const { return n_; }
+    void run(size_t n_items, const std::function<void(size_t, int)>& fn) {
+        if (n_ == 1 || n_items <= 1) { for (size_t i = 0; i < n_items; i++) fn(i, 0); return; }
+        { std::lock_guard<std::mutex> g(m_); fn_ = &fn; items_ = n_items; next_.store(0); busy_ = n_ - 1; ++gen_; }
+        cv_.notify_all();
+        work(0);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return busy_ == 0; });
+        fn_ = nullptr;
     }
 
    private:
-    static constexpr int kBlock = 0xff00;
-    FILE* f_ = nullptr;
-    std::vector<uint8_t> buf_;
-    void flush() {
-        if (buf_.empty()) return;
-        uint8_t out[0x10000];
-        z_stream zs;
-        memset(&zs, 0, sizeof(zs));
-        if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("zlib deflateInit2 failed");
-        zs.next_in = buf_.data(); zs.avail_in = (uInt)buf_.size();
-        zs.next_out = out + 18; zs.avail_out = sizeof(out) - 18 - 8;
-        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) die("BGZF block does not fit");
-        const uint32_t clen = (uint32_t)zs.total_out;
-        deflateEnd(&zs);
-        const uint8_t hdr[12] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0};
-        memcpy(out, hdr, 12);
-        out[12] = 'B'; out[13] = 'C'; out[14] = 2; out[15] = 0;
-        const uint16_t bsize = (uint16_t)(clen + 25);  // total block size - 1
-        out[16] = bsize & 0xff; out[17] = bsize >> 8;
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf_.data(), (uInt)buf_.size());
-        const uint32_t isize = (uint32_t)buf_.size();
-        memcpy(out + 18 + clen, &crc, 4);
-        memcpy(out + 22 + clen, &isize, 4);
-        fwrite(out, 1, clen + 26, f_);
-        buf_.clear();
+    int n_;
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t, int)>* fn_ = nullptr;
+    size_t items_ = 0;
+    std::atomic<size_t> next_{0};
+    int busy_ = 0;
+    unsigned long gen_ = 0;
+    bool quit_ = false;
+    void work(int me) { for (size_t i; (i = next_.fetch_add(1)) < items_;) (*fn_)(i, me); }
+    void loop(int me) {
+        unsigned long seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> g(m_); cv_.wait(g, [&] { return gen_ != seen; }); seen = gen_; if (quit_) return; }
+            work(me);
+            { std::lock_guard<std::mutex> g(m_); if (--busy_ == 0) done_.notify_one(); }
+        }
     }
 };
 
@@ -70,15 +116,17 @@ class BgzfReader {
             if (pos_ == blk_.size() && !fill()) return false;
             size_t k = std::min(n, blk_.size() - pos_);
             memcpy(d, blk_.data() + pos_, k);
-            d += k; pos_ += k; n -= k;
+            d += k; pos_ += k; n -= k; consumed_ += k;
         }
         return true;
     }
+    uint64_t consumed() const { return consumed_; }  // bytes of the uncompressed stream handed out so far
 
    private:
     FILE* f_ = nullptr;
     std::vector<uint8_t> blk_;
     size_t pos_ = 0;
+    uint64_t consumed_ = 0;
     bool fill() {
         for (;;) {
             uint8_t h[18];
@@ -216,6 +264,7 @@ class AlignmentReader {
                 header.names.push_back(nm);
                 header.lens.push_back(l_ref);
             }
+            records_at_ = bgzf_.consumed();
         } else {
             if (!map_.open(path)) die("Cannot open %s!", path.c_str());
             p_ = map_.data;
@@ -232,31 +281,19 @@ class AlignmentReader {
             std::sort(name2id_.begin(), name2id_.end());
         }
     }
-    bool next(AlnRecord& r) {
-        if (is_bam_) {
-            int32_t bs;
-            if (!bgzf_.read(&bs, 4)) return false;
-            r.d.resize(bs);
-            return bgzf_.read(r.d.data(), bs);
-        }
-        while (p_ < end_) {
-            const char* nl = (const char*)memchr(p_, '\n', end_ - p_);
-            const char* e = nl ? nl : end_;
-            const char* b = p_;
-            p_ = nl ? nl + 1 : end_;
-            if (e > b && e[-1] == '\r') --e;
-            if (e == b) continue;
-            encode_sam_line(b, e, r);
-            return true;
-        }
-        return false;
-    }
+    bool is_bam() const { return is_bam_; }
+    // SAM input: the alignment lines (the mapped file behind the header)
+    const char* body_begin() const { return p_; }
+    const char* body_end() const { return end_; }
+    // BAM input: where the first record starts in the uncompressed stream
+    uint64_t records_at() const { return records_at_; }
 
    private:
     bool is_bam_ = false;
     BgzfReader bgzf_;
     MappedFile map_;
     const char *p_ = nullptr, *end_ = nullptr;
+    uint64_t records_at_ = 0;
     std::vector<std::pair<std::string, int>> name2id_;
 
     int ref_id(const std::string& n) const {
@@ -274,8 +311,9 @@ class AlignmentReader {
     template <typename T>
     static void put(std::vector<uint8_t>& d, T v) { const uint8_t* p = (const uint8_t*)&v; d.insert(d.end(), p, p + sizeof(T)); }
 
-    // one SAM text line -> BAM record bytes (SAM spec 4.2; integer tags take the smallest fitting type as htslib does)
-    void encode_sam_line(const char* b, const char* e, AlnRecord& r) {
+   public:
+    // one SAM text line -> BAM record bytes (SAM spec 4.2; integer tags take the smallest fitting type as htslib does); any thread
+    void encode_sam_line(const char* b, const char* e, AlnRecord& r) const {
         std::vector<std::pair<const char*, const char*>> f;
         for (const char* q = b;;) {
             const char* t = (const char*)memchr(q, '\t', e - q);
@@ -416,8 +454,20 @@ inline void set_alignment_weight(AlnRecord& r, double prb) {
 }
 
 // BamWriter::work (BamWriter.h:82-146).  weights: one per alignment (per mate pair for paired-end data), in .dat order.
+//
+// The input is taken in super-chunks of ~256 MB (RSEM_HIP_BAM_CHUNK bytes; the tests use small ones), each in three stages on
+// `nthreads` threads (StagePool), a barrier between stages:
+//   SAM input: the super-chunk's lines are cut into pieces at line boundaries; (A) count the records of every piece -- piece
+//     boundaries then move by one line where a mate pair would be split; (B) count the alignments (pairs) of every piece that
+//     carry a weight, whence the index of every piece's first weight; (C) encode the piece's lines as BAM records, set MAPQ and
+//     ZW:f, deflate the piece's records as a run of BGZF blocks of its own.
+//   BAM input: (A) inflate the super-chunk's BGZF blocks side by side into one buffer (a record cut by the end of the buffer is
+//     carried over to the next super-chunk); the records are framed by one thread (four bytes per record) and cut into pieces;
+//     (B), (C) as above, on copies of the records.
+// The pieces' block runs are written in order.  Output: the same records in the same order as the reference writes; the BGZF
+// block boundaries differ from htslib's (a run of blocks per piece instead of one per 0xff00 bytes of the whole stream).
 inline void write_transcript_bam(const std::string& inpF, const std::string& outF, bool paired, const int32_t* hit_sid,
-                                 const double* weights, uint64_t n_hits, const Transcripts& T) {
+                                 const double* weights, uint64_t n_hits, const Transcripts& T, int nthreads = 1) {
     AlignmentReader in;
     in.open(inpF);
     // external (header order) -> internal sid, Transcripts::buildMappings (Transcripts.h:96-144)
@@ -430,43 +480,53 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
         if (it == dict.end() || it->first != in.header.names[k]) die("RSEM can not recognize reference sequence name %s!", in.header.names[k].c_str());
         e2i[k] = it->second;
     }
-    AlnHeader out_h;
-    out_h.text = header_with_pg(in.header.text);
-    parse_sq(out_h);
-    BgzfWriter out;
-    if (!out.open(outF)) die("Cannot open %s for writing!", outF.c_str());
-    out.write("BAM\1", 4);
-    const int32_t l_text = (int32_t)out_h.text.size();
-    out.write(&l_text, 4);
-    out.write(out_h.text.data(), l_text);
-    const int32_t n_ref = (int32_t)out_h.names.size();
-    out.write(&n_ref, 4);
-    for (int i = 0; i < n_ref; i++) {
-        const int32_t l_name = (int32_t)out_h.names[i].size() + 1;
-        out.write(&l_name, 4);
-        out.write(out_h.names[i].c_str(), l_name);
-        out.write(&out_h.lens[i], 4);
+    nthreads = std::max(1, std::min(nthreads, (int)std::max(1u, std::thread::hardware_concurrency())));
+    StagePool pool(nthreads);
+    std::vector<BgzfDeflater> defl(nthreads);
+    FILE* fo = fopen(outF.c_str(), "wb");
+    if (!fo) die("Cannot open %s for writing!", outF.c_str());
+    {  // header
+        AlnHeader out_h;
+        out_h.text = header_with_pg(in.header.text);
+        parse_sq(out_h);
+        std::vector<uint8_t> raw, comp;
+        auto put = [&](const void* q, size_t n) { raw.insert(raw.end(), (const uint8_t*)q, (const uint8_t*)q + n); };
+        put("BAM\1", 4);
+        const int32_t l_text = (int32_t)out_h.text.size();
+        put(&l_text, 4);
+        put(out_h.text.data(), l_text);
+        const int32_t n_ref = (int32_t)out_h.names.size();
+        put(&n_ref, 4);
+        for (int i = 0; i < n_ref; i++) {
+            const int32_t l_name = (int32_t)out_h.names[i].size() + 1;
+            put(&l_name, 4);
+            put(out_h.names[i].c_str(), l_name);
+            put(&out_h.lens[i], 4);
+        }
+        defl[0].stream(raw.data(), raw.size(), comp);
+        fwrite(comp.data(), 1, comp.size(), fo);
     }
-    auto emit = [&](const AlnRecord& r) {
+    size_t super_bytes = 256u << 20;
+    if (const char* e = getenv("RSEM_HIP_BAM_CHUNK")) super_bytes = std::max<size_t>(64, (size_t)atoll(e));
+    const size_t n_pieces_max = (size_t)nthreads * 4;
+
+    // what stages B and C do with a record (SE) or a pair of records (PE), shared by both kinds of input
+    auto emit = [](std::vector<uint8_t>& raw, const AlnRecord& r) {
         const int32_t bs = (int32_t)r.d.size();
-        out.write(&bs, 4);
-        out.write(r.d.data(), r.d.size());
+        raw.insert(raw.end(), (const uint8_t*)&bs, (const uint8_t*)&bs + 4);
+        raw.insert(raw.end(), r.d.begin(), r.d.end());
     };
-    uint64_t h = 0;
-    AlnRecord a, b;
-    if (!paired) {
-        while (in.next(a)) {
+    auto finish_unit = [&](std::vector<uint8_t>& raw, AlnRecord& a, AlnRecord* b, uint64_t& h) {  // BamWriter.h:101-141
+        if (!paired) {
             if (a.mapped()) {
                 if (h >= n_hits) die("The alignment file holds more alignments than the .dat file!");
                 if (e2i[a.refID()] != hit_sid[h]) die("The alignment file and the .dat file are out of step!");
                 set_alignment_weight(a, weights[h++]);
             }
-            emit(a);
-        }
-    } else {
-        while (in.next(a) && in.next(b)) {
+            emit(raw, a);
+        } else {
             AlnRecord* r1 = &a;
-            AlnRecord* r2 = &b;
+            AlnRecord* r2 = b;
             if (!r1->read1()) std::swap(r1, r2);
             if (r1->mapped() && r2->mapped()) {
                 if (h >= n_hits) die("The alignment file holds more alignments than the .dat file!");
@@ -475,12 +535,249 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
                 set_alignment_weight(*r2, weights[h]);
                 ++h;
             }
-            emit(*r1);
-            emit(*r2);
+            emit(raw, *r1);
+            emit(raw, *r2);
+        }
+    };
+    struct Piece {
+        size_t b = 0, e = 0;          // SAM: byte range of the lines; BAM: range of record indices
+        uint64_t records = 0, units = 0, h0 = 0;
+        std::vector<uint8_t> out;
+    };
+    std::vector<Piece> pieces;
+    uint64_t h_total = 0;
+    auto write_pieces = [&]() {
+        for (Piece& P : pieces) {
+            if (!P.out.empty() && fwrite(P.out.data(), 1, P.out.size(), fo) != P.out.size()) die("Cannot write %s!", outF.c_str());
+            std::vector<uint8_t>().swap(P.out);
+        }
+    };
+    const int per_unit = paired ? 2 : 1;
+
+    if (!in.is_bam()) {
+        const char* cur = in.body_begin();
+        const char* const end = in.body_end();
+        auto next_line = [](const char*& q, const char* lim, const char*& b, const char*& e) -> bool {  // the next non-empty line of [q, lim)
+            while (q < lim) {
+                const char* nl = (const char*)memchr(q, '\n', lim - q);
+                b = q;
+                e = nl ? nl : lim;
+                q = nl ? nl + 1 : lim;
+                if (e > b && e[-1] == '\r') --e;
+                if (e > b) return true;
+            }
+            return false;
+        };
+        auto line_end_after = [&](const char* q) -> const char* {  // first line start at or behind q
+            if (q >= end) return end;
+            if (q == in.body_begin() || q[-1] == '\n') return q;
+            const char* nl = (const char*)memchr(q, '\n', end - q);
+            return nl ? nl + 1 : end;
+        };
+        while (cur < end) {
+            const char* sc_end = line_end_after(std::min(end, cur + super_bytes));
+            // pieces at line boundaries
+            const size_t total = (size_t)(sc_end - cur);
+            const size_t np = std::max<size_t>(1, std::min(n_pieces_max, total / 4096 + 1));
+            pieces.assign(np, Piece());
+            for (size_t i = 0; i < np; i++) {
+                const char* b = i == 0 ? cur : line_end_after(cur + total * i / np);
+                pieces[i].b = (size_t)(std::min(b, sc_end) - in.body_begin());
+            }
+            for (size_t i = 0; i < np; i++) pieces[i].e = i + 1 < np ? pieces[i + 1].b : (size_t)(sc_end - in.body_begin());
+            // (A) records per piece
+            pool.run(np, [&](size_t i, int) {
+                const char *q = in.body_begin() + pieces[i].b, *lim = in.body_begin() + pieces[i].e, *b, *e;
+                uint64_t n = 0;
+                while (next_line(q, lim, b, e)) ++n;
+                pieces[i].records = n;
+            });
+            if (paired) {  // no pair may straddle two pieces: a piece that would start with a second mate gives that line to its predecessor
+                const char* const base = in.body_begin();
+                uint64_t before = 0;
+                long last = -1;  // the last piece so far that holds records
+                for (size_t i = 0; i < np; i++) {
+                    if (pieces[i].records == 0) continue;
+                    if (before & 1) {  // (then last >= 0)
+                        const char *q = base + pieces[i].b, *lim = base + pieces[i].e, *lb, *le;
+                        next_line(q, lim, lb, le);
+                        const size_t nb = (size_t)(q - base);
+                        pieces[last].e = nb;
+                        pieces[last].records += 1;
+                        for (size_t z = (size_t)last + 1; z < i; z++) pieces[z].b = pieces[z].e = nb;
+                        pieces[i].b = nb;
+                        pieces[i].records -= 1;
+                        before += 1;
+                        if (pieces[i].records == 0) continue;
+                    }
+                    before += pieces[i].records;
+                    last = (long)i;
+                }
+                if (before & 1) {  // the super-chunk ends inside a pair: take the second mate's line in, or drop a last record without a mate
+                    const char *q = sc_end, *lb, *le;
+                    if (next_line(q, end, lb, le)) {
+                        sc_end = q;
+                        const size_t nb = (size_t)(q - base);
+                        pieces[last].e = nb;
+                        pieces[last].records += 1;
+                        for (size_t z = (size_t)last + 1; z < np; z++) pieces[z].b = pieces[z].e = nb;
+                    } else {  // (`while (in.next(a) && in.next(b))` of the reference: it is not written)
+                        Piece& P = pieces[last];
+                        const char *q2 = base + P.b, *lim = base + P.e, *last_start = q2;
+                        while (next_line(q2, lim, lb, le)) last_start = lb;
+                        P.e = (size_t)(last_start - base);
+                        P.records -= 1;
+                        sc_end = end;
+                    }
+                }
+            }
+            // (B) weighted units per piece
+            pool.run(np, [&](size_t i, int) {
+                const char *q = in.body_begin() + pieces[i].b, *lim = in.body_begin() + pieces[i].e, *b, *e;
+                auto flag_of = [](const char* lb, const char* le) -> int {
+                    const char* t = (const char*)memchr(lb, '\t', le - lb);
+                    return t ? atoi(t + 1) : 4;
+                };
+                uint64_t u = 0;
+                while (next_line(q, lim, b, e)) {
+                    const int f1 = flag_of(b, e);
+                    if (!paired) { u += !(f1 & 4); continue; }
+                    const char *b2, *e2;
+                    if (!next_line(q, lim, b2, e2)) break;
+                    u += !(f1 & 4) && !(flag_of(b2, e2) & 4);
+                }
+                pieces[i].units = u;
+            });
+            for (size_t i = 0; i < np; i++) { pieces[i].h0 = h_total; h_total += pieces[i].units; }
+            // (C) encode, weigh, deflate
+            pool.run(np, [&](size_t i, int me) {
+                Piece& P = pieces[i];
+                const char *q = in.body_begin() + P.b, *lim = in.body_begin() + P.e, *b, *e;
+                std::vector<uint8_t> raw;
+                raw.reserve((P.e - P.b) / 2 + 64);
+                AlnRecord ra, rb;
+                uint64_t h = P.h0;
+                while (next_line(q, lim, b, e)) {
+                    in.encode_sam_line(b, e, ra);
+                    if (paired) {
+                        const char *b2, *e2;
+                        if (!next_line(q, lim, b2, e2)) break;
+                        in.encode_sam_line(b2, e2, rb);
+                    }
+                    finish_unit(raw, ra, &rb, h);
+                }
+                if (h != P.h0 + P.units) die("internal error: a piece of the alignment file weighed %llu alignments, counted %llu", (unsigned long long)(h - P.h0), (unsigned long long)P.units);
+                defl[me].stream(raw.data(), raw.size(), P.out);
+            });
+            write_pieces();
+            cur = sc_end;
+        }
+    } else {
+        // the BGZF blocks of the file
+        MappedFile mf;
+        if (!mf.open(inpF)) die("Cannot open %s!", inpF.c_str());
+        struct Blk { size_t off, clen; uint32_t isize; };
+        std::vector<Blk> blks;
+        for (size_t o = 0; o + 18 <= mf.size;) {
+            const uint8_t* h = (const uint8_t*)mf.data + o;
+            if (h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4)) die("input BAM: not a BGZF block");
+            const int xlen = h[10] | (h[11] << 8);
+            int bsize = -1;
+            for (int i = 0; i + 4 <= xlen;) {
+                const uint8_t* x = h + 12 + i;
+                const int slen = x[2] | (x[3] << 8);
+                if (x[0] == 'B' && x[1] == 'C' && slen == 2) bsize = x[4] | (x[5] << 8);
+                i += 4 + slen;
+            }
+            if (bsize < 0 || o + (size_t)bsize + 1 > mf.size) die("input BAM: truncated or corrupt BGZF block");
+            uint32_t isize;
+            memcpy(&isize, h + bsize + 1 - 4, 4);
+            blks.push_back({o + 12 + (size_t)xlen, (size_t)bsize + 1 - 12 - xlen - 8, isize});
+            o += (size_t)bsize + 1;
+        }
+        std::vector<uint8_t> buf, carry;
+        std::vector<uint64_t> rec;  // offsets of the records' block_size words in buf
+        uint64_t skip = in.records_at();  // header bytes of the uncompressed stream still to pass
+        size_t bi = 0;
+        while (bi < blks.size()) {
+            size_t be = bi, bytes = 0;
+            while (be < blks.size() && (be == bi || bytes + blks[be].isize <= super_bytes)) bytes += blks[be++].isize;
+            std::vector<size_t> at(be - bi + 1, carry.size());
+            for (size_t k = bi; k < be; k++) at[k - bi + 1] = at[k - bi] + blks[k].isize;
+            buf.resize(at.back());
+            if (!carry.empty()) memcpy(buf.data(), carry.data(), carry.size());
+            // (A) inflate
+            pool.run(be - bi, [&](size_t k, int) {
+                const Blk& B = blks[bi + k];
+                if (!B.isize) return;
+                z_stream zs;
+                memset(&zs, 0, sizeof(zs));
+                if (inflateInit2(&zs, -15) != Z_OK) die("zlib inflateInit2 failed");
+                zs.next_in = (Bytef*)mf.data + B.off; zs.avail_in = (uInt)B.clen;
+                zs.next_out = buf.data() + at[k]; zs.avail_out = B.isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (rc != Z_STREAM_END) die("input BAM: corrupt BGZF block");
+            });
+            bi = be;
+            // frame the records
+            size_t pos = 0;
+            if (skip) { const size_t k = (size_t)std::min<uint64_t>(skip, buf.size()); pos = k; skip -= k; }
+            rec.clear();
+            while (pos + 4 <= buf.size()) {
+                int32_t bs;
+                memcpy(&bs, buf.data() + pos, 4);
+                if (bs < 32) die("input BAM: corrupt alignment record");
+                if (pos + 4 + (size_t)bs > buf.size()) break;
+                rec.push_back(pos);
+                pos += 4 + (size_t)bs;
+            }
+            size_t usable = rec.size();
+            size_t carry_from = pos;  // the first byte behind the complete records
+            if (paired && (usable & 1)) { --usable; carry_from = rec[usable]; }  // keep pairs together: the odd record waits for its mate
+            if (bi >= blks.size()) {
+                if (pos != buf.size()) die("input BAM: the last record is cut short");
+                carry.clear();  // (a last record without a mate is not written: `while (in.next(a) && in.next(b))` of the reference)
+            } else {
+                carry.assign(buf.begin() + carry_from, buf.end());
+            }
+            const size_t units_all = usable / per_unit;
+            const size_t np = std::max<size_t>(1, std::min(n_pieces_max, units_all / 64 + 1));
+            pieces.assign(np, Piece());
+            for (size_t i = 0; i < np; i++) { pieces[i].b = units_all * i / np * per_unit; pieces[i].e = units_all * (i + 1) / np * per_unit; }
+            auto load = [&](size_t r, AlnRecord& out) {
+                int32_t bs;
+                memcpy(&bs, buf.data() + rec[r], 4);
+                out.d.assign(buf.begin() + rec[r] + 4, buf.begin() + rec[r] + 4 + bs);
+            };
+            auto flag_at = [&](size_t r) -> int { const uint8_t* d = buf.data() + rec[r] + 4; return d[14] | (d[15] << 8); };
+            // (B)
+            pool.run(np, [&](size_t i, int) {
+                uint64_t u = 0;
+                for (size_t r = pieces[i].b; r < pieces[i].e; r += per_unit)
+                    u += paired ? (!(flag_at(r) & 4) && !(flag_at(r + 1) & 4)) : !(flag_at(r) & 4);
+                pieces[i].units = u;
+            });
+            for (size_t i = 0; i < np; i++) { pieces[i].h0 = h_total; h_total += pieces[i].units; }
+            // (C)
+            pool.run(np, [&](size_t i, int me) {
+                Piece& P = pieces[i];
+                std::vector<uint8_t> raw;
+                AlnRecord ra, rb;
+                uint64_t h = P.h0;
+                for (size_t r = P.b; r < P.e; r += per_unit) {
+                    load(r, ra);
+                    if (paired) load(r + 1, rb);
+                    finish_unit(raw, ra, &rb, h);
+                }
+                defl[me].stream(raw.data(), raw.size(), P.out);
+            });
+            write_pieces();
         }
     }
-    if (h != n_hits) die("The alignment file holds fewer alignments (%llu) than the .dat file (%llu)!", (unsigned long long)h, (unsigned long long)n_hits);
-    out.close();
+    if (h_total != n_hits) die("The alignment file holds %s alignments (%llu) than the .dat file (%llu)!", h_total < n_hits ? "fewer" : "more", (unsigned long long)h_total, (unsigned long long)n_hits);
+    bgzf_write_eof(fo);
+    if (fclose(fo) != 0) die("Cannot write %s!", outF.c_str());
 }
 
 }  // namespace rsemh

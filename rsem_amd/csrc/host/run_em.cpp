@@ -290,8 +290,9 @@ int main(int argc, char* argv[]) {
     bool verbose = true, genBamF = false, genGibbsOut = false, appendNames = false, bamSampling = false, hasSeed = false;
     uint32_t seed = 0;
     std::string inpSamF, devices_s;
-    int device = 0, ngpus = 1, value_bits = 64, value_range_bits = -1;
-    for (int i = 6; i < argc; i++) {  // EM.cpp:578-595; -p is accepted and irrelevant (the GPU is the parallelism)
+    int device = 0, ngpus = 1, value_bits = 64, value_range_bits = -1, nThreads = 1;
+    for (int i = 6; i < argc; i++) {  // EM.cpp:578-595; -p: the host threads of the -b pass (as the reference's hts_set_threads); the EM's parallelism is the GPU
+        if (!strcmp(argv[i], "-p") && i + 1 < argc) nThreads = std::max(1, atoi(argv[i + 1]));
         if (!strcmp(argv[i], "-b") && i + 1 < argc) { genBamF = true; inpSamF = argv[i + 1]; }
         if (!strcmp(argv[i], "--sampling")) bamSampling = true;
         if (!strcmp(argv[i], "--seed") && i + 1 < argc) {
@@ -838,7 +839,7 @@ int main(int argc, char* argv[]) {
             }
             if (verbose) printf("Sampling is finished.\n");
         }
-        write_transcript_bam(inpSamF, outName + ".transcript.bam", pe, sid_abs.data(), w.data(), nnz, T);
+        write_transcript_bam(inpSamF, outName + ".transcript.bam", pe, sid_abs.data(), w.data(), nnz, T, nThreads);  // (BamWriter.h:72: hts_set_threads(out, nThreads))
         if (verbose) printf("Bam output file is generated!\n");
         lap("transcript.bam");
     }

@@ -1,0 +1,49 @@
+"""The -b pass of rsem-run-em (rsem_amd/csrc/host/bam_io.hpp: SAM / BAM input -> <sample>.transcript.bam with MAPQ and ZW:f set from
+the posterior weights, BamWriter.h:39-146) without a GPU: tests/bam_write_check.cpp takes the weights from the ZW:f tags of the
+transcript.bam the REFERENCE wrote for the fixture and runs the writer on the fixture's alignment file.  The records must be the
+reference's (same bytes; MAPQ may differ by one where it is recomputed from a float), and the decompressed output must be the same
+stream of bytes for every thread count, every super-chunk size (down to chunks shorter than a line, so that pieces, mate pairs and
+records straddle every kind of boundary) and for SAM and BAM input alike."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CXX = shutil.which("g++")
+pytestmark = pytest.mark.skipif(CXX is None, reason="needs g++")
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = os.path.join(str(tmp_path_factory.mktemp("bam_write_check")), "bam_write_check")
+    subprocess.check_call([CXX, "-O2", "-std=c++17", os.path.join(ROOT, "tests", "bam_write_check.cpp"), "-o", exe, "-lpthread", "-lz"])
+    return exe
+
+
+def _run(exe, fx, inp, paired, threads, chunk, out):
+    env = dict(os.environ)
+    env.pop("BAM_CHECK_REPEAT", None)
+    if chunk:
+        env["RSEM_HIP_BAM_CHUNK"] = str(chunk)
+    else:
+        env.pop("RSEM_HIP_BAM_CHUNK", None)
+    g = os.path.join(ROOT, "tests", "golden", fx)
+    r = subprocess.run([exe, os.path.join(g, "ref.ti"), os.path.join(g, inp), os.path.join(g, "golden.transcript.bam"), out, str(int(paired)), str(threads)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    f = dict(zip(r.stdout.split()[0::2], r.stdout.split()[1::2]))
+    assert f["header_equal"] == "1" and int(f["identical"]) + int(f["mapq_off_by_one"]) == int(f["records"])
+    return f
+
+
+@pytest.mark.parametrize("fx,paired", [("se_q", False), ("pe_q", True)])
+def test_transcript_bam_is_the_same_for_every_thread_count_and_chunk_size(checker, fx, paired, tmp_path):
+    out = os.path.join(str(tmp_path), "o.bam")
+    base = _run(checker, fx, "aln.sam", paired, 1, 0, out)
+    assert int(base["records"]) > 3000
+    for inp in ("aln.sam", "golden.transcript.bam"):
+        for threads, chunk in [(3, 0), (8, 0), (8, 5000), (5, 777), (6, 200), (4, 64)]:
+            f = _run(checker, fx, inp, paired, threads, chunk, out)
+            assert (f["fnv"], f["stream_bytes"], f["records"]) == (base["fnv"], base["stream_bytes"], base["records"]), (inp, threads, chunk)

@@ -20,3 +20,4 @@ echo "fetch calibration $(( $(now) - t )) s"
 t=$(now); MODES="default lib:mahead lib:mahead3w" timeout 900 tools/profile_model_rounds.sh 10526315 200000 > $O/model_rounds.log 2>&1; echo "model rounds rc=$? $(( $(now) - t )) s"; grep -E "^==|k_model_group" $O/model_rounds.log
 t=$(now); timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$? $(( $(now) - t )) s"; tail -3 $O/bench.err; cut -c1-1500 $O/bench.json
 t=$(now); timeout 1200 tools/profile_round.sh ${TAG:-r05q} "C3" > $O/profile.log 2>&1; echo "profile rc=$? $(( $(now) - t )) s"; tail -25 $O/profile.log
+find gpurun_out -name "*kernel_trace.csv" -size +4M -delete 2>/dev/null; find gpurun_out -name "*.db" -size +4M -delete 2>/dev/null; du -sh gpurun_out | cut -f1
