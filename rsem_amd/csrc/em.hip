@@ -59,8 +59,34 @@ struct Ctrl {  // device-resident loop control, one per ctx
     int last_totNum;
     int last_round;
     unsigned long long tick2;  // k_mstep_fast: (sum of totNum) << 32 | arrivals, one atomic per workgroup
-    double fsum;               // accumulating: the floating-point sum of the round's counts, the SUM of the reference's ROUND line
+    double fsum;               // closers beyond kSumSlots add here (none with today's launch shapes)
+    // The floating-point sum of the round's counts -- the SUM of the reference's ROUND line -- is put together from one partial sum
+    // per closer, ADDED IN CLOSER ORDER by the last one to arrive: its last digits do not depend on who arrived when.
+    double fslot[1024];
 };
+constexpr int kSumSlots = 1024;
+
+
+// A closer leaves its partial sum in its slot (an exchange: the returned old value is what the arrival that follows is made to
+// depend on, see solo_close_round); the last closer adds the slots up in index order.
+__device__ inline unsigned int sum_slot_put(Ctrl* ctrl, int me, double csum) {
+    double was;
+    if (me < kSumSlots) was = __hip_atomic_exchange(&ctrl->fslot[me], csum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else was = __hip_atomic_fetch_add(&ctrl->fsum, csum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int z;
+    asm volatile("v_and_b32 %0, 0, %1" : "=v"(z) : "v"((unsigned int)__double_as_longlong(was)));
+    return z;
+}
+__device__ inline double sum_slots_take(Ctrl* ctrl, int n_closers) {
+    double s = 0.0;
+    const int n = n_closers < kSumSlots ? n_closers : kSumSlots;
+    for (int i = 0; i < n; i++) s += __hip_atomic_load(&ctrl->fslot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n_closers > kSumSlots) {
+        s += __hip_atomic_load(&ctrl->fsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctrl->fsum, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return s;
+}
 
 // What the host reads while the loop runs, in pinned host memory the M-step kernel writes directly (no stream sync, no
 // copy): the statistics line of every finished round (EM.cpp:415) and the stop flag.  hist is a ring; the host keeps
@@ -472,19 +498,14 @@ __device__ inline void solo_close_round(const SoloArgs& A, int M, double N0, con
                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"((unsigned int)was));
         }
-        {   // this closer's share of the floating-point sum of the counts (the reference's SUM, EM.cpp:394-398,415)
-            const double was = __hip_atomic_fetch_add(&ctrl->fsum, csum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned int z2;
-            asm volatile("v_and_b32 %0, 0, %1" : "=v"(z2) : "v"((unsigned int)__double_as_longlong(was)));
-            zero += z2;
-        }
+        zero += sum_slot_put(ctrl, me, csum);  // this closer's share of the floating-point sum of the counts (the reference's SUM, EM.cpp:394-398,415)
         const unsigned long long old = __hip_atomic_fetch_add(&ctrl->tick2, (((unsigned long long)(unsigned)tot << 32) | 1ull) + zero,
                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)(old & 0xffffffffull) == n_close - 1) {  // last closer: stop rule (EM.cpp:416) for round stat_round
             const int round = A.stat_round;
             const int totNum = (int)(old >> 32) + tot;
             const unsigned long long bb = __hip_atomic_load(&ctrl->bbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double fsum = __hip_atomic_load(&ctrl->fsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double fsum = sum_slots_take(ctrl, n_close);
             ctrl->last_sum = fsum;
             ctrl->last_bchange = __longlong_as_double((long long)bb);
             ctrl->last_totNum = totNum;
@@ -506,7 +527,6 @@ __device__ inline void solo_close_round(const SoloArgs& A, int M, double N0, con
             }
             __hip_atomic_store(&ctrl->bbits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctrl->tick2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctrl->fsum, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int k = 0; k < 2 * kTotSlots; k++) A.prev[n + k] = 0.0;  // every other closer has read them
         }
     }
@@ -890,18 +910,13 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, dou
                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"((unsigned int)was));
         }
-        {   // the floating-point sum of the counts, for the ROUND line only (theta divides by the exact `sum` above)
-            const double was = __hip_atomic_fetch_add(&ctrl->fsum, csum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned int z2;
-            asm volatile("v_and_b32 %0, 0, %1" : "=v"(z2) : "v"((unsigned int)__double_as_longlong(was)));
-            zero += z2;
-        }
+        zero += sum_slot_put(ctrl, (int)blockIdx.x, csum);  // the floating-point sum of the counts, for the ROUND line only (theta divides by the exact `sum` above)
         const unsigned long long old = __hip_atomic_fetch_add(&ctrl->tick2, (((unsigned long long)(unsigned)tot << 32) | 1ull) + zero,
                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(old & 0xffffffffull) == gridDim.x - 1) {  // last workgroup: stop rule (EM.cpp:416)
             const int totNum = (int)(old >> 32) + tot;
             const unsigned long long bb = __hip_atomic_load(&ctrl->bbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double fsum = __hip_atomic_load(&ctrl->fsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double fsum = sum_slots_take(ctrl, (int)gridDim.x);
             ctrl->last_sum = fsum;
             ctrl->last_bchange = __longlong_as_double((long long)bb);
             ctrl->last_totNum = totNum;
@@ -923,7 +938,6 @@ __global__ __launch_bounds__(kBlock) void k_mstep_fast(int32_t M, double N0, dou
             }
             __hip_atomic_store(&ctrl->bbits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctrl->tick2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctrl->fsum, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = 1;
         }
     }
@@ -1617,6 +1631,12 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
     // accumulates into a buffer nobody reads).  theta, counts_last and the ROUND lines come from the statistics kernels.
     const Loop loop = mir ? loop_wanted(c, sharded) : Loop::PLAIN;
     const bool fused = loop == Loop::FUSED, solo = loop == Loop::SOLO;
+    // The instantiations that take theta out of the previous round's counts (kFC) walk F64X rows as plain F64: no far part, no
+    // reciprocal stored.  loop_wanted() does not pick them for a layout with split rows; whoever adds another way here meets this.
+    if ((fused || solo) && c->L.n_x_rows) {
+        set_last_error("internal: the fused / one-launch EM loops cannot run a layout with split rows");
+        return RSEM_ERR_STATE;
+    }
     const size_t R = (size_t)c->M + 1 + 2 * kTotSlots;
     hipStream_t st2 = c->stream2;
     // SOLO: round r is ONE launch (see SoloArgs); the same three rotating buffers, seeded the same way.  Round q's line and
@@ -1838,9 +1858,13 @@ __global__ void k_invert_order(uint64_t n, const uint32_t* __restrict__ order, u
     if (p < n) rank[order[p]] = (uint32_t)p;
 }
 
+bool em_planes_writable(const rsem_em_ctx* c) {
+    return c && c->layout_ok && !c->layout_has_q32 && c->value_bits != 32 && !c->L.n_x_rows;
+}
+
 int em_planes_view(rsem_em_ctx* c, EmPlanesView* v) {
     RSEM_REQUIRE(c && v, "NULL argument");
-    if (!c->layout_ok || c->layout_has_q32 || c->value_bits == 32 || c->L.n_x_rows) {
+    if (!em_planes_writable(c)) {
         set_last_error("the layout holds Q32 planes or split rows");
         return RSEM_ERR_STATE;
     }

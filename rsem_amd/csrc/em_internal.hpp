@@ -35,6 +35,9 @@ int em_values_changed(rsem_em_ctx* c);
 // The planes of the current layout, for in-place writers.  RSEM_ERR_STATE when the layout cannot take doubles in place (Q32
 // shapes) -- the caller then falls back to em_values_changed.  After writing d_cp / d_ncp AND the planes:
 int em_planes_view(rsem_em_ctx* c, EmPlanesView* v);
+// Can the layout take doubles in place (F64 planes, no split rows)?  A question, not an error: nothing is written to the
+// last-error string (callers that only want to know must not use em_planes_view as a probe).
+bool em_planes_writable(const rsem_em_ctx* c);
 int em_values_written_in_place(rsem_em_ctx* c);
 // E step with posterior write-back into d_w / d_wn (EM.cpp:199-244, calcExpectedWeights-style) followed by the M
 // step; host outputs as rsem_em_step.  The weights stay on the device for the model accumulation kernels.

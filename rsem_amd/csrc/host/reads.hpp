@@ -70,7 +70,7 @@ inline bool calc_lq_single_ids(const uint8_t* s, int len, bool hasPolyA, int see
 // files above this size are parsed by several threads, each a run of whole records (RSEM_HIP_PARSE_SPLIT_BYTES: tests set it
 // to a few hundred bytes so that the chunk-boundary logic is exercised on small files)
 inline size_t parse_split_bytes() {
-    static const size_t v = []() { const char* e = getenv("RSEM_HIP_PARSE_SPLIT_BYTES"); return e ? (size_t)atoll(e) : ((size_t)32 << 20); }();
+    static const size_t v = []() { const char* e = getenv("RSEM_HIP_PARSE_SPLIT_BYTES"); return e ? (size_t)std::max(0ll, atoll(e)) : ((size_t)32 << 20); }();
     return v;
 }
 
@@ -252,6 +252,9 @@ inline DatData load_dat(const std::string& path, int expect_read_type, int threa
             long long k;
             if (parse_long(q, le, k)) {
                 if (k <= 0) die("%s: a read without alignments", path.c_str());
+                // every alignment takes at least " s p": a count the line cannot hold is a corrupt file, said here and not by an
+                // allocation of that many records
+                if ((unsigned long long)k > (unsigned long long)(le - q) / 2 + 1) die("%s: Cannot read alignments (a line announces %lld of them and is %lld bytes long)", path.c_str(), k, (long long)(le - q));
                 ++r;
                 h += (uint64_t)k;
             }

@@ -761,7 +761,11 @@ int launch_group_any(rsem_model_ctx* c, const double* d_theta, const AccumPtrs* 
     PlaneOut PO{nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
     rsem::EmPlanesView pv;
     const char* e = getenv("RSEM_MODEL_PLANES");
-    const bool in_place = !(e && !strcmp(e, "0")) && rsem::em_planes_view(c->em, &pv) == RSEM_OK;
+    bool in_place = !(e && !strcmp(e, "0")) && rsem::em_planes_writable(c->em);  // (a question: a layout of Q32 planes or split rows is no error)
+    if (in_place) {
+        const int vrc = rsem::em_planes_view(c->em, &pv);
+        if (vrc != RSEM_OK) return vrc;
+    }
     if (in_place) PO = PlaneOut{pv.d_rank, (const Shape*)pv.d_shapes, pv.n_shapes, pv.T, pv.n_sell_rows, pv.d_sval, pv.d_sncp};
     int rc;
     switch (c->D.model_type) {

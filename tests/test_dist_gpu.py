@@ -106,3 +106,114 @@ def test_bench_forced_dist_line_on_one_gpu():
     assert "error" not in g, g
     assert g["parallel"]["sweeps_per_s_per_rank"][0] > 0 and g["parallel"]["final_reduce_ms"] is not None and g["parallel"]["final_reduce_ms"] >= 0
     assert g["exact"]["final_reduce_ms"] is not None
+
+
+# ---- real ranks: these run where the box has at least two GPUs (the driver's 8-GPU node), RCCL over xGMI --------------------------
+
+def _two_gpus():
+    try:
+        from rsem_amd import capi
+        return capi.device_count() >= 2
+    except Exception:
+        return False
+
+
+needs_two_gpus = pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs (RCCL refuses two ranks on one device)")
+
+
+def _rccl_ranks(world, body):
+    """world threads of this process, rank r on GPU r, one RCCL communicator (ncclCommInitRank from every thread at once)."""
+    from rsem_amd import capi
+    uid = capi.Comm.unique_id()
+    out, err = [None] * world, [None] * world
+
+    def run(r):
+        try:
+            comm = capi.Comm.create(r, r, world, uid)
+            try:
+                out[r] = body(r, comm)
+            finally:
+                comm.close()
+        except BaseException as e:  # (a rank that dies must not leave the others waiting without a word)
+            err[r] = e
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(timeout=600) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a rank is still waiting in a collective"
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@needs_two_gpus
+def test_em_on_two_gpus_one_allreduce_per_round_equals_single_context():
+    """EM.cpp:385-389 across devices: rows split by the reference's rule, ONE ncclAllReduce of [counts | totals] per round on each
+    rank's EM stream (comm.hip), every rank with the same theta and the same ROUND count as one context on the whole matrix."""
+    from rsem_amd import capi
+    from tools.synth_data import make_em_workload
+    world = 2
+    wl = make_em_workload("small", seed=9, long_row_every=50000)
+    M = wl["M"]
+    ctx = capi.EmContext(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], device=0)
+    ref = ctx.run(wl["theta0"], wl["N0"], max_round=400)
+    ctx.close()
+    shards = _shards(wl, world)
+
+    def body(r, comm):
+        assert (comm.rank, comm.world) == (r, world)
+        rp, sid, cp, ncp = shards[r]
+        c = capi.EmContext(M, rp, np.ascontiguousarray(sid), np.ascontiguousarray(cp), np.ascontiguousarray(ncp), device=r)
+        c.set_comm(comm)
+        o = c.run(wl["theta0"], wl["N0"], max_round=400)
+        c.close()
+        return o
+
+    out = _rccl_ranks(world, body)
+    for o in out:
+        assert o["rounds"] == ref["rounds"]
+        assert np.allclose(o["theta"], ref["theta"], rtol=1e-9, atol=1e-18)
+        assert np.array_equal(o["theta"], out[0]["theta"])
+    assert np.allclose(out[0]["counts"], ref["counts"], rtol=1e-9, atol=1e-9)
+
+
+@needs_two_gpus
+def test_gibbs_chains_dealt_to_two_gpus_one_reduce_equals_single_context():
+    """Gibbs.cpp:211-254,372-388 across devices: chain k on rank k % 2 (each GPU advances its chains with teams of workgroups as
+    large as ITS compute units allow for ITS number of chains -- the count vectors do not depend on the team), the accumulator
+    sums meet in ONE ncclReduce on rank 0: equal to all chains in one context, count vectors chain for chain."""
+    from rsem_amd import capi
+    from rsem_amd.dist import gibbs_rank_chains
+    from tools.synth_data import make_em_workload, to_gibbs_items
+    world, nchains = 2, 6
+    wl = make_em_workload("small", seed=4)
+    M = wl["M"]
+    irp, isid, icp = to_gibbs_items(wl)
+    N1 = len(irp) - 1
+    init = np.zeros(M + 1, np.int32)
+    eel, mw, grp = np.full(M + 1, 700.0), np.ones(M + 1), np.array([1, M + 1], np.int32)
+    totc = (M + 1) + wl["N0"] + N1
+    seeds = capi.gibbs_chain_seeds(11, nchains)
+    ns = [3, 3, 2, 2, 2, 2]
+    mk = lambda dev: capi.GibbsContext(M, irp, isid, icp, init, None, 1.0, totc, wl["N0"], eel, mw, grp, device=dev)
+    g = mk(0)
+    cvs1, acc1, _, p1 = g.run_chains(capi.GIBBS_EXACT, seeds, 4, ns, 2)
+    g.close()
+
+    def body(r, comm):
+        mine = gibbs_rank_chains(nchains, world, r)
+        gr = mk(r)
+        gr.set_comm(comm)
+        cvs, acc, _, prof = gr.run_chains(capi.GIBBS_EXACT, [seeds[k] for k in mine], 4, [ns[k] for k in mine], 2)
+        gr.close()
+        return mine, cvs, acc, prof
+
+    out = _rccl_ranks(world, body)
+    for mine, cvs, _, prof in out:
+        assert prof.chains == len(mine) and prof.team >= 1
+        for k, cv in zip(mine, cvs):
+            assert np.array_equal(cv, cvs1[k])
+    assert out[0][3].reduce_ms > 0  # the one collective ran
+    for a, b in zip(out[0][2], acc1):  # rank 0 holds the sums over all chains (added in another order: doubles, not bit for bit)
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-9)
