@@ -1634,7 +1634,7 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
     // The instantiations that take theta out of the previous round's counts (kFC) walk F64X rows as plain F64: no far part, no
     // reciprocal stored.  loop_wanted() does not pick them for a layout with split rows; whoever adds another way here meets this.
     if ((fused || solo) && c->L.n_x_rows) {
-        set_last_error("internal: the fused / one-launch EM loops cannot run a layout with split rows");
+        rsem::set_last_error("internal: the fused / one-launch EM loops cannot run a layout with split rows");
         return RSEM_ERR_STATE;
     }
     const size_t R = (size_t)c->M + 1 + 2 * kTotSlots;
