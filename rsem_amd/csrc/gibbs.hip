@@ -476,88 +476,17 @@ __global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint
     }
 }
 
-// ---- EXACT mode, the default implementation: one WORKGROUP per chain (gibbs_exact_wg.hpp) ------------------------------
-#include "gibbs_exact_wg.hpp"
-
-template <bool kInit>
-__global__ __launch_bounds__(kXThr) void k_gibbs_exact_wg(uint32_t n_tiles, const uint32_t* __restrict__ tile_start, const uint64_t* __restrict__ tile_items,
-                                                        const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
-                                                        const double* __restrict__ cp, int32_t* counts_base, int32_t* z_base,
-                                                        double pseudoC, MtState* mt_base, const int32_t* __restrict__ last_round,
-                                                        int round, uint64_t stride_c, uint64_t stride_z, unsigned long long* prof) {
-    __shared__ XTile tile;
-    const int chain = blockIdx.x;
-    if (round > last_round[chain]) return;  // (uniform over the workgroup)
-    MtState* mt_state = mt_base + chain;
-    for (int i = threadIdx.x; i < 624; i += blockDim.x) tile.mt[i] = mt_state->mt[i];
-    if (threadIdx.x == 0) tile.idx = mt_state->idx;
-    // the move-endpoint table starts out all zero (every resolve round leaves it that way)
-    for (int i = threadIdx.x; i < kXKeys * 2 * kXW; i += blockDim.x) (&tile.ends[0][0][0])[i] = 0ull;
-    for (int i = threadIdx.x; i < kXKeys; i += blockDim.x) tile.key[i] = 0;
-    for (int i = threadIdx.x; i < kXBits / 64; i += blockDim.x) tile.bits[i] = 0ull;
-    __syncthreads();
-    gibbs_exact_wg_body<kInit>((int)threadIdx.x, &tile, n_tiles, tile_start, tile_items, row_ptr, sid, cp, counts_base + (uint64_t)chain * stride_c,
-                               z_base + (uint64_t)chain * stride_z, pseudoC, prof);
-    __syncthreads();
-    for (int i = threadIdx.x; i < 624; i += blockDim.x) mt_state->mt[i] = tile.mt[i];
-    if (threadIdx.x == 0) mt_state->idx = tile.idx;
-}
-
-// ---- EXACT mode, W workgroups per chain (gibbs_exact_team.hpp): the same chain, W tiles of a window at once ---------------------
+// ---- EXACT mode, the default implementation: a team of workgroups per chain (gibbs_exact_team.hpp over gibbs_exact_wg.hpp) ----
+// Two passes over the two headers: the uniform pseudo count, and --prior (per-transcript pseudo counts) in namespace gx_prior.
 #include "gibbs_exact_team.hpp"
-
-struct TeamArgs {  // what every workgroup of every team needs (one argument: cooperative launches take an array of pointers)
-    int W, nchains;
-    XTeamCtl* ctl;       // [nchains]
-    uint32_t* net;       // [nchains][(M + 2) * nw]
-    uint32_t* gnet;      // [nchains][(M + 2) * 2]
-    int32_t* ref;        // [nchains][M + 2]
-    uint32_t nw;
-    const XSlot* slots;  // [n_win][W]
-    uint32_t n_win;
-    uint64_t N1;
-    int32_t M;
-};
-
-// Workgroup b belongs to chain b % nchains: workgroups are dealt to the 8 XCDs round-robin, so with 8 chains (or a divisor or
-// multiple of 8) a chain's team shares one XCD and its L2.  The generator is read from mt_in and handed on in mt_out (two
-// buffers: a launch without team barriers -- the initial assignment -- has workgroups that start after workgroup 0 has left).
-template <bool kInit>
-__global__ __launch_bounds__(kXThr) void k_gibbs_exact_team(TeamArgs ta, const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
-                                                          const double* __restrict__ cp, int32_t* counts_base, int32_t* z_base, double pseudoC,
-                                                          const MtState* __restrict__ mt_in, MtState* mt_out, const int32_t* __restrict__ last_round,
-                                                          int round, uint64_t stride_c, uint64_t stride_z, unsigned long long* prof) {
-    __shared__ XTile tile;
-    const int chain = (int)(blockIdx.x % (unsigned)ta.nchains), tw = (int)(blockIdx.x / (unsigned)ta.nchains);
-    if (round > last_round[chain]) return;  // (uniform over the team)
-    const MtState* src = mt_in + chain;
-    for (int i = threadIdx.x; i < 624; i += blockDim.x) tile.mt[i] = src->mt[i];
-    if (threadIdx.x == 0) tile.idx = src->idx;
-    for (int i = threadIdx.x; i < kXKeys * 2 * kXW; i += blockDim.x) (&tile.ends[0][0][0])[i] = 0ull;
-    for (int i = threadIdx.x; i < kXKeys; i += blockDim.x) tile.key[i] = 0;
-    for (int i = threadIdx.x; i < kXBits / 64; i += blockDim.x) tile.bits[i] = 0ull;
-    __syncthreads();
-    XTeam tm;
-    tm.W = ta.W;
-    tm.tw = tw;
-    tm.ctl = ta.ctl + chain;
-    tm.net = ta.net + (size_t)chain * ((size_t)ta.M + 2) * ta.nw;
-    tm.gnet = ta.gnet + (size_t)chain * ((size_t)ta.M + 2) * 2;
-    tm.ref = ta.ref + (size_t)chain * ((size_t)ta.M + 2);
-    tm.nw = ta.nw;
-    tm.slots = ta.slots;
-    tm.n_win = ta.n_win;
-    tm.N1 = ta.N1;
-    tm.M = ta.M;
-    const bool ok = gibbs_exact_team_body<kInit>((int)threadIdx.x, &tile, tm, row_ptr, sid, cp, counts_base + (uint64_t)chain * stride_c,
-                                                 z_base + (uint64_t)chain * stride_z, pseudoC, prof);
-    __syncthreads();
-    if (ok && tw == 0) {
-        MtState* dst = mt_out + chain;
-        for (int i = threadIdx.x; i < 624; i += blockDim.x) dst->mt[i] = tile.mt[i];
-        if (threadIdx.x == 0) dst->idx = tile.idx;
-    }
+#define RSEM_GX_PRIOR 1
+namespace gx_prior {
+#include "gibbs_exact_team.hpp"
 }
+#undef RSEM_GX_PRIOR
+static_assert(sizeof(GxMtState) == sizeof(MtState) && sizeof(gx_prior::GxMtState) == sizeof(MtState), "one layout of a chain's generator");
+static_assert(sizeof(TeamArgs) == sizeof(gx_prior::TeamArgs) && sizeof(XSlot) == sizeof(gx_prior::XSlot) && sizeof(XTeamCtl) == sizeof(gx_prior::XTeamCtl),
+              "the host fills the uniform pass's records for either kernel");
 
 constexpr int kSerialTileItems = 3072;
 
@@ -814,11 +743,9 @@ struct rsem_gibbs_ctx {
     uint64_t* d_irp = nullptr;
     int32_t* d_isid = nullptr;
     double* d_icp = nullptr;
-    uint32_t* d_tiles = nullptr;  // k_gibbs_exact_wg: first read of every tile (+ N1), gx_build_tiles
-    uint64_t* d_tile_items = nullptr;  // ... and its first item (row_ptr[d_tiles[t]])
     uint32_t n_tiles = 0;
-    std::vector<uint32_t> h_tiles;       // host copies of the two (the windows of k_gibbs_exact_team are cut from them per team size)
-    std::vector<uint64_t> h_tile_items;
+    std::vector<uint32_t> h_tiles;       // first read of every tile (+ N1), gx_build_tiles; host: the windows of k_gibbs_exact_team
+    std::vector<uint64_t> h_tile_items;  // ... and its first item (row_ptr[h_tiles[t]])            are cut from them per team size
     int team_W = 0;                      // the team size d_slots was built for (0: none yet)
     void* d_slots = nullptr;             // XSlot[n_win][team_W]
     uint32_t n_win = 0;
@@ -960,15 +887,16 @@ int ensure_parallel_layout(rsem_gibbs_ctx* c) {
     return RSEM_OK;
 }
 
-// RSEM_GIBBS_EXACT_IMPL = wg (default) | coop | serial: the three implementations of the same chain (cross-checks)
-enum ExactImpl { kExactWg, kExactCoop, kExactSerial };
+// RSEM_GIBBS_EXACT_IMPL = team (default) | coop | serial: three implementations of the same chain (the last two: cross-checks of the tests)
+enum ExactImpl { kExactTeam, kExactCoop, kExactSerial };
 constexpr int kMaxTeamDevices = 64;
 std::atomic<int> g_team_busy[kMaxTeamDevices];  // team runs in flight per device (zero-initialised)
 ExactImpl exact_impl_requested(bool have_alpha) {
     const char* e = getenv("RSEM_GIBBS_EXACT_IMPL");
     if (e && !strcmp(e, "serial")) return kExactSerial;
     if (e && !strcmp(e, "coop")) return kExactCoop;
-    return have_alpha ? kExactCoop : kExactWg;  // a per-transcript alpha (not in the reference) runs on the one-wave kernel
+    (void)have_alpha;  // (--prior runs on the same kernel: its own pass of the headers, namespace gx_prior)
+    return kExactTeam;
 }
 
 }  // namespace
@@ -992,7 +920,7 @@ int rsem_gibbs_chain_seeds(uint32_t seed, int nchains, uint32_t* out) {
 int rsem_gibbs_destroy(rsem_gibbs_ctx* c) {
     if (!c) return RSEM_OK;
     (void)hipSetDevice(c->device);
-    hipFree(c->d_irp); hipFree(c->d_isid); hipFree(c->d_icp); hipFree(c->d_tiles); hipFree(c->d_tile_items); hipFree(c->d_slots); hipFree(c->d_row_ptr); hipFree(c->d_sid);
+    hipFree(c->d_irp); hipFree(c->d_isid); hipFree(c->d_icp); hipFree(c->d_slots); hipFree(c->d_row_ptr); hipFree(c->d_sid);
     hipFree(c->d_cp); hipFree(c->d_ncp); sell_free(c->L); hipFree(c->d_scp); hipFree(c->d_sncp);
     hipFree(c->d_init_counts); hipFree(c->d_g); hipFree(c->d_alpha);
     hipFree(c->d_eel); hipFree(c->d_mw); hipFree(c->d_grp);
@@ -1090,15 +1018,11 @@ int rsem_gibbs_create(rsem_gibbs_ctx** out, int device, int32_t M, uint64_t N1, 
             rsem_gibbs_destroy(c);
             return RSEM_ERR_INVALID;
         }
-    gx_build_tiles(N1, row_ptr, tiles);
+    if (alpha) gx_prior::gx_build_tiles(N1, row_ptr, tiles);  // (--prior: tiles of 3072 items)
+    else gx_build_tiles(N1, row_ptr, tiles);
     c->n_tiles = (uint32_t)tiles.size() - 1;
-    G_TRY(dmalloc(&c->d_tiles, tiles.size()));
-    G_TRY(hipMemcpyAsync(c->d_tiles, tiles.data(), sizeof(uint32_t) * tiles.size(), hipMemcpyHostToDevice, st));
     std::vector<uint64_t> tile_items(tiles.size());
     for (size_t i = 0; i < tiles.size(); i++) tile_items[i] = row_ptr[tiles[i]];
-    G_TRY(dmalloc(&c->d_tile_items, tile_items.size()));
-    G_TRY(hipMemcpyAsync(c->d_tile_items, tile_items.data(), sizeof(uint64_t) * tile_items.size(), hipMemcpyHostToDevice, st));
-    G_TRY(hipStreamSynchronize(st));  // (tile_items is a local)
     c->h_tiles = tiles;
     c->h_tile_items = tile_items;
     // the ids index counts[] on the device: check them there (the host copy is not walked)
@@ -1223,35 +1147,55 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             void take(int d) { dev = d; mine = d >= 0 && d < kMaxTeamDevices && g_team_busy[d].fetch_add(1) == 0; if (!mine && dev >= 0 && dev < kMaxTeamDevices) g_team_busy[dev].fetch_sub(1); }
             ~TeamLease() { if (mine) g_team_busy[dev].fetch_sub(1); }
         } lease;
+        const bool prior = c->d_alpha != nullptr;  // --prior: the pass of the two headers compiled in namespace gx_prior
         int W = 1;
-        if (impl == kExactWg) lease.take(c->device);
-        if (impl == kExactWg && lease.mine) {
+        if (impl == kExactTeam) lease.take(c->device);
+        if (impl == kExactTeam && lease.mine) {
             W = std::max(1, std::min(kXTeamMax, c->n_cus / std::max(1, nchains)));
             if (W < 8) W = 1;  // with every compute unit busy, teams of 4 advance a chain no faster than one workgroup (profiles/r05b_c3_64chains.log)
             if (const char* e = getenv("RSEM_GX_TEAM")) W = std::max(1, std::min(kXTeamMax, atoi(e)));
             W = (int)std::min<uint64_t>((uint64_t)W, std::max<uint64_t>(1, c->n_tiles));
             int coop = 0, per_cu = 0;
             (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gibbs_exact_team<false>, kXThr, 0) != hipSuccess) per_cu = 0;
+            hipError_t oe = prior ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gx_prior::k_gibbs_exact_team<false>, kXThr, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gibbs_exact_team<false>, kXThr, 0);
+            if (oe != hipSuccess) per_cu = 0;
             (void)hipGetLastError();
             if (!coop || per_cu < 1) W = 1;
             else W = std::min(W, std::max(1, per_cu * c->n_cus / std::max(1, nchains)));
         }
         DevBuf t_ctl, t_net, t_gnet, t_ref;
-        TeamArgs ta{};
-        if (W > 1) {
-            if (c->team_W != W) {
-                std::vector<XSlot> slots;
-                gx_build_windows(W, c->h_tiles, c->h_tile_items, slots);
+        TeamArgs ta{};  // (the same bytes for either pass: see the static_asserts behind the includes)
+        if (impl == kExactTeam) {
+            if (c->team_W != W) {  // the windows of this team size (W = 1: a window per tile)
+                std::vector<unsigned char> bytes;
+                size_t n_slots;
+                if (prior) {
+                    std::vector<gx_prior::XSlot> slots;
+                    gx_prior::gx_build_windows(W, c->h_tiles, c->h_tile_items, slots);
+                    n_slots = slots.size();
+                    bytes.assign((const unsigned char*)slots.data(), (const unsigned char*)slots.data() + sizeof(gx_prior::XSlot) * n_slots);
+                } else {
+                    std::vector<XSlot> slots;
+                    gx_build_windows(W, c->h_tiles, c->h_tile_items, slots);
+                    n_slots = slots.size();
+                    bytes.assign((const unsigned char*)slots.data(), (const unsigned char*)slots.data() + sizeof(XSlot) * n_slots);
+                }
                 if (c->d_slots) { (void)hipFree(c->d_slots); c->d_slots = nullptr; }
-                RSEM_HIP_TRY(hipMalloc(&c->d_slots, std::max<size_t>(sizeof(XSlot) * slots.size(), 8)));
-                RSEM_HIP_TRY(hipMemcpy(c->d_slots, slots.data(), sizeof(XSlot) * slots.size(), hipMemcpyHostToDevice));
-                c->n_win = (uint32_t)(slots.size() / (size_t)W);
+                RSEM_HIP_TRY(hipMalloc(&c->d_slots, std::max<size_t>(bytes.size(), 8)));
+                RSEM_HIP_TRY(hipMemcpy(c->d_slots, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+                c->n_win = (uint32_t)(n_slots / (size_t)W);
                 c->team_W = W;
             }
             ta.W = W;
             ta.nchains = nchains;
             ta.nw = (uint32_t)(((W + 15) / 16) * 16 / 2);
+            ta.slots = (const XSlot*)c->d_slots;
+            ta.n_win = c->n_win;
+            ta.N1 = c->N1;
+            ta.M = c->M;
+        }
+        if (W > 1) {  // what the workgroups of a team tell each other through
             const size_t rows = (size_t)c->M + 2;
             RSEM_HIP_TRY(t_ctl.alloc(sizeof(XTeamCtl) * nchains));
             RSEM_HIP_TRY(t_net.alloc(sizeof(uint32_t) * rows * ta.nw * nchains));
@@ -1265,13 +1209,9 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             ta.net = t_net.as<uint32_t>();
             ta.gnet = t_gnet.as<uint32_t>();
             ta.ref = t_ref.as<int32_t>();
-            ta.slots = (const XSlot*)c->d_slots;
-            ta.n_win = c->n_win;
-            ta.N1 = c->N1;
-            ta.M = c->M;
             if (getenv("RSEM_GX_VERBOSE")) fprintf(stderr, "[gibbs exact] teams of %d workgroups per chain, %u windows per sweep\n", W, c->n_win);
         }
-        team_used = W;
+        team_used = impl == kExactTeam ? W : 0;
         int mt_flip = 0;  // which half of mts holds the chains' generators
         hipError_t team_err = hipSuccess;
         auto sweep_team = [&](bool init, int round) {
@@ -1281,30 +1221,28 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             int32_t* a_counts = counts.as<int32_t>();
             int32_t* a_z = z.as<int32_t>();
             double a_pc = c->pseudoC;
+            const double* a_alpha = c->d_alpha;
             const MtState* a_in = mts.as<MtState>() + (size_t)mt_flip * nchains;
             MtState* a_out = mts.as<MtState>() + (size_t)(mt_flip ^ 1) * nchains;
             const int32_t* a_last = d_last.as<int32_t>();
             int a_round = round;
             uint64_t a_sc = stride_c, a_sz = stride_z;
             unsigned long long* a_prof = (RSEM_GX_PROFILE && !init) ? prof_buf.as<unsigned long long>() : (unsigned long long*)nullptr;
-            void* args[] = {&ta, &a_rp, &a_sid, &a_cp, &a_counts, &a_z, &a_pc, &a_in, &a_out, &a_last, &a_round, &a_sc, &a_sz, &a_prof};
-            const void* fn = init ? (const void*)k_gibbs_exact_team<true> : (const void*)k_gibbs_exact_team<false>;
-            hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)(nchains * W)), dim3(kXThr), args, 0, st);
+            void* args[] = {&ta, &a_rp, &a_sid, &a_cp, &a_counts, &a_z, &a_pc, &a_alpha, &a_in, &a_out, &a_last, &a_round, &a_sc, &a_sz, &a_prof};
+            const void* fn = prior ? (init ? (const void*)gx_prior::k_gibbs_exact_team<true> : (const void*)gx_prior::k_gibbs_exact_team<false>)
+                                   : (init ? (const void*)k_gibbs_exact_team<true> : (const void*)k_gibbs_exact_team<false>);
+            // a team needs all its workgroups resident: a cooperative launch (the runtime refuses a grid that is not); one workgroup
+            // per chain waits for nobody and may be any number of chains
+            hipError_t e = W > 1 ? hipLaunchCooperativeKernel(fn, dim3((unsigned)(nchains * W)), dim3(kXThr), args, 0, st)
+                                 : hipLaunchKernel(fn, dim3((unsigned)nchains), dim3(kXThr), args, 0, st);
             if (e != hipSuccess && team_err == hipSuccess) team_err = e;
             mt_flip ^= 1;
         };
         auto sweep = [&](bool init, int round) {
-            if (W > 1) { sweep_team(init, round); return; }
+            if (impl == kExactTeam) { sweep_team(init, round); return; }
 #define EXACT_ARGS c->N1, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->d_alpha, c->pseudoC, \
                    mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z
-            if (impl == kExactWg) {
-#define EXACT_WG_ARGS c->n_tiles, c->d_tiles, c->d_tile_items, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->pseudoC, \
-                      mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z, \
-                      ((RSEM_GX_PROFILE && !init) ? prof_buf.as<unsigned long long>() : (unsigned long long*)nullptr)
-                if (init) hipLaunchKernelGGL(k_gibbs_exact_wg<true>, dim3(nchains), dim3(kXThr), 0, st, EXACT_WG_ARGS);
-                else hipLaunchKernelGGL(k_gibbs_exact_wg<false>, dim3(nchains), dim3(kXThr), 0, st, EXACT_WG_ARGS);
-#undef EXACT_WG_ARGS
-            } else if (impl == kExactSerial) {
+            if (impl == kExactSerial) {
                 if (init) hipLaunchKernelGGL(k_gibbs_exact_serial<true>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
                 else hipLaunchKernelGGL(k_gibbs_exact_serial<false>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
             } else {
@@ -1326,11 +1264,11 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                 if (rc != RSEM_OK) return rc;
             }
         }
+        if (impl == kExactTeam && team_err != hipSuccess) {
+            rsem::set_last_error("k_gibbs_exact_team: launch of %d x %d workgroups failed: %s", nchains, W, hipGetErrorString(team_err));
+            return RSEM_ERR_HIP;
+        }
         if (W > 1) {
-            if (team_err != hipSuccess) {
-                rsem::set_last_error("k_gibbs_exact_team: cooperative launch of %d x %d workgroups failed: %s", nchains, W, hipGetErrorString(team_err));
-                return RSEM_ERR_HIP;
-            }
             std::vector<XTeamCtl> hc(nchains);
             RSEM_HIP_TRY(hipMemcpyAsync(hc.data(), t_ctl.p, sizeof(XTeamCtl) * nchains, hipMemcpyDeviceToHost, st));
             RSEM_HIP_TRY(hipStreamSynchronize(st));
@@ -1345,7 +1283,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                 fprintf(stderr, "[gibbs exact] %.2f team barriers per window\n", (double)nb / std::max(1.0, (double)nchains * (double)c->n_win * (double)sweeps));
             }
         }
-        if (RSEM_GX_PROFILE && impl == kExactWg && W > 1) {
+        if (RSEM_GX_PROFILE && impl == kExactTeam) {
             unsigned long long h[16];
             RSEM_HIP_TRY(hipMemcpyAsync(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost, st));
             RSEM_HIP_TRY(hipStreamSynchronize(st));
@@ -1354,17 +1292,6 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                             "redraw + clean-up %.0f | publish %.0f | team barrier %.0f | cross look-ups %.0f | commit + barrier %.0f ; phases %.2f ; tiles %.0f\n",
                     h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[8] / tiles, h[11] / tiles, h[5] / tiles, h[6] / tiles, h[10] / tiles,
                     h[13] / tiles, h[9] / tiles, tiles);
-        }
-        if (RSEM_GX_PROFILE && impl == kExactWg && W == 1) {
-            unsigned long long h[16];
-            RSEM_HIP_TRY(hipMemcpyAsync(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost, st));
-            RSEM_HIP_TRY(hipStreamSynchronize(st));
-            const double tiles = h[7] ? (double)h[7] : 1.0;
-            fprintf(stderr, "[gibbs exact wg] shader-clock cycles per tile of <= %d reads: stage %.0f | own flags %.0f | rng + gather %.0f | first draw %.0f | "
-                            "resolve %.0f (%.2f rounds) | commit %.0f ; tiles %.0f\n",
-                    kXT, h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[8] / tiles, h[5] / tiles, tiles);
-            fprintf(stderr, "[gibbs exact wg] inside the rounds: enter %.0f | barrier %.0f | scan %.0f | item walk %.0f (%.2f items of thread 0) | redraw %.0f | "
-                            "clean-up %.0f\n", h[9] / tiles, h[10] / tiles, h[11] / tiles, h[12] / tiles, h[15] / tiles, h[13] / tiles, h[14] / tiles);
         }
         if (dbg & 4) {
             unsigned long long h4[4] = {0, 0, 0, 0};

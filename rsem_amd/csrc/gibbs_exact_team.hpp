@@ -27,10 +27,16 @@
 // nothing is published decides, and in that pass nothing is written.  The random stream is position-addressed: read r of a sweep
 // takes the r-th output of the sweep whoever visits it, every workgroup carries its own copy of the generator and twists it
 // forward to the block its tile starts in.
-// A read with more items than a tile holds is a window of its own (workgroup 0 walks it over global memory, as before).
-// Uniform pseudo count only (see gibbs_exact_wg.hpp).
-#pragma once
+// A read with more items than a tile holds is a window of its own (workgroup 0 walks it over global memory).
+// W = 1 is one workgroup per chain: no table, no barrier, the phases of a window are the resolve rounds of its one tile.
+// Two passes like gibbs_exact_wg.hpp: the uniform pseudo count, and --prior inside namespace gx_prior.
 #include "gibbs_exact_wg.hpp"
+#if (!defined(RSEM_GX_PRIOR) && !defined(GX_TEAM_UNIFORM_PASS)) || (defined(RSEM_GX_PRIOR) && !defined(GX_TEAM_PRIOR_PASS))
+#ifdef RSEM_GX_PRIOR
+#define GX_TEAM_PRIOR_PASS
+#else
+#define GX_TEAM_UNIFORM_PASS
+#endif
 
 #ifndef GX_EMU
 #define GX_G_LOAD32(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -58,7 +64,7 @@
 #endif
 
 constexpr int kXTeamMax = 64;          // workgroups per chain at most (one 8-byte word of group cells: 4 groups of 16)
-constexpr int kXStep = 4;             // items per thread whose cells are loaded together in the cross look-ups
+constexpr int kXStep = kXPlanes % 4 == 0 ? 4 : (kXPlanes % 3 == 0 ? 3 : 2);  // items per thread whose cells are loaded together in the cross look-ups
 static_assert(kXPlanes % kXStep == 0, "whole steps");
 constexpr unsigned kXBias = 0x8080u;   // a cell holds net + bias (hipMemset with 0x80 makes an all-bias table)
 constexpr unsigned long long kXSpinLimit = 3000000000ull;  // wall-clock ticks (30 s) a workgroup waits for its team at most
@@ -190,7 +196,8 @@ GX_DEVFN int gx_team_barrier(int g, XTile* L, const XTeam& tm, unsigned long lon
 // Returns false when the team gave up (XTeamCtl::abort).
 template <bool kInit>
 GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
-                                    const double* __restrict__ cp, int32_t* counts, int32_t* z, double pseudoC, unsigned long long* prof) {
+                                    const double* __restrict__ cp, int32_t* counts, int32_t* z, double pseudoC,
+                                    const double* __restrict__ alpha /* --prior pass: pseudo_counts[M + 1]; else unused */, unsigned long long* prof) {
     const int lane = g & 63, w = g >> 6;
     const bool rd = kXThr == kXT || g < kXT;
     const int W = tm.W, tw = tm.tw;
@@ -336,17 +343,19 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
             auto load = [&](auto width, int k0, double* a) {
                 constexpr int Wd = decltype(width)::value;
                 int cc[Wd];
-                double pp[Wd];
+                double pp[Wd], aa[Wd];
 #pragma unroll
                 for (int j = 0; j < Wd; j++) {
                     const uint32_t at = fr + (uint32_t)(k0 + j < len ? k0 + j : last);
+                    aa[j] = 0.0;
                     pp[j] = L->p[at];
                     cc[j] = kInit ? 0 : L->c[at];
                     if (kDelta) cc[j] += (int)L->dl[at];
+                    if (kXPrior && !kInit) aa[j] = L->al[at];
                 }
 #pragma unroll
                 for (int j = 0; j < Wd; j++) {
-                    const double wgt = kInit ? pp[j] : ((double)cc[j] + pseudoC) * pp[j];
+                    const double wgt = kInit ? pp[j] : ((double)cc[j] + (kXPrior ? aa[j] : pseudoC)) * pp[j];  // Gibbs.cpp:300-303
                     a[j] = (k0 + j < len) ? wgt : 0.0;
                 }
             };
@@ -412,7 +421,7 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
                     const int s = sid[j];
                     const double p = cp[j];
                     if (kInit) return p;
-                    return ((double)GX_CNT_LOAD(&counts[s]) + pseudoC) * p;
+                    return ((double)GX_CNT_LOAD(&counts[s]) + (kXPrior ? alpha[s] : pseudoC)) * p;
                 };
                 double tot = 0.0;
                 for (uint64_t j = 0; j < n; j++) { const double a = wt(fr64 + j); tot = (j == 0) ? a : tot + a; }
@@ -436,6 +445,16 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
                 int cj[kXPlanes], zo[kXPlanes];
 #pragma unroll
                 for (int u = 0; u < kXPlanes; u++) cj[u] = GX_CNT_LOAD(&counts[sj[u]]);
+                if (kXPrior) {  // (the items' pseudo counts ride along with their counts: one round trip for both)
+                    double aj[kXPlanes];
+#pragma unroll
+                    for (int u = 0; u < kXPlanes; u++) aj[u] = alpha[sj[u]];
+#pragma unroll
+                    for (int u = 0; u < kXPlanes; u++) {
+                        const uint32_t j = (uint32_t)u * kXThr + g;
+                        if (j < T) L->al[j] = aj[u];
+                    }
+                }
                 int ow_[kXPlanes];
 #pragma unroll
                 for (int u = 0; u < kXPlanes; u++) {
@@ -725,3 +744,62 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
 #endif
     return true;
 }
+
+#ifndef GX_EMU
+struct TeamArgs {  // what every workgroup of every team needs (one argument: cooperative launches take an array of pointers)
+    int W, nchains;
+    XTeamCtl* ctl;       // [nchains]
+    uint32_t* net;       // [nchains][(M + 2) * nw]
+    uint32_t* gnet;      // [nchains][(M + 2) * 2]
+    int32_t* ref;        // [nchains][M + 2]
+    uint32_t nw;
+    const XSlot* slots;  // [n_win][W]
+    uint32_t n_win;
+    uint64_t N1;
+    int32_t M;
+};
+
+// Workgroup b belongs to chain b % nchains: workgroups are dealt to the 8 XCDs round-robin, so with 8 chains (or a divisor or
+// multiple of 8) a chain's team shares one XCD and its L2.  The generator is read from mt_in and handed on in mt_out (two
+// buffers: a launch without team barriers -- the initial assignment, W = 1 -- has workgroups that start after workgroup 0 has left).
+template <bool kInit>
+__global__ __launch_bounds__(kXThr) void k_gibbs_exact_team(TeamArgs ta, const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
+                                                          const double* __restrict__ cp, int32_t* counts_base, int32_t* z_base, double pseudoC,
+                                                          const double* __restrict__ alpha, const GxMtState* __restrict__ mt_in, GxMtState* mt_out,
+                                                          const int32_t* __restrict__ last_round, int round, uint64_t stride_c, uint64_t stride_z,
+                                                          unsigned long long* prof) {
+    __shared__ XTile tile;
+    const int chain = (int)(blockIdx.x % (unsigned)ta.nchains), tw = (int)(blockIdx.x / (unsigned)ta.nchains);
+    if (round > last_round[chain]) return;  // (uniform over the team)
+    const GxMtState* src = mt_in + chain;
+    for (int i = threadIdx.x; i < 624; i += blockDim.x) tile.mt[i] = src->mt[i];
+    if (threadIdx.x == 0) tile.idx = src->idx;
+    // the move-endpoint table starts out all zero (every resolve round leaves it that way)
+    for (int i = threadIdx.x; i < kXKeys * 2 * kXW; i += blockDim.x) (&tile.ends[0][0][0])[i] = 0ull;
+    for (int i = threadIdx.x; i < kXKeys; i += blockDim.x) tile.key[i] = 0;
+    for (int i = threadIdx.x; i < kXBits / 64; i += blockDim.x) tile.bits[i] = 0ull;
+    __syncthreads();
+    XTeam tm;
+    tm.W = ta.W;
+    tm.tw = tw;
+    tm.ctl = ta.ctl ? ta.ctl + chain : nullptr;
+    tm.net = ta.net ? ta.net + (size_t)chain * ((size_t)ta.M + 2) * ta.nw : nullptr;
+    tm.gnet = ta.gnet ? ta.gnet + (size_t)chain * ((size_t)ta.M + 2) * 2 : nullptr;
+    tm.ref = ta.ref ? ta.ref + (size_t)chain * ((size_t)ta.M + 2) : nullptr;
+    tm.nw = ta.nw;
+    tm.slots = ta.slots;
+    tm.n_win = ta.n_win;
+    tm.N1 = ta.N1;
+    tm.M = ta.M;
+    const bool ok = gibbs_exact_team_body<kInit>((int)threadIdx.x, &tile, tm, row_ptr, sid, cp, counts_base + (uint64_t)chain * stride_c,
+                                                 z_base + (uint64_t)chain * stride_z, pseudoC, alpha, prof);
+    __syncthreads();
+    if (ok && tw == 0) {
+        GxMtState* dst = mt_out + chain;
+        for (int i = threadIdx.x; i < 624; i += blockDim.x) dst->mt[i] = tile.mt[i];
+        if (threadIdx.x == 0) dst->idx = tile.idx;
+    }
+}
+#endif  // !GX_EMU
+
+#endif  // (pass guard)

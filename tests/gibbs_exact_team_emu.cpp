@@ -3,8 +3,9 @@
 // W workgroups of kXThr threads side by side, workgroup barriers and wave synchronisation points as real barriers, the team
 // barrier as the very spin loop the GPU runs, LDS / global atomics as CPU atomics.  Never part of the product.
 //
-//   gibbs_exact_team_emu in.bin out.bin W     in:  i32 M, N1, rounds, seed, N0, pad, pad, pad; f64 pseudoC
-//                                                  u64 row_ptr[N1+1]; i32 sid[n]; f64 cp[n]; i32 init_counts[M+1]
+//   gibbs_exact_team_emu in.bin out.bin W     in:  i32 M, N1, rounds, seed, N0, has_alpha, pad, pad; f64 pseudoC
+//                                                  u64 row_ptr[N1+1]; i32 sid[n]; f64 cp[n]; i32 init_counts[M+1]; [f64 alpha[M+1]]
+//   Built with -DRSEM_GX_PRIOR=1 it is the --prior pass of the two headers (per-transcript pseudo counts: has_alpha must be 1).
 //                                             out: i32 counts[rounds][M+1]  (after every sweep; the initial assignment is not dumped)
 //   stderr: windows, team barriers and cross iterations per sweep (how the tests know the team path was taken)
 #include <pthread.h>
@@ -88,6 +89,12 @@ int main(int argc, char** argv) {
     std::vector<int32_t> sid(n), init(M + 1);
     std::vector<double> cp(n);
     if (fread(sid.data(), 4, n, f) != n || fread(cp.data(), 8, n, f) != n || fread(init.data(), 4, M + 1, f) != (size_t)M + 1) return 2;
+    std::vector<double> alpha;
+    if (hdr[5]) {
+        alpha.resize(M + 1);
+        if (fread(alpha.data(), 8, M + 1, f) != (size_t)M + 1) return 2;
+    }
+    if (kXPrior != (hdr[5] != 0)) { fprintf(stderr, "this build is the %s pass\n", kXPrior ? "--prior" : "uniform pseudo count"); return 2; }
     fclose(f);
 
     std::vector<uint32_t> tiles;
@@ -138,9 +145,9 @@ int main(int argc, char** argv) {
             pthread_barrier_wait(&all);
             bool ok;
             if (round == 0)
-                ok = gibbs_exact_team_body<true>(tid, &mc.tile, tm, rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, nullptr);
+                ok = gibbs_exact_team_body<true>(tid, &mc.tile, tm, rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, kXPrior ? alpha.data() : nullptr, nullptr);
             else
-                ok = gibbs_exact_team_body<false>(tid, &mc.tile, tm, rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, nullptr);
+                ok = gibbs_exact_team_body<false>(tid, &mc.tile, tm, rp.data(), sid.data(), cp.data(), counts.data(), z.data(), pseudoC, kXPrior ? alpha.data() : nullptr, nullptr);
             if (!ok) failed = 1;
             pthread_barrier_wait(&all);
             if (k == 0 && tid == 0) {

@@ -1,6 +1,7 @@
-"""The per-wave body of the workgroup-per-chain exact Gibbs sampler (rsem_amd/csrc/gibbs_exact_wg.hpp -- the file gibbs.hip
-compiles for the GPU) run on the CPU by tests/gibbs_exact_emu.cpp: one OS thread per lane, four waves, the phases between
-workgroup barriers, the fixed-point rounds inside a tile.  Its count vectors after every sweep must be the oracle chain's (Gibbs.cpp:265-311 with
+"""The exact Gibbs sampler's sweep with ONE workgroup per chain (rsem_amd/csrc/gibbs_exact_team.hpp over gibbs_exact_wg.hpp -- the
+files gibbs.hip compiles for the GPU -- with a team of 1; teams of several workgroups: tests/test_gibbs_exact_team_emu_cpu.py)
+run on the CPU by tests/gibbs_exact_team_emu.cpp: one OS thread per lane, four waves, the phases between workgroup barriers, the
+fixed-point rounds inside a tile.  Its count vectors after every sweep must be the oracle chain's (Gibbs.cpp:265-311 with
 MT19937 and sampling.h's sample()) BIT FOR BIT -- on data built to collide: few transcripts, so that most reads of a tile
 share transcripts with earlier reads of the same tile, reads moving to and from the noise transcript, tiles cut short
 by the item capacity, a read longer than a tile holds.  No GPU involved."""
@@ -22,7 +23,7 @@ pytestmark = pytest.mark.skipif(CXX is None, reason="needs g++")
 def _build(tmp_path_factory, name, defs):
     exe = os.path.join(str(tmp_path_factory.mktemp(name)), name)
     subprocess.check_call([CXX, "-O1", "-std=c++17", "-pthread"] + defs + os.environ.get("RSEM_EMU_DEFS", "").split()  # (variant builds by hand)
-                          + [os.path.join(ROOT, "tests", "gibbs_exact_emu.cpp"), "-o", exe])
+                          + [os.path.join(ROOT, "tests", "gibbs_exact_team_emu.cpp"), "-o", exe])
     return exe
 
 
@@ -62,25 +63,27 @@ def _items(seed, M, N1, maxlen, noise_scale, long_read=0):
     return rp, sid, cp
 
 
-def _run(exe, M, rp, sid, cp, init, rounds, seed, N0, pseudoC, tile_items=0):
+def _run(exe, M, rp, sid, cp, init, rounds, seed, N0, pseudoC, tile_items=0, alpha=None, W=1):
     d = tempfile.mkdtemp()
     try:
         inp, outp = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
         with open(inp, "wb") as f:
-            f.write(np.array([M, len(rp) - 1, rounds, seed, N0, 0, 0, 0], np.int32).tobytes())
+            f.write(np.array([M, len(rp) - 1, rounds, seed, N0, 0 if alpha is None else 1, 0, 0], np.int32).tobytes())
             f.write(np.array([pseudoC], np.float64).tobytes())
             for a, t in ((rp, np.uint64), (sid, np.int32), (cp, np.float64), (init, np.int32)):
                 f.write(np.ascontiguousarray(a, t).tobytes())
-        subprocess.check_call([exe, inp, outp], timeout=1200)
+            if alpha is not None:
+                f.write(np.ascontiguousarray(alpha, np.float64).tobytes())
+        subprocess.check_call([exe, inp, outp, str(W)], timeout=1200, stderr=subprocess.DEVNULL)
         return np.fromfile(outp, np.int32).reshape(rounds, M + 1)
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
 
-def _oracle(M, rp, sid, cp, init, rounds, seed, N0, pseudoC):
+def _oracle(M, rp, sid, cp, init, rounds, seed, N0, pseudoC, alpha=None):
     eel, mw, grp = np.full(M + 1, 500.0), np.ones(M + 1), np.array([1, M + 1], np.int32)
     totc = (M + 1) * pseudoC + N0 + (len(rp) - 1)
-    cv, _ = orc.gibbs_chain(M, rp, sid, cp, init, None, pseudoC, totc, N0, eel, mw, grp, seed, 0, rounds, 1)
+    cv, _ = orc.gibbs_chain(M, rp, sid, cp, init, alpha, pseudoC, totc, N0, eel, mw, grp, seed, 0, rounds, 1)
     return cv
 
 
@@ -123,3 +126,24 @@ def test_a_predecessor_that_moves_back(emulator, seed):
     init = np.zeros(M + 1, np.int32)
     got = _run(emulator, M, rp, sid, cp, init, 40, seed, 0, 0.05)
     assert np.array_equal(got, _oracle(M, rp, sid, cp, init, 40, seed, 0, 0.05))
+
+
+@pytest.fixture(scope="module")
+def emulator_prior(tmp_path_factory):
+    """the --prior pass of the two headers (RSEM_GX_PRIOR: per-transcript pseudo counts, tiles of 3072 items)"""
+    return _build(tmp_path_factory, "gibbs_exact_emu_prior", ["-DRSEM_GX_PRIOR=1"])
+
+
+@pytest.mark.parametrize("W", [1, 3])
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[5]], ids=lambda c: "seed%d" % c["seed"])
+def test_chain_with_per_transcript_pseudo_counts(emulator_prior, case, W):
+    """--prior (Gibbs.cpp:171-194, 300-303): the weight of an item is (count + pseudo_counts[sid]) * conprb; same draws as the
+    oracle's chain with that alpha, with one workgroup per chain and with a team of three"""
+    c = dict(case)
+    rp, sid, cp = _items(c["seed"], c["M"], c["N1"], c["maxlen"], c["noise_scale"], c.get("long_read", 0))
+    init = np.zeros(c["M"] + 1, np.int32)
+    alpha = np.random.default_rng(100 + c["seed"]).uniform(0.05, 3.0, c["M"] + 1)
+    alpha[0] = 1.0
+    got = _run(emulator_prior, c["M"], rp, sid, cp, init, c["rounds"], 1000 + c["seed"], c["N0"], c["pseudoC"], alpha=alpha, W=W)
+    want = _oracle(c["M"], rp, sid, cp, init, c["rounds"], 1000 + c["seed"], c["N0"], c["pseudoC"], alpha=alpha)
+    assert np.array_equal(got, want)

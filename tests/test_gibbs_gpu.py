@@ -133,26 +133,35 @@ def test_exact_tile_kernel_at_scale_vs_oracle_and_serial_kernel(n_reads, long_ev
     ctx.close()
 
 
-@pytest.mark.parametrize("n_reads,long_every,chains", [(150_000, 0, 8), (30_000, 4000, 3), (60_000, 0, 1)])
-def test_exact_chain_is_the_same_for_every_team_size(n_reads, long_every, chains, monkeypatch):
+@pytest.mark.parametrize("n_reads,long_every,chains,prior", [(150_000, 0, 8, False), (30_000, 4000, 3, False), (60_000, 0, 1, False),
+                                                             (120_000, 0, 8, True), (30_000, 3500, 2, True)])
+def test_exact_chain_is_the_same_for_every_team_size(n_reads, long_every, chains, prior, monkeypatch):
     """k_gibbs_exact_team (gibbs_exact_team.hpp): W workgroups per chain take W tiles of a window at once and settle the moves
     between them through the team's tables.  Whatever W is -- one workgroup per chain (the kernel of rounds 3-4), 2, 7 (no
     divisor of anything), 16 / 17 (the boundary of the group cells), what the device offers for this many chains -- the count
-    vectors are the same integers, and they are the oracle's sequential chain's."""
+    vectors are the same integers, and they are the oracle's sequential chain's.  prior: per-transcript pseudo counts (--prior,
+    Gibbs.cpp:171-194,300-303) -- the second pass of the kernel's headers (tiles of 3072 items), also against the one-wave kernel."""
     M, (irp, isid, icp) = _synthetic_items(n_reads, long_row_every=long_every)
     init = np.zeros(M + 1, np.int32)
     N0, pseudoC = 777, 1.0
+    alpha = np.concatenate([[1.0], np.random.default_rng(8).uniform(0.05, 3.0, M)]) if prior else None
     eel, mw = np.full(M + 1, 700.0), np.ones(M + 1)
     grp = np.array([1, M + 1], np.int32)
     totc = (M + 1) * pseudoC + N0 + n_reads
     seeds = capi().gibbs_chain_seeds(4242, chains)
     ns = [2 + (k % 2) for k in range(chains)]
     burnin, gap = 2, 2
-    ctx = capi().GibbsContext(M, irp, isid, icp, init, None, pseudoC, totc, N0, eel, mw, grp)
+    ctx = capi().GibbsContext(M, irp, isid, icp, init, alpha, pseudoC, totc, N0, eel, mw, grp)
     monkeypatch.setenv("RSEM_GX_TEAM", "1")
     base, acc1, _, p1 = ctx.run_chains(capi().GIBBS_EXACT, seeds, burnin, ns, gap)
-    ocv, _ = orc.gibbs_chain(M, irp, isid, icp, init, None, pseudoC, totc, N0, eel, mw, grp, seeds[0], burnin, ns[0], gap)
+    ocv, _ = orc.gibbs_chain(M, irp, isid, icp, init, alpha, pseudoC, totc, N0, eel, mw, grp, seeds[0], burnin, ns[0], gap)
     assert np.array_equal(base[0], ocv)
+    if prior:
+        monkeypatch.setenv("RSEM_GIBBS_EXACT_IMPL", "coop")
+        cvs_c, _, _, _ = ctx.run_chains(capi().GIBBS_EXACT, seeds, burnin, ns, gap)
+        monkeypatch.delenv("RSEM_GIBBS_EXACT_IMPL")
+        for k in range(chains):
+            assert np.array_equal(cvs_c[k], base[k])
     times = {1: p1.sweep_ms}
     for W in (2, 7, 16, 17, 0):
         if W:
