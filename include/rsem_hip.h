@@ -319,6 +319,14 @@ int rsem_ci_calculate(int device, int32_t M, int32_t nCV, int32_t nSpC, const in
                       const int32_t* gene_starts, int32_t m_trans, const int32_t* trans_starts, float* tpm_ci,
                       float* fpkm_ci, float* gene_tpm_ci, float* gene_fpkm_ci, float* iso_tpm_ci, float* iso_fpkm_ci,
                       rsem_ci_profile* prof);
+/* The same with the samples GIVEN: tpm_samples M x nSamples float (row j-1 = transcript j, TPM), l_bars nSamples -- the layout of
+ * the reference's temporary file (Buffer.h:66-80).  For a caller that draws them itself: rsem-calculate-credibility-intervals
+ * --ci-stream reference reproduces the reference's per-thread MT19937 + boost gamma draws on the host (csrc/host/ci_stream.hpp:
+ * a stream whose consumption depends on the values drawn cannot be cut into device-sized pieces) and hands them over here. */
+int rsem_ci_calculate_samples(int device, int32_t M, int32_t nSamples, const float* tpm_samples, const float* l_bars, double confidence,
+                              int32_t m, const int32_t* gene_starts, int32_t m_trans, const int32_t* trans_starts, float* tpm_ci,
+                              float* fpkm_ci, float* gene_tpm_ci, float* gene_fpkm_ci, float* iso_tpm_ci, float* iso_fpkm_ci,
+                              rsem_ci_profile* prof);
 /* The sampling stage alone (tests): tpm_samples M x (nCV*nSpC) float, row j-1 = transcript j, as the reference's
  * temporary file (Buffer.h:66-80); l_bars nCV*nSpC. */
 int rsem_ci_sample(int device, int32_t M, int32_t nCV, int32_t nSpC, const int32_t* cvecs, const double* eel,

@@ -378,6 +378,86 @@ extern "C" int rsem_ci_sample(int device, int32_t M, int32_t nCV, int32_t nSpC, 
     return rc;
 }
 
+namespace {
+
+// Everything behind the sampling stage (calcCI.cpp:286-388): per transcript, per gene and -- for an allele-specific reference --
+// per transcript over its alleles: sort the row's samples, shortest interval, quartile statistics; TPM and FPKM.  S holds the
+// samples on the device (Y: M x nS; TPM of sample s = (float)(Y * sc[s])).
+int ci_after_sampling(Sampler& S, int32_t M, int32_t nS, double confidence, int32_t m, const int32_t* gene_starts, int32_t m_trans,
+                      const int32_t* trans_starts, float* tpm_ci, float* fpkm_ci, float* gene_tpm_ci, float* gene_fpkm_ci, float* iso_tpm_ci,
+                      float* iso_fpkm_ci, hipStream_t st, RowSorter& sorter) {
+    const bool allele = trans_starts != nullptr;
+    DevMem mem;
+    float* d_keys = nullptr;
+    int32_t *d_gb = nullptr, *d_ge = nullptr;
+    const int64_t R = batch_rows(nS, M);
+    int rc = sorter.init(nS, R, st);
+    if (rc == RSEM_OK && (mem.alloc(&d_keys, (size_t)R * nS) != hipSuccess || mem.alloc(&d_gb, (size_t)R) != hipSuccess ||
+                          mem.alloc(&d_ge, (size_t)R) != hipSuccess)) {
+        rsem::set_last_error("out of device memory"); rc = RSEM_ERR_NOMEM;
+    }
+    // per transcript (calcCI.cpp:343-354)
+    for (int pass = 0; rc == RSEM_OK && pass < 2; pass++) {
+        float* out = pass ? fpkm_ci : tpm_ci;
+        for (int64_t r0 = 0; rc == RSEM_OK && r0 < M; r0 += R) {
+            const int64_t n = std::min<int64_t>(R, M - r0);
+            hipLaunchKernelGGL(k_ci_keys_rows, dim3(rsem::ceil_div((uint64_t)n * nS, kBlock)), dim3(kBlock), 0, st, nS, S.d_Y, S.d_sc,
+                               S.d_lbar, r0, n, pass == 1, d_keys);
+            rc = sorter.run(d_keys, n, confidence, out + r0, out + (size_t)M + r0, out + 2 * (size_t)M + r0);
+        }
+    }
+    // groups: genes, and transcripts of an allele-specific reference.  Single-member groups copy their member's
+    // interval (calcCI.cpp:356-363, 330-337); the others sort the float sums of their members' rows.
+    auto groups = [&](int32_t ng, const int32_t* starts, float* out_t, float* out_f) -> int {
+        std::vector<int32_t> multi;
+        for (int g = 0; g < ng; g++) {
+            const int b = starts[g], e = starts[g + 1];
+            if (e - b > 1) multi.push_back(g);
+            else if (e - b == 1)
+                for (int k = 0; k < 3; k++) {
+                    out_t[(size_t)k * ng + g] = tpm_ci[(size_t)k * M + b - 1];
+                    out_f[(size_t)k * ng + g] = fpkm_ci[(size_t)k * M + b - 1];
+                }
+            else
+                for (int k = 0; k < 3; k++) out_t[(size_t)k * ng + g] = out_f[(size_t)k * ng + g] = 0.0f;
+        }
+        std::vector<int32_t> gb, ge;
+        std::vector<float> lb, ub, cq;
+        for (size_t i0 = 0; i0 < multi.size(); i0 += (size_t)R) {
+            const size_t n = std::min<size_t>((size_t)R, multi.size() - i0);
+            gb.resize(n); ge.resize(n); lb.resize(n); ub.resize(n); cq.resize(n);
+            for (size_t i = 0; i < n; i++) { gb[i] = starts[multi[i0 + i]]; ge[i] = starts[multi[i0 + i] + 1]; }
+            RSEM_HIP_TRY(hipMemcpyAsync(d_gb, gb.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+            RSEM_HIP_TRY(hipMemcpyAsync(d_ge, ge.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+            for (int pass = 0; pass < 2; pass++) {
+                hipLaunchKernelGGL(k_ci_keys_groups, dim3(rsem::ceil_div((uint64_t)n * nS, kBlock)), dim3(kBlock), 0, st, nS, S.d_Y, S.d_sc,
+                                   S.d_lbar, d_gb, d_ge, (int64_t)n, pass == 1, d_keys);
+                int r = sorter.run(d_keys, (int64_t)n, confidence, lb.data(), ub.data(), cq.data());
+                if (r != RSEM_OK) return r;
+                float* out = pass ? out_f : out_t;
+                for (size_t i = 0; i < n; i++) {
+                    const int g = multi[i0 + i];
+                    out[g] = lb[i]; out[(size_t)ng + g] = ub[i]; out[2 * (size_t)ng + g] = cq[i];
+                }
+            }
+        }
+        return RSEM_OK;
+    };
+    if (rc == RSEM_OK) rc = groups(m, gene_starts, gene_tpm_ci, gene_fpkm_ci);
+    if (rc == RSEM_OK && allele) rc = groups(m_trans, trans_starts, iso_tpm_ci, iso_fpkm_ci);
+    return rc;
+}
+
+int ci_check_groups(int32_t M, const int32_t* gene_starts, int32_t m, const int32_t* trans_starts, int32_t m_trans, double confidence,
+                    const float* iso_tpm_ci, const float* iso_fpkm_ci) {
+    RSEM_REQUIRE(m > 0 && gene_starts[0] == 1 && gene_starts[m] == M + 1, "gene_starts must run from 1 to M+1");
+    RSEM_REQUIRE(confidence > 0.0 && confidence <= 1.0, "confidence must be in (0, 1]");
+    if (trans_starts) RSEM_REQUIRE(m_trans > 0 && iso_tpm_ci && iso_fpkm_ci && trans_starts[0] == 1 && trans_starts[m_trans] == M + 1, "bad trans_starts");
+    return RSEM_OK;
+}
+
+}  // namespace
+
 extern "C" int rsem_ci_calculate(int device, int32_t M, int32_t nCV, int32_t nSpC, const int32_t* cvecs, const double* eel,
                                  const double* mw, double pseudoC, uint64_t seed, double confidence, int32_t m,
                                  const int32_t* gene_starts, int32_t m_trans, const int32_t* trans_starts, float* tpm_ci,
@@ -386,10 +466,8 @@ extern "C" int rsem_ci_calculate(int device, int32_t M, int32_t nCV, int32_t nSp
     int rc = check_common(M, nCV, nSpC);
     if (rc != RSEM_OK) return rc;
     RSEM_REQUIRE(cvecs && eel && mw && gene_starts && tpm_ci && fpkm_ci && gene_tpm_ci && gene_fpkm_ci, "null argument");
-    RSEM_REQUIRE(m > 0 && gene_starts[0] == 1 && gene_starts[m] == M + 1, "gene_starts must run from 1 to M+1");
-    RSEM_REQUIRE(confidence > 0.0 && confidence <= 1.0, "confidence must be in (0, 1]");
-    const bool allele = trans_starts != nullptr;
-    if (allele) RSEM_REQUIRE(m_trans > 0 && iso_tpm_ci && iso_fpkm_ci && trans_starts[0] == 1 && trans_starts[m_trans] == M + 1, "bad trans_starts");
+    rc = ci_check_groups(M, gene_starts, m, trans_starts, m_trans, confidence, iso_tpm_ci, iso_fpkm_ci);
+    if (rc != RSEM_OK) return rc;
     RSEM_HIP_TRY(hipSetDevice(device));
     StreamGuard sg;
     RSEM_HIP_TRY(sg.create());
@@ -402,65 +480,10 @@ extern "C" int rsem_ci_calculate(int device, int32_t M, int32_t nCV, int32_t nSp
     {
         Sampler S;
         RowSorter sorter;
-        DevMem mem;
-        float* d_keys = nullptr;
-        int32_t *d_gb = nullptr, *d_ge = nullptr;
-        const int64_t R = batch_rows(nS, M);
         rc = S.run(M, nCV, nSpC, cvecs, eel, mw, pseudoC, seed, st);
-        if (rc == RSEM_OK) rc = sorter.init(nS, R, st);
-        if (rc == RSEM_OK && (mem.alloc(&d_keys, (size_t)R * nS) != hipSuccess || mem.alloc(&d_gb, (size_t)R) != hipSuccess ||
-                              mem.alloc(&d_ge, (size_t)R) != hipSuccess)) {
-            rsem::set_last_error("out of device memory"); rc = RSEM_ERR_NOMEM;
-        }
-        // per transcript (calcCI.cpp:343-354)
-        for (int pass = 0; rc == RSEM_OK && pass < 2; pass++) {
-            float* out = pass ? fpkm_ci : tpm_ci;
-            for (int64_t r0 = 0; rc == RSEM_OK && r0 < M; r0 += R) {
-                const int64_t n = std::min<int64_t>(R, M - r0);
-                hipLaunchKernelGGL(k_ci_keys_rows, dim3(rsem::ceil_div((uint64_t)n * nS, kBlock)), dim3(kBlock), 0, st, nS, S.d_Y, S.d_sc,
-                                   S.d_lbar, r0, n, pass == 1, d_keys);
-                rc = sorter.run(d_keys, n, confidence, out + r0, out + (size_t)M + r0, out + 2 * (size_t)M + r0);
-            }
-        }
-        // groups: genes, and transcripts of an allele-specific reference.  Single-member groups copy their member's
-        // interval (calcCI.cpp:356-363, 330-337); the others sort the float sums of their members' rows.
-        auto groups = [&](int32_t ng, const int32_t* starts, float* out_t, float* out_f) -> int {
-            std::vector<int32_t> multi;
-            for (int g = 0; g < ng; g++) {
-                const int b = starts[g], e = starts[g + 1];
-                if (e - b > 1) multi.push_back(g);
-                else if (e - b == 1)
-                    for (int k = 0; k < 3; k++) {
-                        out_t[(size_t)k * ng + g] = tpm_ci[(size_t)k * M + b - 1];
-                        out_f[(size_t)k * ng + g] = fpkm_ci[(size_t)k * M + b - 1];
-                    }
-                else
-                    for (int k = 0; k < 3; k++) out_t[(size_t)k * ng + g] = out_f[(size_t)k * ng + g] = 0.0f;
-            }
-            std::vector<int32_t> gb, ge;
-            std::vector<float> lb, ub, cq;
-            for (size_t i0 = 0; i0 < multi.size(); i0 += (size_t)R) {
-                const size_t n = std::min<size_t>((size_t)R, multi.size() - i0);
-                gb.resize(n); ge.resize(n); lb.resize(n); ub.resize(n); cq.resize(n);
-                for (size_t i = 0; i < n; i++) { gb[i] = starts[multi[i0 + i]]; ge[i] = starts[multi[i0 + i] + 1]; }
-                RSEM_HIP_TRY(hipMemcpyAsync(d_gb, gb.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
-                RSEM_HIP_TRY(hipMemcpyAsync(d_ge, ge.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
-                for (int pass = 0; pass < 2; pass++) {
-                    hipLaunchKernelGGL(k_ci_keys_groups, dim3(rsem::ceil_div((uint64_t)n * nS, kBlock)), dim3(kBlock), 0, st, nS, S.d_Y, S.d_sc,
-                                       S.d_lbar, d_gb, d_ge, (int64_t)n, pass == 1, d_keys);
-                    int r = sorter.run(d_keys, (int64_t)n, confidence, lb.data(), ub.data(), cq.data());
-                    if (r != RSEM_OK) return r;
-                    float* out = pass ? out_f : out_t;
-                    for (size_t i = 0; i < n; i++) {
-                        const int g = multi[i0 + i];
-                        out[g] = lb[i]; out[(size_t)ng + g] = ub[i]; out[2 * (size_t)ng + g] = cq[i];
-                    }
-                }
-            }
-            return RSEM_OK;
-        };
-        if (rc == RSEM_OK) rc = groups(m, gene_starts, gene_tpm_ci, gene_fpkm_ci);
-        if (rc == RSEM_OK && allele) rc = groups(m_trans, trans_starts, iso_tpm_ci, iso_fpkm_ci);
+        if (rc == RSEM_OK)
+            rc = ci_after_sampling(S, M, nS, confidence, m, gene_starts, m_trans, trans_starts, tpm_ci, fpkm_ci, gene_tpm_ci, gene_fpkm_ci, iso_tpm_ci,
+                                   iso_fpkm_ci, st, sorter);
         if (rc == RSEM_OK) {
             hipError_t e = hipEventRecord(t1, st);
             if (e == hipSuccess) e = hipEventSynchronize(t1);
@@ -470,6 +493,50 @@ extern "C" int rsem_ci_calculate(int device, int32_t M, int32_t nCV, int32_t nSp
             if (prof) {
                 prof->sample_ms = S.sample_ms; prof->sort_ms = sorter.sort_ms; prof->interval_ms = sorter.interval_ms; prof->total_ms = ms;
                 prof->n_draws = (uint64_t)M * nS; prof->n_keys_sorted = sorter.n_keys;
+            }
+        }
+    }
+    return rc;
+}
+
+extern "C" int rsem_ci_calculate_samples(int device, int32_t M, int32_t nSamples, const float* tpm_samples, const float* l_bars, double confidence,
+                                         int32_t m, const int32_t* gene_starts, int32_t m_trans, const int32_t* trans_starts, float* tpm_ci,
+                                         float* fpkm_ci, float* gene_tpm_ci, float* gene_fpkm_ci, float* iso_tpm_ci, float* iso_fpkm_ci,
+                                         rsem_ci_profile* prof) {
+    RSEM_REQUIRE(M > 0 && nSamples > 0 && nSamples < (1 << 30), "M and nSamples must be positive (nSamples < 2^30)");
+    RSEM_REQUIRE(tpm_samples && l_bars && gene_starts && tpm_ci && fpkm_ci && gene_tpm_ci && gene_fpkm_ci, "null argument");
+    int rc = ci_check_groups(M, gene_starts, m, trans_starts, m_trans, confidence, iso_tpm_ci, iso_fpkm_ci);
+    if (rc != RSEM_OK) return rc;
+    RSEM_HIP_TRY(hipSetDevice(device));
+    StreamGuard sg;
+    RSEM_HIP_TRY(sg.create());
+    hipStream_t st = sg.s;
+    const int32_t nS = nSamples;
+    EventGuard gt0, gt1;
+    RSEM_HIP_TRY(gt0.create()); RSEM_HIP_TRY(gt1.create());
+    RSEM_HIP_TRY(hipEventRecord(gt0.e, st));
+    {
+        Sampler S;  // filled from the caller's samples: Y = the TPM values themselves, every scale 1
+        RowSorter sorter;
+        RSEM_HIP_TRY(S.mem.alloc(&S.d_Y, (size_t)M * nS));
+        RSEM_HIP_TRY(S.mem.alloc(&S.d_sc, (size_t)nS));
+        RSEM_HIP_TRY(S.mem.alloc(&S.d_lbar, (size_t)nS));
+        std::vector<double> ones((size_t)nS, 1.0);
+        RSEM_HIP_TRY(hipMemcpyAsync(S.d_Y, tpm_samples, sizeof(float) * (size_t)M * nS, hipMemcpyHostToDevice, st));
+        RSEM_HIP_TRY(hipMemcpyAsync(S.d_sc, ones.data(), sizeof(double) * nS, hipMemcpyHostToDevice, st));
+        RSEM_HIP_TRY(hipMemcpyAsync(S.d_lbar, l_bars, sizeof(float) * nS, hipMemcpyHostToDevice, st));
+        RSEM_HIP_TRY(hipStreamSynchronize(st));  // (`ones` is a local)
+        rc = ci_after_sampling(S, M, nS, confidence, m, gene_starts, m_trans, trans_starts, tpm_ci, fpkm_ci, gene_tpm_ci, gene_fpkm_ci, iso_tpm_ci,
+                               iso_fpkm_ci, st, sorter);
+        if (rc == RSEM_OK) {
+            hipError_t e = hipEventRecord(gt1.e, st);
+            if (e == hipSuccess) e = hipEventSynchronize(gt1.e);
+            float ms = 0;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, gt0.e, gt1.e);
+            if (e != hipSuccess) { rsem::set_last_error("event timing failed"); rc = RSEM_ERR_HIP; }
+            if (prof) {
+                prof->sample_ms = 0.0; prof->sort_ms = sorter.sort_ms; prof->interval_ms = sorter.interval_ms; prof->total_ms = ms;
+                prof->n_draws = 0; prof->n_keys_sorted = sorter.n_keys;
             }
         }
     }

@@ -2,7 +2,7 @@
 // (calcCI.cpp:489-581).
 //
 //   rsem-calculate-credibility-intervals refName imdName statName confidence nCV nSpC nMB
-//                                        [-p #Threads] [--seed seed] [--pseudo-count a] [-q]     + [--device d]
+//                                        [-p #Threads] [--seed seed] [--pseudo-count a] [-q]     + [--device d] [--ci-stream device|reference]
 //
 // reads   refName.{seq,grp[,ta]}, statName.model (gld + mw), imdName.countvectors<k> for k < min(#Threads, nCV)
 // appends six rows (TPM lb / ub / cqv, FPKM lb / ub / cqv, "%.6g") to imdName.iso_res (allele_res when the
@@ -11,6 +11,10 @@
 // nMB (the reference's buffer before it spills the sample matrix to imdName.tmp) is accepted and ignored: the matrix
 // stays in HBM (rsem_ci_calculate, rsem_amd/csrc/ci.hip).  -p only tells how many count-vector files rsem-run-gibbs
 // wrote.  Without --seed the generator is seeded from the clock, as the reference's is (sampling.h:21-24).
+//
+// --ci-stream device (the default): the expression samples are drawn on the GPU from a counter-based generator -- the reference's
+// distribution, not its draws.  --ci-stream reference: the reference's own per-thread MT19937 + boost gamma draws for this
+// --seed and -p (host/ci_stream.hpp, on -p host threads like the reference's), the intervals on the GPU: the reference's numbers.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +23,7 @@
 #include <vector>
 
 #include "../../../include/rsem_hip.h"
+#include "ci_stream.hpp"
 #include "files.hpp"
 #include "model_host.hpp"
 #include "results.hpp"
@@ -58,7 +63,7 @@ int main(int argc, char* argv[]) {
     const double confidence = atof(argv[4]);
     const int nCV = atoi(argv[5]), nSpC = atoi(argv[6]);
     int nThreads = 1, device = 0;
-    bool quiet = false, hasSeed = false;
+    bool quiet = false, hasSeed = false, refStream = false;
     uint64_t seed = 0;
     double pseudoC = 1.0;
     for (int i = 8; i < argc; i++) {  // calcCI.cpp:507-518
@@ -72,6 +77,10 @@ int main(int argc, char* argv[]) {
         if (!strcmp(argv[i], "--pseudo-count") && i + 1 < argc) pseudoC = atof(argv[i + 1]);
         if (!strcmp(argv[i], "-q")) quiet = true;
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--ci-stream") && i + 1 < argc) {
+            if (!strcmp(argv[i + 1], "reference")) refStream = true;
+            else if (strcmp(argv[i + 1], "device")) die("--ci-stream: device or reference");
+        }
     }
     const bool verbose = !quiet;
     if (!hasSeed) seed = (uint64_t)std::chrono::system_clock::now().time_since_epoch().count();
@@ -129,9 +138,37 @@ int main(int argc, char* argv[]) {
     std::vector<float> tpm(3 * (size_t)M), fpkm(3 * (size_t)M), gtpm(3 * (size_t)m), gfpkm(3 * (size_t)m), itpm(3 * (size_t)m_trans),
         ifpkm(3 * (size_t)m_trans);
     rsem_ci_profile prof;
-    const int rc = rsem_ci_calculate(device, M, nCV, nSpC, cvecs.data(), eel.data(), model.mw.data(), pseudoC, seed, confidence, m,
-                                     gi.starts.data(), m_trans, alleleS ? ta.starts.data() : nullptr, tpm.data(), fpkm.data(), gtpm.data(),
-                                     gfpkm.data(), alleleS ? itpm.data() : nullptr, alleleS ? ifpkm.data() : nullptr, &prof);
+    int rc;
+    if (!refStream) {
+        rc = rsem_ci_calculate(device, M, nCV, nSpC, cvecs.data(), eel.data(), model.mw.data(), pseudoC, seed, confidence, m,
+                               gi.starts.data(), m_trans, alleleS ? ta.starts.data() : nullptr, tpm.data(), fpkm.data(), gtpm.data(),
+                               gfpkm.data(), alleleS ? itpm.data() : nullptr, alleleS ? ifpkm.data() : nullptr, &prof);
+    } else {
+        // The reference's draws: thread t takes the count vectors of imdName.countvectors<t> and the t-th engine of the factory
+        // (calcCI.cpp:171-187).  The columns of the sample matrix are laid thread after thread (the reference's own column order is
+        // the order in which its threads happen to reach the buffer: no result depends on it).
+        const size_t nS = (size_t)nCV * nSpC;
+        std::vector<float> samples((size_t)M * nS), l_bars(nS);
+        const std::vector<uint32_t> seeds = ref_engine_seeds((uint32_t)seed, nfiles);
+        std::vector<size_t> col0(nfiles + 1, 0);
+        for (int k = 0; k < nfiles; k++) col0[k + 1] = col0[k] + parts[k].size() / ((size_t)M + 1) * nSpC;
+        std::vector<int> ok(nfiles, 1);
+        const auto t0 = std::chrono::steady_clock::now();
+        parallel_for(nfiles, [&](int k) {
+            RefMt19937 eng(seeds[k]);
+            ok[k] = ref_sample_thread(eng, M, parts[k].data(), (int)(parts[k].size() / ((size_t)M + 1)), nSpC, pseudoC, eel.data(), model.mw.data(), nS,
+                                      col0[k], samples.data(), l_bars.data());
+        });
+        for (int k = 0; k < nfiles; k++)
+            if (!ok[k]) die("a sampled expression vector sums to less than EPSILON (the reference stops at an assert here, calcCI.cpp:135,143)");
+        const double host_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        rc = rsem_ci_calculate_samples(device, M, (int32_t)nS, samples.data(), l_bars.data(), confidence, m, gi.starts.data(), m_trans,
+                                       alleleS ? ta.starts.data() : nullptr, tpm.data(), fpkm.data(), gtpm.data(), gfpkm.data(),
+                                       alleleS ? itpm.data() : nullptr, alleleS ? ifpkm.data() : nullptr, &prof);
+        prof.sample_ms = host_s * 1e3;
+        prof.n_draws = (uint64_t)M * nS;
+        if (verbose) printf("[host] the reference's stream: %d engines, %.1f ms\n", nfiles, host_s * 1e3);
+    }
     if (rc != RSEM_OK) die("rsem-calculate-credibility-intervals: %s: %s", rsem_hip_strerror(rc), rsem_hip_last_error());
     if (verbose) {
         printf("Sampling is finished!\n");

@@ -29,9 +29,6 @@
 #pragma once
 #include "simt_macros.hpp"
 
-#ifndef RSEM_MODEL_AHEAD
-#define RSEM_MODEL_AHEAD 0
-#endif
 constexpr int kProfLds = 5120;  // doubles of the profile COUNT table kept in LDS (Q: 2500; no-Q: 204 positions)
 constexpr int kGldLds = 1024;
 constexpr int kRspdLds = 128;
@@ -332,8 +329,9 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
     constexpr int kMates = kPE ? 2 : 1;
     // What the kernel needs to know about a read before it can ask for anything else (its row header), loaded for a row that
     // exists (the last one stands in for the rows past the end) and masked afterwards: a load under a condition is a branch with
-    // a wait of its own.  -DRSEM_MODEL_AHEAD=1: the header of the NEXT step's read is requested at the top of a step and used a
-    // step later (10 more registers per lane), so that a step starts with its first dependent round trip already made.
+    // a wait of its own.  (Requesting the NEXT step's header at the top of a step and using it a step later -- 10 more registers per
+    // lane -- bought nothing: 13.15 against 13.17 ms per round at a fifth of configs[2], and 20.8 ms with three waves per SIMD to
+    // make room for it, profiles/r05q_model_rounds_header_ahead.log.  The step's first round trip is not what the kernel waits for.)
     struct RowHdr {
         uint8_t lq;
         uint64_t fr, to;
@@ -354,19 +352,10 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
         H.rank = PO.rank ? PO.rank[rowc] : 0u;
         return H;
     };
-#if RSEM_MODEL_AHEAD
-    RowHdr Hnext = load_hdr(row0 + (uint64_t)(lane >> 4));
-#endif
     for (uint64_t rbase = row0; rbase < D.N1; rbase += row_stride) {  // (wave-uniform)
         const uint64_t row = rbase + (uint64_t)(lane >> 4);
         const bool valid = row < D.N1;
-#if RSEM_MODEL_AHEAD
-        const RowHdr H = Hnext;
-        Hnext = load_hdr(row + row_stride);
-        RSEM_SCHED_FENCE();  // (keep the requests up here: the scheduler would sink them to their use, a step later)
-#else
         const RowHdr H = load_hdr(row);
-#endif
         const uint8_t lq_v = H.lq;
         const uint64_t fr_v = H.fr, to_v = H.to;
         uint64_t r8_v[2] = {H.r8[0], H.r8[1]};

@@ -303,6 +303,42 @@ def test_transcript_bam_matches_reference(name, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["se_noq", "se_q", "pe_q", "se_q_polya_rspd", "se_q_allele"])
+def test_credibility_intervals_with_the_reference_stream_are_the_reference_rows(name, tmp_path):
+    """--ci-stream reference: the reference's own draws (per-thread MT19937 seeded by the engine factory, boost's gamma
+    distribution, calcCI.cpp:93-164, sampling.h:19-44; restated in csrc/host/ci_stream.hpp) for the same --seed and -p, the
+    intervals on the GPU: the six appended rows are the rows the REFERENCE BINARY appended (ci_stat golden, same argv) -- not
+    statistically, but value for value as printed with %.6g (a last printed digit may differ where the host's libm rounds a
+    transcendental differently from the machine the golden was made on; the fixtures were made with this image's)."""
+    fx, dst = _stage(name, tmp_path)
+    meta = rf.read_meta(fx)
+    nCV = int(meta["gibbs"][1])
+    threads = int(meta["gibbs_threads"])
+    pc = meta.get("pseudo_count_x1000", 1000) / 1000.0
+    imd = os.path.join(dst, "temp", "s")
+    res_files = [f for f in ("iso_res", "gene_res", "allele_res") if os.path.exists(imd + "." + f)]
+    before = {f: open(imd + "." + f).read() for f in res_files}
+    cmd = [os.path.join(BIN, "rsem-calculate-credibility-intervals"), os.path.join(dst, "ref"), imd, os.path.join(dst, "stat", "s"),
+           "0.95", str(nCV), "500", "1024", "-p", str(threads), "--seed", "777", "-q", "--ci-stream", "reference"]
+    if pc != 1.0:
+        cmd += ["--pseudo-count", str(pc)]
+    _run(cmd)
+    n_fields = n_same = 0
+    for f in res_files:
+        after = open(imd + "." + f).read()
+        assert after.startswith(before[f])
+        new = after[len(before[f]):].strip("\n").split("\n")
+        gold = open(os.path.join(fx, "ci_stat", f + ".txt")).read().strip().split("\n")
+        assert len(new) == 6 and len(gold) == 6
+        for a, b in zip(new, gold):
+            fa, fb = a.split("\t"), b.split("\t")
+            assert len(fa) == len(fb)
+            n_fields += len(fa)
+            n_same += sum(x == y for x, y in zip(fa, fb))
+            assert np.allclose(np.array(fa, float), np.array(fb, float), rtol=2e-5, atol=1e-9)
+    assert n_same >= 0.995 * n_fields, (n_same, n_fields)
+
+
+@pytest.mark.parametrize("name", ["se_noq", "se_q", "pe_q", "se_q_polya_rspd", "se_q_allele"])
 def test_rsem_calculate_credibility_intervals_cli(name, tmp_path):
     """Drop-in rsem-calculate-credibility-intervals on the fixture's own count vectors: six "%.6g" rows appended to
     every result file, statistically equal to the rows the reference binary appended (ci_stat golden, same argv;

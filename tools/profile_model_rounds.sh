@@ -5,7 +5,7 @@ N=${1:-5263157}; M=${2:-200000}; D=/tmp/pmr
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf $D; tools/bin/gen_temp $D $N $M 3 20250925 100 nosam 5-16 | tail -1
 tools/bin/temp_to_rsb $D/temp/s $D/stat/s 3 > /dev/null
-# a mode "lib:<tag>" runs the default kernels of the variant build rsem_amd/librsem_hip_<tag>.so (tools/build_model_variant.sh)
+# a mode "lib:<tag>" runs the default kernels of the variant build rsem_amd/librsem_hip_<tag>.so (built like tools/build_variants.sh builds its own, with model.hip's object replaced)
 for mode in ${MODES:-default alignment}; do
   export RSEM_HIP_NORMAL_EXIT=1
   unset LD_LIBRARY_PATH

@@ -7,7 +7,7 @@ tag=${1:-rXX}; cfgs=${2:-"C3 C2"}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out
 for cfg in $cfgs; do
-  B="python bench.py --config $cfg --legs= --steps 40 --warmup 4 --no-cpu-baseline --no-gibbs --no-ci"
+  B="python bench.py --config $cfg --legs= --steps 40 --warmup 4 --no-cpu-baseline --no-gibbs --no-ci --no-q32"  # (--no-q32: the Q32 leg launches the same kernel name on other planes)
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_bench_$cfg -o b -- $B > $out/${tag}_bench_$cfg.json 2> $out/${tag}_bench_$cfg.err
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_${cfg}_$c -o p -- $B > /dev/null 2> $out/${tag}_pmc_${cfg}_$c.err
