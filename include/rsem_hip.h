@@ -93,6 +93,10 @@ int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64
                    const double* ncp);
 /* Replace the CSR values (hit.setConPrb / ncpv[i], EM.cpp:210,216) in the caller's (file) order. */
 int rsem_em_set_values(rsem_em_ctx* ctx, const double* conprb, const double* ncp);
+/* The current values in caller order (conprb[nnz], ncp[N1]) -- what rsem_em_create / rsem_em_set_values put there or the model
+ * rounds computed (hit.getConPrb() / ncpvecs of EM.cpp:421-458 when it writes imdName.ofg).  Works after option "release_csr"
+ * (the values are read back from the planes first). */
+int rsem_em_get_values(rsem_em_ctx* ctx, double* conprb, double* ncp);
 /* Options (none of them is part of the reference's surface):
  *   "kernel"            RSEM_EM_KERNEL_*;
  *   "check_every"       rounds between the host's looks at the loop;
@@ -101,10 +105,16 @@ int rsem_em_set_values(rsem_em_ctx* ctx, const double* conprb, const double* ncp
  *                       one exponent per read (value = m * 2^e, rounded to nearest: relative error <= 2^-33 of the
  *                       read's largest value), all other reads stay doubles.  Affects the counts of rsem_em_step /
  *                       rsem_em_run / rsem_em_expected_weights; the weights w[] always come from the doubles.
- *   "value_range_bits"  0..24, default 8. */
+ *   "value_range_bits"  0..24, default 8;
+ *   "release_csr"       1: free the caller-order transcript ids and values on the device (12 bytes per alignment: half of the
+ *                       context's memory) -- the theta-only rounds of rsem_em_step / rsem_em_run stream the sliced layout
+ *                       alone -- until something needs them again (weights, new values, a rebuild of the layout, a model
+ *                       context), which reads them back from the planes: the same doubles.  RSEM_ERR_STATE, nothing changed,
+ *                       where the planes do not hold everything (Q32 planes, split rows, reads with more than 256
+ *                       alignments, the CSR kernel, a live model context).  0: bring them back now. */
 int rsem_em_set_option(rsem_em_ctx* ctx, const char* key, int64_t value);
 /* Layout facts: "value_bits", "value_range_bits", "reads_q32", "reads_sliced", "reads_long", "value_plane_bytes",
- * "sid_plane_bytes", "slots", "units". */
+ * "sid_plane_bytes", "slots", "units", "csr_released" (0 / 1), "csr_bytes" (what "release_csr" frees). */
 int rsem_em_get_info(const rsem_em_ctx* ctx, const char* key, int64_t* value);
 /* Tuning aid (not part of the reference's surface): one E-step launch of the LANE kernel with per-workgroup start/end
  * timestamps (100 MHz clock), out[2u], out[2u+1] in dispatch order; *n_units_io = capacity in, units written out. */

@@ -66,6 +66,7 @@ def lib():
         L.rsem_hip_stream_probe.argtypes = [ci, u64, ci, C.POINTER(dbl), C.POINTER(dbl)]
         L.rsem_em_create.argtypes = [C.POINTER(vp), ci, i32, u64, u64, _u64p, vp, vp, vp]
         L.rsem_em_set_values.argtypes = [vp, _f64p, _f64p]
+        L.rsem_em_get_values.argtypes = [vp, _f64p, _f64p]
         L.rsem_em_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         L.rsem_em_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
         L.rsem_em_destroy.argtypes = [vp]
@@ -162,6 +163,11 @@ class EmContext:
         v = C.c_int64()
         _check(lib().rsem_em_get_info(self._h, key.encode(), C.byref(v)))
         return v.value
+
+    def get_values(self):
+        cp, ncp = np.zeros(self.nnz), np.zeros(self.N1)
+        _check(lib().rsem_em_get_values(self._h, cp, ncp))
+        return cp, ncp
 
     def set_comm(self, comm):
         _check(lib().rsem_em_set_comm(self._h, comm._h if comm is not None else None))

@@ -1011,6 +1011,11 @@ struct rsem_em_ctx {
     hipStream_t stream2 = nullptr;  // fused loop: the statistics kernel of round r runs here, beside the E step of round r+1
     hipEvent_t ev_e[4] = {nullptr, nullptr, nullptr, nullptr}, ev_s[4] = {nullptr, nullptr, nullptr, nullptr};
     rsem_comm* comm = nullptr;     // not owned; rows sharded over its ranks when set
+    // Option "release_csr": d_sid / d_cp (12 bytes per alignment, the caller-order half of the device memory) are freed while only
+    // the theta-only rounds run -- they stream the sliced layout alone -- and read back from the planes (k_unfill_sell, the same
+    // doubles) by whatever needs them next: the weights pass, new values, a rebuild of the layout, a model context's view.
+    bool csr_released = false;
+    int views_out = 0;             // model contexts holding d_sid / d_cp (em_device_view .. em_view_release)
     rsem_em_progress_fn progress = nullptr;
     void* progress_user = nullptr;
 };
@@ -1109,6 +1114,38 @@ __global__ void k_sum_row_lengths(uint32_t n, const uint32_t* __restrict__ rows,
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v += row_ptr[rows[i] + 1] - row_ptr[rows[i]];
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+int release_csr(rsem_em_ctx* c) {
+    if (c->csr_released) return RSEM_OK;
+    const char* why = nullptr;
+    if (!c->layout_ok || !c->have_values) why = "there is no layout with values yet";
+    else if (c->layout_has_q32 || c->value_bits == 32) why = "Q32 planes hold rounded values";
+    else if (c->L.n_x_rows) why = "split rows keep part of their alignments outside the planes";
+    else if (c->L.n_long_rows) why = "reads with more than 256 alignments live in the CSR alone";
+    else if (resolved_kernel(c) == RSEM_EM_KERNEL_CSR) why = "the CSR kernel is selected";
+    else if (c->views_out > 0) why = "a model context still holds the arrays";
+    if (why) { rsem::set_last_error("release_csr: %s", why); return RSEM_ERR_STATE; }
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_sid); c->d_sid = nullptr;
+    (void)hipFree(c->d_cp); c->d_cp = nullptr;
+    c->csr_released = true;
+    return RSEM_OK;
+}
+
+int ensure_csr(rsem_em_ctx* c) {
+    if (!c->csr_released) return RSEM_OK;
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    RSEM_HIP_TRY(dmalloc(&c->d_sid, c->nnz));
+    RSEM_HIP_TRY(dmalloc(&c->d_cp, c->nnz));
+    if (c->L.n_sell_rows)
+        hipLaunchKernelGGL(k_unfill_sell, dim3(rsem::ceil_div(c->L.n_sell_rows, kBlock)), dim3(kBlock), 0, c->stream, c->L.d_shapes, c->L.n_shapes, c->L.T,
+                           c->L.n_sell_rows, (const uint32_t*)c->L.d_order, (const uint64_t*)c->d_row_ptr, (const int32_t*)c->L.d_ssid,
+                           (const unsigned char*)c->d_sval, c->d_sid, c->d_cp);
+    RSEM_HIP_TRY(hipGetLastError());
+    c->csr_released = false;
+    return RSEM_OK;
 }
 
 int write_values(rsem_em_ctx* c) {
@@ -1307,11 +1344,23 @@ int rsem_em_create(rsem_em_ctx** out, int device, int32_t M, uint64_t N1, uint64
 int rsem_em_set_values(rsem_em_ctx* c, const double* conprb, const double* ncp) {
     RSEM_REQUIRE(c && conprb && ncp, "NULL argument");
     RSEM_HIP_TRY(hipSetDevice(c->device));
+    { int rc0 = ensure_csr(c); if (rc0 != RSEM_OK) return rc0; }
     if (c->nnz) RSEM_HIP_TRY(hipMemcpyAsync(c->d_cp, conprb, sizeof(double) * c->nnz, hipMemcpyHostToDevice, c->stream));
     if (c->N1) RSEM_HIP_TRY(hipMemcpyAsync(c->d_ncp, ncp, sizeof(double) * c->N1, hipMemcpyHostToDevice, c->stream));
     c->have_values = true;
     int rc = fill_values(c);
     if (rc != RSEM_OK) return rc;
+    RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSEM_OK;
+}
+
+int rsem_em_get_values(rsem_em_ctx* c, double* conprb, double* ncp) {
+    RSEM_REQUIRE(c && conprb && ncp, "NULL argument");
+    if (!c->have_values) { rsem::set_last_error("CSR values were never set"); return RSEM_ERR_STATE; }
+    RSEM_HIP_TRY(hipSetDevice(c->device));
+    { int rc0 = ensure_csr(c); if (rc0 != RSEM_OK) return rc0; }
+    if (c->nnz) RSEM_HIP_TRY(hipMemcpyAsync(conprb, c->d_cp, sizeof(double) * c->nnz, hipMemcpyDeviceToHost, c->stream));
+    if (c->N1) RSEM_HIP_TRY(hipMemcpyAsync(ncp, c->d_ncp, sizeof(double) * c->N1, hipMemcpyDeviceToHost, c->stream));
     RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
     return RSEM_OK;
 }
@@ -1353,6 +1402,17 @@ int rsem_em_set_progress(rsem_em_ctx* c, rsem_em_progress_fn fn, void* user) {
 
 int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
     RSEM_REQUIRE(c && key, "NULL argument");
+    if (!strcmp(key, "release_csr")) {
+        // 1: free the caller-order ids and values (12 B per alignment) until something needs them again (then they are read back
+        // from the planes: the same doubles).  Refused -- RSEM_ERR_STATE, nothing changed -- where the planes do not hold everything:
+        // Q32 planes, split rows, reads with more than 256 alignments, the CSR kernel, a live model context.  0: bring them back now.
+        RSEM_REQUIRE(value == 0 || value == 1, "release_csr must be 0 or 1");
+        return value ? release_csr(c) : ensure_csr(c);
+    }
+    if (!strcmp(key, "kernel") || !strcmp(key, "split_rows") || !strcmp(key, "value_bits") || !strcmp(key, "value_range_bits")) {
+        int rc0 = ensure_csr(c);  // (these may rebuild the layout from the CSR)
+        if (rc0 != RSEM_OK) return rc0;
+    }
     if (!strcmp(key, "kernel")) {
         RSEM_REQUIRE(value >= RSEM_EM_KERNEL_AUTO && value <= RSEM_EM_KERNEL_LANE, "unknown kernel variant");
         c->kernel = (int)value;
@@ -1409,6 +1469,8 @@ int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
 int rsem_em_get_info(const rsem_em_ctx* c, const char* key, int64_t* value) {
     RSEM_REQUIRE(c && key && value, "NULL argument");
     if (!strcmp(key, "value_bits")) *value = c->value_bits;
+    else if (!strcmp(key, "csr_released")) *value = c->csr_released ? 1 : 0;
+    else if (!strcmp(key, "csr_bytes")) *value = (int64_t)(12 * c->nnz);                  // d_sid + d_cp: what "release_csr" frees
     else if (!strcmp(key, "value_range_bits")) *value = c->value_range_bits;
     else if (!strcmp(key, "far_units")) *value = c->n_far_units;                        // units with an id outside their LDS window
     else if (!strcmp(key, "units")) *value = c->n_units;
@@ -1805,6 +1867,7 @@ int rsem_em_expected_weights(rsem_em_ctx* c, const double* theta, double N0, dou
     RSEM_HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const size_t nb = sizeof(double) * ((size_t)c->M + 1);
+    if (w || w_noise) { int rc0 = ensure_csr(c); if (rc0 != RSEM_OK) return rc0; }  // (the weights pass walks the caller-order CSR)
     if ((w || w_noise) && !c->d_w) RSEM_HIP_TRY(dmalloc(&c->d_w, c->nnz));
     if ((w || w_noise) && !c->d_wn) RSEM_HIP_TRY(dmalloc(&c->d_wn, c->N1));
     RSEM_HIP_TRY(hipMemcpyAsync(c->d_theta[0], theta, nb, hipMemcpyHostToDevice, st));
@@ -1837,6 +1900,7 @@ namespace rsem {
 int em_device_view(rsem_em_ctx* c, EmDeviceView* v) {
     RSEM_REQUIRE(c && v, "NULL argument");
     RSEM_HIP_TRY(hipSetDevice(c->device));
+    { int rc0 = ensure_csr(c); if (rc0 != RSEM_OK) return rc0; }
     // (the weight buffers -- 8 B per alignment -- are allocated by the first pass that fills them, em_step_with_weights /
     // rsem_em_expected_weights: the round kernel of model.hip never needs them)
     v->device = c->device;
@@ -1856,6 +1920,13 @@ int em_device_view(rsem_em_ctx* c, EmDeviceView* v) {
 __global__ void k_invert_order(uint64_t n, const uint32_t* __restrict__ order, uint32_t* rank) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n) rank[order[p]] = (uint32_t)p;
+}
+
+void em_view_hold(rsem_em_ctx* c) {
+    if (c) c->views_out += 1;
+}
+void em_view_release(rsem_em_ctx* c) {
+    if (c && c->views_out > 0) c->views_out -= 1;
 }
 
 bool em_planes_writable(const rsem_em_ctx* c) {

@@ -30,6 +30,10 @@ struct EmPlanesView {
 
 // device pointers of the ctx (d_w / d_wn are NULL until a weights pass has run: take the view again after em_step_with_weights)
 int em_device_view(rsem_em_ctx* c, EmDeviceView* v);
+// A model context keeps the view's d_sid / d_cp for its lifetime: between hold and release the EM context does not free them
+// (option "release_csr" is refused).
+void em_view_hold(rsem_em_ctx* c);
+void em_view_release(rsem_em_ctx* c);
 // d_cp / d_ncp were rewritten on the device: rebuild the sliced value planes
 int em_values_changed(rsem_em_ctx* c);
 // The planes of the current layout, for in-place writers.  RSEM_ERR_STATE when the layout cannot take doubles in place (Q32

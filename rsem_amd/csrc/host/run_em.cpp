@@ -1,7 +1,7 @@
 // rsem-run-em on MI355X: same argv, same files as the reference program (EM.cpp:541-675).
 //
 //   rsem-run-em refName read_type sampleName imdName statName [-p N] [-b samInpF has_fai [fai]] [-q]
-//               [--gibbs-out] [--sampling] [--seed u32] [--append-names]
+//               [--gibbs-out] [--sampling] [--seed u32] [--append-names]          + [--lean-device]
 //               + ignored-by-the-reference: [--device d] [--ngpus N] [--devices d0,d1,..] [--value-bits 32 [--value-range-bits D]]
 //
 // Structure (EM<>() of EM.cpp:313-539): text inputs are parsed ONCE into packed arrays and uploaded;
@@ -287,7 +287,7 @@ int main(int argc, char* argv[]) {
     // RSEM_HIP_BINARY=1 / =both in the environment, the switch the unmodified Perl driver cannot put on the command line
     int ofbMode = 0;
     if (const char* e = getenv("RSEM_HIP_BINARY")) ofbMode = !strcmp(e, "both") ? 2 : ((*e && strcmp(e, "0")) ? 1 : 0);
-    bool verbose = true, genBamF = false, genGibbsOut = false, appendNames = false, bamSampling = false, hasSeed = false;
+    bool verbose = true, genBamF = false, genGibbsOut = false, appendNames = false, bamSampling = false, hasSeed = false, leanDevice = false;
     uint32_t seed = 0;
     std::string inpSamF, devices_s;
     int device = 0, ngpus = 1, value_bits = 64, value_range_bits = -1, nThreads = 1;
@@ -304,6 +304,7 @@ int main(int argc, char* argv[]) {
         if (!strcmp(argv[i], "--gibbs-out")) genGibbsOut = true;
         if (!strcmp(argv[i], "--gibbs-out-binary")) { genGibbsOut = true; ofbMode = 1; }  // not in the reference: imdName.ofb/ only
         if (!strcmp(argv[i], "--append-names")) appendNames = true;
+        if (!strcmp(argv[i], "--lean-device")) leanDevice = true;  // the theta-only rounds hold the sliced layout alone in HBM
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--ngpus") && i + 1 < argc) ngpus = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices_s = argv[i + 1];
@@ -646,6 +647,18 @@ int main(int argc, char* argv[]) {
         std::vector<uint8_t>().swap(lq);
     });
     Joiner release_joiner{releaser};
+    if (leanDevice) {
+        // Nothing but the sliced layout is read from here to the last round: the model contexts (the packed reads, their
+        // alignments' coordinates, the reference strands) and the caller-order ids and values of the EM contexts go back to the
+        // device's allocator; the values are read back from the planes by whatever asks for them afterwards (weights, .ofg).
+        each_shard([&](Shard& X, int) {
+            rsem_model_destroy(X.mc);
+            X.mc = nullptr;
+            if (rsem_em_set_option(X.em, "release_csr", 1) != RSEM_OK && verbose)
+                printf("--lean-device: the caller-order arrays stay on the device (%s)\n", rsem_hip_last_error());
+        });
+        lap("lean device");
+    }
     if (ROUND < MIN_ROUND || (totNum > 0 && ROUND < MAX_ROUND)) {
         const int round0 = ROUND;
         std::vector<std::vector<double>> s_theta(S, theta);
@@ -686,7 +699,7 @@ int main(int argc, char* argv[]) {
         std::unique_ptr<double[]> cp(new double[nnz ? nnz : 1]), ncp(new double[N1 ? N1 : 1]);  // filled by the copies below
         OfbHeader ofb_hdr;
         each_shard([&](Shard& X, int) {
-            X.rc = rsem_model_get_values(X.mc, cp.get() + X.a, ncp.get() + X.lo);
+            X.rc = X.mc ? rsem_model_get_values(X.mc, cp.get() + X.a, ncp.get() + X.lo) : rsem_em_get_values(X.em, cp.get() + X.a, ncp.get() + X.lo);
             if (X.rc != RSEM_OK) X.err = rsem_hip_last_error();
         });
         check_shards("rsem_model_get_values");

@@ -652,6 +652,7 @@ __global__ void k_pack_reads(uint64_t N1, const uint64_t* __restrict__ off, cons
 
 struct rsem_model_ctx {
     rsem_em_ctx* em = nullptr;
+    bool holds_view = false;  // em_view_hold .. em_view_release
     rsem::EmDeviceView v;
     DevData D;
     DevTables T;
@@ -794,6 +795,7 @@ extern "C" {
 int rsem_model_destroy(rsem_model_ctx* c) {
     if (!c) return RSEM_OK;
     (void)hipSetDevice(c->v.device);
+    if (c->em && c->holds_view) rsem::em_view_release(c->em);
     for (void* p : c->owned) hipFree(p);
     hipFree(c->t_rspd_pdf); hipFree(c->t_rspd_cdf); hipFree(c->t_gld_pdf); hipFree(c->t_gld_cdf); hipFree(c->t_mld_pdf);
     hipFree(c->t_mld_cdf); hipFree(c->t_prof); hipFree(c->t_noise); hipFree(c->t_mw);
@@ -818,6 +820,8 @@ int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_da
     c->em = em;
     int rc = rsem::em_device_view(em, &c->v);
     if (rc != RSEM_OK) { delete c; return rc; }
+    rsem::em_view_hold(em);
+    c->holds_view = true;
     if (c->v.N1 != d->N1 || c->v.nnz != d->nnz || c->v.M != d->M) {
         delete c;
         rsem::set_last_error("model data does not match the EM context (N1/nnz/M)");

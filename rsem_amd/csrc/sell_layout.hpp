@@ -256,6 +256,29 @@ __host__ __device__ inline void sell_fill_row(const Shape& S, uint32_t T, uint32
     if (ncp) sncp[slot] = ncp[orig];
 }
 
+// The inverse of sell_fill_row for F64 rows: the caller-order CSR (ids and values) of sorted row p, read back from the planes --
+// the same doubles, so a CSR that was released to save memory (rsem_em_set_option "release_csr") is restored bit for bit.
+__global__ void k_unfill_sell(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_sell_rows,
+                              const uint32_t* __restrict__ order, const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ ssid,
+                              const unsigned char* __restrict__ sval, int32_t* sid, double* cp) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_sell_rows) return;
+    const Shape S = shapes[find_shape_by_row(shapes, n_shapes, p)];
+    const int G = shape_G(S);
+    uint32_t slice_local, r;
+    row_to_slot(S, T, p - S.row_base, slice_local, r);
+    const uint32_t orig = order[p];
+    const uint64_t fr = row_ptr[orig];
+    const int L = (int)(row_ptr[orig + 1] - fr);
+    const uint64_t pl_local = (uint64_t)slice_local * S.K * 64;
+    const uint64_t pl0 = S.plane_base * 64 + pl_local;
+    for (int c = 0; c < L; c++) {
+        const uint64_t off = (uint64_t)(c >> S.lg) * 64 + r * G + (c & (G - 1));
+        sid[fr + c] = ssid[pl0 + off];
+        cp[fr + c] = ((const double*)(sval + S.val_base))[pl_local + off];
+    }
+}
+
 // d_xanchor: anchors of the split rows, indexed by sorted row - x_row_base (nullptr: no split rows)
 template <bool kIds>
 __global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_sell_rows,

@@ -54,7 +54,10 @@ def _res_close(path_a, path_b, atol=0.011):
 SHARDED = ["--ngpus", "2", "--devices", "0,0"]  # two row shards on GPU 0 (LOCAL communicator); on a node: RCCL, one GPU each
 
 
-@pytest.mark.parametrize("extra", [[], SHARDED], ids=["1gpu", "2shards"])
+LEAN = ["--lean-device"]  # after the model rounds: the model context and the caller-order arrays leave the device; .ofg from the planes
+
+
+@pytest.mark.parametrize("extra", [[], SHARDED, LEAN], ids=["1gpu", "2shards", "lean"])
 @pytest.mark.parametrize("name", rf.FIXTURES)
 def test_rsem_run_em_matches_reference(name, extra, tmp_path):
     fx, dst = _stage(name, tmp_path)
@@ -77,7 +80,7 @@ def test_rsem_run_em_matches_reference(name, extra, tmp_path):
         # SUM: the floating-point sum of the round's counts, as the reference prints it (EM.cpp:394-398,415) -- the same
         # number up to the order of the additions
         assert abs(float(fa[5]) - float(fb[5])) <= 1e-9 * float(fb[5]), (a, b)
-    if extra:
+    if extra == SHARDED:
         assert sum(l.startswith("GPU ") for l in out.split("\n")) == 2
     # the first 11 rounds print the same SUM / totNum lines as the reference
     ref_lines = open(os.path.join(fx, "em.log")).read().strip().split("\n")[:11]

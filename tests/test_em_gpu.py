@@ -354,3 +354,40 @@ def test_reads_that_also_hit_another_gene(config, scale, monkeypatch):
         config, far, units, strays, far_mixed))
     assert far < far_mixed and ctx.info("stray_reads") == 0
     ctx.close()
+
+
+def test_release_csr_keeps_every_result_and_gives_the_values_back_bit_for_bit():
+    """Option "release_csr" (rsem_hip.h): the caller-order ids and values -- 12 of a context's ~25 bytes per alignment -- are freed while
+    the theta-only rounds run and read back from the value planes by whatever needs them next.  The rounds give the same theta, the
+    values come back as the very doubles that went in, the weights pass gives the same weights, and the option is refused where the
+    planes do not hold everything (Q32 planes here)."""
+    from rsem_amd import capi
+    from tools.synth_data import make_em_workload
+    wl = make_em_workload("small", seed=21)
+    M = wl["M"]
+    ctx = capi.EmContext(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
+    ref = ctx.run(wl["theta0"], wl["N0"], max_round=60)
+    c0, w0, wn0 = ctx.expected_weights(ref["theta"], wl["N0"])
+    assert ctx.info("csr_released") == 0 and ctx.info("csr_bytes") == 12 * len(wl["sid"])
+    ctx.set_option("release_csr", 1)
+    assert ctx.info("csr_released") == 1
+    again = ctx.run(wl["theta0"], wl["N0"], max_round=60)   # the loop streams the sliced layout alone
+    assert again["rounds"] == ref["rounds"] and np.allclose(again["theta"], ref["theta"], rtol=1e-12, atol=0)
+    assert ctx.info("csr_released") == 1
+    cp, ncp = ctx.get_values()                              # read back from the planes
+    assert ctx.info("csr_released") == 0
+    assert np.array_equal(cp, wl["conprb"]) and np.array_equal(ncp, wl["ncp"])
+    ctx.set_option("release_csr", 1)
+    c1, w1, wn1 = ctx.expected_weights(ref["theta"], wl["N0"])  # the weights pass walks the caller-order CSR: restored first
+    assert ctx.info("csr_released") == 0
+    assert np.allclose(c1, c0, rtol=1e-12, atol=1e-9) and np.array_equal(w1, w0) and np.array_equal(wn1, wn0)
+    ctx.set_option("release_csr", 1)
+    ctx.set_values(wl["conprb"] * 0.5, wl["ncp"])           # new values: restored, overwritten, planes refilled
+    half = ctx.step(wl["theta0"], wl["N0"])
+    assert ctx.info("csr_released") == 0 and np.isfinite(half[0]).all()
+    ctx.set_option("value_bits", 32)
+    if ctx.info("reads_q32") > 0:
+        with pytest.raises(Exception):
+            ctx.set_option("release_csr", 1)                # Q32 planes hold rounded values
+        assert ctx.info("csr_released") == 0
+    ctx.close()
