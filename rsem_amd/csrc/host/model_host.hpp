@@ -329,8 +329,7 @@ struct Model {
         }
         if (!mw.empty()) {
             fprintf(fo, "\n%d\n", M);
-            for (int i = 0; i < M; i++) fprintf(fo, "%.15g ", mw[i]);
-            fprintf(fo, "%.15g\n", mw[M]);
+            write_cells_line(fo, 0, M, ' ', [&](char* b, long i) { return snprintf(b, 64, "%.15g", mw[i]); });
         }
         fclose(fo);
     }

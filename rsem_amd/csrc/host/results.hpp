@@ -63,10 +63,10 @@ class RowFile {
         }
     }
     void values(int first, int last, const double* v, double scale = 1.0) {
-        row(first, last, [&](FILE* f, int i) { fprintf(f, "%.2f", v[i] * scale); });
+        write_cells_line(f_, first, last, '\t', [&](char* b, long i) { return snprintf(b, 64, "%.2f", v[i] * scale); });
     }
     void roots(int first, int last, const double* v) {
-        row(first, last, [&](FILE* f, int i) { fprintf(f, "%.2f", sqrt(v[i])); });
+        write_cells_line(f_, first, last, '\t', [&](char* b, long i) { return snprintf(b, 64, "%.2f", sqrt(v[i])); });
     }
 
   private:

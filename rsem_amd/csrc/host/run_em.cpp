@@ -802,12 +802,10 @@ int main(int argc, char* argv[]) {
     FILE* fo = fopen((statName + ".theta").c_str(), "w");
     if (!fo) die("Cannot open %s.theta for writing!", statName.c_str());
     fprintf(fo, "%d\n", M + 1);
-    for (int i = 0; i < M; i++) fprintf(fo, "%.15g ", theta[i]);
-    fprintf(fo, "%.15g\n", theta[M]);
+    write_cells_line(fo, 0, M, ' ', [&](char* b, long i) { return snprintf(b, 64, "%.15g", theta[i]); });
     std::vector<double> eel = calc_eel(M, refs, model.gld);
     polish_theta(M, theta, eel, model.mw.data());
-    for (int i = 0; i < M; i++) fprintf(fo, "%.15g ", theta[i]);
-    fprintf(fo, "%.15g\n", theta[M]);
+    write_cells_line(fo, 0, M, ' ', [&](char* b, long i) { return snprintf(b, 64, "%.15g", theta[i]); });
     fclose(fo);
 
     model.write(statName + ".model");
