@@ -258,6 +258,8 @@ def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True, bam_leg=Tru
                         "same_round_count_as_the_reference": new_rounds == r["rounds"],
                         "speedup_vs_recorded_reference": r["wall_s_measured"] / new_wall,
                         "speedup_vs_recorded_reference_undisturbed": r["wall_s_if_all_late_rounds_at_the_undisturbed_rate"] / new_wall,
+                        "reference_s_alone_pinned": (mref.get("reference_alone_pinned_round5") or {}).get("wall_s_measured"),
+                        "speedup_vs_recorded_reference_alone_pinned": ((mref.get("reference_alone_pinned_round5") or {}).get("wall_s_measured") or 0.0) / new_wall or None,
                         "recorded_reference_note": "the reference's time is a RECORDING (round 4, another session and host state: reference_measured_in); "
                                                    "only `measured.speedup` above divides two times of this run",
                         "parity_full_size_recorded": mref["parity_full_size"]})
