@@ -161,6 +161,7 @@ GX_DEVFN int gx_team_barrier(int g, XTile* L, const XTeam& tm, unsigned long lon
         XTeamCtl* c = tm.ctl;
         const unsigned slot = (unsigned)((epoch + (unsigned long long)nbar) & 3ull);
         // one atomic per workgroup: arrival and flag together, so that whoever sees W arrivals sees every flag
+        GX_TEAM_RELEASE();
         GX_G_ADD64(&c->cnt[slot], 1ull + (flag ? (1ull << 32) : 0ull));
         int res = 0;
         unsigned long long t0 = 0, v = 0;
