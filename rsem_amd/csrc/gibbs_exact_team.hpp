@@ -59,12 +59,21 @@
 #define GX_TEAM_RELEASE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define GX_TEAM_ACQUIRE() asm volatile("" ::: "memory")
 #endif
-#define GX_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
+// pause between two looks at the barrier's counter, in units of 64 clocks: 256 workgroups polling without a pause slow everybody's
+// memory traffic down (0 / 1 / 4 / 8 / 16 / 32: 101 / 98-100 / 93-95 / 95 / 94 / 96.5 ms per round at a fifth of configs[2], profiles/r05w_*)
+#ifndef RSEM_GX_SLEEP
+#define RSEM_GX_SLEEP 8
+#endif
+#define GX_SPIN_PAUSE() __builtin_amdgcn_s_sleep(RSEM_GX_SLEEP)
 #define GX_WALL() ((unsigned long long)wall_clock64()) /* 100 MHz, constant */
 #endif
 
 constexpr int kXTeamMax = 64;          // workgroups per chain at most (one 8-byte word of group cells: 4 groups of 16)
-constexpr int kXStep = kXPlanes % 4 == 0 ? 4 : (kXPlanes % 3 == 0 ? 3 : 2);  // items per thread whose cells are loaded together in the cross look-ups
+#ifdef RSEM_GX_STEP
+constexpr int kXStep = RSEM_GX_STEP;
+#else
+constexpr int kXStep = kXPlanes % 4 == 0 ? 4 : (kXPlanes % 3 == 0 ? 3 : 2);
+#endif  // items per thread whose cells are loaded together in the cross look-ups
 static_assert(kXPlanes % kXStep == 0, "whole steps");
 constexpr unsigned kXBias = 0x8080u;   // a cell holds net + bias (hipMemset with 0x80 makes an all-bias table)
 constexpr unsigned long long kXSpinLimit = 3000000000ull;  // wall-clock ticks (30 s) a workgroup waits for its team at most
@@ -770,6 +779,7 @@ __global__ __launch_bounds__(kXThr) void k_gibbs_exact_team(TeamArgs ta, const u
                                                           const int32_t* __restrict__ last_round, int round, uint64_t stride_c, uint64_t stride_z,
                                                           unsigned long long* prof) {
     __shared__ XTile tile;
+    // (a team spread over all XCDs instead -- chain = b / W -- is slower: 104.6 against 98.3 ms per round, profiles/r05w_*)
     const int chain = (int)(blockIdx.x % (unsigned)ta.nchains), tw = (int)(blockIdx.x / (unsigned)ta.nchains);
     if (round > last_round[chain]) return;  // (uniform over the team)
     const GxMtState* src = mt_in + chain;
