@@ -280,7 +280,7 @@ typedef struct {
 
 /* Run nchains independent chains on this GPU -- the reference's worker threads (Gibbs.cpp:207-254): chain k starts
  * from MT19937(seeds[k]) (EXACT) / Philox keyed by seeds[k] (PARALLEL), keeps nsamples[k] samples after `burnin`
- * rounds, one every `gap` rounds.  EXACT: one wave per chain, all chains in every launch.  PARALLEL: one chain after
+ * rounds, one every `gap` rounds.  EXACT: a team of workgroups per chain, all chains in every launch.  PARALLEL: one chain after
  * the other (a sweep fills the GPU).  count_vectors: NULL, or nchains host pointers (each NULL or nsamples[k] x (M+1)
  * int32 = the lines of imd.countvectors<k>, Gibbs.cpp:257-262).  The accumulators receive the SUMS over the kept
  * samples of all chains, added in chain order (release(), Gibbs.cpp:372-388; not yet divided): pme_c, pve_c (sum of

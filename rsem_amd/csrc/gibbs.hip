@@ -8,9 +8,10 @@
 //
 //   RSEM_GIBBS_EXACT     the reference chain itself: same visiting order, same left-to-right
 //                        cumulative sums, MT19937 + u = mt()*2^-32 (sampling.h:50-65), hence the
-//                        same integer count vectors bit for bit.  One wave; 63 lanes stage the
-//                        next tile of reads into LDS while lane 0 walks the chain.  Latency
-//                        bound by construction -- the verification mode.
+//                        same integer count vectors bit for bit.  A team of workgroups per chain:
+//                        tiles of 256 reads resolved in LDS, W tiles of a window at once, the moves
+//                        between them settled through the team's tables (gibbs_exact_team.hpp); the
+//                        one-wave and the lane-0 kernels below are kept as independent cross-checks.
 //   RSEM_GIBBS_PARALLEL  the data-augmentation (uncollapsed) Gibbs sampler for the same posterior:
 //                        theta | z ~ Dirichlet(counts + alpha) (one Gamma draw per transcript,
 //                        Marsaglia-Tsang, Philox4x32-10 counter RNG), then all z_i | theta drawn
@@ -1144,7 +1145,12 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         struct TeamLease {
             int dev = -1;
             bool mine = false;
-            void take(int d) { dev = d; mine = d >= 0 && d < kMaxTeamDevices && g_team_busy[d].fetch_add(1) == 0; if (!mine && dev >= 0 && dev < kMaxTeamDevices) g_team_busy[dev].fetch_sub(1); }
+            void take(int d) {
+                if (d < 0 || d >= kMaxTeamDevices) return;
+                dev = d;
+                mine = g_team_busy[d].fetch_add(1) == 0;
+                if (!mine) g_team_busy[d].fetch_sub(1);
+            }
             ~TeamLease() { if (mine) g_team_busy[dev].fetch_sub(1); }
         } lease;
         const bool prior = c->d_alpha != nullptr;  // --prior: the pass of the two headers compiled in namespace gx_prior
