@@ -183,6 +183,47 @@ __global__ __launch_bounds__(kBlock) void k_estep_csr(
     block_add_totals(noise, neff, noise_partial, totals);
 }
 
+// The reads the sliced layout does not take (more than 256 alignments: a Trinity-shaped tail), a WAVE per read: the lanes stride
+// over the read's alignments (coalesced 4- and 8-byte loads), the normaliser is a wave sum, the fractions go to counts[] by
+// atomics.  Until round 5 these reads went through k_estep_csr, a thread per read: ONE read of 2 000 alignments walked by one
+// thread is 2 000 dependent round trips -- 100 such reads among 10 M took the E step of configs[1] from 0.12 to 1.99 ms
+// (profiles/r05z_long_rows.log).  Summation order within a read differs from the thread's (a tree over lanes), like the lane
+// kernel's.
+__global__ __launch_bounds__(kBlock) void k_estep_long(uint64_t n_rows, const uint32_t* __restrict__ row_list, const uint64_t* __restrict__ row_ptr,
+                                                        const int32_t* __restrict__ sid, const double* __restrict__ cp, const double* __restrict__ ncp,
+                                                        const double* __restrict__ theta, double* counts, double* noise_partial, const Ctrl* ctrl,
+                                                        double* totals) {
+    if (ctrl && ctrl->done) return;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    double noise = 0.0, neff = 0.0;
+    const double th0 = theta[0];
+    for (uint64_t t = wave; t < n_rows; t += n_waves) {  // (wave-uniform)
+        const uint64_t i = row_list[t];
+        const uint64_t fr = row_ptr[i], to = row_ptr[i + 1];
+        double f0 = th0 * ncp[i];
+        if (f0 < kEpsilon) f0 = 0.0;
+        double part = 0.0;
+        for (uint64_t j = fr + lane; j < to; j += 64) {
+            double f = theta[sid[j]] * cp[j];
+            if (f < kEpsilon) f = 0.0;
+            part += f;
+        }
+        const double sum = wave_sum(part) + f0;
+        if (sum >= kEpsilon) {
+            if (lane == 0) { noise += f0 / sum; neff += 1.0; }
+            for (uint64_t j = fr + lane; j < to; j += 64) {  // (the read's lines are in the L2 from the first pass)
+                const int s = sid[j];
+                double f = theta[s] * cp[j];
+                if (f < kEpsilon) f = 0.0;
+                f /= sum;
+                if (f != 0.0) unsafeAtomicAdd(&counts[s], f);
+            }
+        }
+    }
+    block_add_totals(noise, neff, noise_partial, totals);
+}
+
 // Posterior weight of every alignment in file order (calcExpectedWeights, EM.cpp:237-243): w[j] = f_j / sum_i and
 // w_noise[i]; rows whose normaliser is < 1e-300 get zeros.  Thread per read over the caller's CSR, no atomics: the
 // counts of the same round come from the main E-step kernel, this pass only serves the consumers that need the
@@ -1067,9 +1108,9 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
     }
     RSEM_HIP_TRY(hipGetLastError());
     if (c->L.n_long_rows) {
-        hipLaunchKernelGGL(k_estep_csr<false>, dim3(c->grid_long), dim3(kBlock), 0, st, (uint64_t)c->L.n_long_rows,
-                           c->L.d_order + c->L.n_sell_rows, c->d_row_ptr, c->d_sid, c->d_cp, c->d_ncp, d_theta, d_counts,
-                           c->d_noise_b, (double*)nullptr, (double*)nullptr, ctrl, c->use_totals ? c->d_totals : nullptr);
+        hipLaunchKernelGGL(k_estep_long, dim3(c->grid_long), dim3(kBlock), 0, st, (uint64_t)c->L.n_long_rows,
+                           (const uint32_t*)(c->L.d_order + c->L.n_sell_rows), (const uint64_t*)c->d_row_ptr, (const int32_t*)c->d_sid, (const double*)c->d_cp,
+                           (const double*)c->d_ncp, d_theta, d_counts, c->d_noise_b, ctrl, c->use_totals ? c->d_totals : nullptr);
         RSEM_HIP_TRY(hipGetLastError());
     }
     return RSEM_OK;
@@ -1227,7 +1268,7 @@ int build_layout(rsem_em_ctx* c) {
     RSEM_HIP_TRY(dmalloc(&c->d_noise_a, c->noise_cap));
     RSEM_HIP_TRY(hipMemsetAsync(c->d_noise_a, 0, sizeof(double) * c->noise_cap, c->stream));
 
-    c->grid_long = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_long_rows, kBlock)));
+    c->grid_long = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_long_rows, kBlock / 64)));  // (k_estep_long: a wave per read)
     c->long_nnz = 0;
     if (c->L.n_long_rows) {
         unsigned long long* d_n = (unsigned long long*)c->d_noise_a;  // (cleared again below)
