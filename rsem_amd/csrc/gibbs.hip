@@ -113,36 +113,67 @@ __global__ __launch_bounds__(kBlock, RSEM_GIBBS_MIN_WAVES) void k_sample_z_lane(
     if (threadIdx.x == 0 && s_noise) atomicAdd(&counts[0], s_noise);
 }
 
-// reads with > 256 alignments: thread per read over the caller's CSR
-__global__ void k_sample_z_long(uint32_t n_rows, const uint32_t* __restrict__ row_list, uint32_t row_id_base,
-                                const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
-                                const double* __restrict__ cp, const double* __restrict__ ncp,
-                                const double* __restrict__ g, Philox ph, uint32_t sweep, int32_t* counts) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+// reads with > 256 alignments (not in the sliced layout): a WAVE per read over the caller's CSR.  The read is walked in chunks of 64
+// alignments, lane = alignment: an inclusive scan inside the chunk (shuffles), the chunks one after the other -- once for the total,
+// once more for the first alignment whose running sum passes the target (the same scan, so the two passes agree to the bit and the
+// target always lands on an alignment).  (A thread per read was 2 x 2 000 dependent round trips for a read of 2 000 alignments: the
+// cliff profiles/r05z_long_rows.log shows for the E step.)  The pick is a pick from the same distribution as before, not the same
+// pick: the partial sums are formed in another order.
+__global__ __launch_bounds__(kBlock) void k_sample_z_long(uint32_t n_rows, const uint32_t* __restrict__ row_list, uint32_t row_id_base,
+                                                           const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
+                                                           const double* __restrict__ cp, const double* __restrict__ ncp,
+                                                           const double* __restrict__ g, Philox ph, uint32_t sweep, int32_t* counts) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // (wave-uniform)
     if (t >= n_rows) return;
-    uint32_t i = row_list[t];
-    uint64_t fr = row_ptr[i], to = row_ptr[i + 1];
-    double f0 = g[0] * ncp[i], total = f0;
-    for (uint64_t j = fr; j < to; j++) total += g[sid[j]] * cp[j];
+    const uint32_t i = row_list[t];
+    const uint64_t fr = row_ptr[i], to = row_ptr[i + 1];
+    const double f0 = g[0] * ncp[i];
+    auto chunk_scan = [&](uint64_t j0, double& f, int& s) -> double {  // inclusive scan of the chunk's weights; returns this lane's prefix
+        const uint64_t j = j0 + (uint64_t)lane;
+        s = j < to ? sid[j] : 0;
+        f = j < to ? g[s] * cp[j] : 0.0;
+        double p = f;
+        for (int d = 1; d < 64; d <<= 1) {
+            const double o = __shfl_up(p, d);
+            if (lane >= d) p += o;
+        }
+        return p;
+    };
+    double total = f0;
+    for (uint64_t j0 = fr; j0 < to; j0 += 64) {
+        double f;
+        int s;
+        const double p = chunk_scan(j0, f, s);
+        total += __shfl(p, 63);
+    }
     if (!(total > 0.0)) return;
     uint32_t r[4];
     ph.gen(row_id_base + t, sweep, 0x5a5a5a5au, 0u, r);
     double target = u53(r[0], r[1]) * total;
     if (target >= total) target = total * (1.0 - 1.1102230246251565e-16);
-    double run = f0;
     int pick = 0;
-    if (!(target < run)) {
+    if (!(target < f0)) {
+        double run = f0;
         int last = 0;
         bool found = false;
-        for (uint64_t j = fr; j < to && !found; j++) {
-            double f = g[sid[j]] * cp[j];
-            run += f;
-            if (f > 0.0) last = sid[j];
-            if (target < run) { pick = sid[j]; found = true; }
+        for (uint64_t j0 = fr; j0 < to && !found; j0 += 64) {  // (wave-uniform: found comes from a ballot)
+            double f;
+            int s;
+            const double p = chunk_scan(j0, f, s);
+            const unsigned long long hit = __ballot(target < run + p);
+            const unsigned long long pos = __ballot(f > 0.0);
+            if (hit) {
+                pick = __shfl(s, __builtin_ctzll(hit));
+                found = true;
+            } else {
+                if (pos) last = __shfl(s, 63 - __builtin_clzll(pos));
+                run += __shfl(p, 63);
+            }
         }
         if (!found) pick = last;
     }
-    atomicAdd(&counts[pick], 1);
+    if (lane == 0) atomicAdd(&counts[pick], 1);
 }
 
 // ---- EXACT mode: the reference chain, one wave per chain, all chains of a GPU in one launch -----------
@@ -1319,7 +1350,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                                        c->d_g, c->d_scp, c->L.d_ssid, c->d_sncp, c->L.d_masks, ph, sw, ck
                                        );
                 if (c->L.n_long_rows)
-                    hipLaunchKernelGGL(k_sample_z_long, dim3(rsem::ceil_div(c->L.n_long_rows, kBlock)), dim3(kBlock), 0, st,
+                    hipLaunchKernelGGL(k_sample_z_long, dim3(rsem::ceil_div(c->L.n_long_rows, kBlock / 64)), dim3(kBlock), 0, st,
                                        c->L.n_long_rows, c->L.d_order + c->L.n_sell_rows, c->L.n_sell_rows, c->d_row_ptr, c->d_sid,
                                        c->d_cp, c->d_ncp, c->d_g, ph, sw, ck);
                 RSEM_HIP_TRY(hipGetLastError());

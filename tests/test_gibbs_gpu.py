@@ -225,6 +225,52 @@ def test_parallel_sampler_invariants_and_determinism():
     ctx.close()
 
 
+def test_parallel_sampler_reads_with_more_than_256_alignments():
+    """The data-augmentation sweep walks reads that the sliced layout does not take (> 256 alignments) with a wave per read
+    (k_sample_z_long: chunk scans instead of one thread's serial walk).  Here 40 such reads hit transcripts that no other read
+    touches: every sample must put exactly those 40 reads on exactly those transcripts (their noise weight is negligible), every
+    read is assigned once, the chain is a function of its seed, and the long reads' picks follow their weights -- half of a long
+    read's weight sits on its first 10 alignments."""
+    rng = np.random.default_rng(5)
+    M, n_short, n_long, L = 3000, 20000, 40, 700
+    lens = np.concatenate([rng.integers(1, 9, n_short), np.full(n_long, L)]) + 1   # + the noise item
+    order = rng.permutation(n_short + n_long)
+    is_long = (np.arange(n_short + n_long) >= n_short)[order]
+    lens = lens[order]
+    rp = np.zeros(len(lens) + 1, np.uint64)
+    rp[1:] = np.cumsum(lens)
+    sid = np.zeros(int(rp[-1]), np.int32)
+    cp = np.zeros(int(rp[-1]))
+    for i in range(len(lens)):
+        a, b = int(rp[i]), int(rp[i + 1])
+        cp[a] = 1e-12                                                  # noise
+        if is_long[i]:
+            sid[a + 1:b] = 2001 + np.sort(rng.choice(999, L, replace=False))   # ids 2001..2999: the long reads' own
+            w = np.full(L, 0.5 / (L - 10))
+            w[:10] = 0.05
+            cp[a + 1:b] = w
+        else:
+            k = b - a - 1
+            sid[a + 1:b] = 1 + np.sort(rng.choice(2000, k, replace=False))
+            cp[a + 1:b] = 10.0 ** rng.uniform(-2, 0, k)
+    N1 = len(lens)
+    init = np.zeros(M + 1, np.int32)
+    eel, mw, grp = np.full(M + 1, 500.0), np.ones(M + 1), np.array([1, M + 1], np.int32)
+    ctx = capi().GibbsContext(M, rp, sid, cp, init, None, 1.0, (M + 1) + N1, 0, eel, mw, grp)
+    cv1, _, _ = ctx.run(capi().GIBBS_PARALLEL, 11, 3, 30, 1, thin=1)
+    cv2, _, _ = ctx.run(capi().GIBBS_PARALLEL, 11, 3, 30, 1, thin=1)
+    ctx.close()
+    assert np.array_equal(cv1, cv2)
+    assert np.all(cv1.sum(1) == N1) and cv1.min() >= 0
+    assert np.all(cv1[:, 2001:].sum(1) == n_long)                     # the long reads, and nobody else, on their own transcripts
+    # (with the sampler's theta in play the first ten alignments keep about half of a read's weight: counts + 1 are nearly flat here)
+    first_ids = np.zeros(M + 1, bool)
+    for i in np.nonzero(is_long)[0]:
+        first_ids[sid[int(rp[i]) + 1:int(rp[i]) + 11]] = True
+    share = cv1[:, first_ids].sum() / (30.0 * n_long)
+    assert 0.2 < share < 0.9, share
+
+
 @pytest.mark.parametrize("name", ["se_q", "pe_q", "se_q_polya_rspd", "se_noq_rev_rspd_omit"])
 def test_parallel_posterior_means_within_sampling_tolerance(name):
     """z-test of PARALLEL posterior mean counts against a long oracle (reference-equivalent) chain."""
