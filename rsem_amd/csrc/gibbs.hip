@@ -24,8 +24,13 @@
 //
 // Per kept sample (Gibbs.cpp:313-346): theta = (counts + alpha) / totc, polishTheta,
 // calcExpressionValues (WriteResults.h:55-104) and the running sums -- on the device.
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <cmath>
+#include <string>
 
 #include <cstdlib>
 
@@ -1173,16 +1178,33 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         // One team run per device and process at a time: two cooperative grids that each want every compute unit cannot both be
         // resident (contexts of two host threads sharing a GPU -- the LOCAL communicator of the tests -- take one workgroup per
         // chain for whichever comes second).
+        // ... and per device across the processes of this host: an advisory lock on a file named after the GPU's PCI address, held for
+        // the run (released by close, also when the process dies).  Best effort: where the file cannot be made the run goes ahead.
         struct TeamLease {
-            int dev = -1;
+            int dev = -1, fd = -1;
             bool mine = false;
             void take(int d) {
                 if (d < 0 || d >= kMaxTeamDevices) return;
                 dev = d;
                 mine = g_team_busy[d].fetch_add(1) == 0;
-                if (!mine) g_team_busy[d].fetch_sub(1);
+                if (!mine) { g_team_busy[d].fetch_sub(1); return; }
+                char bus[64] = {0};
+                if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, d) != hipSuccess) { (void)hipGetLastError(); return; }
+                for (char* q = bus; *q; ++q) if (*q == ':' || *q == '.' || *q == '/') *q = '_';
+                const std::string path = std::string("/tmp/rsem_hip_team_") + bus + ".lock";
+                fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+                if (fd < 0) return;  // (no lock file: go ahead)
+                if (::flock(fd, LOCK_EX | LOCK_NB) != 0) {  // another process of this host runs its teams on this GPU
+                    ::close(fd);
+                    fd = -1;
+                    mine = false;
+                    g_team_busy[d].fetch_sub(1);
+                }
             }
-            ~TeamLease() { if (mine) g_team_busy[dev].fetch_sub(1); }
+            ~TeamLease() {
+                if (fd >= 0) ::close(fd);
+                if (mine) g_team_busy[dev].fetch_sub(1);
+            }
         } lease;
         const bool prior = c->d_alpha != nullptr;  // --prior: the pass of the two headers compiled in namespace gx_prior
         int W = 1;
