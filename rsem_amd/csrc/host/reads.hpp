@@ -8,15 +8,19 @@
 namespace rsemh {
 
 // get_base_id (utils.h:36-50): A C G T N (either case) -> 0..4
+// (Built once, by whichever thread comes first, behind the language's own guard for function-local statics: the read files of the
+// two mates and the reference strands are converted by threads that start at the same time, and a hand-made "init" flag let a
+// second thread wipe the table while the first was already reading it -- a rare "unknown sequence letter T".)
 inline const int8_t* base_table() {
-    static int8_t tbl[256];
-    static bool init = false;
-    if (!init) {
-        memset(tbl, -1, sizeof(tbl));
-        tbl['a'] = tbl['A'] = 0; tbl['c'] = tbl['C'] = 1; tbl['g'] = tbl['G'] = 2; tbl['t'] = tbl['T'] = 3; tbl['n'] = tbl['N'] = 4;
-        init = true;
-    }
-    return tbl;
+    struct Table {
+        int8_t t[256];
+        Table() {
+            memset(t, -1, sizeof(t));
+            t['a'] = t['A'] = 0; t['c'] = t['C'] = 1; t['g'] = t['G'] = 2; t['t'] = t['T'] = 3; t['n'] = t['N'] = 4;
+        }
+    };
+    static const Table tbl;
+    return tbl.t;
 }
 
 struct ReadFile {
