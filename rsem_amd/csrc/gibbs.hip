@@ -10,8 +10,7 @@
 //                        cumulative sums, MT19937 + u = mt()*2^-32 (sampling.h:50-65), hence the
 //                        same integer count vectors bit for bit.  A team of workgroups per chain:
 //                        tiles of 256 reads resolved in LDS, W tiles of a window at once, the moves
-//                        between them settled through the team's tables (gibbs_exact_team.hpp); the
-//                        one-wave and the lane-0 kernels below are kept as independent cross-checks.
+//                        between them settled through the team's tables (gibbs_exact_team.hpp).
 //   RSEM_GIBBS_PARALLEL  the data-augmentation (uncollapsed) Gibbs sampler for the same posterior:
 //                        theta | z ~ Dirichlet(counts + alpha) (one Gamma draw per transcript,
 //                        Marsaglia-Tsang, Philox4x32-10 counter RNG), then all z_i | theta drawn
@@ -181,340 +180,19 @@ __global__ __launch_bounds__(kBlock) void k_sample_z_long(uint32_t n_rows, const
     if (lane == 0) atomicAdd(&counts[pick], 1);
 }
 
-// ---- EXACT mode: the reference chain, one wave per chain, all chains of a GPU in one launch -----------
+// ---- EXACT mode: the reference chain (Gibbs.cpp:297-311), a team of workgroups per chain ------------------------------
 //
 // The chain is sequential from read to read only through `counts`, and one visit changes at most two of its entries
-// (counts[z_old]--, counts[z_new]++).  k_gibbs_exact_coop therefore evaluates a TILE of up to 64 consecutive reads
-// speculatively, one read per lane, against the counts as they were before the tile, and then commits them in file
-// order: only reads whose draw actually changed their transcript are walked (a ballot mask), each of them broadcasts
-// its (z_old, z_new) pair, later lanes whose transcript range contains one of the two patch their private copy of the
-// counts and redo their draw with the SAME random number.  The result is the reference chain itself -- same visiting
-// order, same left-to-right cumulative sums (one lane sums one read), same MT19937 stream (read r of the tile takes the
-// r-th next output) -- hence the same integer count vectors bit for bit (tests/test_gibbs_gpu.py, tests/test_cli_gpu.py
-// against the reference's own countvectors files).  k_gibbs_exact_serial is the previous kernel (lane 0 walks, the
-// other lanes stage): kept as the cross-check (RSEM_GIBBS_EXACT_IMPL=serial).
+// (counts[z_old]--, counts[z_new]++).  The kernel therefore draws tiles of consecutive reads speculatively against the counts as
+// they were before the tile and settles, in file order, the draws that a move of an earlier read of the tile (or of the window
+// of tiles the team took together) actually touches -- with the SAME random numbers.  The fixed point is the sequential chain:
+// same visiting order, same left-to-right cumulative sums, same MT19937 stream (read r takes the r-th output), hence the same
+// integer count vectors bit for bit (tests/test_gibbs_gpu.py, tests/test_cli_gpu.py against the reference's own countvectors
+// files; the kernel body on the CPU emulator: tests/test_gibbs_exact_team_emu_cpu.py).  gibbs_exact_team.hpp over
+// gibbs_exact_wg.hpp, compiled twice: the uniform pseudo count, and --prior (per-transcript pseudo counts) in namespace gx_prior.
 
-constexpr int kTileRows = 64;
-constexpr int kTileItems = 2048;
-constexpr int kHeldSlots = 1024;
+struct MtState { uint32_t mt[624]; int idx; };  // a chain's generator between launches (= GxMtState of the headers)
 
-struct MtState { uint32_t mt[624]; int idx; };
-
-__device__ inline uint32_t mt_temper(uint32_t y) {
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
-}
-
-__device__ inline uint32_t mt_next(uint32_t* mt, int& idx) {  // lane 0 only; mt in LDS
-    if (idx >= 624) {
-        for (int k = 0; k < 624; k++) {
-            uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
-            mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        }
-        idx = 0;
-    }
-    return mt_temper(mt[idx++]);
-}
-
-// The in-place twist of all 624 words by one wave, 64 words per pass in increasing order.  Word k needs the OLD k+1
-// (same pass: every lane reads before any lane writes; next pass: not yet written) and word (k+397)%624, which is old
-// for k < 227 (indices >= 397, written by later passes) and new for k >= 227 (index k-227, at least one pass back);
-// k = 623 needs the new words 0 and 396.  So the plain pass order reproduces the sequential loop.
-__device__ inline void mt_regen_wave(uint32_t* mt, int lane) {
-    for (int k0 = 0; k0 < 624; k0 += 64) {
-        const int k = k0 + lane;
-        uint32_t v = 0;
-        if (k < 624) {
-            const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
-            v = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        }
-        __syncthreads();
-        if (k < 624) mt[k] = v;
-        __syncthreads();
-    }
-}
-
-// One sweep over all reads in file order (Gibbs.cpp:297-311), or the initial assignment (Gibbs.cpp:281-291) when
-// kInit.  grid = chains, blockDim = 64.  Chain c owns counts_base + c * stride_c, z_base + c * stride_z, mt_base[c]
-// and takes part in rounds 1 .. last_round[c].
-template <bool kInit>
-__global__ __launch_bounds__(64) void k_gibbs_exact_coop(uint64_t N1, const uint64_t* __restrict__ row_ptr,
-                                                          const int32_t* __restrict__ sid, const double* __restrict__ cp,
-                                                          int32_t* counts_base, int32_t* z_base,
-                                                          const double* __restrict__ alpha, double pseudoC, MtState* mt_base,
-                                                          const int32_t* __restrict__ last_round, int round, uint64_t stride_c,
-                                                          uint64_t stride_z, int dbg, unsigned long long* dbg_out) {
-    // dbg (tools/gibbs_exact_profile.py only; results are wrong when set): 1 = no commit loop, 2 = no draw either,
-    // 4 = count the commit loop's iterations / redraws into dbg_out[0..3]
-    const int chain = blockIdx.x;
-    if (round > last_round[chain]) return;
-    int32_t* counts = counts_base + (uint64_t)chain * stride_c;
-    int32_t* z = z_base + (uint64_t)chain * stride_z;
-    MtState* mt_state = mt_base + chain;
-    unsigned long long n_changed = 0, n_iter = 0, n_redraw_events = 0, n_redraw_lanes = 0;
-    __shared__ uint32_t mt[624];
-    __shared__ uint64_t t_rp[kTileRows + 1];
-    __shared__ int32_t t_sid[kTileItems];
-    __shared__ double t_p[kTileItems];
-    __shared__ int32_t t_c[kTileItems];
-    __shared__ double t_al[kTileItems];
-    __shared__ int32_t t_held[kHeldSlots];  // how many items of the tile carry a transcript id (hashed): the commit filter
-    const int lane = threadIdx.x;
-    for (int i = lane; i < 624; i += 64) mt[i] = mt_state->mt[i];
-    int idx = mt_state->idx;  // wave-uniform
-    __syncthreads();
-
-    // weight of item j of this lane's read under its private view of the counts
-    auto weight = [&](uint32_t j) -> double {
-        if (kInit) return t_p[j];
-        return ((double)t_c[j] + (alpha ? t_al[j] : pseudoC)) * t_p[j];
-    };
-    // sample() of sampling.h:50-65 on arr[k] = arr[k-1] + weight_k: the index of the first partial sum > prb, which for
-    // a non-decreasing array is the number of partial sums <= prb (what the binary search there finds), capped at len-1.
-    // The first kChunk partial sums stay in registers (their LDS reads are independent and overlap); 0.0 + a == a and
-    // x + 0.0 == x exactly, so the padded positions leave the left-to-right sums bit-identical.
-    constexpr int kChunk = 16;
-    auto draw = [&](uint32_t fr, int len, uint32_t rnd) -> int {
-        double part[kChunk];
-        double run = 0.0;
-#pragma unroll
-        for (int j = 0; j < kChunk; j++) {
-            const double a = (j < len) ? weight(fr + j) : 0.0;
-            run += a;
-            part[j] = run;
-        }
-        for (int k = kChunk; k < len; k++) run += weight(fr + k);
-        const double prb = ((double)rnd * (1.0 / 4294967296.0)) * run;
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < kChunk; j++) cnt += (j < len && part[j] <= prb) ? 1 : 0;
-        if (len > kChunk) {
-            double r2 = part[kChunk - 1];
-            for (int k = kChunk; k < len; k++) {
-                r2 += weight(fr + k);
-                cnt += (r2 <= prb) ? 1 : 0;
-            }
-        }
-        const int l = cnt < len ? cnt : len - 1;
-        return t_sid[fr + l];
-    };
-
-    uint64_t i0 = 0;
-    // row pointers and current assignments of the NEXT tile are requested while this one is worked on
-    uint64_t pf_i0 = ~0ull, pf_rp = 0, pf_rp_last = 0;
-    int pf_z = 0;
-    while (i0 < N1) {
-        const int nrt = (int)min((uint64_t)kTileRows, N1 - i0);
-        __syncthreads();  // the previous tile's LDS reads are done
-        const bool have_pf = (pf_i0 == i0);
-        t_rp[lane] = have_pf ? pf_rp : row_ptr[i0 + min(lane, nrt)];  // entries past nrt repeat the tile's end
-        if (lane == 0) t_rp[kTileRows] = have_pf ? pf_rp_last : row_ptr[i0 + nrt];
-        int z_old = 0;
-        if (!kInit) z_old = have_pf ? pf_z : ((lane < nrt) ? z[i0 + lane] : 0);
-        __syncthreads();
-        const uint64_t base = t_rp[0];
-        // reads of this tile = the longest prefix whose items fit the LDS tile
-        const bool fits = lane < nrt && (t_rp[lane + 1] - base) <= (uint64_t)kTileItems;
-        const int nr = __popcll(__ballot(fits));
-        if (nr == 0) {
-            // one read with more items than the tile holds: lane 0 walks it over global memory (two passes)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // earlier tiles' count updates
-            if (lane == 0) {
-                const uint64_t fr = base, to = t_rp[1];
-                const uint64_t len = to - fr;
-                if (!kInit) {
-                    __hip_atomic_fetch_add(&counts[z_old], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                auto wt = [&](uint64_t j) -> double {
-                    const int s = sid[j];
-                    const double p = cp[j];
-                    if (kInit) return p;
-                    const int c = __hip_atomic_load(&counts[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return ((double)c + (alpha ? alpha[s] : pseudoC)) * p;
-                };
-                double tot = 0.0;
-                for (uint64_t j = 0; j < len; j++) { const double a = wt(fr + j); tot = (j == 0) ? a : tot + a; }
-                const double prb = ((double)mt_next(mt, idx) * (1.0 / 4294967296.0)) * tot;
-                double cum = 0.0;
-                uint64_t l = len - 1;
-                for (uint64_t j = 0; j < len; j++) {
-                    const double a = wt(fr + j);
-                    cum = (j == 0) ? a : cum + a;
-                    if (cum > prb) { l = j; break; }
-                }
-                const int zn = sid[fr + l];
-                __hip_atomic_fetch_add(&counts[zn], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                z[i0] = zn;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            idx = __builtin_amdgcn_readfirstlane(idx);
-            i0 += 1;
-            continue;
-        }
-        const uint32_t T = (uint32_t)(t_rp[nr] - base);
-        if (!kInit) {
-#pragma unroll
-            for (int u = 0; u < kHeldSlots / 64; u++) t_held[u * 64 + lane] = 0;
-        }
-        // items of the tile: coalesced loads, eight in flight per lane; the counts as they are now (L2 copy: the
-        // updates below are device atomics)
-        for (uint32_t j0 = 0; j0 < T; j0 += 64 * 8) {
-            int s8[8], c8[8];
-            double p8[8], a8[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t j = j0 + u * 64 + lane;
-                s8[u] = j < T ? sid[base + j] : 0;
-                p8[u] = j < T ? cp[base + j] : 0.0;
-            }
-            if (!kInit) {
-                // the previous tile's count updates (device atomics, not waited for there) are in L2 before these loads
-                // are issued; their latency overlapped this tile's row-pointer / item loads
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint32_t j = j0 + u * 64 + lane;
-                    c8[u] = j < T ? __hip_atomic_load(&counts[s8[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                    a8[u] = (alpha && j < T) ? alpha[s8[u]] : 0.0;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t j = j0 + u * 64 + lane;
-                if (j < T) {
-                    t_sid[j] = s8[u];
-                    t_p[j] = p8[u];
-                    if (!kInit) {
-                        t_c[j] = c8[u];
-                        if (alpha) t_al[j] = a8[u];
-                    }
-                }
-            }
-        }
-        {   // prefetch for the tile that starts at i0 + nr (issued after the count loads: their wait must not cover it)
-            const uint64_t nxt = i0 + (uint64_t)nr;
-            pf_i0 = nxt;
-            if (nxt < N1) {
-                const int nrn = (int)min((uint64_t)kTileRows, N1 - nxt);
-                pf_rp = row_ptr[nxt + min(lane, nrn)];
-                pf_rp_last = row_ptr[nxt + nrn];
-                if (!kInit) pf_z = (lane < nrn) ? z[nxt + lane] : 0;
-            }
-        }
-        const bool mine = lane < nr;
-        // the next nr MT19937 outputs, read r of the tile takes the r-th (= the order the sequential chain draws them)
-        uint32_t rnd = 0;
-        {
-            if (idx >= 624) { mt_regen_wave(mt, lane); idx = 0; }
-            const int avail = 624 - idx;
-            if (lane < avail && mine) rnd = mt_temper(mt[idx + lane]);
-            if (nr > avail) {
-                __syncthreads();
-                mt_regen_wave(mt, lane);
-                if (lane >= avail && mine) rnd = mt_temper(mt[lane - avail]);
-                idx = nr - avail;
-            } else {
-                idx += nr;
-            }
-        }
-        __syncthreads();  // tile staged
-        const uint32_t fr = mine ? (uint32_t)(t_rp[lane] - base) : 0;
-        const int len = mine ? (int)(t_rp[lane + 1] - t_rp[lane]) : 0;
-        // Which transcripts does this read hold?  The commit loop asks that for every committed (z_old, z_new) pair, so the
-        // answer must not cost a walk over the items: a 64-bit set of the ids relative to the read's first one (isoforms
-        // of a gene are neighbours in id space), exact; reads spanning more than that fall back to their id range
-        // (conservative: a false hit only costs a redraw).  Noise (id 0) apart.
-        int lo = 0x7fffffff, hi = -1, ref = 0;
-        unsigned long long present = 0;
-        bool has_noise = false, wide = false, have_ref = false;
-        for (int k = 0; k < len; k++) {
-            const int s = t_sid[fr + k];
-            if (s == 0) has_noise = true;
-            else {
-                lo = min(lo, s); hi = max(hi, s);
-                if (!have_ref) { ref = s - 32; have_ref = true; }
-                const unsigned b = (unsigned)(s - ref);
-                if (b < 64u) present |= 1ull << b;
-                else wide = true;
-            }
-            if (!kInit) {
-                if (s == z_old) t_c[fr + k] -= 1;  // the read leaves its current transcript (Gibbs.cpp:298)
-                atomicAdd(&t_held[s & (kHeldSlots - 1)], 1);
-            }
-        }
-        auto holds = [&](int zz) -> bool {  // branch-free: this sits in the commit loop
-            const unsigned b = (unsigned)(zz - ref);
-            const bool bit = (b < 64u) & (((present >> (b & 63u)) & 1ull) != 0ull);
-            const bool rng = (zz >= lo) & (zz <= hi);
-            const bool tr = wide ? rng : bit;
-            return zz == 0 ? has_noise : tr;
-        };
-        int z_new = (mine && !(dbg & 2)) ? draw(fr, len, rnd) : z_old;
-        if (!kInit) {
-            __syncthreads();  // t_held complete
-            // a changed read needs a turn in the commit loop only if some OTHER item of the tile carries its old or its
-            // new transcript (the table counts the read's own items too, hence >= 2; hash collisions only add turns);
-            // everybody else's move concerns nobody in this tile
-            auto concerns_others = [&](int zo, int zn) -> bool {
-                return (t_held[zo & (kHeldSlots - 1)] >= 2) | (t_held[zn & (kHeldSlots - 1)] >= 2);
-            };
-            bool turn = mine && z_new != z_old && concerns_others(z_old, z_new);
-            unsigned long long changed = __ballot(turn);
-            if (dbg & 4) n_changed += __popcll(__ballot(mine && z_new != z_old));
-            if (dbg & 1) changed = 0;
-            while (changed) {
-                if (dbg & 4) ++n_iter;
-                const int r1 = __ffsll((long long)changed) - 1;
-                const int zo = __builtin_amdgcn_readlane(z_old, r1), zn = __builtin_amdgcn_readlane(z_new, r1);
-                changed &= ~(1ull << r1);
-                // later reads see counts[zo] - 1 and counts[zn] + 1
-                const bool cand = mine & (lane > r1) & (holds(zo) | holds(zn));
-                if (__ballot(cand)) {
-                    bool hit = false;
-                    if (cand) {
-                        for (int k = 0; k < len; k++) {
-                            const int s = t_sid[fr + k];
-                            const int d = (s == zn ? 1 : 0) - (s == zo ? 1 : 0);
-                            if (d != 0) { t_c[fr + k] += d; hit = true; }
-                        }
-                    }
-                    if (__ballot(hit)) {
-                        if (dbg & 4) { ++n_redraw_events; n_redraw_lanes += __popcll(__ballot(hit)); }
-                        if (hit) {
-                            z_new = draw(fr, len, rnd);
-                            turn = z_new != z_old && concerns_others(z_old, z_new);
-                        }
-                        const unsigned long long later = (r1 >= 63) ? 0ull : (~0ull << (r1 + 1));
-                        changed = __ballot(turn) & later;
-                    }
-                }
-            }
-            if (mine && z_new != z_old) {
-                __hip_atomic_fetch_add(&counts[z_old], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(&counts[z_new], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                z[i0 + lane] = z_new;
-            }
-        } else if (mine) {
-            __hip_atomic_fetch_add(&counts[z_new], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            z[i0 + lane] = z_new;
-        }
-        i0 += (uint64_t)nr;  // (the count updates are waited for where the next tile reads the counts)
-    }
-    __syncthreads();
-    for (int i = lane; i < 624; i += 64) mt_state->mt[i] = mt[i];
-    if (lane == 0) mt_state->idx = idx;
-    if ((dbg & 4) && dbg_out && lane == 0) {
-        atomicAdd(&dbg_out[0], n_changed); atomicAdd(&dbg_out[1], n_iter);
-        atomicAdd(&dbg_out[2], n_redraw_events); atomicAdd(&dbg_out[3], n_redraw_lanes);
-    }
-}
-
-// ---- EXACT mode, the default implementation: a team of workgroups per chain (gibbs_exact_team.hpp over gibbs_exact_wg.hpp) ----
-// Two passes over the two headers: the uniform pseudo count, and --prior (per-transcript pseudo counts) in namespace gx_prior.
 #include "gibbs_exact_team.hpp"
 #define RSEM_GX_PRIOR 1
 namespace gx_prior {
@@ -524,99 +202,6 @@ namespace gx_prior {
 static_assert(sizeof(GxMtState) == sizeof(MtState) && sizeof(gx_prior::GxMtState) == sizeof(MtState), "one layout of a chain's generator");
 static_assert(sizeof(TeamArgs) == sizeof(gx_prior::TeamArgs) && sizeof(XSlot) == sizeof(gx_prior::XSlot) && sizeof(XTeamCtl) == sizeof(gx_prior::XTeamCtl),
               "the host fills the uniform pass's records for either kernel");
-
-constexpr int kSerialTileItems = 3072;
-
-// The previous implementation: lane 0 walks the chain, the other 63 lanes stage the next tile of reads into LDS.
-template <bool kInit>
-__global__ __launch_bounds__(64) void k_gibbs_exact_serial(uint64_t N1, const uint64_t* __restrict__ row_ptr,
-                                                            const int32_t* __restrict__ sid,
-                                                            const double* __restrict__ cp, int32_t* counts_base, int32_t* z_base,
-                                                            const double* __restrict__ alpha, double pseudoC,
-                                                            MtState* mt_base, const int32_t* __restrict__ last_round, int round,
-                                                            uint64_t stride_c, uint64_t stride_z) {
-    const int chain = blockIdx.x;
-    if (round > last_round[chain]) return;
-    int32_t* counts = counts_base + (uint64_t)chain * stride_c;
-    int32_t* z = z_base + (uint64_t)chain * stride_z;
-    MtState* mt_state = mt_base + chain;
-    __shared__ uint32_t mt[624];
-    __shared__ uint64_t t_rp[kTileRows + 1];
-    __shared__ int32_t t_sid[kSerialTileItems];
-    __shared__ double t_cp[kSerialTileItems];
-    __shared__ double arr[kSerialTileItems];
-    __shared__ int32_t t_z[kTileRows];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < 624; i += 64) mt[i] = mt_state->mt[i];
-    int idx = mt_state->idx;
-    __syncthreads();
-
-    for (uint64_t i0 = 0; i0 < N1; i0 += kTileRows) {
-        const int nr = (int)min((uint64_t)kTileRows, N1 - i0);
-        for (int r = lane; r <= nr; r += 64) t_rp[r] = row_ptr[i0 + r];
-        if (lane < nr) t_z[lane] = kInit ? 0 : z[i0 + lane];
-        __syncthreads();
-        const uint64_t base = t_rp[0];
-        const uint64_t n_items = t_rp[nr] - base;
-        const bool staged = n_items <= (uint64_t)kSerialTileItems;
-        if (staged) {
-            for (uint64_t j = lane; j < n_items; j += 64) { t_sid[j] = sid[base + j]; t_cp[j] = cp[base + j]; }
-        }
-        __syncthreads();
-        if (lane == 0) {
-            for (int r = 0; r < nr; r++) {
-                const uint64_t fr = t_rp[r] - base, to = t_rp[r + 1] - base;
-                const int len = (int)(to - fr);
-                if (!kInit) --counts[t_z[r]];
-                int l = 0;
-                if (staged || len <= kSerialTileItems) {
-                    double cum = 0.0;
-                    for (int j = 0; j < len; j++) {
-                        int s = staged ? t_sid[fr + j] : sid[base + fr + j];
-                        double p = staged ? t_cp[fr + j] : cp[base + fr + j];
-                        double a = kInit ? p : ((double)counts[s] + (alpha ? alpha[s] : pseudoC)) * p;
-                        cum = (j == 0) ? a : cum + a;  // arr[j] = a; arr[j] += arr[j-1]
-                        arr[j] = cum;
-                    }
-                    double prb = ((double)mt_next(mt, idx) * (1.0 / 4294967296.0)) * arr[len - 1];
-                    int lo = 0, hi = len - 1;
-                    while (lo <= hi) {  // sampling.h:55-60
-                        int mid = (lo + hi) / 2;
-                        if (arr[mid] <= prb) lo = mid + 1; else hi = mid - 1;
-                    }
-                    l = lo < len ? lo : len - 1;
-                } else {
-                    // a single read with more alignments than the LDS tile: two passes over global memory
-                    double tot = 0.0;
-                    for (int j = 0; j < len; j++) {
-                        int s = sid[base + fr + j];
-                        double p = cp[base + fr + j];
-                        double a = kInit ? p : ((double)counts[s] + (alpha ? alpha[s] : pseudoC)) * p;
-                        tot = (j == 0) ? a : tot + a;
-                    }
-                    double prb = ((double)mt_next(mt, idx) * (1.0 / 4294967296.0)) * tot;
-                    double cum = 0.0;
-                    l = len - 1;
-                    for (int j = 0; j < len; j++) {
-                        int s = sid[base + fr + j];
-                        double p = cp[base + fr + j];
-                        double a = kInit ? p : ((double)counts[s] + (alpha ? alpha[s] : pseudoC)) * p;
-                        cum = (j == 0) ? a : cum + a;
-                        if (cum > prb) { l = j; break; }
-                    }
-                }
-                int zn = staged ? t_sid[fr + l] : sid[base + fr + l];
-                ++counts[zn];
-                t_z[r] = zn;
-            }
-        }
-        __syncthreads();
-        if (lane < nr) z[i0 + lane] = t_z[lane];
-        __syncthreads();
-    }
-    for (int i = lane; i < 624; i += 64) mt_state->mt[i] = mt[i];
-    if (lane == 0) mt_state->idx = idx;
-}
 
 // ---- per-sample statistics (Gibbs.cpp:313-346, WriteResults.h:55-104) ---------------------------
 //
@@ -924,17 +509,8 @@ int ensure_parallel_layout(rsem_gibbs_ctx* c) {
     return RSEM_OK;
 }
 
-// RSEM_GIBBS_EXACT_IMPL = team (default) | coop | serial: three implementations of the same chain (the last two: cross-checks of the tests)
-enum ExactImpl { kExactTeam, kExactCoop, kExactSerial };
 constexpr int kMaxTeamDevices = 64;
 std::atomic<int> g_team_busy[kMaxTeamDevices];  // team runs in flight per device (zero-initialised)
-ExactImpl exact_impl_requested(bool have_alpha) {
-    const char* e = getenv("RSEM_GIBBS_EXACT_IMPL");
-    if (e && !strcmp(e, "serial")) return kExactSerial;
-    if (e && !strcmp(e, "coop")) return kExactCoop;
-    (void)have_alpha;  // (--prior runs on the same kernel: its own pass of the headers, namespace gx_prior)
-    return kExactTeam;
-}
 
 }  // namespace
 
@@ -1160,15 +736,10 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
     int team_used = 0;  // EXACT: workgroups per chain
     RSEM_HIP_TRY(hipEventRecord(ev.a, st));
     if (exact) {
-        // all chains advance together, one wave each (Gibbs.cpp:207-254: the reference's threads)
+        // all chains advance together, a team of workgroups each (Gibbs.cpp:207-254: the reference's threads)
         std::vector<MtState> h(nchains);
         for (int k = 0; k < nchains; k++) host_mt_seed(h[k], seeds[k]);
         RSEM_HIP_TRY(hipMemcpyAsync(mts.p, h.data(), sizeof(MtState) * nchains, hipMemcpyHostToDevice, st));
-        const ExactImpl impl = exact_impl_requested(c->d_alpha != nullptr);
-        const int dbg = getenv("RSEM_GIBBS_EXACT_DEBUG") ? atoi(getenv("RSEM_GIBBS_EXACT_DEBUG")) : 0;
-        DevBuf dbg_buf;
-        RSEM_HIP_TRY(dbg_buf.alloc(4 * sizeof(unsigned long long)));
-        RSEM_HIP_TRY(hipMemsetAsync(dbg_buf.p, 0, 4 * sizeof(unsigned long long), st));
         DevBuf prof_buf;  // RSEM_GX_PROFILE builds: the workgroup kernel's phase cycles
         RSEM_HIP_TRY(prof_buf.alloc(16 * sizeof(unsigned long long)));
         RSEM_HIP_TRY(hipMemsetAsync(prof_buf.p, 0, 16 * sizeof(unsigned long long), st));
@@ -1208,8 +779,8 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         } lease;
         const bool prior = c->d_alpha != nullptr;  // --prior: the pass of the two headers compiled in namespace gx_prior
         int W = 1;
-        if (impl == kExactTeam) lease.take(c->device);
-        if (impl == kExactTeam && lease.mine) {
+        lease.take(c->device);
+        if (lease.mine) {
             W = std::max(1, std::min(kXTeamMax, c->n_cus / std::max(1, nchains)));
             if (W < 8) W = 1;  // with every compute unit busy, teams of 4 advance a chain no faster than one workgroup (profiles/r05b_c3_64chains.log)
             if (const char* e = getenv("RSEM_GX_TEAM")) W = std::max(1, std::min(kXTeamMax, atoi(e)));
@@ -1225,7 +796,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         }
         DevBuf t_ctl, t_net, t_gnet, t_ref;
         TeamArgs ta{};  // (the same bytes for either pass: see the static_asserts behind the includes)
-        if (impl == kExactTeam) {
+        {
             if (c->team_W != W) {  // the windows of this team size (W = 1: a window per tile)
                 std::vector<unsigned char> bytes;
                 size_t n_slots;
@@ -1270,7 +841,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             ta.ref = t_ref.as<int32_t>();
             if (getenv("RSEM_GX_VERBOSE")) fprintf(stderr, "[gibbs exact] teams of %d workgroups per chain, %u windows per sweep\n", W, c->n_win);
         }
-        team_used = impl == kExactTeam ? W : 0;
+        team_used = W;
         int mt_flip = 0;  // which half of mts holds the chains' generators
         hipError_t team_err = hipSuccess;
         auto sweep_team = [&](bool init, int round) {
@@ -1297,19 +868,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             if (e != hipSuccess && team_err == hipSuccess) team_err = e;
             mt_flip ^= 1;
         };
-        auto sweep = [&](bool init, int round) {
-            if (impl == kExactTeam) { sweep_team(init, round); return; }
-#define EXACT_ARGS c->N1, c->d_irp, c->d_isid, c->d_icp, counts.as<int32_t>(), z.as<int32_t>(), c->d_alpha, c->pseudoC, \
-                   mts.as<MtState>(), d_last.as<int32_t>(), round, stride_c, stride_z
-            if (impl == kExactSerial) {
-                if (init) hipLaunchKernelGGL(k_gibbs_exact_serial<true>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
-                else hipLaunchKernelGGL(k_gibbs_exact_serial<false>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS);
-            } else {
-                if (init) hipLaunchKernelGGL(k_gibbs_exact_coop<true>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS, dbg, dbg_buf.as<unsigned long long>());
-                else hipLaunchKernelGGL(k_gibbs_exact_coop<false>, dim3(nchains), dim3(64), 0, st, EXACT_ARGS, dbg, dbg_buf.as<unsigned long long>());
-            }
-#undef EXACT_ARGS
-        };
+        auto sweep = [&](bool init, int round) { sweep_team(init, round); };
         sweep(true, 0);  // initial state: z_i ~ conprb (Gibbs.cpp:281-291)
         RSEM_HIP_TRY(hipGetLastError());
         RSEM_HIP_TRY(hipStreamSynchronize(st));  // h must outlive the copy
@@ -1323,7 +882,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                 if (rc != RSEM_OK) return rc;
             }
         }
-        if (impl == kExactTeam && team_err != hipSuccess) {
+        if (team_err != hipSuccess) {
             rsem::set_last_error("k_gibbs_exact_team: launch of %d x %d workgroups failed: %s", nchains, W, hipGetErrorString(team_err));
             return RSEM_ERR_HIP;
         }
@@ -1342,7 +901,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                 fprintf(stderr, "[gibbs exact] %.2f team barriers per window\n", (double)nb / std::max(1.0, (double)nchains * (double)c->n_win * (double)sweeps));
             }
         }
-        if (RSEM_GX_PROFILE && impl == kExactTeam) {
+        if (RSEM_GX_PROFILE) {
             unsigned long long h[16];
             RSEM_HIP_TRY(hipMemcpyAsync(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost, st));
             RSEM_HIP_TRY(hipStreamSynchronize(st));
@@ -1351,14 +910,6 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                             "redraw + clean-up %.0f | publish %.0f | team barrier %.0f | cross look-ups %.0f | commit + barrier %.0f ; phases %.2f ; tiles %.0f\n",
                     h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[8] / tiles, h[11] / tiles, h[5] / tiles, h[6] / tiles, h[10] / tiles,
                     h[13] / tiles, h[9] / tiles, tiles);
-        }
-        if (dbg & 4) {
-            unsigned long long h4[4] = {0, 0, 0, 0};
-            RSEM_HIP_TRY(hipMemcpyAsync(h4, dbg_buf.p, sizeof(h4), hipMemcpyDeviceToHost, st));
-            RSEM_HIP_TRY(hipStreamSynchronize(st));
-            const double visits = (double)c->N1 * rounds * nchains;
-            fprintf(stderr, "[gibbs exact] per read visit: changed %.3f, commit iterations %.3f, redraw events %.4f, lanes redrawn %.4f\n",
-                    h4[0] / visits, h4[1] / visits, h4[2] / visits, h4[3] / visits);
         }
     } else {
         // one chain after the other: a sweep of this sampler fills the GPU by itself
