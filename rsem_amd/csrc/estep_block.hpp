@@ -255,7 +255,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         // (every lane of the read stores the same value rather than its first lane alone: no lane predicate, no branch; the
         // store costs the split shapes' loop 90 us of 1.2 ms at configs[2] with 10 % cross-gene reads either way,
         // profiles/r04d_call.log)
-        if (kX) (X.inv + (cur.slot0 - X.slot_base))[uslot] = inv;
+        if (kX) RSEM_STORE_SAME(&(X.inv + (cur.slot0 - X.slot_base))[uslot], inv);
         noise += f0 * inv;
         // reads whose fractions sum to one: sum(counts) without a reduction
         neff += (g0 && part >= kEpsilon) ? 1.0 : 0.0;

@@ -579,7 +579,7 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
                         auto enter = [&](int id, int dir) -> unsigned {
                             unsigned h = gx_hash(id);
                             for (;;) {
-                                int old = L->key[h];
+                                int old = GX_LDS_PEEK32(&L->key[h]);
                                 if (old == 0) old = GX_LDS_CAS32(&L->key[h], 0, id + 1);
                                 if (old == 0 || old == id + 1) break;
                                 h = (h + 1) & (kXKeys - 1);
@@ -659,13 +659,13 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
                     if (mv) {          // leave the table as it was found: all zero
 #pragma unroll
                         for (int q = 0; q < kXW; q++) {
-                            L->ends[h_fr][0][q] = 0ull; L->ends[h_fr][1][q] = 0ull;
-                            L->ends[h_to][0][q] = 0ull; L->ends[h_to][1][q] = 0ull;
+                            GX_LDS_STORE_SAME(&L->ends[h_fr][0][q], 0ull); GX_LDS_STORE_SAME(&L->ends[h_fr][1][q], 0ull);
+                            GX_LDS_STORE_SAME(&L->ends[h_to][0][q], 0ull); GX_LDS_STORE_SAME(&L->ends[h_to][1][q], 0ull);
                         }
-                        L->key[h_fr] = 0;
-                        L->key[h_to] = 0;
-                        L->bits[gx_bit(z_old) >> 6] = 0ull;
-                        L->bits[gx_bit(z_ent) >> 6] = 0ull;
+                        GX_LDS_STORE_SAME(&L->key[h_fr], 0);
+                        GX_LDS_STORE_SAME(&L->key[h_to], 0);
+                        GX_LDS_STORE_SAME(&L->bits[gx_bit(z_old) >> 6], 0ull);
+                        GX_LDS_STORE_SAME(&L->bits[gx_bit(z_ent) >> 6], 0ull);
                     }
                     if (rd && lane == 0) L->dirty[w] = 0ull;
 #pragma unroll

@@ -55,6 +55,11 @@ constexpr bool kXPrior = false;
 #define GX_BALLOT(p) __ballot(p)
 #define GX_LDS_OR64(p, v) (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define GX_LDS_CAS32(p, expected, desired) atomicCAS(p, expected, desired) /* returns the old value */
+// a look at a word other lanes may be claiming with GX_LDS_CAS32, and a store of a value every storing lane agrees on: plain LDS
+// accesses on the GPU (a word is read and written whole); the emulator makes them relaxed atomics, so that its ThreadSanitizer
+// build (tests/test_gibbs_exact_team_emu_cpu.py) reports exactly the accesses that are NOT meant to overlap
+#define GX_LDS_PEEK32(p) (*(p))
+#define GX_LDS_STORE_SAME(p, v) (*(p) = (v))
 #define GX_POPC64(x) __popcll(x)
 #define GX_CNT_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GX_CNT_ADD(p, v) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)

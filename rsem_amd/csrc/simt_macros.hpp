@@ -25,5 +25,8 @@
 #define RSEM_DPP_MOV(v, ctrl) __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false)
 #define RSEM_LL_AS_DOUBLE(x) __longlong_as_double(x)
 #define RSEM_DOUBLE_AS_LL(x) __double_as_longlong(x)
+/* a store of a value every storing lane agrees on: a plain store on the GPU; a relaxed atomic in the emulator, so that its
+   ThreadSanitizer runs report exactly the accesses that are not meant to overlap */
+#define RSEM_STORE_SAME(p, v) (*(p) = (v))
 #define RSEM_NT_LOAD(p) __builtin_nontemporal_load(p)  /* read-once streams: kept out of the way of theta / counts in L2 and MALL */
 #endif

@@ -46,6 +46,8 @@ inline unsigned long long ballot(bool p) {
 #define GX_BALLOT(p) emu::ballot(p)
 #define GX_LDS_OR64(p, v) (void)__atomic_fetch_or(p, v, __ATOMIC_RELAXED)
 #define GX_LDS_CAS32(p, expected, desired) __sync_val_compare_and_swap(p, expected, desired)
+#define GX_LDS_PEEK32(p) __atomic_load_n(p, __ATOMIC_RELAXED)
+#define GX_LDS_STORE_SAME(p, v) __atomic_store_n(p, v, __ATOMIC_RELAXED)
 #define GX_POPC64(x) __builtin_popcountll(x)
 #define GX_CNT_LOAD(p) __atomic_load_n(p, __ATOMIC_RELAXED)
 #define GX_CNT_ADD(p, v) (void)__atomic_fetch_add(p, v, __ATOMIC_RELAXED)

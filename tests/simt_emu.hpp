@@ -77,6 +77,11 @@ inline void atomic_add(double* p, double v) {
         memcpy(&neu, &d, 8);
     } while (!a->compare_exchange_weak(old, neu, std::memory_order_relaxed));
 }
+inline void store_same(double* p, double v) {
+    unsigned long long u;
+    memcpy(&u, &v, 8);
+    reinterpret_cast<std::atomic<unsigned long long>*>(p)->store(u, std::memory_order_relaxed);
+}
 inline double ll_as_double(long long x) { double d; memcpy(&d, &x, 8); return d; }
 inline long long double_as_ll(double d) { long long x; memcpy(&x, &d, 8); return x; }
 }  // namespace emu
@@ -102,6 +107,7 @@ inline long long double_as_ll(double d) { long long x; memcpy(&x, &d, 8); return
 #define RSEM_LL_AS_DOUBLE(x) emu::ll_as_double(x)
 #define RSEM_DOUBLE_AS_LL(x) emu::double_as_ll(x)
 #define RSEM_NT_LOAD(p) (*(p))
+#define RSEM_STORE_SAME(p, v) emu::store_same(p, v)
 
 // ---- the layout, on the host -----------------------------------------------------------------------------------------
 struct HostLayout {

@@ -23,6 +23,9 @@ pytestmark = pytest.mark.skipif(not os.path.exists(CC), reason="needs hipcc (hos
 BUILDS = {
     "product": [],
     "variants": ["-DRSEM_F64_DEPTHS=4,3,3,2", "-DRSEM_Q32_DEPTHS=5,4,3,2"],
+    # the product's body under ThreadSanitizer: one OS thread per lane and pthread barriers for the kernel's barriers, so a report is an
+    # LDS / global access of two lanes that no barrier of the kernel orders (None where the toolchain cannot build it)
+    "tsan": ["-fsanitize=thread", "-g"],
 }
 
 
@@ -32,14 +35,14 @@ def emulators(tmp_path_factory):
     procs = {}
     for name, defs in BUILDS.items():
         exe = os.path.join(d, "estep_emu_" + name)
-        procs[name] = (exe, subprocess.Popen([CC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-DRSEM_EMU", "-Wno-unused-result", "-Wno-unused-value"] + defs +
+        procs[name] = (exe, subprocess.Popen([CC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-DRSEM_EMU", "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("RSEM_EMU_FLAGS", "").split() + defs +
                                              [os.path.join(ROOT, "tests", "estep_emu.cpp"), "-o", exe, "-lpthread"],
                                              stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
     out = {}
     for name, (exe, p) in procs.items():
         err = p.communicate()[1]
-        assert p.returncode == 0, err[-3000:]
-        out[name] = exe
+        assert p.returncode == 0 or name == "tsan", err[-3000:]
+        out[name] = exe if p.returncode == 0 else None
     return out
 
 
@@ -115,3 +118,13 @@ def test_kernel_body_as_built_for_the_product(emulators, kw):
 @pytest.mark.parametrize("kw", CASES[:4] + [dict(q32=1, from_counts=1, T=5, seed=2)], ids=lambda k: "-".join("%s%s" % kv for kv in sorted(k.items())) or "plain")
 def test_other_prefetch_depths(emulators, kw):
     _check(emulators["variants"], **kw)
+
+
+@pytest.mark.parametrize("kw", [dict(from_counts=1), dict(q32=1), dict(policy=2, window=64)], ids=lambda k: "-".join("%s%s" % kv for kv in sorted(k.items())))
+def test_no_unordered_accesses_between_lanes(emulators, kw, monkeypatch):
+    """The kernel body under ThreadSanitizer (a report makes the emulator exit with 66).  The one store that overlaps on purpose --
+    every lane of a split read stores the same reciprocal -- goes through RSEM_STORE_SAME (simt_macros.hpp)."""
+    if emulators["tsan"] is None:
+        pytest.skip("no ThreadSanitizer build with this toolchain")
+    monkeypatch.setenv("TSAN_OPTIONS", "halt_on_error=0 exitcode=66")
+    _check(emulators["tsan"], **kw)

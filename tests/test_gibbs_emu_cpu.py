@@ -16,7 +16,7 @@ import test_estep_emu_cpu as te
 ROOT = te.ROOT
 pytestmark = pytest.mark.skipif(not os.path.exists(te.CC), reason="needs hipcc (host compilation of the HIP headers)")
 
-BUILDS = {"product": []}
+BUILDS = {"product": [], "tsan": ["-fsanitize=thread", "-g"]}  # (tsan: None where the toolchain cannot build it)
 
 
 @pytest.fixture(scope="module")
@@ -25,14 +25,17 @@ def emulators(tmp_path_factory):
     procs = {}
     for name, defs in BUILDS.items():
         exe = os.path.join(d, "gibbs_emu_" + name)
-        procs[name] = (exe, subprocess.Popen([te.CC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-DRSEM_EMU", "-Wno-unused-result", "-Wno-unused-value"] + defs +
+        procs[name] = (exe, subprocess.Popen([te.CC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-DRSEM_EMU", "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("RSEM_EMU_FLAGS", "").split() + defs +
                                              [os.path.join(ROOT, "tests", "gibbs_emu.cpp"), "-o", exe, "-lpthread"],
                                              stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
     out = {}
     for name, (exe, p) in procs.items():
         err = p.communicate()[1]
-        assert p.returncode == 0, err[-3000:]
-        out[name] = exe
+        assert p.returncode == 0 or name == "tsan", err[-3000:]
+        if p.returncode == 0 and name != "tsan":
+            out[name] = exe
+        if name == "tsan":
+            out["_tsan"] = exe if p.returncode == 0 else None
     return out
 
 
@@ -65,7 +68,7 @@ def test_sweep_body_distribution_and_variants(emulators):
     var = np.bincount(sid, weights=p * (1 - p), minlength=M + 1)
     exp[0], var[0] = p0.sum(), (p0 * (1 - p0)).sum()
     S = 8
-    res = {name: _run(exe, M, rp, sid, cp, ncp, g, T=4, sweeps=S, seed=5, window=0) for name, exe in emulators.items()}
+    res = {name: _run(exe, M, rp, sid, cp, ncp, g, T=4, sweeps=S, seed=5, window=0) for name, exe in emulators.items() if not name.startswith("_")}
     for name, c in res.items():
         assert np.all(c.sum(1) == N1), name                      # every read picks exactly one of its items in every sweep
         big = S * var > 5
@@ -77,3 +80,16 @@ def test_sweep_body_distribution_and_variants(emulators):
     halves = _run(emulators["product"], M, rp, sid, cp, ncp, g, T=7, sweeps=S, seed=5, half_units=1)  # waves that cross from one block into the next
     assert np.array_equal(halves, res["product"])
     assert not np.array_equal(res["product"][0], res["product"][1])  # sweeps differ from one another
+
+
+def test_no_unordered_accesses_between_lanes(emulators, monkeypatch):
+    """The sweep's body under ThreadSanitizer (one OS thread per lane, pthread barriers for the kernel's barriers): a report -- an LDS
+    or global access of two lanes that no barrier orders -- makes the emulator exit with 66.  Same picks as the plain build."""
+    if emulators["_tsan"] is None:
+        pytest.skip("no ThreadSanitizer build with this toolchain")
+    monkeypatch.setenv("TSAN_OPTIONS", "halt_on_error=0 exitcode=66")
+    M, rp, sid, cp, ncp, _ = te._data(1, n=300)
+    g = np.random.default_rng(9).gamma(0.5, 1.0, M + 1) + 1e-3
+    a = _run(emulators["_tsan"], M, rp, sid, cp, ncp, g, T=3, sweeps=2, seed=5, window=64)
+    b = _run(emulators["product"], M, rp, sid, cp, ncp, g, T=3, sweeps=2, seed=5, window=64)
+    assert np.array_equal(a, b)

@@ -109,3 +109,52 @@ def test_single_read_tiles_across_a_team(team_256, seed):
     for W in (2, 4):
         got, _ = _run(team_256, W, M, rp, sid, cp, init, 12, seed, 0, 0.05)
         assert np.array_equal(got, _oracle(M, rp, sid, cp, init, 12, seed, 0, 0.05))
+
+
+# ---- the same body under ThreadSanitizer -------------------------------------------------------------------------------------------
+# One OS thread per lane, pthread barriers for __syncthreads() / the wave barrier, CPU atomics for the LDS and global atomics: what
+# ThreadSanitizer then reports is an LDS or global access of two lanes that no barrier of the kernel orders -- the missing
+# __syncthreads() that shows on the GPU once in many runs (or never on one compiler version).  The two accesses that overlap on purpose
+# (a look at a hash slot others may be claiming; lanes storing the same zero) go through GX_LDS_PEEK32 / GX_LDS_STORE_SAME.  With the
+# barrier behind the initial assignment's draw taken out, these cases report races (tried by hand; profiles/HISTORY.md).
+def _tsan_build(tmp_path_factory, name, defs):
+    exe = os.path.join(str(tmp_path_factory.mktemp(name)), name)
+    r = subprocess.run([CXX, "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread"] + defs
+                       + [os.path.join(ROOT, "tests", "gibbs_exact_team_emu.cpp"), "-o", exe], stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        pytest.skip("this g++ cannot build with -fsanitize=thread: " + r.stderr[-300:])
+    probe = subprocess.run([exe], stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)  # (no arguments: usage, exit 2 -- or the runtime refuses to start)
+    if "ThreadSanitizer" in probe.stderr and "FATAL" in probe.stderr:
+        pytest.skip("ThreadSanitizer does not start here: " + probe.stderr[-300:])
+    return exe
+
+
+@pytest.fixture(scope="module")
+def team_tsan(tmp_path_factory):
+    return _tsan_build(tmp_path_factory, "gibbs_exact_team_tsan", [])
+
+
+@pytest.fixture(scope="module")
+def team_tsan_prior(tmp_path_factory):
+    return _tsan_build(tmp_path_factory, "gibbs_exact_team_tsan_prior", ["-DRSEM_GX_PRIOR=1"])
+
+
+@pytest.mark.parametrize("ci,W", [(0, 1), (0, 3), (4, 1), (5, 1), (5, 3), (6, 2), (6, 8)])  # (all of CASES x W = 1, 2, 3, 8 were run once by hand: clean)
+def test_no_unordered_accesses_between_lanes(team_tsan, ci, W, monkeypatch):
+    case = CASES[ci]
+    monkeypatch.setenv("TSAN_OPTIONS", "halt_on_error=0 exitcode=66")
+    log = _check(team_tsan, W, case)  # (a report makes the exit code 66: _run asserts 0 and shows the report)
+    assert "ThreadSanitizer" not in log
+
+
+def test_no_unordered_accesses_between_lanes_prior(team_tsan_prior, monkeypatch):
+    from tests.test_gibbs_exact_emu_cpu import _run as run_alpha
+    monkeypatch.setenv("TSAN_OPTIONS", "halt_on_error=0 exitcode=66")
+    c = dict(CASES[2])
+    rp, sid, cp = _items(c["seed"], c["M"], c["N1"], c["maxlen"], c["noise_scale"], 0)
+    init = np.zeros(c["M"] + 1, np.int32)
+    alpha = np.random.default_rng(100 + c["seed"]).uniform(0.05, 3.0, c["M"] + 1)
+    alpha[0] = 1.0
+    for W in (1, 3):
+        got = run_alpha(team_tsan_prior, c["M"], rp, sid, cp, init, c["rounds"], 1000 + c["seed"], c["N0"], c["pseudoC"], alpha=alpha, W=W)
+        assert np.array_equal(got, _oracle(c["M"], rp, sid, cp, init, c["rounds"], 1000 + c["seed"], c["N0"], c["pseudoC"], alpha=alpha))

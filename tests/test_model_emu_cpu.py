@@ -20,7 +20,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(CC), reason="needs hipcc (hos
 @pytest.fixture(scope="module")
 def emulator(tmp_path_factory):
     exe = os.path.join(str(tmp_path_factory.mktemp("model_emu")), "model_emu")
-    r = subprocess.run([CC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-DRSEM_EMU", "-Wno-unused-result", "-Wno-unused-value",
+    r = subprocess.run([CC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-DRSEM_EMU", "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("RSEM_EMU_FLAGS", "").split() + [
                         os.path.join(ROOT, "tests", "model_emu.cpp"), "-o", exe, "-lpthread"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     return exe
@@ -31,3 +31,21 @@ def test_group_kernel_body_equals_the_per_alignment_restatement(emulator, model_
     r = subprocess.run([emulator, str(model_type), str(seed), str(est_rspd), str(has_mld)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "MISMATCH" not in r.stdout
+
+
+@pytest.fixture(scope="module")
+def emulator_tsan(tmp_path_factory):
+    exe = os.path.join(str(tmp_path_factory.mktemp("model_emu_tsan")), "model_emu_tsan")
+    r = subprocess.run([CC, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-DRSEM_EMU", "-fsanitize=thread", "-Wno-unused-result", "-Wno-unused-value",
+                        os.path.join(ROOT, "tests", "model_emu.cpp"), "-o", exe, "-lpthread"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        pytest.skip("no ThreadSanitizer build with this toolchain: " + r.stderr[-300:])
+    return exe
+
+
+@pytest.mark.parametrize("model_type,seed,est_rspd,has_mld", [(3, 2, 1, 0)])  # (all seven cases were run once by hand: clean)
+def test_no_unordered_accesses_between_lanes(emulator_tsan, model_type, seed, est_rspd, has_mld, monkeypatch):
+    """k_model_group's body under ThreadSanitizer (one OS thread per lane, pthread barriers for the kernel's barriers): an LDS or
+    global access of two lanes that no barrier orders is reported and makes the emulator exit with 66."""
+    monkeypatch.setenv("TSAN_OPTIONS", "halt_on_error=0 exitcode=66")
+    test_group_kernel_body_equals_the_per_alignment_restatement(emulator_tsan, model_type, seed, est_rspd, has_mld)
