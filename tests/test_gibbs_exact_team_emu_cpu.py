@@ -158,3 +158,31 @@ def test_no_unordered_accesses_between_lanes_prior(team_tsan_prior, monkeypatch)
     for W in (1, 3):
         got = run_alpha(team_tsan_prior, c["M"], rp, sid, cp, init, c["rounds"], 1000 + c["seed"], c["N0"], c["pseudoC"], alpha=alpha, W=W)
         assert np.array_equal(got, _oracle(c["M"], rp, sid, cp, init, c["rounds"], 1000 + c["seed"], c["N0"], c["pseudoC"], alpha=alpha))
+
+
+@pytest.mark.parametrize("W", [1, 2])
+def test_tile_and_item_capacity_boundaries(team_256, W):
+    """one read; reads of the noise transcript alone; 255 / 256 / 257 / 512 / 513 reads (a tile takes 256); a read of 4095 / 4096 / 4097
+    items (a tile's LDS takes 4096: the last one is walked alone); items with conprb 0 inside reads -- for one workgroup and for a team
+    of two (with fewer tiles than workgroups in most of these)"""
+    rng = np.random.default_rng(3)
+
+    def run(M, rp, sid, cp, rounds=3, seed=7, N0=2, pc=1.0):
+        rp, sid, cp = np.asarray(rp, np.uint64), np.asarray(sid, np.int32), np.asarray(cp, float)
+        init = np.zeros(M + 1, np.int32)
+        got, _ = _run(team_256, W, M, rp, sid, cp, init, rounds, seed, N0, pc)
+        assert np.array_equal(got, _oracle(M, rp, sid, cp, init, rounds, seed, N0, pc))
+
+    run(3, [0, 3], [0, 1, 2], [0.1, 1, 1])
+    run(3, [0, 1, 2, 3], [0, 0, 0], [1, 1, 1])
+    for n in (255, 256, 257, 512, 513):
+        k = 3
+        run(5, np.arange(n + 1) * k, np.concatenate([[0] + list(rng.integers(1, 6, k - 1)) for _ in range(n)]), rng.uniform(0.01, 1, n * k))
+    for k in (4095, 4096, 4097):
+        sid = [0, 1] + [0] + list(rng.integers(1, 6, k - 1)) + [0, 2]
+        run(5, [0, 2, 2 + k, 4 + k], sid, rng.uniform(0.01, 1, len(sid)))
+    n, k = 700, 4
+    cp = rng.uniform(0.01, 1, n * k)
+    cp[rng.random(n * k) < 0.4] = 0.0
+    cp[::k] = 0.3
+    run(6, np.arange(n + 1) * k, np.concatenate([[0] + list(rng.integers(1, 7, k - 1)) for _ in range(n)]), cp)
