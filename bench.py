@@ -187,6 +187,8 @@ def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True, bam_leg=Tru
                          "per alignment, so it carries over to the full size (E step is O(alignments))"
                          % (cores, " pinned to the physical cores of one socket (its fastest setting found: profiles/r04p_ref_threads_probe.json)" if pinned else "", {1: "SingleQModel", 3: "PairedEndQModel"}[rt], cs["frac"] * 100, n1, nhits, nhits / n1, cs["M"],
                             late[-1][0] - late[0][0], per_round * 1e3),
+               "sample_short": "oracle/_ref/rsem-run-em -p %d%s, generated %s input at %.0f %% of the workload's reads (%d alignments), rounds >= 12 from its ROUND lines"
+                               % (cores, " pinned to one socket" if pinned else "", {1: "SingleQModel", 3: "PairedEndQModel"}[rt], cs["frac"] * 100, nhits),
                "ms_per_round": per_round * 1e3, "rounds_timed": late[-1][0] - late[0][0], "startup_s": startup_s,
                "host_cores_available": ncpu, "pinned_cpus": ",".join(map(str, pinned)) if pinned else None, "generate_s": gen_s}
         e2e = {"what": "whole programs on the same files, wall clock: parse the .temp files, rounds 1-11 with the model, rounds >= 12 to convergence, "
@@ -445,6 +447,128 @@ def em_leg(capi, make_em_workload, config, K, W, kernel, sync, device, q32=False
         return out
     except Exception as e:
         return {"error": str(e)}
+
+
+DETAIL_NAME = "bench_detail_latest.json"
+LINE_LIMIT = 6000  # bytes; the driver keeps the last 8 187 bytes of stdout: the contract line must fit in them whole
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _num(x, digits=6):
+    """Shorter floats for the contract line (the side file keeps every digit)."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _num(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v, digits) for v in x]
+    return x
+
+
+def _leg_summary(leg):
+    if not isinstance(leg, dict) or "error" in leg:
+        return {"error": str((leg or {}).get("error"))[:120]}
+    par = leg.get("parity_one_step") or {}
+    out = {"ms": leg.get("estep_avg_launch_ms"), "ms_per_step": leg.get("ms_per_step"), "frac": leg.get("frac"),
+           "frac_algorithmic": leg.get("frac_algorithmic"), "parity_one_step": par.get("max_rel_diff_counts_vs_oracle"), "parity_ok": par.get("ok")}
+    q = leg.get("q32_value_planes")
+    if isinstance(q, dict) and "error" not in q:
+        out["q32_ms"] = q.get("estep_avg_launch_ms")
+    return out
+
+
+def _gibbs_summary(g):
+    if not isinstance(g, dict) or "error" in g:
+        return {"error": str((g or {}).get("error"))[:160]}
+    out = {"items_per_chain": g.get("items_per_chain"), "gpus": g.get("gpus")}
+    p, e = g.get("parallel") or {}, g.get("exact") or {}
+    many = ("ms_per_sweep_per_rank", "sweeps_per_s_per_rank", "frac_of_hbm_peak_per_rank", "ms_per_round_per_rank") if (g.get("gpus") or 1) > 1 else ()
+    out["parallel"] = _pick(p, ("ms_per_sweep", "sweeps_per_s_all_gpus", "frac_of_hbm_peak_per_gpu", "final_reduce_ms") + many)
+    out["exact"] = _pick(e, ("ms_per_round", "chains_per_gpu", "workgroups_per_chain", "us_per_read_visit_and_chain", "read_visits_per_s_all_gpus", "final_reduce_ms") + many)
+    for k in ("exact_strong", "cpu_baseline"):
+        if isinstance(g.get(k), dict):
+            out[k] = {kk: vv for kk, vv in g[k].items() if not isinstance(vv, (dict, list)) and not (isinstance(vv, str) and len(vv) > 100)}
+    return out
+
+
+def contract_line(detail, detail_path):
+    """The ONE line of stdout: the contract's keys and one-number summaries of the legs, well under LINE_LIMIT bytes.  Everything
+    else (prose, conditions, recordings, per-part byte tables, per-leg records) is `detail`, written to `detail_path` by the
+    same run."""
+    line = _pick(detail, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data",
+                          "em_iterations_per_s", "timed_rounds", "timed_region_s"))
+    line["vs_baseline"] = detail.get("vs_baseline")
+    line["config"] = _pick(detail["config"], ("workload", "synthetic_config", "kernel", "value_bits", "parallelism"))
+    r = detail["roofline"]
+    line["roofline"] = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "algorithmic_bytes_per_launch",
+                                 "achieved_algorithmic", "frac_algorithmic", "step_over_launch"))
+    line["roofline"]["traffic"] = r.get("traffic")
+    line["roofline"]["physical_bytes_per_launch"] = (r.get("physical") or {}).get("physical_bytes_per_launch")
+    if isinstance(r.get("stream"), dict):
+        line["roofline"]["stream_read_GBps"] = r["stream"].get("read_GBps")
+    cb = detail.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "ms_per_round", "rounds_timed", "host_cores_available"))
+        line["cpu_baseline"]["sample"] = cb.get("sample_short") or str(cb.get("sample"))[:200]
+        line["speedup_vs_cpu_baseline_rounds"] = detail.get("speedup_vs_cpu_baseline_rounds")
+    par = (detail.get("checks") or {}).get("parity_one_step")
+    line["checks"] = {"theta_sum": (detail.get("checks") or {}).get("theta_sum"),
+                      "parity_one_step": _pick(par, ("max_rel_diff_counts_vs_oracle", "ok", "tolerance", "alignments_checked", "error")) if par else None}
+    e = detail.get("e2e_wall_clock")
+    if isinstance(e, dict):
+        o = {}
+        if isinstance(e.get("measured"), dict):
+            o["measured"] = _pick(e["measured"], ("reference_s", "dropin_s", "speedup", "same_round_count", "dropin_rounds", "theta_max_rel_diff", "reference_threads", "frac_of_workload"))
+        if isinstance(e.get("bam_on"), dict):
+            o["bam_on"] = _pick(e["bam_on"], ("reference_s", "dropin_s", "speedup", "theta_max_rel_diff", "frac_of_workload", "input", "bam_pass_reference_s", "bam_pass_dropin_s", "error"))
+        if isinstance(e.get("full_size"), dict):
+            o["full_size"] = _pick(e["full_size"], ("dropin_s", "dropin_rounds", "same_round_count_as_the_reference", "reference_s_extrapolated", "speedup_extrapolated",
+                                                   "reference_s", "speedup_vs_recorded_reference", "theta_max_rel_diff_vs_recorded_reference"))
+        line["e2e"] = o
+    if isinstance(detail.get("other_configs"), dict):
+        line["legs"] = {k: _leg_summary(v) for k, v in detail["other_configs"].items()}
+    q = detail.get("q32_value_planes")
+    if isinstance(q, dict):
+        line["q32"] = _pick(q, ("estep_avg_launch_ms", "ms_per_step", "frac_physical", "reads_q32_fraction", "error"))
+    if detail.get("gibbs") is not None:
+        line["gibbs"] = _gibbs_summary(detail["gibbs"])
+    ci = detail.get("credibility_intervals")
+    if isinstance(ci, dict):
+        line["ci"] = {k: v for k, v in ci.items() if not isinstance(v, (dict, list)) and not (isinstance(v, str) and len(v) > 100)}
+    if isinstance(detail.get("distributed"), dict):
+        line["distributed"] = detail["distributed"]
+    line["upload_and_layout_s"] = detail.get("upload_and_layout_s")
+    line["detail"] = detail_path
+    line = _num(line)
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) > LINE_LIMIT:  # never again a line the driver cannot parse: drop the summaries, largest first, keep the contract
+        for k in sorted(("legs", "gibbs", "ci", "e2e", "q32", "distributed"), key=lambda k: -len(json.dumps(line.get(k)))):
+            if k in line:
+                line[k] = {"see": "detail"}
+                s = json.dumps(line, separators=(",", ":"))
+                if len(s) <= LINE_LIMIT:
+                    break
+    return s
+
+
+def write_detail(detail):
+    """profiles/bench_detail_latest.json (BENCH_DETAIL_PATH overrides: tests), and a copy under gpurun_out/ where that exists."""
+    path = os.environ.get("BENCH_DETAIL_PATH") or os.path.join(ROOT, "profiles", DETAIL_NAME)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(detail, f, indent=1)
+        scratch = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(scratch) and not os.environ.get("BENCH_DETAIL_PATH"):
+            with open(os.path.join(scratch, DETAIL_NAME), "w") as f:
+                json.dump(detail, f, indent=1)
+    except OSError as e:
+        log("bench detail not written: %s" % e)
+        return None
+    return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
 
 
 def main():
@@ -737,7 +861,7 @@ def main():
                     line["e2e_full_size_recorded_round4"] = json.load(f)
             except Exception:
                 pass
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        os.write(json_fd, (contract_line(line, write_detail(line)) + "\n").encode())
     if comm is not None:
         barrier()
         comm.close()

@@ -73,37 +73,72 @@ capi.gibbs_chain_seeds = lambda seed, n: list(range(n))
 '''
 
 
-def test_bench_main_prints_one_contract_line():
-    r = subprocess.run([sys.executable, "-c", DRIVER % {"root": ROOT, "extra": "", "argv": []}], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+def _run_driver(tmp_path, extra="", argv=()):
+    detail = os.path.join(str(tmp_path), "detail.json")
+    r = subprocess.run([sys.executable, "-c", DRIVER % {"root": ROOT, "extra": extra, "argv": list(argv)}], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=300, env=dict(os.environ, BENCH_DETAIL_PATH=detail))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.split("\n") if l.strip()]
     assert len(lines) == 1, r.stdout[:500]
-    d = json.loads(lines[0])
+    with open(detail) as f:
+        return lines[0], json.loads(lines[0]), json.load(f)
+
+
+def test_bench_main_prints_one_contract_line(tmp_path):
+    raw, d, det = _run_driver(tmp_path)
+    # the driver keeps the last 8 187 bytes of stdout: the line must fit in them whole (round 5's 22.5 KB line was not parsed)
+    assert len(raw) < 8000, len(raw)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-                "data", "config", "roofline"):
+                "data", "config", "roofline", "detail"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "algorithmic_bytes_per_launch", "frac_algorithmic"):
         assert key in d["roofline"], key
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
-    assert d["q32_value_planes"]["value_bits"] == 32 and "tinyR" in d["other_configs"] and "10000 reads" in d["other_configs"]["tiny@0.5"]["workload"]
-    assert "error" in d["gibbs"] and "error" in d["credibility_intervals"]  # the EM line survives a failing side leg
+    # the contract's fraction is the physical one (the layout's own bytes over its own launch time: never above 1 for a kernel that
+    # moves what its layout says); the formula's sits beside it
+    assert abs(d["roofline"]["frac"] - 1500 / 1e-3 / 1e9 / 8000.0) < 1e-9 and abs(d["roofline"]["achieved"] - d["roofline"]["frac"] * 8000.0) < 1e-3
+    assert d["roofline"]["frac_algorithmic"] > 0 and d["roofline"]["physical_bytes_per_launch"] == 1500 and d["roofline"]["stream_read_GBps"] == 6000.0
+    # one-number summaries of the legs; a failing side leg does not take the EM line with it
+    assert set(d["legs"]) == {"tinyR", "tiny@0.5"} and d["legs"]["tinyR"]["frac"] > 0 and d["legs"]["tinyR"]["ms"] == 1.0
+    assert "error" in d["gibbs"] and "error" in d["ci"]
     # the parity check beside the measurement really compares with the oracle (the stand-in returns nonsense counts)
-    assert d["checks"]["parity_one_step"]["ok"] is False and d["other_configs"]["tinyR"]["parity_one_step"]["ok"] is False
-    assert d["roofline"]["stream"]["read_GBps"] == 6000.0 and d["roofline"]["achieved_over_stream_read"] > 0
-    assert "frac_of_traffic" in d["roofline"]
-    # the roofline fraction the run can vouch for: the layout's own bytes over its own launch time, on the headline AND every leg
-    assert d["roofline"]["frac_physical"] == 1500 / 1e-3 / 1e9 / 8000.0 and d["roofline"]["physical"]["parts"]["sid_planes_loaded"] == 100
-    # the contract's fraction is the physical one (never above 1 for a kernel that moves what its layout says); the formula's sits beside it
-    assert d["roofline"]["frac"] == d["roofline"]["frac_physical"] and d["roofline"]["achieved"] == d["roofline"]["frac"] * 8000.0
-    assert d["roofline"]["frac_algorithmic"] > 0 and "achieved_algorithmic" in d["roofline"]
-    for leg in d["other_configs"].values():
+    assert d["checks"]["parity_one_step"]["ok"] is False and d["legs"]["tinyR"]["parity_ok"] is False
+    assert d["q32"]["estep_avg_launch_ms"] == 1.0 and abs(d["q32"]["frac_physical"] - 1020 / 1e-3 / 1e9 / 8000.0) < 1e-9
+    # everything else is in the side file the line names
+    assert det["metric"] == d["metric"] and det["steps"] == 3
+    assert det["roofline"]["physical"]["parts"]["sid_planes_loaded"] == 100 and "note" in det["roofline"] and "frac_of_traffic" in det["roofline"]
+    assert det["roofline"]["stream"]["read_GBps"] == 6000.0 and det["roofline"]["achieved_over_stream_read"] > 0
+    assert det["roofline"]["frac"] == det["roofline"]["frac_physical"] == 1500 / 1e-3 / 1e9 / 8000.0
+    assert det["q32_value_planes"]["value_bits"] == 32 and "10000 reads" in det["other_configs"]["tiny@0.5"]["workload"]
+    for leg in det["other_configs"].values():
         assert leg["frac_physical"] > 0 and leg["physical"]["physical_bytes_per_launch"] == 1500
-    assert d["q32_value_planes"]["frac_physical"] == 1020 / 1e-3 / 1e9 / 8000.0
+    assert det["q32_value_planes"]["frac_physical"] == 1020 / 1e-3 / 1e9 / 8000.0
 
 
-def test_bench_two_ranks_line_carries_per_rank_numbers():
+def test_contract_line_of_a_full_run_fits_the_drivers_tail():
+    """The line assembled from a whole default run's record (round 5's 22.5 KB one, committed) stays below 8 000 bytes and keeps
+    roofline.frac and cpu_baseline.value; a record ten times as wordy still does."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    with open(os.path.join(ROOT, "profiles", "r05y_bench_default_final.json")) as f:
+        det = json.load(f)
+    raw = b.contract_line(det, "profiles/bench_detail_latest.json")
+    d = json.loads(raw)
+    assert len(raw) < 8000 and "\n" not in raw
+    assert 0 < d["roofline"]["frac"] <= 1 and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["cores"] == 64
+    assert d["e2e"]["measured"]["speedup"] > 1 and d["e2e"]["full_size"]["dropin_s"] > 0 and d["checks"]["parity_one_step"]["ok"] is True
+    assert set(d["legs"]) == {"C2", "C2R", "C3X", "C3X30", "C5"} and d["gibbs"]["exact"]["ms_per_round"] > 0
+    det["other_configs"] = {"leg%d" % i: det["other_configs"]["C2"] for i in range(200)}
+    raw = b.contract_line(det, "x.json")
+    d = json.loads(raw)
+    assert len(raw) < 8000 and d["legs"] == {"see": "detail"} and d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
+
+
+def test_bench_two_ranks_line_carries_per_rank_numbers(tmp_path):
     """The N > 1 control flow of bench.py as two gloo processes on the CPU (BENCH_DIST_BACKEND=gloo; the C-ABI wrappers and
     the communicator are stand-ins): rank 0 prints ONE line, n_gpus = 2, value = the sum over ranks, and the line carries what
     a scaling run is read for -- per-rank E-step times and physical roofline fractions, per-rank sweeps/s of the PARALLEL Gibbs
@@ -115,7 +150,7 @@ def test_bench_two_ranks_line_carries_per_rank_numbers():
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   BENCH_DIST_BACKEND="gloo")
+                   BENCH_DIST_BACKEND="gloo", BENCH_DETAIL_PATH=os.path.join(str(tmp_path), "detail%d.json" % rank))
         code = DRIVER % {"root": ROOT, "extra": DIST_EXTRA, "argv": ["--gpus", "2", "--no-ci"]}
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
@@ -131,7 +166,7 @@ def test_bench_two_ranks_line_carries_per_rank_numbers():
     assert all(x > 0 for x in di["frac_physical_per_rank"]) and di["allreduce_ms"] >= 0
     g = d["gibbs"]["parallel"]
     assert g["ms_per_sweep_per_rank"] == [2.0, 3.0] and g["ms_per_sweep"] == 3.0  # the slowest GPU sets the job's rate
-    assert g["sweeps_per_s_per_rank"] == [500.0, 1e3 / 3.0] and g["sweeps_per_s_all_gpus"] == 2 * 1e3 / 3.0
+    assert g["sweeps_per_s_per_rank"] == [500.0, 333.333] and g["sweeps_per_s_all_gpus"] == 666.667  # (six digits in the line)
     assert g["final_reduce_ms"] == 0.25 and len(g["frac_of_hbm_peak_per_rank"]) == 2
     assert d["gibbs"]["exact"]["final_reduce_ms"] == 0.25
 
