@@ -106,7 +106,62 @@ def one_socket_cores(want=64):
     return None
 
 
-def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True, bam_leg=True):
+GIBBS_E2E = dict(burnin=20, nsamples=40, gap=1, threads=8)  # per chain: 20 + 5 rounds (the pipeline's 200 / 1000 / 1 would be 325)
+
+
+def gibbs_reference_leg(root, rt, n1, pin_cpus, limit_s=150.0):
+    """rsem-run-gibbs, the UNMODIFIED reference binary (oracle/_ref, its pthread chains: Gibbs.cpp:207-254) and the drop-in
+    (--gibbs-mode exact: the same chains on the GPU), on the SAME imdName.ofg -- written by the drop-in's rsem-run-em --gibbs-out
+    in `root` (the 5 % input of the EM comparison) --, same -p 8 --seed 1 and chain parameters; wall clock of the whole programs,
+    and the count-vector files compared byte for byte (the checker: the chains must be the reference's)."""
+    import filecmp
+    import shutil
+    import subprocess
+    ref_g = os.path.join(ROOT, "oracle", "_ref", "rsem-run-gibbs")
+    new_g = os.path.join(ROOT, "rsem_amd", "bin", "rsem-run-gibbs")
+    new_em = os.path.join(ROOT, "rsem_amd", "bin", "rsem-run-em")
+    if not all(os.path.exists(p) for p in (ref_g, new_g, new_em)):
+        return None
+    g = GIBBS_E2E
+    P = g["threads"]
+    ref, imd, stat = os.path.join(root, "ref"), os.path.join(root, "temp", "s"), os.path.join(root, "stat", "s")
+    t0 = time.perf_counter()
+    r = subprocess.run([new_em, ref, str(rt), os.path.join(root, "s"), imd, stat, "-p", "64", "--gibbs-out", "-q"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0 or not os.path.exists(imd + ".ofg"):
+        return {"error": "rsem-run-em --gibbs-out failed: " + r.stdout[-200:]}
+    ofg_s = time.perf_counter() - t0
+    tref = os.path.join(root, "tref")
+    os.makedirs(tref, exist_ok=True)
+    os.symlink(imd + ".ofg", os.path.join(tref, "s.ofg"))
+    for f in ("omit", "iso_res", "gene_res"):
+        if os.path.exists(imd + "." + f):
+            shutil.copy(imd + "." + f, os.path.join(tref, "s." + f))
+    open(os.path.join(tref, "s.omit"), "a").close()
+    args = [str(g["burnin"]), str(g["nsamples"]), str(g["gap"]), "-p", str(P), "--seed", "1"]
+    pin = ["taskset", "-c", ",".join(map(str, pin_cpus[:P]))] if pin_cpus and len(pin_cpus) >= P else []
+    t0 = time.perf_counter()
+    try:
+        rr = subprocess.run(pin + [ref_g, ref, os.path.join(tref, "s"), stat] + args + ["-q"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "the reference's rsem-run-gibbs did not finish in %.0f s" % limit_s}
+    ref_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rn = subprocess.run([new_g, ref, imd, stat] + args + ["--gibbs-mode", "exact"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    new_s = time.perf_counter() - t0
+    if rr.returncode != 0 or rn.returncode != 0:
+        return {"error": "rsem-run-gibbs failed: reference rc %d, drop-in rc %d %s" % (rr.returncode, rn.returncode, rn.stdout[-200:])}
+    same = [os.path.exists(imd + ".countvectors%d" % k) and filecmp.cmp(imd + ".countvectors%d" % k, os.path.join(tref, "s.countvectors%d" % k), shallow=False)
+            for k in range(P)]
+    rounds = g["burnin"] + 1 + (g["nsamples"] // P - 1) * g["gap"]
+    return {"what": "rsem-run-gibbs %s on the same imdName.ofg (%d reads, %.2f GB of text): oracle/_ref (pthread chains%s) and the drop-in (--gibbs-mode exact), whole programs"
+                    % (" ".join(args), n1, os.path.getsize(imd + ".ofg") / 1e9, ", pinned to %d cores of one socket" % P if pin else ""),
+            "kind": "reference", "cores": P, "reads": n1, "chains": P, "rounds_per_chain": rounds,
+            "value": P * rounds * n1 / ref_s, "unit": "read visits/s (all chains, whole program incl. reading .ofg)",
+            "reference_s": ref_s, "dropin_s": new_s, "speedup": ref_s / new_s, "dropin_read_visits_per_s": P * rounds * n1 / new_s,
+            "count_vector_files": P, "count_vectors_identical": bool(all(same)), "write_ofg_s": ofg_s}
+
+
+def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True, bam_leg=True, gibbs_leg=True):
     """The UNMODIFIED reference binary (oracle/_ref/rsem-run-em, built from /root/reference) and the drop-in
     (rsem_amd/bin/rsem-run-em) on the SAME generated .temp files of the bench workload's shape (tools/gen_temp.cpp: model
     type, transcripts, isoforms per gene; `frac` of its reads), each run to convergence, wall clock of the whole program.
@@ -204,6 +259,11 @@ def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True, bam_leg=Tru
             e2e["measured"].update({"dropin_s": new_wall, "dropin_rounds": new_rounds, "speedup": ref_wall / new_wall,
                                     "same_round_count": new_rounds == marks[-1][0],
                                     "theta_max_rel_diff": float(np.max(np.abs(new_theta - ref_theta)[big] / ref_theta[big])) if big.any() else 0.0})
+        if gibbs_leg and finished:
+            try:
+                e2e["gibbs"] = gibbs_reference_leg(small, rt, n1, pinned)
+            except Exception as e:
+                e2e["gibbs"] = {"error": str(e)[:300]}
         shutil.rmtree(small, ignore_errors=True)
         if bam_leg and finished:
             # -b is ON by default in rsem-calculate-expression (:61,626-632): the same comparison with the transcript.bam pass
@@ -733,11 +793,23 @@ def main():
             ex_seeds = capi.gibbs_chain_seeds(7, n_exact * world)
             _, acc_e, _, pe = g.run_chains(capi.GIBBS_EXACT, [ex_seeds[k] for k in gibbs_rank_chains(n_exact * world, world, rank)],
                                            args.gibbs_exact_rounds - 1, [2] * n_exact, 1, want_vectors=False)
+            # the split north_star names: 8 chains IN ALL dealt to the GPUs (chain k on rank k % N: one chain per GPU at N = 8), a
+            # team of min(64, CUs / chains of the GPU) workgroups per chain -- strong scaling of ONE rsem-run-gibbs -p 8 run.  At N = 1
+            # that IS the leg above (8 chains x teams of 32); beside it one chain alone on the GPU (a team of 64) = what every GPU of
+            # an 8-GPU run does, so the 1 -> 8 prediction can be read off a single-GPU line.
+            strong_total = 8
+            mine = list(gibbs_rank_chains(strong_total, world, rank))
+            ps, p1 = pe, None
+            if 1 < world <= strong_total:  # (every rank has a chain: all of them meet in the run's one reduce)
+                st_seeds = capi.gibbs_chain_seeds(7, strong_total)
+                _, _, _, ps = g.run_chains(capi.GIBBS_EXACT, [st_seeds[k] for k in mine], args.gibbs_exact_rounds - 1, [2] * len(mine), 1, want_vectors=False)
+            if world == 1:
+                _, _, _, p1 = g.run_chains(capi.GIBBS_EXACT, capi.gibbs_chain_seeds(7, 1), args.gibbs_exact_rounds - 1, [2], 1, want_vectors=False)
             g.close()
             b_g = 12 * (len(isid) - N1) + 16 * N1  # conprb + sid per alignment, noise conprb + row slot per read
-            per_rank = [[pp.sweep_ms, pp.reduce_ms, pe.sweep_ms, pe.reduce_ms]]
+            per_rank = [[pp.sweep_ms, pp.reduce_ms, pe.sweep_ms, pe.reduce_ms, ps.sweep_ms if mine else 0.0, float(ps.team if mine else 0)]]
             if distributed:
-                t = torch.zeros(world, 4, dtype=torch.float64, device=tdev)
+                t = torch.zeros(world, 6, dtype=torch.float64, device=tdev)
                 t[rank] = torch.tensor(per_rank[0], dtype=torch.float64)
                 dist.all_reduce(t)
                 per_rank = t.cpu().tolist()
@@ -767,6 +839,15 @@ def main():
                                "items_per_s_all_gpus": world * n_exact * len(isid) * 1e3 / ex if ex > 0 else None,
                                "final_reduce_ms": max(r[3] for r in per_rank) if distributed else None,
                                "sum_of_pme_c_over_samples": float(acc_e[0].sum())}}
+            exs = max(r[4] for r in per_rank)
+            gibbs["exact_strong"] = {"chains_total": strong_total, "chains_per_gpu": (strong_total + world - 1) // world, "gpus": world,
+                                     "workgroups_per_chain": int(max(r[5] for r in per_rank)), "ms_per_round": exs,
+                                     "ms_per_round_per_rank": [r[4] for r in per_rank] if world > 1 else None,
+                                     "rounds_per_s": 1e3 / exs if exs > 0 else None,
+                                     "read_visits_per_s_all_chains": strong_total * N1 * 1e3 / exs if exs > 0 else None}
+            if p1 is not None:
+                gibbs["exact_strong"].update({"one_chain_alone_ms_per_round": p1.sweep_ms, "one_chain_alone_workgroups": p1.team,
+                                              "predicted_speedup_1_to_8_gpus": exs / p1.sweep_ms if p1.sweep_ms > 0 else None})
         except Exception as e:  # the EM line must still be printed
             gibbs = {"error": str(e)}
 
@@ -845,7 +926,7 @@ def main():
             if not args.no_cpu_baseline:  # reported baseline + whole-program wall clock: rank 0 at N=1 only
                 cb, e2e = None, None
                 try:
-                    cb, e2e = reference_e2e(args.config, N1, full_size=not args.no_e2e_full, bam_leg=not args.no_bam_leg)
+                    cb, e2e = reference_e2e(args.config, N1, full_size=not args.no_e2e_full, bam_leg=not args.no_bam_leg, gibbs_leg=not args.no_gibbs)
                 except Exception as e:
                     log("reference_e2e failed: %s" % e)
                 if cb is None:
@@ -856,6 +937,8 @@ def main():
                 line["speedup_vs_cpu_baseline_rounds"] = line["value"] / cb["value"]
                 if e2e is not None:
                     line["e2e_wall_clock"] = e2e
+                    if isinstance(e2e.get("gibbs"), dict) and isinstance(line.get("gibbs"), dict):
+                        line["gibbs"]["cpu_baseline"] = e2e.pop("gibbs")  # the reference's chains timed in this run, beside the GPU's
             try:  # the builder-run record of both programs at FULL size (profiles/scripts/gpu_r04a.sh), for reference
                 with open(os.path.join(ROOT, "profiles", "e2e_full_size_reference.json")) as f:
                     line["e2e_full_size_recorded_round4"] = json.load(f)

@@ -1179,12 +1179,17 @@ int ensure_csr(rsem_em_ctx* c) {
     if (!c->csr_released) return RSEM_OK;
     RSEM_HIP_TRY(hipSetDevice(c->device));
     RSEM_HIP_TRY(dmalloc(&c->d_sid, c->nnz));
-    RSEM_HIP_TRY(dmalloc(&c->d_cp, c->nnz));
+    if (hipError_t e = dmalloc(&c->d_cp, c->nnz); e != hipSuccess) {  // (all or nothing: the next call starts from "released")
+        (void)hipFree(c->d_sid);
+        c->d_sid = nullptr;
+        RSEM_HIP_TRY(e);
+    }
     if (c->L.n_sell_rows)
         hipLaunchKernelGGL(k_unfill_sell, dim3(rsem::ceil_div(c->L.n_sell_rows, kBlock)), dim3(kBlock), 0, c->stream, c->L.d_shapes, c->L.n_shapes, c->L.T,
                            c->L.n_sell_rows, (const uint32_t*)c->L.d_order, (const uint64_t*)c->d_row_ptr, (const int32_t*)c->L.d_ssid,
                            (const unsigned char*)c->d_sval, c->d_sid, c->d_cp);
     RSEM_HIP_TRY(hipGetLastError());
+    RSEM_HIP_TRY(hipStreamSynchronize(c->stream));  // whoever is handed the arrays next may read them on another stream
     c->csr_released = false;
     return RSEM_OK;
 }

@@ -25,6 +25,8 @@
 // calcExpressionValues (WriteResults.h:55-104) and the running sums -- on the device.
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
+#include <cerrno>
 #include <unistd.h>
 
 #include <atomic>
@@ -735,7 +737,9 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
     long long sweeps = 0;
     int team_used = 0;  // EXACT: workgroups per chain
     RSEM_HIP_TRY(hipEventRecord(ev.a, st));
-    if (exact) {
+    // EXACT.  force_one: one workgroup per chain whatever the device has to spare.  aborted: a team gave up at a barrier (a workgroup
+    // of it was not running: another tenant's kernels held the compute units) -- nothing of the run is kept.
+    auto exact_run = [&](bool force_one, bool& aborted) -> int {
         // all chains advance together, a team of workgroups each (Gibbs.cpp:207-254: the reference's threads)
         std::vector<MtState> h(nchains);
         for (int k = 0; k < nchains; k++) host_mt_seed(h[k], seeds[k]);
@@ -754,32 +758,43 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
         struct TeamLease {
             int dev = -1, fd = -1;
             bool mine = false;
-            void take(int d) {
+            hipStream_t st = nullptr;
+            void take(int d, hipStream_t stream) {
                 if (d < 0 || d >= kMaxTeamDevices) return;
                 dev = d;
+                st = stream;
                 mine = g_team_busy[d].fetch_add(1) == 0;
                 if (!mine) { g_team_busy[d].fetch_sub(1); return; }
                 char bus[64] = {0};
                 if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, d) != hipSuccess) { (void)hipGetLastError(); return; }
                 for (char* q = bus; *q; ++q) if (*q == ':' || *q == '.' || *q == '/') *q = '_';
                 const std::string path = std::string("/tmp/rsem_hip_team_") + bus + ".lock";
-                fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-                if (fd < 0) return;  // (no lock file: go ahead)
-                if (::flock(fd, LOCK_EX | LOCK_NB) != 0) {  // another process of this host runs its teams on this GPU
-                    ::close(fd);
-                    fd = -1;
-                    mine = false;
-                    g_team_busy[d].fetch_sub(1);
-                }
+                // Whoever makes the file opens it to every user of the host (the umask is not asked); a user who may not write it --
+                // another user's file from before this rule, or a sticky /tmp with fs.protected_regular -- locks it through a
+                // read-only descriptor (flock does not care).  Never through a link somebody planted.
+                fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
+                if (fd >= 0) (void)::fchmod(fd, 0666);
+                else if (errno == EACCES || errno == EPERM || errno == EROFS) fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC | O_NOFOLLOW);
+                // no descriptor: nobody can tell whether another process runs its teams on this GPU -- one workgroup per chain, which
+                // always makes progress; same when the lock is taken
+                if (fd < 0 || ::flock(fd, LOCK_EX | LOCK_NB) != 0) drop();
+            }
+            void drop() {  // (also as soon as the run turns out to use one workgroup per chain: the next context need not)
+                if (fd >= 0) ::close(fd);
+                fd = -1;
+                if (mine) g_team_busy[dev].fetch_sub(1);
+                mine = false;
             }
             ~TeamLease() {
-                if (fd >= 0) ::close(fd);
-                if (mine) g_team_busy[dev].fetch_sub(1);
+                // an error path may leave team launches queued: they must have left the GPU before the next team run is let in
+                if (mine && st) (void)hipStreamSynchronize(st);
+                drop();
             }
         } lease;
         const bool prior = c->d_alpha != nullptr;  // --prior: the pass of the two headers compiled in namespace gx_prior
         int W = 1;
-        lease.take(c->device);
+        const bool oversubscribe = getenv("RSEM_GX_TEST_OVERSUBSCRIBE") != nullptr;  // tests/test_gibbs_gpu.py: a team that CANNOT be resident
+        if (!force_one) lease.take(c->device, st);
         if (lease.mine) {
             W = std::max(1, std::min(kXTeamMax, c->n_cus / std::max(1, nchains)));
             if (W < 8) W = 1;  // with every compute unit busy, teams of 4 advance a chain no faster than one workgroup (profiles/r05b_c3_64chains.log)
@@ -792,8 +807,9 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             if (oe != hipSuccess) per_cu = 0;
             (void)hipGetLastError();
             if (!coop || per_cu < 1) W = 1;
-            else W = std::min(W, std::max(1, per_cu * c->n_cus / std::max(1, nchains)));
+            else if (!oversubscribe) W = std::min(W, std::max(1, per_cu * c->n_cus / std::max(1, nchains)));
         }
+        if (W == 1) lease.drop();
         DevBuf t_ctl, t_net, t_gnet, t_ref;
         TeamArgs ta{};  // (the same bytes for either pass: see the static_asserts behind the includes)
         {
@@ -824,6 +840,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             ta.n_win = c->n_win;
             ta.N1 = c->N1;
             ta.M = c->M;
+            if (const char* e = getenv("RSEM_GX_SPIN_LIMIT")) ta.spin_limit = strtoull(e, nullptr, 10);  // ticks of 10 ns; tests
         }
         if (W > 1) {  // what the workgroups of a team tell each other through
             const size_t rows = (size_t)c->M + 2;
@@ -863,7 +880,8 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                                    : (init ? (const void*)k_gibbs_exact_team<true> : (const void*)k_gibbs_exact_team<false>);
             // a team needs all its workgroups resident: a cooperative launch (the runtime refuses a grid that is not); one workgroup
             // per chain waits for nobody and may be any number of chains
-            hipError_t e = W > 1 ? hipLaunchCooperativeKernel(fn, dim3((unsigned)(nchains * W)), dim3(kXThr), args, 0, st)
+            hipError_t e = W > 1 && !oversubscribe ? hipLaunchCooperativeKernel(fn, dim3((unsigned)(nchains * W)), dim3(kXThr), args, 0, st)
+                         : W > 1 ? hipLaunchKernel(fn, dim3((unsigned)(nchains * W)), dim3(kXThr), args, 0, st)
                                  : hipLaunchKernel(fn, dim3((unsigned)nchains), dim3(kXThr), args, 0, st);
             if (e != hipSuccess && team_err == hipSuccess) team_err = e;
             mt_flip ^= 1;
@@ -892,7 +910,9 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             RSEM_HIP_TRY(hipStreamSynchronize(st));
             for (int k = 0; k < nchains; k++)
                 if (hc[k].abort) {
-                    rsem::set_last_error("k_gibbs_exact_team: chain %d's team gave up waiting at a team barrier (a workgroup of the team was not running)", k);
+                    rsem::set_last_error("k_gibbs_exact_team: chain %d's team of %d workgroups gave up waiting at a team barrier (a workgroup of the team "
+                                         "was not running: is another program using GPU %d?)", k, W, c->device);
+                    aborted = true;
                     return RSEM_ERR_HIP;
                 }
             if (getenv("RSEM_GX_VERBOSE")) {
@@ -911,6 +931,28 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
                     h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[8] / tiles, h[11] / tiles, h[5] / tiles, h[6] / tiles, h[10] / tiles,
                     h[13] / tiles, h[9] / tiles, tiles);
         }
+        return RSEM_OK;
+    };
+    if (exact) {
+        bool aborted = false;
+        int rc = exact_run(false, aborted);
+        if (rc != RSEM_OK && aborted && !getenv("RSEM_GX_NO_FALLBACK")) {
+            // The chain's integers do not depend on the team size: start the run over with one workgroup per chain, which waits
+            // for nobody.  (What the teams did is lost; the caller gets the same result, later.)
+            fprintf(stderr, "rsem_gibbs_run_chains: %s -- starting the run over with one workgroup per chain\n", rsem_hip_last_error());
+            RSEM_HIP_TRY(hipStreamSynchronize(st));
+            RSEM_HIP_TRY(hipMemsetAsync(acc.p, 0, sizeof(double) * 4 * nM * nchains, st));
+            RSEM_HIP_TRY(hipMemsetAsync(acc_g.p, 0, sizeof(double) * m * nchains, st));
+            if (mt) RSEM_HIP_TRY(hipMemsetAsync(acc_t.p, 0, sizeof(double) * mt * nchains, st));
+            hipLaunchKernelGGL(k_reset_chains, dim3(gM, nchains), dim3(kBlock), 0, st, c->M, c->d_init_counts, (int32_t)c->N0,
+                               counts.as<int32_t>(), stride_c);
+            RSEM_HIP_TRY(hipGetLastError());
+            sweeps = 0;
+            RSEM_HIP_TRY(hipEventRecord(ev.a, st));
+            aborted = false;
+            rc = exact_run(true, aborted);
+        }
+        if (rc != RSEM_OK) return rc;
     } else {
         // one chain after the other: a sweep of this sampler fills the GPU by itself
         for (int k = 0; k < nchains; k++) {

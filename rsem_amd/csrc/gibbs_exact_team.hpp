@@ -107,6 +107,7 @@ struct XTeam {
     uint32_t n_win;
     uint64_t N1;
     int32_t M;             // row M + 1 of the tables is never written (the address of loads that are not needed)
+    unsigned long long spin_limit;  // wall-clock ticks a workgroup waits at a team barrier at most (kXSpinLimit; tests lower it)
 };
 
 // Windows: up to W consecutive tiles; a long tile is a window of its own.  (Host; also the emulator.)
@@ -182,7 +183,7 @@ GX_DEVFN int gx_team_barrier(int g, XTile* L, const XTeam& tm, unsigned long lon
                 if (GX_G_LOAD32(&c->abort) != 0u) { res = -1; break; }
                 const unsigned long long now = GX_WALL();
                 if (t0 == 0) t0 = now;
-                else if (now - t0 > kXSpinLimit) { GX_G_STORE32(&c->abort, 1u); res = -1; break; }
+                else if (now - t0 > tm.spin_limit) { GX_G_STORE32(&c->abort, 1u); res = -1; break; }
             }
             GX_SPIN_PAUSE();
         }
@@ -767,6 +768,7 @@ struct TeamArgs {  // what every workgroup of every team needs (one argument: co
     uint32_t n_win;
     uint64_t N1;
     int32_t M;
+    unsigned long long spin_limit;  // 0: kXSpinLimit
 };
 
 // Workgroup b belongs to chain b % nchains: workgroups are dealt to the 8 XCDs round-robin, so with 8 chains (or a divisor or
@@ -782,6 +784,7 @@ __global__ __launch_bounds__(kXThr) void k_gibbs_exact_team(TeamArgs ta, const u
     // (a team spread over all XCDs instead -- chain = b / W -- is slower: 104.6 against 98.3 ms per round, profiles/r05w_*)
     const int chain = (int)(blockIdx.x % (unsigned)ta.nchains), tw = (int)(blockIdx.x / (unsigned)ta.nchains);
     if (round > last_round[chain]) return;  // (uniform over the team)
+    if (ta.ctl && ta.ctl[chain].abort != 0u) return;  // an earlier launch of the run gave up: the host starts the run over (uniform)
     const GxMtState* src = mt_in + chain;
     for (int i = threadIdx.x; i < 624; i += blockDim.x) tile.mt[i] = src->mt[i];
     if (threadIdx.x == 0) tile.idx = src->idx;
@@ -802,6 +805,7 @@ __global__ __launch_bounds__(kXThr) void k_gibbs_exact_team(TeamArgs ta, const u
     tm.n_win = ta.n_win;
     tm.N1 = ta.N1;
     tm.M = ta.M;
+    tm.spin_limit = ta.spin_limit ? ta.spin_limit : kXSpinLimit;
     const bool ok = gibbs_exact_team_body<kInit>((int)threadIdx.x, &tile, tm, row_ptr, sid, cp, counts_base + (uint64_t)chain * stride_c,
                                                  z_base + (uint64_t)chain * stride_z, pseudoC, alpha, prof);
     __syncthreads();

@@ -126,9 +126,11 @@ inline void parallel_for(int n, const std::function<void(int)>& fn) {
     for (auto& t : th) t.join();
 }
 
-// One line of cells first..last (inclusive) separated by `sep` and closed by a newline; cell(buf, i) writes cell i (at most 63
-// characters) and returns its length.  A long line -- the per-transcript rows of .theta, .model and the result files: 200 k numbers
+// One line of cells first..last (inclusive) separated by `sep` and closed by a newline; cell(buf, i) writes cell i into a buffer of
+// kCellBuf bytes and returns its length as snprintf does (a "%.2f" of 1e300 has 304 characters: the buffer holds them; a cell that
+// still does not fit ends the program rather than the line with garbage).  A long line -- the per-transcript rows of .theta, .model and the result files: 200 k numbers
 // each, 0.1-0.2 s of printf per file when done by one thread -- is formatted in pieces on the host's threads and written in order.
+constexpr int kCellBuf = 352;
 template <typename Cell>
 inline void write_cells_line(FILE* f, long first, long last, char sep, Cell cell) {
     const long n = last - first + 1;
@@ -139,9 +141,10 @@ inline void write_cells_line(FILE* f, long first, long last, char sep, Cell cell
         const long lo = first + n * t / nt, hi = first + n * (t + 1) / nt;
         std::string& out = part[t];
         out.reserve((size_t)(hi - lo) * 12);
-        char buf[64];
+        char buf[kCellBuf];
         for (long i = lo; i < hi; i++) {
             const int k = cell(buf, i);
+            if (k < 0 || k >= kCellBuf) die("write_cells_line: a cell of %d characters does not fit", k);
             out.append(buf, (size_t)k);
             out.push_back(i < last ? sep : '\n');
         }

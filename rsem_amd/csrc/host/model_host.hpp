@@ -329,7 +329,7 @@ struct Model {
         }
         if (!mw.empty()) {
             fprintf(fo, "\n%d\n", M);
-            write_cells_line(fo, 0, M, ' ', [&](char* b, long i) { return snprintf(b, 64, "%.15g", mw[i]); });
+            write_cells_line(fo, 0, M, ' ', [&](char* b, long i) { return snprintf(b, rsemh::kCellBuf, "%.15g", mw[i]); });
         }
         fclose(fo);
     }

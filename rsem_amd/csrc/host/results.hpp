@@ -63,10 +63,10 @@ class RowFile {
         }
     }
     void values(int first, int last, const double* v, double scale = 1.0) {
-        write_cells_line(f_, first, last, '\t', [&](char* b, long i) { return snprintf(b, 64, "%.2f", v[i] * scale); });
+        write_cells_line(f_, first, last, '\t', [&](char* b, long i) { return snprintf(b, rsemh::kCellBuf, "%.2f", v[i] * scale); });
     }
     void roots(int first, int last, const double* v) {
-        write_cells_line(f_, first, last, '\t', [&](char* b, long i) { return snprintf(b, 64, "%.2f", sqrt(v[i])); });
+        write_cells_line(f_, first, last, '\t', [&](char* b, long i) { return snprintf(b, rsemh::kCellBuf, "%.2f", sqrt(v[i])); });
     }
 
   private:

@@ -37,7 +37,8 @@
 
 using namespace rsemh;
 
-static const int MAX_ROUND = 10000, MIN_ROUND = 20;  // EM.cpp:53-55
+static int MAX_ROUND = 10000;       // EM.cpp:54 (RSEM_HIP_MAX_ROUND lowers it for counter passes over the model rounds: tools/model_group_pmc.sh)
+static const int MIN_ROUND = 20;    // EM.cpp:55
 
 static void hip_check(int rc, const char* what) {
     if (rc != RSEM_OK) die("rsem-run-em: %s failed: %s (%s)", what, rsem_hip_strerror(rc), rsem_hip_last_error());
@@ -286,6 +287,7 @@ int main(int argc, char* argv[]) {
     // Gibbs hand-off (host/ofb.hpp): 0 = imdName.ofg (the reference's text), 1 = imdName.ofb/ (arrays), 2 = both; also
     // RSEM_HIP_BINARY=1 / =both in the environment, the switch the unmodified Perl driver cannot put on the command line
     int ofbMode = 0;
+    if (const char* e = getenv("RSEM_HIP_MAX_ROUND")) MAX_ROUND = std::max(MIN_ROUND, atoi(e));
     if (const char* e = getenv("RSEM_HIP_BINARY")) ofbMode = !strcmp(e, "both") ? 2 : ((*e && strcmp(e, "0")) ? 1 : 0);
     bool verbose = true, genBamF = false, genGibbsOut = false, appendNames = false, bamSampling = false, hasSeed = false, leanDevice = false;
     uint32_t seed = 0;
@@ -802,10 +804,10 @@ int main(int argc, char* argv[]) {
     FILE* fo = fopen((statName + ".theta").c_str(), "w");
     if (!fo) die("Cannot open %s.theta for writing!", statName.c_str());
     fprintf(fo, "%d\n", M + 1);
-    write_cells_line(fo, 0, M, ' ', [&](char* b, long i) { return snprintf(b, 64, "%.15g", theta[i]); });
+    write_cells_line(fo, 0, M, ' ', [&](char* b, long i) { return snprintf(b, rsemh::kCellBuf, "%.15g", theta[i]); });
     std::vector<double> eel = calc_eel(M, refs, model.gld);
     polish_theta(M, theta, eel, model.mw.data());
-    write_cells_line(fo, 0, M, ' ', [&](char* b, long i) { return snprintf(b, 64, "%.15g", theta[i]); });
+    write_cells_line(fo, 0, M, ' ', [&](char* b, long i) { return snprintf(b, rsemh::kCellBuf, "%.15g", theta[i]); });
     fclose(fo);
 
     model.write(statName + ".model");

@@ -823,7 +823,7 @@ int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_da
     rsem::em_view_hold(em);
     c->holds_view = true;
     if (c->v.N1 != d->N1 || c->v.nnz != d->nnz || c->v.M != d->M) {
-        delete c;
+        rsem_model_destroy(c);  // (gives the view back: a held view refuses every later release_csr of the EM context)
         rsem::set_last_error("model data does not match the EM context (N1/nnz/M)");
         return RSEM_ERR_INVALID;
     }

@@ -140,7 +140,7 @@ int main(int argc, char** argv) {
         emu::t_block = &mc.block_bar;
         XTeam tm;
         tm.W = W; tm.tw = k; tm.ctl = &ctl; tm.net = net.data(); tm.gnet = gnet.data(); tm.ref = ref.data(); tm.nw = nw;
-        tm.slots = slots.data(); tm.n_win = n_win; tm.N1 = N1; tm.M = M;
+        tm.slots = slots.data(); tm.n_win = n_win; tm.N1 = N1; tm.M = M; tm.spin_limit = kXSpinLimit;
         for (int round = 0; round <= rounds; round++) {
             // what the kernel wrapper does: every workgroup loads the chain's generator as it is before the sweep
             if (tid == 0) { memcpy(mc.tile.mt, mt0, sizeof(mt0)); mc.tile.idx = idx0; }

@@ -169,6 +169,9 @@ def test_bench_two_ranks_line_carries_per_rank_numbers(tmp_path):
     assert g["sweeps_per_s_per_rank"] == [500.0, 333.333] and g["sweeps_per_s_all_gpus"] == 666.667  # (six digits in the line)
     assert g["final_reduce_ms"] == 0.25 and len(g["frac_of_hbm_peak_per_rank"]) == 2
     assert d["gibbs"]["exact"]["final_reduce_ms"] == 0.25
+    # the split north_star names: 8 chains in all, 4 per GPU here, the slowest GPU sets the rate
+    es = d["gibbs"]["exact_strong"]
+    assert es["chains_total"] == 8 and es["chains_per_gpu"] == 4 and es["gpus"] == 2 and es["ms_per_round"] == 3.0 and es["workgroups_per_chain"] == 32
 
 
 def test_bench_starts_its_own_ranks():

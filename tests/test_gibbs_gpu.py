@@ -164,6 +164,53 @@ def test_exact_chain_is_the_same_for_every_team_size(n_reads, long_every, chains
     ctx.close()
 
 
+def test_a_team_that_cannot_be_resident_gives_up_and_the_run_starts_over(monkeypatch, capfd):
+    """The team barrier's way out (gibbs_exact_team.hpp: kXSpinLimit, XTeamCtl::abort).  A team needs all its workgroups on the GPU at
+    once; the product guarantees that with a cooperative launch and a per-GPU lease, but another tenant's kernels can still hold the
+    compute units.  Provoked for real here: 8 chains x 64 workgroups = 512 workgroups of 154 KB LDS each, launched NON-cooperatively
+    (RSEM_GX_TEST_OVERSUBSCRIBE) on 256 compute units -- the resident half waits for the half that cannot start -- with the
+    30-second limit lowered to 0.2 s (RSEM_GX_SPIN_LIMIT, ticks of 10 ns).  The run must (a) not hang, (b) start over with one
+    workgroup per chain and return the SAME integers (the chain does not depend on the team size), telling the user on stderr;
+    (c) with the fallback switched off (RSEM_GX_NO_FALLBACK) fail through the C ABI with a message that names the cause."""
+    n_reads, chains = 150_000, 8
+    M, (irp, isid, icp) = _synthetic_items(n_reads)
+    init = np.zeros(M + 1, np.int32)
+    N0, pseudoC = 777, 1.0
+    eel, mw = np.full(M + 1, 700.0), np.ones(M + 1)
+    grp = np.array([1, M + 1], np.int32)
+    totc = (M + 1) * pseudoC + N0 + n_reads
+    seeds = capi().gibbs_chain_seeds(31, chains)
+    ns = [2] * chains
+    ctx = capi().GibbsContext(M, irp, isid, icp, init, None, pseudoC, totc, N0, eel, mw, grp)
+    base, acc0, _, p0 = ctx.run_chains(capi().GIBBS_EXACT, seeds, 2, ns, 1)
+    assert p0.team > 1
+    monkeypatch.setenv("RSEM_GX_TEAM", "64")
+    monkeypatch.setenv("RSEM_GX_TEST_OVERSUBSCRIBE", "1")
+    monkeypatch.setenv("RSEM_GX_SPIN_LIMIT", "20000000")
+    capfd.readouterr()
+    import time
+    t0 = time.perf_counter()
+    cvs, acc, _, p = ctx.run_chains(capi().GIBBS_EXACT, seeds, 2, ns, 1)
+    took = time.perf_counter() - t0
+    err = capfd.readouterr().err
+    assert "gave up waiting at a team barrier" in err and "starting the run over with one workgroup per chain" in err
+    assert p.team == 1 and took < 25.0
+    for k in range(chains):
+        assert np.array_equal(cvs[k], base[k]), k
+    for a, b in zip(acc, acc0):
+        assert np.array_equal(a, b)
+    monkeypatch.setenv("RSEM_GX_NO_FALLBACK", "1")
+    with pytest.raises(capi().RsemHipError) as ei:
+        ctx.run_chains(capi().GIBBS_EXACT, seeds, 2, ns, 1)
+    assert "gave up waiting at a team barrier" in str(ei.value) and "another program" in str(ei.value)
+    # and the context is usable afterwards: the product's own launch again
+    for v in ("RSEM_GX_TEAM", "RSEM_GX_TEST_OVERSUBSCRIBE", "RSEM_GX_SPIN_LIMIT", "RSEM_GX_NO_FALLBACK"):
+        monkeypatch.delenv(v)
+    again, _, _, p2 = ctx.run_chains(capi().GIBBS_EXACT, seeds, 2, ns, 1)
+    assert p2.team == p0.team and all(np.array_equal(again[k], base[k]) for k in range(chains))
+    ctx.close()
+
+
 def test_chain_groups_reduce_over_local_comm():
     """Chains dealt to two groups (here: both on GPU 0, the LOCAL communicator; on a multi-GPU node the same calls run
     over RCCL): group sums meet in one reduce on rank 0 and equal the single-group run; count vectors stay with the
