@@ -619,8 +619,8 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
         const uint32_t u_end = S.slice_base + U.slice_begin + U.n_slices;
         const uint32_t s_begin = S.slice_base + U.slice_begin + (uint32_t)w * U.per_wave;
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
-#define RSEM_ESTEP_BLOCK(KK, QQ, FF, XX) \
-    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF, XX>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M, xa)
+#define RSEM_ESTEP_BLOCK(KK, QQ, FF, XX, ...) \
+    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF, XX, ##__VA_ARGS__>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M, xa)
         // (uniform over the workgroup)  split rows (F64X) only exist where theta is a plain array: the loops that read theta
         // out of the previous round's counts (kFC) are not taken for a layout with split rows (loop_wanted)
         const int code = (S.K - 1) | ((S.fmt == kFmtQ32 ? 1 : 0) << 2) | ((U.pad[0] != 0 ? 1 : 0) << 3) | (((!kFC && S.fmt == kFmtF64X) ? 1 : 0) << 4);
@@ -642,15 +642,25 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
             case 14: RSEM_ESTEP_BLOCK(3, true, true, false); break;
             case 15: RSEM_ESTEP_BLOCK(4, true, true, false); break;
             default:
-                if constexpr (!kFC) switch (code & 11) {
+                // (split rows; bit 2 of the selector: a tuple starts in most slices of the unit -- Unit::pad[1] -- so the id planes are
+                // loaded without asking)
+                if constexpr (!kFC) switch ((code & 11) | (U.pad[1] != 0 ? 4 : 0)) {
                     case 0: RSEM_ESTEP_BLOCK(1, false, false, true); break;
                     case 1: RSEM_ESTEP_BLOCK(2, false, false, true); break;
                     case 2: RSEM_ESTEP_BLOCK(3, false, false, true); break;
                     case 3: RSEM_ESTEP_BLOCK(4, false, false, true); break;
+                    case 4: RSEM_ESTEP_BLOCK(1, false, false, true, true); break;
+                    case 5: RSEM_ESTEP_BLOCK(2, false, false, true, true); break;
+                    case 6: RSEM_ESTEP_BLOCK(3, false, false, true, true); break;
+                    case 7: RSEM_ESTEP_BLOCK(4, false, false, true, true); break;
                     case 8: RSEM_ESTEP_BLOCK(1, false, true, true); break;
                     case 9: RSEM_ESTEP_BLOCK(2, false, true, true); break;
                     case 10: RSEM_ESTEP_BLOCK(3, false, true, true); break;
-                    default: RSEM_ESTEP_BLOCK(4, false, true, true); break;
+                    case 11: RSEM_ESTEP_BLOCK(4, false, true, true); break;
+                    case 12: RSEM_ESTEP_BLOCK(1, false, true, true, true); break;
+                    case 13: RSEM_ESTEP_BLOCK(2, false, true, true, true); break;
+                    case 14: RSEM_ESTEP_BLOCK(3, false, true, true, true); break;
+                    default: RSEM_ESTEP_BLOCK(4, false, true, true, true); break;
                 }
                 break;
 #undef RSEM_ESTEP_BLOCK
@@ -1021,10 +1031,18 @@ struct rsem_em_ctx {
     uint32_t* d_rank = nullptr;  // caller row -> sorted row (inverse of L.d_order), built on first use (em_planes_view)
     double *d_xextra = nullptr, *d_xinv = nullptr;  // split rows: far part of the normaliser / its reciprocal, per row slot from L.x_slot_base
     int split_rows = 1;          // lay reads with ids outside their window out as split rows (LANE kernel only; option "split_rows")
+    int split_policy = 1;        // 1: the reads that are mostly outside their window split; 2: every read with an id outside
     uint32_t n_far_units = 0;               // units with an id outside their LDS window (Unit::pad[0])
     unsigned long long n_stray_reads = 0;   // reads the second layout pass sorted apart (sell_build_refined)
     int tune_passes_left = 1;               // measured-lifetime reordering of the units, done on first use
     uint32_t n_units = 0;
+    // Split rows: the units of the F64X shapes stand behind the others in d_units, [n_units_main, n_units), and run BESIDE them -- on
+    // stream_x: k_far_rowsum -> their lane launch -> k_far_colsum, a chain of passes bound by the L2's request rate and by their own
+    // round trips, while the compact units stream from HBM on the context's stream (launch_estep).
+    uint32_t n_units_main = 0;
+    hipStream_t stream_x = nullptr;
+    hipEvent_t ev_x_fork = nullptr, ev_x_join = nullptr;
+    int x_overlap = 1;
     int noise_n = 0;  // workgroups of the last main E-step launch (= valid entries of d_noise_a)
     size_t noise_cap = 0;
     // EM state
@@ -1067,6 +1085,17 @@ int resolved_kernel(const rsem_em_ctx* c) {
     return c->kernel == RSEM_EM_KERNEL_AUTO ? RSEM_EM_KERNEL_LANE : c->kernel;
 }
 
+// the units of the split rows' shapes behind all the others (both parts keep their order), host and device copy
+int partition_units(rsem_em_ctx* c) {
+    auto is_main = [](const Unit& u) { return u.S.fmt != kFmtF64X; };
+    const auto mid = std::stable_partition(c->h_units.begin(), c->h_units.end(), is_main);
+    c->n_units_main = (uint32_t)(mid - c->h_units.begin());
+    if (c->n_units_main != c->n_units && c->n_units)
+        RSEM_HIP_TRY(hipMemcpyAsync(c->d_units, c->h_units.data(), sizeof(Unit) * c->n_units, hipMemcpyHostToDevice, c->stream));
+    RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSEM_OK;
+}
+
 int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStream_t st, bool use_ctrl) {
     const Ctrl* ctrl = c->d_ctrl;
     const int kern = resolved_kernel(c);
@@ -1081,24 +1110,43 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
     }
     if (kern == RSEM_EM_KERNEL_LANE) {
         XArgs xa;
+        // the split rows' chain on a stream of its own, beside the compact units
+        hipStream_t sx = st;
+        const uint32_t n_main = c->n_units_main;
+        const bool beside = c->x_overlap && c->L.n_x_rows && c->stream_x && n_main > 0 && n_main < c->n_units;
+        if (beside) {
+            sx = c->stream_x;
+            RSEM_HIP_TRY(hipEventRecord(c->ev_x_fork, st));
+            RSEM_HIP_TRY(hipStreamWaitEvent(sx, c->ev_x_fork, 0));
+        }
+        auto lane = [&](uint32_t u0, uint32_t u1, hipStream_t s) {
+            if (u1 > u0)
+                hipLaunchKernelGGL((k_estep_lane<false, false>), dim3(u1 - u0), dim3(kBlock), 0, s, c->L.d_shapes, c->d_units + u0, c->L.T, c->M,
+                                   d_theta, (const double*)nullptr, 0.0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid,
+                                   c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a + u0, c->use_totals ? c->d_totals : nullptr, ctrl,
+                                   c->d_trace ? c->d_trace + 2 * (size_t)u0 : nullptr, SoloArgs(), xa);
+        };
         if (c->L.n_x_rows) {  // split rows: the far part of their normalisers first
             xa.extra = c->d_xextra; xa.inv = c->d_xinv; xa.slot_base = c->L.x_slot_base;
             static const bool batched = !(getenv("RSEM_HIP_ROWSUM_BATCHED") && atoi(getenv("RSEM_HIP_ROWSUM_BATCHED")) == 0);  // measurement knob
-            hipLaunchKernelGGL(batched ? k_far_rowsum<true> : k_far_rowsum<false>, dim3(rsem::ceil_div(c->L.n_x_slots, kBlock)), dim3(kBlock), 0, st, c->L.n_x_slots,
+            hipLaunchKernelGGL(batched ? k_far_rowsum<true> : k_far_rowsum<false>, dim3(rsem::ceil_div(c->L.n_x_slots, kBlock)), dim3(kBlock), 0, sx, c->L.n_x_slots,
                                (const uint64_t*)c->L.d_far_ptr, (const int32_t*)c->L.d_far_sid, (const double*)c->L.d_far_cp, d_theta, c->d_xextra, ctrl);
         }
-        if (c->n_units)
-            hipLaunchKernelGGL((k_estep_lane<false, false>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
-                               d_theta, (const double*)nullptr, 0.0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid,
-                               c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a, c->use_totals ? c->d_totals : nullptr, ctrl, c->d_trace, SoloArgs(), xa);
+        if (beside) { lane(0, n_main, st); lane(n_main, c->n_units, sx); }
+        else lane(0, c->n_units, st);
         if (c->L.n_far) {  // ... and their far alignments' fractions afterwards, in transcript order
             // one step of 4 x 64 entries per wave: the pass is a chain of dependent trips (entries -> theta, reciprocal -> shuffles ->
             // atomic), and more waves in flight hide more of it than a loop per wave (8 / 16 / 32 workgroups per CU: 335 / 326 /
             // 312 us at configs[1]'s size without gene structure, the whole grid 294: profiles/r04l_call.log)
             const int grid = std::max(1, rsem::ceil_div(c->L.n_far, kBlock * 4));
             static const bool xcd = !(getenv("RSEM_HIP_COLSUM_XCD") && atoi(getenv("RSEM_HIP_COLSUM_XCD")) == 0);  // measurement knob
-            hipLaunchKernelGGL(xcd ? k_far_colsum<true> : k_far_colsum<false>, dim3(grid), dim3(kBlock), 0, st, c->L.n_far, (const int32_t*)c->L.d_csc_sid,
+            hipLaunchKernelGGL(xcd ? k_far_colsum<true> : k_far_colsum<false>, dim3(grid), dim3(kBlock), 0, sx, c->L.n_far, (const int32_t*)c->L.d_csc_sid,
                                (const double*)c->L.d_csc_cp, (const uint32_t*)c->L.d_csc_slot, c->L.x_slot_base, d_theta, (const double*)c->d_xinv, d_counts, ctrl);
+        }
+        if (beside) {
+            RSEM_HIP_TRY(hipGetLastError());
+            RSEM_HIP_TRY(hipEventRecord(c->ev_x_join, sx));
+            RSEM_HIP_TRY(hipStreamWaitEvent(st, c->ev_x_join, 0));
         }
     } else {
         if (c->L.n_x_rows) { rsem::set_last_error("the SELL kernel cannot walk a layout with split rows (set the kernel before the values, or option split_rows = 0)"); return RSEM_ERR_STATE; }
@@ -1238,6 +1286,9 @@ int build_layout(rsem_em_ctx* c) {
     // (not together with Q32 planes: which reads take that format is a documented function of their values alone)
     int split = c->split_rows && resolved_kernel(c) == RSEM_EM_KERNEL_LANE && !q32;
     if (const char* e = getenv("RSEM_HIP_SPLIT")) split = split && atoi(e) != 0;  // measurement knob: 0 = reads that leave their window stay whole
+    // which reads split: those that are mostly outside their window (1), or every read with an id outside (2)
+    if (split) split = c->split_policy;
+    if (const char* e = getenv("RSEM_HIP_SPLIT_POLICY")) { if (split) split = !strcmp(e, "all") ? 2 : 1; }  // measurement knob
     int rc = sell_build_refined(c->L, c->stream, c->N1, c->M, c->d_row_ptr, c->d_sid, target_waves, c->forced_T,
                                 q32 ? c->d_cp : nullptr, c->value_range_bits, kWindow, units, &c->d_units, &c->n_stray_reads, split);
     if (rc != RSEM_OK) return rc;
@@ -1263,7 +1314,22 @@ int build_layout(rsem_em_ctx* c) {
     }
     RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_units = (uint32_t)units.size();
+    if (const char* e = getenv("RSEM_HIP_X_IDS")) {  // measurement knob: 0 = no unit loads the id planes of every slice
+        if (atoi(e) == 0) {
+            for (Unit& u : units) u.pad[1] = 0;
+            if (!units.empty()) RSEM_HIP_TRY(hipMemcpyAsync(c->d_units, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice, c->stream));
+            RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+    }
     c->h_units = units;
+    rc = partition_units(c);
+    if (rc != RSEM_OK) return rc;
+    if (c->L.n_x_rows && !c->stream_x) {
+        RSEM_HIP_TRY(hipStreamCreateWithFlags(&c->stream_x, hipStreamNonBlocking));
+        RSEM_HIP_TRY(hipEventCreateWithFlags(&c->ev_x_fork, hipEventDisableTiming));
+        RSEM_HIP_TRY(hipEventCreateWithFlags(&c->ev_x_join, hipEventDisableTiming));
+    }
+    if (const char* e = getenv("RSEM_HIP_X_OVERLAP")) c->x_overlap = atoi(e);  // measurement knob: 0 = one stream
     c->tune_passes_left = 1;
     if (const char* e = getenv("RSEM_HIP_TUNE")) c->tune_passes_left = atoi(e);  // tuning knob: 0 disables
     c->n_far_units = 0;
@@ -1593,6 +1659,9 @@ int rsem_em_destroy(rsem_em_ctx* c) {
     hipFree(c->d_theta[0]); hipFree(c->d_theta[1]); hipFree(c->d_red3);
     for (int i = 0; i < 4; i++) { if (c->ev_e[i]) (void)hipEventDestroy(c->ev_e[i]); if (c->ev_s[i]) (void)hipEventDestroy(c->ev_s[i]); }
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream_x) (void)hipStreamDestroy(c->stream_x);
+    if (c->ev_x_fork) (void)hipEventDestroy(c->ev_x_fork);
+    if (c->ev_x_join) (void)hipEventDestroy(c->ev_x_join);
     hipFree(c->d_counts_last); hipFree(c->d_noise_a); hipFree(c->d_noise_b); hipFree(c->d_partials);
     if (c->mirror) (void)hipHostFree(c->mirror);
     for (int i = 0; i < 2; i++) if (c->lag_ev[i]) (void)hipEventDestroy(c->lag_ev[i]);
@@ -1633,6 +1702,8 @@ static int tune_unit_order(rsem_em_ctx* c, const double* d_theta) {
         c->h_units.swap(sorted);
         RSEM_HIP_TRY(hipMemcpyAsync(c->d_units, c->h_units.data(), sizeof(Unit) * n, hipMemcpyHostToDevice, c->stream));
         RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+        rc = partition_units(c);
+        if (rc != RSEM_OK) return rc;
     }
     return RSEM_OK;
 }

@@ -170,7 +170,8 @@ __host__ __device__ inline uint64_t row_key_of(uint64_t i, int32_t M, const uint
     // stays whole: as a row of its own shape its tuple runs are too short for the lane kernel to skip anything (a wave
     // re-reads its ids whenever ANY of its 64 lanes starts a new tuple), so the split only added the two side passes
     // (configs[2] with 10 % such reads: 1.48 ms split against 1.17-1.25 whole, profiles/r04d_call.log).
-    if (far && split && 2 * L_in <= L && shape != kLongShape && (uint64_t)mn <= kKeyMinSidCap) {  // split row: keyed by its in-window part
+    // split == 2: every read with an id outside splits (the X units then run beside the compact ones: em.hip launch_estep)
+    if (far && split && (split == 2 || 2 * L_in <= L) && shape != kLongShape && (uint64_t)mn <= kKeyMinSidCap) {  // split row: keyed by its in-window part
         shape = shape_id_of(L_in) + 2 * kShapesPerFmt;
         if (split_far) *split_far = (uint32_t)(L - L_in);
         return ((uint64_t)shape << (64 - kShapeBits)) | ((uint64_t)mn << 32) | h_in;
@@ -630,7 +631,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
             RSEM_HIP_TRY(dmalloc(&d_ns, 2));
             RSEM_HIP_TRY(hipMemsetAsync(d_ns, 0, 2 * sizeof(unsigned long long), st));
             hipLaunchKernelGGL(k_row_keys, dim3(rsem::ceil_div(N1, kBlock)), dim3(kBlock), 0, st, N1, M, d_row_ptr, d_sid,
-                               d_cp_for_q32, range_bits, apart, 1, d_also_apart, d_keys, d_vals, d_err, d_ns);
+                               d_cp_for_q32, range_bits, apart, do_split, d_also_apart, d_keys, d_vals, d_err, d_ns);
             RSEM_HIP_TRY(hipGetLastError());
             RSEM_HIP_TRY(hipMemcpyAsync(h_ns, d_ns, sizeof(h_ns), hipMemcpyDeviceToHost, st));
             RSEM_HIP_TRY(hipStreamSynchronize(st));
@@ -755,7 +756,7 @@ struct Unit {
     uint32_t per_wave;     // wave w walks slices [slice_begin + w * per_wave, + per_wave)
     int32_t base;
     int32_t span;          // sids [base, base + span) are staged in LDS (<= the window capacity)
-    int32_t pad[2];        // pad[0]: 1 = some id of the unit lies outside [base, base + span) (sell_flag_far_units)
+    int32_t pad[2];        // pad[0]: 1 = some id of the unit lies outside [base, base + span); pad[1]: 1 = a tuple starts in most slices (sell_flag_far_units)
     Shape S;               // copy of the shape: one dependent load less at the start of every workgroup
 };
 
@@ -820,22 +821,34 @@ inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units, int w
 // counted.  One workgroup per unit; the flag lands in Unit::pad[0] on the device and in `units`.
 __host__ __device__ inline bool unit_entry_is_far(const Unit& U, int32_t v) { return v > 0 && (unsigned)(v - U.base) >= (unsigned)U.span; }
 
-__global__ __launch_bounds__(256) void k_unit_far(Unit* units, const int32_t* __restrict__ ssid) {
-    __shared__ int any;
-    if (threadIdx.x == 0) any = 0;
+// pad[1]: 1 = a new id tuple starts in most of the unit's slices (short runs: split rows among themselves, genes with few reads).
+// The loop of such a unit loads the id planes of EVERY slice (estep_block.hpp kIds): behind the scalar branch "only where a tuple
+// starts" the compiler's waits are those of the path with the fewest loads in flight, i.e. with the branch taken every time the
+// next slice's loads are waited for before this slice is reduced.
+__global__ __launch_bounds__(256) void k_unit_far(Unit* units, const int32_t* __restrict__ ssid, const unsigned long long* __restrict__ masks) {
+    __shared__ int any, dense;
+    if (threadIdx.x == 0) { any = 0; dense = 0; }
     __syncthreads();
     const Unit U = units[blockIdx.x];
+    {
+        int nz = 0;
+        for (uint32_t t = threadIdx.x; t < U.n_slices; t += blockDim.x) nz += masks[U.S.slice_base + U.slice_begin + t] != 0ull ? 1 : 0;
+        if (nz) atomicAdd(&dense, nz);
+    }
     const uint64_t p0 = (U.S.plane_base + (uint64_t)U.slice_begin * U.S.K) * 64, n = (uint64_t)U.n_slices * U.S.K * 64;
     bool far = false;
     for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) far = far || unit_entry_is_far(U, ssid[p0 + i]);
     if (far) any = 1;
     __syncthreads();
-    if (threadIdx.x == 0) units[blockIdx.x].pad[0] = any;
+    if (threadIdx.x == 0) {
+        units[blockIdx.x].pad[0] = any;
+        units[blockIdx.x].pad[1] = 2 * (uint32_t)dense > U.n_slices ? 1 : 0;
+    }
 }
 
 inline int sell_flag_far_units(const SellLayout& L, std::vector<Unit>& units, Unit* d_units, hipStream_t st) {
     if (units.empty()) return RSEM_OK;
-    hipLaunchKernelGGL(k_unit_far, dim3((unsigned)units.size()), dim3(256), 0, st, d_units, (const int32_t*)L.d_ssid);
+    hipLaunchKernelGGL(k_unit_far, dim3((unsigned)units.size()), dim3(256), 0, st, d_units, (const int32_t*)L.d_ssid, (const unsigned long long*)L.d_masks);
     RSEM_HIP_TRY(hipGetLastError());
     RSEM_HIP_TRY(hipMemcpyAsync(units.data(), d_units, sizeof(Unit) * units.size(), hipMemcpyDeviceToHost, st));
     RSEM_HIP_TRY(hipStreamSynchronize(st));

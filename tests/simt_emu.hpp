@@ -134,7 +134,7 @@ static void build_layout(HostLayout& H, int M, uint64_t N1, const uint64_t* rp, 
     (void)policy;
     for (uint64_t i = 0; i < N1; i++) {
         int err = 0;
-        const uint64_t key = row_key_of(i, M, rp, sid, q32 ? cp : nullptr, range_bits, apart, &err, policy == 2 ? 1 : 0);
+        const uint64_t key = row_key_of(i, M, rp, sid, q32 ? cp : nullptr, range_bits, apart, &err, policy == 2 ? 1 : (policy == 3 ? 2 : 0));  // policy 3: every read that reaches beyond its window splits
         if (err) { fprintf(stderr, "simt_emu: bad CSR (%d)\n", err); exit(2); }
         if ((int)(key >> (64 - kShapeBits)) == kLongShape) { fprintf(stderr, "simt_emu: rows with more than 256 alignments are not modelled\n"); exit(2); }
         keyed[i] = {key, (uint32_t)i};

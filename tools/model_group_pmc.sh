@@ -15,8 +15,12 @@ i=0
 while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1)); rm -rf /tmp/mgp_pmc_$i
-  timeout 200 rocprofv3 --pmc $group --kernel-trace --output-format csv -d /tmp/mgp_pmc_$i -o p -- rsem_amd/bin/rsem-run-em $D/ref 3 $D/s $D/temp/s $D/stat/s -q > $out/pmc_$i.log 2>&1
+  timeout 90 rocprofv3 --pmc $group --kernel-trace --output-format csv -d /tmp/mgp_pmc_$i -o p -- rsem_amd/bin/rsem-run-em $D/ref 3 $D/s $D/temp/s $D/stat/s -q > $out/pmc_$i.log 2>&1
   echo "group $i ($group): rc=$?"
+  # (the counters of the round kernel leave the box with every pass: a later pass that hangs must not take them along)
+  f=$(find /tmp/mgp_pmc_$i -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && grep -E "Counter_Name|k_model_group" "$f" > $out/counters_$i.csv
+  rm -rf /tmp/mgp_pmc_$i
 done <<'GROUPS'
 FETCH_SIZE
 WRITE_SIZE
@@ -30,14 +34,14 @@ TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
 TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
 TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
-TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TC_STALL_sum TA_TA_BUSY_sum
+TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum
 GROUPS
 python - $out $i <<'PY'
 import csv, glob, json, sys, collections
 out, n = sys.argv[1], int(sys.argv[2])
 res = collections.defaultdict(dict)
 for i in range(1, n + 1):
-    for f in glob.glob("/tmp/mgp_pmc_%d/**/*counter_collection.csv" % i, recursive=True):
+    for f in glob.glob(out + "/counters_%d.csv" % i):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for x in csv.DictReader(open(f)):
             k = x["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:48]
