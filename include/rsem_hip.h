@@ -80,8 +80,8 @@ typedef struct rsem_em_ctx rsem_em_ctx;
 
 /* E-step kernel variants (rsem_em_set_option "kernel") */
 #define RSEM_EM_KERNEL_AUTO 0
-#define RSEM_EM_KERNEL_CSR 1   /* thread-per-read over the CSR as given (baseline / long rows / K5) */
-#define RSEM_EM_KERNEL_SELL 2  /* sliced layout, per-slice segmented shuffle reduction + device atomics (cross-check) */
+#define RSEM_EM_KERNEL_CSR 1   /* RETIRED in round 6 (was: thread-per-read over the CSR as given); rsem_em_set_option refuses it */
+#define RSEM_EM_KERNEL_SELL 2  /* RETIRED in round 6 (was: per-slice segmented shuffle reduction, a cross-check); refused */
 #define RSEM_EM_KERNEL_LANE 3  /* sliced layout, lane-private runs, LDS-staged theta + LDS count window (default) */
 
 /* Upload one shard: N1 reads, nnz alignments.  row_ptr[N1+1] (row_ptr[0]==0, row_ptr[N1]==nnz),

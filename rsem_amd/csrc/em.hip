@@ -107,18 +107,6 @@ struct HostMirror {
 // wave_sum and the per-wave body of the LANE kernel (also run on the CPU by tests/estep_emu.cpp)
 #include "estep_block.hpp"
 
-__device__ inline void block_store_partial(double v, double* out) {
-    __shared__ double red[kBlock / 64];
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < kBlock / 64; i++) t += red[i];
-        out[blockIdx.x] = t;
-    }
-}
-
 // per-workgroup noise partial (for the callers that reduce the partials themselves) and, when `tot` is given, two
 // device-wide totals: tot[0] += v (noise fraction), tot[1] += u (reads with a non-zero normaliser: an integer
 // count, so its total is exact in any order)
@@ -138,49 +126,6 @@ __device__ inline void block_add_totals(double v, double u, double* out_v, doubl
             if (tu != 0.0) unsafeAtomicAdd(&tot[kTotSlots + slot], tu);
         }
     }
-}
-
-// Thread-per-read over the caller's CSR (EM.cpp:199-244 literally).  Used as the baseline
-// variant, for reads with > 256 alignments, and for the final expected-weights pass.
-template <bool kWriteW>
-__global__ __launch_bounds__(kBlock) void k_estep_csr(
-    uint64_t n_rows, const uint32_t* __restrict__ row_list, const uint64_t* __restrict__ row_ptr,
-    const int32_t* __restrict__ sid, const double* __restrict__ cp, const double* __restrict__ ncp,
-    const double* __restrict__ theta, double* counts, double* noise_partial, double* w,
-    double* w_noise, const Ctrl* ctrl, double* totals = nullptr) {
-    if (ctrl && ctrl->done) return;
-    double noise = 0.0, neff = 0.0;
-    const double th0 = theta[0];
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_rows;
-         t += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t i = row_list ? row_list[t] : t;
-        uint64_t fr = row_ptr[i], to = row_ptr[i + 1];
-        double f0 = th0 * ncp[i];
-        if (f0 < kEpsilon) f0 = 0.0;
-        double sum = f0;
-        for (uint64_t j = fr; j < to; j++) {
-            double f = theta[sid[j]] * cp[j];
-            if (f < kEpsilon) f = 0.0;
-            sum += f;
-        }
-        if (sum >= kEpsilon) {
-            noise += f0 / sum;
-            neff += 1.0;
-            if (kWriteW) w_noise[i] = f0 / sum;
-            for (uint64_t j = fr; j < to; j++) {
-                int s = sid[j];
-                double f = theta[s] * cp[j];
-                if (f < kEpsilon) f = 0.0;
-                f /= sum;
-                if (f != 0.0) unsafeAtomicAdd(&counts[s], f);
-                if (kWriteW) w[j] = f;
-            }
-        } else if (kWriteW) {
-            w_noise[i] = 0.0;
-            for (uint64_t j = fr; j < to; j++) w[j] = 0.0;
-        }
-    }
-    block_add_totals(noise, neff, noise_partial, totals);
 }
 
 // The reads the sliced layout does not take (more than 256 alignments: a Trinity-shaped tail), a WAVE per read: the lanes stride
@@ -398,59 +343,6 @@ __global__ __launch_bounds__(kBlock) void k_far_colsum(uint64_t n_far, const int
             if (tail && key[u] > 0 && v != 0.0) unsafeAtomicAdd(&counts[key[u]], v);
         }
     }
-}
-
-// Variant SELL (cross-check / fallback): every slice on its own, per-plane segmented shuffle
-// reduction keyed by sid, run tails issue device atomics.  Makes no use of the lane-major order.
-__global__ __launch_bounds__(kBlock) void k_estep_sell(
-    const Shape* __restrict__ shapes, int n_shapes, uint32_t n_slices, const double* __restrict__ theta,
-    const double* __restrict__ scp, const int32_t* __restrict__ ssid, const double* __restrict__ sncp,
-    double* counts, double* noise_partial, const Ctrl* ctrl) {
-    if (ctrl->done) return;
-    __shared__ Shape sh_shapes[kMaxShapes];
-    for (int i = threadIdx.x; i < n_shapes; i += blockDim.x) sh_shapes[i] = shapes[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (kBlock / 64);
-    const double th0 = theta[0];
-    double noise = 0.0;
-    for (uint32_t s = wave; s < n_slices; s += n_waves) {
-        int sh = 0;
-        while (sh + 1 < n_shapes && s >= sh_shapes[sh + 1].slice_base) ++sh;
-        const int K = sh_shapes[sh].K, lg = sh_shapes[sh].lg;
-        const uint32_t sl = s - sh_shapes[sh].slice_base;
-        const uint64_t pl0 = (sh_shapes[sh].plane_base + (uint64_t)sl * K) * 64 + lane;
-        const int g = lane & ((1 << lg) - 1);
-        double f0 = 0.0;
-        if (g == 0) {
-            f0 = th0 * sncp[sh_shapes[sh].slot_base + sl * (64u >> lg) + (lane >> lg)];
-            if (f0 < kEpsilon) f0 = 0.0;
-        }
-        double f[kMaxK];
-        int id[kMaxK];
-        double part = f0;
-#pragma unroll
-        for (int k = 0; k < kMaxK; k++)
-            if (k < K) {
-                id[k] = ssid[pl0 + (uint64_t)k * 64];
-                double v = theta[id[k]] * scp[pl0 + (uint64_t)k * 64];
-                if (v < kEpsilon) v = 0.0;
-                f[k] = v;
-                part += v;
-            }
-        for (int d = 1; d < (1 << lg); d <<= 1) part += __shfl_xor(part, d);
-        const double inv = (part >= kEpsilon) ? 1.0 / part : 0.0;
-        noise += f0 * inv;
-#pragma unroll
-        for (int k = 0; k < kMaxK; k++)
-            if (k < K) {
-                double v = f[k] * inv;
-                bool tail = seg_reduce(id[k], v, lane, lg);
-                if (tail && id[k] != 0 && v != 0.0) unsafeAtomicAdd(&counts[id[k]], v);
-            }
-    }
-    block_store_partial(noise, noise_partial);
 }
 
 // (Variant LANE, the default: k_estep_lane below; its per-wave body is estep_block.hpp, included above.)
@@ -1098,17 +990,9 @@ int partition_units(rsem_em_ctx* c) {
 
 int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStream_t st, bool use_ctrl) {
     const Ctrl* ctrl = c->d_ctrl;
-    const int kern = resolved_kernel(c);
     (void)use_ctrl;
-    c->noise_n = (kern == RSEM_EM_KERNEL_LANE) ? (int)c->n_units : c->grid_main;
-    if (kern == RSEM_EM_KERNEL_CSR) {
-        hipLaunchKernelGGL(k_estep_csr<false>, dim3(c->grid_main), dim3(kBlock), 0, st, c->N1, (const uint32_t*)nullptr,
-                           c->d_row_ptr, c->d_sid, c->d_cp, c->d_ncp, d_theta, d_counts, c->d_noise_a,
-                           (double*)nullptr, (double*)nullptr, ctrl);
-        RSEM_HIP_TRY(hipGetLastError());
-        return RSEM_OK;
-    }
-    if (kern == RSEM_EM_KERNEL_LANE) {
+    c->noise_n = (int)c->n_units;
+    {
         XArgs xa;
         // the split rows' chain on a stream of its own, beside the compact units
         hipStream_t sx = st;
@@ -1148,11 +1032,6 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
             RSEM_HIP_TRY(hipEventRecord(c->ev_x_join, sx));
             RSEM_HIP_TRY(hipStreamWaitEvent(st, c->ev_x_join, 0));
         }
-    } else {
-        if (c->L.n_x_rows) { rsem::set_last_error("the SELL kernel cannot walk a layout with split rows (set the kernel before the values, or option split_rows = 0)"); return RSEM_ERR_STATE; }
-        if (c->layout_has_q32) { rsem::set_last_error("the SELL kernel reads F64 planes only (value_bits = 32 needs the LANE kernel)"); return RSEM_ERR_STATE; }
-        hipLaunchKernelGGL(k_estep_sell, dim3(c->grid_main), dim3(kBlock), 0, st, c->L.d_shapes, c->L.n_shapes,
-                           c->L.n_slices, d_theta, (const double*)c->d_sval, c->L.d_ssid, c->d_sncp, d_counts, c->d_noise_a, ctrl);
     }
     RSEM_HIP_TRY(hipGetLastError());
     if (c->L.n_long_rows) {
@@ -1165,8 +1044,7 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
 }
 
 int n_noise_b(const rsem_em_ctx* c) {
-    const int kern = resolved_kernel(c);
-    return (kern != RSEM_EM_KERNEL_CSR && c->L.n_long_rows) ? c->grid_long : 0;
+    return c->L.n_long_rows ? c->grid_long : 0;
 }
 
 int launch_weights(rsem_em_ctx* c, const double* d_theta, hipStream_t st) {
@@ -1212,7 +1090,6 @@ int release_csr(rsem_em_ctx* c) {
     else if (c->layout_has_q32 || c->value_bits == 32) why = "Q32 planes hold rounded values";
     else if (c->L.n_x_rows) why = "split rows keep part of their alignments outside the planes";
     else if (c->L.n_long_rows) why = "reads with more than 256 alignments live in the CSR alone";
-    else if (resolved_kernel(c) == RSEM_EM_KERNEL_CSR) why = "the CSR kernel is selected";
     else if (c->views_out > 0) why = "a model context still holds the arrays";
     if (why) { rsem::set_last_error("release_csr: %s", why); return RSEM_ERR_STATE; }
     RSEM_HIP_TRY(hipSetDevice(c->device));
@@ -1357,11 +1234,7 @@ int build_layout(rsem_em_ctx* c) {
 }
 
 void set_grid_for_kernel(rsem_em_ctx* c) {
-    const int kern = resolved_kernel(c);
-    if (kern == RSEM_EM_KERNEL_CSR)
-        c->grid_main = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->N1, kBlock)));
-    else
-        c->grid_main = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_slices, kBlock / 64)));
+    c->grid_main = std::max(1, std::min<int>(c->n_cus * 8, rsem::ceil_div(c->L.n_slices, kBlock / 64)));
 }
 
 }  // namespace
@@ -1527,6 +1400,9 @@ int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
     }
     if (!strcmp(key, "kernel")) {
         RSEM_REQUIRE(value >= RSEM_EM_KERNEL_AUTO && value <= RSEM_EM_KERNEL_LANE, "unknown kernel variant");
+        // (the thread-per-read and slice-at-a-time kernels of rounds 1-2 left the product in round 6: the checker is oracle/, not a
+        // second kernel in the shipped library)
+        RSEM_REQUIRE(value == RSEM_EM_KERNEL_AUTO || value == RSEM_EM_KERNEL_LANE, "kernel variants CSR (1) and SELL (2) were retired: AUTO (0) or LANE (3)");
         c->kernel = (int)value;
         if (c->layout_ok && c->L.n_x_rows && resolved_kernel(c) != RSEM_EM_KERNEL_LANE) {  // only the LANE kernel walks split rows
             RSEM_HIP_TRY(hipSetDevice(c->device));
@@ -2086,36 +1962,5 @@ int em_values_changed(rsem_em_ctx* c) {
     return fill_values(c);
 }
 
-int em_step_with_weights(rsem_em_ctx* c, const double* theta, double N0, double* counts, double* theta_new, double* sum,
-                         double* bChange, int32_t* totNum) {
-    RSEM_REQUIRE(c && theta, "NULL argument");
-    if (!c->have_values) { set_last_error("CSR values were never set"); return RSEM_ERR_STATE; }
-    if (!c->layout_ok) { set_last_error("the device layout could not be rebuilt after the last change of values / options"); return RSEM_ERR_STATE; }
-    RSEM_HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = c->stream;
-    const size_t nb = sizeof(double) * ((size_t)c->M + 1);
-    if (!c->d_w) RSEM_HIP_TRY(dmalloc(&c->d_w, c->nnz));
-    if (!c->d_wn) RSEM_HIP_TRY(dmalloc(&c->d_wn, c->N1));
-    RSEM_HIP_TRY(hipMemcpyAsync(c->d_theta[0], theta, nb, hipMemcpyHostToDevice, st));
-    RSEM_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), st));
-    RSEM_HIP_TRY(hipMemsetAsync(c->d_counts, 0, nb, st));
-    // the round's counts / theta come from the main E-step kernel, exactly as in a theta-only round; the weights the
-    // model statistics need (d_w, d_wn: EM.cpp:227,234) from their own file-order pass with the same theta
-    int rc = launch_estep(c, c->d_theta[0], c->d_counts, st, true);
-    if (rc != RSEM_OK) return rc;
-    rc = launch_mstep(c, N0, c->d_counts, c->d_theta[0], c->d_theta[1], 1, 1, 1, st);
-    if (rc != RSEM_OK) return rc;
-    if (c->N1) rc = launch_weights(c, c->d_theta[0], st);
-    if (rc != RSEM_OK) return rc;
-    Ctrl h;
-    RSEM_HIP_TRY(hipMemcpyAsync(&h, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
-    if (counts) RSEM_HIP_TRY(hipMemcpyAsync(counts, c->d_counts_last, nb, hipMemcpyDeviceToHost, st));
-    if (theta_new) RSEM_HIP_TRY(hipMemcpyAsync(theta_new, c->d_theta[1], nb, hipMemcpyDeviceToHost, st));
-    RSEM_HIP_TRY(hipStreamSynchronize(st));
-    if (sum) *sum = h.last_sum;
-    if (bChange) *bChange = h.last_bchange;
-    if (totNum) *totNum = h.last_totNum;
-    return RSEM_OK;
-}
 
 }  // namespace rsem

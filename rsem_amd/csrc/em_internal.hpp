@@ -28,7 +28,7 @@ struct EmPlanesView {
     double* d_sncp;
 };
 
-// device pointers of the ctx (d_w / d_wn are NULL until a weights pass has run: take the view again after em_step_with_weights)
+// device pointers of the ctx (d_w / d_wn are NULL until a weights pass has run)
 int em_device_view(rsem_em_ctx* c, EmDeviceView* v);
 // A model context keeps the view's d_sid / d_cp for its lifetime: between hold and release the EM context does not free them
 // (option "release_csr" is refused).
@@ -43,9 +43,5 @@ int em_planes_view(rsem_em_ctx* c, EmPlanesView* v);
 // last-error string (callers that only want to know must not use em_planes_view as a probe).
 bool em_planes_writable(const rsem_em_ctx* c);
 int em_values_written_in_place(rsem_em_ctx* c);
-// E step with posterior write-back into d_w / d_wn (EM.cpp:199-244, calcExpectedWeights-style) followed by the M
-// step; host outputs as rsem_em_step.  The weights stay on the device for the model accumulation kernels.
-int em_step_with_weights(rsem_em_ctx* c, const double* theta, double N0, double* counts, double* theta_new,
-                         double* sum, double* bChange, int32_t* totNum);
 
 }  // namespace rsem

@@ -275,6 +275,12 @@ int main(int argc, char* argv[]) {
         exit(-1);
     }
     const auto t_start = std::chrono::steady_clock::now();
+    // (finer marks inside a phase, RSEM_HIP_TIMING=2: they do not reset the phase's clock)
+    const auto t_mark0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        static const bool on = getenv("RSEM_HIP_TIMING") && atoi(getenv("RSEM_HIP_TIMING")) >= 2;
+        if (on) printf("[timing]     at %7.3f s: %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_mark0).count(), what);
+    };
     auto lap = [&](const char* what) {  // phase timing (stdout is not parsed by the pipeline driver)
         static auto last = std::chrono::steady_clock::now();
         auto now = std::chrono::steady_clock::now();
@@ -480,7 +486,9 @@ int main(int argc, char* argv[]) {
 
     // ---- device contexts -----------------------------------------------------------------------------
     validate_alignments(dat, rs.mate[1], lq, refs, model.P.seedLen, pe, imdName, read_type);
+    mark("alignments validated");
     em_builder.join();
+    mark("EM contexts built (upload + layout, started behind .dat)");
     if (ndev < 1) die("rsem-run-em: no usable GPU (this program has no CPU path)");
     check_shards("rsem_em_create");
     // packed references
@@ -506,6 +514,7 @@ int main(int argc, char* argv[]) {
             }
         });
     }
+    mark("references packed");
     each_shard([&](Shard& X, int) {
         rsem_model_data md;
         memset(&md, 0, sizeof(md));
@@ -524,6 +533,7 @@ int main(int argc, char* argv[]) {
         if (X.rc != RSEM_OK) X.err = rsem_hip_last_error();
     });
     check_shards("rsem_model_create");
+    mark("model contexts built (reads, references, alignment fields uploaded)");
     // the communicator of the device loop: RCCL, one rank per GPU; shards that share a GPU exchange inside the process
     if (S > 1) {
         bool shared_device = false;

@@ -32,36 +32,6 @@ constexpr int kBlk = 256;
 #include "sell_shape.hpp"
 #include "model_block.hpp"
 
-// (Q)Profile::getProb (QProfile.h:111-120, Profile.h:114-120): product over the read, 8 bases per step
-// (three 8-byte loads instead of 24 byte loads; the factors are multiplied in read order, padding multiplies by 1).
-template <bool kQ>
-__device__ inline double profile_prob(const double* __restrict__ prof, const uint64_t* __restrict__ rs,
-                                      const uint64_t* __restrict__ rq, int len, const uint64_t* __restrict__ refw,
-                                      uint64_t a /* byte address of the first strand position */) {
-    double prob = 1.0;
-    const uint64_t* rw = refw + (a >> 3);
-    const int sh = (int)(a & 7) * 8;
-    uint64_t w0 = rw[0];
-    for (int i = 0; i < len; i += 8) {
-        const uint64_t w1 = rw[(i >> 3) + 1];
-        const uint64_t rf = funnel8(w0, w1, sh);
-        w0 = w1;
-        const uint64_t sb = rs[i >> 3];
-        const uint64_t qb = kQ ? rq[i >> 3] : 0;
-        const int n = len - i;
-        double p[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int row = kQ ? (int)((qb >> (8 * u)) & 0xff) : i + u;
-            const int idx = (row * 5 + (int)((rf >> (8 * u)) & 0xff)) * 5 + (int)((sb >> (8 * u)) & 0xff);
-            p[u] = (u < n) ? prof[idx] : 1.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) prob *= p[u];
-    }
-    return prob;
-}
-
 // Do two strand windows of `len` bases hold the same bases?  The alignments of a read mostly do: isoforms of a gene share
 // the exon the read came from, which is WHY the read is multi-mapped.  Then the profile product of the read against the
 // window (the expensive part of getConPrb) and the profile counts it feeds (update) are the same for both alignments.
@@ -80,348 +50,6 @@ __device__ inline bool same_window(const uint64_t* __restrict__ refw, uint64_t a
         if (x) return false;
     }
     return true;
-}
-
-// One thread per READ: its alignments are walked in file order and the profile product of a mate is taken over from the
-// previous alignment when the reference window is the same (same bases, same read, same multiplication order: the value
-// is bit-identical to recomputing it).  Everything else of getConPrb is per alignment as in the reference
-// (SingleQModel.h:101-151, PairedEndQModel.h:94-138 and the no-quality twins).
-template <bool kQ, bool kPE>
-__global__ __launch_bounds__(kBlk) void k_conprb_read(DevData D, DevTables T, double* cp) {
-    __shared__ double s_prof[kQ ? 2500 : 1];
-    if (kQ) {
-        for (int i = threadIdx.x; i < 2500; i += blockDim.x) s_prof[i] = T.prof[i];
-        __syncthreads();
-    }
-    const double* prof = kQ ? s_prof : T.prof;
-    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= D.N1) return;
-    const uint64_t fr = D.row_ptr[row], to = D.row_ptr[row + 1];
-    if (D.lq[row]) {
-        for (uint64_t j = fr; j < to; j++) cp[j] = 0.0;
-        return;
-    }
-    const uint64_t r0 = D.roff8[0][row];
-    const int len1 = D.rlen[0][row];
-    const uint64_t q0 = kPE ? D.roff8[1][row] : 0;
-    const int len2 = kPE ? D.rlen[1][row] : 0;
-    bool have1 = false, have2 = false;
-    uint64_t w1 = 0, w2 = 0;     // windows the cached products belong to
-    double p1 = 0.0, p2 = 0.0;
-    auto product1 = [&](uint64_t a) -> double {
-        if (!(have1 && same_window(D.refw, a, w1, len1))) {
-            p1 = profile_prob<kQ>(prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, a);
-            w1 = a; have1 = true;
-        }
-        return p1;
-    };
-    auto product2 = [&](uint64_t a) -> double {
-        if (!(have2 && same_window(D.refw, a, w2, len2))) {
-            p2 = profile_prob<kQ>(prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2, D.refw, a);
-            w2 = a; have2 = true;
-        }
-        return p2;
-    };
-    for (uint64_t j = fr; j < to; j++) {
-        double prob = 0.0;
-        const int s = D.sid_signed[j];
-        const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
-        const int pos = D.pos[j];
-        const int fullLen = D.fullLen[sid], totLen = D.totLen[sid];
-        if (!kPE) {
-            const int fpos = dir == 0 ? pos : totLen - pos - len1;
-            const int seedPos = dir == 0 ? pos : totLen - pos - T.seedLen;
-            if (!(seedPos >= fullLen || ref_mask(D, sid, seedPos))) {
-                double value;
-                if (T.has_mld) {  // SingleQModel.h:127-136
-                    const int minL = max(len1, T.gld_lb + 1), maxL = min(totLen - pos, T.gld_ub);
-                    value = 0.0;
-                    for (int fragLen = minL; fragLen <= maxL; fragLen++) {
-                        const int pfpos = dir == 0 ? pos : totLen - pos - fragLen;
-                        const int effL = min(fullLen, totLen - fragLen + 1);
-                        value += ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, fragLen, totLen) * rspd_adj(T, pfpos, effL, fullLen) *
-                                 ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len1, fragLen);
-                    }
-                } else {
-                    const int effL = min(fullLen, totLen - len1 + 1);
-                    value = ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, len1, totLen) * rspd_adj(T, fpos, effL, fullLen);
-                }
-                const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
-                prob = ori * value * product1(D.soff[2 * sid + dir] + pos);
-                if (prob < kEpsilon) prob = 0.0;
-                prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
-            }
-        } else {  // PairedEndQModel.h:94-138
-            const int insertLen = D.insertL[j];
-            const int fpos = dir == 0 ? pos : totLen - pos - insertLen;
-            const int effL = min(fullLen, totLen - insertLen + 1);
-            if (!(fpos >= fullLen || ref_mask(D, sid, fpos))) {
-                const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
-                prob = ori * ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, insertLen, totLen) * rspd_adj(T, fpos, effL, fullLen);
-                prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len1, insertLen) * product1(D.soff[2 * sid + dir] + pos);
-                const int m2pos = totLen - pos - insertLen, m2dir = !dir;
-                prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len2, insertLen) * product2(D.soff[2 * sid + m2dir] + m2pos);
-                if (prob < kEpsilon) prob = 0.0;
-                prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
-            }
-        }
-        cp[j] = prob;
-    }
-}
-
-// Profile products shared between alignments (same_prev flags): pass 1 computes the product of a mate only for the HEAD of
-// every run of alignments whose window of that mate holds the same bases; pass 2 (k_conprb<.., true>) takes the head's value.
-// Same bases, same read, same multiplication order: the value is the one every alignment of the run would compute itself.
-template <bool kQ, bool kPE>
-__global__ __launch_bounds__(kBlk) void k_profile_heads(DevData D, DevTables T, double* P1, double* P2) {
-    __shared__ double s_prof[kQ ? 2500 : 1];
-    if (kQ) {
-        for (int i = threadIdx.x; i < 2500; i += blockDim.x) s_prof[i] = T.prof[i];
-        __syncthreads();
-    }
-    const double* prof = kQ ? s_prof : T.prof;
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= D.nnz) return;
-    const uint32_t row = D.hit_row[j];
-    if (D.lq[row]) return;
-    const uint8_t f = D.same_prev[j];
-    if ((f & 1) && (!kPE || (f & 2))) return;
-    const int s = D.sid_signed[j];
-    const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
-    const int pos = D.pos[j];
-    if (!(f & 1)) {
-        const uint64_t r0 = D.roff8[0][row];
-        P1[j] = profile_prob<kQ>(prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, D.rlen[0][row], D.refw, D.soff[2 * sid + dir] + pos);
-    }
-    if (kPE && !(f & 2)) {
-        const uint64_t q0 = D.roff8[1][row];
-        P2[j] = profile_prob<kQ>(prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, D.rlen[1][row], D.refw,
-                                 D.soff[2 * sid + (!dir)] + (D.totLen[sid] - pos - D.insertL[j]));
-    }
-}
-
-template <bool kQ, bool kPE, bool kShared = false>
-__global__ __launch_bounds__(kBlk) void k_conprb(DevData D, DevTables T, double* cp, const double* __restrict__ P1 = nullptr,
-                                                  const double* __restrict__ P2 = nullptr) {
-    // QProfile (100 x 5 x 5 doubles = 20 KB) is staged in LDS; the position-indexed Profile stays in global memory
-    __shared__ double s_prof[(kQ && !kShared) ? 2500 : 1];
-    if (kQ && !kShared) {
-        for (int i = threadIdx.x; i < 2500; i += blockDim.x) s_prof[i] = T.prof[i];
-        __syncthreads();
-    }
-    const double* prof = (kQ && !kShared) ? s_prof : T.prof;
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= D.nnz) return;
-    const uint32_t row = D.hit_row[j];
-    // kShared: the product of mate m comes from the head of this alignment's run (walk back while the flag says "same")
-    auto shared_product = [&](const double* __restrict__ P, int bit) -> double {
-        uint64_t h = j;
-        while (D.same_prev[h] & bit) --h;
-        return P[h];
-    };
-    double prob = 0.0;
-    if (!D.lq[row]) {
-        const int s = D.sid_signed[j];
-        const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
-        const int pos = D.pos[j];
-        const int fullLen = D.fullLen[sid], totLen = D.totLen[sid];
-        const uint64_t r0 = D.roff8[0][row];
-        const int len1 = D.rlen[0][row];
-        if (!kPE) {
-            const int fpos = dir == 0 ? pos : totLen - pos - len1;
-            const int seedPos = dir == 0 ? pos : totLen - pos - T.seedLen;
-            if (!(seedPos >= fullLen || ref_mask(D, sid, seedPos))) {
-                double value;
-                if (T.has_mld) {  // SingleQModel.h:127-136
-                    const int minL = max(len1, T.gld_lb + 1), maxL = min(totLen - pos, T.gld_ub);
-                    value = 0.0;
-                    for (int fragLen = minL; fragLen <= maxL; fragLen++) {
-                        const int pfpos = dir == 0 ? pos : totLen - pos - fragLen;
-                        const int effL = min(fullLen, totLen - fragLen + 1);
-                        value += ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, fragLen, totLen) * rspd_adj(T, pfpos, effL, fullLen) *
-                                 ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len1, fragLen);
-                    }
-                } else {
-                    const int effL = min(fullLen, totLen - len1 + 1);
-                    value = ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, len1, totLen) * rspd_adj(T, fpos, effL, fullLen);
-                }
-                const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
-                const double pp1 = kShared ? shared_product(P1, 1)
-                                           : profile_prob<kQ>(prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, D.soff[2 * sid + dir] + pos);
-                prob = ori * value * pp1;
-                if (prob < kEpsilon) prob = 0.0;
-                prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
-            }
-        } else {  // PairedEndQModel.h:94-138
-            const int insertLen = D.insertL[j];
-            const int fpos = dir == 0 ? pos : totLen - pos - insertLen;
-            const int effL = min(fullLen, totLen - insertLen + 1);
-            if (!(fpos >= fullLen || ref_mask(D, sid, fpos))) {
-                const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
-                prob = ori * ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, insertLen, totLen) * rspd_adj(T, fpos, effL, fullLen);
-                const double pp1 = kShared ? shared_product(P1, 1)
-                                           : profile_prob<kQ>(prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, D.soff[2 * sid + dir] + pos);
-                prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len1, insertLen) * pp1;
-                const uint64_t q0 = D.roff8[1][row];
-                const int len2 = D.rlen[1][row];
-                const int m2pos = totLen - pos - insertLen, m2dir = !dir;
-                const double pp2 = kShared ? shared_product(P2, 2)
-                                           : profile_prob<kQ>(prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2, D.refw, D.soff[2 * sid + m2dir] + m2pos);
-                prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len2, insertLen) * pp2;
-                if (prob < kEpsilon) prob = 0.0;
-                prob = (T.mw[sid] < kEpsilon) ? 0.0 : prob / T.mw[sid];
-            }
-        }
-    }
-    cp[j] = prob;
-}
-
-// Noise(Q)Profile::getProb
-template <bool kQ>
-__device__ inline double noise_prob(const double* __restrict__ noise, const uint64_t* __restrict__ rs,
-                                    const uint64_t* __restrict__ rq, int len) {
-    double prob = 1.0;
-    for (int i = 0; i < len; i += 8) {
-        const uint64_t sb = rs[i >> 3];
-        const uint64_t qb = kQ ? rq[i >> 3] : 0;
-        const int n = len - i;
-        double p[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int b = (int)((sb >> (8 * u)) & 0xff);
-            p[u] = (u < n) ? (kQ ? noise[(int)((qb >> (8 * u)) & 0xff) * 5 + b] : noise[b]) : 1.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) prob *= p[u];
-    }
-    return prob;
-}
-
-template <bool kQ, bool kPE>
-__global__ __launch_bounds__(kBlk) void k_noise(DevData D, DevTables T, double* ncp) {
-    __shared__ double s_noise[kQ ? 500 : 5];
-    for (int i = threadIdx.x; i < (kQ ? 500 : 5); i += blockDim.x) s_noise[i] = T.noise[i];
-    __syncthreads();
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= D.N1) return;
-    double prob = 0.0;
-    if (!D.lq[i]) {
-        const uint64_t r0 = D.roff8[0][i];
-        const int len1 = D.rlen[0][i];
-        const double* lpdf = (kPE || T.has_mld) ? T.mld_pdf : T.gld_pdf;
-        const int llb = (kPE || T.has_mld) ? T.mld_lb : T.gld_lb;
-        prob = lpdf[len1 - llb] * noise_prob<kQ>(s_noise, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1);
-        if (kPE) {
-            const uint64_t q0 = D.roff8[1][i];
-            const int len2 = D.rlen[1][i];
-            prob *= lpdf[len2 - llb] * noise_prob<kQ>(s_noise, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2);
-        }
-        if (prob < kEpsilon) prob = 0.0;
-        prob = (T.mw[0] < kEpsilon) ? 0.0 : prob / T.mw[0];
-    }
-    ncp[i] = prob;
-}
-
-// ---- sufficient statistics (updateModel rounds) ----------------------------------------------------
-
-// The LDS side is spelled as an LDS operation (RSEM_LDS_ADD in add_tbl): left as a generic pointer, the two branches can be
-// merged into one flat atomic on a selected address, which this compiler then fails to encode (and which would be slower).
-template <bool kQ>
-__device__ inline void profile_update(double* lds, double* glob, const uint64_t* __restrict__ rs,
-                                      const uint64_t* __restrict__ rq, int len, const uint64_t* __restrict__ refw, uint64_t a,
-                                      double frac) {
-    const uint64_t* rw = refw + (a >> 3);
-    const int sh = (int)(a & 7) * 8;
-    uint64_t w0 = rw[0];
-    for (int i = 0; i < len; i += 8) {
-        const uint64_t w1 = rw[(i >> 3) + 1];
-        const uint64_t rf = funnel8(w0, w1, sh);
-        w0 = w1;
-        const uint64_t sb = rs[i >> 3];
-        const uint64_t qb = kQ ? rq[i >> 3] : 0;
-        const int n = min(8, len - i);
-        for (int u = 0; u < n; u++) {
-            const int row = kQ ? (int)((qb >> (8 * u)) & 0xff) : i + u;
-            add_tbl(lds, kProfLds, glob, (row * 5 + (int)((rf >> (8 * u)) & 0xff)) * 5 + (int)((sb >> (8 * u)) & 0xff), frac);
-        }
-    }
-}
-
-template <bool kQ, bool kPE>
-__global__ __launch_bounds__(kBlk) void k_update(DevData D, DevTables T, const double* __restrict__ w,
-                                                  const double* __restrict__ wn, AccumPtrs A) {
-    __shared__ double s_prof[kProfLds];
-    __shared__ double s_noise[kNoiseLds];
-    __shared__ double s_rspd[kRspdLds];
-    __shared__ double s_gld[kGldLds];
-    for (int i = threadIdx.x; i < kProfLds; i += blockDim.x) s_prof[i] = 0.0;
-    for (int i = threadIdx.x; i < kNoiseLds; i += blockDim.x) s_noise[i] = 0.0;
-    for (int i = threadIdx.x; i < kRspdLds; i += blockDim.x) s_rspd[i] = 0.0;
-    for (int i = threadIdx.x; i < kGldLds; i += blockDim.x) s_gld[i] = 0.0;
-    __syncthreads();
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    // alignments: (Q)Profile / RSPD / gld   (SingleQModel.h:168-215, PairedEndQModel.h:161-180)
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < D.nnz; j += stride) {
-        const double frac = w[j];
-        const uint32_t row = D.hit_row[j];
-        if (D.lq[row] || frac < kEpsilon) continue;
-        const int s = D.sid_signed[j];
-        const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
-        const int pos = D.pos[j];
-        const int fullLen = D.fullLen[sid], totLen = D.totLen[sid];
-        const uint64_t r0 = D.roff8[0][row];
-        const int len1 = D.rlen[0][row];
-        if (!kPE) {
-            if (T.estRSPD) {  // only one strand estimates the RSPD; helper models have no mld (SingleQModel.h:176-213)
-                if (T.probF >= 0.1 && dir == 0) rspd_update(s_rspd, A.rspd, T.B, pos, fullLen, frac);
-                if (T.probF < 0.1 && dir == 1) rspd_update(s_rspd, A.rspd, T.B, totLen - pos - len1, fullLen, frac);
-            }
-            profile_update<kQ>(s_prof, A.prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, D.soff[2 * sid + dir] + pos, frac);
-        } else {
-            const int insertL = D.insertL[j];
-            add_tbl(s_gld, kGldLds, A.gld, insertL - A.gld0_lb, frac);  // LenDist::update (LenDist.h:46-49)
-            if (T.estRSPD) {
-                const int fpos = dir == 0 ? pos : totLen - pos - insertL;
-                rspd_update(s_rspd, A.rspd, T.B, fpos, fullLen, frac);
-            }
-            profile_update<kQ>(s_prof, A.prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, D.soff[2 * sid + dir] + pos, frac);
-            const uint64_t q0 = D.roff8[1][row];
-            const int len2 = D.rlen[1][row];
-            profile_update<kQ>(s_prof, A.prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2, D.refw,
-                               D.soff[2 * sid + (!dir)] + (totLen - pos - insertL), frac);
-        }
-    }
-    // reads: noise profile (SingleQModel.h:217-221, PairedEndQModel.h:182-188)
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D.N1; i += stride) {
-        const double frac = wn[i];
-        if (D.lq[i] || frac < kEpsilon) continue;
-        for (int m = 0; m < (kPE ? 2 : 1); m++) {
-            const uint64_t* sq = D.rseq_w[m] + D.roff8[m][i];
-            const uint64_t* ql = kQ ? D.rqual_w[m] + D.roff8[m][i] : nullptr;
-            const int len = D.rlen[m][i];
-            for (int k = 0; k < len; k += 8) {
-                const uint64_t sb = sq[k >> 3], qb = kQ ? ql[k >> 3] : 0;
-                const int n = min(8, len - k);
-                for (int u = 0; u < n; u++) {
-                    const int b = (int)((sb >> (8 * u)) & 0xff);
-                    unsafeAtomicAdd(&s_noise[kQ ? (int)((qb >> (8 * u)) & 0xff) * 5 + b : b], frac);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int nprof = min(kProfLds, T.prof_rows * 25);
-    for (int i = threadIdx.x; i < nprof; i += blockDim.x)
-        if (s_prof[i] != 0.0) unsafeAtomicAdd(&A.prof[i], s_prof[i]);
-    const int nnoise = kQ ? 500 : 5;
-    for (int i = threadIdx.x; i < nnoise; i += blockDim.x)
-        if (s_noise[i] != 0.0) unsafeAtomicAdd(&A.noise[i], s_noise[i]);
-    if (A.rspd)
-        for (int i = threadIdx.x; i < min(kRspdLds, T.B + 2); i += blockDim.x)
-            if (s_rspd[i] != 0.0) unsafeAtomicAdd(&A.rspd[i], s_rspd[i]);
-    if (A.gld)
-        for (int i = threadIdx.x; i < min(kGldLds, A.gld0_ub - A.gld0_lb + 1); i += blockDim.x)
-            if (s_gld[i] != 0.0) unsafeAtomicAdd(&A.gld[i], s_gld[i]);
 }
 
 // same_prev flags (DevData): one thread per alignment, once per model context
@@ -447,110 +75,6 @@ __global__ __launch_bounds__(kBlk) void k_window_flags(DevData D, uint8_t* flags
         if (kPE && same_window(D.refw, a2, p2, D.rlen[1][row])) f |= 2;
     }
     flags[j] = f;
-}
-
-// One thread per READ.  Consecutive alignments whose reference windows hold the same bases put the SAME (quality, reference
-// base, read base) triples into the profile counts (QProfile::update, QProfile.h:88-93), so their posterior weights are
-// added up first and the read is walked once per group instead of once per alignment: one LDS atomic per base and group
-// instead of per base and alignment (the kernel is bound by those atomics).  RSPD / fragment-length counts stay per
-// alignment; the noise profile is per read anyway (SingleQModel.h:168-221, PairedEndQModel.h:161-188).
-template <bool kQ, bool kPE>
-__global__ __launch_bounds__(kBlk) void k_update_read(DevData D, DevTables T, const double* __restrict__ w,
-                                                       const double* __restrict__ wn, AccumPtrs A) {
-    __shared__ double s_prof[kProfLds];
-    __shared__ double s_noise[kNoiseLds];
-    __shared__ double s_rspd[kRspdLds];
-    __shared__ double s_gld[kGldLds];
-    for (int i = threadIdx.x; i < kProfLds; i += blockDim.x) s_prof[i] = 0.0;
-    for (int i = threadIdx.x; i < kNoiseLds; i += blockDim.x) s_noise[i] = 0.0;
-    for (int i = threadIdx.x; i < kRspdLds; i += blockDim.x) s_rspd[i] = 0.0;
-    for (int i = threadIdx.x; i < kGldLds; i += blockDim.x) s_gld[i] = 0.0;
-    __syncthreads();
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; row < D.N1; row += stride) {
-        if (D.lq[row]) continue;
-        const uint64_t r0 = D.roff8[0][row];
-        const int len1 = D.rlen[0][row];
-        const uint64_t q0 = kPE ? D.roff8[1][row] : 0;
-        const int len2 = kPE ? D.rlen[1][row] : 0;
-        // the open group: windows of its first alignment, the weight collected so far, and the "window generation" it
-        // belongs to (the generation advances whenever an alignment's windows differ from its predecessor's, skipped
-        // alignments included, so equal generations mean equal bases)
-        bool open = false;
-        uint64_t g1 = 0, g2 = 0;
-        double gw = 0.0;
-        int gen = 0, ggen = -1;
-        // (a macro, not a lambda: the LDS tables must reach the atomics as LDS pointers, not through a captured reference)
-#define RSEM_FLUSH_GROUP()                                                                                                              \
-    do {                                                                                                                                \
-        if (open) {                                                                                                                     \
-            profile_update<kQ>(s_prof, A.prof, D.rseq_w[0] + r0, kQ ? D.rqual_w[0] + r0 : nullptr, len1, D.refw, g1, gw);               \
-            if (kPE) profile_update<kQ>(s_prof, A.prof, D.rseq_w[1] + q0, kQ ? D.rqual_w[1] + q0 : nullptr, len2, D.refw, g2, gw);     \
-            open = false;                                                                                                               \
-        }                                                                                                                               \
-    } while (0)
-        for (uint64_t j = D.row_ptr[row]; j < D.row_ptr[row + 1]; j++) {
-            if (D.same_prev[j] != (kPE ? 3 : 1)) ++gen;
-            const double frac = w[j];
-            if (frac < kEpsilon) continue;
-            const int s = D.sid_signed[j];
-            const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
-            const int pos = D.pos[j];
-            const int fullLen = D.fullLen[sid], totLen = D.totLen[sid];
-            if (!kPE) {
-                if (T.estRSPD) {  // only one strand estimates the RSPD; helper models have no mld (SingleQModel.h:176-213)
-                    if (T.probF >= 0.1 && dir == 0) rspd_update(s_rspd, A.rspd, T.B, pos, fullLen, frac);
-                    if (T.probF < 0.1 && dir == 1) rspd_update(s_rspd, A.rspd, T.B, totLen - pos - len1, fullLen, frac);
-                }
-            } else {
-                const int insertL = D.insertL[j];
-                add_tbl(s_gld, kGldLds, A.gld, insertL - A.gld0_lb, frac);  // LenDist::update (LenDist.h:46-49)
-                if (T.estRSPD) {
-                    const int fpos = dir == 0 ? pos : totLen - pos - insertL;
-                    rspd_update(s_rspd, A.rspd, T.B, fpos, fullLen, frac);
-                }
-            }
-            if (open && ggen == gen) {
-                gw += frac;
-            } else {
-                RSEM_FLUSH_GROUP();
-                open = true; ggen = gen; gw = frac;
-                g1 = D.soff[2 * sid + dir] + pos;
-                g2 = kPE ? D.soff[2 * sid + (!dir)] + (totLen - pos - D.insertL[j]) : 0;
-            }
-        }
-        RSEM_FLUSH_GROUP();
-#undef RSEM_FLUSH_GROUP
-        // noise profile (SingleQModel.h:217-221, PairedEndQModel.h:182-188)
-        const double nfrac = wn[row];
-        if (nfrac < kEpsilon) continue;
-        for (int m = 0; m < (kPE ? 2 : 1); m++) {
-            const uint64_t* sq = D.rseq_w[m] + D.roff8[m][row];
-            const uint64_t* ql = kQ ? D.rqual_w[m] + D.roff8[m][row] : nullptr;
-            const int len = D.rlen[m][row];
-            for (int k = 0; k < len; k += 8) {
-                const uint64_t sb = sq[k >> 3], qb = kQ ? ql[k >> 3] : 0;
-                const int n = min(8, len - k);
-                for (int u = 0; u < n; u++) {
-                    const int b = (int)((sb >> (8 * u)) & 0xff);
-                    unsafeAtomicAdd(&s_noise[kQ ? (int)((qb >> (8 * u)) & 0xff) * 5 + b : b], nfrac);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int nprof = min(kProfLds, T.prof_rows * 25);
-    for (int i = threadIdx.x; i < nprof; i += blockDim.x)
-        if (s_prof[i] != 0.0) unsafeAtomicAdd(&A.prof[i], s_prof[i]);
-    const int nnoise = kQ ? 500 : 5;
-    for (int i = threadIdx.x; i < nnoise; i += blockDim.x)
-        if (s_noise[i] != 0.0) unsafeAtomicAdd(&A.noise[i], s_noise[i]);
-    if (A.rspd)
-        for (int i = threadIdx.x; i < min(kRspdLds, T.B + 2); i += blockDim.x)
-            if (s_rspd[i] != 0.0) unsafeAtomicAdd(&A.rspd[i], s_rspd[i]);
-    if (A.gld)
-        for (int i = threadIdx.x; i < min(kGldLds, A.gld0_ub - A.gld0_lb + 1); i += blockDim.x)
-            if (s_gld[i] != 0.0) unsafeAtomicAdd(&A.gld[i], s_gld[i]);
 }
 
 // The model rounds' kernel (model_block.hpp): a group of 16 lanes per read, 512 threads per workgroup (two per CU: the
@@ -659,7 +183,6 @@ struct rsem_model_ctx {
     bool have_tables = false;
     int B_alloc = 0, gld_n = 0, mld_n = 0, prof_n = 0, noise_n = 0;
     std::vector<void*> owned;       // device allocations of the immutable data
-    double *d_P1 = nullptr, *d_P2 = nullptr;  // profile products of the run heads (k_profile_heads), [nnz] each
     double* d_theta = nullptr;                // the round's theta for the weights of k_model_group, [M+1]
     int n_cus = 0;
     // table buffers (re-uploaded every round)
@@ -682,62 +205,9 @@ int up_field(rsem_model_ctx* c, const T*& field, const T* src, size_t n, hipStre
     return RSEM_OK;
 }
 
-// Which variant runs.  Measured on 5 M read pairs / 56 M alignments (tools/profile_model_rounds.sh, profiles/r02_model_rounds.log):
-// update: per read 23.6 ms vs per alignment 38.1 ms (the LDS atomics are what the per-alignment kernel waits for);
-// conprb: per alignment 13.8 ms vs per read 49.7 ms (the product is cheap next to walking a read's alignments serially);
-//         products shared between identical windows: 3.6 + 2.1 ms (profiles/r02c_model_rounds.log).
-// Default = the per-read update and, for conprb, the two-pass variant that shares the products between alignments with
-// identical windows (k_profile_heads + k_conprb<.., true>); RSEM_MODEL_KERNELS=alignment | read forces one family
-// (cross-checks in tests/).
-bool per_alignment_kernels(bool for_update) {
-    const char* e = getenv("RSEM_MODEL_KERNELS");
-    if (e && !strcmp(e, "alignment")) return true;
-    if (e && !strcmp(e, "read")) return false;
-    return !for_update;
-}
-
-template <bool kQ, bool kPE>
-int launch_conprb(rsem_model_ctx* c) {
-    hipStream_t st = c->v.stream;
-    const char* fam = getenv("RSEM_MODEL_KERNELS");
-    if (c->D.nnz && fam && !strcmp(fam, "alignment"))
-        hipLaunchKernelGGL((k_conprb<kQ, kPE, false>), dim3(rsem::ceil_div(c->D.nnz, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_cp,
-                           (const double*)nullptr, (const double*)nullptr);
-    else if (c->D.N1 && fam && !strcmp(fam, "read"))
-        hipLaunchKernelGGL((k_conprb_read<kQ, kPE>), dim3(rsem::ceil_div(c->D.N1, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_cp);
-    else if (c->D.nnz) {  // default: products once per run of identical windows, then one thread per alignment
-        if (!c->d_P1) RSEM_HIP_TRY(dmalloc(&c->d_P1, (size_t)c->D.nnz));
-        if (kPE && !c->d_P2) RSEM_HIP_TRY(dmalloc(&c->d_P2, (size_t)c->D.nnz));
-        hipLaunchKernelGGL((k_profile_heads<kQ, kPE>), dim3(rsem::ceil_div(c->D.nnz, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->d_P1, c->d_P2);
-        hipLaunchKernelGGL((k_conprb<kQ, kPE, true>), dim3(rsem::ceil_div(c->D.nnz, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_cp,
-                           (const double*)c->d_P1, (const double*)c->d_P2);
-    }
-    if (c->D.N1)
-        hipLaunchKernelGGL((k_noise<kQ, kPE>), dim3(rsem::ceil_div(c->D.N1, kBlk)), dim3(kBlk), 0, st, c->D, c->T, c->v.d_ncp);
-    RSEM_HIP_TRY(hipGetLastError());
-    return RSEM_OK;
-}
-
-template <bool kQ, bool kPE>
-int launch_update(rsem_model_ctx* c, const AccumPtrs& A) {
-    if (per_alignment_kernels(true)) {
-        int grid = std::max(1, std::min(1024, rsem::ceil_div(std::max<uint64_t>(c->D.nnz, c->D.N1), kBlk * 4)));
-        hipLaunchKernelGGL((k_update<kQ, kPE>), dim3(grid), dim3(kBlk), 0, c->v.stream, c->D, c->T, (const double*)c->v.d_w,
-                           (const double*)c->v.d_wn, A);
-    } else {
-        int grid = std::max(1, std::min(1024, rsem::ceil_div(c->D.N1, kBlk)));
-        hipLaunchKernelGGL((k_update_read<kQ, kPE>), dim3(grid), dim3(kBlk), 0, c->v.stream, c->D, c->T, (const double*)c->v.d_w,
-                           (const double*)c->v.d_wn, A);
-    }
-    RSEM_HIP_TRY(hipGetLastError());
-    return RSEM_OK;
-}
-
-// the group-per-read kernel: conprb + noise (+ weights and statistics when theta / accumulators are given)
-bool group_kernel_selected() {
-    const char* e = getenv("RSEM_MODEL_KERNELS");
-    return !(e && (!strcmp(e, "alignment") || !strcmp(e, "read")));
-}
+// the group-per-read kernel: conprb + noise (+ weights and statistics when theta / accumulators are given).  (The thread-per-
+// alignment and thread-per-read kernel families of rounds 2-3, kept behind RSEM_MODEL_KERNELS as cross-checks until round 5, left the
+// product in round 6: the kernel body is checked on the CPU emulator and the programs against the reference's files.)
 template <bool kQ, bool kPE>
 int launch_group(rsem_model_ctx* c, const double* d_theta, const AccumPtrs* A, const PlaneOut& PO) {
     if (!c->D.N1) return RSEM_OK;
@@ -800,7 +270,7 @@ int rsem_model_destroy(rsem_model_ctx* c) {
     hipFree(c->t_rspd_pdf); hipFree(c->t_rspd_cdf); hipFree(c->t_gld_pdf); hipFree(c->t_gld_cdf); hipFree(c->t_mld_pdf);
     hipFree(c->t_mld_cdf); hipFree(c->t_prof); hipFree(c->t_noise); hipFree(c->t_mw);
     hipFree(c->a_prof); hipFree(c->a_noise); hipFree(c->a_rspd); hipFree(c->a_gld);
-    hipFree(c->d_P1); hipFree(c->d_P2); hipFree(c->d_theta);
+    hipFree(c->d_theta);
     delete c;
     return RSEM_OK;
 }
@@ -985,57 +455,16 @@ int rsem_model_calc_conprb(rsem_model_ctx* c) {
     RSEM_REQUIRE(c, "NULL argument");
     if (!c->have_tables) { rsem::set_last_error("model tables were never set"); return RSEM_ERR_STATE; }
     RSEM_HIP_TRY(hipSetDevice(c->v.device));
-    int rc;
-    if (group_kernel_selected()) {
-        return launch_group_any(c, nullptr, nullptr);
-    }
-    switch (c->D.model_type) {
-        case 0: rc = launch_conprb<false, false>(c); break;
-        case 1: rc = launch_conprb<true, false>(c); break;
-        case 2: rc = launch_conprb<false, true>(c); break;
-        default: rc = launch_conprb<true, true>(c); break;
-    }
-    if (rc != RSEM_OK) return rc;
-    return rsem::em_values_changed(c->em);
+    return launch_group_any(c, nullptr, nullptr);
 }
 
 int rsem_model_estep_update(rsem_model_ctx* c, const double* theta, double N0, double* counts, double* theta_new, double* sum,
                             double* bChange, int32_t* totNum, rsem_model_accum* acc) {
+    // (Kept for callers of the two-call form -- rsem_model_calc_conprb, then this.  Since round 6 it IS the one-pass round: the
+    // kernel recomputes the probabilities from the tables last set -- the same values rsem_model_calc_conprb left -- on its way to
+    // the weights and the statistics.)
     RSEM_REQUIRE(c && theta && acc && acc->prof && acc->noise, "NULL argument");
-    if (!c->have_tables) { rsem::set_last_error("model tables were never set"); return RSEM_ERR_STATE; }
-    const bool q = c->D.model_type == 1 || c->D.model_type == 3, pe = c->D.model_type >= 2;
-    RSEM_REQUIRE(!pe || acc->gld, "paired-end models accumulate the fragment length distribution");
-    RSEM_REQUIRE(!c->T.estRSPD || acc->rspd, "estRSPD needs the rspd accumulator");
-    int rc = rsem::em_step_with_weights(c->em, theta, N0, counts, theta_new, sum, bChange, totNum);
-    if (rc != RSEM_OK) return rc;
-    rc = rsem::em_device_view(c->em, &c->v);  // (the weight buffers exist from the first such pass on)
-    if (rc != RSEM_OK) return rc;
-    RSEM_HIP_TRY(hipSetDevice(c->v.device));
-    hipStream_t st = c->v.stream;
-    const size_t np = (size_t)c->T.prof_rows * 25, nn = q ? 500 : 5, nr = (size_t)c->T.B + 2;
-    const size_t ng = pe ? (size_t)(acc->gld0_ub - acc->gld0_lb + 1) : 1;
-    if (c->a_prof_n < np) { hipFree(c->a_prof); c->a_prof = nullptr; RSEM_HIP_TRY(dmalloc(&c->a_prof, np)); c->a_prof_n = np; }
-    if (!c->a_noise) RSEM_HIP_TRY(dmalloc(&c->a_noise, (size_t)500));
-    if (!c->a_rspd) RSEM_HIP_TRY(dmalloc(&c->a_rspd, std::max<size_t>(nr, 1024)));
-    if (c->a_gld_n < ng) { hipFree(c->a_gld); c->a_gld = nullptr; RSEM_HIP_TRY(dmalloc(&c->a_gld, ng)); c->a_gld_n = ng; }
-    RSEM_HIP_TRY(hipMemsetAsync(c->a_prof, 0, sizeof(double) * np, st));
-    RSEM_HIP_TRY(hipMemsetAsync(c->a_noise, 0, sizeof(double) * 500, st));
-    RSEM_HIP_TRY(hipMemsetAsync(c->a_rspd, 0, sizeof(double) * nr, st));
-    RSEM_HIP_TRY(hipMemsetAsync(c->a_gld, 0, sizeof(double) * ng, st));
-    AccumPtrs A{c->a_prof, c->a_noise, c->T.estRSPD ? c->a_rspd : nullptr, pe ? c->a_gld : nullptr, acc->gld0_lb, acc->gld0_ub};
-    switch (c->D.model_type) {
-        case 0: rc = launch_update<false, false>(c, A); break;
-        case 1: rc = launch_update<true, false>(c, A); break;
-        case 2: rc = launch_update<false, true>(c, A); break;
-        default: rc = launch_update<true, true>(c, A); break;
-    }
-    if (rc != RSEM_OK) return rc;
-    RSEM_HIP_TRY(hipMemcpyAsync(acc->prof, c->a_prof, sizeof(double) * np, hipMemcpyDeviceToHost, st));
-    RSEM_HIP_TRY(hipMemcpyAsync(acc->noise, c->a_noise, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
-    if (c->T.estRSPD) RSEM_HIP_TRY(hipMemcpyAsync(acc->rspd, c->a_rspd, sizeof(double) * nr, hipMemcpyDeviceToHost, st));
-    if (pe) RSEM_HIP_TRY(hipMemcpyAsync(acc->gld, c->a_gld, sizeof(double) * ng, hipMemcpyDeviceToHost, st));
-    RSEM_HIP_TRY(hipStreamSynchronize(st));
-    return RSEM_OK;
+    return rsem_model_round(c, theta, N0, counts, theta_new, sum, bChange, totNum, acc);
 }
 
 // One model round in one pass over the reads (rounds 1-11 of EM.cpp:383-404): alignment probabilities with the tables last
@@ -1045,12 +474,6 @@ int rsem_model_round(rsem_model_ctx* c, const double* theta, double N0, double* 
                      double* bChange, int32_t* totNum, rsem_model_accum* acc) {
     RSEM_REQUIRE(c && theta, "NULL argument");
     if (!c->have_tables) { rsem::set_last_error("model tables were never set"); return RSEM_ERR_STATE; }
-    if (!group_kernel_selected()) {  // the older kernel families (cross-checks): the same round as two calls
-        int rc = rsem_model_calc_conprb(c);
-        if (rc != RSEM_OK) return rc;
-        if (acc) return rsem_model_estep_update(c, theta, N0, counts, theta_new, sum, bChange, totNum, acc);
-        return rsem_em_step(c->em, theta, N0, counts, theta_new, sum, bChange, totNum);
-    }
     const bool q = c->D.model_type == 1 || c->D.model_type == 3, pe = c->D.model_type >= 2;
     RSEM_REQUIRE(!acc || (acc->prof && acc->noise), "NULL accumulator");
     RSEM_REQUIRE(!acc || !pe || acc->gld, "paired-end models accumulate the fragment length distribution");

@@ -226,30 +226,6 @@ def test_rsem_run_em_binary_input_equals_text_input(name, tmp_path):
     assert oa[:2] == ob[:2] and np.array_equal(oa[2], ob[2]) and np.array_equal(oa[3], ob[3]) and np.allclose(oa[4], ob[4], rtol=1e-9, atol=0)
 
 
-@pytest.mark.parametrize("name", ["pe_q", "se_noq_rev_rspd_omit", "se_q_fragmean"])
-def test_per_read_model_kernels_equal_per_alignment_kernels(name, tmp_path):
-    """The model rounds' kernel of the product (k_model_group: a group of 16 lanes per read, profile products and profile
-    counts shared by alignments whose reference windows hold the same bases, probabilities written into the value planes in
-    place) against the two older kernel families kept for this cross-check -- thread per alignment
-    (RSEM_MODEL_KERNELS=alignment) and thread per read (=read): same rounds, theta and .ofg values to 1e-9 (the products
-    and count sums differ in the order of their operations)."""
-    fx, dst = _stage(name, tmp_path)
-    meta = rf.read_meta(fx)
-    args = [os.path.join(dst, "ref"), str(meta["model_type"]), os.path.join(dst, "s"), os.path.join(dst, "temp", "s"), os.path.join(dst, "stat", "s"), "--gibbs-out"]
-    out_r = _run([os.path.join(BIN, "rsem-run-em")] + args)
-    th_r = rf.read_theta(os.path.join(dst, "stat", "s.theta"))
-    ofg_r = rf.read_ofg(os.path.join(dst, "temp", "s.ofg"))
-    for family in ("alignment", "read"):
-        r = subprocess.run([os.path.join(BIN, "rsem-run-em")] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                           env=dict(os.environ, RSEM_MODEL_KERNELS=family))
-        assert r.returncode == 0, r.stdout[-2000:]
-        th_a = rf.read_theta(os.path.join(dst, "stat", "s.theta"))
-        ofg_a = rf.read_ofg(os.path.join(dst, "temp", "s.ofg"))
-        assert [l for l in out_r.split("\n") if l.startswith("ROUND")][-1].split(",")[0] == [l for l in r.stdout.split("\n") if l.startswith("ROUND")][-1].split(",")[0]
-        assert np.allclose(th_r[0], th_a[0], rtol=1e-9, atol=1e-15)
-        assert np.array_equal(ofg_r[2], ofg_a[2]) and np.array_equal(ofg_r[3], ofg_a[3]) and np.allclose(ofg_r[4], ofg_a[4], rtol=1e-9, atol=0)
-
-
 def _bam_records(path):
     """Decompress a BAM (BGZF = concatenated gzip members) and split it into (header bytes, [record bytes])."""
     import gzip

@@ -15,7 +15,7 @@ from tools.synth_data import make_em_workload
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [1, 2, 3]  # CSR, SELL, LANE
+VARIANTS = [0, 3]  # AUTO (= LANE), LANE: the thread-per-read (1) and slice-at-a-time (2) kernels of rounds 1-2 were retired in round 6
 
 
 def capi():
@@ -180,9 +180,24 @@ def test_full_size_c2_properties():
     assert np.allclose(counts, oc, rtol=1e-9, atol=1e-7)
     out = ctx.run(wl["theta0"], wl["N0"], min_round=30, max_round=30)
     assert out["rounds"] == 30 and abs(out["theta"].sum() - 1.0) < 1e-12
-    ctx.set_option("kernel", 1)
-    out2 = ctx.run(wl["theta0"], wl["N0"], min_round=30, max_round=30)
-    assert np.allclose(out["theta"], out2["theta"], rtol=1e-9, atol=1e-18)
+    oth, orounds, _, _ = orc.em_run(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["N0"], wl["theta0"], min_round=30, max_round=30)
+    assert orounds == 30 and np.allclose(out["theta"], oth, rtol=1e-9, atol=1e-18)
+    ctx.close()
+
+
+def test_retired_kernel_variants_are_refused():
+    """The cross-check kernels of rounds 1-2 (thread per read over the CSR, a slice at a time) no longer ship: the option says so
+    instead of silently running something else."""
+    c = capi()
+    wl = make_em_workload("tiny", seed=1)
+    ctx = c.EmContext(wl["M"], wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
+    for v in (1, 2):
+        with pytest.raises(c.RsemHipError) as e:
+            ctx.set_option("kernel", v)
+        assert "retired" in str(e.value)
+    ctx.set_option("kernel", 3)
+    counts, *_ = ctx.step(wl["theta0"], wl["N0"])
+    assert counts.sum() > 0
     ctx.close()
 
 

@@ -145,11 +145,6 @@ def test_q32_edge_cases():
     oc = orc.em_estep(M, rp, sid, q, ncp, theta)
     oc[0] += 2.0
     assert np.allclose(counts, oc, rtol=1e-12, atol=0)
-    # the cross-check kernel reads doubles only
-    ctx.set_option("kernel", 2)
-    with pytest.raises(c.RsemHipError):
-        ctx.step(theta, 2.0)
-    ctx.set_option("kernel", 3)
     # new values: the formats are chosen again from them
     cp2 = cp.copy()
     cp2[3], cp2[4] = 1e-200, 3e-200

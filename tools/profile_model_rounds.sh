@@ -1,12 +1,12 @@
 #!/bin/bash
 # Per-kernel times of the model rounds (1-11) of rsem-run-em on a generated PairedEndQModel input, for the per-read model
-# kernels of the default path and the thread-per-alignment ones (RSEM_MODEL_KERNELS=alignment; MODES="default alignment read").   tools/profile_model_rounds.sh [n_reads] [M]
+# kernel (MODES="default lib:<tag>": variant builds beside it; the older kernel families left the library in round 6).   tools/profile_model_rounds.sh [n_reads] [M]
 N=${1:-5263157}; M=${2:-200000}; D=/tmp/pmr
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf $D; tools/bin/gen_temp $D $N $M 3 20250925 100 nosam 5-16 | tail -1
 tools/bin/temp_to_rsb $D/temp/s $D/stat/s 3 > /dev/null
 # a mode "lib:<tag>" runs the default kernels of the variant build rsem_amd/librsem_hip_<tag>.so (built like tools/build_variants.sh builds its own, with model.hip's object replaced)
-for mode in ${MODES:-default alignment}; do
+for mode in ${MODES:-default}; do
   export RSEM_HIP_NORMAL_EXIT=1
   unset LD_LIBRARY_PATH
   if [ $mode = default ]; then unset RSEM_MODEL_KERNELS
