@@ -40,6 +40,13 @@ int rsem_hip_device_count(int* n);
 int rsem_hip_device_info(int device, const char* key, int64_t* value);
 /* Initialise the HIP runtime and the device context (callable from a helper thread while inputs are parsed). */
 int rsem_hip_warmup(int device);
+/* ... and load the device code of the parts a program is going to use, so that the first real launch does not pay for it
+ * (the runtime loads a translation unit's code object at its first launch: tens of milliseconds each).  what = OR of: */
+#define RSEM_PRELOAD_EM 1
+#define RSEM_PRELOAD_MODEL 2
+#define RSEM_PRELOAD_GIBBS 4
+#define RSEM_PRELOAD_CI 8
+int rsem_hip_preload(int device, int what);
 /* ABI version of this header: bumped on any signature change. */
 int rsem_hip_abi_version(void);
 /* Measurement aid ("also measure a device STREAM-copy and report both"): streams `bytes` of HBM

@@ -542,3 +542,7 @@ extern "C" int rsem_ci_calculate_samples(int device, int32_t M, int32_t nSamples
     }
     return rc;
 }
+
+// rsem_hip_preload (status.hip): the first launch of a translation unit makes the runtime load its code object
+namespace { __global__ void k_preload_ci() {} }
+namespace rsem { void preload_ci() { hipLaunchKernelGGL(k_preload_ci, dim3(1), dim3(1), 0, nullptr); (void)hipGetLastError(); } }

@@ -19,6 +19,13 @@ constexpr int kWave = 64;            // gfx950 wavefront
 
 inline int ceil_div(uint64_t a, uint64_t b) { return (int)((a + b - 1) / b); }
 
+// one empty launch per translation unit = its code object is loaded (rsem_hip_preload, status.hip); defined in em.hip, model.hip,
+// gibbs.hip, ci.hip
+void preload_em();
+void preload_model();
+void preload_gibbs();
+void preload_ci();
+
 }  // namespace rsem
 
 #define RSEM_HIP_TRY(expr)                                                                      \

@@ -1964,3 +1964,7 @@ int em_values_changed(rsem_em_ctx* c) {
 
 
 }  // namespace rsem
+
+// rsem_hip_preload (status.hip): the first launch of a translation unit makes the runtime load its code object
+namespace { __global__ void k_preload_em() {} }
+namespace rsem { void preload_em() { hipLaunchKernelGGL(k_preload_em, dim3(1), dim3(1), 0, nullptr); (void)hipGetLastError(); } }

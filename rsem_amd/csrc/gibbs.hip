@@ -1058,3 +1058,7 @@ int rsem_gibbs_run(rsem_gibbs_ctx* c, int mode, uint32_t seed, int burnin, int n
 }
 
 }  // extern "C"
+
+// rsem_hip_preload (status.hip): the first launch of a translation unit makes the runtime load its code object
+namespace { __global__ void k_preload_gibbs() {} }
+namespace rsem { void preload_gibbs() { hipLaunchKernelGGL(k_preload_gibbs, dim3(1), dim3(1), 0, nullptr); (void)hipGetLastError(); } }

@@ -546,11 +546,34 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
     };
     std::vector<Piece> pieces;
     uint64_t h_total = 0;
+    // Where the pass's time goes (RSEM_HIP_TIMING: one line at the end).  Wall clock of the stages as the main thread sees them, and
+    // -- summed over the threads -- the seconds and bytes of the three things a thread does: inflate, encode / copy + weigh, deflate.
+    struct PassClock {
+        double wall[5] = {0, 0, 0, 0, 0};  // A (count / inflate), frame, B, C, waiting for the writer
+        std::atomic<uint64_t> ns_inflate{0}, ns_encode{0}, ns_deflate{0}, b_inflated{0}, b_encoded{0}, b_deflated{0};
+        double write_s = 0;
+        std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+        void lap(int i) { const auto n = std::chrono::steady_clock::now(); wall[i] += std::chrono::duration<double>(n - t).count(); t = n; }
+    } clk;
+    auto ns_since = [](std::chrono::steady_clock::time_point t0) {
+        return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    };
+    // The pieces' block runs are written in order by a thread of their own while the next super-chunk is counted, encoded and
+    // deflated (until round 6 the main thread wrote them between two super-chunks with every worker idle).
+    std::thread writer;
+    std::vector<Piece> writing;
     auto write_pieces = [&]() {
-        for (Piece& P : pieces) {
-            if (!P.out.empty() && fwrite(P.out.data(), 1, P.out.size(), fo) != P.out.size()) die("Cannot write %s!", outF.c_str());
-            std::vector<uint8_t>().swap(P.out);
-        }
+        if (writer.joinable()) writer.join();
+        clk.lap(4);
+        writing.swap(pieces);
+        writer = std::thread([&]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (Piece& P : writing) {
+                if (!P.out.empty() && fwrite(P.out.data(), 1, P.out.size(), fo) != P.out.size()) die("Cannot write %s!", outF.c_str());
+                std::vector<uint8_t>().swap(P.out);
+            }
+            clk.write_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
     };
     const int per_unit = paired ? 2 : 1;
 
@@ -592,6 +615,7 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
                 while (next_line(q, lim, b, e)) ++n;
                 pieces[i].records = n;
             });
+            clk.lap(0);
             if (paired) {  // no pair may straddle two pieces: a piece that would start with a second mate gives that line to its predecessor
                 const char* const base = in.body_begin();
                 uint64_t before = 0;
@@ -649,6 +673,7 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
                 pieces[i].units = u;
             });
             for (size_t i = 0; i < np; i++) { pieces[i].h0 = h_total; h_total += pieces[i].units; }
+            clk.lap(2);
             // (C) encode, weigh, deflate
             pool.run(np, [&](size_t i, int me) {
                 Piece& P = pieces[i];
@@ -657,6 +682,7 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
                 raw.reserve((P.e - P.b) / 2 + 64);
                 AlnRecord ra, rb;
                 uint64_t h = P.h0;
+                const auto t_enc = std::chrono::steady_clock::now();
                 while (next_line(q, lim, b, e)) {
                     in.encode_sam_line(b, e, ra);
                     if (paired) {
@@ -667,8 +693,14 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
                     finish_unit(raw, ra, &rb, h);
                 }
                 if (h != P.h0 + P.units) die("internal error: a piece of the alignment file weighed %llu alignments, counted %llu", (unsigned long long)(h - P.h0), (unsigned long long)P.units);
+                clk.ns_encode += ns_since(t_enc);
+                clk.b_encoded += raw.size();
+                const auto t_def = std::chrono::steady_clock::now();
                 defl[me].stream(raw.data(), raw.size(), P.out);
+                clk.ns_deflate += ns_since(t_def);
+                clk.b_deflated += P.out.size();
             });
+            clk.lap(3);
             write_pieces();
             cur = sc_end;
         }
@@ -710,6 +742,7 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
             pool.run(be - bi, [&](size_t k, int) {
                 const Blk& B = blks[bi + k];
                 if (!B.isize) return;
+                const auto t_inf = std::chrono::steady_clock::now();
                 z_stream zs;
                 memset(&zs, 0, sizeof(zs));
                 if (inflateInit2(&zs, -15) != Z_OK) die("zlib inflateInit2 failed");
@@ -718,7 +751,10 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
                 const int rc = inflate(&zs, Z_FINISH);
                 inflateEnd(&zs);
                 if (rc != Z_STREAM_END) die("input BAM: corrupt BGZF block");
+                clk.ns_inflate += ns_since(t_inf);
+                clk.b_inflated += B.isize;
             });
+            clk.lap(0);
             bi = be;
             // frame the records
             size_t pos = 0;
@@ -741,6 +777,7 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
             } else {
                 carry.assign(buf.begin() + carry_from, buf.end());
             }
+            clk.lap(1);
             const size_t units_all = usable / per_unit;
             const size_t np = std::max<size_t>(1, std::min(n_pieces_max, units_all / 64 + 1));
             pieces.assign(np, Piece());
@@ -759,23 +796,41 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
                 pieces[i].units = u;
             });
             for (size_t i = 0; i < np; i++) { pieces[i].h0 = h_total; h_total += pieces[i].units; }
+            clk.lap(2);
             // (C)
             pool.run(np, [&](size_t i, int me) {
                 Piece& P = pieces[i];
                 std::vector<uint8_t> raw;
                 AlnRecord ra, rb;
                 uint64_t h = P.h0;
+                const auto t_enc = std::chrono::steady_clock::now();
                 for (size_t r = P.b; r < P.e; r += per_unit) {
                     load(r, ra);
                     if (paired) load(r + 1, rb);
                     finish_unit(raw, ra, &rb, h);
                 }
+                clk.ns_encode += ns_since(t_enc);
+                clk.b_encoded += raw.size();
+                const auto t_def = std::chrono::steady_clock::now();
                 defl[me].stream(raw.data(), raw.size(), P.out);
+                clk.ns_deflate += ns_since(t_def);
+                clk.b_deflated += P.out.size();
             });
+            clk.lap(3);
             write_pieces();
         }
     }
+    if (writer.joinable()) writer.join();
+    clk.lap(4);
     if (h_total != n_hits) die("The alignment file holds %s alignments (%llu) than the .dat file (%llu)!", h_total < n_hits ? "fewer" : "more", (unsigned long long)h_total, (unsigned long long)n_hits);
+    if (getenv("RSEM_HIP_TIMING")) {
+        auto rate = [](uint64_t bytes, uint64_t ns) { return ns ? (double)bytes / 1e6 / ((double)ns * 1e-9) : 0.0; };
+        printf("[timing]   transcript.bam pass, %d threads: stages (wall) %s %.2f s | frame %.2f | count weights %.2f | %s + deflate %.2f | waiting for the writer %.2f"
+               " (writing itself %.2f s beside them); per thread: inflate %.0f MB/s (%.1f GB), %s %.0f MB/s (%.1f GB of records), deflate %.0f MB/s in -> %.1f GB out\n",
+               nthreads, in.is_bam() ? "inflate" : "count lines", clk.wall[0], clk.wall[1], clk.wall[2], in.is_bam() ? "copy + weigh" : "encode + weigh", clk.wall[3],
+               clk.wall[4], clk.write_s, rate(clk.b_inflated, clk.ns_inflate), (double)clk.b_inflated / 1e9, in.is_bam() ? "copy + weigh" : "encode + weigh",
+               rate(clk.b_encoded, clk.ns_encode), (double)clk.b_encoded / 1e9, rate(clk.b_encoded, clk.ns_deflate), (double)clk.b_deflated / 1e9);
+    }
     bgzf_write_eof(fo);
     if (fclose(fo) != 0) die("Cannot write %s!", outF.c_str());
 }

@@ -333,8 +333,8 @@ int main(int argc, char* argv[]) {
     }
     device = devs[0];
     if (read_type < 0 || read_type > 3) die("Unknown Read Type!");
-    // HIP runtime + device context come up (0.5 s) while the text inputs are parsed
-    std::thread warm([device]() { rsem_hip_warmup(device); });
+    // HIP runtime + device context come up (0.5 s) and the kernels' code objects are loaded while the text inputs are parsed
+    std::thread warm([device]() { rsem_hip_preload(device, RSEM_PRELOAD_EM | RSEM_PRELOAD_MODEL); });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } warm_joiner{warm};
 
     RefInfo refs = load_refs(refName + ".seq", true);

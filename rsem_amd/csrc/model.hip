@@ -77,9 +77,28 @@ __global__ __launch_bounds__(kBlk) void k_window_flags(DevData D, uint8_t* flags
     flags[j] = f;
 }
 
+// DevData::aw0 .. atot and bit 2 of the flags (model_block.hpp alignment_fields): one thread per alignment, once per model context
+// and seed length.  Low-quality reads are never walked (and their coordinates were not range-checked): zeros.
+template <bool kPE>
+__global__ __launch_bounds__(kBlk) void k_alignment_fields(DevData D, int seedLen, uint32_t* aw0, uint32_t* aw1, uint32_t* afull, uint32_t* atot, uint8_t* flags) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D.nnz) return;
+    AlnFields F{0u, 0u, 1u, 1u, false};
+    if (!D.lq[D.hit_row[j]]) F = alignment_fields<kPE>(D, seedLen, j);
+    aw0[j] = F.a0;
+    if (kPE) aw1[j] = F.a1;
+    afull[j] = F.full;
+    atot[j] = F.tot;
+    flags[j] = (uint8_t)((flags[j] & 3u) | (F.masked ? 4u : 0u));
+}
+
 // The model rounds' kernel (model_block.hpp): a group of 16 lanes per read, 512 threads per workgroup (two per CU: the
 // probability and count tables take 57 KB of LDS each), persistent grid, reads dealt to the waves four at a time.
 constexpr int kGroupBlk = 512;
+#ifndef RSEM_GROUP_CHUNK
+#define RSEM_GROUP_CHUNK 256
+#endif
+constexpr int kGroupChunk = RSEM_GROUP_CHUNK;  // rows per chunk (a multiple of the 32 rows a workgroup takes per step)
 // 4 waves per SIMD (<= 128 VGPRs, a few dwords of scratch in the variants with the update) instead of the 2-3 the
 // allocator would settle for: 14.1 against 17.1 ms per round at a fifth of configs[2] (profiles/r04b_call.log) -- the kernel
 // waits on dependent loads, and the fourth wave hides more of them than the spills cost.
@@ -111,9 +130,14 @@ __global__ __launch_bounds__(kGroupBlk) RSEM_GROUP_ATTR void k_model_group(DevDa
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const uint64_t waves_per_block = blockDim.x / 64, wave = (uint64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
-    model_group_rows<kQ, kPE, kUpdate>(D, T, theta, cp, ncp, A, kQ ? s_prob : T.prof, s_nprob, s_prof, s_noise, s_rspd, s_gld, wave * 4, n_waves * 4, lane, PO);
+    // chunks of kGroupChunk rows dealt to the workgroups round-robin; inside a chunk the workgroup's waves take 4 rows each per step
+    const uint64_t waves_per_block = blockDim.x / 64;
+    if (kGroupChunk > 0)
+        model_group_rows<kQ, kPE, kUpdate>(D, T, theta, cp, ncp, A, kQ ? s_prob : T.prof, s_nprob, s_prof, s_noise, s_rspd, s_gld, (uint64_t)(threadIdx.x >> 6) * 4,
+                                           waves_per_block * 4, lane, PO, (uint64_t)kGroupChunk, (uint64_t)blockIdx.x, (uint64_t)gridDim.x);
+    else  // (measurement builds, -DRSEM_GROUP_CHUNK=0: the grid-wide stride of rounds 4-5)
+        model_group_rows<kQ, kPE, kUpdate>(D, T, theta, cp, ncp, A, kQ ? s_prob : T.prof, s_nprob, s_prof, s_noise, s_rspd, s_gld,
+                                           ((uint64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6)) * 4, (uint64_t)gridDim.x * waves_per_block * 4, lane, PO);
     if (!kUpdate) return;
     __syncthreads();
     const int nprof = min(kProfCap, T.prof_rows * 25);
@@ -183,6 +207,9 @@ struct rsem_model_ctx {
     bool have_tables = false;
     int B_alloc = 0, gld_n = 0, mld_n = 0, prof_n = 0, noise_n = 0;
     std::vector<void*> owned;       // device allocations of the immutable data
+    uint32_t *d_aw0 = nullptr, *d_aw1 = nullptr, *d_afull = nullptr, *d_atot = nullptr;  // DevData::aw0 .. atot (owned)
+    uint8_t* d_flags = nullptr;     // DevData::same_prev, writable (bit 2 is set with the first tables: it needs the seed length)
+    int fields_seedLen = -1;        // the seed length aw0 .. atot / bit 2 were computed with (-1: not yet)
     double* d_theta = nullptr;                // the round's theta for the weights of k_model_group, [M+1]
     int n_cus = 0;
     // table buffers (re-uploaded every round)
@@ -216,8 +243,8 @@ int launch_group(rsem_model_ctx* c, const double* d_theta, const AccumPtrs* A, c
         RSEM_HIP_TRY(hipGetDeviceProperties(&p, c->v.device));
         c->n_cus = std::max(1, p.multiProcessorCount);
     }
-    const uint64_t quads = (c->D.N1 + 3) / 4;
-    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->n_cus * 2, (quads + kGroupBlk / 64 - 1) / (kGroupBlk / 64)));
+    const uint64_t chunks = kGroupChunk > 0 ? (c->D.N1 + kGroupChunk - 1) / kGroupChunk : (c->D.N1 + 31) / 32;
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->n_cus * 2, chunks));
     if (A)
         hipLaunchKernelGGL((k_model_group<kQ, kPE, true>), dim3(grid), dim3(kGroupBlk), 0, c->v.stream, c->D, c->T, d_theta, c->v.d_cp, c->v.d_ncp, *A, PO);
     else
@@ -267,6 +294,7 @@ int rsem_model_destroy(rsem_model_ctx* c) {
     (void)hipSetDevice(c->v.device);
     if (c->em && c->holds_view) rsem::em_view_release(c->em);
     for (void* p : c->owned) hipFree(p);
+    hipFree(c->d_aw0); hipFree(c->d_aw1); hipFree(c->d_afull); hipFree(c->d_atot);
     hipFree(c->t_rspd_pdf); hipFree(c->t_rspd_cdf); hipFree(c->t_gld_pdf); hipFree(c->t_gld_cdf); hipFree(c->t_mld_pdf);
     hipFree(c->t_mld_cdf); hipFree(c->t_prof); hipFree(c->t_noise); hipFree(c->t_mw);
     hipFree(c->a_prof); hipFree(c->a_noise); hipFree(c->a_rspd); hipFree(c->a_gld);
@@ -398,6 +426,19 @@ int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_da
     if (dmalloc(&fl, d->nnz) != hipSuccess) { rsem_model_destroy(c); return RSEM_ERR_NOMEM; }
     c->owned.push_back(fl);
     D.same_prev = fl;
+    c->d_flags = fl;
+    {   // the strand array is addressed with 32 bits per alignment (DevData::aw0 / aw1)
+        uint64_t strand_bytes = 0;
+        for (int sid = 1; sid <= d->M; sid++) strand_bytes += 2 * (((uint64_t)d->totLen[sid] + 7) / 8 * 8);
+        if (strand_bytes + 16 >= (1ull << 32)) {
+            rsem_model_destroy(c);
+            rsem::set_last_error("the transcript sequences take %llu bytes on both strands: the model context addresses them with 32 bits", (unsigned long long)strand_bytes);
+            return RSEM_ERR_INVALID;
+        }
+        if (dmalloc(&c->d_aw0, d->nnz) != hipSuccess || (pe && dmalloc(&c->d_aw1, d->nnz) != hipSuccess) || dmalloc(&c->d_afull, d->nnz) != hipSuccess ||
+            dmalloc(&c->d_atot, d->nnz) != hipSuccess) { rsem_model_destroy(c); return RSEM_ERR_NOMEM; }
+        D.aw0 = c->d_aw0; D.aw1 = c->d_aw1; D.afull = c->d_afull; D.atot = c->d_atot;
+    }
     if (d->nnz) {
         if (pe) hipLaunchKernelGGL(k_window_flags<true>, dim3(rsem::ceil_div(d->nnz, kBlk)), dim3(kBlk), 0, st, D, fl);
         else hipLaunchKernelGGL(k_window_flags<false>, dim3(rsem::ceil_div(d->nnz, kBlk)), dim3(kBlk), 0, st, D, fl);
@@ -447,6 +488,16 @@ int rsem_model_set_tables(rsem_model_ctx* c, const rsem_model_tables* t) {
     T.gld_lb = t->gld_lb; T.gld_ub = t->gld_ub; T.gld_pdf = c->t_gld_pdf; T.gld_cdf = c->t_gld_cdf;
     T.has_mld = t->has_mld; T.mld_lb = t->mld_lb; T.mld_ub = t->mld_ub; T.mld_pdf = c->t_mld_pdf; T.mld_cdf = c->t_mld_cdf;
     T.prof_rows = t->prof_rows; T.prof = c->t_prof; T.noise = c->t_noise; T.mw = c->t_mw;
+    if (c->fields_seedLen != t->seedLen) {  // (once per context in the programs: the seed length is a constant of the model)
+        if (c->D.nnz) {
+            const bool pe = c->D.model_type >= 2;
+            if (pe) hipLaunchKernelGGL(k_alignment_fields<true>, dim3(rsem::ceil_div(c->D.nnz, kBlk)), dim3(kBlk), 0, st, c->D, t->seedLen, c->d_aw0, c->d_aw1, c->d_afull, c->d_atot, c->d_flags);
+            else hipLaunchKernelGGL(k_alignment_fields<false>, dim3(rsem::ceil_div(c->D.nnz, kBlk)), dim3(kBlk), 0, st, c->D, t->seedLen, c->d_aw0, c->d_aw1, c->d_afull, c->d_atot, c->d_flags);
+            RSEM_HIP_TRY(hipGetLastError());
+            RSEM_HIP_TRY(hipStreamSynchronize(st));
+        }
+        c->fields_seedLen = t->seedLen;
+    }
     c->have_tables = true;
     return RSEM_OK;
 }
@@ -522,3 +573,7 @@ int rsem_model_get_values(rsem_model_ctx* c, double* conprb, double* ncp) {
 }
 
 }  // extern "C"
+
+// rsem_hip_preload (status.hip): the first launch of a translation unit makes the runtime load its code object
+namespace { __global__ void k_preload_model() {} }
+namespace rsem { void preload_model() { hipLaunchKernelGGL(k_preload_model, dim3(1), dim3(1), 0, nullptr); (void)hipGetLastError(); } }

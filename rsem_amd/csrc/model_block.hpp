@@ -70,8 +70,18 @@ struct DevData {
     const uint64_t* mask_off;
     const uint32_t* mask_words;
     // per alignment: bit 0 / bit 1 = the reference window of mate 1 / mate 2 holds the same bases as the window of the
-    // read's PREVIOUS alignment (computed once at create: the windows never change); 0 for a read's first alignment
+    // read's PREVIOUS alignment (computed once at create: the windows never change); 0 for a read's first alignment;
+    // bit 2 = the alignment's start position is masked (RefSeq::getMask at the seed / fragment position: alignment_fields)
     const uint8_t* same_prev;
+    // per alignment, computed once (alignment_fields): what getConPrb needs of the alignment's TRANSCRIPT -- lengths, the byte
+    // addresses of the mates' windows in the strand array.  Until round 6 the round kernel looked these up per alignment and round:
+    // six gathers into per-transcript tables (fullLen, totLen, soff x 2, mask_off -> mask_words) behind the alignment's own fields,
+    // a dependent round trip and -- a read's ~11 transcripts lying in ~11 different lines of each table -- most of the kernel's
+    // fetched bytes (counters: profiles/r06b_model_group_pmc.json).  Now 16 bytes per alignment streamed beside sid / pos.
+    const uint32_t* aw0;     // [nnz] window of mate 1 (byte address into refw)
+    const uint32_t* aw1;     // [nnz] window of mate 2 (paired-end only)
+    const uint32_t* afull;   // [nnz] fullLen of the transcript
+    const uint32_t* atot;    // [nnz] totLen of the transcript
 };
 
 // Where the sliced layout of the EM context (sell_layout.hpp) keeps the values of a read: with this the round kernel writes
@@ -127,6 +137,25 @@ RSEM_DEVFN double rspd_adj(const DevTables& T, int fpos, int effL, int fullLen) 
 RSEM_DEVFN uint64_t funnel8(uint64_t w0, uint64_t w1, int sh) { return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0; }
 RSEM_DEVFN bool ref_mask(const DevData& D, int sid, int p) {  // RefSeq.h:89-92
     return (D.mask_words[D.mask_off[sid] + (p >> 5)] >> (p & 31)) & 1u;
+}
+// The per-alignment fields above, from the per-transcript tables (alignment j of a read that is not low-quality; seedLen: the
+// model's, SingleQModel.h:108-110).  `masked` = what getConPrb asks RefSeq::getMask for this alignment (SingleModel.h:104-106,
+// PairedEndModel.h:100-102); the position is range-checked here, the kernel's own test `pos >= fullLen` comes first there too.
+struct AlnFields { uint32_t a0, a1, full, tot; bool masked; };
+template <bool kPE>
+RSEM_DEVFN AlnFields alignment_fields(const DevData& D, int seedLen, uint64_t j) {
+    AlnFields F;
+    const int s = D.sid_signed[j];
+    const int sid = s < 0 ? -s : s, dir = s < 0 ? 1 : 0;
+    const int pos = D.pos[j], ins = kPE ? D.insertL[j] : 0;
+    const int full = D.fullLen[sid], tot = D.totLen[sid];
+    F.full = (uint32_t)full;
+    F.tot = (uint32_t)tot;
+    F.a0 = (uint32_t)(D.soff[2 * sid + dir] + (uint64_t)pos);
+    F.a1 = kPE ? (uint32_t)(D.soff[2 * sid + (dir ^ 1)] + (uint64_t)(tot - pos - ins)) : 0u;
+    const int p = kPE ? (dir == 0 ? pos : tot - pos - ins) : (dir == 0 ? pos : tot - pos - seedLen);
+    F.masked = (p >= 0 && p < full) ? ref_mask(D, sid, p) : false;
+    return F;
 }
 RSEM_DEVFN void add_tbl(double* lds, int cap, double* glob, int idx, double v) {
     if (idx < cap) RSEM_LDS_ADD(&lds[idx], v);
@@ -280,7 +309,7 @@ RSEM_DEVFN double alignment_prob(const DevData& D, const DevTables& T, const Chu
     if (!kPE) {
         const int fpos = dir == 0 ? pos : totLen - pos - len1;
         const int seedPos = dir == 0 ? pos : totLen - pos - T.seedLen;
-        if (!(seedPos >= fullLen || ref_mask(D, sid, seedPos))) {
+        if (!(seedPos >= fullLen || (R.flags & 4u))) {
             double value;
             if (T.has_mld) {  // SingleQModel.h:127-136
                 const int minL = len1 > T.gld_lb + 1 ? len1 : T.gld_lb + 1, maxL = totLen - pos < T.gld_ub ? totLen - pos : T.gld_ub;
@@ -304,7 +333,7 @@ RSEM_DEVFN double alignment_prob(const DevData& D, const DevTables& T, const Chu
         const int insertLen = R.insertL;
         const int fpos = dir == 0 ? pos : totLen - pos - insertLen;
         const int effL = fullLen < totLen - insertLen + 1 ? fullLen : totLen - insertLen + 1;
-        if (!(fpos >= fullLen || ref_mask(D, sid, fpos))) {
+        if (!(fpos >= fullLen || (R.flags & 4u))) {
             const double ori = dir == 0 ? T.probF : 1.0 - T.probF;
             prob = ori * ld_adj(T.gld_pdf, T.gld_cdf, T.gld_lb, T.gld_ub, insertLen, totLen) * rspd_adj(T, fpos, effL, fullLen);
             prob *= ld_adj(T.mld_pdf, T.mld_cdf, T.mld_lb, T.mld_ub, len1, insertLen) * pp1;
@@ -317,13 +346,17 @@ RSEM_DEVFN double alignment_prob(const DevData& D, const DevTables& T, const Chu
 }
 
 // The rows [row0, N1) in steps of row_stride, this wave taking rows row0 + (lane >> 4) of every step (4 reads per wave).
+// With chunk_rows: the rows are cut into chunks of that many; this WORKGROUP takes chunks chunk0, chunk0 + chunk_stride, ... and walks
+// each one with row0 / row_stride counted inside the chunk -- its waves' successive steps then touch neighbouring rows, so the halves
+// of a 128-byte line that one step leaves unused are used by the next (same L1, same L2) instead of by another workgroup on another
+// XCD (the grid-wide stride of rounds 4-5 fetched 4.2 x the bytes the kernel uses: profiles/r06b_model_group_pmc.json).
 // prob / nprob: the profile / noise probability tables (LDS copies where they fit); s_*: the LDS count tables of the update.
 // theta (kUpdate): the round's theta, for the posterior weights.  cp / ncp: the CSR values, written for every read.
 template <bool kQ, bool kPE, bool kUpdate>
 RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const double* __restrict__ theta, double* __restrict__ cp,
                                  double* __restrict__ ncp, const AccumPtrs& A, const double* prob, const double* nprob, double* s_prof,
                                  double* s_noise, double* s_rspd, double* s_gld, uint64_t row0, uint64_t row_stride, int lane,
-                                 const PlaneOut& PO) {
+                                 const PlaneOut& PO, uint64_t chunk_rows = 0, uint64_t chunk0 = 0, uint64_t chunk_stride = 1) {
     const int g = lane & (kGrp - 1);
     const int g0 = lane & ~(kGrp - 1);  // first lane of my group
     constexpr int kMates = kPE ? 2 : 1;
@@ -352,7 +385,9 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
         H.rank = PO.rank ? PO.rank[rowc] : 0u;
         return H;
     };
-    for (uint64_t rbase = row0; rbase < D.N1; rbase += row_stride) {  // (wave-uniform)
+    const uint64_t n_chunks = chunk_rows ? (D.N1 + chunk_rows - 1) / chunk_rows : 1;
+    for (uint64_t ch = chunk_rows ? chunk0 : 0; ch < n_chunks; ch += chunk_stride)  // (workgroup-uniform)
+    for (uint64_t rbase = ch * chunk_rows + row0, rend = chunk_rows ? (ch + 1) * chunk_rows : D.N1; rbase < rend && rbase < D.N1; rbase += row_stride) {  // (wave-uniform)
         const uint64_t row = rbase + (uint64_t)(lane >> 4);
         const bool valid = row < D.N1;
         const RowHdr H = load_hdr(row);
@@ -407,23 +442,23 @@ RSEM_DEVFN void model_group_rows(const DevData& D, const DevTables& T, const dou
             const int idx = c * kGrp + g;
             const bool in = valid && idx < L;
             R.has = active && idx < L;
-            // (two round trips: the alignment's own fields, then what hangs on its transcript id -- every load issued for an
-            // alignment that exists, the read's first or the file's first for the lanes without one, and masked afterwards)
+            // (ONE round trip: the alignment's own fields, among them what getConPrb needs of its transcript, DevData::aw0 .. atot --
+            // every load issued for an alignment that exists, the read's first or the file's first for the lanes without one, and
+            // masked afterwards; what still hangs on the transcript id -- mw, theta -- is two 1.6 MB tables)
             const uint64_t j = fr + (uint64_t)(in ? idx : 0);
             const int s_v = D.sid_signed[j], pos_v = D.pos[j], ins_v = kPE ? D.insertL[j] : 0;
             const unsigned fl_v = D.same_prev[j];
+            const uint32_t a0_v = D.aw0[j], a1_v = kPE ? D.aw1[j] : 0u, full_v = D.afull[j], tot_v = D.atot[j];
             const int s = R.has ? s_v : 1;
             R.sid = s < 0 ? -s : s;
             R.dir = s < 0 ? 1 : 0;
             R.pos = R.has ? pos_v : 0;
             R.insertL = R.has ? ins_v : 0;
             R.flags = R.has ? fl_v : 0u;
-            const int full_v = D.fullLen[R.sid], tot_v = D.totLen[R.sid];
-            const uint64_t so0 = D.soff[2 * R.sid + R.dir], so1 = kPE ? D.soff[2 * R.sid + (R.dir ^ 1)] : 0;
-            R.fullLen = R.has ? full_v : 1;
-            R.totLen = R.has ? tot_v : 1;
-            R.a[0] = R.has ? so0 + (uint64_t)R.pos : 0;
-            if (kPE) R.a[kMates - 1] = R.has ? so1 + (uint64_t)(R.totLen - R.pos - R.insertL) : 0;
+            R.fullLen = R.has ? (int)full_v : 1;
+            R.totLen = R.has ? (int)tot_v : 1;
+            R.a[0] = R.has ? (uint64_t)a0_v : 0;
+            if (kPE) R.a[kMates - 1] = R.has ? (uint64_t)a1_v : 0;
             R.cp = 0.0;
             if (in && !R.has) { cp[j] = 0.0; plane_put(idx, 0.0); }  // low-quality read: every alignment gets probability 0 (SingleQModel.h:102)
         };

@@ -286,11 +286,14 @@ __global__ void k_fill_sell(const Shape* __restrict__ shapes, int n_shapes, uint
                             const uint32_t* __restrict__ order, const uint64_t* __restrict__ row_ptr,
                             const int32_t* __restrict__ sid, const double* __restrict__ cp,
                             const double* __restrict__ ncp, int32_t* ssid, unsigned char* sval, double* sncp,
-                            int16_t* sexp, int* err, const uint32_t* __restrict__ xanchor, uint32_t x_row_base, int reach) {
+                            int16_t* sexp, int* err, const uint32_t* __restrict__ xanchor, uint32_t x_row_base, int reach,
+                            const uint32_t* __restrict__ xreach = nullptr /* [n_x_rows] a window of its own per split row (sell_refine_split_windows) */) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_sell_rows) return;
     const Shape S = shapes[find_shape_by_row(shapes, n_shapes, p)];
-    sell_fill_row<kIds>(S, T, p, order, row_ptr, sid, cp, ncp, ssid, sval, sncp, sexp, err, S.fmt == kFmtF64X ? xanchor[p - x_row_base] : 0u, reach);
+    const bool x = S.fmt == kFmtF64X;
+    sell_fill_row<kIds>(S, T, p, order, row_ptr, sid, cp, ncp, ssid, sval, sncp, sexp, err, x ? xanchor[p - x_row_base] : 0u,
+                        (x && xreach) ? (int)xreach[p - x_row_base] : reach);
 }
 
 // per slice: bit l set when lane l's read has a different sid tuple than the same lane's read in
@@ -408,9 +411,10 @@ __global__ void k_x_anchors(uint32_t n_x, uint32_t x_row_base, const uint64_t* _
 __global__ void k_x_far(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_x, uint32_t x_row_base, uint32_t x_slot_base,
                         const uint32_t* __restrict__ order, const uint64_t* __restrict__ row_ptr, const int32_t* __restrict__ sid,
                         const uint32_t* __restrict__ xanchor, uint64_t* nfar, const uint64_t* __restrict__ far_ptr, int32_t* far_sid, uint64_t* far_src,
-                        uint32_t* far_eslot, int reach) {
+                        uint32_t* far_eslot, int reach, const uint32_t* __restrict__ xreach = nullptr) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n_x) return;
+    if (xreach) reach = (int)xreach[x];
     const uint32_t p = x_row_base + x, orig = order[p], anchor = xanchor[x];
     const uint64_t fr = row_ptr[orig], to = row_ptr[orig + 1];
     const Shape S = shapes[find_shape_by_row(shapes, n_shapes, p)];
@@ -481,6 +485,7 @@ struct SellLayout {
     uint32_t x_slot_base = 0;                // their row slots start here (extra / inv arrays are indexed by slot - x_slot_base)
     uint64_t n_far = 0;                      // alignments of split rows outside their window
     uint32_t* d_xanchor = nullptr;           // [n_x_rows]
+    uint32_t* d_xreach = nullptr;            // [n_x_rows] ids [anchor, anchor + reach) stay in the row (nullptr: kLayoutWindow for every row)
     uint32_t n_x_slots = 0;                  // n_slots - x_slot_base
     uint64_t* d_far_ptr = nullptr;           // [n_x_slots + 1] far entries of the split row in slot x_slot_base + xs, in file order
     int32_t* d_far_sid = nullptr;            // [n_far]
@@ -498,7 +503,7 @@ struct SellLayout {
 
 inline void sell_free(SellLayout& L) {
     hipFree(L.d_order); hipFree(L.d_shapes); hipFree(L.d_ssid); hipFree(L.d_masks); hipFree(L.d_slice_minsid); hipFree(L.d_slice_maxsid);
-    hipFree(L.d_xanchor); hipFree(L.d_far_ptr); hipFree(L.d_far_sid); hipFree(L.d_far_src); hipFree(L.d_far_cp);
+    hipFree(L.d_xanchor); hipFree(L.d_xreach); hipFree(L.d_far_ptr); hipFree(L.d_far_sid); hipFree(L.d_far_src); hipFree(L.d_far_cp);
     hipFree(L.d_csc_sid); hipFree(L.d_csc_src); hipFree(L.d_csc_slot); hipFree(L.d_csc_cp);
     L = SellLayout();
 }
@@ -515,7 +520,8 @@ inline int sell_fill_values(const SellLayout& L, hipStream_t st, const uint64_t*
     if (L.n_sell_rows) {
         hipLaunchKernelGGL(k_fill_sell<false>, dim3(rsem::ceil_div(L.n_sell_rows, kBlock)), dim3(kBlock), 0, st,
                            L.d_shapes, L.n_shapes, L.T, L.n_sell_rows, L.d_order, d_row_ptr, d_sid,
-                           d_cp, d_ncp, (int32_t*)nullptr, (unsigned char*)d_sval, d_sncp, d_sexp, d_err, (const uint32_t*)L.d_xanchor, L.x_row_base, kLayoutWindow);
+                           d_cp, d_ncp, (int32_t*)nullptr, (unsigned char*)d_sval, d_sncp, d_sexp, d_err, (const uint32_t*)L.d_xanchor, L.x_row_base, kLayoutWindow,
+                           (const uint32_t*)L.d_xreach);
         RSEM_HIP_TRY(hipGetLastError());
     }
     if (L.n_far) {
@@ -528,14 +534,23 @@ inline int sell_fill_values(const SellLayout& L, hipStream_t st, const uint64_t*
 
 // The far entries of the split rows, in row order and in column (transcript id) order.  Called by sell_build once the shape
 // table and the sorted order stand.
+// d_keys_sorted == nullptr: once more for a layout whose anchors stand (L.d_xanchor) -- the rows' windows have changed (L.d_xreach).
 inline int sell_build_far(SellLayout& L, hipStream_t st, const uint64_t* d_row_ptr, const int32_t* d_sid, const uint64_t* d_keys_sorted) {
     const uint32_t nx = L.n_x_rows;
     if (!nx) return RSEM_OK;
     const uint32_t nxs = L.n_slots - L.x_slot_base;
     L.n_x_slots = nxs;
-    RSEM_HIP_TRY(dmalloc(&L.d_xanchor, nx));
+    if (d_keys_sorted) {
+        RSEM_HIP_TRY(dmalloc(&L.d_xanchor, nx));
+        hipLaunchKernelGGL(k_x_anchors, dim3(rsem::ceil_div(nx, kBlock)), dim3(kBlock), 0, st, nx, L.x_row_base, d_keys_sorted, L.d_xanchor);
+    } else {
+        hipFree(L.d_far_ptr); hipFree(L.d_far_sid); hipFree(L.d_far_src); hipFree(L.d_far_cp);
+        hipFree(L.d_csc_sid); hipFree(L.d_csc_src); hipFree(L.d_csc_slot); hipFree(L.d_csc_cp);
+        L.d_far_ptr = nullptr; L.d_far_sid = nullptr; L.d_far_src = nullptr; L.d_far_cp = nullptr;
+        L.d_csc_sid = nullptr; L.d_csc_src = nullptr; L.d_csc_slot = nullptr; L.d_csc_cp = nullptr;
+        L.n_far = 0;
+    }
     RSEM_HIP_TRY(dmalloc(&L.d_far_ptr, (size_t)nxs + 1));
-    hipLaunchKernelGGL(k_x_anchors, dim3(rsem::ceil_div(nx, kBlock)), dim3(kBlock), 0, st, nx, L.x_row_base, d_keys_sorted, L.d_xanchor);
     uint64_t* d_n = nullptr;
     void* d_tmp = nullptr;
     uint64_t *d_perm_in = nullptr, *d_perm = nullptr, *d_k_in = nullptr, *d_k_out = nullptr;
@@ -546,7 +561,7 @@ inline int sell_build_far(SellLayout& L, hipStream_t st, const uint64_t* d_row_p
     if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
     hipLaunchKernelGGL(k_x_far, dim3(rsem::ceil_div(nx, kBlock)), dim3(kBlock), 0, st, (const Shape*)L.d_shapes, L.n_shapes, L.T, nx, L.x_row_base, L.x_slot_base,
                        (const uint32_t*)L.d_order, d_row_ptr, d_sid, (const uint32_t*)L.d_xanchor, d_n, (const uint64_t*)nullptr, (int32_t*)nullptr,
-                       (uint64_t*)nullptr, (uint32_t*)nullptr, kLayoutWindow);
+                       (uint64_t*)nullptr, (uint32_t*)nullptr, kLayoutWindow, (const uint32_t*)L.d_xreach);
     size_t tb = 0;
     e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_n, L.d_far_ptr, (size_t)nxs + 1, st);
     if (e == hipSuccess) e = hipMalloc(&d_tmp, tb ? tb : 1);
@@ -569,7 +584,7 @@ inline int sell_build_far(SellLayout& L, hipStream_t st, const uint64_t* d_row_p
     if (e != hipSuccess) { cleanup(); RSEM_HIP_TRY(e); }
     hipLaunchKernelGGL(k_x_far, dim3(rsem::ceil_div(nx, kBlock)), dim3(kBlock), 0, st, (const Shape*)L.d_shapes, L.n_shapes, L.T, nx, L.x_row_base, L.x_slot_base,
                        (const uint32_t*)L.d_order, d_row_ptr, d_sid, (const uint32_t*)L.d_xanchor, (uint64_t*)nullptr, (const uint64_t*)L.d_far_ptr,
-                       L.d_far_sid, L.d_far_src, d_eslot, kLayoutWindow);
+                       L.d_far_sid, L.d_far_src, d_eslot, kLayoutWindow, (const uint32_t*)L.d_xreach);
     if (nf) {  // column order: a stable sort of the entries by (block of row slots, transcript id)
         hipFree(d_tmp); d_tmp = nullptr;
         e = dmalloc(&d_perm_in, nf);
@@ -855,6 +870,70 @@ inline int sell_flag_far_units(const SellLayout& L, std::vector<Unit>& units, Un
     return RSEM_OK;
 }
 
+// ---- split rows: every row's window = its UNIT's window ----------------------------------------------------------------------------------
+// A split row keeps the ids inside [anchor, anchor + kLayoutWindow) -- but the unit it lands in stages [base, base + span) only, as wide
+// as its reads' own genes need, and ONE id beyond that sends the whole unit through the loop with the global gather and atomics (kFar:
+// every wait of that instantiation is a wait for everything, estep_block.hpp).  With a few reads in a hundred carrying a stray id
+// somewhere in the 2048 above their anchor that is every unit of split rows (configs[2] with 10 % cross-gene reads: 390 of 390,
+// profiles/r06b_xrows_probe.log).  So, once the units are cut: a split row's window ends where its unit's does -- reach[x] = base +
+// span - anchor[x] -- the ids beyond it join the row's far entries, the planes of the split rows are filled again, masks, far arrays
+// and flags follow.  One workgroup per unit.
+__global__ __launch_bounds__(256) void k_x_reach(const Unit* __restrict__ units, uint32_t T, const uint32_t* __restrict__ xanchor, uint32_t x_row_base, uint32_t* xreach) {
+    const Unit U = units[blockIdx.x];
+    const Shape& S = U.S;
+    if (S.fmt != kFmtF64X) return;
+    const uint32_t R = shape_R(S);
+    for (uint32_t i = threadIdx.x; i < U.n_slices * R; i += blockDim.x) {
+        uint32_t q;
+        if (!slot_to_row(S, T, U.slice_begin + i / R, i % R, q)) continue;
+        const uint32_t x = S.row_base + q - x_row_base;
+        const long long top = (long long)U.base + U.span;  // (anchor >= base: the unit's base is the smallest anchor of its slices)
+        const long long r = top - (long long)xanchor[x];
+        xreach[x] = (uint32_t)(r < 1 ? 1 : (r > kLayoutWindow ? kLayoutWindow : r));
+    }
+}
+
+inline int sell_masks(SellLayout& L, hipStream_t st) {
+    if (!L.n_slices) return RSEM_OK;
+    hipLaunchKernelGGL(k_slice_masks, dim3(rsem::ceil_div(L.n_slices, kBlock / 64)), dim3(kBlock), 0, st, L.d_shapes, L.n_shapes, L.T, L.n_slices, L.d_ssid, L.d_masks);
+    RSEM_HIP_TRY(hipGetLastError());
+    unsigned long long* d_cnt = nullptr;
+    RSEM_HIP_TRY(dmalloc(&d_cnt, 1));
+    hipError_t e = hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_count_sid_planes, dim3(rsem::ceil_div(L.n_slices, kBlock)), dim3(kBlock), 0, st, L.d_shapes, L.n_shapes, L.n_slices,
+                           (const unsigned long long*)L.d_masks, d_cnt);
+        e = hipGetLastError();
+    }
+    unsigned long long h_cnt = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_cnt);
+    RSEM_HIP_TRY(e);
+    L.n_sid_planes_loaded = h_cnt;
+    return RSEM_OK;
+}
+
+inline int sell_refine_split_windows(SellLayout& L, hipStream_t st, const uint64_t* d_row_ptr, const int32_t* d_sid, std::vector<Unit>& units, Unit* d_units) {
+    if (!L.n_x_rows || units.empty()) return RSEM_OK;
+    size_t n_far_x = 0;
+    for (const Unit& u : units) n_far_x += (u.S.fmt == kFmtF64X && u.pad[0] != 0) ? 1 : 0;
+    if (!n_far_x) return RSEM_OK;
+    RSEM_HIP_TRY(dmalloc(&L.d_xreach, L.n_x_rows));
+    hipLaunchKernelGGL(k_x_reach, dim3((unsigned)units.size()), dim3(256), 0, st, (const Unit*)d_units, L.T, (const uint32_t*)L.d_xanchor, L.x_row_base, L.d_xreach);
+    RSEM_HIP_TRY(hipGetLastError());
+    // the id planes once more (the split rows' entries move up where an id left; everything else is written as before)
+    RSEM_HIP_TRY(hipMemsetAsync(L.d_ssid, 0, sizeof(int32_t) * L.n_planes * 64, st));
+    hipLaunchKernelGGL(k_fill_sell<true>, dim3(rsem::ceil_div(L.n_sell_rows, kBlock)), dim3(kBlock), 0, st, L.d_shapes, L.n_shapes, L.T, L.n_sell_rows, L.d_order,
+                       d_row_ptr, d_sid, (const double*)nullptr, (const double*)nullptr, L.d_ssid, (unsigned char*)nullptr, (double*)nullptr, (int16_t*)nullptr,
+                       (int*)nullptr, (const uint32_t*)L.d_xanchor, L.x_row_base, kLayoutWindow, (const uint32_t*)L.d_xreach);
+    RSEM_HIP_TRY(hipGetLastError());
+    int rc = sell_masks(L, st);
+    if (rc == RSEM_OK) rc = sell_build_far(L, st, d_row_ptr, d_sid, nullptr);
+    if (rc == RSEM_OK) rc = sell_flag_far_units(L, units, d_units, st);
+    return rc;
+}
+
 // The reads of the units that are NOT made of far-reaching reads but still have an id outside the unit's window -- a read
 // whose foreign id happens to lie within a window's width of its anchor (so the sort key kept it among the compact reads),
 // while the unit's window, as wide as its reads' ids need, ends before it.  A handful per unit are enough to send the
@@ -931,6 +1010,8 @@ inline int sell_build_refined(SellLayout& L, hipStream_t st, uint64_t N1, int32_
         sell_free(L);       // second pass with the marks
     }
     (void)hipFree(d_also);
+    if (L.n_x_rows && !(getenv("RSEM_HIP_X_REFINE") && atoi(getenv("RSEM_HIP_X_REFINE")) == 0))  // (measurement knob: 0 = the rows keep their own windows)
+        return sell_refine_split_windows(L, st, d_row_ptr, d_sid, units, *d_units);
     return RSEM_OK;
 }
 

@@ -97,6 +97,17 @@ int rsem_hip_warmup(int device) {
     return RSEM_OK;
 }
 
+int rsem_hip_preload(int device, int what) {
+    int rc = rsem_hip_warmup(device);
+    if (rc != RSEM_OK) return rc;
+    if (what & RSEM_PRELOAD_EM) rsem::preload_em();
+    if (what & RSEM_PRELOAD_MODEL) rsem::preload_model();
+    if (what & RSEM_PRELOAD_GIBBS) rsem::preload_gibbs();
+    if (what & RSEM_PRELOAD_CI) rsem::preload_ci();
+    RSEM_HIP_TRY(hipDeviceSynchronize());
+    return RSEM_OK;
+}
+
 int rsem_hip_stream_probe(int device, uint64_t bytes, int reps, double* read_GBps, double* copy_GBps) {
     RSEM_REQUIRE(read_GBps && copy_GBps && bytes >= (1u << 20) && reps >= 1, "stream probe: bad arguments");
     RSEM_HIP_TRY(hipSetDevice(device));

@@ -47,9 +47,11 @@ static void lane_body(Job* J, int tid) {
     }
     RSEM_SYNC();
     const int lane = tid & 63;
-    const uint64_t wave = (uint64_t)J->block * 4 + (uint64_t)(tid >> 6), n_waves = (uint64_t)J->n_blocks * 4;
+    // the mapping of k_model_group (model.hip): chunks of rows dealt to the workgroups round-robin, a workgroup's waves taking 4 rows
+    // each per step inside a chunk (chunks of 48 rows here -- three steps of this 4-wave workgroup -- so that the data sets of the
+    // tests hold several chunks per workgroup and a last, shorter one)
     model_group_rows<kQ, kPE, kUpdate>(J->D, J->T, J->theta, J->cp, J->ncp, J->A, kQ ? J->s_prob : J->T.prof, J->s_nprob, J->s_prof, J->s_noise,
-                                       J->s_rspd, J->s_gld, wave * 4, n_waves * 4, lane, J->PO);
+                                       J->s_rspd, J->s_gld, (uint64_t)(tid >> 6) * 4, 16, lane, J->PO, 48, (uint64_t)J->block, (uint64_t)J->n_blocks);
     if (!kUpdate) return;
     RSEM_SYNC();
     const int nprof = std::min(kQ ? 2500 : kProfLds, J->T.prof_rows * 25);
@@ -232,6 +234,16 @@ int main(int argc, char** argv) {
     for (int m = 0; m < (pe ? 2 : 1); m++) { D.roff8[m] = roff8[m].data(); D.rlen[m] = rlen[m].data(); D.rseq_w[m] = seqw[m].data(); D.rqual_w[m] = qualw[m].data(); }
     D.lq = lq.data(); D.soff = soff.data(); D.refw = (const uint64_t*)strands.data(); D.fullLen = fullLen.data(); D.totLen = totLen.data();
     D.mask_off = mask_off.data(); D.mask_words = mask_words.data(); D.same_prev = same_prev.data();
+    // DevData::aw0 .. atot and bit 2 of the flags, with the product's own function (k_alignment_fields of model.hip)
+    std::vector<uint32_t> aw0(nnz, 0), aw1(nnz, 0), afull(nnz, 1), atot(nnz, 1);
+    for (uint64_t i = 0; i < N1; i++)
+        for (uint64_t j = row_ptr[i]; j < row_ptr[i + 1]; j++) {
+            if (lq[i]) continue;
+            const AlnFields F = pe ? alignment_fields<true>(D, T.seedLen, j) : alignment_fields<false>(D, T.seedLen, j);
+            aw0[j] = F.a0; aw1[j] = F.a1; afull[j] = F.full; atot[j] = F.tot;
+            if (F.masked) same_prev[j] |= 4;
+        }
+    D.aw0 = aw0.data(); D.aw1 = aw1.data(); D.afull = afull.data(); D.atot = atot.data();
 
     // ---- restatement ------------------------------------------------------------------------------------------------------
     std::vector<double> rcp(nnz, 0.0), rncp(N1, 0.0);
@@ -245,6 +257,10 @@ int main(int argc, char** argv) {
             const int s = sid_signed[j];
             R.has = true; R.sid = s < 0 ? -s : s; R.dir = s < 0 ? 1 : 0; R.pos = pos[j]; R.insertL = insertL[j];
             R.fullLen = fullLen[R.sid]; R.totLen = totLen[R.sid];
+            {   // RefSeq::getMask at the seed / fragment start (SingleModel.h:104-106, PairedEndModel.h:100-102), stated on its own
+                const int p = pe ? (R.dir == 0 ? R.pos : R.totLen - R.pos - R.insertL) : (R.dir == 0 ? R.pos : R.totLen - R.pos - T.seedLen);
+                R.flags = (p >= 0 && p < R.fullLen && ((mask_words[mask_off[R.sid] + (p >> 5)] >> (p & 31)) & 1u)) ? 4u : 0u;
+            }
             const double p1 = seq_profile_prob(q, prof.data(), rseq[0][i].data(), rqual[0][i].data(), len1, window(j, 0, len1));
             const double p2 = pe ? seq_profile_prob(q, prof.data(), rseq[1][i].data(), rqual[1][i].data(), len2, window(j, 1, len2)) : 1.0;
             rcp[j] = pe ? alignment_prob<true>(D, T, R, len1, len2, p1, p2) : alignment_prob<false>(D, T, R, len1, len2, p1, p2);
@@ -366,8 +382,8 @@ int main(int argc, char** argv) {
     for (uint64_t i = 0; i < N1; i++) {
         if (row_ptr[i + 1] - row_ptr[i] > 16) ++long_rows;
         for (uint64_t j = row_ptr[i]; j < row_ptr[i + 1]; j++) {
-            if (same_prev[j]) ++shared;
-            if (same_prev[j] && (j - row_ptr[i]) % 16 == 0) ++contd;
+            if (same_prev[j] & 3) ++shared;
+            if ((same_prev[j] & 3) && (j - row_ptr[i]) % 16 == 0) ++contd;
         }
     }
     printf("reads %llu alignments %llu, reads with > 16 alignments %d, alignments sharing a window with their predecessor %d, of them first of a chunk %d\n",

@@ -34,7 +34,6 @@ TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
 TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
 TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
-TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum
 GROUPS
 python - $out $i <<'PY'
 import csv, glob, json, sys, collections
