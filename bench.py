@@ -153,12 +153,48 @@ def gibbs_reference_leg(root, rt, n1, pin_cpus, limit_s=150.0):
     same = [os.path.exists(imd + ".countvectors%d" % k) and filecmp.cmp(imd + ".countvectors%d" % k, os.path.join(tref, "s.countvectors%d" % k), shallow=False)
             for k in range(P)]
     rounds = g["burnin"] + 1 + (g["nsamples"] // P - 1) * g["gap"]
+    ci = None
+    try:  # rsem-calculate-credibility-intervals on those count vectors: the reference (calcCI.cpp:216-284) beside the drop-in
+        ref_ci = os.path.join(ROOT, "oracle", "_ref", "rsem-calculate-credibility-intervals")
+        new_ci = os.path.join(ROOT, "rsem_amd", "bin", "rsem-calculate-credibility-intervals")
+        if all(same) and os.path.exists(ref_ci) and os.path.exists(new_ci):
+            ci_args = ["0.95", str(g["nsamples"]), "50", "1024", "-p", str(P), "--seed", "7"]
+            keep = {f: open(imd + "." + f).read() for f in ("iso_res", "gene_res")}  # (the programs append their rows to these files)
+
+            def restore(prefix):
+                for f, text in keep.items():
+                    open(prefix + "." + f, "w").write(text)
+
+            def ci_rows(prefix):
+                return [l for l in open(prefix + ".iso_res").read().strip().split("\n")[-6:]]
+            restore(os.path.join(tref, "s"))
+            t0 = time.perf_counter()
+            rc_r = subprocess.run(pin + [ref_ci, ref, os.path.join(tref, "s"), stat] + ci_args + ["-q"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=limit_s).returncode
+            ci_ref_s = time.perf_counter() - t0
+            rows_ref = ci_rows(os.path.join(tref, "s"))
+            restore(imd)
+            t0 = time.perf_counter()
+            rc_n = subprocess.run([new_ci, ref, imd, stat] + ci_args + ["-q"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+            ci_new_s = time.perf_counter() - t0
+            restore(imd)
+            t0 = time.perf_counter()
+            rc_s = subprocess.run([new_ci, ref, imd, stat] + ci_args + ["-q", "--ci-stream", "reference"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+            ci_stream_s = time.perf_counter() - t0
+            ci = {"what": "rsem-calculate-credibility-intervals 0.95 %d 50 on those count vectors: reference -p %d; drop-in (samples drawn on the GPU); "
+                          "drop-in --ci-stream reference (the reference's own draws restated on %d host threads, intervals on the GPU)" % (g["nsamples"], P, P),
+                  "reference_s": ci_ref_s, "dropin_s": ci_new_s, "speedup": ci_ref_s / ci_new_s if ci_new_s > 0 else None,
+                  "dropin_reference_stream_s": ci_stream_s, "rows_equal_with_reference_stream": bool(rc_r == 0 and rc_s == 0 and ci_rows(imd) == rows_ref),
+                  "rc": [rc_r, rc_n, rc_s]}
+    except Exception as e:
+        ci = {"error": str(e)[:200]}
     return {"what": "rsem-run-gibbs %s on the same imdName.ofg (%d reads, %.2f GB of text): oracle/_ref (pthread chains%s) and the drop-in (--gibbs-mode exact), whole programs"
                     % (" ".join(args), n1, os.path.getsize(imd + ".ofg") / 1e9, ", pinned to %d cores of one socket" % P if pin else ""),
             "kind": "reference", "cores": P, "reads": n1, "chains": P, "rounds_per_chain": rounds,
             "value": P * rounds * n1 / ref_s, "unit": "read visits/s (all chains, whole program incl. reading .ofg)",
             "reference_s": ref_s, "dropin_s": new_s, "speedup": ref_s / new_s, "dropin_read_visits_per_s": P * rounds * n1 / new_s,
-            "count_vector_files": P, "count_vectors_identical": bool(all(same)), "write_ofg_s": ofg_s}
+            "count_vector_files": P, "count_vectors_identical": bool(all(same)), "write_ofg_s": ofg_s, "credibility_intervals": ci,
+            "ci_reference_s": (ci or {}).get("reference_s"), "ci_dropin_s": (ci or {}).get("dropin_s"),
+            "ci_rows_equal_with_reference_stream": (ci or {}).get("rows_equal_with_reference_stream")}
 
 
 def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True, bam_leg=True, gibbs_leg=True):

@@ -364,6 +364,24 @@ __global__ void k_slice_minsid(const Shape* __restrict__ shapes, int n_shapes, u
     slice_minsid[s] = (uint32_t)((keys_sorted[S.row_base + q] >> 32) & kKeyMinSidCap);
 }
 
+// ... and the anchor of the read in the slice's LAST occupied row slot: the largest anchor of the slice (the rows of a block are sorted
+// by anchor and laid out lane-major, so row slot r holds later rows than row slot r - 1).  sell_build_units needs it to see when the
+// anchors of a would-be unit alone outrun one LDS window.
+__global__ void k_slice_maxanchor(const Shape* __restrict__ shapes, int n_shapes, uint32_t T, uint32_t n_slices,
+                                  const uint64_t* __restrict__ keys_sorted, uint32_t* slice_maxanchor) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slices) return;
+    int sh = 0;
+    while (sh + 1 < n_shapes && s >= shapes[sh + 1].slice_base) ++sh;
+    const Shape S = shapes[sh];
+    const uint32_t sl = s - S.slice_base;
+    uint32_t q = 0, best = 0;
+    bool any = false;
+    for (int r = (int)shape_R(S) - 1; r >= 0 && !any; r--)
+        if (slot_to_row(S, T, sl, (uint32_t)r, q)) { best = q; any = true; }
+    slice_maxanchor[s] = any ? (uint32_t)((keys_sorted[S.row_base + best] >> 32) & kKeyMinSidCap) : 0u;
+}
+
 // largest sid of every slice that a window starting at the slice's own anchor could still hold (for the extent of a unit's
 // LDS windows: a unit starts at or below the anchors of its slices, so ids beyond anchor + window_cap are outside anyway,
 // and a far-away foreign id must not stretch the window of a small gene to the full capacity)
@@ -499,10 +517,11 @@ struct SellLayout {
     unsigned long long* d_masks = nullptr;
     uint32_t* d_slice_minsid = nullptr;
     uint32_t* d_slice_maxsid = nullptr;
+    uint32_t* d_slice_maxanchor = nullptr;
 };
 
 inline void sell_free(SellLayout& L) {
-    hipFree(L.d_order); hipFree(L.d_shapes); hipFree(L.d_ssid); hipFree(L.d_masks); hipFree(L.d_slice_minsid); hipFree(L.d_slice_maxsid);
+    hipFree(L.d_order); hipFree(L.d_shapes); hipFree(L.d_ssid); hipFree(L.d_masks); hipFree(L.d_slice_minsid); hipFree(L.d_slice_maxsid); hipFree(L.d_slice_maxanchor);
     hipFree(L.d_xanchor); hipFree(L.d_xreach); hipFree(L.d_far_ptr); hipFree(L.d_far_sid); hipFree(L.d_far_src); hipFree(L.d_far_cp);
     hipFree(L.d_csc_sid); hipFree(L.d_csc_src); hipFree(L.d_csc_slot); hipFree(L.d_csc_cp);
     L = SellLayout();
@@ -725,6 +744,7 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
     RSEM_HIP_TRY(dmalloc(&L.d_masks, (size_t)L.n_slices));
     RSEM_HIP_TRY(dmalloc(&L.d_slice_minsid, (size_t)L.n_slices));
     RSEM_HIP_TRY(dmalloc(&L.d_slice_maxsid, (size_t)L.n_slices));
+    RSEM_HIP_TRY(dmalloc(&L.d_slice_maxanchor, (size_t)L.n_slices));
     RSEM_HIP_TRY(hipMemsetAsync(L.d_ssid, 0, sizeof(int32_t) * L.n_planes * 64, st));
     if (L.n_x_rows) {
         const int frc = sell_build_far(L, st, d_row_ptr, d_sid, d_keys2);
@@ -738,6 +758,9 @@ inline int sell_build(SellLayout& L, hipStream_t st, uint64_t N1, int32_t M, con
         RSEM_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_slice_minsid, dim3(rsem::ceil_div(L.n_slices, kBlock)), dim3(kBlock), 0, st, L.d_shapes,
                            L.n_shapes, L.T, L.n_slices, d_keys2, L.d_slice_minsid);
+        RSEM_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_slice_maxanchor, dim3(rsem::ceil_div(L.n_slices, kBlock)), dim3(kBlock), 0, st, L.d_shapes,
+                           L.n_shapes, L.T, L.n_slices, d_keys2, L.d_slice_maxanchor);
         RSEM_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_slice_maxsid, dim3(rsem::ceil_div(L.n_slices, kBlock / 64)), dim3(kBlock), 0, st, L.d_shapes,
                            L.n_shapes, L.n_slices, L.d_ssid, L.d_slice_minsid, kLayoutWindow, L.d_slice_maxsid);
@@ -776,10 +799,11 @@ struct Unit {
 };
 
 inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units, int window_cap) {
-    std::vector<uint32_t> ms(L.n_slices), mx(L.n_slices);
+    std::vector<uint32_t> ms(L.n_slices), mx(L.n_slices), ma(L.n_slices);
     if (L.n_slices) {
         RSEM_HIP_TRY(hipMemcpy(ms.data(), L.d_slice_minsid, sizeof(uint32_t) * L.n_slices, hipMemcpyDeviceToHost));
         RSEM_HIP_TRY(hipMemcpy(mx.data(), L.d_slice_maxsid, sizeof(uint32_t) * L.n_slices, hipMemcpyDeviceToHost));
+        RSEM_HIP_TRY(hipMemcpy(ma.data(), L.d_slice_maxanchor, sizeof(uint32_t) * L.n_slices, hipMemcpyDeviceToHost));
     }
     // fractions of a shape's blocks that go into full-size and half-size units (the rest: quarter-size)
     double f_full = 1.0, f_half = 0.0;
@@ -819,8 +843,25 @@ inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units, int w
             add(sh, S, sl0, n, per_wave);
             b += nblocks;
         };
-        while (b < b_full) emit(W, T);
-        while (b < b_full + b_half) emit(2, (T + 1) / 2);
+        // A unit's LDS window holds window_cap ids from its smallest anchor on.  Where the reads of a shape are thin on the ground --
+        // the split rows of reads that reach beyond their gene, one read in ten: their four blocks span ten times the ids four blocks
+        // of compact reads do -- four blocks' anchors alone can outrun the window, and then every read behind it is "outside" and the
+        // whole unit runs the loop with the global gather and atomics (configs[2] with 10 % such reads: all 390 units of split rows,
+        // profiles/r06c_xrows_probe.log).  So a unit is as many blocks (4, 2 or 1) as fit one window.
+        auto fits = [&](uint32_t nblocks) -> bool {
+            const uint32_t s0 = S.slice_base + b * T, s1 = S.slice_base + std::min(S.n_slices, (b + nblocks) * T);
+            uint32_t top = 0, low = 0xffffffffu;
+            for (uint32_t t = s0; t < s1; t++) { top = std::max(top, std::max(mx[t], ma[t])); low = std::min(low, ms[t]); }
+            return s1 <= s0 || (long long)top - (long long)low + 1 <= (long long)window_cap;
+        };
+        auto emit_fitting = [&](uint32_t want) {
+            if (want >= W && fits(W)) emit(W, T);
+            else if (want >= 2 && T >= 2 && fits(2)) emit(2, (T + 1) / 2);
+            else if (T >= 4) emit(1, (T + 3) / 4);
+            else emit(std::min<uint32_t>(want, nb - b), T);
+        };
+        while (b < b_full) emit_fitting(std::min<uint32_t>(W, b_full - b));
+        while (b < b_full + b_half) emit_fitting(2);
         if (T < 4) while (b < nb) emit(std::min<uint32_t>(W, nb - b), T);
         else while (b < nb) emit(1, (T + 3) / 4);
     }
@@ -889,7 +930,9 @@ __global__ __launch_bounds__(256) void k_x_reach(const Unit* __restrict__ units,
         const uint32_t x = S.row_base + q - x_row_base;
         const long long top = (long long)U.base + U.span;  // (anchor >= base: the unit's base is the smallest anchor of its slices)
         const long long r = top - (long long)xanchor[x];
-        xreach[x] = (uint32_t)(r < 1 ? 1 : (r > kLayoutWindow ? kLayoutWindow : r));
+        // (a row whose anchor itself lies beyond the window -- a block wider than a window, sell_build_units -- keeps what it has: its
+        // unit runs the far loop whatever this row gives up)
+        xreach[x] = (uint32_t)(r < 1 ? kLayoutWindow : (r > kLayoutWindow ? kLayoutWindow : r));
     }
 }
 
