@@ -934,7 +934,8 @@ struct rsem_em_ctx {
     uint32_t n_units_main = 0;
     hipStream_t stream_x = nullptr;
     hipEvent_t ev_x_fork = nullptr, ev_x_join = nullptr;
-    int x_overlap = 1;
+    int x_overlap = 0;            // (measured: +4 % on configs[2] with 10 % cross-gene reads split, -4 % at configs[1]'s size without genes)
+    int spread_far_units = 0;     // deal the units with ids outside their window evenly over the launch order (partition_units)
     int noise_n = 0;  // workgroups of the last main E-step launch (= valid entries of d_noise_a)
     size_t noise_cap = 0;
     // EM state
@@ -982,6 +983,24 @@ int partition_units(rsem_em_ctx* c) {
     auto is_main = [](const Unit& u) { return u.S.fmt != kFmtF64X; };
     const auto mid = std::stable_partition(c->h_units.begin(), c->h_units.end(), is_main);
     c->n_units_main = (uint32_t)(mid - c->h_units.begin());
+    if (c->spread_far_units) {
+        // Units with ids outside their window (whole rows of reads that reach beyond their gene) wait for gathers and for the device's
+        // global atomic rate, the others for HBM: in the order of their measured lifetimes the far ones all start first and the launch
+        // begins with a phase that leaves the memory system idle.  Dealt evenly over the first 7/8 of the launch order instead, their
+        // atomics and gathers run beside the compact units' streaming.
+        std::vector<Unit> far, rest;
+        for (uint32_t i = 0; i < c->n_units_main; i++) (c->h_units[i].pad[0] ? far : rest).push_back(c->h_units[i]);
+        if (!far.empty() && !rest.empty()) {
+            const size_t n = far.size() + rest.size(), span = std::max<size_t>(far.size(), n - n / 8);
+            size_t fi = 0, ri = 0;
+            for (size_t i = 0; i < n; i++) {
+                const bool take_far = fi < far.size() && (ri >= rest.size() || fi * span <= i * far.size());
+                c->h_units[i] = take_far ? far[fi++] : rest[ri++];
+            }
+            c->n_units_main = (uint32_t)n;
+            RSEM_HIP_TRY(hipMemcpyAsync(c->d_units, c->h_units.data(), sizeof(Unit) * c->n_units, hipMemcpyHostToDevice, c->stream));
+        }
+    }
     if (c->n_units_main != c->n_units && c->n_units)
         RSEM_HIP_TRY(hipMemcpyAsync(c->d_units, c->h_units.data(), sizeof(Unit) * c->n_units, hipMemcpyHostToDevice, c->stream));
     RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1199,6 +1218,8 @@ int build_layout(rsem_em_ctx* c) {
         }
     }
     c->h_units = units;
+    if (const char* e = getenv("RSEM_HIP_X_OVERLAP")) c->x_overlap = atoi(e);  // measurement knob: 1 = the split rows' chain on its own stream
+    if (const char* e = getenv("RSEM_HIP_SPREAD_FAR")) c->spread_far_units = atoi(e);  // measurement knob
     rc = partition_units(c);
     if (rc != RSEM_OK) return rc;
     if (c->L.n_x_rows && !c->stream_x) {
@@ -1206,7 +1227,6 @@ int build_layout(rsem_em_ctx* c) {
         RSEM_HIP_TRY(hipEventCreateWithFlags(&c->ev_x_fork, hipEventDisableTiming));
         RSEM_HIP_TRY(hipEventCreateWithFlags(&c->ev_x_join, hipEventDisableTiming));
     }
-    if (const char* e = getenv("RSEM_HIP_X_OVERLAP")) c->x_overlap = atoi(e);  // measurement knob: 0 = one stream
     c->tune_passes_left = 1;
     if (const char* e = getenv("RSEM_HIP_TUNE")) c->tune_passes_left = atoi(e);  // tuning knob: 0 disables
     c->n_far_units = 0;

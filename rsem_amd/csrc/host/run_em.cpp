@@ -361,6 +361,33 @@ int main(int argc, char* argv[]) {
     }
 
     lap("refs + transcripts");
+    // packed references (base ids, mask words): they depend on nothing but the reference, so a thread of its own packs them while
+    // the read and alignment files are parsed (0.1 s at GENCODE scale that used to stand between the parsers and the model context)
+    std::vector<uint64_t> ref_off(M + 2, 0), mask_off(M + 2, 0);
+    std::vector<uint8_t> ref_seq;
+    std::vector<uint32_t> mask_words;
+    std::thread ref_packer([&]() {
+        for (int i = 1; i <= M; i++) {
+            ref_off[i + 1] = ref_off[i] + refs.seq[i].size();
+            mask_off[i + 1] = mask_off[i] + refs.masks[i].size();
+            if ((int)refs.seq[i].size() != refs.totLen[i]) die("%s.seq: sequence %d has length %zu, header says %d", refName.c_str(), i, refs.seq[i].size(), refs.totLen[i]);
+        }
+        ref_seq.resize(ref_off[M + 1]);
+        mask_words.resize(mask_off[M + 1]);
+        const int8_t* tbl = base_table();
+        const int nt = M > 2000 ? std::max(1, hardware_threads() / 4) : 1;  // (0.6 GB of letters at GENCODE scale: not a job for one thread; the parsers run beside it)
+        parallel_for(nt, [&](int t) {
+            for (int i = 1 + t; i <= M; i += nt) {
+                for (size_t k = 0; k < refs.seq[i].size(); k++) {
+                    int8_t id = tbl[(unsigned char)refs.seq[i][k]];
+                    if (id < 0) die("Found unknown sequence letter %c at function get_base_id!", refs.seq[i][k]);
+                    ref_seq[ref_off[i] + k] = (uint8_t)id;
+                }
+                std::copy(refs.masks[i].begin(), refs.masks[i].end(), mask_words.begin() + mask_off[i]);
+            }
+        });
+    });
+    Joiner ref_joiner{ref_packer};
     ModelParams P = load_mparams(imdName + ".mparams");
     const bool pe = read_type >= 2, hasQ = (read_type == 1 || read_type == 3);
 
@@ -491,29 +518,7 @@ int main(int argc, char* argv[]) {
     mark("EM contexts built (upload + layout, started behind .dat)");
     if (ndev < 1) die("rsem-run-em: no usable GPU (this program has no CPU path)");
     check_shards("rsem_em_create");
-    // packed references
-    std::vector<uint64_t> ref_off(M + 2, 0), mask_off(M + 2, 0);
-    for (int i = 1; i <= M; i++) {
-        ref_off[i + 1] = ref_off[i] + refs.seq[i].size();
-        mask_off[i + 1] = mask_off[i] + refs.masks[i].size();
-        if ((int)refs.seq[i].size() != refs.totLen[i]) die("%s.seq: sequence %d has length %zu, header says %d", refName.c_str(), i, refs.seq[i].size(), refs.totLen[i]);
-    }
-    std::vector<uint8_t> ref_seq(ref_off[M + 1]);
-    std::vector<uint32_t> mask_words(mask_off[M + 1]);
-    const int8_t* tbl = base_table();
-    {
-        const int nt = M > 2000 ? hardware_threads() : 1;  // (0.6 GB of letters at GENCODE scale: not a job for one thread)
-        parallel_for(nt, [&](int t) {
-            for (int i = 1 + t; i <= M; i += nt) {
-                for (size_t k = 0; k < refs.seq[i].size(); k++) {
-                    int8_t id = tbl[(unsigned char)refs.seq[i][k]];
-                    if (id < 0) die("Found unknown sequence letter %c at function get_base_id!", refs.seq[i][k]);
-                    ref_seq[ref_off[i] + k] = (uint8_t)id;
-                }
-                std::copy(refs.masks[i].begin(), refs.masks[i].end(), mask_words.begin() + mask_off[i]);
-            }
-        });
-    }
+    if (ref_packer.joinable()) ref_packer.join();
     mark("references packed");
     each_shard([&](Shard& X, int) {
         rsem_model_data md;
