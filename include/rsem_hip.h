@@ -105,7 +105,12 @@ int rsem_em_set_values(rsem_em_ctx* ctx, const double* conprb, const double* ncp
  * (the values are read back from the planes first). */
 int rsem_em_get_values(rsem_em_ctx* ctx, double* conprb, double* ncp);
 /* Options (none of them is part of the reference's surface):
- *   "kernel"            RSEM_EM_KERNEL_*;
+ *   "kernel"            RSEM_EM_KERNEL_AUTO or _LANE (the cross-check variants were retired in round 6);
+ *   "split_rows"        1 (default) / 0: reads with transcript ids outside the LDS window of their own gene are laid out as a row of
+ *                       their in-window alignments plus far entries handled by two passes around the E-step kernel;
+ *   "split_policy"      1 (default): the reads that are MOSTLY outside split; 2: every read with an id outside (its split rows then
+ *                       run on a stream of their own beside the compact reads: "split_overlap" 1, the default with policy 2) --
+ *                       measured equal or slower on the bench's inputs, kept as an option;
  *   "check_every"       rounds between the host's looks at the loop;
  *   "value_bits"        64 (default): the theta-only E step streams the conprb doubles as given; 32: reads whose
  *                       non-zero conprb values span less than 2^value_range_bits are streamed as 32-bit mantissas with
@@ -118,7 +123,7 @@ int rsem_em_get_values(rsem_em_ctx* ctx, double* conprb, double* ncp);
  *                       alone -- until something needs them again (weights, new values, a rebuild of the layout, a model
  *                       context), which reads them back from the planes: the same doubles.  RSEM_ERR_STATE, nothing changed,
  *                       where the planes do not hold everything (Q32 planes, split rows, reads with more than 256
- *                       alignments, the CSR kernel, a live model context).  0: bring them back now. */
+ *                       alignments, a live model context).  0: bring them back now. */
 int rsem_em_set_option(rsem_em_ctx* ctx, const char* key, int64_t value);
 /* Layout facts: "value_bits", "value_range_bits", "reads_q32", "reads_sliced", "reads_long", "value_plane_bytes",
  * "sid_plane_bytes", "slots", "units", "csr_released" (0 / 1), "csr_bytes" (what "release_csr" frees). */

@@ -511,8 +511,8 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
         const uint32_t u_end = S.slice_base + U.slice_begin + U.n_slices;
         const uint32_t s_begin = S.slice_base + U.slice_begin + (uint32_t)w * U.per_wave;
         const uint32_t s_end = min(u_end, s_begin + U.per_wave);
-#define RSEM_ESTEP_BLOCK(KK, QQ, FF, XX, ...) \
-    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF, XX, ##__VA_ARGS__>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M, xa)
+#define RSEM_ESTEP_BLOCK(KK, QQ, FF, XX) \
+    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF, XX>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M, xa)
         // (uniform over the workgroup)  split rows (F64X) only exist where theta is a plain array: the loops that read theta
         // out of the previous round's counts (kFC) are not taken for a layout with split rows (loop_wanted)
         const int code = (S.K - 1) | ((S.fmt == kFmtQ32 ? 1 : 0) << 2) | ((U.pad[0] != 0 ? 1 : 0) << 3) | (((!kFC && S.fmt == kFmtF64X) ? 1 : 0) << 4);
@@ -534,25 +534,15 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
             case 14: RSEM_ESTEP_BLOCK(3, true, true, false); break;
             case 15: RSEM_ESTEP_BLOCK(4, true, true, false); break;
             default:
-                // (split rows; bit 2 of the selector: a tuple starts in most slices of the unit -- Unit::pad[1] -- so the id planes are
-                // loaded without asking)
-                if constexpr (!kFC) switch ((code & 11) | (U.pad[1] != 0 ? 4 : 0)) {
+                if constexpr (!kFC) switch (code & 11) {
                     case 0: RSEM_ESTEP_BLOCK(1, false, false, true); break;
                     case 1: RSEM_ESTEP_BLOCK(2, false, false, true); break;
                     case 2: RSEM_ESTEP_BLOCK(3, false, false, true); break;
                     case 3: RSEM_ESTEP_BLOCK(4, false, false, true); break;
-                    case 4: RSEM_ESTEP_BLOCK(1, false, false, true, true); break;
-                    case 5: RSEM_ESTEP_BLOCK(2, false, false, true, true); break;
-                    case 6: RSEM_ESTEP_BLOCK(3, false, false, true, true); break;
-                    case 7: RSEM_ESTEP_BLOCK(4, false, false, true, true); break;
                     case 8: RSEM_ESTEP_BLOCK(1, false, true, true); break;
                     case 9: RSEM_ESTEP_BLOCK(2, false, true, true); break;
                     case 10: RSEM_ESTEP_BLOCK(3, false, true, true); break;
-                    case 11: RSEM_ESTEP_BLOCK(4, false, true, true); break;
-                    case 12: RSEM_ESTEP_BLOCK(1, false, true, true, true); break;
-                    case 13: RSEM_ESTEP_BLOCK(2, false, true, true, true); break;
-                    case 14: RSEM_ESTEP_BLOCK(3, false, true, true, true); break;
-                    default: RSEM_ESTEP_BLOCK(4, false, true, true, true); break;
+                    default: RSEM_ESTEP_BLOCK(4, false, true, true); break;
                 }
                 break;
 #undef RSEM_ESTEP_BLOCK
@@ -935,7 +925,6 @@ struct rsem_em_ctx {
     hipStream_t stream_x = nullptr;
     hipEvent_t ev_x_fork = nullptr, ev_x_join = nullptr;
     int x_overlap = 0;            // (measured: +4 % on configs[2] with 10 % cross-gene reads split, -4 % at configs[1]'s size without genes)
-    int spread_far_units = 0;     // deal the units with ids outside their window evenly over the launch order (partition_units)
     int noise_n = 0;  // workgroups of the last main E-step launch (= valid entries of d_noise_a)
     size_t noise_cap = 0;
     // EM state
@@ -983,24 +972,6 @@ int partition_units(rsem_em_ctx* c) {
     auto is_main = [](const Unit& u) { return u.S.fmt != kFmtF64X; };
     const auto mid = std::stable_partition(c->h_units.begin(), c->h_units.end(), is_main);
     c->n_units_main = (uint32_t)(mid - c->h_units.begin());
-    if (c->spread_far_units) {
-        // Units with ids outside their window (whole rows of reads that reach beyond their gene) wait for gathers and for the device's
-        // global atomic rate, the others for HBM: in the order of their measured lifetimes the far ones all start first and the launch
-        // begins with a phase that leaves the memory system idle.  Dealt evenly over the first 7/8 of the launch order instead, their
-        // atomics and gathers run beside the compact units' streaming.
-        std::vector<Unit> far, rest;
-        for (uint32_t i = 0; i < c->n_units_main; i++) (c->h_units[i].pad[0] ? far : rest).push_back(c->h_units[i]);
-        if (!far.empty() && !rest.empty()) {
-            const size_t n = far.size() + rest.size(), span = std::max<size_t>(far.size(), n - n / 8);
-            size_t fi = 0, ri = 0;
-            for (size_t i = 0; i < n; i++) {
-                const bool take_far = fi < far.size() && (ri >= rest.size() || fi * span <= i * far.size());
-                c->h_units[i] = take_far ? far[fi++] : rest[ri++];
-            }
-            c->n_units_main = (uint32_t)n;
-            RSEM_HIP_TRY(hipMemcpyAsync(c->d_units, c->h_units.data(), sizeof(Unit) * c->n_units, hipMemcpyHostToDevice, c->stream));
-        }
-    }
     if (c->n_units_main != c->n_units && c->n_units)
         RSEM_HIP_TRY(hipMemcpyAsync(c->d_units, c->h_units.data(), sizeof(Unit) * c->n_units, hipMemcpyHostToDevice, c->stream));
     RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1210,16 +1181,8 @@ int build_layout(rsem_em_ctx* c) {
     }
     RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_units = (uint32_t)units.size();
-    if (const char* e = getenv("RSEM_HIP_X_IDS")) {  // measurement knob: 0 = no unit loads the id planes of every slice
-        if (atoi(e) == 0) {
-            for (Unit& u : units) u.pad[1] = 0;
-            if (!units.empty()) RSEM_HIP_TRY(hipMemcpyAsync(c->d_units, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice, c->stream));
-            RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
-        }
-    }
     c->h_units = units;
     if (const char* e = getenv("RSEM_HIP_X_OVERLAP")) c->x_overlap = atoi(e);  // measurement knob: 1 = the split rows' chain on its own stream
-    if (const char* e = getenv("RSEM_HIP_SPREAD_FAR")) c->spread_far_units = atoi(e);  // measurement knob
     rc = partition_units(c);
     if (rc != RSEM_OK) return rc;
     if (c->L.n_x_rows && !c->stream_x) {
@@ -1414,7 +1377,7 @@ int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
         RSEM_REQUIRE(value == 0 || value == 1, "release_csr must be 0 or 1");
         return value ? release_csr(c) : ensure_csr(c);
     }
-    if (!strcmp(key, "kernel") || !strcmp(key, "split_rows") || !strcmp(key, "value_bits") || !strcmp(key, "value_range_bits")) {
+    if (!strcmp(key, "kernel") || !strcmp(key, "split_rows") || !strcmp(key, "split_policy") || !strcmp(key, "value_bits") || !strcmp(key, "value_range_bits")) {
         int rc0 = ensure_csr(c);  // (these may rebuild the layout from the CSR)
         if (rc0 != RSEM_OK) return rc0;
     }
@@ -1430,6 +1393,23 @@ int rsem_em_set_option(rsem_em_ctx* c, const char* key, int64_t value) {
             int rc = build_layout(c);
             if (rc != RSEM_OK) return rc;
         }
+        set_grid_for_kernel(c);
+        return RSEM_OK;
+    }
+    if (!strcmp(key, "split_overlap")) {
+        RSEM_REQUIRE(value == 0 || value == 1, "split_overlap must be 0 or 1");
+        c->x_overlap = (int)value;
+        return RSEM_OK;
+    }
+    if (!strcmp(key, "split_policy")) {
+        RSEM_REQUIRE(value == 1 || value == 2, "split_policy must be 1 (reads mostly outside their window) or 2 (every read with an id outside)");
+        if (c->split_policy == (int)value) return RSEM_OK;
+        c->split_policy = (int)value;
+        c->x_overlap = value == 2 ? 1 : 0;
+        RSEM_HIP_TRY(hipSetDevice(c->device));
+        free_layout(c);
+        int rc = build_layout(c);
+        if (rc != RSEM_OK) return rc;
         set_grid_for_kernel(c);
         return RSEM_OK;
     }

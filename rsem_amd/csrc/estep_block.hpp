@@ -125,9 +125,7 @@ constexpr int kQ32Depth[4] = {RSEM_Q32_DEPTHS};
 // runs a loop that touches global memory only through its streaming loads: theta and counts in LDS, no gather, no global
 // atomic -- with a global atomic possibly in flight (they do not return in order with loads) every wait the compiler
 // places in the loop is a wait for everything, and a gather in the middle of a slice drains the prefetch.
-// kIds: the id planes of every slice are loaded, tuple start or not (units whose runs of equal tuples are short, Unit::pad[1]: the
-// branch below would be taken nearly every time, and the waits behind a branch are those of its emptier side).
-template <int K, bool kFC, bool kQ, int NBUF, bool kFar, bool kX = false, bool kIds = false>
+template <int K, bool kFC, bool kQ, int NBUF, bool kFar, bool kX = false>
 RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
                                    const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, double* th_win, double* cnt_win,
                                    const unsigned char* __restrict__ sval, const int16_t* __restrict__ sexp, const int32_t* __restrict__ ssid,
@@ -166,8 +164,10 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         // (Behind a branch the compiler counts the loads in flight as on the path with the fewest, so its wait for this
         // slice's planes also waits for the next slice's sid planes where that slice has them.  Issuing the same K loads
         // always -- to the shape's first slice where m == 0: L1 / L2 hits, exact waits on every path -- was measured and
-        // is slower: 0.971 against 0.936 ms at configs[2], Q32 0.713 against 0.700, profiles/r03t.)
-        if (kIds || m != 0ull) {
+        // is slower: 0.971 against 0.936 ms at configs[2], Q32 0.713 against 0.700, profiles/r03t; tried again in round 6 for the
+        // units of split rows alone, where a tuple starts in most slices: no difference either way, profiles/r06b_xrows_probe.log,
+        // r06c_xrows_probe.log.)
+        if (m != 0ull) {
             const int32_t* __restrict__ ip = ssid + (S.plane_base * 64 + v0);
 #pragma unroll
             for (int k = 0; k < K; k++) b.id[k] = ip[k * 64 + ulane];

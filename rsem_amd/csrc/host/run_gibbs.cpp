@@ -63,6 +63,14 @@ int main(int argc, char* argv[]) {
     }
     if (nThreads < 1) nThreads = 1;
 
+    // the HIP runtime, the device context and the sampler's code object come up while the items are read (not for --dry-run: no GPU work)
+    std::thread warm;
+    struct WarmJoin { std::thread& t; ~WarmJoin() { if (t.joinable()) t.join(); } } warm_join{warm};
+    if (!dry_run) {
+        int dev0 = device < 0 ? 0 : device;
+        if (!devices_s.empty()) dev0 = atoi(devices_s.c_str());
+        warm = std::thread([dev0]() { (void)rsem_hip_preload(dev0, RSEM_PRELOAD_GIBBS); });
+    }
     // load_data (Gibbs.cpp:101-137)
     RefInfo refs = load_refs(refName + ".seq", false);
     const int M = refs.M;

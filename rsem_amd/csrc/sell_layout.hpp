@@ -794,7 +794,7 @@ struct Unit {
     uint32_t per_wave;     // wave w walks slices [slice_begin + w * per_wave, + per_wave)
     int32_t base;
     int32_t span;          // sids [base, base + span) are staged in LDS (<= the window capacity)
-    int32_t pad[2];        // pad[0]: 1 = some id of the unit lies outside [base, base + span); pad[1]: 1 = a tuple starts in most slices (sell_flag_far_units)
+    int32_t pad[2];        // pad[0]: 1 = some id of the unit lies outside [base, base + span) (sell_flag_far_units)
     Shape S;               // copy of the shape: one dependent load less at the start of every workgroup
 };
 
@@ -877,34 +877,22 @@ inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units, int w
 // counted.  One workgroup per unit; the flag lands in Unit::pad[0] on the device and in `units`.
 __host__ __device__ inline bool unit_entry_is_far(const Unit& U, int32_t v) { return v > 0 && (unsigned)(v - U.base) >= (unsigned)U.span; }
 
-// pad[1]: 1 = a new id tuple starts in most of the unit's slices (short runs: split rows among themselves, genes with few reads).
-// The loop of such a unit loads the id planes of EVERY slice (estep_block.hpp kIds): behind the scalar branch "only where a tuple
-// starts" the compiler's waits are those of the path with the fewest loads in flight, i.e. with the branch taken every time the
-// next slice's loads are waited for before this slice is reduced.
-__global__ __launch_bounds__(256) void k_unit_far(Unit* units, const int32_t* __restrict__ ssid, const unsigned long long* __restrict__ masks) {
-    __shared__ int any, dense;
-    if (threadIdx.x == 0) { any = 0; dense = 0; }
+__global__ __launch_bounds__(256) void k_unit_far(Unit* units, const int32_t* __restrict__ ssid) {
+    __shared__ int any;
+    if (threadIdx.x == 0) any = 0;
     __syncthreads();
     const Unit U = units[blockIdx.x];
-    {
-        int nz = 0;
-        for (uint32_t t = threadIdx.x; t < U.n_slices; t += blockDim.x) nz += masks[U.S.slice_base + U.slice_begin + t] != 0ull ? 1 : 0;
-        if (nz) atomicAdd(&dense, nz);
-    }
     const uint64_t p0 = (U.S.plane_base + (uint64_t)U.slice_begin * U.S.K) * 64, n = (uint64_t)U.n_slices * U.S.K * 64;
     bool far = false;
     for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) far = far || unit_entry_is_far(U, ssid[p0 + i]);
     if (far) any = 1;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        units[blockIdx.x].pad[0] = any;
-        units[blockIdx.x].pad[1] = 2 * (uint32_t)dense > U.n_slices ? 1 : 0;
-    }
+    if (threadIdx.x == 0) units[blockIdx.x].pad[0] = any;
 }
 
 inline int sell_flag_far_units(const SellLayout& L, std::vector<Unit>& units, Unit* d_units, hipStream_t st) {
     if (units.empty()) return RSEM_OK;
-    hipLaunchKernelGGL(k_unit_far, dim3((unsigned)units.size()), dim3(256), 0, st, d_units, (const int32_t*)L.d_ssid, (const unsigned long long*)L.d_masks);
+    hipLaunchKernelGGL(k_unit_far, dim3((unsigned)units.size()), dim3(256), 0, st, d_units, (const int32_t*)L.d_ssid);
     RSEM_HIP_TRY(hipGetLastError());
     RSEM_HIP_TRY(hipMemcpyAsync(units.data(), d_units, sizeof(Unit) * units.size(), hipMemcpyDeviceToHost, st));
     RSEM_HIP_TRY(hipStreamSynchronize(st));

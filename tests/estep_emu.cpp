@@ -25,7 +25,6 @@ struct Job {
     uint32_t slice_begin, n_slices;
     int base, span, M;
     bool far;  // the rule of sell_flag_far_units (sell_layout.hpp): some id of the unit lies outside its window
-    bool ids;  // ... and its second flag (Unit::pad[1]): a tuple starts in most of the unit's slices
     bool from_counts;
     const double* theta;  // plain: theta[M+1]; from_counts: counts[M+1] followed by 2 * kTotSlots totals
     double N0;
@@ -50,8 +49,8 @@ static void lane_body(Job* J, int tid) {
     const uint32_t s_end = std::min(u_end, s_begin + per_wave);
     const double* tsrc = J->theta + J->M + 1;
     double noise = 0.0, neff = 0.0;
-#define EMU_BLOCK(KK, QQ, FF, XX, ...)                                                                                                 \
-    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF, XX, ##__VA_ARGS__>(S, s_begin, s_end, lane, J->base, J->span, J->theta, tsrc, J->N0, \
+#define EMU_BLOCK(KK, QQ, FF, XX)                                                                                                      \
+    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF, XX>(S, s_begin, s_end, lane, J->base, J->span, J->theta, tsrc, J->N0, \
         J->th_win, J->cnt_win, H.sval.data(), H.sexp.data(), H.ssid.data(), H.sncp.data(), H.masks.data(), J->counts, noise, neff, J->M, J->xa)
     // the dispatch of k_estep_lane (em.hip)
     const int code = (S.K - 1) | ((S.fmt == kFmtQ32 ? 1 : 0) << 2) | ((J->far ? 1 : 0) << 3) | (((!kFC && S.fmt == kFmtF64X) ? 1 : 0) << 4);
@@ -73,23 +72,15 @@ static void lane_body(Job* J, int tid) {
         case 14: EMU_BLOCK(3, true, true, false); break;
         case 15: EMU_BLOCK(4, true, true, false); break;
         default:
-            if constexpr (!kFC) switch ((code & 11) | (J->ids ? 4 : 0)) {
+            if constexpr (!kFC) switch (code & 11) {
                 case 0: EMU_BLOCK(1, false, false, true); break;
                 case 1: EMU_BLOCK(2, false, false, true); break;
                 case 2: EMU_BLOCK(3, false, false, true); break;
                 case 3: EMU_BLOCK(4, false, false, true); break;
-                case 4: EMU_BLOCK(1, false, false, true, true); break;
-                case 5: EMU_BLOCK(2, false, false, true, true); break;
-                case 6: EMU_BLOCK(3, false, false, true, true); break;
-                case 7: EMU_BLOCK(4, false, false, true, true); break;
                 case 8: EMU_BLOCK(1, false, true, true); break;
                 case 9: EMU_BLOCK(2, false, true, true); break;
                 case 10: EMU_BLOCK(3, false, true, true); break;
-                case 11: EMU_BLOCK(4, false, true, true); break;
-                case 12: EMU_BLOCK(1, false, true, true, true); break;
-                case 13: EMU_BLOCK(2, false, true, true, true); break;
-                case 14: EMU_BLOCK(3, false, true, true, true); break;
-                default: EMU_BLOCK(4, false, true, true, true); break;
+                default: EMU_BLOCK(4, false, true, true); break;
             }
             break;
     } else {
@@ -155,11 +146,6 @@ int main(int argc, char** argv) {
             J->base = lo;
             J->span = std::min(hi - lo + 1, hdr[7] > 0 ? hdr[7] : kWindow);  // hdr[7]: a smaller window, to force the out-of-window path
             J->far = false;
-            {
-                uint32_t nz = 0;  // k_unit_far's second flag
-                for (uint32_t t = 0; t < J->n_slices; t++) nz += H.masks[S.slice_base + b0 + t] != 0ull ? 1u : 0u;
-                J->ids = 2 * nz > J->n_slices;
-            }
             {
                 Unit U{};
                 U.base = J->base;

@@ -371,6 +371,38 @@ def test_reads_that_also_hit_another_gene(config, scale, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("config,scale", [("smallX", 1.0), ("C3X30", 0.02)])
+def test_every_read_with_a_foreign_id_split(config, scale):
+    """Option "split_policy" 2 (rsem_hip.h): EVERY read with an id outside the window of its own gene is laid out as a split row (its
+    in-window alignments in the planes, the others as far entries of the two side passes), not only the reads that are mostly outside;
+    a split row's window ends where its unit's does (sell_refine_split_windows); the split rows' chain of kernels runs on a stream of
+    its own beside the compact reads ("split_overlap").  Step and whole run against the oracle, with and without the second stream,
+    and back to the default layout."""
+    wl = make_em_workload(config, scale=scale, seed=11)
+    M = wl["M"]
+    oc = orc.em_estep(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["theta0"])
+    oc[0] += wl["N0"]
+    oth, orounds, _, _ = orc.em_run(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"], wl["N0"], wl["theta0"], max_round=200)
+    ctx = capi().EmContext(M, wl["row_ptr"], wl["sid"], wl["conprb"], wl["ncp"])
+    split_default = ctx.info("split_rows")
+    ctx.set_option("split_policy", 2)
+    N1 = len(wl["row_ptr"]) - 1
+    assert ctx.info("split_rows") > max(split_default, 0.05 * N1) and ctx.info("far_entries") > 0
+    for overlap in (1, 0):
+        ctx.set_option("split_overlap", overlap)
+        counts, *_ = ctx.step(wl["theta0"], wl["N0"])
+        assert np.allclose(counts, oc, rtol=1e-9, atol=1e-9), overlap
+        out = ctx.run(wl["theta0"], wl["N0"], max_round=200)
+        assert out["rounds"] == orounds and np.allclose(out["theta"], oth, rtol=1e-6, atol=1e-12), overlap
+    c2, w, wn = ctx.expected_weights(wl["theta0"], wl["N0"])  # the weights pass walks the caller-order CSR: whole rows whatever the layout
+    assert np.allclose(c2, oc, rtol=1e-9, atol=1e-9)
+    ctx.set_option("split_policy", 1)
+    assert ctx.info("split_rows") == split_default
+    counts, *_ = ctx.step(wl["theta0"], wl["N0"])
+    assert np.allclose(counts, oc, rtol=1e-9, atol=1e-9)
+    ctx.close()
+
+
 def test_release_csr_keeps_every_result_and_gives_the_values_back_bit_for_bit():
     """Option "release_csr" (rsem_hip.h): the caller-order ids and values -- 12 of a context's ~25 bytes per alignment -- are freed while
     the theta-only rounds run and read back from the value planes by whatever needs them next.  The rounds give the same theta, the

@@ -108,8 +108,7 @@ CASES = [dict(), dict(from_counts=1), dict(window=64), dict(q32=1), dict(q32=1, 
          # policy=2: split rows -- a read that reaches beyond the window keeps its in-window alignments in the planes (F64X shapes,
          # an extra term in its normaliser, its reciprocal handed on), the others are far entries summed before / after the blocks
          dict(policy=2, window=64), dict(policy=2, window=16, T=3, seed=2), dict(policy=2, window=128, T=1, seed=3),
-         # policy=3: EVERY read that reaches beyond the window splits (not only those that are mostly outside); units in most of
-         # whose slices a tuple starts load the id planes of every slice (Unit::pad[1], estep_block's kIds)
+         # policy=3: EVERY read that reaches beyond the window splits (not only those that are mostly outside)
          dict(policy=3, window=64), dict(policy=3, window=16, T=3, seed=2), dict(policy=3, window=256, T=8, seed=4)]
 
 

@@ -6,8 +6,8 @@ matrix.  Variants are environment knobs read when a context lays its reads out (
     most       (round 5's rule) only reads that are mostly outside their window split
     all_1s     RSEM_HIP_SPLIT_POLICY=all RSEM_HIP_X_OVERLAP=0     every read with an id outside splits; one stream
     all        RSEM_HIP_SPLIT_POLICY=all RSEM_HIP_X_OVERLAP=1     ... the split rows' chain beside the compact units (two streams)
-    most_spread RSEM_HIP_SPREAD_FAR=1                             round 5's rule, the units with ids outside their window dealt evenly over the launch
-    all_noids  RSEM_HIP_SPLIT_POLICY=all RSEM_HIP_X_IDS=0         ... without the every-slice id loads in the split rows' units
+(Measured in round 6 and taken out again: id planes loaded in every slice of the split rows' units; the units with ids outside their
+window dealt evenly over the launch order -- profiles/r06b_xrows_probe.log .. r06e_xrows_probe.log.)
     python tools/xrows_probe.py [configs=C3X,C3X30,C2R] [variants=most,all_1s,all,all_noids] [scale=1.0]"""
 import os
 import sys
@@ -21,13 +21,12 @@ from oracle import pyoracle as orc  # noqa: E402  (the checker beside the measur
 from rsem_amd import capi  # noqa: E402
 from tools.synth_data import make_em_workload  # noqa: E402
 
-VARIANTS = {"whole": {"RSEM_HIP_SPLIT": "0"}, "most": {}, "most_spread": {"RSEM_HIP_SPREAD_FAR": "1"}, "all_spread": {"RSEM_HIP_SPLIT_POLICY": "all", "RSEM_HIP_SPREAD_FAR": "1", "RSEM_HIP_X_OVERLAP": "1"},
-            "all_1s": {"RSEM_HIP_SPLIT_POLICY": "all", "RSEM_HIP_X_OVERLAP": "0"}, "all": {"RSEM_HIP_SPLIT_POLICY": "all", "RSEM_HIP_X_OVERLAP": "1"},
-            "all_noids": {"RSEM_HIP_SPLIT_POLICY": "all", "RSEM_HIP_X_IDS": "0", "RSEM_HIP_X_OVERLAP": "1"}}
-KNOBS = ("RSEM_HIP_SPLIT", "RSEM_HIP_SPLIT_POLICY", "RSEM_HIP_X_OVERLAP", "RSEM_HIP_X_IDS", "RSEM_HIP_SPREAD_FAR")
+VARIANTS = {"whole": {"RSEM_HIP_SPLIT": "0"}, "most": {},
+            "all_1s": {"RSEM_HIP_SPLIT_POLICY": "all", "RSEM_HIP_X_OVERLAP": "0"}, "all": {"RSEM_HIP_SPLIT_POLICY": "all", "RSEM_HIP_X_OVERLAP": "1"},}
+KNOBS = ("RSEM_HIP_SPLIT", "RSEM_HIP_SPLIT_POLICY", "RSEM_HIP_X_OVERLAP")
 
 configs = (sys.argv[1] if len(sys.argv) > 1 else "C3X,C3X30,C2R").split(",")
-variants = (sys.argv[2] if len(sys.argv) > 2 else "most,all_1s,all,all_noids").split(",")
+variants = (sys.argv[2] if len(sys.argv) > 2 else "most,all_1s,all").split(",")
 scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 for cfg in configs:
     t0 = time.perf_counter()
