@@ -479,7 +479,10 @@ __global__ __launch_bounds__(kBlock) void k_solo_finish(int32_t M, double N0, co
 }
 
 // kFC: `theta` holds the previous round's raw counts, tsrc its totals (see ThetaSrc)
-template <bool kFC, bool kSolo = false>
+// kFQ: the launch over the units with ids outside their window (Unit::pad[0]; launch_estep deals them to a launch of their own): partial
+// counts for such ids queue up in LDS per wave (FarQueue, estep_block.hpp) -- 18 KB more per workgroup, three workgroups per CU
+// instead of four, which is why the compact units are not launched with it.
+template <bool kFC, bool kSolo = false, bool kFQ = false>
 __global__ __launch_bounds__(kBlock) void k_estep_lane(
     const Shape* __restrict__ shapes, const Unit* __restrict__ units, uint32_t T, int M,
     const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, const unsigned char* __restrict__ sval,
@@ -490,9 +493,19 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
     if (trace && threadIdx.x == 0) trace[2 * blockIdx.x] = wall_clock64();  // rsem_em_debug_trace only
     __shared__ double th_win[kWindow];
     __shared__ double cnt_win[kWindow];
+    __shared__ int fq_sid[kFQ ? (kBlock / 64) * kFarQCap : 1];
+    __shared__ double fq_val[kFQ ? (kBlock / 64) * kFarQCap : 1];
+    __shared__ int fq_n[kBlock / 64];
     const Unit U = units[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // the wave index, as a scalar
+    FarQueue fq;
+    if (kFQ) {
+        fq.sid = fq_sid + w * kFarQCap;
+        fq.val = fq_val + w * kFarQCap;
+        fq.n = fq_n + w;
+        if (lane == 0) fq_n[w] = 0;
+    }
     if (kSolo && solo.stat_round > 0) solo_close_round(solo, M, N0, theta);
     double noise = 0.0, neff = 0.0;
     {
@@ -515,7 +528,33 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
     estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF, XX>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M, xa)
         // (uniform over the workgroup)  split rows (F64X) only exist where theta is a plain array: the loops that read theta
         // out of the previous round's counts (kFC) are not taken for a layout with split rows (loop_wanted)
+#define RSEM_ESTEP_BLOCK_FQ(KK, QQ, XX) \
+    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), true, XX, true>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M, xa, fq)
         const int code = (S.K - 1) | ((S.fmt == kFmtQ32 ? 1 : 0) << 2) | ((U.pad[0] != 0 ? 1 : 0) << 3) | (((!kFC && S.fmt == kFmtF64X) ? 1 : 0) << 4);
+        if constexpr (kFQ) {
+            // (every unit of this launch takes the loop with the far path and the queue: a unit without ids outside never uses either)
+            if (s_begin < u_end) switch ((code & 7) | ((code >> 4) << 3)) {
+                case 0: RSEM_ESTEP_BLOCK_FQ(1, false, false); break;
+                case 1: RSEM_ESTEP_BLOCK_FQ(2, false, false); break;
+                case 2: RSEM_ESTEP_BLOCK_FQ(3, false, false); break;
+                case 3: RSEM_ESTEP_BLOCK_FQ(4, false, false); break;
+                case 4: RSEM_ESTEP_BLOCK_FQ(1, true, false); break;
+                case 5: RSEM_ESTEP_BLOCK_FQ(2, true, false); break;
+                case 6: RSEM_ESTEP_BLOCK_FQ(3, true, false); break;
+                case 7: RSEM_ESTEP_BLOCK_FQ(4, true, false); break;
+                default:
+                    if constexpr (!kFC) switch (code & 3) {
+                        case 0: RSEM_ESTEP_BLOCK_FQ(1, false, true); break;
+                        case 1: RSEM_ESTEP_BLOCK_FQ(2, false, true); break;
+                        case 2: RSEM_ESTEP_BLOCK_FQ(3, false, true); break;
+                        default: RSEM_ESTEP_BLOCK_FQ(4, false, true); break;
+                    }
+                    break;
+            } else {
+                const ThetaSrc th = theta_src<kFC>(theta, tsrc, N0, lane);
+                stage_windows<kFC>(U.base, U.span, M, th, th_win, cnt_win);
+            }
+        } else
         if (s_begin < u_end) switch (code) {
             case 0: RSEM_ESTEP_BLOCK(1, false, false, false); break;
             case 1: RSEM_ESTEP_BLOCK(2, false, false, false); break;
@@ -546,6 +585,7 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
                 }
                 break;
 #undef RSEM_ESTEP_BLOCK
+#undef RSEM_ESTEP_BLOCK_FQ
         } else {
             const ThetaSrc th = theta_src<kFC>(theta, tsrc, N0, lane);
             stage_windows<kFC>(U.base, U.span, M, th, th_win, cnt_win);
@@ -922,6 +962,11 @@ struct rsem_em_ctx {
     // stream_x: k_far_rowsum -> their lane launch -> k_far_colsum, a chain of passes bound by the L2's request rate and by their own
     // round trips, while the compact units stream from HBM on the context's stream (launch_estep).
     uint32_t n_units_main = 0;
+    // ... and inside [0, n_units_main) the units with ids outside their window stand behind the compact ones, [n_units_compact,
+    // n_units_main): they are launched with the far-queue instantiation (k_estep_lane<.., kFQ = true>), beside the compact units on
+    // stream_x.  far_queue = 0 (option / RSEM_HIP_FAR_QUEUE=0): one launch over all of them as until round 5.
+    uint32_t n_units_compact = 0;
+    int far_queue = 1;
     hipStream_t stream_x = nullptr;
     hipEvent_t ev_x_fork = nullptr, ev_x_join = nullptr;
     int x_overlap = 0;            // (measured: +4 % on configs[2] with 10 % cross-gene reads split, -4 % at configs[1]'s size without genes)
@@ -972,6 +1017,10 @@ int partition_units(rsem_em_ctx* c) {
     auto is_main = [](const Unit& u) { return u.S.fmt != kFmtF64X; };
     const auto mid = std::stable_partition(c->h_units.begin(), c->h_units.end(), is_main);
     c->n_units_main = (uint32_t)(mid - c->h_units.begin());
+    const auto midc = std::stable_partition(c->h_units.begin(), mid, [](const Unit& u) { return u.pad[0] == 0; });
+    c->n_units_compact = c->far_queue ? (uint32_t)(midc - c->h_units.begin()) : c->n_units_main;
+    if (c->n_units_compact != c->n_units_main && c->n_units)
+        RSEM_HIP_TRY(hipMemcpyAsync(c->d_units, c->h_units.data(), sizeof(Unit) * c->n_units, hipMemcpyHostToDevice, c->stream));
     if (c->n_units_main != c->n_units && c->n_units)
         RSEM_HIP_TRY(hipMemcpyAsync(c->d_units, c->h_units.data(), sizeof(Unit) * c->n_units, hipMemcpyHostToDevice, c->stream));
     RSEM_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -984,18 +1033,29 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
     c->noise_n = (int)c->n_units;
     {
         XArgs xa;
-        // the split rows' chain on a stream of its own, beside the compact units
-        hipStream_t sx = st;
-        const uint32_t n_main = c->n_units_main;
-        const bool beside = c->x_overlap && c->L.n_x_rows && c->stream_x && n_main > 0 && n_main < c->n_units;
-        if (beside) {
-            sx = c->stream_x;
+        // Up to three groups of units (partition_units): compact [0, nc), with ids outside their window [nc, n_main) -- the far-queue
+        // instantiation, on stream_x beside the compact ones --, split rows [n_main, n) -- between their two side passes; on stream_x
+        // too with option split_overlap.
+        const uint32_t nc = c->n_units_compact, n_main = c->n_units_main, n_all = c->n_units;
+        const bool far_launch = c->far_queue && nc < n_main;
+        const bool x_beside = c->x_overlap && c->L.n_x_rows && n_main > 0 && n_main < n_all;
+        const bool second = c->stream_x && (x_beside || (far_launch && nc > 0));
+        hipStream_t s2 = second ? c->stream_x : st;
+        hipStream_t sx = x_beside ? s2 : st, sf = far_launch ? s2 : st;
+        if (second) {
             RSEM_HIP_TRY(hipEventRecord(c->ev_x_fork, st));
-            RSEM_HIP_TRY(hipStreamWaitEvent(sx, c->ev_x_fork, 0));
+            RSEM_HIP_TRY(hipStreamWaitEvent(s2, c->ev_x_fork, 0));
         }
         auto lane = [&](uint32_t u0, uint32_t u1, hipStream_t s) {
             if (u1 > u0)
                 hipLaunchKernelGGL((k_estep_lane<false, false>), dim3(u1 - u0), dim3(kBlock), 0, s, c->L.d_shapes, c->d_units + u0, c->L.T, c->M,
+                                   d_theta, (const double*)nullptr, 0.0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid,
+                                   c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a + u0, c->use_totals ? c->d_totals : nullptr, ctrl,
+                                   c->d_trace ? c->d_trace + 2 * (size_t)u0 : nullptr, SoloArgs(), xa);
+        };
+        auto lane_fq = [&](uint32_t u0, uint32_t u1, hipStream_t s) {
+            if (u1 > u0)
+                hipLaunchKernelGGL((k_estep_lane<false, false, true>), dim3(u1 - u0), dim3(kBlock), 0, s, c->L.d_shapes, c->d_units + u0, c->L.T, c->M,
                                    d_theta, (const double*)nullptr, 0.0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid,
                                    c->d_sncp, c->L.d_masks, d_counts, c->d_noise_a + u0, c->use_totals ? c->d_totals : nullptr, ctrl,
                                    c->d_trace ? c->d_trace + 2 * (size_t)u0 : nullptr, SoloArgs(), xa);
@@ -1006,8 +1066,12 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
             hipLaunchKernelGGL(batched ? k_far_rowsum<true> : k_far_rowsum<false>, dim3(rsem::ceil_div(c->L.n_x_slots, kBlock)), dim3(kBlock), 0, sx, c->L.n_x_slots,
                                (const uint64_t*)c->L.d_far_ptr, (const int32_t*)c->L.d_far_sid, (const double*)c->L.d_far_cp, d_theta, c->d_xextra, ctrl);
         }
-        if (beside) { lane(0, n_main, st); lane(n_main, c->n_units, sx); }
-        else lane(0, c->n_units, st);
+        if (far_launch) lane_fq(nc, n_main, sf);
+        if (!far_launch && sx == st) lane(0, n_all, st);
+        else {
+            lane(0, far_launch ? nc : n_main, st);
+            lane(n_main, n_all, sx);
+        }
         if (c->L.n_far) {  // ... and their far alignments' fractions afterwards, in transcript order
             // one step of 4 x 64 entries per wave: the pass is a chain of dependent trips (entries -> theta, reciprocal -> shuffles ->
             // atomic), and more waves in flight hide more of it than a loop per wave (8 / 16 / 32 workgroups per CU: 335 / 326 /
@@ -1017,9 +1081,9 @@ int launch_estep(rsem_em_ctx* c, const double* d_theta, double* d_counts, hipStr
             hipLaunchKernelGGL(xcd ? k_far_colsum<true> : k_far_colsum<false>, dim3(grid), dim3(kBlock), 0, sx, c->L.n_far, (const int32_t*)c->L.d_csc_sid,
                                (const double*)c->L.d_csc_cp, (const uint32_t*)c->L.d_csc_slot, c->L.x_slot_base, d_theta, (const double*)c->d_xinv, d_counts, ctrl);
         }
-        if (beside) {
+        if (second) {
             RSEM_HIP_TRY(hipGetLastError());
-            RSEM_HIP_TRY(hipEventRecord(c->ev_x_join, sx));
+            RSEM_HIP_TRY(hipEventRecord(c->ev_x_join, s2));
             RSEM_HIP_TRY(hipStreamWaitEvent(st, c->ev_x_join, 0));
         }
     }
@@ -1183,9 +1247,10 @@ int build_layout(rsem_em_ctx* c) {
     c->n_units = (uint32_t)units.size();
     c->h_units = units;
     if (const char* e = getenv("RSEM_HIP_X_OVERLAP")) c->x_overlap = atoi(e);  // measurement knob: 1 = the split rows' chain on its own stream
+    if (const char* e = getenv("RSEM_HIP_FAR_QUEUE")) c->far_queue = atoi(e);  // measurement knob: 0 = one launch, global atomics in the far units' loop
     rc = partition_units(c);
     if (rc != RSEM_OK) return rc;
-    if (c->L.n_x_rows && !c->stream_x) {
+    if ((c->L.n_x_rows || c->n_units_compact < c->n_units_main) && !c->stream_x) {
         RSEM_HIP_TRY(hipStreamCreateWithFlags(&c->stream_x, hipStreamNonBlocking));
         RSEM_HIP_TRY(hipEventCreateWithFlags(&c->ev_x_fork, hipEventDisableTiming));
         RSEM_HIP_TRY(hipEventCreateWithFlags(&c->ev_x_join, hipEventDisableTiming));
@@ -1728,9 +1793,24 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
                     hipLaunchKernelGGL(k_solo_close, dim3(std::min<uint32_t>(c->n_units, (uint32_t)kCloseMax)), dim3(kBlock), 0, st, c->M, (const double*)src, N0,
                                        (const Ctrl*)c->d_ctrl, sa);
             } else {
-                hipLaunchKernelGGL((k_estep_lane<true, true>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
+                // the units with ids outside their window: a launch of their own (far-queue instantiation) beside the compact ones, on
+                // stream_x; the closers ride on the compact launch
+                const uint32_t nc = c->n_units_compact;
+                const bool far_launch = c->far_queue && nc < c->n_units && nc > 0 && c->stream_x;
+                if (far_launch) {
+                    RSEM_HIP_TRY(hipEventRecord(c->ev_x_fork, st));
+                    RSEM_HIP_TRY(hipStreamWaitEvent(c->stream_x, c->ev_x_fork, 0));
+                    hipLaunchKernelGGL((k_estep_lane<true, false, true>), dim3(c->n_units - nc), dim3(kBlock), 0, c->stream_x, c->L.d_shapes, c->d_units + nc, c->L.T, c->M,
+                                       (const double*)src, (const double*)(src + c->M + 1), N0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
+                                       c->d_noise_a + nc, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, SoloArgs());
+                }
+                hipLaunchKernelGGL((k_estep_lane<true, true>), dim3(far_launch ? nc : c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
                                    (const double*)src, (const double*)(src + c->M + 1), N0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
                                    c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, sa);
+                if (far_launch) {
+                    RSEM_HIP_TRY(hipEventRecord(c->ev_x_join, c->stream_x));
+                    RSEM_HIP_TRY(hipStreamWaitEvent(st, c->ev_x_join, 0));
+                }
             }
             RSEM_HIP_TRY(hipGetLastError());
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));
@@ -1739,9 +1819,17 @@ int rsem_em_run(rsem_em_ctx* c, double* theta, double N0, int round0, int min_ro
             double* dst = c->d_red3 + (size_t)(r % 3) * R;
             if (r - round0 >= 3) RSEM_HIP_TRY(hipStreamWaitEvent(st, c->ev_s[(r - 2) & 3], 0));  // dst was cleared by round r-2's statistics
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[2 + 2 * ti], st));
-            hipLaunchKernelGGL((k_estep_lane<true, false>), dim3(c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
-                               (const double*)src, (const double*)(src + c->M + 1), N0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
-                               c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, SoloArgs());
+            {
+                const uint32_t nc = c->n_units_compact;
+                const bool far_launch = c->far_queue && nc < c->n_units;
+                hipLaunchKernelGGL((k_estep_lane<true, false>), dim3(far_launch ? nc : c->n_units), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units, c->L.T, c->M,
+                                   (const double*)src, (const double*)(src + c->M + 1), N0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
+                                   c->d_noise_a, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, SoloArgs());
+                if (far_launch)  // (this loop keeps its second stream for the statistics: the far units follow on the same stream)
+                    hipLaunchKernelGGL((k_estep_lane<true, false, true>), dim3(c->n_units - nc), dim3(kBlock), 0, st, c->L.d_shapes, c->d_units + nc, c->L.T, c->M,
+                                       (const double*)src, (const double*)(src + c->M + 1), N0, (const unsigned char*)c->d_sval, (const int16_t*)c->d_sexp, c->L.d_ssid, c->d_sncp, c->L.d_masks, dst,
+                                       c->d_noise_a + nc, dst + c->M + 1, (const Ctrl*)c->d_ctrl, (unsigned long long*)nullptr, SoloArgs());
+            }
             RSEM_HIP_TRY(hipGetLastError());
             if (prof && ti < timed) RSEM_HIP_TRY(hipEventRecord(c->events[3 + 2 * ti], st));
             if (sharded) {  // EM.cpp:385-389 across shards

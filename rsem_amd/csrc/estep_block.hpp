@@ -64,6 +64,24 @@ struct XArgs {
     uint32_t slot_base = 0;
 };
 
+// The far queue of a wave (kFQ: the launch over the units with ids outside their window, em.hip).  A lane that spills a partial count
+// for an id outside its unit's window takes a place here -- (id, value) in LDS -- instead of issuing a global atomic: with an atomic
+// possibly in flight (they do not return in order with loads) every wait the compiler places in the loop is a wait for EVERYTHING, and
+// the loads of the next slice, issued a moment ago, are waited for before this slice is reduced: the units of far-reaching reads ran
+// without any overlap of loads and arithmetic (rounds 3-5; profiles/r06d_xrows_probe_units_fit_window.log: 10 % of the reads, a
+// fifth of the launch).  The queue is emptied -- its atomics issued AND waited for, RSEM_WAIT_VM0, so that the compiler sees none in
+// flight behind that point -- where a new tuple starts and fewer than a slice's worth of places are left, and at the block's end.
+#ifndef RSEM_FARQ_CAP
+#define RSEM_FARQ_CAP 384
+#endif
+constexpr int kFarQCap = RSEM_FARQ_CAP;  // places per wave: > 64 * 4 (what one slice can append) + room to make emptying rare (tests build it smaller)
+static_assert(kFarQCap > 256, "a slice of K = 4 planes can append 256 entries");
+struct FarQueue {
+    int* sid = nullptr;     // [kFarQCap]
+    double* val = nullptr;  // [kFarQCap]
+    int* n = nullptr;       // places taken
+};
+
 // one slice's loads: sids (only where a tuple starts), values (doubles, or Q32 mantissas + the read's exponent), noise
 template <int K, bool kQ>
 struct SliceRegs {
@@ -125,12 +143,13 @@ constexpr int kQ32Depth[4] = {RSEM_Q32_DEPTHS};
 // runs a loop that touches global memory only through its streaming loads: theta and counts in LDS, no gather, no global
 // atomic -- with a global atomic possibly in flight (they do not return in order with loads) every wait the compiler
 // places in the loop is a wait for everything, and a gather in the middle of a slice drains the prefetch.
-template <int K, bool kFC, bool kQ, int NBUF, bool kFar, bool kX = false>
+template <int K, bool kFC, bool kQ, int NBUF, bool kFar, bool kX = false, bool kFQ = false>
 RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, int lane, int base, int span,
                                    const double* __restrict__ theta, const double* __restrict__ tsrc, double N0, double* th_win, double* cnt_win,
                                    const unsigned char* __restrict__ sval, const int16_t* __restrict__ sexp, const int32_t* __restrict__ ssid,
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
-                                   double* counts, double& noise, double& neff, int M, const XArgs& X = XArgs()) {
+                                   double* counts, double& noise, double& neff, int M, const XArgs& X = XArgs(), const FarQueue& FQ = FarQueue()) {
+    static_assert(!kFQ || kFar, "the far queue belongs to the loop of the units with ids outside their window");
     using ValT = typename std::conditional<kQ, uint32_t, double>::type;
     const ValT* __restrict__ scp = (const ValT*)(sval + S.val_base);  // this shape's value planes
     const int lg = S.lg;
@@ -190,9 +209,26 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
                 const unsigned off = (unsigned)(rsid[k] - base);
                 if (!kFar) RSEM_LDS_ADD(&cnt_win[off < (unsigned)span ? off : 0u], acc[k]);  // (the clamp never acts: no id of the unit is outside)
                 else if (off < (unsigned)span) RSEM_LDS_ADD(&cnt_win[off], acc[k]);
-                else RSEM_ATOMIC_ADD(&counts[rsid[k]], acc[k]);
+                else if (kFQ) {
+                    const int at = RSEM_LDS_FETCH_ADD_I32(FQ.n, 1);  // (room for a whole slice was made before this slice: far_queue_room)
+                    FQ.sid[at] = rsid[k];
+                    FQ.val[at] = acc[k];
+                } else RSEM_ATOMIC_ADD(&counts[rsid[k]], acc[k]);
             }
             acc[k] = 0.0;
+        }
+    };
+    // kFQ, all lanes: empty the wave's queue if a slice's worth of appends (64 K) might not fit any more, or if `all`
+    auto far_queue_room = [&](bool all) {
+        if (!kFQ) return;
+        RSEM_WAVE_SYNC();
+        const int n = RSEM_READFIRSTLANE(*FQ.n);
+        if (n > (all ? 0 : kFarQCap - 64 * K)) {  // (uniform over the wave)
+            for (int i = lane; i < n; i += 64) RSEM_ATOMIC_ADD(&counts[FQ.sid[i]], FQ.val[i]);
+            RSEM_WAIT_VM0();
+            RSEM_WAVE_SYNC();
+            if (lane == 0) *FQ.n = 0;
+            RSEM_WAVE_SYNC();
         }
     };
 
@@ -204,6 +240,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
     double th0 = 0.0;
     auto reduce = [&](const SliceRegs<K, kQ>& cur, unsigned long long cur_m) {
         if (cur_m != 0ull) {                 // wave-uniform
+            far_queue_room(false);
             if ((cur_m >> lane) & 1ull) {    // lanes whose read starts a new sid tuple
                 spill(rsid, acc);
                 // theta of the new tuple: the window (LDS) for every id -- a clamped offset where the id is outside --, then,
@@ -327,7 +364,9 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         for (int j = 0; j < NBUF - 1; j++)
             if (s + j < s_end) reduce(buf[j], mk[j]);  // (uniform over the wave)
     }
+    far_queue_room(false);
     spill(rsid, acc);
+    far_queue_room(true);
 }
 
 template <bool kFC>

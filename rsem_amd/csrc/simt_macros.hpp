@@ -17,6 +17,19 @@
 #define RSEM_ATOMIC_ADD_I32(p, v) atomicAdd(p, v)
 #define RSEM_LDS_ADD(p, v) (void)__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(p), v)
 #define RSEM_LDS_ADD_I32(p, v) (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+/* ... the returning form (ds_add_rtn_u32): a lane takes a place in a queue of its wave */
+#define RSEM_LDS_FETCH_ADD_I32(p, v) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+/* the lanes of a wave have all passed this point (the LDS serves a wave's instructions in order: what any lane wrote to LDS before it
+   is there for every lane after it) */
+#define RSEM_WAVE_SYNC()                                        \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+/* every global load, store and atomic this wave has issued is done -- and the compiler knows it: no "possibly in flight" behind this */
+#define RSEM_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70) /* vmcnt(0), expcnt and lgkmcnt untouched (gfx9 encoding: vmcnt = bits 15:14 | 3:0) */
+#define RSEM_READFIRSTLANE(v) __builtin_amdgcn_readfirstlane(v)
 /* the value must be in its register HERE: the wait for its load is placed at this point and not at a later join of paths */
 #define RSEM_PIN(x) asm volatile("" : "+v"(x))
 /* nothing moves across this point in the instruction schedule */

@@ -25,6 +25,7 @@ struct Job {
     uint32_t slice_begin, n_slices;
     int base, span, M;
     bool far;  // the rule of sell_flag_far_units (sell_layout.hpp): some id of the unit lies outside its window
+    bool far_queue;  // ... and such units take the far-queue instantiation (environment ESTEP_EMU_FAR_QUEUE=0: the loop with global atomics)
     bool from_counts;
     const double* theta;  // plain: theta[M+1]; from_counts: counts[M+1] followed by 2 * kTotSlots totals
     double N0;
@@ -33,6 +34,10 @@ struct Job {
     double* tot_neff;
     double th_win[kWindow], cnt_win[kWindow];
     XArgs xa;  // split rows (policy 2)
+    // the far queues of the four waves (k_estep_lane<.., kFQ = true>: the launch over the units with ids outside their window)
+    int fq_sid[4][kFarQCap];
+    double fq_val[4][kFarQCap];
+    int fq_n[4];
     emu::Block blk;
 };
 
@@ -52,7 +57,14 @@ static void lane_body(Job* J, int tid) {
 #define EMU_BLOCK(KK, QQ, FF, XX)                                                                                                      \
     estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), FF, XX>(S, s_begin, s_end, lane, J->base, J->span, J->theta, tsrc, J->N0, \
         J->th_win, J->cnt_win, H.sval.data(), H.sexp.data(), H.ssid.data(), H.sncp.data(), H.masks.data(), J->counts, noise, neff, J->M, J->xa)
-    // the dispatch of k_estep_lane (em.hip)
+    FarQueue fq;
+    fq.sid = J->fq_sid[w]; fq.val = J->fq_val[w]; fq.n = &J->fq_n[w];
+    if (lane == 0) J->fq_n[w] = 0;
+#define EMU_BLOCK_FQ(KK, QQ)                                                                                                          \
+    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), true, false, true>(S, s_begin, s_end, lane, J->base, J->span, J->theta, tsrc, J->N0, \
+        J->th_win, J->cnt_win, H.sval.data(), H.sexp.data(), H.ssid.data(), H.sncp.data(), H.masks.data(), J->counts, noise, neff, J->M, J->xa, fq)
+    // the dispatch of k_estep_lane (em.hip); the units with ids outside their window (not those of split rows) go to the launch with the
+    // far queue, as launch_estep deals them
     const int code = (S.K - 1) | ((S.fmt == kFmtQ32 ? 1 : 0) << 2) | ((J->far ? 1 : 0) << 3) | (((!kFC && S.fmt == kFmtF64X) ? 1 : 0) << 4);
     if (s_begin < u_end) switch (code) {
         case 0: EMU_BLOCK(1, false, false, false); break;
@@ -63,14 +75,14 @@ static void lane_body(Job* J, int tid) {
         case 5: EMU_BLOCK(2, true, false, false); break;
         case 6: EMU_BLOCK(3, true, false, false); break;
         case 7: EMU_BLOCK(4, true, false, false); break;
-        case 8: EMU_BLOCK(1, false, true, false); break;
-        case 9: EMU_BLOCK(2, false, true, false); break;
-        case 10: EMU_BLOCK(3, false, true, false); break;
-        case 11: EMU_BLOCK(4, false, true, false); break;
-        case 12: EMU_BLOCK(1, true, true, false); break;
-        case 13: EMU_BLOCK(2, true, true, false); break;
-        case 14: EMU_BLOCK(3, true, true, false); break;
-        case 15: EMU_BLOCK(4, true, true, false); break;
+        case 8: if (J->far_queue) EMU_BLOCK_FQ(1, false); else EMU_BLOCK(1, false, true, false); break;
+        case 9: if (J->far_queue) EMU_BLOCK_FQ(2, false); else EMU_BLOCK(2, false, true, false); break;
+        case 10: if (J->far_queue) EMU_BLOCK_FQ(3, false); else EMU_BLOCK(3, false, true, false); break;
+        case 11: if (J->far_queue) EMU_BLOCK_FQ(4, false); else EMU_BLOCK(4, false, true, false); break;
+        case 12: if (J->far_queue) EMU_BLOCK_FQ(1, true); else EMU_BLOCK(1, true, true, false); break;
+        case 13: if (J->far_queue) EMU_BLOCK_FQ(2, true); else EMU_BLOCK(2, true, true, false); break;
+        case 14: if (J->far_queue) EMU_BLOCK_FQ(3, true); else EMU_BLOCK(3, true, true, false); break;
+        case 15: if (J->far_queue) EMU_BLOCK_FQ(4, true); else EMU_BLOCK(4, true, true, false); break;
         default:
             if constexpr (!kFC) switch (code & 11) {
                 case 0: EMU_BLOCK(1, false, false, true); break;
@@ -88,6 +100,7 @@ static void lane_body(Job* J, int tid) {
         stage_windows<kFC>(J->base, J->span, J->M, th, J->th_win, J->cnt_win);
     }
 #undef EMU_BLOCK
+#undef EMU_BLOCK_FQ
     RSEM_SYNC();
     for (int i = tid; i < J->span; i += 256)
         if (J->cnt_win[i] != 0.0) emu::atomic_add(&J->counts[J->base + i], J->cnt_win[i]);
@@ -128,6 +141,7 @@ int main(int argc, char** argv) {
         xextra[e.slot - H.x_slot_base] += fv;
     }
     Job* J = new Job();
+    J->far_queue = !(getenv("ESTEP_EMU_FAR_QUEUE") && atoi(getenv("ESTEP_EMU_FAR_QUEUE")) == 0);
     J->xa.extra = xextra.data();
     J->xa.inv = xinv.data();
     J->xa.slot_base = H.x_slot_base;

@@ -100,6 +100,10 @@ inline long long double_as_ll(double d) { long long x; memcpy(&x, &d, 8); return
 #define RSEM_ATOMIC_ADD_I32(p, v) __atomic_fetch_add(p, v, __ATOMIC_RELAXED)
 #define RSEM_LDS_ADD(p, v) emu::atomic_add(p, v)
 #define RSEM_LDS_ADD_I32(p, v) __atomic_fetch_add(p, v, __ATOMIC_RELAXED)
+#define RSEM_LDS_FETCH_ADD_I32(p, v) __atomic_fetch_add(p, v, __ATOMIC_RELAXED)
+#define RSEM_WAVE_SYNC() pthread_barrier_wait(&emu::wave().bar)
+#define RSEM_WAIT_VM0() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define RSEM_READFIRSTLANE(v) emu::exchange(v, 0)
 #define RSEM_PIN(x) (void)(x)
 #define RSEM_SCHED_FENCE() (void)0
 #define RSEM_RCP(x) (1.0 / (x) * (1.0 + 3e-8))  /* v_rcp_f64 is not exact either: the Newton steps must repair this */

@@ -22,7 +22,8 @@ pytestmark = pytest.mark.skipif(not os.path.exists(CC), reason="needs hipcc (hos
 
 BUILDS = {
     "product": [],
-    "variants": ["-DRSEM_F64_DEPTHS=4,3,3,2", "-DRSEM_Q32_DEPTHS=5,4,3,2"],
+    # (... and a far queue of 260 places per wave, 4 more than one slice can append: it is emptied before nearly every slice that appends)
+    "variants": ["-DRSEM_F64_DEPTHS=4,3,3,2", "-DRSEM_Q32_DEPTHS=5,4,3,2", "-DRSEM_FARQ_CAP=260"],
     # the product's body under ThreadSanitizer: one OS thread per lane and pthread barriers for the kernel's barriers, so a report is an
     # LDS / global access of two lanes that no barrier of the kernel orders (None where the toolchain cannot build it)
     "tsan": ["-fsanitize=thread", "-g"],
@@ -117,12 +118,23 @@ def test_kernel_body_as_built_for_the_product(emulators, kw):
     _check(emulators["product"], **kw)
 
 
-@pytest.mark.parametrize("kw", CASES[:4] + [dict(q32=1, from_counts=1, T=5, seed=2)], ids=lambda k: "-".join("%s%s" % kv for kv in sorted(k.items())) or "plain")
+@pytest.mark.parametrize("kw", CASES[:4] + [dict(q32=1, from_counts=1, T=5, seed=2), dict(T=1, window=16, seed=3), dict(policy=1, window=16, from_counts=1, T=3, seed=2)],
+                         ids=lambda k: "-".join("%s%s" % kv for kv in sorted(k.items())) or "plain")
 def test_other_prefetch_depths(emulators, kw):
     _check(emulators["variants"], **kw)
 
 
-@pytest.mark.parametrize("kw", [dict(policy=2, window=64)] + ([dict(from_counts=1), dict(q32=1)] if os.environ.get("RSEM_TSAN_ALL") else []), ids=lambda k: "-".join("%s%s" % kv for kv in sorted(k.items())))
+@pytest.mark.parametrize("kw", [dict(window=64), dict(policy=1, window=16, from_counts=1, T=3, seed=2), dict(q32=1, window=64)],
+                         ids=lambda k: "-".join("%s%s" % kv for kv in sorted(k.items())))
+def test_far_units_without_the_queue(emulators, kw, monkeypatch):
+    """The units with ids outside their window take the far-queue instantiation (a lane's partial counts for such ids wait in LDS and
+    leave by atomics the wave then waits for, estep_block.hpp FarQueue) -- every case above with `window`; the loop that issues a global
+    atomic per such count (option far_queue 0; the units of split rows) must give the same counts."""
+    monkeypatch.setenv("ESTEP_EMU_FAR_QUEUE", "0")
+    _check(emulators["product"], **kw)
+
+
+@pytest.mark.parametrize("kw", [dict(policy=2, window=64), dict(T=1, window=16, seed=3)] + ([dict(from_counts=1), dict(q32=1)] if os.environ.get("RSEM_TSAN_ALL") else []), ids=lambda k: "-".join("%s%s" % kv for kv in sorted(k.items())))
 def test_no_unordered_accesses_between_lanes(emulators, kw, monkeypatch):
     """The kernel body under ThreadSanitizer (a report makes the emulator exit with 66).  The one store that overlaps on purpose --
     every lane of a split read stores the same reciprocal -- goes through RSEM_STORE_SAME (simt_macros.hpp)."""

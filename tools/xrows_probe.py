@@ -4,6 +4,8 @@ layout policies for them, one workload generation per config, every variant chec
 matrix.  Variants are environment knobs read when a context lays its reads out:
     whole      RSEM_HIP_SPLIT=0                                   every read a whole row (ids outside: gather + global atomics)
     most       (round 5's rule) only reads that are mostly outside their window split
+    most_noq   RSEM_HIP_FAR_QUEUE=0                               ... the units with ids outside their window in the same launch as the others, a global atomic per far count
+               (until round 6; now a launch of their own whose far counts queue up in LDS: estep_block.hpp FarQueue)
     all_1s     RSEM_HIP_SPLIT_POLICY=all RSEM_HIP_X_OVERLAP=0     every read with an id outside splits; one stream
     all        RSEM_HIP_SPLIT_POLICY=all RSEM_HIP_X_OVERLAP=1     ... the split rows' chain beside the compact units (two streams)
 (Measured in round 6 and taken out again: id planes loaded in every slice of the split rows' units; the units with ids outside their
@@ -21,9 +23,9 @@ from oracle import pyoracle as orc  # noqa: E402  (the checker beside the measur
 from rsem_amd import capi  # noqa: E402
 from tools.synth_data import make_em_workload  # noqa: E402
 
-VARIANTS = {"whole": {"RSEM_HIP_SPLIT": "0"}, "most": {},
+VARIANTS = {"whole": {"RSEM_HIP_SPLIT": "0"}, "most": {}, "most_noq": {"RSEM_HIP_FAR_QUEUE": "0"},
             "all_1s": {"RSEM_HIP_SPLIT_POLICY": "all", "RSEM_HIP_X_OVERLAP": "0"}, "all": {"RSEM_HIP_SPLIT_POLICY": "all", "RSEM_HIP_X_OVERLAP": "1"},}
-KNOBS = ("RSEM_HIP_SPLIT", "RSEM_HIP_SPLIT_POLICY", "RSEM_HIP_X_OVERLAP")
+KNOBS = ("RSEM_HIP_SPLIT", "RSEM_HIP_SPLIT_POLICY", "RSEM_HIP_X_OVERLAP", "RSEM_HIP_FAR_QUEUE")
 
 configs = (sys.argv[1] if len(sys.argv) > 1 else "C3X,C3X30,C2R").split(",")
 variants = (sys.argv[2] if len(sys.argv) > 2 else "most,all_1s,all").split(",")
