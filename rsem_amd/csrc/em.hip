@@ -479,6 +479,10 @@ __global__ __launch_bounds__(kBlock) void k_solo_finish(int32_t M, double N0, co
 }
 
 // kFC: `theta` holds the previous round's raw counts, tsrc its totals (see ThetaSrc)
+#ifndef RSEM_FQ_DEPTH
+#define RSEM_FQ_DEPTH 3
+#endif
+constexpr int kFarQDepth = RSEM_FQ_DEPTH;  // register sets of the far-queue loop: loads two slices ahead, theta of far ids one slice ahead
 // kFQ: the launch over the units with ids outside their window (Unit::pad[0]; launch_estep deals them to a launch of their own): partial
 // counts for such ids queue up in LDS per wave (FarQueue, estep_block.hpp) -- 18 KB more per workgroup, three workgroups per CU
 // instead of four, which is why the compact units are not launched with it.
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void k_estep_lane(
         // (uniform over the workgroup)  split rows (F64X) only exist where theta is a plain array: the loops that read theta
         // out of the previous round's counts (kFC) are not taken for a layout with split rows (loop_wanted)
 #define RSEM_ESTEP_BLOCK_FQ(KK, QQ, XX) \
-    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), true, XX, true>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M, xa, fq)
+    estep_block<KK, kFC, QQ, kFarQDepth, true, XX, true>(S, s_begin, s_end, lane, U.base, U.span, theta, tsrc, N0, th_win, cnt_win, sval, sexp, ssid, sncp, masks, counts, noise, neff, M, xa, fq)
         const int code = (S.K - 1) | ((S.fmt == kFmtQ32 ? 1 : 0) << 2) | ((U.pad[0] != 0 ? 1 : 0) << 3) | (((!kFC && S.fmt == kFmtF64X) ? 1 : 0) << 4);
         if constexpr (kFQ) {
             // (every unit of this launch takes the loop with the far path and the queue: a unit without ids outside never uses either)
@@ -1017,8 +1021,15 @@ int partition_units(rsem_em_ctx* c) {
     auto is_main = [](const Unit& u) { return u.S.fmt != kFmtF64X; };
     const auto mid = std::stable_partition(c->h_units.begin(), c->h_units.end(), is_main);
     c->n_units_main = (uint32_t)(mid - c->h_units.begin());
-    const auto midc = std::stable_partition(c->h_units.begin(), mid, [](const Unit& u) { return u.pad[0] == 0; });
-    c->n_units_compact = c->far_queue ? (uint32_t)(midc - c->h_units.begin()) : c->n_units_main;
+    // The far-queue launch takes the units with FEW entries outside their window per slice -- reads of a gene that also hit a couple of
+    // transcripts elsewhere: the queue then empties every few slices; a unit of reads without a gene, half of whose entries are
+    // outside, would empty it before every slice and is better off with its atomics inline (configs[1]'s size without genes: 0.634
+    // against 0.650 ms, profiles/r06g_xrows_probe.log) -- and only where such units are worth a launch of their own (one unit in
+    // twenty-five; configs[2] itself has 53 among 3 903 and paid 1 % for the second stream).
+    auto queued = [](const Unit& u) { return u.pad[0] != 0 && (uint64_t)u.pad[1] <= 48ull * u.n_slices; };
+    const auto midc = std::stable_partition(c->h_units.begin(), mid, [&](const Unit& u) { return !queued(u); });
+    const uint32_t n_first = (uint32_t)(midc - c->h_units.begin());
+    c->n_units_compact = (c->far_queue && (c->n_units_main - n_first) * 25ull >= c->n_units_main) ? n_first : c->n_units_main;
     if (c->n_units_compact != c->n_units_main && c->n_units)
         RSEM_HIP_TRY(hipMemcpyAsync(c->d_units, c->h_units.data(), sizeof(Unit) * c->n_units, hipMemcpyHostToDevice, c->stream));
     if (c->n_units_main != c->n_units && c->n_units)

@@ -91,6 +91,7 @@ struct SliceRegs {
     int e;
     double x;        // split rows: the far part of the normaliser
     uint32_t slot0;  // first row slot of the slice (split rows: where the reciprocal goes)
+    double traw[K];  // kFQ: the theta source's words for the ids outside the window, requested a slice ahead (pregather)
 };
 
 // 2^e for the exponents q32_scale_of admits (always a normal double)
@@ -150,6 +151,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
                                    const double* __restrict__ sncp, const unsigned long long* __restrict__ masks,
                                    double* counts, double& noise, double& neff, int M, const XArgs& X = XArgs(), const FarQueue& FQ = FarQueue()) {
     static_assert(!kFQ || kFar, "the far queue belongs to the loop of the units with ids outside their window");
+    static_assert(!kFQ || NBUF >= 3, "the far-queue loop requests theta a slice ahead: three register sets at least (the ring loop)");
     using ValT = typename std::conditional<kQ, uint32_t, double>::type;
     const ValT* __restrict__ scp = (const ValT*)(sval + S.val_base);  // this shape's value planes
     const int lg = S.lg;
@@ -186,7 +188,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
         // is slower: 0.971 against 0.936 ms at configs[2], Q32 0.713 against 0.700, profiles/r03t; tried again in round 6 for the
         // units of split rows alone, where a tuple starts in most slices: no difference either way, profiles/r06b_xrows_probe.log,
         // r06c_xrows_probe.log.)
-        if (m != 0ull) {
+        if (kFQ || m != 0ull) {  // (the far-queue loop reads the ids of every slice: a tuple starts in nearly all of them, and pregather wants no branch)
             const int32_t* __restrict__ ip = ssid + (S.plane_base * 64 + v0);
 #pragma unroll
             for (int k = 0; k < K; k++) b.id[k] = ip[k * 64 + ulane];
@@ -238,6 +240,20 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
     for (int k = 0; k < K; k++) { rsid[k] = 0; rth[k] = 0.0; acc[k] = 0.0; }
     ThetaSrc th{theta, 0.0, 1.0};
     double th0 = 0.0;
+    // kFQ: theta of the ids outside the window is requested ONE SLICE AHEAD of its use -- until round 6 a lane that started a tuple
+    // with such an id asked for it inside reduce() and the wave waited a whole round trip to memory, every slice of a unit of
+    // far-reaching reads.  Every lane issues its K loads whatever it needs (word 0 where it needs none: a cache hit), so that no
+    // path through the loop has fewer loads in flight than another and the compiler's waits stay exact.
+    auto pregather = [&](SliceRegs<K, kQ>& b, unsigned long long m) {
+        if (!kFQ) return;
+        const bool starts = ((m >> lane) & 1ull) != 0ull;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int sidv = b.id[k];
+            const bool want = starts && !((unsigned)(sidv - base) < (unsigned)span);
+            b.traw[k] = th.v[want ? sidv : 0];
+        }
+    };
     auto reduce = [&](const SliceRegs<K, kQ>& cur, unsigned long long cur_m) {
         if (cur_m != 0ull) {                 // wave-uniform
             far_queue_room(false);
@@ -260,7 +276,12 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
                     rth[k] = th_win[in ? off : 0u];
                     far = far || !in;
                 }
-                if (kFar && far) {
+                if (kFQ) {  // (requested a slice ago: pregather)
+#pragma unroll
+                    for (int k = 0; k < K; k++)
+                        if (!((unsigned)(rsid[k] - base) < (unsigned)span))
+                            rth[k] = kFC ? (cur.traw[k] + (rsid[k] == 0 ? th.extra0 : 0.0)) / th.sum : cur.traw[k];
+                } else if (kFar && far) {
                     double t[K];
 #pragma unroll
                     for (int k = 0; k < K; k++) {
@@ -348,6 +369,7 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
             mk[j] = mask_of(tt);
             issue(tt, mk[j], buf[j]);
         }
+        pregather(buf[0], mk[0]);
         uint32_t s = s_begin;
         for (; s + NBUF <= s_end; s += NBUF) {
 #pragma unroll
@@ -357,12 +379,16 @@ RSEM_DEVFN void estep_block(const Shape& S, uint32_t s_begin, uint32_t s_end, in
                 const uint32_t tt = within(s + j + ahead);
                 mk[nj] = mask_of(tt);
                 issue(tt, mk[nj], buf[nj]);
+                pregather(buf[(j + 1) % NBUF], mk[(j + 1) % NBUF]);  // (the slice behind this one: its ids were requested a step ago)
                 reduce(buf[j], mk[j]);
             }
         }
 #pragma unroll
         for (int j = 0; j < NBUF - 1; j++)
-            if (s + j < s_end) reduce(buf[j], mk[j]);  // (uniform over the wave)
+            if (s + j < s_end) {  // (uniform over the wave)
+                if (j > 0) pregather(buf[j], mk[j]);
+                reduce(buf[j], mk[j]);
+            }
     }
     far_queue_room(false);
     spill(rsid, acc);

@@ -794,7 +794,7 @@ struct Unit {
     uint32_t per_wave;     // wave w walks slices [slice_begin + w * per_wave, + per_wave)
     int32_t base;
     int32_t span;          // sids [base, base + span) are staged in LDS (<= the window capacity)
-    int32_t pad[2];        // pad[0]: 1 = some id of the unit lies outside [base, base + span) (sell_flag_far_units)
+    int32_t pad[2];        // pad[0]: 1 = some id of the unit lies outside [base, base + span), pad[1]: how many entries (sell_flag_far_units)
     Shape S;               // copy of the shape: one dependent load less at the start of every workgroup
 };
 
@@ -878,16 +878,19 @@ inline int sell_build_units(const SellLayout& L, std::vector<Unit>& units, int w
 __host__ __device__ inline bool unit_entry_is_far(const Unit& U, int32_t v) { return v > 0 && (unsigned)(v - U.base) >= (unsigned)U.span; }
 
 __global__ __launch_bounds__(256) void k_unit_far(Unit* units, const int32_t* __restrict__ ssid) {
-    __shared__ int any;
-    if (threadIdx.x == 0) any = 0;
+    __shared__ int n_far;
+    if (threadIdx.x == 0) n_far = 0;
     __syncthreads();
     const Unit U = units[blockIdx.x];
     const uint64_t p0 = (U.S.plane_base + (uint64_t)U.slice_begin * U.S.K) * 64, n = (uint64_t)U.n_slices * U.S.K * 64;
-    bool far = false;
-    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) far = far || unit_entry_is_far(U, ssid[p0 + i]);
-    if (far) any = 1;
+    int mine = 0;
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) mine += unit_entry_is_far(U, ssid[p0 + i]) ? 1 : 0;
+    if (mine) atomicAdd(&n_far, mine);
     __syncthreads();
-    if (threadIdx.x == 0) units[blockIdx.x].pad[0] = any;
+    if (threadIdx.x == 0) {
+        units[blockIdx.x].pad[0] = n_far != 0;
+        units[blockIdx.x].pad[1] = n_far;  // how many: the far-queue launch takes the units with few of them per slice (em.hip partition_units)
+    }
 }
 
 inline int sell_flag_far_units(const SellLayout& L, std::vector<Unit>& units, Unit* d_units, hipStream_t st) {

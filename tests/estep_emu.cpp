@@ -61,7 +61,7 @@ static void lane_body(Job* J, int tid) {
     fq.sid = J->fq_sid[w]; fq.val = J->fq_val[w]; fq.n = &J->fq_n[w];
     if (lane == 0) J->fq_n[w] = 0;
 #define EMU_BLOCK_FQ(KK, QQ)                                                                                                          \
-    estep_block<KK, kFC, QQ, (QQ ? kQ32Depth[KK - 1] : kF64Depth[KK - 1]), true, false, true>(S, s_begin, s_end, lane, J->base, J->span, J->theta, tsrc, J->N0, \
+    estep_block<KK, kFC, QQ, 3, true, false, true>(S, s_begin, s_end, lane, J->base, J->span, J->theta, tsrc, J->N0, \
         J->th_win, J->cnt_win, H.sval.data(), H.sexp.data(), H.ssid.data(), H.sncp.data(), H.masks.data(), J->counts, noise, neff, J->M, J->xa, fq)
     // the dispatch of k_estep_lane (em.hip); the units with ids outside their window (not those of split rows) go to the launch with the
     // far queue, as launch_estep deals them
