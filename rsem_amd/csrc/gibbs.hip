@@ -633,8 +633,10 @@ int rsem_gibbs_create(rsem_gibbs_ctx** out, int device, int32_t M, uint64_t N1, 
             rsem_gibbs_destroy(c);
             return RSEM_ERR_INVALID;
         }
-    if (alpha) gx_prior::gx_build_tiles(N1, row_ptr, tiles);  // (--prior: tiles of 3072 items)
-    else gx_build_tiles(N1, row_ptr, tiles);
+    uint64_t soft_cap = 0;  // measurement knob: tiles closed at fewer items than LDS holds (gx_build_tiles)
+    if (const char* e = getenv("RSEM_GX_TILE_ITEMS")) soft_cap = strtoull(e, nullptr, 10);
+    if (alpha) gx_prior::gx_build_tiles(N1, row_ptr, tiles, soft_cap);  // (--prior: tiles of 3072 items)
+    else gx_build_tiles(N1, row_ptr, tiles, soft_cap);
     c->n_tiles = (uint32_t)tiles.size() - 1;
     std::vector<uint64_t> tile_items(tiles.size());
     for (size_t i = 0; i < tiles.size(); i++) tile_items[i] = row_ptr[tiles[i]];
@@ -843,7 +845,7 @@ int rsem_gibbs_run_chains(rsem_gibbs_ctx* c, int mode, int nchains, const uint32
             if (const char* e = getenv("RSEM_GX_SPIN_LIMIT")) ta.spin_limit = strtoull(e, nullptr, 10);  // ticks of 10 ns; tests
         }
         if (W > 1) {  // what the workgroups of a team tell each other through
-            const size_t rows = (size_t)c->M + 2;
+            const size_t rows = 2 * ((size_t)c->M + 2);  // (both copies of each table: XTeam)
             RSEM_HIP_TRY(t_ctl.alloc(sizeof(XTeamCtl) * nchains));
             RSEM_HIP_TRY(t_net.alloc(sizeof(uint32_t) * rows * ta.nw * nchains));
             RSEM_HIP_TRY(t_gnet.alloc(sizeof(uint32_t) * rows * 2 * nchains));

@@ -21,8 +21,11 @@
 //      step 1; once tiles 0 .. w-1 are final, tile w reads their final cells and is final one iteration later: at most W
 //      iterations, in practice two or three, and a pass in which nobody publishes leaves every tile consistent with all
 //      earlier ones -- the sequential chain's state (induction over the tile index, as inside a tile over the thread index);
-//   5. commit: counts and z, the workgroup's cells and reference counts taken back (the tables are all-bias / all-zero between
-//      windows); team barrier; next window.
+//   5. commit: counts and z; team barrier; next window.  The workgroup's cells and reference counts are taken back BEHIND that
+//      barrier, beside the next window's first phase: the tables exist twice and a window uses the copy of its parity, so nobody
+//      reads what is being taken back, and the take-backs are performed before the workgroup arrives at the next team barrier --
+//      a window before the copy is used again (until round 6 they stood in front of the barrier: 6 of a moved read's 8 commit
+//      atomics, all 256 workgroups at once).  Between sweeps both copies are all-bias / all-zero.
 // Values read while another workgroup is still publishing are intermediate guesses like any other: only the pass in which
 // nothing is published decides, and in that pass nothing is written.  The random stream is position-addressed: read r of a sweep
 // takes the r-th output of the sweep whoever visits it, every workgroup carries its own copy of the generator and twists it
@@ -99,9 +102,10 @@ struct XTeamCtl {
 struct XTeam {
     int W, tw;             // workgroups of the team, this one's index
     XTeamCtl* ctl;
-    uint32_t* net;         // [(M + 2)][nw] words of two cells: cell w of id s = what workgroup w's tile adds to counts[s] (+ bias)
-    uint32_t* gnet;        // [(M + 2)][2] words: cell g = the sum over workgroups 16 g .. 16 g + 15 (+ bias)
-    int32_t* ref;          // [(M + 2)] moves of the window that hold a reference on the id (0: every cell of the id is at bias)
+    // each table twice: copy (window & 1) behind the other, (M + 2) rows apart
+    uint32_t* net;         // [2][(M + 2)][nw] words of two cells: cell w of id s = what workgroup w's tile adds to counts[s] (+ bias)
+    uint32_t* gnet;        // [2][(M + 2)][2] words: cell g = the sum over workgroups 16 g .. 16 g + 15 (+ bias)
+    int32_t* ref;          // [2][(M + 2)] moves of the window that hold a reference on the id (0: every cell of the id is at bias)
     uint32_t nw;           // words per row of net: roundup(W, 16) / 2
     const XSlot* slots;
     uint32_t n_win;
@@ -237,14 +241,34 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
     for (int i = 0; i < 4; i++)
         if (i < grp) { m_g |= 0xFFFFull << (16 * i); ++n_cells; }
     const int bias_total = n_cells * (int)kXBias;
-    const size_t dummy_row = (size_t)tm.M + 1;
+    const int dummy_id = tm.M + 1;
     auto swar = [](unsigned long long v) -> int {  // the sum of the four 16-bit fields
         const unsigned long long t = (v & 0x0000FFFF0000FFFFull) + ((v >> 16) & 0x0000FFFF0000FFFFull);
         return (int)(unsigned)((t + (t >> 32)) & 0xFFFFFFFFull);
     };
-    auto cell_add = [&](int s, int delta) {  // this workgroup's cell of id s, and its group's
-        GX_G_ADD32(&tm.net[(size_t)s * tm.nw + (size_t)(tw >> 1)], (uint32_t)delta << (16 * (tw & 1)));
-        GX_G_ADD32(&tm.gnet[(size_t)s * 2 + (size_t)(grp >> 1)], (uint32_t)delta << (16 * (grp & 1)));
+    // the tables' rows of id s in the copy window `wn` uses
+    auto trow = [&](uint32_t wn, int s) -> size_t { return (size_t)(wn & 1u) * ((size_t)tm.M + 2) + (size_t)s; };
+    auto cell_add_at = [&](size_t row, int delta) {  // this workgroup's cell of a row, and its group's
+        GX_G_ADD32(&tm.net[row * tm.nw + (size_t)(tw >> 1)], (uint32_t)delta << (16 * (tw & 1)));
+        GX_G_ADD32(&tm.gnet[row * 2 + (size_t)(grp >> 1)], (uint32_t)delta << (16 * (grp & 1)));
+    };
+    // The move this thread's read published in the previous window, taken back (see the head of the file): that window's copy of
+    // the tables is not read again before the window after this one, and the atomics are performed before this workgroup's next
+    // arrival at a team barrier.  Issued behind the first draw, where nothing waits for memory until the phase's barrier.  What is to
+    // be taken back waits in LDS (L->tb_old / tb_pub; equal: nothing), not in registers: the kernel has none to spare.
+    bool tb_any = false;  // (uniform) the previous window published
+    auto take_back = [&](uint32_t prev_win) {
+        if (tb_any) {  // (uniform)
+            const int o = rd ? L->tb_old[g] : 0, p = rd ? L->tb_pub[g] : 0;
+            if (o != p) {
+                const size_t ro = trow(prev_win, o), rp_ = trow(prev_win, p);
+                cell_add_at(ro, 1);
+                cell_add_at(rp_, -1);
+                GX_G_ADD32(&tm.ref[ro], -1);
+                GX_G_ADD32(&tm.ref[rp_], -1);
+            }
+            tb_any = false;
+        }
     };
 
     struct Ahead {
@@ -487,6 +511,7 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
             if (mine) z_new = draw(std::false_type{});
             lap(3);
         }
+        take_back(win - 1u);
         // ---- the phases of a window ---------------------------------------------------------------------------------------------------
         // A phase = take what the EARLIER tiles of the window published (not in the first phase), one resolve round inside the tile
         // (gibbs_exact_wg.hpp, step 4: the movers enter their endpoints, every item gets the delta of the earlier reads of the
@@ -502,7 +527,7 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
                 if (phase > 0 && tw > 0 && nr > 0) {  // (uniform over the workgroup)
                     int rf[kXPlanes];
 #pragma unroll
-                    for (int u = 0; u < kXPlanes; u++) rf[u] = GX_G_LOAD32(&tm.ref[sj[u]]);
+                    for (int u = 0; u < kXPlanes; u++) rf[u] = GX_G_LOAD32(&tm.ref[trow(win, sj[u])]);
                     // All loads of a step are issued whether needed or not (an item that needs none reads row M + 1, which nobody
                     // writes): no load waits for a decision.  Words that hold no earlier workgroup's cell are not loaded at all.
                     auto take = [&](auto n_words, auto with_groups) {
@@ -515,7 +540,7 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
                             for (int i = 0; i < kXStep; i++) {
                                 const int u = u0 + i;
                                 const uint32_t j = (uint32_t)u * kXThr + g;
-                                const size_t row = (j < T && rf[u] != 0) ? (size_t)sj[u] : dummy_row;
+                                const size_t row = trow(win, (j < T && rf[u] != 0) ? sj[u] : dummy_id);
                                 const unsigned long long* pn = (const unsigned long long*)(tm.net + row * tm.nw + (size_t)grp * 8);
                                 const unsigned long long* pg = (const unsigned long long*)(tm.gnet + row * 2);
 #pragma unroll
@@ -679,13 +704,14 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
                 if (W > 1) {
                     const bool ch = mine && z_new != z_pub;
                     if (ch) {
-                        cell_add(z_pub, -1);
-                        cell_add(z_new, 1);
+                        const size_t r_pub = trow(win, z_pub), r_new = trow(win, z_new), r_old = trow(win, z_old);
+                        cell_add_at(r_pub, -1);
+                        cell_add_at(r_new, 1);
                         // a published move holds one reference on either endpoint
-                        if (z_pub == z_old) GX_G_ADD32(&tm.ref[z_old], 1);
-                        else GX_G_ADD32(&tm.ref[z_pub], -1);
-                        if (z_new == z_old) GX_G_ADD32(&tm.ref[z_old], -1);
-                        else GX_G_ADD32(&tm.ref[z_new], 1);
+                        if (z_pub == z_old) GX_G_ADD32(&tm.ref[r_old], 1);
+                        else GX_G_ADD32(&tm.ref[r_pub], -1);
+                        if (z_new == z_old) GX_G_ADD32(&tm.ref[r_old], -1);
+                        else GX_G_ADD32(&tm.ref[r_new], 1);
                         z_pub = z_new;
                     }
                     const unsigned long long cb = GX_BALLOT(ch);
@@ -713,14 +739,14 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
                 z[r0 + g] = z_new;
             }
             if (W > 1) {
-                if (!win_long && mine && z_pub != z_old) {  // take the published move back: the tables are clean between windows
-                    cell_add(z_old, 1);
-                    cell_add(z_pub, -1);
-                    GX_G_ADD32(&tm.ref[z_old], -1);
-                    GX_G_ADD32(&tm.ref[z_pub], -1);
-                }
                 // every workgroup's updates of counts are performed before anybody gathers for the next window
                 if (gx_team_barrier(g, L, tm, epoch, nbar, false) < 0) return false;
+                // the published move is taken back beside the next window's first phase (take_back above; every thread writes
+                // and reads its own words)
+                if (!win_long) {  // (uniform)
+                    if (rd) { L->tb_old[g] = mine ? z_old : 0; L->tb_pub[g] = mine ? z_pub : 0; }
+                    tb_any = true;
+                }
             } else {
                 GX_BLOCK_SYNC();  // (the next tile's staging overwrites what a draw may still be reading)
             }
@@ -734,6 +760,7 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
         lap(13);
         if (RSEM_GX_PROFILE && nr > 0) pa[7] += 1;
     }
+    take_back(tm.n_win - 1u);
     // ---- the generator after the sweep (workgroup 0 hands it on) ----------------------------------------------------------------------
     if (tw == 0) {
         if (tm.N1 > 0) {
@@ -760,9 +787,9 @@ GX_DEVFN bool gibbs_exact_team_body(int g, XTile* L, const XTeam& tm, const uint
 struct TeamArgs {  // what every workgroup of every team needs (one argument: cooperative launches take an array of pointers)
     int W, nchains;
     XTeamCtl* ctl;       // [nchains]
-    uint32_t* net;       // [nchains][(M + 2) * nw]
-    uint32_t* gnet;      // [nchains][(M + 2) * 2]
-    int32_t* ref;        // [nchains][M + 2]
+    uint32_t* net;       // [nchains][2][(M + 2) * nw]
+    uint32_t* gnet;      // [nchains][2][(M + 2) * 2]
+    int32_t* ref;        // [nchains][2][M + 2]
     uint32_t nw;
     const XSlot* slots;  // [n_win][W]
     uint32_t n_win;
@@ -797,9 +824,9 @@ __global__ __launch_bounds__(kXThr) void k_gibbs_exact_team(TeamArgs ta, const u
     tm.W = ta.W;
     tm.tw = tw;
     tm.ctl = ta.ctl ? ta.ctl + chain : nullptr;
-    tm.net = ta.net ? ta.net + (size_t)chain * ((size_t)ta.M + 2) * ta.nw : nullptr;
-    tm.gnet = ta.gnet ? ta.gnet + (size_t)chain * ((size_t)ta.M + 2) * 2 : nullptr;
-    tm.ref = ta.ref ? ta.ref + (size_t)chain * ((size_t)ta.M + 2) : nullptr;
+    tm.net = ta.net ? ta.net + (size_t)chain * 2 * ((size_t)ta.M + 2) * ta.nw : nullptr;
+    tm.gnet = ta.gnet ? ta.gnet + (size_t)chain * 2 * ((size_t)ta.M + 2) * 2 : nullptr;
+    tm.ref = ta.ref ? ta.ref + (size_t)chain * 2 * ((size_t)ta.M + 2) : nullptr;
     tm.nw = ta.nw;
     tm.slots = ta.slots;
     tm.n_win = ta.n_win;

@@ -88,7 +88,7 @@ constexpr int kXPlanes = kXCap / kXThr;  // items per thread in the item-major p
 struct GxMtState { uint32_t mt[624]; int idx; };  // a chain's MT19937 between launches (layout of gibbs.hip's MtState)
 
 constexpr int kXBits = 8192;
-struct XTile {  // the workgroup's LDS: 151 KB (--prior: 156 KB) of the CU's 160 KB
+struct XTile {  // the workgroup's LDS: 153 KB (--prior: 158 KB) of the CU's 160 KB
     unsigned long long rp[kXT + 1];
     unsigned long long ends[kXKeys][2][kXW];  // per entry: the threads that move TO the id / FROM the id (all zero between rounds)
     int32_t key[kXKeys];                      // id + 1 of the entry, 0 = free (all zero between rounds)
@@ -105,13 +105,18 @@ struct XTile {  // the workgroup's LDS: 151 KB (--prior: 156 KB) of the CU's 160
     int idx;
     // the team of workgroups of gibbs_exact_team.hpp: which waves published a change; what the team barrier returned
     unsigned long long pub[kXW];
+    int32_t tb_old[kXT], tb_pub[kXT];  // the move a read published in the previous window, to be taken back (equal: none)
     unsigned long long team_epoch;
     int team_res;
 };
 
 // Tiles: greedy cut into runs of <= kXT consecutive reads holding <= kXCap items; a read with more items than that is a tile
-// of its own (walked over global memory).  Depends on the row pointers only.  (Host; also tests/gibbs_exact_emu.cpp.)
-inline void gx_build_tiles(uint64_t N1, const uint64_t* row_ptr, std::vector<uint32_t>& tiles) {
+// of its own (walked over global memory).  Depends on the row pointers only.  (Host; also the emulators.)
+// `soft_cap` (0: none): a tile is closed at that many items although LDS would hold more (a measurement knob: tiles that differ less
+// in their item-major phases; 3300 / 3500 / 3700 items against 4096 at configs[2]'s shape: 105 / 102 / 103 against 101 ms per round,
+// profiles/r06i_*).  The chain does not depend on the cut.
+inline void gx_build_tiles(uint64_t N1, const uint64_t* row_ptr, std::vector<uint32_t>& tiles, uint64_t soft_cap = 0) {
+    const uint64_t cap = soft_cap > 0 && soft_cap < (uint64_t)kXCap ? soft_cap : (uint64_t)kXCap;
     tiles.clear();
     tiles.reserve(N1 / 200 + 2);
     uint64_t i = 0;
@@ -119,7 +124,7 @@ inline void gx_build_tiles(uint64_t N1, const uint64_t* row_ptr, std::vector<uin
         tiles.push_back((uint32_t)i);
         const uint64_t b = row_ptr[i];
         uint64_t e = i + 1;  // the first read always belongs to the tile
-        while (e < N1 && e - i < (uint64_t)kXT && row_ptr[e + 1] - b <= (uint64_t)kXCap) ++e;
+        while (e < N1 && e - i < (uint64_t)kXT && row_ptr[e + 1] - b <= cap) ++e;
         i = e;
     }
     tiles.push_back((uint32_t)N1);

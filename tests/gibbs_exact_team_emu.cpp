@@ -112,8 +112,8 @@ int main(int argc, char** argv) {
 
     // the team's tables: all bias / all zero between windows (checked after every sweep)
     const uint32_t nw = (uint32_t)(((W + 15) / 16) * 16 / 2);
-    std::vector<uint32_t> net((size_t)(M + 2) * nw, kXBias | (kXBias << 16)), gnet((size_t)(M + 2) * 2, kXBias | (kXBias << 16));
-    std::vector<int32_t> ref((size_t)M + 2, 0);
+    std::vector<uint32_t> net((size_t)2 * (M + 2) * nw, kXBias | (kXBias << 16)), gnet((size_t)2 * (M + 2) * 2, kXBias | (kXBias << 16));
+    std::vector<int32_t> ref((size_t)2 * (M + 2), 0);  // (two copies of each: a window uses the one of its parity)
     XTeamCtl ctl;
     memset(&ctl, 0, sizeof(ctl));
 
