@@ -26,15 +26,26 @@ namespace rsemh {
 struct BgzfDeflater {
     z_stream zs;
     bool live = false;
+    int tune[4] = {0, 0, 0, 0}, nt = 0;
     static constexpr size_t kBlock = 0xff00;  // input bytes per block, as htslib cuts them
     ~BgzfDeflater() { if (live) deflateEnd(&zs); }
     // append the BGZF block of p[0..n), n <= kBlock, to out
     void block(const uint8_t* p, size_t n, std::vector<uint8_t>& out) {
         if (!live) {
             memset(&zs, 0, sizeof(zs));
-            if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("zlib deflateInit2 failed");
+            // zlib's level 6 (what the reference's samtools writes BAM with) walks hash chains of up to 128 candidates and stops at a
+            // match of 128 bytes; a transcript BAM repeats a read's sequence and qualities in every one of its alignments' records
+            // (the longest match sits at the head of the chain) and its qualities match nothing anywhere.  Chains of 16 and no early
+            // stop (matches up to 258) deflate 1.6 x as fast AND 0.9 % smaller on the bench's input (30 -> 49 MB/s per thread, 524.8 ->
+            // 520.1 MB at 2 % of configs[2]; profiles/r06m_*, r06n_*: level 4 is as fast and 0.3 % larger, level 1 2.5 x and 6 % larger).
+            // RSEM_HIP_DEFLATE="level[,memLevel[,good,lazy,nice,chain]]" overrules (measurement knob; "6,8" = zlib's own level 6).
+            int lv = Z_DEFAULT_COMPRESSION, ml = 8;
+            nt = 6; tune[0] = 8; tune[1] = 16; tune[2] = 258; tune[3] = 16;
+            if (const char* e = getenv("RSEM_HIP_DEFLATE")) nt = sscanf(e, "%d,%d,%d,%d,%d,%d", &lv, &ml, &tune[0], &tune[1], &tune[2], &tune[3]);
+            if (deflateInit2(&zs, lv, Z_DEFLATED, -15, nt >= 2 ? ml : 8, Z_DEFAULT_STRATEGY) != Z_OK) die("zlib deflateInit2 failed");
             live = true;
         } else if (deflateReset(&zs) != Z_OK) die("zlib deflateReset failed");
+        if (nt == 6) (void)deflateTune(&zs, tune[0], tune[1], tune[2], tune[3]);  // (a reset restores the level's own)
         const size_t at = out.size();
         out.resize(at + 0x10000);
         uint8_t* o = out.data() + at;
@@ -784,8 +795,53 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
             bi = be;
             C.last = bi >= blks.size();
         };
-        // frame: the records of the chunk, what is left over for the next one
+        // frame: the records of the chunk, what is left over for the next one.  One walk over the length words is a chain of cache
+        // misses (2 GB/s: 11.3 s beside the stages at 10 % of configs[2], which the pass cannot get below once deflate is faster,
+        // profiles/r06g_e2e_bam_10pct_bam_input.log), so the chunk is cut into segments that are walked at the same time: segment 0 from
+        // the known start, every other one from a GUESSED record start -- the first offset in the segment at which a chain of
+        // plausible record headers begins (lengths that fit each other, a reference id the header knows, a printable NUL-terminated
+        // name).  A guess is never trusted: the walks are stitched in order, and a segment's records are taken only if the walk
+        // before it (itself verified) arrives exactly at the segment's first record; otherwise that stretch is walked again from
+        // the verified position (never seen on real files; the tests force it).
         double frame_s = 0.0;
+        const int32_t n_ref_in = (int32_t)in.header.names.size();
+        int frame_threads = std::max(1, std::min(16, nthreads / 4));
+        if (const char* e = getenv("RSEM_HIP_BAM_FRAME_THREADS")) frame_threads = std::max(1, atoi(e));  // (tests)
+        uint64_t seg_taken = 0, seg_again = 0;  // guessed segments whose records were taken / stretches walked again
+        size_t frame_seg_bytes = (size_t)4 << 20;  // a segment is worth a thread from here on (tests: RSEM_HIP_BAM_FRAME_SEG)
+        if (const char* e = getenv("RSEM_HIP_BAM_FRAME_SEG")) frame_seg_bytes = std::max<size_t>(1, (size_t)atoll(e));
+        const bool frame_force_bad = getenv("RSEM_HIP_BAM_BAD_GUESS") != nullptr;  // tests: every guess a record late, or none
+        auto plausible = [n_ref_in](const uint8_t* buf, size_t n, size_t p, size_t& next) -> bool {
+            if (p + 36 > n) return false;
+            int32_t bs, refid, pos, lseq;
+            memcpy(&bs, buf + p, 4);
+            if (bs < 32 || bs > (1 << 28)) return false;
+            memcpy(&refid, buf + p + 4, 4);
+            memcpy(&pos, buf + p + 8, 4);
+            memcpy(&lseq, buf + p + 20, 4);
+            const unsigned lname = buf[p + 12], ncig = (unsigned)buf[p + 16] | ((unsigned)buf[p + 17] << 8);
+            if (refid < -1 || refid >= n_ref_in || pos < -1 || lname < 1 || lseq < 0) return false;
+            if (32ull + lname + 4ull * ncig + ((uint64_t)lseq + 1) / 2 + (uint64_t)lseq > (uint64_t)bs) return false;
+            if (p + 36 + lname > n) return false;  // (only what can be checked whole is plausible)
+            if (buf[p + 36 + lname - 1] != 0) return false;
+            for (unsigned i = 0; i + 1 < lname; i++) { const uint8_t ch = buf[p + 36 + i]; if (ch < 33 || ch > 126) return false; }
+            next = p + 4 + (size_t)bs;
+            return true;
+        };
+        // the records from `pos` on whose length words lie before `lim` (and that are complete in the chunk); returns where it stopped
+        auto walk = [](const uint8_t* buf, size_t n, size_t pos, size_t lim, std::vector<uint64_t>& rec, bool& cut) -> size_t {
+            cut = false;
+            while (pos < lim && pos + 4 <= n) {
+                int32_t bs;
+                memcpy(&bs, buf + pos, 4);
+                if (bs < 32) die("input BAM: corrupt alignment record");
+                if (pos + 4 + (size_t)bs > n) { cut = true; break; }
+                __builtin_prefetch(buf + pos + 4 + (size_t)bs + 1024);  // (a record's length word lies ~3 lines behind the last)
+                rec.push_back(pos);
+                pos += 4 + (size_t)bs;
+            }
+            return pos;
+        };
         auto frame_chunk = [&](Chunk& C) {
             const auto t0 = std::chrono::steady_clock::now();
             const uint8_t* buf = C.buf.p;
@@ -793,14 +849,57 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
             size_t pos = 0;
             if (skip) { const size_t k = (size_t)std::min<uint64_t>(skip, n); pos = k; skip -= k; }
             C.rec.clear();
-            while (pos + 4 <= n) {
-                int32_t bs;
-                memcpy(&bs, buf + pos, 4);
-                if (bs < 32) die("input BAM: corrupt alignment record");
-                if (pos + 4 + (size_t)bs > n) break;
-                __builtin_prefetch(buf + pos + 4 + (size_t)bs + 1024);  // (the walk is a chain of misses otherwise: a record's length word lies ~3 lines behind the last)
-                C.rec.push_back(pos);
-                pos += 4 + (size_t)bs;
+            const size_t span = n > pos ? n - pos : 0;
+            const int K = (int)std::max<size_t>(1, std::min<size_t>((size_t)frame_threads, span / frame_seg_bytes + 1));
+            if (K == 1 && !frame_force_bad) {
+                bool cut;
+                pos = walk(buf, n, pos, n, C.rec, cut);
+            } else {
+                const int KK = std::max(K, frame_force_bad ? 3 : 1);
+                struct Seg { size_t lo = 0, first = 0, stop = 0; bool found = false, cut = false; std::vector<uint64_t> rec; };
+                std::vector<Seg> seg((size_t)KK);
+                for (int k = 0; k < KK; k++) seg[k].lo = pos + span * (size_t)k / (size_t)KK;
+                auto run_seg = [&](int k) {
+                    Seg& S = seg[k];
+                    const size_t lim = k + 1 < KK ? seg[k + 1].lo : n;
+                    if (k == 0) { S.first = S.lo; S.found = true; }
+                    else {
+                        for (size_t q = S.lo; q < lim && !S.found; q++) {
+                            size_t a = q, nx;
+                            int ok = 0;
+                            while (ok < 6 && plausible(buf, n, a, nx)) { ++ok; a = nx; if (a + 36 > n) break; }
+                            if (ok >= 6 || (ok >= 1 && a + 36 > n)) { S.first = q; S.found = true; }
+                        }
+                        if (S.found && frame_force_bad) {  // (tests) a wrong guess: the record behind the first one / no guess at all
+                            int32_t bs;
+                            memcpy(&bs, buf + S.first, 4);
+                            S.first += 4 + (size_t)bs;
+                            if ((k & 1) == 0 || S.first >= lim) S.found = false;
+                        }
+                    }
+                    if (S.found) S.stop = walk(buf, n, S.first, lim, S.rec, S.cut);
+                };
+                {
+                    std::vector<std::thread> th;
+                    for (int k = 1; k < KK; k++) th.emplace_back(run_seg, k);
+                    run_seg(0);
+                    for (auto& t : th) t.join();
+                }
+                // stitch: `pos` = the verified position; a segment is taken if its first record is where the verified walk arrived
+                bool cut = false;
+                for (int k = 0; k < KK && !cut; k++) {
+                    Seg& S = seg[k];
+                    const size_t lim = k + 1 < KK ? seg[k + 1].lo : n;
+                    if (S.found && S.first == pos && !S.rec.empty()) {
+                        C.rec.insert(C.rec.end(), S.rec.begin(), S.rec.end());
+                        pos = S.stop;
+                        cut = S.cut;
+                        seg_taken += k > 0;
+                    } else if (pos < lim) {  // no guess, a wrong one, or the walk before ran past it: this stretch again, from what is known
+                        pos = walk(buf, n, pos, lim, C.rec, cut);
+                        seg_again += 1;
+                    }
+                }
             }
             size_t usable = C.rec.size();
             size_t carry_from = pos;  // the first byte behind the complete records
@@ -879,6 +978,7 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
             cur ^= 1;
         }
         clk.frame_thread_s = frame_s;
+        if (getenv("RSEM_HIP_TIMING")) printf("[timing]   framing: %d walks at once, %llu guessed segments taken, %llu stretches walked again\n", frame_threads, (unsigned long long)seg_taken, (unsigned long long)seg_again);
     }
     if (writer.joinable()) writer.join();
     clk.lap(4);

@@ -33,7 +33,12 @@ def _run(exe, fx, inp, paired, threads, chunk, out):
     r = subprocess.run([exe, os.path.join(g, "ref.ti"), os.path.join(g, inp), os.path.join(g, "golden.transcript.bam"), out, str(int(paired)), str(threads)],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
-    f = dict(zip(r.stdout.split()[0::2], r.stdout.split()[1::2]))
+    import re
+    m = re.search(r"(\d+) guessed segments taken, (\d+) stretches walked again", r.stdout)
+    text = "\n".join(l for l in r.stdout.split("\n") if not l.startswith("[timing]"))
+    f = dict(zip(text.split()[0::2], text.split()[1::2]))
+    if m:
+        f["_taken"], f["_again"] = m.group(1), m.group(2)
     assert f["header_equal"] == "1" and int(f["identical"]) + int(f["mapq_off_by_one"]) == int(f["records"])
     return f
 
@@ -47,3 +52,25 @@ def test_transcript_bam_is_the_same_for_every_thread_count_and_chunk_size(checke
         for threads, chunk in [(3, 0), (8, 0), (8, 5000), (5, 777), (6, 200), (4, 64)]:
             f = _run(checker, fx, inp, paired, threads, chunk, out)
             assert (f["fnv"], f["stream_bytes"], f["records"]) == (base["fnv"], base["stream_bytes"], base["records"]), (inp, threads, chunk)
+
+
+@pytest.mark.parametrize("fx,paired", [("se_q", False), ("pe_q", True)])
+def test_bam_input_framed_in_segments_from_guessed_record_starts(checker, fx, paired, tmp_path, monkeypatch):
+    """BAM input: a super-chunk's records are found by several walks at once, all but the first from a GUESSED record start
+    (bam_io.hpp, frame_chunk).  Segments of a few hundred bytes (every guess lands in another record), guesses forced wrong
+    (one record late / none: the stretch is walked again from the verified position) -- the same stream of bytes every time."""
+    out = os.path.join(str(tmp_path), "o.bam")
+    base = _run(checker, fx, "golden.transcript.bam", paired, 1, 0, out)
+    for seg, bad, threads, chunk in [(300, False, 8, 0), (1000, False, 16, 0), (5000, False, 64, 0), (300, False, 8, 20000), (700, True, 8, 0),
+                                     (4000, True, 32, 50000), (1 << 22, True, 8, 0)]:
+        monkeypatch.setenv("RSEM_HIP_BAM_FRAME_SEG", str(seg))
+        monkeypatch.setenv("RSEM_HIP_BAM_FRAME_THREADS", str(threads))
+        monkeypatch.setenv("RSEM_HIP_TIMING", "1")
+        if bad:
+            monkeypatch.setenv("RSEM_HIP_BAM_BAD_GUESS", "1")
+        else:
+            monkeypatch.delenv("RSEM_HIP_BAM_BAD_GUESS", raising=False)
+        f = _run(checker, fx, "golden.transcript.bam", paired, threads, chunk, out)
+        assert (f["fnv"], f["stream_bytes"], f["records"]) == (base["fnv"], base["stream_bytes"], base["records"]), (seg, bad, threads, chunk)
+        taken, again = int(f["_taken"]), int(f["_again"])
+        assert (again > 0 and taken == 0) if bad else (taken > 0 and again == 0), (seg, bad, threads, chunk, taken, again)
