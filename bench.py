@@ -72,6 +72,22 @@ CPU_SAMPLE = {"C2": dict(read_type=1, frac=0.1, M=50_000, iso="4-12"), "C3": dic
               "C5": dict(read_type=1, frac=0.01, M=500_000, iso="32-64"), "tiny": dict(read_type=1, frac=1.0, M=400, iso="4-12")}
 
 
+def _cpu_quota_cores():
+    """The CPU time the container's cgroup grants, in cores (cpu.max of cgroup v2, cfs quota of v1); None = no limit found.  The gpurun
+    boxes show 256 hardware threads and grant 16 cores' worth of time (profiles/r06q_*): what `-p 64` of either program really gets."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def _theta_line(path):
     with open(path) as f:
         return np.array(f.read().split("\n")[1].split(), float)
@@ -281,7 +297,7 @@ def reference_e2e(config, n_full, ref_limit_s=260.0, full_size=True, bam_leg=Tru
                "sample_short": "oracle/_ref/rsem-run-em -p %d%s, generated %s input at %.0f %% of the workload's reads (%d alignments), rounds >= 12 from its ROUND lines"
                                % (cores, " pinned to one socket" if pinned else "", {1: "SingleQModel", 3: "PairedEndQModel"}[rt], cs["frac"] * 100, nhits),
                "ms_per_round": per_round * 1e3, "rounds_timed": late[-1][0] - late[0][0], "startup_s": startup_s,
-               "host_cores_available": ncpu, "pinned_cpus": ",".join(map(str, pinned)) if pinned else None, "generate_s": gen_s}
+               "host_cores_available": ncpu, "cpu_quota_cores": _cpu_quota_cores(), "pinned_cpus": ",".join(map(str, pinned)) if pinned else None, "generate_s": gen_s}
         e2e = {"what": "whole programs on the same files, wall clock: parse the .temp files, rounds 1-11 with the model, rounds >= 12 to convergence, "
                        "expected counts, results",
                "measured": {"size": "%d alignable reads, %d alignments, %d transcripts (%.0f %% of the bench workload's reads)" % (n1, nhits, cs["M"], cs["frac"] * 100),
@@ -607,7 +623,7 @@ def contract_line(detail, detail_path):
         line["roofline"]["stream_read_GBps"] = r["stream"].get("read_GBps")
     cb = detail.get("cpu_baseline")
     if isinstance(cb, dict):
-        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "ms_per_round", "rounds_timed", "host_cores_available"))
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "ms_per_round", "rounds_timed", "host_cores_available", "cpu_quota_cores"))
         line["cpu_baseline"]["sample"] = cb.get("sample_short") or str(cb.get("sample"))[:200]
         line["speedup_vs_cpu_baseline_rounds"] = detail.get("speedup_vs_cpu_baseline_rounds")
     par = (detail.get("checks") or {}).get("parity_one_step")

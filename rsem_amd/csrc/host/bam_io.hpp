@@ -14,50 +14,65 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 
+#include "crc32_fold.hpp"
+#include "deflate_fast.hpp"
 #include "files.hpp"
 
 namespace rsemh {
 
 // ---- BGZF (blocked gzip, SAM spec 4.1) ----------------------------------------------------------------
 
-// One deflate stream per thread, re-used from block to block.
+// One encoder per thread, re-used from block to block.  The blocks' DEFLATE streams come from this repository's own encoder
+// (deflate_fast.hpp: made for streams of BAM records -- 5 x zlib's rate per thread at 1.05 x its bytes on the bench's input); with
+// RSEM_HIP_DEFLATE in the environment from zlib.
 struct BgzfDeflater {
     z_stream zs;
-    bool live = false;
+    bool live = false, use_zlib = false, asked = false;
     int tune[4] = {0, 0, 0, 0}, nt = 0;
+    std::unique_ptr<FastDeflate> fast;
     static constexpr size_t kBlock = 0xff00;  // input bytes per block, as htslib cuts them
+    static_assert(kBlock <= FastDeflate::kMaxIn && FastDeflate::kMaxOut + 8 <= 0x10000 - 18 - 8, "a block fits its BGZF frame");
     ~BgzfDeflater() { if (live) deflateEnd(&zs); }
-    // append the BGZF block of p[0..n), n <= kBlock, to out
-    void block(const uint8_t* p, size_t n, std::vector<uint8_t>& out) {
+    size_t zlib_block(const uint8_t* p, size_t n, uint8_t* dst, size_t cap) {
         if (!live) {
-            memset(&zs, 0, sizeof(zs));
             // zlib's level 6 (what the reference's samtools writes BAM with) walks hash chains of up to 128 candidates and stops at a
             // match of 128 bytes; a transcript BAM repeats a read's sequence and qualities in every one of its alignments' records
             // (the longest match sits at the head of the chain) and its qualities match nothing anywhere.  Chains of 16 and no early
             // stop (matches up to 258) deflate 1.6 x as fast AND 0.9 % smaller on the bench's input (30 -> 49 MB/s per thread, 524.8 ->
             // 520.1 MB at 2 % of configs[2]; profiles/r06m_*, r06n_*: level 4 is as fast and 0.3 % larger, level 1 2.5 x and 6 % larger).
-            // RSEM_HIP_DEFLATE="level[,memLevel[,good,lazy,nice,chain]]" overrules (measurement knob; "6,8" = zlib's own level 6).
+            // RSEM_HIP_DEFLATE="level[,memLevel[,good,lazy,nice,chain]]"; "zlib" or "" = level 6 tuned as above; "6,8" = zlib's own level 6.
             int lv = Z_DEFAULT_COMPRESSION, ml = 8;
             nt = 6; tune[0] = 8; tune[1] = 16; tune[2] = 258; tune[3] = 16;
-            if (const char* e = getenv("RSEM_HIP_DEFLATE")) nt = sscanf(e, "%d,%d,%d,%d,%d,%d", &lv, &ml, &tune[0], &tune[1], &tune[2], &tune[3]);
+            const char* e = getenv("RSEM_HIP_DEFLATE");
+            if (e && *e >= '0' && *e <= '9') nt = sscanf(e, "%d,%d,%d,%d,%d,%d", &lv, &ml, &tune[0], &tune[1], &tune[2], &tune[3]);
             if (deflateInit2(&zs, lv, Z_DEFLATED, -15, nt >= 2 ? ml : 8, Z_DEFAULT_STRATEGY) != Z_OK) die("zlib deflateInit2 failed");
             live = true;
         } else if (deflateReset(&zs) != Z_OK) die("zlib deflateReset failed");
         if (nt == 6) (void)deflateTune(&zs, tune[0], tune[1], tune[2], tune[3]);  // (a reset restores the level's own)
+        zs.next_in = (Bytef*)p; zs.avail_in = (uInt)n;
+        zs.next_out = dst; zs.avail_out = (uInt)cap;
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) die("BGZF block does not fit");
+        return (size_t)zs.total_out;
+    }
+    // append the BGZF block of p[0..n), n <= kBlock, to out
+    void block(const uint8_t* p, size_t n, std::vector<uint8_t>& out) {
+        if (!asked) {
+            asked = true;
+            use_zlib = getenv("RSEM_HIP_DEFLATE") != nullptr;
+            if (!use_zlib) fast.reset(new FastDeflate());
+        }
         const size_t at = out.size();
         out.resize(at + 0x10000);
         uint8_t* o = out.data() + at;
-        zs.next_in = (Bytef*)p; zs.avail_in = (uInt)n;
-        zs.next_out = o + 18; zs.avail_out = 0x10000 - 18 - 8;
-        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) die("BGZF block does not fit");
-        const uint32_t clen = (uint32_t)zs.total_out;
+        const uint32_t clen = (uint32_t)(use_zlib ? zlib_block(p, n, o + 18, 0x10000 - 18 - 8) : fast->compress(p, n, o + 18));
         static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
         memcpy(o, hdr, 16);
         const uint16_t bsize = (uint16_t)(clen + 25);  // total block size - 1
         o[16] = bsize & 0xff; o[17] = bsize >> 8;
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
+        const uint32_t crc = crc32_fast(0u, p, n);  // (crc32_fold.hpp: 18 GB/s against 0.9 for zlib's)
         const uint32_t isize = (uint32_t)n;
         memcpy(o + 18 + clen, &crc, 4);
         memcpy(o + 22 + clen, &isize, 4);
