@@ -26,7 +26,7 @@ namespace rsemh {
 // ---- BGZF (blocked gzip, SAM spec 4.1) ----------------------------------------------------------------
 
 // One encoder per thread, re-used from block to block.  The blocks' DEFLATE streams come from this repository's own encoder
-// (deflate_fast.hpp: made for streams of BAM records -- 5 x zlib's rate per thread at 1.05 x its bytes on the bench's input); with
+// (deflate_fast.hpp: made for streams of BAM records -- 4.6 x zlib's rate a thread at 1.03 x its bytes on the bench's input); with
 // RSEM_HIP_DEFLATE in the environment from zlib.
 struct BgzfDeflater {
     z_stream zs;
