@@ -39,6 +39,9 @@ def _run(exe, fx, inp, paired, threads, chunk, out):
     f = dict(zip(text.split()[0::2], text.split()[1::2]))
     if m:
         f["_taken"], f["_again"] = m.group(1), m.group(2)
+    m = re.search(r"blocks inflated by inflate_fast.hpp (\d+), by zlib (\d+)", r.stdout)
+    if m:
+        f["_fast_blocks"], f["_zlib_blocks"] = m.group(1), m.group(2)
     assert f["header_equal"] == "1" and int(f["identical"]) + int(f["mapq_off_by_one"]) == int(f["records"])
     return f
 
@@ -74,3 +77,18 @@ def test_bam_input_framed_in_segments_from_guessed_record_starts(checker, fx, pa
         assert (f["fnv"], f["stream_bytes"], f["records"]) == (base["fnv"], base["stream_bytes"], base["records"]), (seg, bad, threads, chunk)
         taken, again = int(f["_taken"]), int(f["_again"])
         assert (again > 0 and taken == 0) if bad else (taken > 0 and again == 0), (seg, bad, threads, chunk, taken, again)
+
+
+def test_bam_input_inflated_by_the_repositorys_decoder_or_by_zlib(checker, tmp_path, monkeypatch):
+    """BAM input: every BGZF block is inflated by host/inflate_fast.hpp and believed only if the block's CRC-32 agrees; RSEM_HIP_INFLATE_ZLIB
+    sends every block to zlib.  Same output stream either way; the timing line says who inflated how many."""
+    out = os.path.join(str(tmp_path), "o.bam")
+    monkeypatch.setenv("RSEM_HIP_TIMING", "1")
+    for fx, paired in (("se_q", False), ("pe_q", True)):
+        a = _run(checker, fx, "golden.transcript.bam", paired, 4, 0, out)
+        assert int(a["_fast_blocks"]) > 0 and int(a["_zlib_blocks"]) == 0
+        monkeypatch.setenv("RSEM_HIP_INFLATE_ZLIB", "1")
+        b = _run(checker, fx, "golden.transcript.bam", paired, 4, 0, out)
+        monkeypatch.delenv("RSEM_HIP_INFLATE_ZLIB")
+        assert int(b["_fast_blocks"]) == 0 and int(b["_zlib_blocks"]) > 0
+        assert (a["fnv"], a["stream_bytes"], a["records"]) == (b["fnv"], b["stream_bytes"], b["records"])

@@ -92,3 +92,51 @@ def test_crc32_by_carry_less_multiplication_is_zlibs(tmp_path):
     subprocess.check_call([CXX, "-O2", "-std=c++17", os.path.join(ROOT, "tests", "crc32_fold_check.cpp"), "-o", exe, "-lz"])
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout
+
+
+# ---- the decoder (rsem_amd/csrc/host/inflate_fast.hpp): BAM input's BGZF blocks ----------------------------------------------------------
+
+def _build_inflate(tmp_path_factory, name, flags):
+    exe = os.path.join(str(tmp_path_factory.mktemp(name)), name)
+    subprocess.check_call([CXX, "-std=c++17"] + flags + [os.path.join(ROOT, "tests", "inflate_fast_check.cpp"), "-o", exe, "-lz"])
+    return exe
+
+
+@pytest.fixture(scope="module")
+def inflate_checker(tmp_path_factory):
+    return _build_inflate(tmp_path_factory, "inflate_fast_check", ["-O2"])
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_decoder_on_generated_streams_good_and_damaged(inflate_checker, seed):
+    """zlib's streams at every level x strategy (default, filtered, Huffman only, RLE, fixed codes) and deflate_fast.hpp's inflate to their
+    input; truncated and bit-flipped copies are refused or inflate to the right length (the caller's CRC decides) -- never a byte outside
+    the output, which the checker brackets with guard bytes."""
+    out = _ok(inflate_checker, "fuzz", seed, 1500)
+    assert "rejected" in out
+
+
+def test_decoder_on_the_fixtures_streams(inflate_checker, tmp_path):
+    raw = os.path.join(str(tmp_path), "stream.bin")
+    with open(raw, "wb") as g:
+        g.write(_bam_stream(os.path.join(ROOT, "tests", "golden", "pe_q", "golden.transcript.bam")))
+    for blk in (65280, 30000, 4097):
+        _ok(inflate_checker, "file", raw, blk)
+    small = os.path.join(str(tmp_path), "prefix.bin")
+    with open(small, "wb") as g:
+        g.write(open(raw, "rb").read()[:6000])
+    for blk in (300, 17, 1):  # (51 streams per block)
+        _ok(inflate_checker, "file", small, blk)
+    _ok(inflate_checker, "file", os.path.join(ROOT, "tests", "golden", "pe_q", "aln.sam"))
+
+
+def test_decoder_under_address_and_undefined_behaviour_sanitizers(tmp_path_factory, tmp_path):
+    try:
+        exe = _build_inflate(tmp_path_factory, "inflate_fast_check_san", ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"])
+    except subprocess.CalledProcessError:
+        pytest.skip("this g++ cannot build with -fsanitize=address,undefined")
+    _ok(exe, "fuzz", 21, 600)
+    raw = os.path.join(str(tmp_path), "stream.bin")
+    with open(raw, "wb") as g:
+        g.write(_bam_stream(os.path.join(ROOT, "tests", "golden", "se_q", "golden.transcript.bam")))
+    _ok(exe, "file", raw, 20000)

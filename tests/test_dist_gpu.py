@@ -89,7 +89,9 @@ def test_bench_forced_dist_line_on_one_gpu():
     import json
     import subprocess
     import sys
-    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_PORT="29631")
+    import tempfile
+    detail_path = os.path.join(tempfile.mkdtemp(), "detail.json")  # (the printed line is a summary since round 6: the full record goes here)
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_PORT="29631", BENCH_DETAIL_PATH=detail_path)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C2", "--scale", "0.1", "--legs=", "--no-cpu-baseline", "--no-ci",
@@ -99,8 +101,10 @@ def test_bench_forced_dist_line_on_one_gpu():
     lines = [l for l in r.stdout.split("\n") if l.strip()]
     assert len(lines) == 1, r.stdout[:1000]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["roofline"]["frac_physical"] > 0
+    assert d["n_gpus"] == 1 and d["roofline"]["frac"] > 0 and len(lines[0]) < 8000
     di = d["distributed"]
+    d = json.load(open(detail_path))
+    assert d["distributed"] == di or d["distributed"]["rccl_ranks"] == di["rccl_ranks"]
     assert di["rccl_ranks"] == 1 and len(di["estep_ms_per_rank"]) == 1 and di["frac_physical_per_rank"][0] > 0 and di["allreduce_ms"] > 0
     g = d["gibbs"]
     assert "error" not in g, g
