@@ -108,8 +108,8 @@ constexpr int kGroupChunk = RSEM_GROUP_CHUNK;  // rows per chunk (a multiple of 
 template <bool kQ, bool kPE, bool kUpdate>
 __global__ __launch_bounds__(kGroupBlk) RSEM_GROUP_ATTR void k_model_group(DevData D, DevTables T, const double* __restrict__ theta, double* __restrict__ cp,
                                                              double* __restrict__ ncp, AccumPtrs A, PlaneOut PO) {
-    __shared__ double s_prob[kQ ? 2500 : 1];                 // QProfile (100 x 5 x 5); the position-indexed Profile stays in global memory
-    __shared__ double s_nprob[kQ ? 500 : 8];
+    __shared__ double s_prob[kQ ? kQProbLds : 1];            // QProfile (100 x 5 x 5) + the pad code's entries; the position-indexed Profile stays in global memory
+    __shared__ double s_nprob[kQ ? kQNoiseProbLds : 8];
     __shared__ double s_prof[kUpdate ? (kQ ? 2500 : kProfLds) : 1];
     __shared__ double s_noise[kUpdate ? kNoiseLds : 1];
     __shared__ double s_rspd[kUpdate ? kRspdLds : 1];
@@ -119,8 +119,9 @@ __global__ __launch_bounds__(kGroupBlk) RSEM_GROUP_ATTR void k_model_group(DevDa
         for (int i = threadIdx.x; i < PO.n_shapes && i < kPlaneShapesMax; i += blockDim.x) s_shapes[i] = PO.shapes[i];
         PO.shapes = s_shapes;
     }
-    if (kQ) for (int i = threadIdx.x; i < 2500; i += blockDim.x) s_prob[i] = T.prof[i];
-    for (int i = threadIdx.x; i < (kQ ? 500 : 5); i += blockDim.x) s_nprob[i] = T.noise[i];
+    // (quality models: what the pad code of the positions past a read's end selects is 1 -- model_block.hpp, kPadCode8)
+    if (kQ) for (int i = threadIdx.x; i < kQProbLds; i += blockDim.x) s_prob[i] = i < 2500 ? T.prof[i] : 1.0;
+    for (int i = threadIdx.x; i < (kQ ? kQNoiseProbLds : 5); i += blockDim.x) s_nprob[i] = i < (kQ ? 500 : 5) ? T.noise[i] : 1.0;
     constexpr int kProfCap = kQ ? 2500 : kProfLds;           // entries of the count table held in LDS (the rest: global atomics)
     if (kUpdate) {
         for (int i = threadIdx.x; i < kProfCap; i += blockDim.x) s_prof[i] = 0.0;
@@ -193,6 +194,28 @@ __global__ void k_pack_reads(uint64_t N1, const uint64_t* __restrict__ off, cons
         const uint64_t n = l - w * 8 < 8 ? l - w * 8 : 8;
         for (uint64_t k = 0; k < n; k++) v |= (uint64_t)raw[b0 + w * 8 + k] << (8 * k);  // little-endian: byte k of the word
         o[w] = v;
+    }
+}
+
+// Quality models: a read position becomes ONE 16-bit code (model_block.hpp, DevData): first the bases (code = 8 * base, the pad code past
+// the read's end), then the qualities (code += 200 * quality).  `raw` holds the mate's bases / qualities of all reads back to back;
+// word w of `lo` takes positions 8w .. 8w + 3, word w of `hi` positions 8w + 4 .. 8w + 7.
+__global__ void k_code_reads(uint64_t N1, const uint64_t* __restrict__ off, const uint64_t* __restrict__ off8, const uint8_t* __restrict__ raw,
+                             uint64_t* lo, uint64_t* hi, int qualities) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N1) return;
+    const uint64_t b0 = off[i] - off[0], l = off[i + 1] - off[i];
+    for (uint64_t w = 0; w * 8 < l; w++) {
+        uint64_t v[2] = {qualities ? lo[off8[i] + w] : 0ull, qualities ? hi[off8[i] + w] : 0ull};
+        for (uint64_t k = 0; k < 8; k++) {
+            const uint64_t at = w * 8 + k;
+            uint64_t c;
+            if (!qualities) c = at < l ? 8ull * raw[b0 + at] : (uint64_t)kPadCode8;
+            else c = at < l ? 200ull * raw[b0 + at] : 0ull;
+            v[k >> 2] += c << (16 * (k & 3));  // (a code is below 2^16 with its quality added: no carry into the next field)
+        }
+        lo[off8[i] + w] = v[0];
+        hi[off8[i] + w] = v[1];
     }
 }
 
@@ -365,8 +388,15 @@ int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_da
             uint64_t*& d_w = what ? d_wq : d_ws;
             if (dmalloc(&d_w, (size_t)nw) != hipSuccess) return bail(RSEM_ERR_NOMEM);
             if (hipMemsetAsync(d_w + (nw - 1), 0, sizeof(uint64_t), st) != hipSuccess) return bail(RSEM_ERR_HIP);
+        }
+        // without qualities: the bases, 8 per word.  With: a position's base and quality become one 16-bit code (k_code_reads) -- the
+        // bases first, then the qualities through the same staging buffer (the stream keeps the order)
+        for (int what = 0; what < (q ? 2 : 1); what++) {
             if ((rc = rsem::staged_h2d(d_raw, (what ? d->read_qual[m] : d->read_seq[m]) + b_lo, (size_t)nbytes, st)) != RSEM_OK) return bail(rc);
-            if (d->N1) hipLaunchKernelGGL(k_pack_reads, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, d->N1, d_off, d_off8, d_raw, d_w);
+            if (d->N1) {
+                if (!q) hipLaunchKernelGGL(k_pack_reads, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, d->N1, d_off, d_off8, d_raw, d_ws);
+                else hipLaunchKernelGGL(k_code_reads, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, d->N1, d_off, d_off8, d_raw, d_ws, d_wq, what);
+            }
             if (hipGetLastError() != hipSuccess) return bail(RSEM_ERR_HIP);
         }
         if (hipStreamSynchronize(st) != hipSuccess) return bail(RSEM_ERR_HIP);

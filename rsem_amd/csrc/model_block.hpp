@@ -33,6 +33,14 @@ constexpr int kProfLds = 5120;  // doubles of the profile COUNT table kept in LD
 constexpr int kGldLds = 1024;
 constexpr int kRspdLds = 128;
 constexpr int kNoiseLds = 512;
+// Quality models: the code of a read position (DevData) and the tables' padded sizes -- entries 2500 + 5 r of the profile table and
+// entry 500 of the noise table are 1.0 (what the pad code of the positions past a read's end selects).
+constexpr unsigned kPadCode8 = 8u * 2500u;
+constexpr int kQProbLds = 2528, kQNoiseProbLds = 512;
+RSEM_DEVFN unsigned read_code8(unsigned quality, unsigned base) { return 8u * (25u * quality + base); }
+// byte offset of the noise table's entry [quality][base] from a code: quality = code / 200 (exact for codes up to the pad's: a
+// multiplication and a shift), 8 * (5 quality + base) = code - 160 quality
+RSEM_DEVFN unsigned noise_off8(unsigned code8) { return code8 - 160u * ((code8 * 1311u) >> 18); }
 
 struct DevTables {  // device copies of rsem_model_tables
     double probF;
@@ -56,7 +64,12 @@ struct DevData {
     const int32_t* sid_signed;
     const int32_t* pos;
     const int32_t* insertL;
-    // reads, packed 8 base ids (or qualities) per 64-bit word, every read starting on a word boundary
+    // reads, 8 positions per pair of 64-bit words, every read starting on a word boundary.  Models without qualities: rseq_w[w] = the
+    // base ids of positions 8w .. 8w + 7, one byte each.  Quality models (round 6): a position is ONE 16-bit code, read_code8(quality,
+    // base) = 8 * (25 * quality + base) -- the byte offset of entry [quality][0][base] of the 100 x 5 x 5 profile table, so that the
+    // entry for reference base r is at code + 40 r: one multiply-add per position where two byte extracts, two multiply-adds and the
+    // selects for positions past the read's end stood (the kernel is bound by instruction issue).  rseq_w[w] = the codes
+    // of positions 8w .. 8w + 3, rqual_w[w] = those of 8w + 4 .. 8w + 7; positions past the end hold kPadCode8, whose table entries are 1.
     const uint64_t* roff8[2];   // [N1+1] first word of read i
     const int32_t* rlen[2];     // [N1]
     const uint64_t* rseq_w[2];
@@ -227,10 +240,26 @@ RSEM_DEVFN double lane_profile_product(const double* prof, const MateWords& W, c
         const uint64_t rf = funnel8(rw[wi], rw[wi + 1], sh);
         const uint64_t sb = W.seq[W.r8 + wi];
         const uint64_t qb = kQ ? W.qual[W.r8 + wi] : 0;
+        if (kQ) {
+            // a position = a 16-bit code (DevData); past the read's end the pad code, whose entries are 1: no index select, no value select
+            // (the eight table reads issued together, then the eight multiplications in read order: left to itself the compiler waits
+            // for every read before it issues the next)
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const unsigned code = (unsigned)(((u < 4 ? sb : qb) >> (16 * (u & 3))) & 0xffffu);
+                const unsigned r = (unsigned)((rf >> (8 * u)) & 0xffu);
+                t[u] = *(const double*)((const char*)prof + (code + 40u * r));
+            }
+            RSEM_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; u++) p *= t[u];
+            continue;
+        }
         const int n = W.len - wi * 8;
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int row = kQ ? (int)((qb >> (8 * u)) & 0xff) : wi * 8 + u;
+            const int row = wi * 8 + u;
             const int idx = (row * 5 + (int)((rf >> (8 * u)) & 0xff)) * 5 + (int)((sb >> (8 * u)) & 0xff);
             // (no look-up under a condition: `(u < n) ? prof[idx] : 1.0` compiles to a branch around the load with a wait of
             // its own, eight round trips one after the other; past the read's end entry 0 is read and not used)
@@ -253,9 +282,13 @@ RSEM_DEVFN void lane_profile_update(double* s_prof, double* g_prof, const MateWo
         const uint64_t qb = kQ ? W.qual[W.r8 + wi] : 0;
         const int n = W.len - wi * 8 < 8 ? W.len - wi * 8 : 8;
         for (int u = 0; u < n; u++) {
-            const int row = kQ ? (int)((qb >> (8 * u)) & 0xff) : wi * 8 + u;
-            // (Q: quality < 100, so every index is inside the 2500-entry table; no-Q: positions beyond the LDS table go to global memory)
-            add_tbl(s_prof, kQ ? 2500 : kProfLds, g_prof, (row * 5 + (int)((rf >> (8 * u)) & 0xff)) * 5 + (int)((sb >> (8 * u)) & 0xff), frac);
+            if (kQ) {  // (quality < 100: every entry is inside the 2500-entry table in LDS)
+                const unsigned code = (unsigned)(((u < 4 ? sb : qb) >> (16 * (u & 3))) & 0xffffu);
+                RSEM_LDS_ADD((double*)((char*)s_prof + (code + 40u * (unsigned)((rf >> (8 * u)) & 0xffu))), frac);
+                continue;
+            }
+            // (positions beyond the LDS table go to global memory)
+            add_tbl(s_prof, kProfLds, g_prof, ((wi * 8 + u) * 5 + (int)((rf >> (8 * u)) & 0xff)) * 5 + (int)((sb >> (8 * u)) & 0xff), frac);
         }
     }
 }
@@ -268,12 +301,23 @@ RSEM_DEVFN double lane_noise_product(const double* nprob, const MateWords& W, in
     for (int wi = g; wi * 8 < W.len; wi += kGrp) {
         const uint64_t sb = W.seq[W.r8 + wi];
         const uint64_t qb = kQ ? W.qual[W.r8 + wi] : 0;
+        if (kQ) {  // (the pad code selects entry 500 = 1)
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const unsigned code = (unsigned)(((u < 4 ? sb : qb) >> (16 * (u & 3))) & 0xffffu);
+                t[u] = *(const double*)((const char*)nprob + noise_off8(code));
+            }
+            RSEM_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; u++) p *= t[u];
+            continue;
+        }
         const int n = W.len - wi * 8;
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int b = (int)((sb >> (8 * u)) & 0xff);
-            const int idx = kQ ? (int)((qb >> (8 * u)) & 0xff) * 5 + b : b;
-            const double t = nprob[(u < n) ? idx : 0];  // (see lane_profile_product)
+            const double t = nprob[(u < n) ? b : 0];  // (see lane_profile_product)
             p *= (u < n) ? t : 1.0;
         }
     }
@@ -286,8 +330,12 @@ RSEM_DEVFN void lane_noise_update(double* s_noise, const MateWords& W, int g, do
         const uint64_t qb = kQ ? W.qual[W.r8 + wi] : 0;
         const int n = W.len - wi * 8 < 8 ? W.len - wi * 8 : 8;
         for (int u = 0; u < n; u++) {
-            const int b = (int)((sb >> (8 * u)) & 0xff);
-            RSEM_LDS_ADD(&s_noise[kQ ? (int)((qb >> (8 * u)) & 0xff) * 5 + b : b], frac);
+            if (kQ) {
+                const unsigned code = (unsigned)(((u < 4 ? sb : qb) >> (16 * (u & 3))) & 0xffffu);
+                RSEM_LDS_ADD((double*)((char*)s_noise + noise_off8(code)), frac);
+            } else {
+                RSEM_LDS_ADD(&s_noise[(int)((sb >> (8 * u)) & 0xff)], frac);
+            }
         }
     }
 }

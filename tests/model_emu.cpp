@@ -28,7 +28,7 @@ struct Job {
     bool q, pe, update;
     int n_blocks, block;
     // "LDS"
-    double s_prob[2500], s_nprob[500], s_prof[kProfLds], s_noise[kNoiseLds], s_rspd[kRspdLds], s_gld[kGldLds];
+    double s_prob[kQProbLds], s_nprob[kQNoiseProbLds], s_prof[kProfLds], s_noise[kNoiseLds], s_rspd[kRspdLds], s_gld[kGldLds];
     emu::Block blk;
 };
 
@@ -37,8 +37,8 @@ static void lane_body(Job* J, int tid) {
     emu::t_tid = tid;
     emu::t_blk = &J->blk;
     // the wrapper of k_model_group (model.hip), block size 256 here
-    if (kQ) for (int i = tid; i < 2500; i += 256) J->s_prob[i] = J->T.prof[i];
-    for (int i = tid; i < (kQ ? 500 : 5); i += 256) J->s_nprob[i] = J->T.noise[i];
+    if (kQ) for (int i = tid; i < kQProbLds; i += 256) J->s_prob[i] = i < 2500 ? J->T.prof[i] : 1.0;  // (as k_model_group: the pad code's entries are 1)
+    for (int i = tid; i < (kQ ? kQNoiseProbLds : 5); i += 256) J->s_nprob[i] = i < (kQ ? 500 : 5) ? J->T.noise[i] : 1.0;
     if (kUpdate) {
         for (int i = tid; i < kProfLds; i += 256) J->s_prof[i] = 0.0;
         for (int i = tid; i < kNoiseLds; i += 256) J->s_noise[i] = 0.0;
@@ -179,11 +179,19 @@ int main(int argc, char** argv) {
         for (uint64_t i = 0; i < N1; i++) { rlen[m][i] = (int32_t)rseq[m][i].size(); roff8[m][i + 1] = roff8[m][i] + (rseq[m][i].size() + 7) / 8; }
         seqw[m].assign(roff8[m][N1] + 2, 0);
         qualw[m].assign(roff8[m][N1] + 2, 0);
-        for (uint64_t i = 0; i < N1; i++)
-            for (size_t k = 0; k < rseq[m][i].size(); k++) {
-                seqw[m][roff8[m][i] + k / 8] |= (uint64_t)rseq[m][i][k] << (8 * (k % 8));
-                qualw[m][roff8[m][i] + k / 8] |= (uint64_t)rqual[m][i][k] << (8 * (k % 8));
+        for (uint64_t i = 0; i < N1; i++) {
+            if (!q) {
+                for (size_t k = 0; k < rseq[m][i].size(); k++) seqw[m][roff8[m][i] + k / 8] |= (uint64_t)rseq[m][i][k] << (8 * (k % 8));
+                continue;
             }
+            // quality models: one 16-bit code per position, positions 8w .. 8w + 3 in seqw[w], 8w + 4 .. 8w + 7 in qualw[w], the pad code
+            // past the read's end (DevData of model_block.hpp; k_code_reads of model.hip)
+            const size_t l = rseq[m][i].size();
+            for (size_t k = 0; k < (l + 7) / 8 * 8; k++) {
+                const uint64_t c = k < l ? read_code8(rqual[m][i][k], rseq[m][i][k]) : kPadCode8;
+                ((k % 8) < 4 ? seqw : qualw)[m][roff8[m][i] + k / 8] |= c << (16 * (k % 4));
+            }
+        }
     }
     // same_prev flags (k_window_flags of model.hip): byte-wise comparison of the windows
     auto window = [&](uint64_t j, int m, int len) -> const uint8_t* {
