@@ -197,25 +197,33 @@ __global__ void k_pack_reads(uint64_t N1, const uint64_t* __restrict__ off, cons
     }
 }
 
-// Quality models: a read position becomes ONE 16-bit code (model_block.hpp, DevData): first the bases (code = 8 * base, the pad code past
-// the read's end), then the qualities (code += 200 * quality).  `raw` holds the mate's bases / qualities of all reads back to back;
-// word w of `lo` takes positions 8w .. 8w + 3, word w of `hi` positions 8w + 4 .. 8w + 7.
-__global__ void k_code_reads(uint64_t N1, const uint64_t* __restrict__ off, const uint64_t* __restrict__ off8, const uint8_t* __restrict__ raw,
-                             uint64_t* lo, uint64_t* hi, int qualities) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Quality models: a read position becomes ONE 16-bit code (model_block.hpp, DevData).  `seq` / `qual` hold the mate's bases / qualities of
+// all reads back to back; word w of `lo` takes positions 8w .. 8w + 3 of a read, word w of `hi` positions 8w + 4 .. 8w + 7, the pad code
+// past the read's end.  A group of 16 lanes per read, a lane per word pair: the 8 + 8 input bytes of a word pair are two (unaligned) 8-byte
+// loads, the stores of a group are contiguous.  (A thread per read with byte loads took 15 ms per launch at a fifth of configs[2].)
+__global__ void k_code_reads(uint64_t N1, const uint64_t* __restrict__ off, const uint64_t* __restrict__ off8, const uint8_t* __restrict__ seq,
+                             const uint8_t* __restrict__ qual, uint64_t* lo, uint64_t* hi) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = t >> 4;
     if (i >= N1) return;
-    const uint64_t b0 = off[i] - off[0], l = off[i + 1] - off[i];
-    for (uint64_t w = 0; w * 8 < l; w++) {
-        uint64_t v[2] = {qualities ? lo[off8[i] + w] : 0ull, qualities ? hi[off8[i] + w] : 0ull};
-        for (uint64_t k = 0; k < 8; k++) {
-            const uint64_t at = w * 8 + k;
-            uint64_t c;
-            if (!qualities) c = at < l ? 8ull * raw[b0 + at] : (uint64_t)kPadCode8;
-            else c = at < l ? 200ull * raw[b0 + at] : 0ull;
-            v[k >> 2] += c << (16 * (k & 3));  // (a code is below 2^16 with its quality added: no carry into the next field)
+    const uint64_t b0 = off[i] - off[0], l = off[i + 1] - off[i], o8 = off8[i];
+    for (uint64_t w = t & 15u; w * 8 < l; w += 16) {
+        const uint64_t at = b0 + w * 8, n = l - w * 8 < 8 ? l - w * 8 : 8;
+        uint64_t sb = 0, qb = 0;
+        if (n == 8) {
+            __builtin_memcpy(&sb, seq + at, 8);
+            __builtin_memcpy(&qb, qual + at, 8);
+        } else {
+            for (uint64_t k = 0; k < n; k++) { sb |= (uint64_t)seq[at + k] << (8 * k); qb |= (uint64_t)qual[at + k] << (8 * k); }
         }
-        lo[off8[i] + w] = v[0];
-        hi[off8[i] + w] = v[1];
+        uint64_t v[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint64_t c = (uint64_t)k < n ? (uint64_t)read_code8((unsigned)((qb >> (8 * k)) & 0xff), (unsigned)((sb >> (8 * k)) & 0xff)) : (uint64_t)kPadCode8;
+            v[k >> 2] |= c << (16 * (k & 3));
+        }
+        lo[o8 + w] = v[0];
+        hi[o8 + w] = v[1];
     }
 }
 
@@ -367,9 +375,9 @@ int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_da
         const uint64_t b_lo = d->read_off[m][0], nbytes = d->read_off[m][d->N1] - b_lo;
         uint64_t *d_off = nullptr, *d_nw = nullptr, *d_off8 = nullptr, *d_ws = nullptr, *d_wq = nullptr;
         int32_t* d_len = nullptr;
-        uint8_t* d_raw = nullptr;
+        uint8_t *d_raw = nullptr, *d_raw_q = nullptr;
         void* d_tmp = nullptr;
-        auto drop = [&]() { hipFree(d_off); hipFree(d_nw); hipFree(d_raw); hipFree(d_tmp); };
+        auto drop = [&]() { hipFree(d_off); hipFree(d_nw); hipFree(d_raw); hipFree(d_raw_q); hipFree(d_tmp); };
         auto bail = [&](int code) { drop(); hipFree(d_off8); hipFree(d_len); hipFree(d_ws); hipFree(d_wq); rsem_model_destroy(c); return code; };
         if ((rc = upload(&d_off, d->read_off[m], (size_t)d->N1 + 1, st)) != RSEM_OK) return bail(rc);
         if (dmalloc(&d_nw, (size_t)d->N1 + 1) != hipSuccess || dmalloc(&d_off8, (size_t)d->N1 + 1) != hipSuccess ||
@@ -389,16 +397,18 @@ int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_da
             if (dmalloc(&d_w, (size_t)nw) != hipSuccess) return bail(RSEM_ERR_NOMEM);
             if (hipMemsetAsync(d_w + (nw - 1), 0, sizeof(uint64_t), st) != hipSuccess) return bail(RSEM_ERR_HIP);
         }
-        // without qualities: the bases, 8 per word.  With: a position's base and quality become one 16-bit code (k_code_reads) -- the
-        // bases first, then the qualities through the same staging buffer (the stream keeps the order)
-        for (int what = 0; what < (q ? 2 : 1); what++) {
-            if ((rc = rsem::staged_h2d(d_raw, (what ? d->read_qual[m] : d->read_seq[m]) + b_lo, (size_t)nbytes, st)) != RSEM_OK) return bail(rc);
-            if (d->N1) {
-                if (!q) hipLaunchKernelGGL(k_pack_reads, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, d->N1, d_off, d_off8, d_raw, d_ws);
-                else hipLaunchKernelGGL(k_code_reads, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, d->N1, d_off, d_off8, d_raw, d_ws, d_wq, what);
-            }
-            if (hipGetLastError() != hipSuccess) return bail(RSEM_ERR_HIP);
+        // without qualities: the bases, 8 per word.  With: a position's base and quality become one 16-bit code (k_code_reads), from both
+        // byte arrays at once (a second staging array for the qualities, freed with the first)
+        if ((rc = rsem::staged_h2d(d_raw, d->read_seq[m] + b_lo, (size_t)nbytes, st)) != RSEM_OK) return bail(rc);
+        if (q) {
+            if (dmalloc(&d_raw_q, (size_t)nbytes) != hipSuccess) return bail(RSEM_ERR_NOMEM);
+            if ((rc = rsem::staged_h2d(d_raw_q, d->read_qual[m] + b_lo, (size_t)nbytes, st)) != RSEM_OK) return bail(rc);
         }
+        if (d->N1) {
+            if (!q) hipLaunchKernelGGL(k_pack_reads, dim3(rsem::ceil_div(d->N1, kBlk)), dim3(kBlk), 0, st, d->N1, d_off, d_off8, d_raw, d_ws);
+            else hipLaunchKernelGGL(k_code_reads, dim3(rsem::ceil_div(d->N1 * 16, kBlk)), dim3(kBlk), 0, st, d->N1, d_off, d_off8, d_raw, d_raw_q, d_ws, d_wq);
+        }
+        if (hipGetLastError() != hipSuccess) return bail(RSEM_ERR_HIP);
         if (hipStreamSynchronize(st) != hipSuccess) return bail(RSEM_ERR_HIP);
         drop();
         c->owned.push_back(d_off8); D.roff8[m] = d_off8;
