@@ -539,6 +539,13 @@ int main(int argc, char* argv[]) {
     });
     check_shards("rsem_model_create");
     mark("model contexts built (reads, references, alignment fields uploaded)");
+    if (getenv("RSEM_HIP_TIMING") && atoi(getenv("RSEM_HIP_TIMING")) >= 2) {
+        int64_t b = 0, ns = 0, nf = 0, nw = 0;
+        rsem_hip_device_info(device, "staged_bytes", &b); rsem_hip_device_info(device, "staged_ns", &ns);
+        rsem_hip_device_info(device, "staged_fill_ns", &nf); rsem_hip_device_info(device, "staged_wait_ns", &nw);
+        printf("[timing]     staged uploads so far: %.2f GB in %.3f s of calls (%.1f GB/s; filling the pinned buffers %.3f s, waiting for the DMA %.3f s)\n", b / 1e9, ns / 1e9,
+               ns ? b / (double)ns : 0.0, nf / 1e9, nw / 1e9);
+    }
     // the communicator of the device loop: RCCL, one rank per GPU; shards that share a GPU exchange inside the process
     if (S > 1) {
         bool shared_device = false;

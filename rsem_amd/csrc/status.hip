@@ -3,6 +3,7 @@
 #include <cstdarg>
 
 #include "common.hpp"
+#include "upload.hpp"
 
 namespace rsem {
 static thread_local char g_last_error[1024] = "";
@@ -75,6 +76,11 @@ int rsem_hip_device_info(int device, const char* key, int64_t* value) {
     if (!strcmp(key, "compute_units")) *value = p.multiProcessorCount;
     else if (!strcmp(key, "clock_khz")) *value = p.clockRate;
     else if (!strcmp(key, "hbm_bytes")) *value = (int64_t)p.totalGlobalMem;
+    // (measurement: the staged host -> device copies of this process so far, upload.hpp)
+    else if (!strcmp(key, "staged_bytes")) *value = (int64_t)rsem::staged_stats().bytes.load();
+    else if (!strcmp(key, "staged_ns")) *value = (int64_t)rsem::staged_stats().ns.load();
+    else if (!strcmp(key, "staged_fill_ns")) *value = (int64_t)rsem::staged_stats().ns_fill.load();
+    else if (!strcmp(key, "staged_wait_ns")) *value = (int64_t)rsem::staged_stats().ns_wait.load();
     else { rsem::set_last_error("unknown device info key '%s'", key); return RSEM_ERR_INVALID; }
     return RSEM_OK;
 }

@@ -6,6 +6,8 @@
 // single core's memcpy rate.  When staged_h2d returns the source may be released; the device side is ordered on `st`.
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -47,8 +49,14 @@ inline Stager& thread_stager() {
     return s;
 }
 
+// (RSEM_HIP_TIMING=2: bytes and seconds of the staged copies, summed; rsem-run-em prints them with its marks)
+struct StagedStats { std::atomic<uint64_t> bytes{0}, ns{0}, ns_fill{0}, ns_wait{0}; };
+inline StagedStats& staged_stats() { static StagedStats s; return s; }
+
 inline int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
     if (bytes == 0) return RSEM_OK;
+    const auto t_all = std::chrono::steady_clock::now();
+    struct Acc { std::chrono::steady_clock::time_point t0; size_t b; ~Acc() { staged_stats().bytes += b; staged_stats().ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } acc{t_all, bytes};
     if (bytes < ((size_t)16 << 20)) {  // small: the runtime's own path, completed before returning (the source may go away)
         RSEM_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
         RSEM_HIP_TRY(hipStreamSynchronize(st));
@@ -64,7 +72,10 @@ inline int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t st) 
     while (done < bytes) {
         const size_t n = std::min(Stager::kChunk, bytes - done);
         const int b = k & 1;
+        const auto t_w = std::chrono::steady_clock::now();
         if (S.used[b]) RSEM_HIP_TRY(hipEventSynchronize(S.ev[b]));  // the DMA that last read this buffer is finished
+        const auto t_f = std::chrono::steady_clock::now();
+        staged_stats().ns_wait += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_f - t_w).count();
         {
             std::vector<std::thread> th;
             const size_t per = (n + nthr - 1) / nthr;
@@ -74,6 +85,7 @@ inline int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t st) 
             }
             for (auto& x : th) x.join();
         }
+        staged_stats().ns_fill += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_f).count();
         RSEM_HIP_TRY(hipMemcpyAsync((char*)dst + done, S.buf[b], n, hipMemcpyHostToDevice, st));
         RSEM_HIP_TRY(hipEventRecord(S.ev[b], st));
         S.used[b] = true;
