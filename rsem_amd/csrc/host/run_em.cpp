@@ -14,6 +14,7 @@
 // (EM.cpp:385-389,400-404), the device loop sums the counts of every round with one RCCL all-reduce.
 #include <charconv>
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -282,7 +283,7 @@ int main(int argc, char* argv[]) {
         if (on) printf("[timing]     at %7.3f s: %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_mark0).count(), what);
     };
     auto lap = [&](const char* what) {  // phase timing (stdout is not parsed by the pipeline driver)
-        static auto last = std::chrono::steady_clock::now();
+        static auto last = t_start;  // (the first lap counts from the program's start)
         auto now = std::chrono::steady_clock::now();
         if (getenv("RSEM_HIP_TIMING")) printf("[timing] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - last).count());
         last = now;
@@ -337,13 +338,24 @@ int main(int argc, char* argv[]) {
     std::thread warm([device]() { rsem_hip_preload(device, RSEM_PRELOAD_EM | RSEM_PRELOAD_MODEL); });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } warm_joiner{warm};
 
+    uint64_t N0, N1, N2, N_tot;
+    load_cnt(statName + ".cnt", N0, N1, N2, N_tot);
+    // imd.dat depends on nothing but itself and is the longest of the text inputs: its parse starts before the reference is read (one
+    // thread walks the .seq file, 0.3 s at 200 k transcripts, during which the host's other cores had nothing to do until round 6)
+    const bool binary_in = rsb_present(imdName);
+    DatData dat;
+    int n_text_files = 1;
+    for (int tag = 0; tag < 3; tag++)
+        if ((tag == 0 ? N0 : tag == 1 ? N1 : N2) != 0) n_text_files += (int)read_file_names(imdName, tag, read_type).size();
+    const int share = file_parse_threads(n_text_files);
+    std::thread dat_parser;
+    Joiner dat_joiner{dat_parser};
+    if (!binary_in && N1 != 0) dat_parser = std::thread([&]() { dat = load_dat(imdName + ".dat", read_type, share); });
     RefInfo refs = load_refs(refName + ".seq", true);
     const int M = refs.M;
     if (verbose) printf("Refs.loadRefs finished!\n");
     Transcripts T = load_transcripts(refName + ".ti");
     if (T.M != M) die("%s.ti and %s.seq disagree on the number of transcripts!", refName.c_str(), refName.c_str());
-    uint64_t N0, N1, N2, N_tot;
-    load_cnt(statName + ".cnt", N0, N1, N2, N_tot);
 
     if (N1 == 0) {  // EM.cpp:615-638
         printf("Warning: There are no alignable reads!\n");
@@ -394,8 +406,6 @@ int main(int argc, char* argv[]) {
     // ---- inputs, parsed once --------------------------------------------------------------------------
     // imdName.rsb/ (rsem-parse-alignments --binary, host/rsb.hpp): the arrays themselves, mapped; otherwise the
     // reference's text files
-    const bool binary_in = rsb_present(imdName);
-    DatData dat;
     ReadSetFiles rs;
     const uint64_t Ncat[3] = {N0, N1, N2};
     // Text inputs: imd.dat and the read files of every category are independent, so they are parsed at the same time, each
@@ -413,14 +423,13 @@ int main(int argc, char* argv[]) {
             for (size_t m = 0; m < names.size(); m++) jobs.push_back(Job{tag, (int)m, names[m]});
             rs.present[tag] = true;
         }
-        const int share = file_parse_threads((int)jobs.size() + 1);
         reads_parser = std::thread([&, jobs, share]() {
             std::vector<std::thread> th;
             for (const Job& J : jobs)
                 th.emplace_back([&, J]() { rs.mate[J.tag][J.m] = parse_read_file(J.path, hasQ, refs.has_polyA, P.seedLen, share); });
             for (auto& t : th) t.join();
         });
-        dat = load_dat(imdName + ".dat", read_type, share);
+        dat_parser.join();
     }
     if (dat.N1 != N1) die("Number of alignable reads does not match!");
     lap(binary_in ? "map .rsb" : "parse .dat");
@@ -479,10 +488,19 @@ int main(int argc, char* argv[]) {
         if (warm.joinable()) warm.join();
         rsem_hip_device_count(&ndev);
         if (ndev < 1) return;
-        for (uint64_t j = 0; j < nnz; j++) {
-            int32_t v = dat.sid_signed[j];
-            sid_abs[j] = v < 0 ? -v : v;
-            if (sid_abs[j] < 1 || sid_abs[j] > M) { sh[0].rc = RSEM_ERR_INVALID; sh[0].err = "transcript id " + std::to_string(v) + " out of range"; return; }
+        {   // |sid| of every alignment, range-checked (560 M of them at configs[2]: not a job for one thread)
+            const int nt = nnz > (1u << 22) ? std::max(1, std::min(16, hardware_threads() / 4)) : 1;
+            std::vector<int32_t> bad(nt, 0);
+            parallel_for(nt, [&](int t) {
+                const uint64_t lo = nnz * (uint64_t)t / (uint64_t)nt, hi = nnz * (uint64_t)(t + 1) / (uint64_t)nt;
+                for (uint64_t j = lo; j < hi; j++) {
+                    const int32_t v = dat.sid_signed[j];
+                    sid_abs[j] = v < 0 ? -v : v;
+                    if ((sid_abs[j] < 1 || sid_abs[j] > M) && !bad[t]) bad[t] = v ? v : INT32_MIN;
+                }
+            });
+            for (int t = 0; t < nt; t++)
+                if (bad[t]) { sh[0].rc = RSEM_ERR_INVALID; sh[0].err = "transcript id " + std::to_string(bad[t] == INT32_MIN ? 0 : bad[t]) + " out of range"; return; }
         }
         for (int k = 0; k < S; k++)
             if (sh[k].device < 0 || sh[k].device >= ndev) { sh[k].rc = RSEM_ERR_NODEVICE; sh[k].err = "no such GPU"; return; }

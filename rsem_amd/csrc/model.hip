@@ -366,6 +366,37 @@ int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_da
         rc = up_field(c, D.field, src, (size_t)(n), st);            \
         if (rc != RSEM_OK) { rsem_model_destroy(c); return rc; }    \
     } while (0)
+    // both strands of every transcript as base ids (RefSeq::get_id, RefSeq.h:84-87), word-aligned starts, one spare word at the end:
+    // host work that depends on the reference alone -- on threads of its own while the alignments and reads go up
+    std::vector<uint64_t> soff(2 * ((size_t)d->M + 1), 0);
+    uint64_t tot = 0;
+    for (int sid = 1; sid <= d->M; sid++)
+        for (int dir = 0; dir < 2; dir++) {
+            soff[2 * sid + dir] = tot;
+            tot += ((uint64_t)d->totLen[sid] + 7) / 8 * 8;
+        }
+    std::vector<uint8_t> strands;
+    std::thread strand_builder([&]() {
+        strands.assign(tot + 16, 0);
+        const int nt = d->M > 2000 ? 16 : 1;
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                for (int sid = 1 + t; sid <= d->M; sid += nt) {
+                    const uint8_t* f = d->ref_seq + d->ref_off[sid];
+                    const int tl = d->totLen[sid];
+                    uint8_t* o0 = strands.data() + soff[2 * sid];
+                    uint8_t* o1 = strands.data() + soff[2 * sid + 1];
+                    memcpy(o0, f, (size_t)tl);
+                    for (int p = 0; p < tl; p++) {
+                        const uint8_t b = f[tl - p - 1];
+                        o1[p] = b == 4 ? 4 : 3 - b;  // get_rbase_id (utils.h:52-66)
+                    }
+                }
+            });
+        for (auto& x : th) x.join();
+    });
+    struct StrandJoin { std::thread& t; ~StrandJoin() { if (t.joinable()) t.join(); } } strand_join{strand_builder};  // (every early return)
     UP(sid_signed, d->sid_signed, d->nnz);
     UP(pos, d->pos, d->nnz);
     if (pe) UP(insertL, d->insertL, d->nnz);
@@ -417,34 +448,8 @@ int rsem_model_create(rsem_model_ctx** out, rsem_em_ctx* em, const rsem_model_da
         if (q) { c->owned.push_back(d_wq); D.rqual_w[m] = d_wq; }
     }
     UP(lq, d->low_quality, d->N1);
-    {   // both strands of every transcript (RefSeq::get_id, RefSeq.h:84-87), word-aligned starts, one spare word at the end
-        std::vector<uint64_t> soff(2 * ((size_t)d->M + 1), 0);
-        uint64_t tot = 0;
-        for (int sid = 1; sid <= d->M; sid++)
-            for (int dir = 0; dir < 2; dir++) {
-                soff[2 * sid + dir] = tot;
-                tot += ((uint64_t)d->totLen[sid] + 7) / 8 * 8;
-            }
-        std::vector<uint8_t> strands(tot + 16, 0);
-        {
-            const int nt = d->M > 2000 ? 16 : 1;
-            std::vector<std::thread> th;
-            for (int t = 0; t < nt; t++)
-                th.emplace_back([&, t]() {
-                    for (int sid = 1 + t; sid <= d->M; sid += nt) {
-                        const uint8_t* f = d->ref_seq + d->ref_off[sid];
-                        const int tl = d->totLen[sid];
-                        uint8_t* o0 = strands.data() + soff[2 * sid];
-                        uint8_t* o1 = strands.data() + soff[2 * sid + 1];
-                        memcpy(o0, f, (size_t)tl);
-                        for (int p = 0; p < tl; p++) {
-                            const uint8_t b = f[tl - p - 1];
-                            o1[p] = b == 4 ? 4 : 3 - b;  // get_rbase_id (utils.h:52-66)
-                        }
-                    }
-                });
-            for (auto& x : th) x.join();
-        }
+    {   // both strands of every transcript (built beside the uploads above: strand_builder)
+        strand_builder.join();
         UP(soff, soff.data(), soff.size());
         const uint64_t* wptr = nullptr;
         rc = up_field(c, wptr, reinterpret_cast<const uint64_t*>(strands.data()), (tot + 16) / 8, st);
