@@ -329,6 +329,29 @@ class AlignmentReader {
         if (it == name2id_.end() || it->first != n) die("SAM record refers to unknown reference %s", n.c_str());
         return it->second;
     }
+    int ref_id_of(const char* n, size_t len) const {  // (the same look-up on a view of the line)
+        if (len == 1 && *n == '*') return -1;
+        size_t lo = 0, hi = name2id_.size();
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            const std::string& k = name2id_[mid].first;
+            const size_t m = std::min(k.size(), len);
+            int c = memcmp(k.data(), n, m);
+            if (c == 0) c = k.size() < len ? -1 : (k.size() > len ? 1 : 0);
+            if (c < 0) lo = mid + 1; else hi = mid;
+        }
+        if (lo == name2id_.size() || name2id_[lo].first.size() != len || memcmp(name2id_[lo].first.data(), n, len) != 0)
+            die("SAM record refers to unknown reference %s", std::string(n, len).c_str());
+        return name2id_[lo].second;
+    }
+    struct Nt16Table {  // base letter -> BAM's 4-bit code ("=ACMGRSVTWYHKDBN", either case; anything else N)
+        uint8_t code[256];
+        Nt16Table() {
+            static const char* nt16 = "=ACMGRSVTWYHKDBN";
+            for (int c = 0; c < 256; c++) code[c] = 15;
+            for (int k = 0; k < 16; k++) { code[(unsigned char)nt16[k]] = (uint8_t)k; code[(unsigned char)tolower((unsigned char)nt16[k])] = (uint8_t)k; }
+        }
+    };
     static int reg2bin(int64_t beg, int64_t end) {  // hts_reg2bin(beg, end, 14, 5)
         int l, s = 14, t = ((1 << 15) - 1) / 7;
         for (--end, l = 5; l > 0; --l, s += 3, t -= 1 << (l * 3))
@@ -341,7 +364,11 @@ class AlignmentReader {
    public:
     // one SAM text line -> BAM record bytes (SAM spec 4.2; integer tags take the smallest fitting type as htslib does); any thread
     void encode_sam_line(const char* b, const char* e, AlnRecord& r) const {
-        std::vector<std::pair<const char*, const char*>> f;
+        // (no heap traffic for the eleven fixed fields -- at 10 % of configs[2] a SAM input is 112 M lines, and strings, vectors and a
+        // strchr per base were most of the pass's CPU time there: the fields stay views into the line, numbers are read in place, the
+        // bases go through a table)
+        static thread_local std::vector<std::pair<const char*, const char*>> f;
+        f.clear();
         for (const char* q = b;;) {
             const char* t = (const char*)memchr(q, '\t', e - q);
             f.push_back({q, t ? t : e});
@@ -349,44 +376,58 @@ class AlignmentReader {
             q = t + 1;
         }
         if (f.size() < 11) die("SAM line with fewer than 11 fields");
-        auto str = [&](int i) { return std::string(f[i].first, f[i].second - f[i].first); };
-        const std::string qname = str(0), rname = str(2), cigar = str(5), rnext = str(6), seq = str(9), qual = str(10);
-        const int flag = atoi(str(1).c_str()), mapq = atoi(str(4).c_str());
-        const int32_t pos = (int32_t)atol(str(3).c_str()) - 1, pnext = (int32_t)atol(str(7).c_str()) - 1, tlen = (int32_t)atol(str(8).c_str());
-        const int32_t tid = ref_id(rname);
-        const int32_t mtid = rnext == "=" ? tid : ref_id(rnext);
-        std::vector<uint32_t> cig;
+        auto len_of = [&](int i) -> size_t { return (size_t)(f[i].second - f[i].first); };
+        auto num = [&](int i) -> long long {  // (as atol: optional sign, digits, stops at the first other character)
+            const char* q = f[i].first;
+            const char* qe = f[i].second;
+            bool neg = false;
+            if (q < qe && (*q == '-' || *q == '+')) { neg = *q == '-'; ++q; }
+            long long v = 0;
+            while (q < qe && *q >= '0' && *q <= '9') v = v * 10 + (*q++ - '0');
+            return neg ? -v : v;
+        };
+        auto is_str = [&](int i, const char* lit) -> bool { const size_t n = strlen(lit); return len_of(i) == n && !memcmp(f[i].first, lit, n); };
+        const int flag = (int)num(1), mapq = (int)num(4);
+        const int32_t pos = (int32_t)num(3) - 1, pnext = (int32_t)num(7) - 1, tlen = (int32_t)num(8);
+        const int32_t tid = ref_id_of(f[2].first, len_of(2));
+        const int32_t mtid = is_str(6, "=") ? tid : ref_id_of(f[6].first, len_of(6));
+        static thread_local std::vector<uint32_t> cig;
+        cig.clear();
         int64_t rlen = 0;
-        if (cigar != "*") {
+        if (!is_str(5, "*")) {
             static const char* ops = "MIDNSHP=X";
-            for (size_t i = 0; i < cigar.size();) {
+            for (const char *c = f[5].first, *ce = f[5].second; c < ce;) {
                 uint32_t n = 0;
-                while (i < cigar.size() && isdigit((unsigned char)cigar[i])) n = n * 10 + (cigar[i++] - '0');
-                const char* o = strchr(ops, cigar[i++]);
-                if (!o) die("SAM record with unknown CIGAR operation");
+                while (c < ce && *c >= '0' && *c <= '9') n = n * 10 + (uint32_t)(*c++ - '0');
+                const char* o = c < ce ? strchr(ops, *c++) : nullptr;
+                if (!o || !*o) die("SAM record with unknown CIGAR operation");
                 const int op = (int)(o - ops);
-                cig.push_back(n << 4 | op);
+                cig.push_back(n << 4 | (uint32_t)op);
                 if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += n;
             }
         }
         const int64_t endp = (cig.empty() || (flag & 4)) ? (int64_t)pos + 1 : (int64_t)pos + rlen;
-        const int l_seq = seq == "*" ? 0 : (int)seq.size();
+        const char* seq = f[9].first;
+        const char* qual = f[10].first;
+        const int l_seq = is_str(9, "*") ? 0 : (int)len_of(9);
+        const size_t l_name = len_of(0);
         std::vector<uint8_t>& d = r.d;
-        d.clear();
-        put<int32_t>(d, tid); put<int32_t>(d, pos);
-        d.push_back((uint8_t)(qname.size() + 1)); d.push_back((uint8_t)mapq);
-        put<uint16_t>(d, (uint16_t)reg2bin(pos, endp));
-        put<uint16_t>(d, (uint16_t)cig.size()); put<uint16_t>(d, (uint16_t)flag);
-        put<int32_t>(d, l_seq); put<int32_t>(d, mtid); put<int32_t>(d, pnext); put<int32_t>(d, tlen);
-        d.insert(d.end(), qname.begin(), qname.end()); d.push_back(0);
-        for (uint32_t c : cig) put<uint32_t>(d, c);
-        static const char* nt16 = "=ACMGRSVTWYHKDBN";
-        for (int i = 0; i < l_seq; i += 2) {
-            auto code = [&](char c) { const char* o = strchr(nt16, toupper((unsigned char)c)); return o && c ? (int)(o - nt16) : 15; };
-            d.push_back((uint8_t)(code(seq[i]) << 4 | (i + 1 < l_seq ? code(seq[i + 1]) : 0)));
-        }
-        if (qual == "*") d.insert(d.end(), l_seq, 0xff);
-        else for (int i = 0; i < l_seq; i++) d.push_back((uint8_t)(qual[i] - 33));
+        d.resize(32 + l_name + 1 + 4 * cig.size() + (size_t)(l_seq + 1) / 2 + (size_t)l_seq);
+        uint8_t* o = d.data();
+        auto w32 = [&](int32_t v) { memcpy(o, &v, 4); o += 4; };
+        auto w16 = [&](uint16_t v) { memcpy(o, &v, 2); o += 2; };
+        w32(tid); w32(pos);
+        *o++ = (uint8_t)(l_name + 1); *o++ = (uint8_t)mapq;
+        w16((uint16_t)reg2bin(pos, endp));
+        w16((uint16_t)cig.size()); w16((uint16_t)flag);
+        w32(l_seq); w32(mtid); w32(pnext); w32(tlen);
+        memcpy(o, f[0].first, l_name); o += l_name; *o++ = 0;
+        if (!cig.empty()) { memcpy(o, cig.data(), 4 * cig.size()); o += 4 * cig.size(); }
+        static const Nt16Table nt16;
+        for (int i = 0; i + 1 < l_seq; i += 2) *o++ = (uint8_t)(nt16.code[(unsigned char)seq[i]] << 4 | nt16.code[(unsigned char)seq[i + 1]]);
+        if (l_seq & 1) *o++ = (uint8_t)(nt16.code[(unsigned char)seq[l_seq - 1]] << 4);
+        if (is_str(10, "*")) { memset(o, 0xff, (size_t)l_seq); o += l_seq; }
+        else for (int i = 0; i < l_seq; i++) *o++ = (uint8_t)(qual[i] - 33);
         for (size_t k = 11; k < f.size(); k++) {
             const char* t = f[k].first;
             const size_t n = f[k].second - t;
