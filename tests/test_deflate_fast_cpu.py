@@ -53,7 +53,7 @@ def _ok(exe, *args):
     return r.stdout
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.parametrize("seed", [1, 2])
 def test_generated_blocks_inflate_to_their_input(checker, seed):
     _ok(checker, "fuzz", seed, 4000)
 
@@ -66,7 +66,7 @@ def test_record_streams_and_text_in_blocks_of_every_size(checker, tmp_path):
     for k, f in enumerate(files):
         with open(raw, "wb") as g:
             g.write(_bam_stream(f))
-        for blk in (65280, 65279, 40000, 4097, 256, 255, 5, 4, 3, 2, 1)[: (11 if k == 0 else 4)]:
+        for blk in (65280, 65279, 40000, 4097, 256, 255, 5, 4, 3, 2, 1)[: (11 if k == 0 else 2)]:
             out = _ok(checker, "file", raw, blk)
             if blk == 65280:  # (not a ratio test -- a sanity check that matches are found at all: half of zlib's level 6 at worst)
                 mine, ref = int(out.split(" bytes in, ")[1].split()[0]), int(out.split("zlib level 6: ")[1].split()[0])
@@ -120,7 +120,7 @@ def test_decoder_on_the_fixtures_streams(inflate_checker, tmp_path):
     raw = os.path.join(str(tmp_path), "stream.bin")
     with open(raw, "wb") as g:
         g.write(_bam_stream(os.path.join(ROOT, "tests", "golden", "pe_q", "golden.transcript.bam")))
-    for blk in (65280, 30000, 4097):
+    for blk in (65280, 4097):
         _ok(inflate_checker, "file", raw, blk)
     small = os.path.join(str(tmp_path), "prefix.bin")
     with open(small, "wb") as g:
