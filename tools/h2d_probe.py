@@ -1,3 +1,5 @@
+"""Host -> device bandwidth of the GPU box by NUMA node of the pinned source, and from pageable memory (torch; 1 GiB copies).
+   python tools/h2d_probe.py     (round 6: 57.4 GB/s pinned from either socket, 7.9 GB/s pageable; the programs' staged uploads reach 36-48)"""
 import os, time, torch
 def cores(node):
     s=open('/sys/devices/system/node/node%d/cpulist'%node).read().strip()
