@@ -92,3 +92,24 @@ def test_bam_input_inflated_by_the_repositorys_decoder_or_by_zlib(checker, tmp_p
         monkeypatch.delenv("RSEM_HIP_INFLATE_ZLIB")
         assert int(b["_fast_blocks"]) == 0 and int(b["_zlib_blocks"]) > 0
         assert (a["fnv"], a["stream_bytes"], a["records"]) == (b["fnv"], b["stream_bytes"], b["records"])
+
+
+def test_bam_input_with_a_wrong_block_checksum_is_refused(checker, tmp_path):
+    """A BGZF block whose CRC-32 does not match its data: the repository's decoder is not believed, zlib inflates the block, and the checksum
+    is compared again -- the pass ends with an error like htslib's reader (until round 6 the input's checksums were not looked at)."""
+    import struct
+    g = os.path.join(ROOT, "tests", "golden", "pe_q")
+    d = bytearray(open(os.path.join(g, "golden.transcript.bam"), "rb").read())
+    blocks, i = [], 0
+    while i < len(d):
+        bs = struct.unpack("<H", d[i + 16:i + 18])[0] + 1
+        blocks.append((i, bs))
+        i += bs
+    assert len(blocks) >= 3
+    off, bs = blocks[-2]  # the last block that holds records (the file ends with the empty EOF block)
+    d[off + bs - 8] ^= 0x55  # its CRC-32
+    bad = os.path.join(str(tmp_path), "bad.bam")
+    open(bad, "wb").write(d)
+    r = subprocess.run([checker, os.path.join(g, "ref.ti"), bad, os.path.join(g, "golden.transcript.bam"), os.path.join(str(tmp_path), "o.bam"), "1", "4"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode != 0 and "checksum" in r.stdout, r.stdout[-500:]
