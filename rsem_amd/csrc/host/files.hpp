@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -92,6 +93,11 @@ struct Arr {
     }
     void view(const T* q, size_t m, std::shared_ptr<MappedFile> k) { own.reset(); keep = std::move(k); p = q; n = m; }
     void release() { own.reset(); keep.reset(); p = nullptr; n = 0; }
+    // the owned storage as a byte range (empty for a view or a small array): what give_back_pages() below takes
+    std::pair<char*, size_t> owned_bytes() const {
+        const size_t bytes = n * sizeof(T);
+        return (own && bytes >= ((size_t)32 << 20)) ? std::make_pair((char*)own.get(), bytes) : std::make_pair((char*)nullptr, (size_t)0);
+    }
 };
 
 inline int hardware_threads() {
@@ -124,6 +130,28 @@ inline void parallel_for(int n, const std::function<void(int)>& fn) {
     std::vector<std::thread> th;
     for (int i = 0; i < n; i++) th.emplace_back(fn, i);
     for (auto& t : th) t.join();
+}
+
+// Give the pages of big arrays back to the system on several threads BEFORE their owners free them.  The boxes' kernels clear every
+// page they take back (51 ms per GB whatever the page size: tools/thp_probe.cpp), so the 35 GB of parsed inputs a run of rsem-run-em holds
+// at configs[2] are 1.7 s of kernel work for whoever frees them -- one thread doing it through munmap held the address space's lock for
+// most of that time and the thread that launches the device loop waited for it (0.8 s of a 5.1-second loop, profiles/r06ai_*).
+// MADV_DONTNEED takes that lock shared, in slices on `threads` threads; the free() that follows finds nothing left to clear.
+inline void give_back_pages(const std::vector<std::pair<char*, size_t>>& ranges, int threads) {
+    const size_t slice = (size_t)256 << 20, huge = (size_t)2 << 20;
+    std::vector<std::pair<char*, size_t>> work;
+    for (const auto& r : ranges) {
+        if (!r.first || !r.second) continue;
+        char* b = (char*)(((uintptr_t)r.first + huge - 1) / huge * huge);
+        char* e = (char*)(((uintptr_t)r.first + r.second) / huge * huge);
+        for (; b < e; b += slice) work.push_back({b, (size_t)std::min<ptrdiff_t>((ptrdiff_t)slice, e - b)});
+    }
+    if (work.empty()) return;
+    std::atomic<size_t> next{0};
+    const int nt = std::max(1, std::min<int>(threads, (int)work.size()));
+    parallel_for(nt, [&](int) {
+        for (size_t k; (k = next.fetch_add(1)) < work.size();) (void)madvise(work[k].first, work[k].second, MADV_DONTNEED);
+    });
 }
 
 // One line of cells first..last (inclusive) separated by `sep` and closed by a newline; cell(buf, i) writes cell i into a buffer of

@@ -681,6 +681,13 @@ int main(int argc, char* argv[]) {
     // 0.3-0.6 s and saves 1.3 s at exit: profiles/r04i_call.log.)  Kept: row_ptr and the transcript ids (.ofg / BAM output).
     std::thread releaser([&]() {
         if (getenv("RSEM_HIP_NO_RELEASE")) return;  // (measurement: everything stays until exit)
+        {   // the pages first, on a few threads and without the address space's exclusive lock (files.hpp, give_back_pages)
+            std::vector<std::pair<char*, size_t>> big;
+            for (int tag = 0; tag < 3; tag++)
+                for (int m = 0; m < 2; m++) { big.push_back(rs.mate[tag][m].off.owned_bytes()); big.push_back(rs.mate[tag][m].seq.owned_bytes()); big.push_back(rs.mate[tag][m].qual.owned_bytes()); }
+            big.push_back(dat.pos.owned_bytes()); big.push_back(dat.insertL.owned_bytes()); big.push_back(dat.sid_signed.owned_bytes());
+            give_back_pages(big, getenv("RSEM_HIP_RELEASE_THREADS") ? atoi(getenv("RSEM_HIP_RELEASE_THREADS")) : 8);
+        }
         for (int tag = 0; tag < 3; tag++)
             for (int m = 0; m < 2; m++) rs.mate[tag][m] = ReadFile();
         dat.pos.release(); dat.insertL.release(); dat.sid_signed.release();
