@@ -57,6 +57,9 @@ struct MappedFile {
         return true;
     }
     ~MappedFile() {
+        // (the pages' entries are dropped under the address space's SHARED lock first: a munmap of a 10 GB text file holds the exclusive one
+        // for its whole walk, and the other parsers' page faults wait for it)
+        if (data && size >= ((size_t)64 << 20)) (void)madvise((void*)data, size, MADV_DONTNEED);
         if (data && size) munmap((void*)data, size);
         if (fd >= 0) ::close(fd);
     }
