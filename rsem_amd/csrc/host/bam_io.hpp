@@ -549,6 +549,7 @@ inline void write_transcript_bam(const std::string& inpF, const std::string& out
         e2i[k] = it->second;
     }
     nthreads = std::max(1, std::min(nthreads, (int)std::max(1u, std::thread::hardware_concurrency())));
+    if (const int granted = cgroup_cpu_cores()) nthreads = std::max(1, std::min(nthreads, granted));  // (no more threads than the cgroup grants cores)
     StagePool pool(nthreads);
     std::vector<BgzfDeflater> defl(nthreads);
     FILE* fo = fopen(outF.c_str(), "wb");
