@@ -127,7 +127,8 @@ inline int cgroup_cpu_cores() {
     return cores;
 }
 
-inline int hardware_threads() {
+inline int hardware_threads() {  // (NOT cut to the cgroup's cores: the parsers share these among five files read at once, and with the boxes' 16 cores the
+    // longest of them got three threads: 10.5-11.8 s at configs[2] where the hardware's count gives 9.5-9.8, profiles/r06aq_call.log)
     unsigned n = std::thread::hardware_concurrency();
     return (int)std::min<unsigned>(std::max<unsigned>(n, 1), 64);
 }
